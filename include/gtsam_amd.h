@@ -1,0 +1,194 @@
+/* gtsam_amd.h -- C ABI of the MI355X-native Levenberg-Marquardt inner loop.
+ *
+ * This is the drop-in boundary for ONE path of borglab/gtsam: the
+ * linearize -> damp -> eliminate -> solve -> retract -> error loop of
+ * gtsam::LevenbergMarquardtOptimizer.  GTSAM has no FFI/plugin ABI of its own; its extension
+ * point is C++ subclassing (NonlinearOptimizer::iterate() nonlinear/NonlinearOptimizer.h:136,
+ * LevenbergMarquardtOptimizer::linearize() LevenbergMarquardtOptimizer.h:112-113,
+ * NonlinearOptimizer::solve() NonlinearOptimizer.h:129-130).  The functions below are what a
+ * subclass overriding iterate() binds to (see INTEGRATION.md for the GTSAM-side shim and
+ * gtsam_amd/host/ for the shipped one).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions: extern "C"; plain pointers + explicit sizes; all host arrays are caller-owned and
+ * copied during the call; int status returns (GTG_OK=0, GTG_INDETERMINATE=1 means "the damped
+ * system was not positive definite" = where the reference throws
+ * IndeterminantLinearSystemException, linear/HessianFactor.cpp:476-483, and LM raises lambda,
+ * nonlinear/LevenbergMarquardtOptimizer.cpp:154-160; negative = usage / HIP error, message via
+ * gtg_last_error()).  No exceptions cross the boundary, no GTSAM or torch types appear.
+ * All floating point is IEEE double (gtsam::Matrix = Eigen::MatrixXd, base/Matrix.h:39).
+ */
+#ifndef GTSAM_AMD_H
+#define GTSAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gtg_context* gtg_handle;
+
+enum { GTG_OK = 0, GTG_INDETERMINATE = 1, GTG_ERR_USAGE = -1, GTG_ERR_HIP = -2,
+       GTG_ERR_UNSUPPORTED = -3 };
+
+/* Variable (gtsam::Value) types and their packed storage.
+ *   POSE3      gtsam::Pose3 (geometry/Pose3.h): 12 doubles = R row-major (9) then t (3); tangent 6 = [omega; v]
+ *   SFM_CAMERA gtsam::PinholeCamera<Cal3Bundler> (geometry/PinholeCamera.h, Cal3Bundler.h):
+ *              17 doubles = pose (12) then f,k1,k2,u0,v0; tangent 9 = [pose(6); f,k1,k2]
+ *   POINT3     gtsam::Point3: 3 doubles; tangent 3                                              */
+enum { GTG_VAR_POSE3 = 0, GTG_VAR_SFM_CAMERA = 1, GTG_VAR_POINT3 = 2 };
+
+/* Factor types on the path. */
+enum { GTG_FAC_GENERAL_SFM = 0,   /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  slam/GeneralSFMFactor.h:127-177 */
+       GTG_FAC_PROJECTION = 1,    /* GenericProjectionFactor<Pose3,Point3,Cal3_S2>        slam/ProjectionFactor.h:138-166 */
+       GTG_FAC_BETWEEN_POSE3 = 2, /* BetweenFactor<Pose3>                                  slam/BetweenFactor.h:111-124 */
+       GTG_FAC_PRIOR = 3 };       /* PriorFactor<T>                                        nonlinear/PriorFactor.h:98-102 */
+
+/* Noise models (linear/NoiseModel.cpp).  whiten(v) is
+ *   UNIT v ; ISOTROPIC v*invsigma (:641-663) ; DIAGONAL v.*invsigmas (:311-325) ; GAUSSIAN R*v (:163-181)
+ * noise_data holds the constructor arguments: UNIT nothing; ISOTROPIC {sigma}; DIAGONAL sigmas[dim];
+ * GAUSSIAN R[dim*dim] row-major (upper-triangular sqrt information).  The library derives
+ * invsigma = 1.0/sigma exactly like the reference constructors do (NoiseModel.cpp:275-281). */
+enum { GTG_NOISE_UNIT = 0, GTG_NOISE_ISOTROPIC = 1, GTG_NOISE_DIAGONAL = 2, GTG_NOISE_GAUSSIAN = 3 };
+
+/* The factor graph in structure-of-arrays form: what the extractor produces by walking a
+ * gtsam::NonlinearFactorGraph once (FactorGraph.h:92 factors_, Factor.h keys_). Variable ids are
+ * dense 0..n_vars-1 (the shim maps gtsam::Key -> id in Values order, Values.h:74-79). */
+typedef struct gtg_problem {
+  int32_t n_vars;
+  const int32_t* var_type;       /* [n_vars] GTG_VAR_* */
+
+  int32_t n_noise;               /* shared noise-model table */
+  const int32_t* noise_kind;     /* [n_noise] GTG_NOISE_* */
+  const int32_t* noise_dim;      /* [n_noise] */
+  const int64_t* noise_off;      /* [n_noise] offset into noise_data */
+  const double* noise_data;
+
+  int64_t n_sfm;                 /* GTG_FAC_GENERAL_SFM */
+  const int32_t* sfm_cam;        /* [n_sfm] variable id of the SFM_CAMERA */
+  const int32_t* sfm_point;      /* [n_sfm] variable id of the POINT3 */
+  const double* sfm_z;           /* [n_sfm*2] measured pixel */
+  const int32_t* sfm_noise;      /* [n_sfm] index into noise table (dim 2) */
+
+  int64_t n_proj;                /* GTG_FAC_PROJECTION */
+  const int32_t* proj_pose;      /* [n_proj] variable id of the POSE3 */
+  const int32_t* proj_point;     /* [n_proj] variable id of the POINT3 */
+  const double* proj_z;          /* [n_proj*2] */
+  const int32_t* proj_noise;     /* [n_proj] */
+  const int32_t* proj_calib;     /* [n_proj] index into calib table */
+  const int32_t* proj_sensor;    /* [n_proj] index into sensor table or -1 (body_P_sensor_ absent) */
+  int32_t n_calib;
+  const double* calib;           /* [n_calib*5] Cal3_S2 fx,fy,s,u0,v0 (geometry/Cal3_S2.cpp:44-50) */
+  int32_t n_sensor;
+  const double* sensor;          /* [n_sensor*12] body_P_sensor poses */
+
+  int64_t n_between;             /* GTG_FAC_BETWEEN_POSE3 */
+  const int32_t* between_v1;     /* [n_between] */
+  const int32_t* between_v2;     /* [n_between] */
+  const double* between_z;       /* [n_between*12] measured relative pose */
+  const int32_t* between_noise;  /* [n_between] (dim 6) */
+
+  int64_t n_prior;               /* GTG_FAC_PRIOR */
+  const int32_t* prior_var;      /* [n_prior] */
+  const int64_t* prior_off;      /* [n_prior] offset into prior_data (storage size of the var type) */
+  const double* prior_data;
+  const int32_t* prior_noise;    /* [n_prior] (dim = tangent dim of the variable) */
+} gtg_problem;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+int gtg_create(gtg_handle* out, int device_id);
+int gtg_destroy(gtg_handle h);
+const char* gtg_last_error(void);
+const char* gtg_version(void);
+
+/* One-time symbolic analysis + upload.  Replaces what the reference redoes on EVERY lambda try:
+ * VariableIndex (inference/VariableIndex-inl.h:27-49), EliminationTree
+ * (EliminationTree-inst.h:77-155), JunctionTree (JunctionTree-inst.h:63-151), Scatter
+ * (linear/Scatter.cpp:39-73).  Landmarks (POINT3 touched only by projection factors / priors) are
+ * eliminated first -- the Schur ordering of timing/timeSFMBAL.h:74-83 -- the remaining variables
+ * form the reduced system.  shard/n_shards: this handle owns landmark-factors with
+ * (landmark rank) % n_shards == shard and other factors with (factor index) % n_shards == shard
+ * (multi-GPU); pass 0,1 for a single GPU. */
+int gtg_upload_problem(gtg_handle h, const gtg_problem* p, int shard, int n_shards);
+
+/* Optional: position of each non-landmark variable in the reduced system (a fill-reducing
+ * ordering, inference/Ordering.cpp:42-124).  order[i] = variable id placed i-th; n = number of
+ * non-landmark variables.  Default: increasing variable id. */
+int gtg_set_reduced_ordering(gtg_handle h, const int32_t* order, int32_t n);
+
+/* Values in packed storage, variable id order (see GTG_VAR_*).  Values.h:74-79. */
+int64_t gtg_values_size(gtg_handle h);   /* doubles in the packed Values */
+int64_t gtg_tangent_size(gtg_handle h);  /* dimension of delta (VectorValues) */
+int gtg_set_values(gtg_handle h, const double* packed, int64_t n);
+int gtg_get_values(gtg_handle h, double* packed, int64_t n);        /* current (accepted) values */
+int gtg_get_trial_values(gtg_handle h, double* packed, int64_t n);  /* values.retract(delta) of the last try */
+
+/* NonlinearFactorGraph::error(values) = sum_i 0.5*||whiten(r_i)||^2
+ * (nonlinear/NonlinearFactorGraph.cpp:170-179, NonlinearFactor.cpp:136-147) at the current values. */
+int gtg_error(gtg_handle h, double* error);
+
+/* NonlinearFactorGraph::linearize(values) (NonlinearFactorGraph.cpp:239-278) fused with the
+ * lambda-invariant part of elimination: J^T J / J^T b block accumulation
+ * (JacobianFactor::updateHessian linear/JacobianFactor.cpp:563-598) and
+ * GaussianFactorGraph::hessianDiagonal (GaussianFactorGraph.cpp:279-287). */
+int gtg_linearize(gtg_handle h);
+
+/* One body of LevenbergMarquardtOptimizer::tryLambda (LevenbergMarquardtOptimizer.cpp:121-270):
+ * buildDampedSystem (internal/LevenbergMarquardtState.h:125-156) -> solve
+ * (GaussianFactorGraph::optimize, linear/GaussianFactorGraph.cpp:316-319: landmark elimination +
+ * Cholesky of the reduced system + back-substitution) -> linear.error(0), linear.error(delta)
+ * (GaussianFactorGraph.cpp:71-78) -> values.retract(delta) (nonlinear/Values.cpp:52-63) ->
+ * graph.error(newValues).  Returns GTG_OK or GTG_INDETERMINATE; on GTG_OK fills
+ *   out[0] = linear.error(0)   out[1] = linear.error(delta)   out[2] = graph.error(trial values)
+ *   out[3] = ||delta||_2
+ * The trial values stay on the device until gtg_accept(). If linear cost change < 0 the retract /
+ * error step is skipped exactly like LM.cpp:178 and out[2] = +inf. */
+int gtg_try_lambda(gtg_handle h, double lambda, int diagonal_damping, double min_diagonal,
+                   double max_diagonal, double out[4]);
+
+/* state_ = decreaseLambda(... newValues ...) (LevenbergMarquardtState.h:81-94): trial -> current. */
+int gtg_accept(gtg_handle h);
+
+/* ---- parity / debug getters (host copies) --------------------------------------------------- */
+int gtg_get_delta(gtg_handle h, double* delta, int64_t n);            /* VectorValues of last solve, variable id order */
+int gtg_get_gradient(gtg_handle h, double* g, int64_t n);             /* J^T b, variable id order */
+int gtg_get_hessian_diagonal(gtg_handle h, double* d, int64_t n);     /* GaussianFactorGraph::hessianDiagonal */
+/* whitened Jacobian blocks + rhs of factor type `factor_type` after gtg_linearize():
+ * row-major per factor: SFM [A1 2x9 | A2 2x3 | b 2], PROJECTION [2x6 | 2x3 | 2],
+ * BETWEEN [6x6 | 6x6 | 6], PRIOR [d x d | d] padded to d=9 (81+9). n = doubles available in out. */
+int gtg_get_jacobians(gtg_handle h, int factor_type, double* out, int64_t n);
+int64_t gtg_reduced_dim(gtg_handle h);
+/* dense damped reduced system of the last try: S (n x n row-major, lower triangle valid; after the
+ * solve it holds the Cholesky factor L) */
+int gtg_get_reduced_matrix(gtg_handle h, double* S, int64_t n_elems);
+
+/* ---- multi-GPU: the one exchange step ------------------------------ */
+/* Called by the library with a DEVICE pointer whenever per-shard partial sums must be combined
+ * (sum) across shards: reduced Hessian+gradient+scalars.  The callback runs the collective
+ * (RCCL all-reduce over xGMI when driven from torch.distributed) and must complete (or be stream
+ * ordered on `stream`) before returning. */
+typedef int (*gtg_allreduce_fn)(void* device_ptr, int64_t n_doubles, void* stream, void* user);
+int gtg_set_allreduce(gtg_handle h, gtg_allreduce_fn fn, void* user);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* HIP-event timings (ms, accumulated since the last reset) per phase; names via gtg_phase_name. */
+enum { GTG_PH_LINEARIZE = 0, GTG_PH_ASSEMBLE, GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY,
+       GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR, GTG_PH_COUNT };
+int gtg_enable_timing(gtg_handle h, int on);
+int gtg_get_phase_ms(gtg_handle h, double* ms, int64_t* calls, int n);
+int gtg_reset_timing(gtg_handle h);
+const char* gtg_phase_name(int phase);
+/* flops of the dense Cholesky factorisation of the last try (n^3/3 + lower order) and the
+ * algorithmic HBM bytes of one linearize pass (DESIGN.md section "rooflines") */
+double gtg_cholesky_flops(gtg_handle h);
+double gtg_linearize_bytes(gtg_handle h);
+
+/* standalone kernels exposed for unit parity tests (tests/ only): dense FP64 Cholesky of an
+ * n x n row-major SPD matrix (lower triangle) held in host memory; returns GTG_INDETERMINATE on a
+ * non-positive pivot (Eigen LLT info, base/cholesky.cpp:124-127). */
+int gtg_dense_cholesky_host(gtg_handle h, double* A, int32_t n, double* rhs_inout /* may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTSAM_AMD_H */

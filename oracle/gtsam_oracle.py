@@ -1,0 +1,608 @@
+"""oracle/gtsam_oracle.py -- TEST INFRASTRUCTURE ONLY (CPU restatement of the reference algorithm).
+
+A plain numpy restatement of borglab/gtsam's Levenberg-Marquardt hot path
+(linearize -> damp -> eliminate -> solve -> retract -> error), vectorised over factors, every
+function citing the reference file:line it follows (paths relative to /root/reference/gtsam).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product
+path (gtsam_amd/) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+  * literals of the reference's own tests (testGeneralSFMFactorB.cpp:44-63 -> 0.0199833 +- 1e-5,
+    testProjectionFactor.cpp:96-189, testCholesky.cpp:26-67, testBetweenFactor.cpp, testSO3/testPose3
+    identities), and
+  * golden fixtures in tests/golden/*.npz produced by the real reference built from
+    /root/reference (oracle/Makefile -> oracle/_ref, generator tests/golden/make_golden.py), and
+  * the live reference (oracle/ref.py) whenever oracle/_ref is present.
+
+All arithmetic is IEEE double, like the reference (base/Matrix.h:39).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from gtsam_amd.problem import (FAC_BETWEEN_POSE3, FAC_GENERAL_SFM, FAC_PRIOR, FAC_PROJECTION,
+                               NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT,
+                               STORAGE, TANGENT, VAR_POINT3, VAR_POSE3, VAR_SFM_CAMERA, Problem)
+
+EPS = np.finfo(np.float64).eps
+
+
+# ------------------------------------------------------------------------------------------------
+# SO(3) / SE(3)   (geometry/SO3.cpp, geometry/Pose3.cpp, base/Lie.h)
+# ------------------------------------------------------------------------------------------------
+def skew(w):
+    """skewSymmetric(wx,wy,wz) (base/Matrix.h). w: [n,3] -> [n,3,3]."""
+    w = np.asarray(w, np.float64)
+    z = np.zeros(w.shape[0])
+    return np.stack([np.stack([z, -w[:, 2], w[:, 1]], -1),
+                     np.stack([w[:, 2], z, -w[:, 0]], -1),
+                     np.stack([-w[:, 1], w[:, 0], z], -1)], -2)
+
+
+def so3_expmap(omega):
+    """SO3::Expmap via so3::ExpmapFunctor (geometry/SO3.cpp:50-88,200-208):
+    near zero (theta^2 <= eps) R = I + W, else R = I + sin(theta) K + 2 sin^2(theta/2) K^2."""
+    omega = np.asarray(omega, np.float64).reshape(-1, 3)
+    theta2 = np.einsum("ni,ni->n", omega, omega)
+    theta = np.sqrt(theta2)
+    W = skew(omega)
+    near = theta2 <= EPS
+    th = np.where(near, 1.0, theta)
+    K = W / th[:, None, None]
+    KK = K @ K
+    s2 = np.sin(th / 2.0)
+    R = np.eye(3)[None] + np.sin(th)[:, None, None] * K + (2.0 * s2 * s2)[:, None, None] * KK
+    R[near] = np.eye(3)[None] + W[near]
+    return R
+
+
+def so3_logmap(R):
+    """SO3::Logmap (geometry/SO3.cpp:247-323): three regimes -- trace near -1 (largest-diagonal
+    branch), the normal acos branch (tr-3 < -1e-6) and the Taylor branch near the identity."""
+    R = np.asarray(R, np.float64).reshape(-1, 3, 3)
+    n = R.shape[0]
+    out = np.zeros((n, 3))
+    for i in range(n):
+        R11, R12, R13 = R[i, 0]; R21, R22, R23 = R[i, 1]; R31, R32, R33 = R[i, 2]
+        tr = R11 + R22 + R33
+        if tr + 1.0 < 1e-3:
+            if R33 > R22 and R33 > R11:
+                W = R21 - R12; Q1 = 2.0 + 2.0 * R33; Q2 = R31 + R13; Q3 = R23 + R32; perm = (1, 2, 0)
+                vec = (Q2, Q3, Q1)
+            elif R22 > R11:
+                W = R13 - R31; Q1 = 2.0 + 2.0 * R22; Q2 = R23 + R32; Q3 = R12 + R21
+                vec = (Q3, Q1, Q2)
+            else:
+                W = R32 - R23; Q1 = 2.0 + 2.0 * R11; Q2 = R12 + R21; Q3 = R31 + R13
+                vec = (Q1, Q2, Q3)
+            r = math.sqrt(Q1)
+            one_over_r = 1 / r
+            norm = math.sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W)
+            sgn_w = -1.0 if W < 0 else 1.0
+            mag = math.pi - (2 * sgn_w * W) / norm
+            scale = 0.5 * one_over_r * mag
+            out[i] = sgn_w * scale * np.array(vec)
+        else:
+            tr_3 = tr - 3.0
+            if tr_3 < -1e-6:
+                theta = math.acos((tr - 1.0) / 2.0)
+                magnitude = theta / (2.0 * math.sin(theta))
+            else:
+                magnitude = 0.5 - tr_3 / 12.0 + tr_3 * tr_3 / 60.0
+            out[i] = magnitude * np.array([R32 - R23, R13 - R31, R21 - R12])
+    return out
+
+
+def pose3_expmap(xi):
+    """Pose3::Expmap (geometry/Pose3.cpp:169-185). xi = [omega; v] -> (R [n,3,3], t [n,3])."""
+    xi = np.asarray(xi, np.float64).reshape(-1, 6)
+    omega, v = xi[:, :3], xi[:, 3:]
+    R = so3_expmap(omega)
+    theta2 = np.einsum("ni,ni->n", omega, omega)
+    big = theta2 > EPS
+    t_parallel = omega * np.einsum("ni,ni->n", omega, v)[:, None]
+    oxv = np.cross(omega, v)
+    th2 = np.where(big, theta2, 1.0)
+    t = (oxv - np.einsum("nij,nj->ni", R, oxv) + t_parallel) / th2[:, None]
+    t[~big] = v[~big]
+    return R, t
+
+
+def pose3_logmap(R, t):
+    """Pose3::Logmap (geometry/Pose3.cpp:188-208)."""
+    R = np.asarray(R, np.float64).reshape(-1, 3, 3)
+    T = np.asarray(t, np.float64).reshape(-1, 3)
+    w = so3_logmap(R)
+    th = np.linalg.norm(w, axis=1)
+    out = np.concatenate([w, T], 1)
+    big = ~(th < 1e-10)
+    if big.any():
+        wb, Tb, tb = w[big], T[big], th[big]
+        W = skew(wb / tb[:, None])
+        Tan = np.tan(0.5 * tb)
+        WT = np.einsum("nij,nj->ni", W, Tb)
+        u = Tb - (0.5 * tb)[:, None] * WT + (1 - tb / (2.0 * Tan))[:, None] * np.einsum("nij,nj->ni", W, WT)
+        out[big, 3:] = u
+    return out
+
+
+def pose_unpack(p12):
+    p12 = np.asarray(p12, np.float64).reshape(-1, 12)
+    return p12[:, :9].reshape(-1, 3, 3), p12[:, 9:12]
+
+
+def pose_pack(R, t):
+    return np.concatenate([R.reshape(-1, 9), t.reshape(-1, 3)], 1)
+
+
+def pose_compose(R1, t1, R2, t2):
+    """Pose3::operator* (geometry/Pose3.h:114-116)."""
+    return R1 @ R2, t1 + np.einsum("nij,nj->ni", R1, t2)
+
+
+def pose_inverse(R, t):
+    """Pose3::inverse (geometry/Pose3.cpp:49-52)."""
+    Rt = np.swapaxes(R, 1, 2)
+    return Rt, np.einsum("nij,nj->ni", Rt, -t)
+
+
+def pose_adjoint(R, t):
+    """Pose3::AdjointMap (geometry/Pose3.cpp:57-63): [R 0; [t]x R  R]."""
+    n = R.shape[0]
+    A = skew(t) @ R
+    adj = np.zeros((n, 6, 6))
+    adj[:, :3, :3] = R; adj[:, 3:, :3] = A; adj[:, 3:, 3:] = R
+    return adj
+
+
+def pose_retract(p12, xi):
+    """LieGroup::retract = compose(Expmap(v)) (base/Lie.h:131-133, GTSAM_POSE3_EXPMAP)."""
+    R, t = pose_unpack(p12)
+    dR, dt = pose3_expmap(xi)
+    return pose_pack(*pose_compose(R, t, dR, dt))
+
+
+def pose_local(p12, q12):
+    """LieGroup::localCoordinates = Logmap(between(g)) (base/Lie.h:136-138)."""
+    R1, t1 = pose_unpack(p12); R2, t2 = pose_unpack(q12)
+    return pose3_logmap(*pose_compose(*pose_inverse(R1, t1), R2, t2))
+
+
+# ------------------------------------------------------------------------------------------------
+# cameras   (geometry/CalibratedCamera.cpp, PinholePose.h, PinholeCamera.h, Cal3Bundler.cpp, Cal3_S2.cpp)
+# ------------------------------------------------------------------------------------------------
+def _project2(R, t, pw):
+    """PinholeBase::project2 (CalibratedCamera.cpp:116-135) with Pose3::transformTo (Pose3.cpp:371-388),
+    Project (:88-94), Dpose (:27-34), Dpoint (:37-46).  Returns pn, Dpose[n,2,6], Dpoint[n,2,3], behind."""
+    Rt = np.swapaxes(R, 1, 2)
+    q = np.einsum("nij,nj->ni", Rt, pw - t)
+    behind = q[:, 2] <= 0  # CheiralityException (GTSAM_THROW_CHEIRALITY_EXCEPTION default ON)
+    qz = np.where(behind, 1.0, q[:, 2])
+    d = 1.0 / qz
+    u, v = q[:, 0] * d, q[:, 1] * d
+    uv, uu, vv = u * v, u * u, v * v
+    z = np.zeros_like(u)
+    Dpose = np.stack([np.stack([uv, -1 - uu, v, -d, z, d * u], -1),
+                      np.stack([1 + vv, -uv, -u, z, -d, d * v], -1)], -2)
+    Dpoint = np.stack([Rt[:, 0, :] - u[:, None] * Rt[:, 2, :],
+                       Rt[:, 1, :] - v[:, None] * Rt[:, 2, :]], -2) * d[:, None, None]
+    return np.stack([u, v], -1), Dpose, Dpoint, behind
+
+
+def sfm_project(cam17, pw):
+    """PinholeCamera<Cal3Bundler>::project2 (PinholeCamera.h:230-248) = PinholeBaseK::_project
+    (PinholePose.h:89-109) + Cal3Bundler::uncalibrate (Cal3Bundler.cpp:66-92).
+    Returns pi[n,2], Dcam[n,2,9] = [Dpose | Dcal], Dpoint[n,2,3], behind[n]."""
+    cam17 = np.asarray(cam17, np.float64).reshape(-1, 17)
+    R, t = pose_unpack(cam17[:, :12])
+    f, k1, k2, u0, v0 = (cam17[:, 12 + i] for i in range(5))
+    pn, Dpose, Dpoint, behind = _project2(R, t, np.asarray(pw, np.float64).reshape(-1, 3))
+    x, y = pn[:, 0], pn[:, 1]
+    r = x * x + y * y
+    g = 1. + (k1 + k2 * r) * r
+    u, v = g * x, g * y
+    rx, ry = r * x, r * y
+    Dcal = np.stack([np.stack([u, f * rx, f * r * rx], -1), np.stack([v, f * ry, f * r * ry], -1)], -2)
+    a = 2. * (k1 + 2. * k2 * r)
+    axx, axy, ayy = a * x * x, a * x * y, a * y * y
+    Dp = np.stack([np.stack([g + axx, axy], -1), np.stack([axy, g + ayy], -1)], -2) * f[:, None, None]
+    pi = np.stack([u0 + f * u, v0 + f * v], -1)
+    Dcam = np.concatenate([Dp @ Dpose, Dcal], 2)
+    return pi, Dcam, Dp @ Dpoint, behind
+
+
+def s2_project(R, t, K5, pw):
+    """PinholeCamera<Cal3_S2>::project (PinholePose.h:89-109) + Cal3_S2::uncalibrate (Cal3_S2.cpp:44-50)."""
+    pn, Dpose, Dpoint, behind = _project2(R, t, pw)
+    fx, fy, s, u0, v0 = (K5[:, i] for i in range(5))
+    x, y = pn[:, 0], pn[:, 1]
+    z = np.zeros_like(fx)
+    Dp = np.stack([np.stack([fx, s], -1), np.stack([z, fy], -1)], -2)
+    pi = np.stack([fx * x + s * y + u0, fy * y + v0], -1)
+    return pi, Dp @ Dpose, Dp @ Dpoint, behind
+
+
+# ------------------------------------------------------------------------------------------------
+# noise models   (linear/NoiseModel.cpp)
+# ------------------------------------------------------------------------------------------------
+def noise_sqrt_info(p: Problem, idx: int):
+    """The matrix W with whiten(v) = W v: Unit I; Isotropic invsigma*I (:641-663, invsigma_=1/sigma);
+    Diagonal diag(1/sigmas) (:275-281,:311-325); Gaussian R (:163-181)."""
+    kind, dim, off = int(p.noise_kind[idx]), int(p.noise_dim[idx]), int(p.noise_off[idx])
+    d = p.noise_data
+    if kind == NOISE_UNIT:
+        return np.eye(dim)
+    if kind == NOISE_ISOTROPIC:
+        return np.eye(dim) * (1.0 / d[off])
+    if kind == NOISE_DIAGONAL:
+        return np.diag(1.0 / d[off:off + dim])
+    return d[off:off + dim * dim].reshape(dim, dim).copy()
+
+
+def _whiten_many(p, noise_idx, *arrays):
+    """Apply whiten per factor to vectors [n,m] / matrices [n,m,k]."""
+    outs = [np.array(a, np.float64, copy=True) for a in arrays]
+    for ni in np.unique(noise_idx):
+        sel = noise_idx == ni
+        if int(p.noise_kind[ni]) == NOISE_UNIT:
+            continue
+        W = noise_sqrt_info(p, int(ni))
+        for a in outs:
+            if a.ndim == 2:
+                a[sel] = np.einsum("ij,nj->ni", W, a[sel])
+            else:
+                a[sel] = np.einsum("ij,njk->nik", W, a[sel])
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# factors: unwhitened error + Jacobians, then NoiseModelFactor::linearize
+# ------------------------------------------------------------------------------------------------
+def _values_views(p: Problem, values):
+    values = np.asarray(values, np.float64)
+    return values, p.val_offsets()
+
+
+def _gather(values, off, ids, size):
+    idx = off[ids][:, None] + np.arange(size)[None, :]
+    return values[idx]
+
+
+def linearize(p: Problem, values):
+    """NonlinearFactorGraph::linearize (nonlinear/NonlinearFactorGraph.cpp:239-278): per factor the
+    whitened [A1 A2 b] of NoiseModelFactor::linearize (NonlinearFactor.cpp:150-182) /
+    GeneralSFMFactor::linearize (slam/GeneralSFMFactor.h:141-177).
+    Returns dict type -> (A1, A2 or None, b), arrays stacked over factors."""
+    values, off = _values_views(p, values)
+    out = {}
+    if p.n_sfm:
+        cam = _gather(values, off, p.sfm_cam, 17); pt = _gather(values, off, p.sfm_point, 3)
+        pi, Dc, Dp, behind = sfm_project(cam, pt)
+        b = p.sfm_z.reshape(-1, 2) - pi
+        Dc[behind] = 0; Dp[behind] = 0; b[behind] = 0          # GeneralSFMFactor.h:153-158
+        Dc, Dp, b = _whiten_many(p, p.sfm_noise, Dc, Dp, b)
+        out[FAC_GENERAL_SFM] = (Dc, Dp, b)
+    if p.n_proj:
+        R, t = pose_unpack(_gather(values, off, p.proj_pose, 12)); pt = _gather(values, off, p.proj_point, 3)
+        K5 = p.calib.reshape(-1, 5)[p.proj_calib]
+        H0 = None
+        has_s = p.proj_sensor >= 0 if p.proj_sensor.size else np.zeros(p.n_proj, bool)
+        if has_s.any():                                          # ProjectionFactor.h:142-148
+            sR, st = pose_unpack(p.sensor.reshape(-1, 12)[np.where(has_s, p.proj_sensor, 0)])
+            cR, ct = pose_compose(R, t, sR, st)
+            R = np.where(has_s[:, None, None], cR, R); t = np.where(has_s[:, None], ct, t)
+            H0 = pose_adjoint(*pose_inverse(sR, st))             # compose H1 = g.inverse().AdjointMap() (Lie.h:56-61)
+        pi, Dpose, Dpt, behind = s2_project(R, t, K5, pt)
+        if H0 is not None:
+            Dpose = np.where(has_s[:, None, None], Dpose @ H0, Dpose)
+        err = pi - p.proj_z.reshape(-1, 2)
+        Dpose[behind] = 0; Dpt[behind] = 0                       # ProjectionFactor.h:157-165
+        err[behind] = (2.0 * K5[behind, 0])[:, None]
+        Dpose, Dpt, b = _whiten_many(p, p.proj_noise, Dpose, Dpt, -err)
+        out[FAC_PROJECTION] = (Dpose, Dpt, b)
+    if p.n_between:
+        R1, t1 = pose_unpack(_gather(values, off, p.between_v1, 12))
+        R2, t2 = pose_unpack(_gather(values, off, p.between_v2, 12))
+        hR, ht = pose_compose(*pose_inverse(R1, t1), R2, t2)     # Lie.h:63-69 between
+        H1 = -pose_adjoint(*pose_inverse(hR, ht))
+        H2 = np.broadcast_to(np.eye(6), H1.shape).copy()
+        zR, zt = pose_unpack(p.between_z.reshape(-1, 12))
+        err = pose3_logmap(*pose_compose(*pose_inverse(zR, zt), hR, ht))  # BetweenFactor.h:113-123 (no Hlocal)
+        H1, H2, b = _whiten_many(p, p.between_noise, H1, H2, -err)
+        out[FAC_BETWEEN_POSE3] = (H1, H2, b)
+    if p.n_prior:
+        A = np.zeros((p.n_prior, 9, 9)); b = np.zeros((p.n_prior, 9)); dims = np.zeros(p.n_prior, np.int32)
+        for k in range(p.n_prior):
+            v = int(p.prior_var[k]); t = int(p.var_type[v]); d = TANGENT[t]
+            x = values[off[v]:off[v] + STORAGE[t]]
+            z = p.prior_data[p.prior_off[k]:p.prior_off[k] + STORAGE[t]]
+            e = -local_coordinates(t, x, z)                      # PriorFactor.h:98-102, H = I
+            W = noise_sqrt_info(p, int(p.prior_noise[k]))
+            A[k, :d, :d] = W @ np.eye(d); b[k, :d] = W @ (-e); dims[k] = d
+        out[FAC_PRIOR] = (A, None, b, dims)
+    return out
+
+
+def local_coordinates(vtype, x, z):
+    """traits<T>::Local(x, z): Pose3 Logmap(between) ; PinholeCamera [pose local; calib diff]
+    (PinholeCamera.h:208-213, Cal3Bundler.h:150-152); Point3 z - x."""
+    if vtype == VAR_POSE3:
+        return pose_local(x[None, :12], z[None, :12])[0]
+    if vtype == VAR_SFM_CAMERA:
+        return np.concatenate([pose_local(x[None, :12], z[None, :12])[0], z[12:15] - x[12:15]])
+    return z - x
+
+
+def jacobians_flat(p: Problem, values, ftype):
+    """Same row layout as gtg_get_jacobians / ref_graph_jacobians."""
+    lin = linearize(p, values)
+    if ftype not in lin:
+        return np.zeros((0, 0))
+    if ftype == FAC_PRIOR:
+        A, _, b, dims = lin[ftype]
+        out = np.zeros((A.shape[0], 90))
+        for k in range(A.shape[0]):
+            d = dims[k]
+            out[k, :d * d] = A[k, :d, :d].reshape(-1); out[k, 81:81 + d] = b[k, :d]
+        return out
+    A1, A2, b = lin[ftype]
+    n = A1.shape[0]
+    return np.concatenate([A1.reshape(n, -1), A2.reshape(n, -1), b], 1)
+
+
+def error(p: Problem, values):
+    """NonlinearFactorGraph::error (NonlinearFactorGraph.cpp:170-179) = sum 0.5*||whiten(r)||^2
+    (NonlinearFactor.cpp:136-147).  b of linearize() is -whiten(r), so the sum of 0.5*|b|^2 is it."""
+    lin = linearize(p, values)
+    e = 0.0
+    for ft, tup in lin.items():
+        b = tup[2]
+        e += 0.5 * float(np.sum(b * b))
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+# linear algebra of the solve
+# ------------------------------------------------------------------------------------------------
+def _factor_blocks(p: Problem, lin):
+    """Yield (var ids tuple, [A blocks], b) per linear factor."""
+    if FAC_GENERAL_SFM in lin:
+        A1, A2, b = lin[FAC_GENERAL_SFM]
+        for k in range(A1.shape[0]):
+            yield (int(p.sfm_cam[k]), int(p.sfm_point[k])), (A1[k], A2[k]), b[k]
+    if FAC_PROJECTION in lin:
+        A1, A2, b = lin[FAC_PROJECTION]
+        for k in range(A1.shape[0]):
+            yield (int(p.proj_pose[k]), int(p.proj_point[k])), (A1[k], A2[k]), b[k]
+    if FAC_BETWEEN_POSE3 in lin:
+        A1, A2, b = lin[FAC_BETWEEN_POSE3]
+        for k in range(A1.shape[0]):
+            yield (int(p.between_v1[k]), int(p.between_v2[k])), (A1[k], A2[k]), b[k]
+    if FAC_PRIOR in lin:
+        A, _, b, dims = lin[FAC_PRIOR]
+        for k in range(A.shape[0]):
+            d = dims[k]
+            yield (int(p.prior_var[k]),), (A[k, :d, :d],), b[k, :d]
+
+
+def hessian_dense(p: Problem, values):
+    """Dense information matrix J^T J and gradient J^T b in variable-id order (the sum of
+    JacobianFactor::updateHessian contributions, linear/JacobianFactor.cpp:563-598).  Small problems."""
+    lin = linearize(p, values)
+    doff = p.dim_offsets(); n = int(doff[-1])
+    H = np.zeros((n, n)); g = np.zeros(n)
+    for vids, As, b in _factor_blocks(p, lin):
+        for i, vi in enumerate(vids):
+            si = slice(doff[vi], doff[vi + 1])
+            g[si] += As[i].T @ b
+            for j, vj in enumerate(vids):
+                H[si, slice(doff[vj], doff[vj + 1])] += As[i].T @ As[j]
+    return H, g, lin
+
+
+def hessian_diagonal(p: Problem, values):
+    """GaussianFactorGraph::hessianDiagonal (GaussianFactorGraph.cpp:279-287) = sum of squared
+    column norms (JacobianFactor::hessianDiagonalAdd JacobianFactor.cpp:516-541)."""
+    lin = linearize(p, values)
+    doff = p.dim_offsets(); d = np.zeros(int(doff[-1]))
+    for vids, As, b in _factor_blocks(p, lin):
+        for i, vi in enumerate(vids):
+            d[doff[vi]:doff[vi + 1]] += np.sum(As[i] * As[i], 0)
+    return d
+
+
+def cholesky_partial(ABC, n_frontal):
+    """gtsam::choleskyPartial (base/cholesky.cpp:107-158) on a symmetric matrix (upper triangle
+    used): A = R^T R (Eigen LLT; fails on a non-positive pivot), B <- R^-T B, C <- C - B^T B, then
+    the exponent test on the last two pivots (underconstrainedExponentDifference = 12).
+    Returns (ok, matrix with [R S; . C'])."""
+    M = np.array(ABC, np.float64, copy=True)
+    n = M.shape[0]; nf = n_frontal
+    if nf == 0:
+        return True, M
+    A = np.triu(M[:nf, :nf]); A = A + np.triu(A, 1).T
+    R = np.zeros((nf, nf))
+    for k in range(nf):                      # Eigen llt_inplace unblocked: x <= 0 -> NumericalIssue
+        x = A[k, k] - R[:k, k] @ R[:k, k]
+        if not (x > 0.0):
+            return False, M
+        R[k, k] = math.sqrt(x)
+        if k + 1 < nf:
+            R[k, k + 1:] = (A[k, k + 1:] - R[:k, k] @ R[:k, k + 1:]) / R[k, k]
+    M[:nf, :nf] = R
+    if nf < n:
+        B = np.linalg.solve(R.T, M[:nf, nf:]) if nf > 0 else M[:nf, nf:]
+        # forward substitution (TRSM) -- np.linalg.solve on a triangular system is the same math
+        M[:nf, nf:] = B
+        C = np.triu(M[nf:, nf:]) - np.triu(B.T @ B)
+        M[nf:, nf:] = C
+    if nf >= 2:
+        e2 = math.frexp(R[nf - 2, nf - 2])[1]; e1 = math.frexp(R[nf - 1, nf - 1])[1]
+        return (e2 - e1 < 12), M
+    e1 = math.frexp(R[0, 0])[1]
+    return (e1 > -12), M
+
+
+def solve_damped(p: Problem, values, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32):
+    """One solve of LevenbergMarquardtOptimizer::tryLambda (LM.cpp:146-160):
+    buildDampedSystem (internal/LevenbergMarquardtState.h:125-156: one prior per variable, sigma =
+    1/sqrt(lambda), A = I or diag(sqrt(clamp(hessianDiagonal))) ) then
+    GaussianFactorGraph::optimize with the Schur ordering (points first; timing/timeSFMBAL.h:74-83):
+    every POINT3 is a clique with 3 frontals eliminated by choleskyPartial
+    (HessianFactor.cpp:459-487), the separators are summed into the reduced system, which is then
+    eliminated as one dense root clique; back-substitution x_F = R^-1 (d - S x_S)
+    (linearAlgorithms-inst.h:49-155).  Returns (status, delta, H, g, lin); status 1 =
+    IndeterminantLinearSystemException."""
+    H, g, lin = hessian_dense(p, values)
+    n = H.shape[0]
+    if diagonal_damping:
+        dd = np.sqrt(np.minimum(np.maximum(np.diag(H).copy(), min_diag), max_diag))  # LM.cpp:293-299
+        Hd = H + np.diag(lam * dd * dd)
+    else:
+        Hd = H + lam * np.eye(n)
+    doff = p.dim_offsets()
+    pts = [v for v in range(p.n_vars) if p.var_type[v] == VAR_POINT3]
+    rest = [v for v in range(p.n_vars) if p.var_type[v] != VAR_POINT3]
+    idx_rest = np.concatenate([np.arange(doff[v], doff[v + 1]) for v in rest]) if rest else np.zeros(0, int)
+    S = Hd[np.ix_(idx_rest, idx_rest)].copy(); gr = g[idx_rest].copy()
+    elim = []
+    for v in pts:
+        ip = np.arange(doff[v], doff[v + 1])
+        W = Hd[np.ix_(idx_rest, ip)]
+        nz = np.where(np.abs(W).sum(1) > 0)[0]
+        sep = np.unique(nz)                              # separator entries of this clique
+        m = 3 + sep.size + 1
+        aug = np.zeros((m, m))
+        aug[:3, :3] = Hd[np.ix_(ip, ip)]; aug[:3, 3:3 + sep.size] = W[sep].T; aug[:3, -1] = g[ip]
+        ok, aug = cholesky_partial(aug, 3)
+        if not ok:
+            return 1, None, H, g, lin
+        Rp = np.triu(aug[:3, :3]); Sp = aug[:3, 3:3 + sep.size]; dp = aug[:3, -1]
+        S[np.ix_(sep, sep)] -= Sp.T @ Sp                 # separator HessianFactor -> parent
+        gr[sep] -= Sp.T @ dp
+        elim.append((ip, sep, Rp, Sp, dp))
+    delta = np.zeros(n)
+    if idx_rest.size:
+        m = idx_rest.size
+        aug = np.zeros((m + 1, m + 1)); aug[:m, :m] = S; aug[:m, m] = gr
+        ok, aug = cholesky_partial(aug, m)
+        if not ok:
+            return 1, None, H, g, lin
+        Rr = np.triu(aug[:m, :m]); dr = aug[:m, m]
+        xr = np.linalg.solve(Rr, dr)
+        if not np.all(np.isfinite(xr)):
+            return 1, None, H, g, lin
+        delta[idx_rest] = xr
+    else:
+        xr = np.zeros(0)
+    for ip, sep, Rp, Sp, dp in elim:
+        delta[ip] = np.linalg.solve(Rp, dp - Sp @ xr[sep])
+    return 0, delta, H, g, lin
+
+
+def linear_error(p: Problem, lin, delta):
+    """GaussianFactorGraph::error(delta) = sum 0.5*||A delta - b||^2 on the UNDAMPED graph
+    (linear/GaussianFactorGraph.cpp:71-78, JacobianFactor.cpp:486-491)."""
+    doff = p.dim_offsets(); e = 0.0
+    for vids, As, b in _factor_blocks(p, lin):
+        r = -b.copy()
+        for i, vi in enumerate(vids):
+            r += As[i] @ delta[doff[vi]:doff[vi + 1]]
+        e += 0.5 * float(r @ r)
+    return e
+
+
+def retract(p: Problem, values, delta):
+    """Values::retract (nonlinear/Values.cpp:52-63): Pose3 T*Expmap(xi); PinholeCamera pose retract +
+    Cal3Bundler::retract (PinholeCamera.h:199-205, Cal3Bundler.h:145-147); Point3 p + d."""
+    values = np.asarray(values, np.float64); out = values.copy()
+    off = p.val_offsets(); doff = p.dim_offsets()
+    for t, st, dm in ((VAR_POSE3, 12, 6), (VAR_SFM_CAMERA, 17, 9), (VAR_POINT3, 3, 3)):
+        ids = np.where(p.var_type == t)[0]
+        if not ids.size:
+            continue
+        x = _gather(values, off, ids, st); d = _gather(delta, doff, ids, dm)
+        if t == VAR_POINT3:
+            y = x + d
+        else:
+            y = x.copy(); y[:, :12] = pose_retract(x[:, :12], d[:, :6])
+            if t == VAR_SFM_CAMERA:
+                y[:, 12:15] = x[:, 12:15] + d[:, 6:9]
+        out[off[ids][:, None] + np.arange(st)[None, :]] = y
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the LM loop   (nonlinear/LevenbergMarquardtOptimizer.cpp, NonlinearOptimizer.cpp)
+# ------------------------------------------------------------------------------------------------
+def check_convergence(rel_tol, abs_tol, err_tol, current_error, new_error):
+    """checkConvergence (nonlinear/NonlinearOptimizer.cpp:182-231)."""
+    if new_error <= err_tol:
+        return True
+    absolute_decrease = current_error - new_error
+    relative_decrease = absolute_decrease / current_error
+    return bool((rel_tol and (relative_decrease <= rel_tol)) or (absolute_decrease <= abs_tol))
+
+
+def lm_optimize(p: Problem, values0, params, max_trace=100000):
+    """LevenbergMarquardtOptimizer::optimize = defaultOptimize (NonlinearOptimizer.cpp:62-117) around
+    iterate()/tryLambda() (LM.cpp:121-308) with the lambda policy of
+    internal/LevenbergMarquardtState.h:70-94.  Returns dict(values, trace rows (inner, error, lambda),
+    iterations)."""
+    values = np.asarray(values0, np.float64).copy()
+    err = error(p, values)
+    lam, factor = params.lambdaInitial, params.lambdaFactor
+    iterations, inner = 0, 0
+    trace = [(inner, err, lam)]
+    if err <= params.errorTol or iterations >= params.maxIterations:
+        return dict(values=values, trace=np.array(trace), iterations=iterations)
+    new_error = err
+    while True:
+        current_error = new_error
+        # ---- iterate(): linearize once, then try lambdas --------------------------------------
+        while True:
+            status, delta, H, g, lin = solve_damped(p, values, lam, params.diagonalDamping,
+                                                    params.minDiagonal, params.maxDiagonal)
+            step_ok = False; stop = False; model_fidelity = 0.0
+            trial_err = math.inf; trial = None
+            if status == 0:
+                old_lin = linear_error(p, lin, np.zeros_like(delta)); new_lin = linear_error(p, lin, delta)
+                lin_change = old_lin - new_lin
+                if lin_change >= 0:
+                    trial = retract(p, values, delta)
+                    trial_err = error(p, trial)
+                    cost_change = err - trial_err
+                    if lin_change > EPS * old_lin:
+                        model_fidelity = cost_change / lin_change
+                        step_ok = model_fidelity > params.minModelFidelity
+                    if abs(cost_change) < params.relativeErrorTol * err:
+                        stop = True
+            if step_ok:
+                # decreaseLambda (LMState.h:81-94)
+                if params.useFixedLambdaFactor:
+                    lam = lam / factor
+                else:
+                    lam = lam * max(1.0 / 3.0, 1.0 - (2.0 * model_fidelity - 1.0) ** 3)
+                    factor = 2.0 * factor
+                lam = max(params.lambdaLowerBound, lam)
+                values, err = trial, trial_err
+                iterations += 1; inner += 1
+                break
+            elif not stop:
+                lam *= factor; inner += 1                   # increaseLambda (LMState.h:70-76)
+                if not params.useFixedLambdaFactor:
+                    factor *= 2.0
+                if lam >= params.lambdaUpperBound:
+                    break
+            else:
+                break
+        new_error = err
+        if len(trace) < max_trace:
+            trace.append((inner, err, lam))
+        if not (iterations < params.maxIterations and
+                not check_convergence(params.relativeErrorTol, params.absoluteErrorTol, params.errorTol,
+                                      current_error, new_error) and math.isfinite(current_error)):
+            break
+    return dict(values=values, trace=np.array(trace), iterations=iterations)

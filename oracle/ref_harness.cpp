@@ -1,0 +1,464 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// C-callable probes over the REAL reference (borglab/gtsam compiled from /root/reference by
+// oracle/Makefile into oracle/_ref/libgtsam_ref.so).  Used by
+//   * tests/golden/make_golden.py   to generate the committed golden fixtures,
+//   * tests/ (not gpu)              to pin the numpy restatement oracle/gtsam_oracle.py,
+//   * tests/ (gpu) and bench.py's cpu_baseline leg, when the prebuilt .so travelled to the box.
+// Nothing in the product path (gtsam_amd/) may load this file's library.
+//
+// It takes the same structure-of-arrays problem description as the product's C ABI
+// (include/gtsam_amd.h: gtg_problem) and builds the corresponding gtsam::NonlinearFactorGraph /
+// gtsam::Values with the reference's own classes, so that every number it returns is computed by
+// the reference's code paths: GeneralSFMFactor.h:127-177, ProjectionFactor.h:138-166,
+// BetweenFactor.h:111-124, PriorFactor.h:98-102, NonlinearFactorGraph.cpp:170-179,239-278,
+// GaussianFactorGraph.cpp:71-78,279-319, LevenbergMarquardtOptimizer.cpp:121-308.
+
+#include "../include/gtsam_amd.h"
+
+#include <gtsam/geometry/Cal3Bundler.h>
+#include <gtsam/geometry/Cal3_S2.h>
+#include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/geometry/Point3.h>
+#include <gtsam/geometry/Pose3.h>
+#include <gtsam/inference/Ordering.h>
+#include <gtsam/linear/GaussianFactorGraph.h>
+#include <gtsam/linear/JacobianFactor.h>
+#include <gtsam/linear/NoiseModel.h>
+#include <gtsam/linear/VectorValues.h>
+#include <gtsam/linear/linearExceptions.h>
+#include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
+#include <gtsam/nonlinear/NonlinearFactorGraph.h>
+#include <gtsam/nonlinear/PriorFactor.h>
+#include <gtsam/nonlinear/Values.h>
+#include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
+#include <gtsam/sfm/SfmData.h>
+#include <gtsam/slam/BetweenFactor.h>
+#include <gtsam/slam/GeneralSFMFactor.h>
+#include <gtsam/slam/ProjectionFactor.h>
+#include <gtsam/slam/dataset.h>
+
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace gtsam;
+typedef PinholeCamera<Cal3Bundler> Camera;
+typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
+typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
+
+namespace {
+
+Pose3 unpackPose(const double* p) {
+  Matrix3 R;
+  R << p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8];
+  return Pose3(Rot3(R), Point3(p[9], p[10], p[11]));
+}
+void packPose(const Pose3& T, double* p) {
+  const Matrix3 R = T.rotation().matrix();
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) p[3 * i + j] = R(i, j);
+  p[9] = T.x(); p[10] = T.y(); p[11] = T.z();
+}
+Camera unpackCamera(const double* p) {
+  return Camera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16]));
+}
+void packCamera(const Camera& c, double* p) {
+  packPose(c.pose(), p);
+  p[12] = c.calibration().fx(); p[13] = c.calibration().k1(); p[14] = c.calibration().k2();
+  p[15] = c.calibration().px(); p[16] = c.calibration().py();
+}
+int storageSize(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }
+int tangentDim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }
+
+struct RefGraph {
+  int n_vars = 0;
+  std::vector<int> var_type;
+  std::vector<int64_t> val_off, dim_off;
+  int64_t val_size = 0, dim_size = 0;
+  NonlinearFactorGraph graph;
+  // factor index ranges per type inside `graph` (inserted in this order)
+  size_t beg[4], end[4];
+  Values unpack(const double* v) const {
+    Values vals;
+    for (int i = 0; i < n_vars; i++) {
+      const double* p = v + val_off[i];
+      if (var_type[i] == GTG_VAR_POSE3) vals.insert(Key(i), unpackPose(p));
+      else if (var_type[i] == GTG_VAR_SFM_CAMERA) vals.insert(Key(i), unpackCamera(p));
+      else vals.insert(Key(i), Point3(p[0], p[1], p[2]));
+    }
+    return vals;
+  }
+  void pack(const Values& vals, double* v) const {
+    for (int i = 0; i < n_vars; i++) {
+      double* p = v + val_off[i];
+      if (var_type[i] == GTG_VAR_POSE3) packPose(vals.at<Pose3>(Key(i)), p);
+      else if (var_type[i] == GTG_VAR_SFM_CAMERA) packCamera(vals.at<Camera>(Key(i)), p);
+      else { const Point3 q = vals.at<Point3>(Key(i)); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
+    }
+  }
+  VectorValues unpackDelta(const double* d) const {
+    VectorValues vv;
+    for (int i = 0; i < n_vars; i++) {
+      const int n = tangentDim(var_type[i]);
+      vv.insert(Key(i), Eigen::Map<const Vector>(d + dim_off[i], n));
+    }
+    return vv;
+  }
+  void packDelta(const VectorValues& vv, double* d) const {
+    for (int i = 0; i < n_vars; i++) {
+      const int n = tangentDim(var_type[i]);
+      const Vector& v = vv.at(Key(i));
+      for (int k = 0; k < n; k++) d[dim_off[i] + k] = v(k);
+    }
+  }
+  Ordering ordering(int kind) const {
+    if (kind == 1) {  // Schur ordering of timing/timeSFMBAL.h:74-83: all points, then the rest
+      Ordering o;
+      for (int i = 0; i < n_vars; i++) if (var_type[i] == GTG_VAR_POINT3) o.push_back(Key(i));
+      for (int i = 0; i < n_vars; i++) if (var_type[i] != GTG_VAR_POINT3) o.push_back(Key(i));
+      return o;
+    }
+    return Ordering::Create(Ordering::COLAMD, graph);
+  }
+};
+
+SharedNoiseModel makeNoise(const gtg_problem* p, int idx) {
+  const int kind = p->noise_kind[idx], dim = p->noise_dim[idx];
+  const double* d = p->noise_data + p->noise_off[idx];
+  switch (kind) {
+    case GTG_NOISE_UNIT: return noiseModel::Unit::Create(dim);
+    case GTG_NOISE_ISOTROPIC: return noiseModel::Isotropic::Sigma(dim, d[0], false);
+    case GTG_NOISE_DIAGONAL: return noiseModel::Diagonal::Sigmas(Eigen::Map<const Vector>(d, dim), false);
+    default: {
+      Matrix R(dim, dim);
+      for (int i = 0; i < dim; i++) for (int j = 0; j < dim; j++) R(i, j) = d[i * dim + j];
+      return noiseModel::Gaussian::SqrtInformation(R, false);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* ref_graph_create(const gtg_problem* p) {
+  RefGraph* g = new RefGraph;
+  g->n_vars = p->n_vars;
+  g->var_type.assign(p->var_type, p->var_type + p->n_vars);
+  g->val_off.resize(p->n_vars); g->dim_off.resize(p->n_vars);
+  for (int i = 0; i < p->n_vars; i++) {
+    g->val_off[i] = g->val_size; g->dim_off[i] = g->dim_size;
+    g->val_size += storageSize(p->var_type[i]); g->dim_size += tangentDim(p->var_type[i]);
+  }
+  std::vector<SharedNoiseModel> noise(p->n_noise);
+  for (int i = 0; i < p->n_noise; i++) noise[i] = makeNoise(p, i);
+
+  g->beg[0] = g->graph.size();
+  for (int64_t i = 0; i < p->n_sfm; i++)
+    g->graph.emplace_shared<SfmFactor>(Point2(p->sfm_z[2 * i], p->sfm_z[2 * i + 1]),
+                                        noise[p->sfm_noise[i]], Key(p->sfm_cam[i]), Key(p->sfm_point[i]));
+  g->end[0] = g->beg[1] = g->graph.size();
+  std::vector<std::shared_ptr<Cal3_S2>> calibs(p->n_calib);
+  for (int i = 0; i < p->n_calib; i++) {
+    const double* c = p->calib + 5 * i;
+    calibs[i] = std::make_shared<Cal3_S2>(c[0], c[1], c[2], c[3], c[4]);
+  }
+  for (int64_t i = 0; i < p->n_proj; i++) {
+    const Point2 z(p->proj_z[2 * i], p->proj_z[2 * i + 1]);
+    std::optional<Pose3> sensor;
+    if (p->proj_sensor && p->proj_sensor[i] >= 0) sensor = unpackPose(p->sensor + 12 * p->proj_sensor[i]);
+    // throwCheirality=false, verboseCheirality=false: the defaults (ProjectionFactor.h:87-92)
+    g->graph.emplace_shared<ProjFactor>(z, noise[p->proj_noise[i]], Key(p->proj_pose[i]),
+                                         Key(p->proj_point[i]), calibs[p->proj_calib[i]], sensor);
+  }
+  g->end[1] = g->beg[2] = g->graph.size();
+  for (int64_t i = 0; i < p->n_between; i++)
+    g->graph.emplace_shared<BetweenFactor<Pose3>>(Key(p->between_v1[i]), Key(p->between_v2[i]),
+                                                   unpackPose(p->between_z + 12 * i),
+                                                   noise[p->between_noise[i]]);
+  g->end[2] = g->beg[3] = g->graph.size();
+  for (int64_t i = 0; i < p->n_prior; i++) {
+    const int v = p->prior_var[i];
+    const double* d = p->prior_data + p->prior_off[i];
+    const SharedNoiseModel& nm = noise[p->prior_noise[i]];
+    if (p->var_type[v] == GTG_VAR_POSE3) g->graph.addPrior(Key(v), unpackPose(d), nm);
+    else if (p->var_type[v] == GTG_VAR_SFM_CAMERA) g->graph.addPrior(Key(v), unpackCamera(d), nm);
+    else g->graph.addPrior(Key(v), Point3(d[0], d[1], d[2]), nm);
+  }
+  g->end[3] = g->graph.size();
+  return g;
+}
+
+void ref_graph_destroy(void* h) { delete static_cast<RefGraph*>(h); }
+int64_t ref_graph_values_size(void* h) { return static_cast<RefGraph*>(h)->val_size; }
+int64_t ref_graph_tangent_size(void* h) { return static_cast<RefGraph*>(h)->dim_size; }
+
+double ref_graph_error(void* h, const double* values) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  return g->graph.error(g->unpack(values));
+}
+
+// Same layout as gtg_get_jacobians(): row-major per factor [A1 | A2 | b]; PRIOR padded to 9.
+int ref_graph_jacobians(void* h, const double* values, int type, double* out, int64_t n_out) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  const Values vals = g->unpack(values);
+  int64_t pos = 0;
+  for (size_t i = g->beg[type]; i < g->end[type]; i++) {
+    auto jf = std::dynamic_pointer_cast<JacobianFactor>(g->graph[i]->linearize(vals));
+    if (!jf) return -1;
+    if (type == GTG_FAC_PRIOR) {
+      if (pos + 90 > n_out) return -2;
+      std::fill(out + pos, out + pos + 90, 0.0);
+      const Matrix A = jf->getA(jf->begin());
+      const Vector b = jf->getb();
+      const int d = (int)A.rows();
+      for (int r = 0; r < d; r++) for (int c = 0; c < d; c++) out[pos + r * d + c] = A(r, c);
+      for (int r = 0; r < d; r++) out[pos + 81 + r] = b(r);
+      pos += 90;
+    } else {
+      for (auto it = jf->begin(); it != jf->end(); ++it) {
+        const Matrix A = jf->getA(it);
+        if (pos + A.size() > n_out) return -2;
+        for (int r = 0; r < A.rows(); r++) for (int c = 0; c < A.cols(); c++) out[pos++] = A(r, c);
+      }
+      const Vector b = jf->getb();
+      if (pos + b.size() > n_out) return -2;
+      for (int r = 0; r < b.size(); r++) out[pos++] = b(r);
+    }
+  }
+  return 0;
+}
+
+// Dense undamped information matrix (variable id order) and gradient J^T b.
+int ref_graph_hessian(void* h, const double* values, double* H, double* grad) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  const Values vals = g->unpack(values);
+  auto lin = g->graph.linearize(vals);
+  Ordering ord;
+  for (int i = 0; i < g->n_vars; i++) ord.push_back(Key(i));
+  auto Hg = lin->hessian(ord);
+  const int64_t n = g->dim_size;
+  if (H) for (int64_t r = 0; r < n; r++) for (int64_t c = 0; c < n; c++) H[r * n + c] = Hg.first(r, c);
+  if (grad) for (int64_t r = 0; r < n; r++) grad[r] = Hg.second(r);
+  return 0;
+}
+
+int ref_graph_hessian_diagonal(void* h, const double* values, double* d) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  auto lin = g->graph.linearize(g->unpack(values));
+  g->packDelta(lin->hessianDiagonal(), d);
+  return 0;
+}
+
+// One tryLambda body up to the linear errors: damp + solve. Returns 1 on
+// IndeterminantLinearSystemException. lin_err[0]=linear.error(0), [1]=linear.error(delta).
+int ref_graph_solve(void* h, const double* values, double lambda, int diagonal_damping,
+                    double min_diag, double max_diag, int ordering_kind, double* delta,
+                    double* lin_err) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  const Values vals = g->unpack(values);
+  auto lin = g->graph.linearize(vals);
+  internal::LevenbergMarquardtState state(vals, 0.0, lambda, 10.0);
+  GaussianFactorGraph damped;
+  if (diagonal_damping) {
+    VectorValues sq = lin->hessianDiagonal();
+    for (auto& [key, value] : sq) value = value.cwiseMax(min_diag).cwiseMin(max_diag).cwiseSqrt();
+    damped = state.buildDampedSystem(*lin, sq);
+  } else {
+    damped = state.buildDampedSystem(*lin);
+  }
+  try {
+    VectorValues d = damped.optimize(g->ordering(ordering_kind), EliminatePreferCholesky);
+    g->packDelta(d, delta);
+    if (lin_err) { lin_err[0] = lin->error(VectorValues::Zero(d)); lin_err[1] = lin->error(d); }
+  } catch (const IndeterminantLinearSystemException&) {
+    return 1;
+  }
+  return 0;
+}
+
+int ref_graph_retract(void* h, const double* values, const double* delta, double* out) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  g->pack(g->unpack(values).retract(g->unpackDelta(delta)), out);
+  return 0;
+}
+
+struct ref_lm_params {
+  int32_t max_iterations; double relative_error_tol, absolute_error_tol, error_tol;
+  double lambda_initial, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity;
+  int32_t diagonal_damping, use_fixed_lambda_factor; double min_diagonal, max_diagonal;
+  int32_t ordering_kind;  // 0 COLAMD, 1 Schur (points first)
+};
+
+// Runs the reference's LM (defaultOptimize loop restated around lm.iterate() so that a
+// per-outer-iteration trace can be recorded). trace rows: [inner_iterations, error, lambda, seconds].
+int ref_graph_lm(void* h, const double* values0, const ref_lm_params* rp, double* values_out,
+                 int max_trace, double* trace, int* n_trace, double* total_seconds) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  LevenbergMarquardtParams params;
+  params.maxIterations = rp->max_iterations;
+  params.relativeErrorTol = rp->relative_error_tol;
+  params.absoluteErrorTol = rp->absolute_error_tol;
+  params.errorTol = rp->error_tol;
+  params.lambdaInitial = rp->lambda_initial;
+  params.lambdaFactor = rp->lambda_factor;
+  params.lambdaUpperBound = rp->lambda_upper_bound;
+  params.lambdaLowerBound = rp->lambda_lower_bound;
+  params.minModelFidelity = rp->min_model_fidelity;
+  params.diagonalDamping = rp->diagonal_damping;
+  params.useFixedLambdaFactor = rp->use_fixed_lambda_factor;
+  params.minDiagonal = rp->min_diagonal;
+  params.maxDiagonal = rp->max_diagonal;
+  const Values initial = g->unpack(values0);
+  auto t0 = std::chrono::high_resolution_clock::now();
+  if (rp->ordering_kind == 1) params.ordering = g->ordering(1);
+  LevenbergMarquardtOptimizer lm(g->graph, initial, params);
+  int nt = 0;
+  auto rec = [&]() {
+    if (nt < max_trace) {
+      auto t = std::chrono::high_resolution_clock::now();
+      trace[4 * nt + 0] = lm.getInnerIterations();
+      trace[4 * nt + 1] = lm.error();
+      trace[4 * nt + 2] = lm.lambda();
+      trace[4 * nt + 3] = std::chrono::duration<double>(t - t0).count();
+      nt++;
+    }
+  };
+  rec();
+  // NonlinearOptimizer::defaultOptimize, nonlinear/NonlinearOptimizer.cpp:62-117
+  double currentError = lm.error();
+  if (!(currentError <= params.errorTol) && lm.iterations() < (size_t)params.maxIterations) {
+    double newError = currentError;
+    do {
+      currentError = newError;
+      lm.iterate();
+      newError = lm.error();
+      rec();
+    } while (lm.iterations() < (size_t)params.maxIterations &&
+             !checkConvergence(params.relativeErrorTol, params.absoluteErrorTol, params.errorTol,
+                               currentError, newError, params.verbosity) &&
+             std::isfinite(currentError));
+  }
+  auto t1 = std::chrono::high_resolution_clock::now();
+  if (total_seconds) *total_seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (n_trace) *n_trace = nt;
+  if (values_out) g->pack(lm.values(), values_out);
+  return (int)lm.iterations();
+}
+
+// Phase timings of ONE LM iteration made of the reference's own calls in the order iterate()/
+// tryLambda() make them (LevenbergMarquardtOptimizer.cpp:121-308). ms[8]: linearize,
+// hessianDiagonal, damp, eliminate+solve, linear error x2, retract, nonlinear error, total.
+int ref_graph_iteration_phases(void* h, const double* values, double lambda, int diagonal_damping,
+                               int ordering_kind, double* ms) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  using clk = std::chrono::high_resolution_clock;
+  auto msec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const Values vals = g->unpack(values);
+  const Ordering ord = g->ordering(ordering_kind);
+  auto t0 = clk::now();
+  auto lin = g->graph.linearize(vals);
+  auto t1 = clk::now();
+  VectorValues sq;
+  if (diagonal_damping) {
+    sq = lin->hessianDiagonal();
+    for (auto& [key, value] : sq) value = value.cwiseMax(1e-6).cwiseMin(1e32).cwiseSqrt();
+  }
+  auto t2 = clk::now();
+  internal::LevenbergMarquardtState state(vals, 0.0, lambda, 10.0);
+  GaussianFactorGraph damped = diagonal_damping ? state.buildDampedSystem(*lin, sq) : state.buildDampedSystem(*lin);
+  auto t3 = clk::now();
+  VectorValues d;
+  int status = 0;
+  try { d = damped.optimize(ord, EliminatePreferCholesky); } catch (const IndeterminantLinearSystemException&) { status = 1; }
+  auto t4 = clk::now();
+  double e = 0;
+  if (!status) { e += lin->error(VectorValues::Zero(d)); e += lin->error(d); }
+  auto t5 = clk::now();
+  Values nv; if (!status) nv = vals.retract(d);
+  auto t6 = clk::now();
+  if (!status) e += g->graph.error(nv);
+  auto t7 = clk::now();
+  ms[0] = msec(t0, t1); ms[1] = msec(t1, t2); ms[2] = msec(t2, t3); ms[3] = msec(t3, t4);
+  ms[4] = msec(t4, t5); ms[5] = msec(t5, t6); ms[6] = msec(t6, t7); ms[7] = msec(t0, t7);
+  return status + (e != e ? 2 : 0);
+}
+
+// ---- dataset loaders (reference's own parsers) -------------------------------------------------
+static SfmData g_bal;
+int ref_load_bal(const char* path, int64_t* n_cam, int64_t* n_pt, int64_t* n_obs) {
+  g_bal = SfmData::FromBalFile(path);  // sfm/SfmData.cpp:189-246 (parses through float)
+  *n_cam = g_bal.numberCameras(); *n_pt = g_bal.numberTracks();
+  int64_t k = 0; for (const SfmTrack& t : g_bal.tracks) k += t.numberMeasurements();
+  *n_obs = k;
+  return 0;
+}
+int ref_bal_fill(double* cams17, double* pts3, int32_t* obs_cam, int32_t* obs_pt, double* obs_z) {
+  for (size_t i = 0; i < g_bal.numberCameras(); i++) packCamera(g_bal.cameras[i], cams17 + 17 * i);
+  int64_t k = 0;
+  for (size_t j = 0; j < g_bal.numberTracks(); j++) {
+    const SfmTrack& t = g_bal.tracks[j];
+    pts3[3 * j] = t.p.x(); pts3[3 * j + 1] = t.p.y(); pts3[3 * j + 2] = t.p.z();
+    for (const SfmMeasurement& m : t.measurements) {
+      obs_cam[k] = (int32_t)m.first; obs_pt[k] = (int32_t)j;
+      obs_z[2 * k] = m.second.x(); obs_z[2 * k + 1] = m.second.y();
+      k++;
+    }
+  }
+  return 0;
+}
+
+// 3D pose graph via readG2o(file, is3D=true) (slam/dataset.cpp:621-633, load3D :922-944).
+static NonlinearFactorGraph::shared_ptr g_pg;
+static Values::shared_ptr g_pg_init;
+int ref_load_g2o3d(const char* path, int64_t* n_between, int64_t* n_vertices) {
+  auto gv = readG2o(path, true);
+  g_pg = gv.first; g_pg_init = gv.second;
+  int64_t nb = 0;
+  for (const auto& f : *g_pg) if (std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) nb++;
+  *n_between = nb; *n_vertices = g_pg_init->size();
+  return 0;
+}
+// noise out: kind per factor + 36 doubles (sigma / sigmas / R row-major)
+int ref_g2o3d_fill(int64_t* v1, int64_t* v2, double* z12, int32_t* noise_kind, double* noise36,
+                   int64_t* vertex_keys, double* vertex_poses12) {
+  int64_t k = 0;
+  for (const auto& f : *g_pg) {
+    auto bf = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f);
+    if (!bf) continue;
+    v1[k] = (int64_t)bf->key1(); v2[k] = (int64_t)bf->key2();
+    packPose(bf->measured(), z12 + 12 * k);
+    double* nd = noise36 + 36 * k;
+    std::fill(nd, nd + 36, 0.0);
+    auto nm = bf->noiseModel();
+    if (nm->isUnit()) noise_kind[k] = GTG_NOISE_UNIT;
+    else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { noise_kind[k] = GTG_NOISE_ISOTROPIC; nd[0] = iso->sigma(); }
+    else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { noise_kind[k] = GTG_NOISE_DIAGONAL; for (int i = 0; i < 6; i++) nd[i] = dg->sigma(i); }
+    else { auto ga = std::dynamic_pointer_cast<noiseModel::Gaussian>(nm); noise_kind[k] = GTG_NOISE_GAUSSIAN; const Matrix R = ga->R(); for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) nd[6 * i + j] = R(i, j); }
+    k++;
+  }
+  int64_t i = 0;
+  for (const auto& kv : *g_pg_init) {
+    vertex_keys[i] = (int64_t)kv.key;
+    packPose(kv.value.cast<Pose3>(), vertex_poses12 + 12 * i);
+    i++;
+  }
+  return 0;
+}
+
+// ---- small-matrix probes used to pin the restated linear algebra --------------------------------
+// gtsam::choleskyPartial (base/cholesky.cpp:107-158) on a col-major... we pass row-major symmetric.
+bool ref_cholesky_partial(double* ABC, int n, int nFrontal);
+}  // extern "C"
+
+#include <gtsam/base/cholesky.h>
+extern "C" bool ref_cholesky_partial(double* ABC, int n, int nFrontal) {
+  Matrix M(n, n);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) M(i, j) = ABC[i * n + j];
+  const bool ok = choleskyPartial(M, nFrontal);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) ABC[i * n + j] = M(i, j);
+  return ok;
+}

@@ -1,0 +1,674 @@
+// api.hip -- the C ABI (include/gtsam_amd.h) and the one-time host-side symbolic analysis.
+//
+// Host work here is O(#factors) bookkeeping done ONCE per graph: landmark classification, CSR
+// incidence lists, the block pattern of the Schur complement.  It replaces the VariableIndex /
+// EliminationTree / JunctionTree / Scatter construction that the reference repeats on every lambda
+// try (inference/VariableIndex-inl.h:27-49, EliminationTree-inst.h:77-155, JunctionTree-inst.h:63-151,
+// linear/Scatter.cpp:39-73).  All arithmetic of the hot path runs in the HIP kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include "factors.h"
+#include "kernels.h"
+
+namespace gt {
+
+static thread_local std::string g_last_error;
+
+void check_hip(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class T> void DevBuf<T>::alloc(size_t count) {
+  free();
+  n = count;
+  if (count) check_hip(hipMalloc(&p, sizeof(T) * count), "hipMalloc");
+}
+template <class T> void DevBuf<T>::upload(const T* host, size_t count, hipStream_t s) {
+  if (count != n || (count && !p)) alloc(count);
+  if (count) check_hip(hipMemcpyAsync(p, host, sizeof(T) * count, hipMemcpyHostToDevice, s), "H2D");
+}
+template <class T> void DevBuf<T>::free() {
+  if (p) (void)hipFree(p);
+  p = nullptr; n = 0;
+}
+template struct DevBuf<double>;
+template struct DevBuf<int32_t>;
+template struct DevBuf<int64_t>;
+
+static inline int storage_size(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }
+static inline int tangent_dim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }
+
+// host copy of the (shard-filtered) factor index arrays needed by the symbolic analysis
+struct HostIndex {
+  std::vector<int32_t> sfm_cam, sfm_point, proj_pose, proj_point, between_v1, between_v2, prior_var;
+  std::vector<int32_t> user_order;  // optional reduced ordering (variable ids)
+};
+static std::vector<std::pair<gtg_context*, HostIndex*>> g_index;  // tiny registry (handles are few)
+static HostIndex& host_index(gtg_context* c) {
+  for (auto& kv : g_index) if (kv.first == c) return *kv.second;
+  g_index.emplace_back(c, new HostIndex);
+  return *g_index.back().second;
+}
+static void drop_index(gtg_context* c) {
+  for (size_t i = 0; i < g_index.size(); i++)
+    if (g_index[i].first == c) { delete g_index[i].second; g_index.erase(g_index.begin() + i); return; }
+}
+
+template <class T> static void up(DevBuf<T>& b, const std::vector<T>& v, hipStream_t s) {
+  b.upload(v.data(), v.size(), s);
+  if (v.empty()) b.alloc(1);  // keep kernels' pointer arguments non-null
+}
+
+// ---- symbolic analysis ------------------------------------------------------------------------------
+static void analyze(gtg_context& c) {
+  HostIndex& hi = host_index(&c);
+  const int nv = c.n_vars;
+  const int64_t n_sfm = c.f.n_sfm, n_proj = c.f.n_proj, n_btw = c.f.n_between, n_pri = c.f.n_prior;
+  hipStream_t s = c.stream;
+
+  // landmarks = POINT3 variables (eliminated first, timing/timeSFMBAL.h:74-83); the rest is reduced
+  c.h_lm_index.assign(nv, -1); c.h_red_index.assign(nv, -1);
+  c.h_lm_var.clear(); c.h_red_var.clear();
+  for (int v = 0; v < nv; v++) {
+    if (c.h_var_type[v] == GTG_VAR_POINT3) { c.h_lm_index[v] = (int)c.h_lm_var.size(); c.h_lm_var.push_back(v); }
+    else { c.h_red_index[v] = (int)c.h_red_var.size(); c.h_red_var.push_back(v); }
+  }
+  c.n_lm = (int)c.h_lm_var.size(); c.n_red_vars = (int)c.h_red_var.size();
+  // validate factor roles
+  for (int64_t i = 0; i < n_sfm; i++)
+    if (c.h_var_type[hi.sfm_cam[i]] != GTG_VAR_SFM_CAMERA || c.h_var_type[hi.sfm_point[i]] != GTG_VAR_POINT3)
+      throw std::invalid_argument("GeneralSFMFactor keys must be (SFM_CAMERA, POINT3)");
+  for (int64_t i = 0; i < n_proj; i++)
+    if (c.h_var_type[hi.proj_pose[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.proj_point[i]] != GTG_VAR_POINT3)
+      throw std::invalid_argument("GenericProjectionFactor keys must be (POSE3, POINT3)");
+  for (int64_t i = 0; i < n_btw; i++)
+    if (c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.between_v2[i]] != GTG_VAR_POSE3 ||
+        hi.between_v1[i] == hi.between_v2[i])
+      throw std::invalid_argument("BetweenFactor<Pose3> keys must be two distinct POSE3 variables");
+
+  // ordering of the reduced variables
+  c.h_red_pos.assign(c.n_red_vars, -1);
+  if (!hi.user_order.empty()) {
+    if ((int)hi.user_order.size() != c.n_red_vars) throw std::invalid_argument("reduced ordering has wrong length");
+    for (int i = 0; i < c.n_red_vars; i++) {
+      const int v = hi.user_order[i];
+      if (v < 0 || v >= nv || c.h_red_index[v] < 0 || c.h_red_pos[c.h_red_index[v]] >= 0)
+        throw std::invalid_argument("reduced ordering is not a permutation of the non-landmark variables");
+      c.h_red_pos[c.h_red_index[v]] = i;
+    }
+  } else {
+    for (int r = 0; r < c.n_red_vars; r++) c.h_red_pos[r] = r;
+  }
+  std::vector<int32_t> pos_to_red(c.n_red_vars);
+  for (int r = 0; r < c.n_red_vars; r++) pos_to_red[c.h_red_pos[r]] = r;
+  c.h_red_dim.assign(c.n_red_vars, 0); c.h_red_off.assign(c.n_red_vars, 0);
+  int64_t off = 0;
+  for (int p = 0; p < c.n_red_vars; p++) {
+    const int r = pos_to_red[p];
+    c.h_red_dim[r] = tangent_dim(c.h_var_type[c.h_red_var[r]]);
+    c.h_red_off[r] = off; off += c.h_red_dim[r];
+  }
+  c.n_red = off;
+  c.NP = (int)((std::max<int64_t>(off, 1) + kTile - 1) / kTile * kTile);
+
+  // observations
+  c.n_obs = n_sfm + n_proj;
+  std::vector<int32_t> obs_red(c.n_obs), obs_lm(c.n_obs);
+  for (int64_t i = 0; i < n_sfm; i++) { obs_red[i] = c.h_red_index[hi.sfm_cam[i]]; obs_lm[i] = c.h_lm_index[hi.sfm_point[i]]; }
+  for (int64_t i = 0; i < n_proj; i++) { obs_red[n_sfm + i] = c.h_red_index[hi.proj_pose[i]]; obs_lm[n_sfm + i] = c.h_lm_index[hi.proj_point[i]]; }
+
+  // landmark -> observations / priors (CSR, factor order)
+  std::vector<int64_t> lm_obs_ptr(c.n_lm + 1, 0), lm_pri_ptr(c.n_lm + 1, 0);
+  for (int64_t o = 0; o < c.n_obs; o++) lm_obs_ptr[obs_lm[o] + 1]++;
+  for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri_ptr[l + 1]++; }
+  for (int l = 0; l < c.n_lm; l++) { lm_obs_ptr[l + 1] += lm_obs_ptr[l]; lm_pri_ptr[l + 1] += lm_pri_ptr[l]; }
+  std::vector<int32_t> lm_obs(c.n_obs), lm_pri(lm_pri_ptr[c.n_lm]);
+  { std::vector<int64_t> w(lm_obs_ptr.begin(), lm_obs_ptr.end() - 1);
+    for (int64_t o = 0; o < c.n_obs; o++) lm_obs[w[obs_lm[o]]++] = (int32_t)o; }
+  { std::vector<int64_t> w(lm_pri_ptr.begin(), lm_pri_ptr.end() - 1);
+    for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri[w[l]++] = (int32_t)i; } }
+  std::vector<int32_t> lm_owned(std::max(c.n_lm, 1), 0);
+  for (int l = 0; l < c.n_lm; l++) lm_owned[l] = (l % c.n_shards) == c.shard;
+
+  // reduced variable -> contributions
+  std::vector<int64_t> inc_ptr(c.n_red_vars + 1, 0);
+  auto count = [&](int v) { const int r = c.h_red_index[v]; if (r >= 0) inc_ptr[r + 1]++; };
+  for (int64_t i = 0; i < n_sfm; i++) count(hi.sfm_cam[i]);
+  for (int64_t i = 0; i < n_proj; i++) count(hi.proj_pose[i]);
+  for (int64_t i = 0; i < n_btw; i++) { count(hi.between_v1[i]); count(hi.between_v2[i]); }
+  for (int64_t i = 0; i < n_pri; i++) count(hi.prior_var[i]);
+  for (int r = 0; r < c.n_red_vars; r++) inc_ptr[r + 1] += inc_ptr[r];
+  std::vector<int32_t> inc_kind(inc_ptr[c.n_red_vars]), inc_idx(inc_ptr[c.n_red_vars]);
+  { std::vector<int64_t> w(inc_ptr.begin(), inc_ptr.end() - 1);
+    auto put = [&](int v, int kind, int64_t idx) { const int r = c.h_red_index[v]; if (r >= 0) { inc_kind[w[r]] = kind; inc_idx[w[r]++] = (int32_t)idx; } };
+    for (int64_t i = 0; i < n_sfm; i++) put(hi.sfm_cam[i], 0, i);
+    for (int64_t i = 0; i < n_proj; i++) put(hi.proj_pose[i], 1, i);
+    for (int64_t i = 0; i < n_btw; i++) { put(hi.between_v1[i], 2, i); put(hi.between_v2[i], 3, i); }
+    for (int64_t i = 0; i < n_pri; i++) put(hi.prior_var[i], 4, i); }
+
+  // off-diagonal pose-pose blocks from BetweenFactors
+  struct HB { int64_t key; int32_t code; };
+  std::vector<HB> hb(n_btw);
+  for (int64_t i = 0; i < n_btw; i++) {
+    const int r1 = c.h_red_index[hi.between_v1[i]], r2 = c.h_red_index[hi.between_v2[i]];
+    const bool swap = c.h_red_pos[r2] > c.h_red_pos[r1];  // row variable (later position) is key2
+    const int rr = swap ? r2 : r1, rc = swap ? r1 : r2;
+    hb[i].key = (int64_t)c.h_red_pos[rr] * c.n_red_vars + c.h_red_pos[rc];
+    hb[i].code = (int32_t)i | (swap ? (1 << 30) : 0);
+  }
+  std::stable_sort(hb.begin(), hb.end(), [](const HB& a, const HB& b) { return a.key < b.key; });
+  std::vector<int32_t> hoff_row, hoff_col, hoff_fac(n_btw);
+  std::vector<int64_t> hoff_ptr;
+  for (int64_t i = 0; i < n_btw; i++) {
+    if (i == 0 || hb[i].key != hb[i - 1].key) {
+      hoff_ptr.push_back(i);
+      hoff_row.push_back(pos_to_red[hb[i].key / c.n_red_vars]);
+      hoff_col.push_back(pos_to_red[hb[i].key % c.n_red_vars]);
+    }
+    hoff_fac[i] = hb[i].code;
+  }
+  hoff_ptr.push_back(n_btw);
+  c.n_hoff = (int64_t)hoff_row.size();
+
+  // Schur block pairs: for every landmark, every pair of its observations
+  struct PT { int64_t key; int32_t oa, ob; };
+  std::vector<PT> pt;
+  { int64_t total = 0;
+    for (int l = 0; l < c.n_lm; l++) { const int64_t k = lm_obs_ptr[l + 1] - lm_obs_ptr[l]; total += k * (k + 1) / 2; }
+    pt.reserve(total); }
+  for (int l = 0; l < c.n_lm; l++) {
+    for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++)
+      for (int64_t b = lm_obs_ptr[l]; b <= a; b++) {
+        int32_t oa = lm_obs[a], ob = lm_obs[b];
+        int pa = c.h_red_pos[obs_red[oa]], pb = c.h_red_pos[obs_red[ob]];
+        if (pa < pb) { std::swap(oa, ob); std::swap(pa, pb); }
+        pt.push_back(PT{(int64_t)pa * c.n_red_vars + pb, oa, ob});
+        if (pa == pb && oa != ob) pt.push_back(PT{(int64_t)pa * c.n_red_vars + pb, ob, oa});  // same camera twice
+      }
+  }
+  std::stable_sort(pt.begin(), pt.end(), [](const PT& a, const PT& b) { return a.key < b.key; });
+  std::vector<int32_t> pair_row, pair_col, pair_oa(pt.size()), pair_ob(pt.size());
+  std::vector<int64_t> pair_ptr;
+  for (size_t i = 0; i < pt.size(); i++) {
+    if (i == 0 || pt[i].key != pt[i - 1].key) {
+      pair_ptr.push_back((int64_t)i);
+      pair_row.push_back(pos_to_red[pt[i].key / c.n_red_vars]);
+      pair_col.push_back(pos_to_red[pt[i].key % c.n_red_vars]);
+    }
+    pair_oa[i] = pt[i].oa; pair_ob[i] = pt[i].ob;
+  }
+  pair_ptr.push_back((int64_t)pt.size());
+  c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = (int64_t)pt.size();
+
+  // ---- upload -----------------------------------------------------------------------------------
+  up(c.lm_var, c.h_lm_var, s); up(c.red_var, c.h_red_var, s); up(c.red_dim, c.h_red_dim, s);
+  up(c.lm_index, c.h_lm_index, s); up(c.red_index, c.h_red_index, s); up(c.red_off, c.h_red_off, s);
+  up(c.lm_owned, lm_owned, s);
+  up(c.obs_red, obs_red, s); up(c.obs_lm, obs_lm, s);
+  up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s); up(c.lm_pri_ptr, lm_pri_ptr, s); up(c.lm_pri, lm_pri, s);
+  up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
+  up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
+  up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s); up(c.pair_ptr, pair_ptr, s);
+  up(c.pair_oa, pair_oa, s); up(c.pair_ob, pair_ob, s);
+
+  // ---- numeric buffers --------------------------------------------------------------------------
+  const size_t NP = c.NP;
+  c.Hd.alloc(std::max<size_t>(81 * (size_t)c.n_red_vars, 1)); c.gred0.alloc(std::max<size_t>(9 * (size_t)c.n_red_vars, 1));
+  c.hdiag_red.alloc(NP);
+  c.V.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.gp.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
+  c.Linv.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.ylm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
+  c.delta_lm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
+  c.E.alloc(std::max<size_t>(27 * (size_t)c.n_obs, 1));
+  c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
+  c.S.alloc((NP + kTile) * NP);
+  c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
+  c.xred.alloc(NP);
+  c.partials.alloc(2 * 2048);
+  c.scalars.alloc(SC_COUNT);
+  check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * SC_COUNT, s), "memset");
+  check_hip(hipMemsetAsync(c.hdiag_red.p, 0, sizeof(double) * NP, s), "memset");
+  check_hip(hipMemsetAsync(c.xred.p, 0, sizeof(double) * NP, s), "memset");
+  check_hip(hipMemsetAsync(c.delta_lm.p, 0, sizeof(double) * c.delta_lm.n, s), "memset");
+  check_hip(hipStreamSynchronize(s), "sync");
+
+  const double n = (double)c.n_red;
+  c.chol_flops = n * n * n / 3.0;
+  // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements +
+  // variable blocks read, Jacobian records written and read once by the assembly, blocks written
+  c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + 2.0 * kSfmRec * 8) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +
+                (double)n_btw * (2 * 4 + 96 + 4 + 2.0 * kBetweenRec * 8) + (double)c.val_size * 8 +
+                (double)c.n_red_vars * 90 * 8 + (double)c.n_lm * 12 * 8 + (double)c.n_hoff * 36 * 8;
+}
+
+static void exchange(gtg_context& c, double* ptr, int64_t n) {
+  if (c.n_shards > 1) {
+    if (!c.allreduce) throw std::runtime_error("n_shards > 1 but no allreduce callback was set (gtg_set_allreduce)");
+    const int rc = c.allreduce(ptr, n, (void*)c.stream, c.allreduce_user);
+    if (rc != 0) throw std::runtime_error("allreduce callback failed");
+  }
+}
+
+static void read_scalars(gtg_context& c) {
+  exchange(c, c.scalars.p, SC_COUNT);
+  check_hip(hipMemcpyAsync(c.h_scalars, c.scalars.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, c.stream), "D2H");
+  check_hip(hipStreamSynchronize(c.stream), "sync");
+  c.h_scalars[SC_DELTA_SQ] /= c.n_shards;  // identical on every shard, summed by the exchange
+}
+
+struct PhaseTimer {
+  gtg_context& c; int ph; hipEvent_t a, b;
+  PhaseTimer(gtg_context& c_, int ph_, hipEvent_t* evs) : c(c_), ph(ph_), a(evs[2 * ph_]), b(evs[2 * ph_ + 1]) {
+    if (c.timing) (void)hipEventRecord(a, c.stream);
+  }
+  ~PhaseTimer() { if (c.timing) (void)hipEventRecord(b, c.stream); }
+};
+static hipEvent_t g_events[2 * GTG_PH_COUNT];
+static bool g_events_ready = false;
+static void ensure_events() {
+  if (!g_events_ready) { for (auto& e : g_events) check_hip(hipEventCreate(&e), "event"); g_events_ready = true; }
+}
+static void collect(gtg_context& c, std::initializer_list<int> phases) {
+  if (!c.timing) return;
+  for (int ph : phases) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_events[2 * ph], g_events[2 * ph + 1]) == hipSuccess) { c.phase_ms[ph] += ms; c.phase_calls[ph]++; }
+  }
+}
+
+}  // namespace gt
+
+using namespace gt;
+
+#define GTG_TRY try {
+#define GTG_CATCH                                                                     \
+  } catch (const std::invalid_argument& e) { g_last_error = e.what(); return GTG_ERR_USAGE; } \
+  catch (const std::exception& e) { g_last_error = e.what(); return GTG_ERR_HIP; }
+
+extern "C" {
+
+const char* gtg_last_error(void) { return g_last_error.c_str(); }
+const char* gtg_version(void) { return "gtsam_amd 0.1 (gfx950, FP64)"; }
+const char* gtg_phase_name(int ph) {
+  static const char* names[GTG_PH_COUNT] = {"linearize", "assemble", "point_eliminate", "schur", "cholesky",
+                                            "solve", "linear_error", "retract", "error"};
+  return (ph >= 0 && ph < GTG_PH_COUNT) ? names[ph] : "?";
+}
+
+int gtg_create(gtg_handle* out, int device_id) {
+  GTG_TRY
+  if (!out) throw std::invalid_argument("null out");
+  int ndev = 0;
+  check_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+  if (device_id < 0 || device_id >= ndev) throw std::invalid_argument("bad device id (no HIP device visible?)");
+  check_hip(hipSetDevice(device_id), "hipSetDevice");
+  gtg_context* c = new gtg_context;
+  c->device = device_id;
+  check_hip(hipStreamCreate(&c->stream), "hipStreamCreate");
+  ensure_events();
+  *out = c;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_destroy(gtg_handle c) {
+  if (!c) return GTG_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  auto& f = c->f;
+  DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
+                           &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
+                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->delta_lm, &c->S,
+                           &c->Dinv, &c->xred, &c->partials, &c->scalars};
+  for (auto* b : dbl) b->free();
+  DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
+                            &c->noise_kind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.proj_pose, &f.proj_point,
+                            &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
+                            &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
+                            &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
+                            &c->pair_col, &c->pair_oa, &c->pair_ob};
+  for (auto* b : i32) b->free();
+  DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
+                            &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr};
+  for (auto* b : i64) b->free();
+  (void)hipStreamDestroy(c->stream);
+  drop_index(c);
+  delete c;
+  return GTG_OK;
+}
+
+int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shards) {
+  GTG_TRY
+  if (!c || !p) throw std::invalid_argument("null argument");
+  if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::invalid_argument("bad shard / n_shards");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  hipStream_t s = c->stream;
+  c->shard = shard; c->n_shards = n_shards;
+  c->n_vars = p->n_vars;
+  c->h_var_type.assign(p->var_type, p->var_type + p->n_vars);
+  c->h_val_off.assign(p->n_vars + 1, 0); c->h_dim_off.assign(p->n_vars + 1, 0);
+  for (int v = 0; v < p->n_vars; v++) {
+    const int t = p->var_type[v];
+    if (t < 0 || t > 2) throw std::invalid_argument("unknown variable type");
+    c->h_val_off[v + 1] = c->h_val_off[v] + storage_size(t);
+    c->h_dim_off[v + 1] = c->h_dim_off[v] + tangent_dim(t);
+  }
+  c->val_size = c->h_val_off[p->n_vars]; c->dim_size = c->h_dim_off[p->n_vars];
+  up(c->var_type, c->h_var_type, s); up(c->val_off, c->h_val_off, s); up(c->dim_off, c->h_dim_off, s);
+  c->values.alloc(std::max<int64_t>(c->val_size, 1)); c->trial.alloc(std::max<int64_t>(c->val_size, 1));
+  c->delta.alloc(std::max<int64_t>(c->dim_size, 1));
+  check_hip(hipMemsetAsync(c->delta.p, 0, sizeof(double) * c->delta.n, s), "memset");
+
+  // noise table: derive the inverse sigmas like the reference constructors (NoiseModel.cpp:275-281, Isotropic ctor)
+  {
+    std::vector<int32_t> kind(p->noise_kind, p->noise_kind + p->n_noise);
+    std::vector<int64_t> noff(p->n_noise);
+    std::vector<double> data;
+    for (int i = 0; i < p->n_noise; i++) {
+      const int dim = p->noise_dim[i];
+      const double* d = p->noise_data + p->noise_off[i];
+      noff[i] = (int64_t)data.size();
+      switch (kind[i]) {
+        case GTG_NOISE_UNIT: data.push_back(0.0); break;
+        case GTG_NOISE_ISOTROPIC: data.push_back(1.0 / d[0]); break;
+        case GTG_NOISE_DIAGONAL: for (int k = 0; k < dim; k++) data.push_back(1.0 / d[k]); break;
+        case GTG_NOISE_GAUSSIAN: for (int k = 0; k < dim * dim; k++) data.push_back(d[k]); break;
+        default: throw std::invalid_argument("unsupported noise model kind (Robust/Constrained are out of scope)");
+      }
+    }
+    up(c->noise_kind, kind, s); up(c->noise_off, noff, s); up(c->noise_data, data, s);
+  }
+  auto check_noise = [&](int idx, int dim, const char* what) {
+    if (idx < 0 || idx >= p->n_noise || p->noise_dim[idx] != dim)
+      throw std::invalid_argument(std::string(what) + ": NoiseModel has wrong dimension");  // NonlinearFactor.cpp:97-104
+  };
+  auto check_var = [&](int v) { if (v < 0 || v >= p->n_vars) throw std::invalid_argument("factor refers to a key that is not in Values"); };
+
+  HostIndex& hi = host_index(c);
+  auto& f = c->f;
+  // shard filter: landmark factors follow their landmark (rank among POINT3 variables), others round-robin
+  std::vector<int32_t> lm_rank(p->n_vars, -1);
+  { int k = 0; for (int v = 0; v < p->n_vars; v++) if (p->var_type[v] == GTG_VAR_POINT3) lm_rank[v] = k++; }
+  auto own_lm = [&](int v) { return lm_rank[v] >= 0 && (lm_rank[v] % n_shards) == shard; };
+
+  { // SFM
+    std::vector<int32_t> cam, pt, nz; std::vector<double> z;
+    for (int64_t i = 0; i < p->n_sfm; i++) {
+      check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor");
+      if (n_shards > 1 && !own_lm(p->sfm_point[i])) continue;
+      cam.push_back(p->sfm_cam[i]); pt.push_back(p->sfm_point[i]); nz.push_back(p->sfm_noise[i]);
+      z.push_back(p->sfm_z[2 * i]); z.push_back(p->sfm_z[2 * i + 1]);
+    }
+    f.n_sfm = (int64_t)cam.size();
+    up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
+    f.sfm_J.alloc(std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
+    hi.sfm_cam = cam; hi.sfm_point = pt;
+  }
+  { // projection
+    std::vector<int32_t> pose, pt, nz, cal, sen; std::vector<double> z;
+    for (int64_t i = 0; i < p->n_proj; i++) {
+      check_var(p->proj_pose[i]); check_var(p->proj_point[i]); check_noise(p->proj_noise[i], 2, "GenericProjectionFactor");
+      if (p->proj_calib[i] < 0 || p->proj_calib[i] >= p->n_calib) throw std::invalid_argument("bad calibration index");
+      const int si = p->proj_sensor ? p->proj_sensor[i] : -1;
+      if (si >= p->n_sensor) throw std::invalid_argument("bad body_P_sensor index");
+      if (n_shards > 1 && !own_lm(p->proj_point[i])) continue;
+      pose.push_back(p->proj_pose[i]); pt.push_back(p->proj_point[i]); nz.push_back(p->proj_noise[i]);
+      cal.push_back(p->proj_calib[i]); sen.push_back(si);
+      z.push_back(p->proj_z[2 * i]); z.push_back(p->proj_z[2 * i + 1]);
+    }
+    f.n_proj = (int64_t)pose.size();
+    up(f.proj_pose, pose, s); up(f.proj_point, pt, s); up(f.proj_noise, nz, s); up(f.proj_calib, cal, s);
+    up(f.proj_sensor, sen, s); up(f.proj_z, z, s);
+    std::vector<double> calib(p->calib, p->calib + 5 * (size_t)p->n_calib), sensor(p->sensor, p->sensor + 12 * (size_t)p->n_sensor);
+    up(f.calib, calib, s); up(f.sensor, sensor, s);
+    f.proj_J.alloc(std::max<size_t>((size_t)kProjRec * f.n_proj, 1));
+    hi.proj_pose = pose; hi.proj_point = pt;
+  }
+  { // between
+    std::vector<int32_t> v1, v2, nz; std::vector<double> z;
+    for (int64_t i = 0; i < p->n_between; i++) {
+      check_var(p->between_v1[i]); check_var(p->between_v2[i]); check_noise(p->between_noise[i], 6, "BetweenFactor<Pose3>");
+      if (n_shards > 1 && (i % n_shards) != shard) continue;
+      v1.push_back(p->between_v1[i]); v2.push_back(p->between_v2[i]); nz.push_back(p->between_noise[i]);
+      for (int k = 0; k < 12; k++) z.push_back(p->between_z[12 * i + k]);
+    }
+    f.n_between = (int64_t)v1.size();
+    up(f.between_v1, v1, s); up(f.between_v2, v2, s); up(f.between_noise, nz, s); up(f.between_z, z, s);
+    f.between_J.alloc(std::max<size_t>((size_t)kBetweenRec * f.n_between, 1));
+    hi.between_v1 = v1; hi.between_v2 = v2;
+  }
+  { // priors
+    std::vector<int32_t> var, nz; std::vector<int64_t> poff; std::vector<double> data;
+    for (int64_t i = 0; i < p->n_prior; i++) {
+      const int v = p->prior_var[i];
+      check_var(v); check_noise(p->prior_noise[i], tangent_dim(p->var_type[v]), "PriorFactor");
+      const bool mine = lm_rank[v] >= 0 ? own_lm(v) : ((i % n_shards) == shard);
+      if (n_shards > 1 && !mine) continue;
+      var.push_back(v); nz.push_back(p->prior_noise[i]); poff.push_back((int64_t)data.size());
+      const double* d = p->prior_data + p->prior_off[i];
+      for (int k = 0; k < storage_size(p->var_type[v]); k++) data.push_back(d[k]);
+    }
+    f.n_prior = (int64_t)var.size();
+    up(f.prior_var, var, s); up(f.prior_noise, nz, s); up(f.prior_off, poff, s); up(f.prior_data, data, s);
+    f.prior_J.alloc(std::max<size_t>((size_t)kPriorRec * f.n_prior, 1));
+    hi.prior_var = var;
+  }
+  analyze(*c);
+  c->uploaded = true; c->linearized = false; c->have_trial = false;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_set_reduced_ordering(gtg_handle c, const int32_t* order, int32_t n) {
+  GTG_TRY
+  if (!c) throw std::invalid_argument("null handle");
+  HostIndex& hi = host_index(c);
+  hi.user_order.assign(order, order + n);
+  if (c->uploaded) { check_hip(hipSetDevice(c->device), "hipSetDevice"); analyze(*c); c->linearized = false; c->have_trial = false; }
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int64_t gtg_values_size(gtg_handle c) { return c ? c->val_size : -1; }
+int64_t gtg_tangent_size(gtg_handle c) { return c ? c->dim_size : -1; }
+int64_t gtg_reduced_dim(gtg_handle c) { return c ? c->n_red : -1; }
+
+int gtg_set_values(gtg_handle c, const double* packed, int64_t n) {
+  GTG_TRY
+  if (!c || !c->uploaded || n != c->val_size) throw std::invalid_argument("gtg_set_values: wrong size or no problem uploaded");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemcpyAsync(c->values.p, packed, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "H2D");
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  c->linearized = false; c->have_trial = false;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+static int get_buf(gtg_handle c, const double* dev, int64_t have, double* out, int64_t n) {
+  GTG_TRY
+  if (!c || !c->uploaded || n != have) throw std::invalid_argument("getter: wrong size or no problem uploaded");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemcpyAsync(out, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  return GTG_OK;
+  GTG_CATCH
+}
+int gtg_get_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->values.p : nullptr, c ? c->val_size : -1, packed, n); }
+int gtg_get_trial_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->trial.p : nullptr, c ? c->val_size : -1, packed, n); }
+int gtg_get_delta(gtg_handle c, double* d, int64_t n) { return get_buf(c, c ? c->delta.p : nullptr, c ? c->dim_size : -1, d, n); }
+
+int gtg_error(gtg_handle c, double* error) {
+  GTG_TRY
+  if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  c->timing = c->timing;
+  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->values.p, SC_ERROR); }
+  read_scalars(*c);
+  collect(*c, {GTG_PH_ERROR});
+  *error = c->h_scalars[SC_ERROR];
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_linearize(gtg_handle c) {
+  GTG_TRY
+  if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  { PhaseTimer t(*c, GTG_PH_LINEARIZE, g_events); launch_linearize(*c); }
+  { PhaseTimer t(*c, GTG_PH_ASSEMBLE, g_events); launch_assemble(*c); }
+  exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  collect(*c, {GTG_PH_LINEARIZE, GTG_PH_ASSEMBLE});
+  c->linearized = true;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dmax, double out[4]) {
+  GTG_TRY
+  if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda: call gtg_linearize first");
+  if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
+  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+  { PhaseTimer t(*c, GTG_PH_SCHUR, g_events); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
+  exchange(*c, c->S.p, (int64_t)(c->NP + kTile) * c->NP);   // the one big exchange: reduced Hessian + rhs
+  { PhaseTimer t(*c, GTG_PH_CHOLESKY, g_events); launch_cholesky(*c, c->S.p, c->NP, kTile, c->Dinv.p, c->scalars.p + SC_FAIL); }
+  { PhaseTimer t(*c, GTG_PH_SOLVE, g_events);
+    launch_backward_solve(*c, c->S.p, c->NP, c->xred.p);
+    launch_back_substitute(*c);
+    if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
+    launch_scatter_delta(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, g_events); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_RETRACT, g_events); launch_retract(*c); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  read_scalars(*c);
+  collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
+  c->have_trial = true;
+  const double dsq = c->h_scalars[SC_DELTA_SQ];
+  if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq)) return GTG_INDETERMINATE;
+  out[0] = c->h_scalars[SC_LIN0];
+  out[1] = c->h_scalars[SC_LIN1];
+  out[2] = (out[0] - out[1] >= 0) ? c->h_scalars[SC_TRIAL_ERROR] : std::numeric_limits<double>::infinity();
+  out[3] = std::sqrt(dsq);
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_accept(gtg_handle c) {
+  GTG_TRY
+  if (!c || !c->have_trial) throw std::invalid_argument("gtg_accept: no trial values (call gtg_try_lambda)");
+  std::swap(c->values.p, c->trial.p);
+  c->linearized = false; c->have_trial = false;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
+  GTG_TRY
+  if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_gradient: linearize first / wrong size");
+  std::vector<double> gr(9 * (size_t)std::max(c->n_red_vars, 1)), gp(3 * (size_t)std::max(c->n_lm, 1));
+  check_hip(hipMemcpy(gr.data(), c->gred0.p, sizeof(double) * gr.size(), hipMemcpyDeviceToHost), "D2H");
+  check_hip(hipMemcpy(gp.data(), c->gp.p, sizeof(double) * gp.size(), hipMemcpyDeviceToHost), "D2H");
+  for (int v = 0; v < c->n_vars; v++) {
+    double* d = g + c->h_dim_off[v];
+    if (c->h_lm_index[v] >= 0) for (int k = 0; k < 3; k++) d[k] = gp[3 * c->h_lm_index[v] + k];
+    else for (int k = 0; k < c->h_red_dim[c->h_red_index[v]]; k++) d[k] = gr[9 * c->h_red_index[v] + k];
+  }
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_get_hessian_diagonal(gtg_handle c, double* out, int64_t n) {
+  GTG_TRY
+  if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_hessian_diagonal: linearize first / wrong size");
+  std::vector<double> hd(c->NP), V(9 * (size_t)std::max(c->n_lm, 1));
+  check_hip(hipMemcpy(hd.data(), c->hdiag_red.p, sizeof(double) * hd.size(), hipMemcpyDeviceToHost), "D2H");
+  check_hip(hipMemcpy(V.data(), c->V.p, sizeof(double) * V.size(), hipMemcpyDeviceToHost), "D2H");
+  for (int v = 0; v < c->n_vars; v++) {
+    double* d = out + c->h_dim_off[v];
+    if (c->h_lm_index[v] >= 0) for (int k = 0; k < 3; k++) d[k] = V[9 * c->h_lm_index[v] + 4 * k];
+    else { const int r = c->h_red_index[v]; for (int k = 0; k < c->h_red_dim[r]; k++) d[k] = hd[c->h_red_off[r] + k]; }
+  }
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
+  GTG_TRY
+  if (!c || !c->linearized) throw std::invalid_argument("gtg_get_jacobians: linearize first");
+  const double* src; int64_t cnt;
+  switch (type) {
+    case GTG_FAC_GENERAL_SFM: src = c->f.sfm_J.p; cnt = c->f.n_sfm * kSfmRec; break;
+    case GTG_FAC_PROJECTION: src = c->f.proj_J.p; cnt = c->f.n_proj * kProjRec; break;
+    case GTG_FAC_BETWEEN_POSE3: src = c->f.between_J.p; cnt = c->f.n_between * kBetweenRec; break;
+    case GTG_FAC_PRIOR: src = c->f.prior_J.p; cnt = c->f.n_prior * kPriorRec; break;
+    default: throw std::invalid_argument("unknown factor type");
+  }
+  if (n != cnt) throw std::invalid_argument("gtg_get_jacobians: wrong output size");
+  if (cnt) check_hip(hipMemcpy(out, src, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H");
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_get_reduced_matrix(gtg_handle c, double* S, int64_t n_elems) {
+  GTG_TRY
+  if (!c || !c->uploaded || n_elems != c->n_red * c->n_red) throw std::invalid_argument("gtg_get_reduced_matrix: wrong size");
+  const int64_t n = c->n_red;
+  check_hip(hipMemcpy2D(S, sizeof(double) * n, c->S.p, sizeof(double) * c->NP, sizeof(double) * n, n, hipMemcpyDeviceToHost), "D2H 2D");
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_set_allreduce(gtg_handle c, gtg_allreduce_fn fn, void* user) {
+  if (!c) return GTG_ERR_USAGE;
+  c->allreduce = fn; c->allreduce_user = user;
+  return GTG_OK;
+}
+
+int gtg_enable_timing(gtg_handle c, int on) { if (!c) return GTG_ERR_USAGE; c->timing = on != 0; return GTG_OK; }
+int gtg_reset_timing(gtg_handle c) {
+  if (!c) return GTG_ERR_USAGE;
+  for (int i = 0; i < GTG_PH_COUNT; i++) { c->phase_ms[i] = 0; c->phase_calls[i] = 0; }
+  return GTG_OK;
+}
+int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
+  if (!c || n < GTG_PH_COUNT) return GTG_ERR_USAGE;
+  for (int i = 0; i < GTG_PH_COUNT; i++) { ms[i] = c->phase_ms[i]; if (calls) calls[i] = c->phase_calls[i]; }
+  return GTG_OK;
+}
+double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
+double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
+
+int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
+  GTG_TRY
+  if (!c || !A || n < 1) throw std::invalid_argument("gtg_dense_cholesky_host: bad arguments");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  const int NP = (n + kTile - 1) / kTile * kTile;
+  DevBuf<double> S, Dinv, x, fail;
+  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(1);
+  check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");
+  check_hip(hipMemsetAsync(fail.p, 0, sizeof(double), c->stream), "memset");
+  check_hip(hipMemcpy2DAsync(S.p, sizeof(double) * NP, A, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream), "H2D 2D");
+  std::vector<double> ones(NP - n, 1.0);
+  if (NP > n) check_hip(hipMemcpy2DAsync(S.p + (size_t)n * NP + n, sizeof(double) * (NP + 1), ones.data(), sizeof(double), sizeof(double), NP - n, hipMemcpyHostToDevice, c->stream), "pad");
+  if (rhs) check_hip(hipMemcpyAsync(S.p + (size_t)NP * NP, rhs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "rhs");
+  DevBuf<double> saved = c->Dinv;  // backward solve reads c->Dinv
+  c->Dinv = Dinv;
+  launch_cholesky(*c, S.p, NP, kTile, Dinv.p, fail.p);
+  if (rhs) launch_backward_solve(*c, S.p, NP, x.p);
+  c->Dinv = saved;
+  double hf = 0;
+  check_hip(hipMemcpyAsync(&hf, fail.p, sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
+  check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
+  if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  S.free(); Dinv.free(); x.free(); fail.free();
+  return hf != 0.0 ? GTG_INDETERMINATE : GTG_OK;
+  GTG_CATCH
+}
+
+}  // extern "C"

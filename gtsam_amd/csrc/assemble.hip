@@ -1,0 +1,387 @@
+// assemble.hip -- J^T J / J^T b block accumulation, landmark elimination (Schur complement) and
+// back-substitution.
+//
+// What the reference does per lambda try inside eliminateMultifrontal with the Schur ordering
+// (SURVEY.md section 8(a) rows S1-S4, H1, H2):
+//   HessianFactor(factors, scatter) + updateHessian      linear/HessianFactor.cpp:239-252, JacobianFactor.cpp:563-598
+//   choleskyPartial on every landmark clique (3 frontals) linear/HessianFactor.cpp:459-487, base/cholesky.cpp:107-158
+//   separator HessianFactors summed into the camera cliques (= the Schur complement)
+//   GaussianBayesTree::optimize back-substitution        linear/linearAlgorithms-inst.h:49-155
+// is split here into a lambda-INVARIANT part done once per linearization (diagonal blocks, gradients,
+// off-diagonal pose-pose blocks, Hessian diagonal) and a per-lambda part (damping, 3x3 landmark
+// Cholesky, E = W L^-T, S = H_cc + lambda D - sum E E^T).  All sums run in a host-fixed order: no
+// floating-point atomics, results are bit-reproducible run to run.
+#include "factors.h"
+#include "kernels.h"
+
+namespace gt {
+
+constexpr int kBlock = 256;
+enum { INC_SFM = 0, INC_PROJ = 1, INC_BTW_A = 2, INC_BTW_B = 3, INC_PRIOR = 4 };
+
+struct JTabs {
+  const double *sfm_J, *proj_J, *bt_J, *pr_J;
+  int64_t n_sfm;
+};
+
+// (A, rows, row stride, b) of one contribution to a reduced variable
+__device__ __forceinline__ void contribution(const JTabs& t, int kind, int idx, int d, const double*& A,
+                                             int& rows, const double*& b) {
+  if (kind == INC_SFM) { const double* J = t.sfm_J + (int64_t)kSfmRec * idx; A = J; rows = 2; b = J + 24; }
+  else if (kind == INC_PROJ) { const double* J = t.proj_J + (int64_t)kProjRec * idx; A = J; rows = 2; b = J + 18; }
+  else if (kind == INC_BTW_A) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J; rows = 6; b = J + 72; }
+  else if (kind == INC_BTW_B) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J + 36; rows = 6; b = J + 72; }
+  else { const double* J = t.pr_J + (int64_t)kPriorRec * idx; A = J; rows = d; b = J + 81; }
+}
+
+// observation o -> (Jc 2 x dc, Jp 2x3, b 2)
+__device__ __forceinline__ void obs_rec(const JTabs& t, int64_t o, const double*& Jc, const double*& Jp,
+                                        const double*& b, int& dc) {
+  if (o < t.n_sfm) { const double* J = t.sfm_J + (int64_t)kSfmRec * o; Jc = J; Jp = J + 18; b = J + 24; dc = 9; }
+  else { const double* J = t.proj_J + (int64_t)kProjRec * (o - t.n_sfm); Jc = J; Jp = J + 12; b = J + 18; dc = 6; }
+}
+
+// ---- lambda-invariant assembly --------------------------------------------------------------------
+// One workgroup per reduced variable; lanes own output entries (d*d Hessian entries, then d gradient
+// entries), the 4 waves split the contribution list and are combined through LDS in wave order.
+__global__ __launch_bounds__(kBlock) void k_red_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
+    const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
+    const int64_t* __restrict__ red_off, JTabs t, double* __restrict__ Hd, double* __restrict__ g,
+    double* __restrict__ hdiag) {
+  __shared__ double part[4][96];
+  const int r = blockIdx.x;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nent = d * d + d;
+  double acc0 = 0.0, acc1 = 0.0;  // entries lane and lane+64
+  const int e0 = lane, e1 = lane + 64;
+  const int64_t beg = inc_ptr[r], end = inc_ptr[r + 1];
+  for (int64_t k = beg + wave; k < end; k += 4) {
+    const double* A; const double* b; int rows;
+    contribution(t, inc_kind[k], inc_idx[k], d, A, rows, b);
+    if (e0 < nent) {
+      if (e0 < d * d) { const int i = e0 / d, j = e0 % d; for (int q = 0; q < rows; q++) acc0 += A[q * d + i] * A[q * d + j]; }
+      else { const int i = e0 - d * d; for (int q = 0; q < rows; q++) acc0 += A[q * d + i] * b[q]; }
+    }
+    if (e1 < nent) {
+      if (e1 < d * d) { const int i = e1 / d, j = e1 % d; for (int q = 0; q < rows; q++) acc1 += A[q * d + i] * A[q * d + j]; }
+      else { const int i = e1 - d * d; for (int q = 0; q < rows; q++) acc1 += A[q * d + i] * b[q]; }
+    }
+  }
+  if (e0 < 96) part[wave][e0] = acc0;
+  if (e1 < 96) part[wave][e1] = acc1;
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < nent) {
+    const double s = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    if (e < d * d) {
+      Hd[(int64_t)81 * r + e] = s;
+      if (e / d == e % d) hdiag[red_off[r] + e / d] = s;
+    } else {
+      g[(int64_t)9 * r + (e - d * d)] = s;
+    }
+  }
+}
+
+// One lane per landmark: V = sum Jp^T Jp (+ priors), gp = sum Jp^T b.
+__global__ __launch_bounds__(kBlock) void k_lm_diag(int32_t n_lm, const int64_t* __restrict__ obs_ptr,
+    const int32_t* __restrict__ obs, const int64_t* __restrict__ pri_ptr, const int32_t* __restrict__ pri,
+    JTabs t, double* __restrict__ V, double* __restrict__ gp) {
+  for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int64_t k = obs_ptr[l]; k < obs_ptr[l + 1]; k++) {
+      const double *Jc, *Jp, *b; int dc;
+      obs_rec(t, obs[k], Jc, Jp, b, dc);
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) v[3 * i + j] += Jp[i] * Jp[j] + Jp[3 + i] * Jp[3 + j];
+        g[i] += Jp[i] * b[0] + Jp[3 + i] * b[1];
+      }
+    }
+    for (int64_t k = pri_ptr[l]; k < pri_ptr[l + 1]; k++) {
+      const double* J = t.pr_J + (int64_t)kPriorRec * pri[k];
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) for (int q = 0; q < 3; q++) v[3 * i + j] += J[3 * q + i] * J[3 * q + j];
+        for (int q = 0; q < 3; q++) g[i] += J[3 * q + i] * J[81 + q];
+      }
+    }
+    for (int i = 0; i < 9; i++) V[9 * l + i] = v[i];
+    for (int i = 0; i < 3; i++) gp[3 * l + i] = g[i];
+  }
+}
+
+// One wavefront per off-diagonal pose-pose block (6x6): sum over the BetweenFactors joining the pair.
+__global__ __launch_bounds__(64) void k_hoff(int64_t n_blocks, const int64_t* __restrict__ ptr,
+    const int32_t* __restrict__ fac, const double* __restrict__ bt_J, double* __restrict__ Hoff) {
+  const int64_t blk = blockIdx.x;
+  if (blk >= n_blocks) return;
+  const int e = threadIdx.x;
+  if (e >= 36) return;
+  const int i = e / 6, j = e % 6;
+  double acc = 0.0;
+  for (int64_t k = ptr[blk]; k < ptr[blk + 1]; k++) {
+    const int code = fac[k];
+    const int f = code & 0x3fffffff;
+    const bool swap = (code >> 30) & 1;  // row variable is the factor's key2
+    const double* J = bt_J + (int64_t)kBetweenRec * f;
+    const double* X = swap ? J + 36 : J;
+    const double* Y = swap ? J : J + 36;
+    for (int q = 0; q < 6; q++) acc += X[6 * q + i] * Y[6 * q + j];
+  }
+  Hoff[(int64_t)81 * blk + e] = acc;
+}
+
+// ---- per lambda -------------------------------------------------------------------------------------
+// what the damping prior adds to a diagonal entry: JacobianFactor(key, A, 0, Isotropic::Sigma(dim,
+// 1/sqrt(lambda))) with A = I or diag(sqrt(clamp(H_jj))) (internal/LevenbergMarquardtState.h:125-156,
+// LM.cpp:293-299): whitened A' = A * invsigma, contribution A'^2.
+__device__ __forceinline__ double damp_term(double hjj, double invsigma, int diag, double dmin, double dmax) {
+  double a = 1.0;
+  if (diag) a = sqrt(fmin(fmax(hjj, dmin), dmax));
+  const double w = a * invsigma;
+  return w * w;
+}
+
+// One lane per landmark: damped 3x3 Cholesky (Eigen LLT semantics + the exponent test of
+// base/cholesky.cpp:144-157), L^-1 and y = L^-1 gp.
+__global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int32_t* __restrict__ owned,
+    const double* __restrict__ V, const double* __restrict__ gp, double invsigma, int diag, double dmin,
+    double dmax, double* __restrict__ Linv, double* __restrict__ y, double* __restrict__ fail) {
+  for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
+    if (!owned[l]) continue;
+    const double* v = V + 9 * l;
+    const double a00 = v[0] + damp_term(v[0], invsigma, diag, dmin, dmax);
+    const double a11 = v[4] + damp_term(v[4], invsigma, diag, dmin, dmax);
+    const double a22 = v[8] + damp_term(v[8], invsigma, diag, dmin, dmax);
+    const double a10 = v[3], a20 = v[6], a21 = v[7];
+    bool bad = !(a00 > 0.0);
+    const double l00 = sqrt(a00);
+    const double l10 = a10 / l00, l20 = a20 / l00;
+    const double x11 = a11 - l10 * l10;
+    bad = bad || !(x11 > 0.0);
+    const double l11 = sqrt(x11);
+    const double l21 = (a21 - l20 * l10) / l11;
+    const double x22 = a22 - l20 * l20 - l21 * l21;
+    bad = bad || !(x22 > 0.0);
+    const double l22 = sqrt(x22);
+    int ex2, ex1;
+    (void)frexp(l11, &ex2);
+    (void)frexp(l22, &ex1);
+    bad = bad || !(ex2 - ex1 < 12);
+    if (bad) *fail = 1.0;
+    // inverse of the lower-triangular factor
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    double* Li = Linv + 9 * l;
+    Li[0] = i00; Li[1] = 0; Li[2] = 0; Li[3] = i10; Li[4] = i11; Li[5] = 0; Li[6] = i20; Li[7] = i21; Li[8] = i22;
+    const double* g = gp + 3 * l;
+    // forward substitution for y (same operation order as a triangular solve, not Linv*g)
+    const double y0 = g[0] / l00;
+    const double y1 = (g[1] - l10 * y0) / l11;
+    const double y2 = (g[2] - l20 * y0 - l21 * y1) / l22;
+    y[3 * l] = y0; y[3 * l + 1] = y1; y[3 * l + 2] = y2;
+  }
+}
+
+// One lane per observation: E = Jc^T (Jp L^-T)   (dc x 3, the clique's S block transposed)
+__global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n_obs, const int32_t* __restrict__ obs_lm, JTabs t,
+    const double* __restrict__ Linv, double* __restrict__ E) {
+  for (int64_t o = blockIdx.x * (int64_t)kBlock + threadIdx.x; o < n_obs; o += (int64_t)gridDim.x * kBlock) {
+    const double *Jc, *Jp, *b; int dc;
+    obs_rec(t, o, Jc, Jp, b, dc);
+    const double* Li = Linv + 9 * (int64_t)obs_lm[o];
+    double T[6];
+    for (int r = 0; r < 2; r++)
+      for (int m = 0; m < 3; m++) {
+        double acc = 0.0;
+        for (int k = 0; k <= m; k++) acc += Jp[3 * r + k] * Li[3 * m + k];
+        T[3 * r + m] = acc;
+      }
+    double* Eo = E + 27 * o;
+    for (int i = 0; i < dc; i++)
+      for (int m = 0; m < 3; m++) Eo[3 * i + m] = Jc[i] * T[m] + Jc[dc + i] * T[3 + m];
+  }
+}
+
+// One wavefront per reduced variable: damped diagonal block into S, rhs entries g - sum E y into the
+// extra row NP of S.
+__global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
+    const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
+    const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
+    const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
+    const double* __restrict__ E, const double* __restrict__ ylm, double invsigma, int diag, double dmin,
+    double dmax, int add_damping, double* __restrict__ S, int NP) {
+  const int r = blockIdx.x;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  const int64_t off = red_off[r];
+  const int lane = threadIdx.x;
+  for (int e = lane; e < d * d; e += 64) {
+    const int i = e / d, j = e % d;
+    double v = Hd[(int64_t)81 * r + e];
+    if (i == j && add_damping) v += damp_term(hdiag[off + i], invsigma, diag, dmin, dmax);
+    S[(off + i) * (int64_t)NP + off + j] = v;
+  }
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t k = inc_ptr[r] + lane; k < inc_ptr[r + 1]; k += 64) {
+    const int kind = inc_kind[k];
+    if (kind > INC_PROJ) continue;
+    const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
+    const double* Eo = E + 27 * o;
+    const double* y = ylm + 3 * (int64_t)obs_lm[o];
+    for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * y[0] + Eo[3 * i + 1] * y[1] + Eo[3 * i + 2] * y[2];
+  }
+  for (int i = 0; i < 9; i++)
+    for (int s = 32; s > 0; s >>= 1) acc[i] += __shfl_down(acc[i], s, 64);
+  if (lane == 0)
+    for (int i = 0; i < d; i++) S[(int64_t)NP * NP + off + i] = g[(int64_t)9 * r + i] - acc[i];
+}
+
+__global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int32_t* __restrict__ row,
+    const int32_t* __restrict__ col, const int64_t* __restrict__ red_off, const double* __restrict__ Hoff,
+    double* __restrict__ S, int NP) {
+  const int64_t blk = blockIdx.x;
+  if (blk >= n_blocks || threadIdx.x >= 36) return;
+  const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+  S[(red_off[row[blk]] + i) * (int64_t)NP + red_off[col[blk]] + j] = Hoff[(int64_t)81 * blk + threadIdx.x];
+}
+
+// One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the
+// landmarks seen by both.  Lanes own output entries; every term is a wave-uniform 2 x 216 B read.
+__global__ __launch_bounds__(64) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
+    const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
+    const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+    const double* __restrict__ E, double* __restrict__ S, int NP) {
+  const int64_t p = blockIdx.x;
+  if (p >= n_pairs) return;
+  const int ra = prow[p], rb = pcol[p];
+  const int da = red_dim[ra], db = red_dim[rb];
+  const int lane = threadIdx.x;
+  const int e0 = lane, e1 = lane + 64, ne = da * db;
+  const int i0 = e0 / db, j0 = e0 % db, i1 = e1 / db, j1 = e1 % db;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int64_t k = pptr[p]; k < pptr[p + 1]; k++) {
+    const double* Ea = E + 27 * (int64_t)oa[k];
+    const double* Eb = E + 27 * (int64_t)ob[k];
+    if (e0 < ne) acc0 += Ea[3 * i0] * Eb[3 * j0] + Ea[3 * i0 + 1] * Eb[3 * j0 + 1] + Ea[3 * i0 + 2] * Eb[3 * j0 + 2];
+    if (e1 < ne) acc1 += Ea[3 * i1] * Eb[3 * j1] + Ea[3 * i1 + 1] * Eb[3 * j1 + 1] + Ea[3 * i1 + 2] * Eb[3 * j1 + 2];
+  }
+  const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
+  if (e0 < ne) S[(oa_ + i0) * (int64_t)NP + ob_ + j0] -= acc0;
+  if (e1 < ne) S[(oa_ + i1) * (int64_t)NP + ob_ + j1] -= acc1;
+}
+
+// identity on the padded diagonal NP > n
+__global__ void k_pad_diag(double* __restrict__ S, int64_t n, int NP) {
+  const int64_t i = n + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < NP) S[i * NP + i] = 1.0;
+}
+
+// ---- back-substitution ---------------------------------------------------------------------------------
+// One lane per landmark: delta_p = L^-T (y - sum_obs E^T x_cam)   (x_F = R^-1 (d - S x_S))
+__global__ __launch_bounds__(kBlock) void k_backsub_lm(int32_t n_lm, const int32_t* __restrict__ owned,
+    const int64_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs, const int32_t* __restrict__ obs_red,
+    const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off, const double* __restrict__ E,
+    const double* __restrict__ Linv, const double* __restrict__ ylm, const double* __restrict__ x,
+    double* __restrict__ dlm) {
+  for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
+    if (!owned[l]) { dlm[3 * l] = 0; dlm[3 * l + 1] = 0; dlm[3 * l + 2] = 0; continue; }
+    double a0 = ylm[3 * l], a1 = ylm[3 * l + 1], a2 = ylm[3 * l + 2];
+    for (int64_t k = obs_ptr[l]; k < obs_ptr[l + 1]; k++) {
+      const int64_t o = obs[k];
+      const int r = obs_red[o];
+      const int d = red_dim[r];
+      const double* xr = x + red_off[r];
+      const double* Eo = E + 27 * o;
+      for (int i = 0; i < d; i++) { a0 -= Eo[3 * i] * xr[i]; a1 -= Eo[3 * i + 1] * xr[i]; a2 -= Eo[3 * i + 2] * xr[i]; }
+    }
+    const double* Li = Linv + 9 * l;
+    dlm[3 * l] = Li[0] * a0 + Li[3] * a1 + Li[6] * a2;
+    dlm[3 * l + 1] = Li[4] * a1 + Li[7] * a2;
+    dlm[3 * l + 2] = Li[8] * a2;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_delta(int32_t n_vars, const int32_t* __restrict__ lm_index,
+    const int32_t* __restrict__ red_index, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+    const int64_t* __restrict__ dim_off, const double* __restrict__ x, const double* __restrict__ dlm,
+    double* __restrict__ delta) {
+  for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < n_vars; v += (int64_t)gridDim.x * kBlock) {
+    double* d = delta + dim_off[v];
+    const int l = lm_index[v];
+    if (l >= 0) { d[0] = dlm[3 * l]; d[1] = dlm[3 * l + 1]; d[2] = dlm[3 * l + 2]; }
+    else { const int r = red_index[v]; const double* xr = x + red_off[r]; for (int i = 0; i < red_dim[r]; i++) d[i] = xr[i]; }
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+static inline int grid1(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+static JTabs jtabs(gtg_context& c) { return JTabs{c.f.sfm_J.p, c.f.proj_J.p, c.f.between_J.p, c.f.prior_J.p, c.f.n_sfm}; }
+
+void launch_assemble(gtg_context& c) {
+  JTabs t = jtabs(c);
+  if (c.n_red_vars)
+    hipLaunchKernelGGL(k_red_diag, dim3(c.n_red_vars), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
+                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, t, c.Hd.p, c.gred0.p, c.hdiag_red.p);
+  if (c.n_lm)
+    hipLaunchKernelGGL(k_lm_diag, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_obs_ptr.p, c.lm_obs.p,
+                       c.lm_pri_ptr.p, c.lm_pri.p, t, c.V.p, c.gp.p);
+  if (c.n_hoff)
+    hipLaunchKernelGGL(k_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_ptr.p, c.hoff_fac.p,
+                       c.f.between_J.p, c.Hoff.p);
+  check_hip(hipGetLastError(), "assemble");
+}
+
+static inline double inv_sigma(double lambda) {
+  // CachedModel(dim, 1.0 / std::sqrt(lambda)) -> Isotropic: invsigma_ = 1.0 / sigma (LMState.h:117-121)
+  const double sigma = 1.0 / std::sqrt(lambda);
+  return 1.0 / sigma;
+}
+
+void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin, double dmax) {
+  if (!c.n_lm) return;
+  const double is = inv_sigma(lambda);
+  hipLaunchKernelGGL(k_point_factor, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.V.p,
+                     c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL);
+  if (c.n_obs)
+    hipLaunchKernelGGL(k_obs_E, dim3(grid1(c.n_obs)), dim3(kBlock), 0, c.stream, c.n_obs, c.obs_lm.p, jtabs(c),
+                       c.Linv.p, c.E.p);
+  check_hip(hipGetLastError(), "point_eliminate");
+}
+
+void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax) {
+  const double is = inv_sigma(lambda);
+  const int NP = c.NP;
+  check_hip(hipMemsetAsync(c.S.p, 0, sizeof(double) * (size_t)(NP + kTile) * NP, c.stream), "memset S");
+  if (c.n_red_vars)
+    hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
+                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
+                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
+  if (c.n_hoff)
+    hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
+                       c.hoff_col.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
+  if (c.n_pairs)
+    hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)c.n_pairs), dim3(64), 0, c.stream, c.n_pairs, c.pair_row.p,
+                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
+  if (NP > c.n_red && c.shard == 0)
+    hipLaunchKernelGGL(k_pad_diag, dim3((NP - c.n_red + 63) / 64), dim3(64), 0, c.stream, c.S.p, c.n_red, NP);
+  check_hip(hipGetLastError(), "build_reduced");
+}
+
+void launch_back_substitute(gtg_context& c) {
+  if (c.n_lm)
+    hipLaunchKernelGGL(k_backsub_lm, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p,
+                       c.lm_obs_ptr.p, c.lm_obs.p, c.obs_red.p, c.red_dim.p, c.red_off.p, c.E.p, c.Linv.p, c.ylm.p,
+                       c.xred.p, c.delta_lm.p);
+  check_hip(hipGetLastError(), "back_substitute");
+}
+
+void launch_scatter_delta(gtg_context& c) {
+  hipLaunchKernelGGL(k_scatter_delta, dim3(grid1(c.n_vars)), dim3(kBlock), 0, c.stream, c.n_vars, c.lm_index.p,
+                     c.red_index.p, c.red_dim.p, c.red_off.p, c.dim_off.p, c.xred.p, c.delta_lm.p, c.delta.p);
+  check_hip(hipGetLastError(), "scatter_delta");
+}
+
+}  // namespace gt

@@ -1,0 +1,129 @@
+// context.h -- device-resident state of one LM problem (one handle = one GPU = one shard).
+//
+// HBM layout (all FP64 unless noted; see DESIGN.md "Data layout"):
+//   values / trial          packed gtsam::Values, variable-id order (12 | 17 | 3 doubles per variable)
+//   *_J                     per-factor whitened records [A1 | A2 | b], AoS, written once per linearize
+//   Hd, gred0               reduced variables: d x d diagonal blocks (stride 81) and gradient (stride 9)
+//   V, gp                   landmarks: 3x3 blocks (stride 9) and gradient (stride 3)
+//   Hoff                    off-diagonal reduced blocks from BetweenFactors (stride 81)
+//   E                       per landmark-observation  E = Jc^T Jp L^-T  (stride 27), rebuilt per lambda
+//   S                       dense reduced system, row-major lower triangle, ld = NP (multiple of 128),
+//                           plus one extra 128-row tile whose first row carries the rhs (g^T -> y^T)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gtsam_amd.h"
+
+namespace gt {
+
+constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Cholesky
+
+// scalar slots reduced on the device (doubles)
+enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_COUNT = 8 };
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count);
+  void upload(const T* host, size_t count, hipStream_t s);
+  void free();
+};
+
+struct FactorTables {
+  // SFM
+  int64_t n_sfm = 0;
+  DevBuf<int32_t> sfm_cam, sfm_point, sfm_noise;
+  DevBuf<double> sfm_z, sfm_J;
+  // projection
+  int64_t n_proj = 0;
+  DevBuf<int32_t> proj_pose, proj_point, proj_noise, proj_calib, proj_sensor;
+  DevBuf<double> proj_z, proj_J, calib, sensor;
+  // between
+  int64_t n_between = 0;
+  DevBuf<int32_t> between_v1, between_v2, between_noise;
+  DevBuf<double> between_z, between_J;
+  // prior
+  int64_t n_prior = 0;
+  DevBuf<int32_t> prior_var, prior_noise;
+  DevBuf<int64_t> prior_off;
+  DevBuf<double> prior_data, prior_J;
+};
+
+}  // namespace gt
+
+struct gtg_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int shard = 0, n_shards = 1;
+  bool uploaded = false, linearized = false, have_trial = false;
+
+  // ---- variables -------------------------------------------------------------------------------
+  int32_t n_vars = 0;
+  std::vector<int32_t> h_var_type;
+  std::vector<int64_t> h_val_off, h_dim_off;   // size n_vars+1
+  int64_t val_size = 0, dim_size = 0;
+  gt::DevBuf<int32_t> var_type;
+  gt::DevBuf<int64_t> val_off, dim_off;
+  gt::DevBuf<double> values, trial, delta;
+
+  // classification: landmark (POINT3 eliminated first) or reduced variable
+  int32_t n_lm = 0, n_red_vars = 0;
+  int64_t n_red = 0;                            // scalar dimension of the reduced system
+  int32_t NP = 0;                               // n_red rounded up to kTile
+  std::vector<int32_t> h_lm_index, h_red_index; // per variable: index among landmarks / reduced (or -1)
+  std::vector<int32_t> h_lm_var, h_red_var;     // inverse maps
+  std::vector<int32_t> h_red_pos;               // reduced index -> position in the ordering
+  std::vector<int64_t> h_red_off;               // per reduced index: scalar offset in S
+  std::vector<int32_t> h_red_dim;
+  gt::DevBuf<int32_t> lm_var, red_var, red_dim, lm_index, red_index, lm_owned;
+  gt::DevBuf<int64_t> red_off;
+
+  // ---- noise table (inverse sigmas precomputed like the reference constructors) ------------------
+  gt::DevBuf<int32_t> noise_kind;
+  gt::DevBuf<int64_t> noise_off;
+  gt::DevBuf<double> noise_data;
+
+  gt::FactorTables f;
+
+  // ---- incidence (host-built CSR, device copies) ---------------------------------------------------
+  // observations: obs id o < n_sfm -> sfm factor o; else projection factor o - n_sfm
+  int64_t n_obs = 0;
+  gt::DevBuf<int32_t> obs_red, obs_lm;          // reduced index / landmark index of each observation
+  gt::DevBuf<int64_t> lm_obs_ptr;  gt::DevBuf<int32_t> lm_obs;      // landmark -> observations
+  gt::DevBuf<int64_t> lm_pri_ptr;  gt::DevBuf<int32_t> lm_pri;      // landmark -> prior factors
+  gt::DevBuf<int64_t> red_inc_ptr; gt::DevBuf<int32_t> red_inc_kind, red_inc_idx;  // reduced var -> contributions
+  int64_t n_hoff = 0;                                                // off-diagonal blocks from between factors
+  gt::DevBuf<int32_t> hoff_row, hoff_col;                            // reduced indices (row pos > col pos)
+  gt::DevBuf<int64_t> hoff_ptr;  gt::DevBuf<int32_t> hoff_fac;       // block -> between factors (sign bit = transposed)
+  int64_t n_pairs = 0, n_pair_terms = 0;                             // Schur block pairs
+  gt::DevBuf<int32_t> pair_row, pair_col;
+  gt::DevBuf<int64_t> pair_ptr;  gt::DevBuf<int32_t> pair_oa, pair_ob;
+
+  // ---- numeric buffers ---------------------------------------------------------------------------
+  gt::DevBuf<double> Hd, gred0, hdiag_red;      // reduced diag blocks (81), gradient (9), diagonal (n_red)
+  gt::DevBuf<double> V, gp;                     // landmark blocks (9) and gradient (3)
+  gt::DevBuf<double> Hoff;                      // (81 per block)
+  gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (27/obs), delta (3)
+  gt::DevBuf<double> S;                         // (NP + kTile) x NP
+  gt::DevBuf<double> Dinv;                      // kTile x kTile inverse of the current diagonal block
+  gt::DevBuf<double> xred;                      // NP solution of the reduced system
+  gt::DevBuf<double> partials;                  // block partial sums for reductions
+  gt::DevBuf<double> scalars;                   // SC_COUNT
+  double h_scalars[gt::SC_COUNT] = {0};
+
+  // ---- multi-GPU exchange --------------------------------------------------------------------------
+  gtg_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+
+  // ---- timing ----------------------------------------------------------------------------------------
+  bool timing = false;
+  double phase_ms[GTG_PH_COUNT] = {0};
+  int64_t phase_calls[GTG_PH_COUNT] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double chol_flops = 0, lin_bytes = 0;
+};

@@ -1,0 +1,152 @@
+// factors.h -- one-factor evaluators: whitened Jacobian blocks + rhs, and the factor's error.
+//
+// Each function is what ONE lane executes for ONE factor.  They restate, for the GPU,
+//   GeneralSFMFactor::linearize / evaluateError      slam/GeneralSFMFactor.h:127-177
+//   GenericProjectionFactor::evaluateError           slam/ProjectionFactor.h:138-166
+//   BetweenFactor<Pose3>::evaluateError              slam/BetweenFactor.h:111-124
+//   PriorFactor<T>::evaluateError                    nonlinear/PriorFactor.h:98-102
+// followed by NoiseModelFactor::linearize's  b = -r, WhitenSystem(A, b)
+// (nonlinear/NonlinearFactor.cpp:150-182) and NoiseModelFactor::error = 0.5*||whiten(r)||^2
+// (NonlinearFactor.cpp:136-147).
+#pragma once
+#include "geom.h"
+
+namespace gt {
+
+// row lengths of the per-factor Jacobian records (doubles)
+constexpr int kSfmRec = 2 * 9 + 2 * 3 + 2;   // [A1 2x9 | A2 2x3 | b 2]
+constexpr int kProjRec = 2 * 6 + 2 * 3 + 2;  // [A1 2x6 | A2 2x3 | b 2]
+constexpr int kBetweenRec = 36 + 36 + 6;     // [A1 6x6 | A2 6x6 | b 6]
+constexpr int kPriorRec = 81 + 9;            // [A dxd packed | pad ... | b d at 81]
+
+// ---- GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3> ---------------------------------------
+GT_HD void sfm_linearize(const double* cam, const double* pt, const double* z, int nkind,
+                         const double* nd, double* J) {
+  double pi[2];
+  if (!sfm_project(cam, pt, pi, J, J + 18)) {  // CheiralityException: H1,H2,b = 0 (:153-158)
+    for (int i = 0; i < kSfmRec; i++) J[i] = 0.0;
+    return;
+  }
+  J[24] = z[0] - pi[0];
+  J[25] = z[1] - pi[1];
+  whiten_cols<2>(nkind, nd, J, 9);
+  whiten_cols<2>(nkind, nd, J + 18, 3);
+  whiten_cols<2>(nkind, nd, J + 24, 1);
+}
+GT_HD double sfm_error(const double* cam, const double* pt, const double* z, int nkind, const double* nd) {
+  double pi[2];
+  if (!sfm_project(cam, pt, pi, nullptr, nullptr)) return 0.0;  // evaluateError returns Z_2x1 (:131-137)
+  double r[2] = {pi[0] - z[0], pi[1] - z[1]};
+  whiten_cols<2>(nkind, nd, r, 1);
+  return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+}
+
+// ---- GenericProjectionFactor<Pose3,Point3,Cal3_S2> ---------------------------------------------
+GT_HD void proj_linearize(const double* pose, const double* K, const double* sensor, const double* pt,
+                          const double* z, int nkind, const double* nd, double* J) {
+  double pi[2];
+  bool ok;
+  if (sensor) {  // pose.compose(body_P_sensor, H0); H1 = H1 * H0, H0 = sensor^-1 AdjointMap (Lie.h:56-61)
+    double T[12], Dp[12], Si[12], H0[36];
+    pose_compose(pose, sensor, T);
+    ok = s2_project(T, K, pt, pi, Dp, J + 12);
+    if (ok) {
+      pose_inverse(sensor, Si);
+      pose_adjoint(Si, H0);
+      for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 6; c++) {
+          double acc = 0.0;
+          for (int k = 0; k < 6; k++) acc += Dp[6 * r + k] * H0[6 * k + c];
+          J[6 * r + c] = acc;
+        }
+    }
+  } else {
+    ok = s2_project(pose, K, pt, pi, J, J + 12);
+  }
+  if (!ok) {  // H = 0 and residual 2*fx (ProjectionFactor.h:157-165, throwCheirality_ = false)
+    for (int i = 0; i < 18; i++) J[i] = 0.0;
+    J[18] = -2.0 * K[0]; J[19] = -2.0 * K[0];
+  } else {
+    J[18] = -(pi[0] - z[0]); J[19] = -(pi[1] - z[1]);
+  }
+  whiten_cols<2>(nkind, nd, J, 6);
+  whiten_cols<2>(nkind, nd, J + 12, 3);
+  whiten_cols<2>(nkind, nd, J + 18, 1);
+}
+GT_HD double proj_error(const double* pose, const double* K, const double* sensor, const double* pt,
+                        const double* z, int nkind, const double* nd) {
+  double pi[2], r[2];
+  bool ok;
+  if (sensor) {
+    double T[12];
+    pose_compose(pose, sensor, T);
+    ok = s2_project(T, K, pt, pi, nullptr, nullptr);
+  } else {
+    ok = s2_project(pose, K, pt, pi, nullptr, nullptr);
+  }
+  if (ok) { r[0] = pi[0] - z[0]; r[1] = pi[1] - z[1]; }
+  else { r[0] = 2.0 * K[0]; r[1] = 2.0 * K[0]; }
+  whiten_cols<2>(nkind, nd, r, 1);
+  return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+}
+
+// ---- BetweenFactor<Pose3> ---------------------------------------------------------------------
+// h = T1^-1 T2 ; H1 = -Ad(h^-1), H2 = I (Lie.h:63-69) ; r = Logmap(z^-1 h), Jacobians NOT
+// multiplied by dLog (GTSAM_SLOW_BUT_CORRECT_BETWEENFACTOR is OFF by default, BetweenFactor.h:115-123)
+GT_HD void between_residual(const double* T1, const double* T2, const double* Z, double* h, double* r) {
+  pose_between(T1, T2, h);
+  pose_local(Z, h, r);
+}
+GT_HD void between_linearize(const double* T1, const double* T2, const double* Z, int nkind,
+                             const double* nd, double* J) {
+  double h[12], hi[12], r[6];
+  between_residual(T1, T2, Z, h, r);
+  pose_inverse(h, hi);
+  pose_adjoint(hi, J);
+  for (int i = 0; i < 36; i++) J[i] = -J[i];
+  for (int i = 0; i < 36; i++) J[36 + i] = 0.0;
+  for (int i = 0; i < 6; i++) J[36 + 7 * i] = 1.0;
+  for (int i = 0; i < 6; i++) J[72 + i] = -r[i];
+  whiten_cols<6>(nkind, nd, J, 6);
+  whiten_cols<6>(nkind, nd, J + 36, 6);
+  whiten_cols<6>(nkind, nd, J + 72, 1);
+}
+GT_HD double between_error(const double* T1, const double* T2, const double* Z, int nkind, const double* nd) {
+  double h[12], r[6];
+  between_residual(T1, T2, Z, h, r);
+  whiten_cols<6>(nkind, nd, r, 1);
+  double e = 0.0;
+  for (int i = 0; i < 6; i++) e += r[i] * r[i];
+  return 0.5 * e;
+}
+
+// ---- PriorFactor<T> ---------------------------------------------------------------------------
+// r = -Local(x, prior), H = I (approximate on purpose, PriorFactor.h:99).  d = tangent dim.
+template <int D>
+GT_HD void prior_linearize_d(int vtype, const double* x, const double* z, int nkind, const double* nd, double* J) {
+  double loc[9];
+  value_local(vtype, x, z, loc);
+  for (int i = 0; i < kPriorRec; i++) J[i] = 0.0;
+  for (int i = 0; i < D; i++) J[i * D + i] = 1.0;
+  for (int i = 0; i < D; i++) J[81 + i] = loc[i];  // b = -r = Local(x, prior)
+  whiten_cols<D>(nkind, nd, J, D);
+  whiten_cols<D>(nkind, nd, J + 81, 1);
+}
+GT_HD void prior_linearize(int vtype, const double* x, const double* z, int nkind, const double* nd, double* J) {
+  if (vtype == 0) prior_linearize_d<6>(vtype, x, z, nkind, nd, J);
+  else if (vtype == 1) prior_linearize_d<9>(vtype, x, z, nkind, nd, J);
+  else prior_linearize_d<3>(vtype, x, z, nkind, nd, J);
+}
+GT_HD double prior_error(int vtype, const double* x, const double* z, int nkind, const double* nd) {
+  double r[9];
+  value_local(vtype, x, z, r);
+  const int d = vtype == 0 ? 6 : vtype == 1 ? 9 : 3;
+  if (d == 6) whiten_cols<6>(nkind, nd, r, 1);
+  else if (d == 9) whiten_cols<9>(nkind, nd, r, 1);
+  else whiten_cols<3>(nkind, nd, r, 1);
+  double e = 0.0;
+  for (int i = 0; i < d; i++) e += r[i] * r[i];
+  return 0.5 * e;
+}
+
+}  // namespace gt

@@ -1,0 +1,321 @@
+// factors.hip -- per-factor kernels: linearize (K1/K2), nonlinear error (K9), linear error, retract (K10).
+//
+// One factor per lane (64 factors per wavefront): the factor->variable index arrays (int32) and the
+// measurements are read coalesced; the variable blocks are gathered from the packed Values, which for
+// the BAL configs is a 234 KB camera table (L2-resident) plus one 24-byte point per factor; each lane
+// writes its whitened record [A1 | A2 | b] contiguously (208 B for an SFM factor).
+// Replaces NonlinearFactorGraph::linearize (nonlinear/NonlinearFactorGraph.cpp:239-278),
+// NonlinearFactorGraph::error (:170-179), GaussianFactorGraph::error (linear/GaussianFactorGraph.cpp:71-78)
+// and Values::retract (nonlinear/Values.cpp:52-63).
+#include "factors.h"
+#include "kernels.h"
+
+namespace gt {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;
+
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// deterministic block reduction (fixed tree) of one double per thread; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double sm[kBlock / 64];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < kBlock / 64; w++) r += sm[w];
+  return r;
+}
+
+struct NoiseTab {
+  const int32_t* kind;
+  const int64_t* off;
+  const double* data;
+};
+
+// ---- linearize ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __restrict__ cam,
+    const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz,
+    const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
+    double* __restrict__ J) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    double c[17], p[3], zz[2], rec[kSfmRec];
+    const double* cp = values + val_off[cam[i]];
+    const double* pp = values + val_off[pt[i]];
+    for (int k = 0; k < 17; k++) c[k] = cp[k];
+    for (int k = 0; k < 3; k++) p[k] = pp[k];
+    zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
+    const int ni = nz[i];
+    sfm_linearize(c, p, zz, nt.kind[ni], nt.data + nt.off[ni], rec);
+    double* out = J + (int64_t)kSfmRec * i;
+    for (int k = 0; k < kSfmRec; k++) out[k] = rec[k];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* __restrict__ pose,
+    const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz,
+    const int32_t* __restrict__ calib_idx, const int32_t* __restrict__ sensor_idx,
+    const double* __restrict__ calib, const double* __restrict__ sensor,
+    const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
+    double* __restrict__ J) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    double T[12], p[3], zz[2], K[5], S[12], rec[kProjRec];
+    const double* tp = values + val_off[pose[i]];
+    const double* pp = values + val_off[pt[i]];
+    for (int k = 0; k < 12; k++) T[k] = tp[k];
+    for (int k = 0; k < 3; k++) p[k] = pp[k];
+    for (int k = 0; k < 5; k++) K[k] = calib[5 * calib_idx[i] + k];
+    const int si = sensor_idx[i];
+    if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
+    zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
+    const int ni = nz[i];
+    proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.kind[ni], nt.data + nt.off[ni], rec);
+    double* out = J + (int64_t)kProjRec * i;
+    for (int k = 0; k < kProjRec; k++) out[k] = rec[k];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lin_between(int64_t n, const int32_t* __restrict__ v1,
+    const int32_t* __restrict__ v2, const double* __restrict__ z, const int32_t* __restrict__ nz,
+    const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
+    double* __restrict__ J) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    double T1[12], T2[12], Z[12];
+    const double* a = values + val_off[v1[i]];
+    const double* b = values + val_off[v2[i]];
+    for (int k = 0; k < 12; k++) { T1[k] = a[k]; T2[k] = b[k]; Z[k] = z[12 * i + k]; }
+    const int ni = nz[i];
+    between_linearize(T1, T2, Z, nt.kind[ni], nt.data + nt.off[ni], J + (int64_t)kBetweenRec * i);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lin_prior(int64_t n, const int32_t* __restrict__ var,
+    const int64_t* __restrict__ poff, const double* __restrict__ pdata, const int32_t* __restrict__ nz,
+    const int32_t* __restrict__ var_type, const double* __restrict__ values,
+    const int64_t* __restrict__ val_off, NoiseTab nt, double* __restrict__ J) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int v = var[i];
+    const int ni = nz[i];
+    prior_linearize(var_type[v], values + val_off[v], pdata + poff[i], nt.kind[ni], nt.data + nt.off[ni],
+                    J + (int64_t)kPriorRec * i);
+  }
+}
+
+// ---- nonlinear error --------------------------------------------------------------------------------
+struct ErrArgs {
+  int64_t n_sfm, n_proj, n_between, n_prior;
+  const int32_t *sfm_cam, *sfm_pt, *sfm_nz; const double* sfm_z;
+  const int32_t *proj_pose, *proj_pt, *proj_nz, *proj_calib, *proj_sensor; const double *proj_z, *calib, *sensor;
+  const int32_t *bt_v1, *bt_v2, *bt_nz; const double* bt_z;
+  const int32_t *pr_var, *pr_nz; const int64_t* pr_off; const double* pr_data;
+  const int32_t* var_type; const int64_t* val_off;
+};
+
+// One launch covers all factor types: block b handles a fixed slice, so the summation order is fixed.
+__global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __restrict__ values, NoiseTab nt,
+                                                  double* __restrict__ partials) {
+  double acc = 0.0;
+  const int64_t tid = blockIdx.x * (int64_t)kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = tid; i < a.n_sfm; i += stride) {
+    double c[17], p[3], zz[2];
+    const double* cp = values + a.val_off[a.sfm_cam[i]];
+    const double* pp = values + a.val_off[a.sfm_pt[i]];
+    for (int k = 0; k < 17; k++) c[k] = cp[k];
+    for (int k = 0; k < 3; k++) p[k] = pp[k];
+    zz[0] = a.sfm_z[2 * i]; zz[1] = a.sfm_z[2 * i + 1];
+    const int ni = a.sfm_nz[i];
+    acc += sfm_error(c, p, zz, nt.kind[ni], nt.data + nt.off[ni]);
+  }
+  for (int64_t i = tid; i < a.n_proj; i += stride) {
+    double T[12], p[3], zz[2], K[5], S[12];
+    const double* tp = values + a.val_off[a.proj_pose[i]];
+    const double* pp = values + a.val_off[a.proj_pt[i]];
+    for (int k = 0; k < 12; k++) T[k] = tp[k];
+    for (int k = 0; k < 3; k++) p[k] = pp[k];
+    for (int k = 0; k < 5; k++) K[k] = a.calib[5 * a.proj_calib[i] + k];
+    const int si = a.proj_sensor[i];
+    if (si >= 0) for (int k = 0; k < 12; k++) S[k] = a.sensor[12 * si + k];
+    zz[0] = a.proj_z[2 * i]; zz[1] = a.proj_z[2 * i + 1];
+    const int ni = a.proj_nz[i];
+    acc += proj_error(T, K, si >= 0 ? S : nullptr, p, zz, nt.kind[ni], nt.data + nt.off[ni]);
+  }
+  for (int64_t i = tid; i < a.n_between; i += stride) {
+    double T1[12], T2[12], Z[12];
+    const double* x = values + a.val_off[a.bt_v1[i]];
+    const double* y = values + a.val_off[a.bt_v2[i]];
+    for (int k = 0; k < 12; k++) { T1[k] = x[k]; T2[k] = y[k]; Z[k] = a.bt_z[12 * i + k]; }
+    const int ni = a.bt_nz[i];
+    acc += between_error(T1, T2, Z, nt.kind[ni], nt.data + nt.off[ni]);
+  }
+  for (int64_t i = tid; i < a.n_prior; i += stride) {
+    const int v = a.pr_var[i];
+    const int ni = a.pr_nz[i];
+    acc += prior_error(a.var_type[v], values + a.val_off[v], a.pr_data + a.pr_off[i], nt.kind[ni],
+                       nt.data + nt.off[ni]);
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// sums `n` partials (n <= kMaxBlocks) in a fixed order into out[slot]; nslots interleaved partial arrays
+__global__ __launch_bounds__(kBlock) void k_final_sum(const double* __restrict__ partials, int n, int nslots,
+                                                      double* __restrict__ out, int slot0) {
+  for (int s = 0; s < nslots; s++) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[(int64_t)s * kMaxBlocks + i];
+    const double r = block_sum(acc);
+    if (threadIdx.x == 0) out[slot0 + s] = r;
+    __syncthreads();
+  }
+}
+
+// ---- linear error: 0.5*||b||^2 and 0.5*||A delta - b||^2 on the undamped system --------------------
+struct LinErrArgs {
+  int64_t n_sfm, n_proj, n_between, n_prior;
+  const int32_t *sfm_cam, *sfm_pt, *proj_pose, *proj_pt, *bt_v1, *bt_v2, *pr_var;
+  const double *sfm_J, *proj_J, *bt_J, *pr_J;
+  const int32_t* var_type; const int64_t* dim_off;
+};
+
+__global__ __launch_bounds__(kBlock) void k_linear_error(LinErrArgs a, const double* __restrict__ delta,
+                                                         double* __restrict__ partials) {
+  double e0 = 0.0, e1 = 0.0;
+  const int64_t tid = blockIdx.x * (int64_t)kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = tid; i < a.n_sfm; i += stride) {
+    const double* J = a.sfm_J + (int64_t)kSfmRec * i;
+    const double* dc = delta + a.dim_off[a.sfm_cam[i]];
+    const double* dp = delta + a.dim_off[a.sfm_pt[i]];
+    for (int r = 0; r < 2; r++) {
+      const double b = J[24 + r];
+      double v = -b;
+      for (int k = 0; k < 9; k++) v += J[9 * r + k] * dc[k];
+      for (int k = 0; k < 3; k++) v += J[18 + 3 * r + k] * dp[k];
+      e0 += b * b; e1 += v * v;
+    }
+  }
+  for (int64_t i = tid; i < a.n_proj; i += stride) {
+    const double* J = a.proj_J + (int64_t)kProjRec * i;
+    const double* dc = delta + a.dim_off[a.proj_pose[i]];
+    const double* dp = delta + a.dim_off[a.proj_pt[i]];
+    for (int r = 0; r < 2; r++) {
+      const double b = J[18 + r];
+      double v = -b;
+      for (int k = 0; k < 6; k++) v += J[6 * r + k] * dc[k];
+      for (int k = 0; k < 3; k++) v += J[12 + 3 * r + k] * dp[k];
+      e0 += b * b; e1 += v * v;
+    }
+  }
+  for (int64_t i = tid; i < a.n_between; i += stride) {
+    const double* J = a.bt_J + (int64_t)kBetweenRec * i;
+    const double* d1 = delta + a.dim_off[a.bt_v1[i]];
+    const double* d2 = delta + a.dim_off[a.bt_v2[i]];
+    for (int r = 0; r < 6; r++) {
+      const double b = J[72 + r];
+      double v = -b;
+      for (int k = 0; k < 6; k++) v += J[6 * r + k] * d1[k] + J[36 + 6 * r + k] * d2[k];
+      e0 += b * b; e1 += v * v;
+    }
+  }
+  for (int64_t i = tid; i < a.n_prior; i += stride) {
+    const double* J = a.pr_J + (int64_t)kPriorRec * i;
+    const int v_ = a.pr_var[i];
+    const int t = a.var_type[v_];
+    const int d = t == 0 ? 6 : t == 1 ? 9 : 3;
+    const double* dv = delta + a.dim_off[v_];
+    for (int r = 0; r < d; r++) {
+      const double b = J[81 + r];
+      double v = -b;
+      for (int k = 0; k < d; k++) v += J[d * r + k] * dv[k];
+      e0 += b * b; e1 += v * v;
+    }
+  }
+  const double s0 = block_sum(0.5 * e0);
+  const double s1 = block_sum(0.5 * e1);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[kMaxBlocks + blockIdx.x] = s1; }
+}
+
+// ---- retract ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_retract(int32_t n_vars, const int32_t* __restrict__ var_type,
+    const int64_t* __restrict__ val_off, const int64_t* __restrict__ dim_off,
+    const double* __restrict__ values, const double* __restrict__ delta, double* __restrict__ trial) {
+  for (int64_t v = blockIdx.x * (int64_t)kBlock + threadIdx.x; v < n_vars; v += (int64_t)gridDim.x * kBlock)
+    value_retract(var_type[v], values + val_off[v], delta + dim_off[v], trial + val_off[v]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sumsq(int64_t n, const double* __restrict__ x, double* __restrict__ partials) {
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) acc += x[i] * x[i];
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// ---- launchers --------------------------------------------------------------------------------------
+static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p}; }
+
+void launch_linearize(gtg_context& c) {
+  auto& f = c.f;
+  NoiseTab nt = noise_tab(c);
+  if (f.n_sfm)
+    hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p,
+                       f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p);
+  if (f.n_proj)
+    hipLaunchKernelGGL(k_lin_proj, dim3(grid_for(f.n_proj)), dim3(kBlock), 0, c.stream, f.n_proj, f.proj_pose.p,
+                       f.proj_point.p, f.proj_z.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.calib.p,
+                       f.sensor.p, c.values.p, c.val_off.p, nt, f.proj_J.p);
+  if (f.n_between)
+    hipLaunchKernelGGL(k_lin_between, dim3(grid_for(f.n_between)), dim3(kBlock), 0, c.stream, f.n_between,
+                       f.between_v1.p, f.between_v2.p, f.between_z.p, f.between_noise.p, c.values.p, c.val_off.p,
+                       nt, f.between_J.p);
+  if (f.n_prior)
+    hipLaunchKernelGGL(k_lin_prior, dim3(grid_for(f.n_prior)), dim3(kBlock), 0, c.stream, f.n_prior, f.prior_var.p,
+                       f.prior_off.p, f.prior_data.p, f.prior_noise.p, c.var_type.p, c.values.p, c.val_off.p, nt,
+                       f.prior_J.p);
+  check_hip(hipGetLastError(), "linearize");
+}
+
+void launch_error(gtg_context& c, const double* values, int slot) {
+  auto& f = c.f;
+  ErrArgs a{f.n_sfm, f.n_proj, f.n_between, f.n_prior,
+            f.sfm_cam.p, f.sfm_point.p, f.sfm_noise.p, f.sfm_z.p,
+            f.proj_pose.p, f.proj_point.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.proj_z.p, f.calib.p, f.sensor.p,
+            f.between_v1.p, f.between_v2.p, f.between_noise.p, f.between_z.p,
+            f.prior_var.p, f.prior_noise.p, f.prior_off.p, f.prior_data.p,
+            c.var_type.p, c.val_off.p};
+  const int64_t nmax = std::max(std::max(f.n_sfm, f.n_proj), std::max(f.n_between, f.n_prior));
+  const int g = grid_for(nmax);
+  hipLaunchKernelGGL(k_error, dim3(g), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 1, c.scalars.p, slot);
+  check_hip(hipGetLastError(), "error");
+}
+
+void launch_linear_error(gtg_context& c) {
+  auto& f = c.f;
+  LinErrArgs a{f.n_sfm, f.n_proj, f.n_between, f.n_prior,
+               f.sfm_cam.p, f.sfm_point.p, f.proj_pose.p, f.proj_point.p, f.between_v1.p, f.between_v2.p, f.prior_var.p,
+               f.sfm_J.p, f.proj_J.p, f.between_J.p, f.prior_J.p, c.var_type.p, c.dim_off.p};
+  const int64_t nmax = std::max(std::max(f.n_sfm, f.n_proj), std::max(f.n_between, f.n_prior));
+  const int g = grid_for(nmax);
+  hipLaunchKernelGGL(k_linear_error, dim3(g), dim3(kBlock), 0, c.stream, a, c.delta.p, c.partials.p);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 2, c.scalars.p, (int)SC_LIN0);
+  check_hip(hipGetLastError(), "linear_error");
+}
+
+void launch_retract(gtg_context& c) {
+  hipLaunchKernelGGL(k_retract, dim3(grid_for(c.n_vars)), dim3(kBlock), 0, c.stream, c.n_vars, c.var_type.p,
+                     c.val_off.p, c.dim_off.p, c.values.p, c.delta.p, c.trial.p);
+  const int g = grid_for(c.dim_size);
+  hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(kBlock), 0, c.stream, c.dim_size, c.delta.p, c.partials.p);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 1, c.scalars.p, (int)SC_DELTA_SQ);
+  check_hip(hipGetLastError(), "retract");
+}
+
+}  // namespace gt

@@ -1,0 +1,317 @@
+// geom.h -- per-factor geometry of the LM hot path, written for one GPU lane per factor.
+//
+// Device-side re-derivation of exactly the formulas the reference evaluates inside every factor
+// (SURVEY.md section 8(a) rows G1, F1-F4, R1); file:line citations are into /root/reference/gtsam.
+// Everything is IEEE double, no fast-math, fused multiply-adds left to the compiler's default
+// contraction (-ffp-contract=fast-honor-pragmas on hipcc): results agree with the reference to a
+// few ulp, not bitwise (tolerances in tests/).
+//
+// GT_HD lets the same header be compiled by plain g++ for the CPU-side unit parity test of these
+// formulas (tests/hostmath/, test infrastructure only -- the product has no CPU path).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GT_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define GT_HD inline
+#endif
+
+namespace gt {
+
+constexpr double kEps = 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- tiny fixed-size helpers (row-major) ------------------------------------------------------
+GT_HD void mat3_mul(const double* A, const double* B, double* C) {  // C = A*B
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+GT_HD void mat3_tmul(const double* A, const double* B, double* C) {  // C = A^T * B
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+GT_HD void mat3_vec(const double* A, const double* x, double* y) {
+  for (int i = 0; i < 3; i++) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+GT_HD void mat3_tvec(const double* A, const double* x, double* y) {  // y = A^T x
+  for (int i = 0; i < 3; i++) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+GT_HD void skew3(double x, double y, double z, double* W) {  // skewSymmetric (base/Matrix.h)
+  W[0] = 0; W[1] = -z; W[2] = y; W[3] = z; W[4] = 0; W[5] = -x; W[6] = -y; W[7] = x; W[8] = 0;
+}
+
+// ---- SO(3) -----------------------------------------------------------------------------------
+// SO3::Expmap through so3::ExpmapFunctor (geometry/SO3.cpp:50-88,200-208).
+GT_HD void so3_expmap(const double* w, double* R) {
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double W[9];
+  skew3(w[0], w[1], w[2], W);
+  if (theta2 <= kEps) {  // nearZero: I + W
+    for (int i = 0; i < 9; i++) R[i] = W[i];
+    R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
+    return;
+  }
+  const double theta = sqrt(theta2);
+  const double sin_theta = sin(theta);
+  const double s2 = sin(theta / 2.0);
+  const double one_minus_cos = 2.0 * s2 * s2;
+  double K[9], KK[9];
+  for (int i = 0; i < 9; i++) K[i] = W[i] / theta;
+  mat3_mul(K, K, KK);
+  for (int i = 0; i < 9; i++) R[i] = sin_theta * K[i] + one_minus_cos * KK[i];
+  R[0] += 1.0; R[4] += 1.0; R[8] += 1.0;
+}
+
+// SO3::Logmap (geometry/SO3.cpp:247-323): near-pi branch by largest diagonal, acos branch,
+// Taylor branch near the identity -- thresholds 1e-3 and -1e-6 as in the reference.
+GT_HD void so3_logmap(const double* R, double* omega) {
+  const double R11 = R[0], R12 = R[1], R13 = R[2];
+  const double R21 = R[3], R22 = R[4], R23 = R[5];
+  const double R31 = R[6], R32 = R[7], R33 = R[8];
+  const double tr = R11 + R22 + R33;
+  if (tr + 1.0 < 1e-3) {
+    double W, Q1, Q2, Q3, o0, o1, o2;
+    if (R33 > R22 && R33 > R11) {
+      W = R21 - R12; Q1 = 2.0 + 2.0 * R33; Q2 = R31 + R13; Q3 = R23 + R32;
+      o0 = Q2; o1 = Q3; o2 = Q1;
+    } else if (R22 > R11) {
+      W = R13 - R31; Q1 = 2.0 + 2.0 * R22; Q2 = R23 + R32; Q3 = R12 + R21;
+      o0 = Q3; o1 = Q1; o2 = Q2;
+    } else {
+      W = R32 - R23; Q1 = 2.0 + 2.0 * R11; Q2 = R12 + R21; Q3 = R31 + R13;
+      o0 = Q1; o1 = Q2; o2 = Q3;
+    }
+    const double r = sqrt(Q1);
+    const double one_over_r = 1 / r;
+    const double norm = sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W);
+    const double sgn_w = W < 0 ? -1.0 : 1.0;
+    const double mag = kPi - (2 * sgn_w * W) / norm;
+    const double scale = 0.5 * one_over_r * mag;
+    omega[0] = sgn_w * scale * o0; omega[1] = sgn_w * scale * o1; omega[2] = sgn_w * scale * o2;
+  } else {
+    double magnitude;
+    const double tr_3 = tr - 3.0;
+    if (tr_3 < -1e-6) {
+      const double theta = acos((tr - 1.0) / 2.0);
+      magnitude = theta / (2.0 * sin(theta));
+    } else {
+      magnitude = 0.5 - tr_3 / 12.0 + tr_3 * tr_3 / 60.0;
+    }
+    omega[0] = magnitude * (R32 - R23); omega[1] = magnitude * (R13 - R31); omega[2] = magnitude * (R21 - R12);
+  }
+}
+
+// ---- SE(3): a pose is 12 doubles, R row-major then t ---------------------------------------
+// Pose3::operator* (geometry/Pose3.h:114-116)
+GT_HD void pose_compose(const double* A, const double* B, double* C) {
+  double R[9], t[3];
+  mat3_mul(A, B, R);
+  mat3_vec(A, B + 9, t);
+  for (int i = 0; i < 9; i++) C[i] = R[i];
+  for (int i = 0; i < 3; i++) C[9 + i] = A[9 + i] + t[i];
+}
+// Pose3::inverse (geometry/Pose3.cpp:49-52)
+GT_HD void pose_inverse(const double* A, double* B) {
+  double nt[3] = {-A[9], -A[10], -A[11]}, t[3];
+  mat3_tvec(A, nt, t);
+  double R[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = A[3 * j + i];
+  for (int i = 0; i < 9; i++) B[i] = R[i];
+  for (int i = 0; i < 3; i++) B[9 + i] = t[i];
+}
+// inverse(A) * B without materialising the inverse: LieGroup::between (base/Lie.h:63-69)
+GT_HD void pose_between(const double* A, const double* B, double* C) {
+  double Ai[12];
+  pose_inverse(A, Ai);
+  pose_compose(Ai, B, C);
+}
+// Pose3::AdjointMap (geometry/Pose3.cpp:57-63): [R 0; [t]x R, R], 6x6 row-major
+GT_HD void pose_adjoint(const double* T, double* Ad) {
+  double S[9], A[9];
+  skew3(T[9], T[10], T[11], S);
+  mat3_mul(S, T, A);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Ad[6 * i + j] = T[3 * i + j];
+      Ad[6 * i + 3 + j] = 0.0;
+      Ad[6 * (3 + i) + j] = A[3 * i + j];
+      Ad[6 * (3 + i) + 3 + j] = T[3 * i + j];
+    }
+}
+// Pose3::Expmap (geometry/Pose3.cpp:169-185), xi = [omega; v]
+GT_HD void pose_expmap(const double* xi, double* T) {
+  const double* w = xi; const double* v = xi + 3;
+  so3_expmap(w, T);
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (theta2 > kEps) {
+    const double wv = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    const double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    double Rc[3];
+    mat3_vec(T, c, Rc);
+    for (int i = 0; i < 3; i++) T[9 + i] = (c[i] - Rc[i] + w[i] * wv) / theta2;
+  } else {
+    T[9] = v[0]; T[10] = v[1]; T[11] = v[2];
+  }
+}
+// Pose3::Logmap (geometry/Pose3.cpp:188-208)
+GT_HD void pose_logmap(const double* T, double* xi) {
+  double w[3];
+  so3_logmap(T, w);
+  const double* Tt = T + 9;
+  const double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (t < 1e-10) {
+    xi[3] = Tt[0]; xi[4] = Tt[1]; xi[5] = Tt[2];
+  } else {
+    double W[9], WT[3], WWT[3];
+    skew3(w[0] / t, w[1] / t, w[2] / t, W);
+    const double Tan = tan(0.5 * t);
+    mat3_vec(W, Tt, WT);
+    mat3_vec(W, WT, WWT);
+    const double c = 1 - t / (2. * Tan);
+    for (int i = 0; i < 3; i++) xi[3 + i] = Tt[i] - (0.5 * t) * WT[i] + c * WWT[i];
+  }
+}
+// LieGroup::retract = compose(Expmap(xi)) (base/Lie.h:131-133; GTSAM_POSE3_EXPMAP default)
+GT_HD void pose_retract(const double* T, const double* xi, double* out) {
+  double E[12];
+  pose_expmap(xi, E);
+  pose_compose(T, E, out);
+}
+// LieGroup::localCoordinates = Logmap(between(g)) (base/Lie.h:136-138)
+GT_HD void pose_local(const double* A, const double* B, double* xi) {
+  double C[12];
+  pose_between(A, B, C);
+  pose_logmap(C, xi);
+}
+
+// ---- pinhole projection -----------------------------------------------------------------------
+// PinholeBase::project2 (geometry/CalibratedCamera.cpp:116-135) with Pose3::transformTo
+// (Pose3.cpp:371-388), Project (:88-94), Dpose (:27-34), Dpoint (:37-46).
+// Returns false on a CheiralityException (q.z <= 0, GTSAM_THROW_CHEIRALITY_EXCEPTION default ON).
+// Dpose 2x6, Dpoint 2x3 row-major; pass nullptr to skip derivatives.
+GT_HD bool project2(const double* T, const double* pw, double* pn, double* Dpose, double* Dpoint) {
+  const double dx[3] = {pw[0] - T[9], pw[1] - T[10], pw[2] - T[11]};
+  double q[3];
+  mat3_tvec(T, dx, q);
+  if (q[2] <= 0) return false;
+  const double d = 1.0 / q[2];
+  const double u = q[0] * d, v = q[1] * d;
+  pn[0] = u; pn[1] = v;
+  if (Dpose) {
+    const double uv = u * v, uu = u * u, vv = v * v;
+    Dpose[0] = uv; Dpose[1] = -1 - uu; Dpose[2] = v; Dpose[3] = -d; Dpose[4] = 0; Dpose[5] = d * u;
+    Dpose[6] = 1 + vv; Dpose[7] = -uv; Dpose[8] = -u; Dpose[9] = 0; Dpose[10] = -d; Dpose[11] = d * v;
+  }
+  if (Dpoint) {  // Rt(i,j) = R(j,i) = T[3*j+i]
+    for (int j = 0; j < 3; j++) {
+      Dpoint[j] = (T[3 * j + 0] - u * T[3 * j + 2]) * d;
+      Dpoint[3 + j] = (T[3 * j + 1] - v * T[3 * j + 2]) * d;
+    }
+  }
+  return true;
+}
+
+// PinholeCamera<Cal3Bundler>::project2 (geometry/PinholeCamera.h:230-248) = PinholeBaseK::_project
+// (PinholePose.h:89-109) + Cal3Bundler::uncalibrate (Cal3Bundler.cpp:66-92).
+// cam = pose(12), f, k1, k2, u0, v0.  Dcam 2x9 = [Dp*Dpose | Dcal], Dpoint 2x3 (row-major).
+GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* Dcam, double* Dpoint) {
+  double pn[2], Dpose[12], Dpt[6];
+  if (!project2(cam, pw, pn, Dcam ? Dpose : nullptr, Dpoint ? Dpt : nullptr)) return false;
+  const double f = cam[12], k1 = cam[13], k2 = cam[14], u0 = cam[15], v0 = cam[16];
+  const double x = pn[0], y = pn[1];
+  const double r = x * x + y * y;
+  const double g = 1. + (k1 + k2 * r) * r;
+  const double u = g * x, v = g * y;
+  pi[0] = u0 + f * u; pi[1] = v0 + f * v;
+  if (Dcam || Dpoint) {
+    const double a = 2. * (k1 + 2. * k2 * r);
+    const double axx = a * x * x, axy = a * x * y, ayy = a * y * y;
+    const double Dp[4] = {(g + axx) * f, axy * f, axy * f, (g + ayy) * f};
+    if (Dcam) {
+      const double rx = r * x, ry = r * y;
+      for (int j = 0; j < 6; j++) {
+        Dcam[j] = Dp[0] * Dpose[j] + Dp[1] * Dpose[6 + j];
+        Dcam[9 + j] = Dp[2] * Dpose[j] + Dp[3] * Dpose[6 + j];
+      }
+      Dcam[6] = u; Dcam[7] = f * rx; Dcam[8] = f * r * rx;
+      Dcam[15] = v; Dcam[16] = f * ry; Dcam[17] = f * r * ry;
+    }
+    if (Dpoint)
+      for (int j = 0; j < 3; j++) {
+        Dpoint[j] = Dp[0] * Dpt[j] + Dp[1] * Dpt[3 + j];
+        Dpoint[3 + j] = Dp[2] * Dpt[j] + Dp[3] * Dpt[3 + j];
+      }
+  }
+  return true;
+}
+
+// PinholeCamera<Cal3_S2>(pose, K).project (PinholePose.h:89-109) + Cal3_S2::uncalibrate
+// (geometry/Cal3_S2.cpp:44-50).  K = fx, fy, s, u0, v0.  Dpose 2x6, Dpoint 2x3.
+GT_HD bool s2_project(const double* T, const double* K, const double* pw, double* pi, double* Dpose,
+                      double* Dpoint) {
+  double pn[2], Dps[12], Dpt[6];
+  if (!project2(T, pw, pn, Dpose ? Dps : nullptr, Dpoint ? Dpt : nullptr)) return false;
+  const double fx = K[0], fy = K[1], s = K[2], u0 = K[3], v0 = K[4];
+  pi[0] = fx * pn[0] + s * pn[1] + u0;
+  pi[1] = fy * pn[1] + v0;
+  if (Dpose)
+    for (int j = 0; j < 6; j++) {
+      Dpose[j] = fx * Dps[j] + s * Dps[6 + j];
+      Dpose[6 + j] = 0.0 * Dps[j] + fy * Dps[6 + j];
+    }
+  if (Dpoint)
+    for (int j = 0; j < 3; j++) {
+      Dpoint[j] = fx * Dpt[j] + s * Dpt[3 + j];
+      Dpoint[3 + j] = 0.0 * Dpt[j] + fy * Dpt[3 + j];
+    }
+  return true;
+}
+
+// ---- noise models (linear/NoiseModel.cpp) ------------------------------------------------------
+enum { kNoiseUnit = 0, kNoiseIsotropic = 1, kNoiseDiagonal = 2, kNoiseGaussian = 3 };
+// Device noise table entry data: ISOTROPIC {invsigma}; DIAGONAL invsigmas[dim]; GAUSSIAN R row-major.
+// whiten a column vector / the columns of a row-major m x n matrix in place:
+//   Unit no-op; Isotropic v*invsigma (:641-663); Diagonal v.*invsigmas (:311-325); Gaussian R*v (:163-181)
+template <int M>
+GT_HD void whiten_cols(int kind, const double* nd, double* A, int ncols) {
+  if (kind == kNoiseUnit) return;
+  if (kind == kNoiseIsotropic) {
+    const double s = nd[0];
+    for (int i = 0; i < M * ncols; i++) A[i] *= s;
+  } else if (kind == kNoiseDiagonal) {
+    for (int r = 0; r < M; r++) for (int c = 0; c < ncols; c++) A[r * ncols + c] *= nd[r];
+  } else {
+    for (int c = 0; c < ncols; c++) {
+      double col[M];
+      for (int r = 0; r < M; r++) col[r] = A[r * ncols + c];
+      for (int r = 0; r < M; r++) {
+        double acc = 0.0;
+        for (int k = 0; k < M; k++) acc += nd[r * M + k] * col[k];
+        A[r * ncols + c] = acc;
+      }
+    }
+  }
+}
+
+// traits<T>::Local(x, z) for the supported value types (PriorFactor.h:98-102):
+// Pose3 Logmap(between); PinholeCamera [pose local; calib diff] (PinholeCamera.h:208-213,
+// Cal3Bundler.h:150-152); Point3 z - x.   vtype: 0 POSE3, 1 SFM_CAMERA, 2 POINT3.
+GT_HD void value_local(int vtype, const double* x, const double* z, double* d) {
+  if (vtype == 2) { d[0] = z[0] - x[0]; d[1] = z[1] - x[1]; d[2] = z[2] - x[2]; return; }
+  pose_local(x, z, d);
+  if (vtype == 1) { d[6] = z[12] - x[12]; d[7] = z[13] - x[13]; d[8] = z[14] - x[14]; }
+}
+// traits<T>::Retract(x, d): Pose3 (Lie.h:131-133), PinholeCamera::retract (PinholeCamera.h:199-205)
+// with Cal3Bundler::retract (Cal3Bundler.h:145-147), Point3 x + d.
+GT_HD void value_retract(int vtype, const double* x, const double* d, double* y) {
+  if (vtype == 2) { y[0] = x[0] + d[0]; y[1] = x[1] + d[1]; y[2] = x[2] + d[2]; return; }
+  pose_retract(x, d, y);
+  if (vtype == 1) { y[12] = x[12] + d[6]; y[13] = x[13] + d[7]; y[14] = x[14] + d[8]; y[15] = x[15]; y[16] = x[16]; }
+}
+
+}  // namespace gt

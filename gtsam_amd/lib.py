@@ -1,0 +1,197 @@
+"""ctypes binding of the C ABI (include/gtsam_amd.h) -> gtsam_amd/lib/libgtsam_amd.so.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, every entry point
+raises.  torch is only used by callers for multi-GPU plumbing (torch.distributed), never here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .problem import Problem, gtg_problem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgtsam_amd.so")
+
+GTG_OK, GTG_INDETERMINATE = 0, 1
+PHASES = ["linearize", "assemble", "point_eliminate", "schur", "cholesky", "solve", "linear_error",
+          "retract", "error"]
+
+# every symbol include/gtsam_amd.h declares (tests check the .so exports all of them)
+SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_upload_problem",
+           "gtg_set_reduced_ordering", "gtg_values_size", "gtg_tangent_size", "gtg_set_values",
+           "gtg_get_values", "gtg_get_trial_values", "gtg_error", "gtg_linearize", "gtg_try_lambda",
+           "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
+           "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
+           "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
+           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host"]
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+_lib = None
+
+
+class GtsamAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgtsam_amd.so; raises loudly when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GtsamAmdError(f"{LIB_PATH} not found: build the HIP extension first "
+                            "(python -c 'import __graft_entry__ as g; g.build()' or make -C gtsam_amd/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    lib.gtg_last_error.restype = C.c_char_p
+    lib.gtg_version.restype = C.c_char_p
+    lib.gtg_phase_name.restype = C.c_char_p
+    for name in ("gtg_values_size", "gtg_tangent_size", "gtg_reduced_dim"):
+        getattr(lib, name).restype = C.c_int64
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.gtg_cholesky_flops.restype = C.c_double
+    lib.gtg_cholesky_flops.argtypes = [C.c_void_p]
+    lib.gtg_linearize_bytes.restype = C.c_double
+    lib.gtg_linearize_bytes.argtypes = [C.c_void_p]
+    lib.gtg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.gtg_destroy.argtypes = [C.c_void_p]
+    lib.gtg_upload_problem.argtypes = [C.c_void_p, C.POINTER(gtg_problem), C.c_int, C.c_int]
+    lib.gtg_set_reduced_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    for name in ("gtg_set_values", "gtg_get_values", "gtg_get_trial_values", "gtg_get_delta",
+                 "gtg_get_gradient", "gtg_get_hessian_diagonal", "gtg_get_reduced_matrix"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.gtg_get_jacobians.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.gtg_error.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.gtg_linearize.argtypes = [C.c_void_p]
+    lib.gtg_try_lambda.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    lib.gtg_accept.argtypes = [C.c_void_p]
+    lib.gtg_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.gtg_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.gtg_reset_timing.argtypes = [C.c_void_p]
+    lib.gtg_get_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.gtg_dense_cholesky_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise GtsamAmdError(f"{what} failed (rc={rc}): {load().gtg_last_error().decode()}")
+    return rc
+
+
+class DeviceGraph:
+    """One factor graph resident on one MI355X (one handle of the C ABI)."""
+
+    JAC_ROW = {0: 26, 1: 20, 2: 78, 3: 90}
+
+    def __init__(self, problem: Problem, device: int = 0, shard: int = 0, n_shards: int = 1,
+                 reduced_ordering=None, allreduce=None):
+        self.lib = load()
+        self.problem = problem
+        self.h = C.c_void_p()
+        _check(self.lib.gtg_create(C.byref(self.h), device), "gtg_create")
+        self._cb = None
+        if allreduce is not None:
+            self.set_allreduce(allreduce)
+        if reduced_ordering is not None:
+            o = np.ascontiguousarray(reduced_ordering, np.int32)
+            _check(self.lib.gtg_set_reduced_ordering(self.h, o.ctypes.data, o.size), "gtg_set_reduced_ordering")
+        self._cp = problem.to_ctypes()
+        _check(self.lib.gtg_upload_problem(self.h, C.byref(self._cp), shard, n_shards), "gtg_upload_problem")
+        self.val_size = self.lib.gtg_values_size(self.h)
+        self.dim_size = self.lib.gtg_tangent_size(self.h)
+        self.reduced_dim = self.lib.gtg_reduced_dim(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.gtg_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, n_doubles:int, stream:int) -> None ; sums the buffer across shards in place."""
+        def _cb(ptr, n, stream, user):
+            try:
+                fn(ptr, n, stream)
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not propagate through C
+                print("allreduce callback failed:", e)
+                return 1
+        self._cb = ALLREDUCE_FN(_cb)
+        _check(self.lib.gtg_set_allreduce(self.h, self._cb, None), "gtg_set_allreduce")
+
+    # values ----------------------------------------------------------------------------------------
+    def set_values(self, v):
+        v = np.ascontiguousarray(v, np.float64)
+        _check(self.lib.gtg_set_values(self.h, v.ctypes.data, v.size), "gtg_set_values")
+
+    def _get(self, fn, n):
+        out = np.empty(n, np.float64)
+        _check(fn(self.h, out.ctypes.data, out.size), fn.__name__)
+        return out
+
+    def values(self): return self._get(self.lib.gtg_get_values, self.val_size)
+    def trial_values(self): return self._get(self.lib.gtg_get_trial_values, self.val_size)
+    def delta(self): return self._get(self.lib.gtg_get_delta, self.dim_size)
+    def gradient(self): return self._get(self.lib.gtg_get_gradient, self.dim_size)
+    def hessian_diagonal(self): return self._get(self.lib.gtg_get_hessian_diagonal, self.dim_size)
+
+    def reduced_matrix(self):
+        n = self.reduced_dim
+        out = np.empty((n, n), np.float64)
+        _check(self.lib.gtg_get_reduced_matrix(self.h, out.ctypes.data, out.size), "gtg_get_reduced_matrix")
+        return out
+
+    def jacobians(self, ftype):
+        n = {0: self.problem.n_sfm, 1: self.problem.n_proj, 2: self.problem.n_between, 3: self.problem.n_prior}[ftype]
+        out = np.empty((n, self.JAC_ROW[ftype]), np.float64)
+        _check(self.lib.gtg_get_jacobians(self.h, ftype, out.ctypes.data, out.size), "gtg_get_jacobians")
+        return out
+
+    # the hot path ------------------------------------------------------------------------------------
+    def error(self):
+        e = C.c_double()
+        _check(self.lib.gtg_error(self.h, C.byref(e)), "gtg_error")
+        return e.value
+
+    def linearize(self):
+        _check(self.lib.gtg_linearize(self.h), "gtg_linearize")
+
+    def try_lambda(self, lam, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32):
+        """-> (status, [linear.error(0), linear.error(delta), graph.error(trial), |delta|])."""
+        out = np.zeros(4)
+        rc = _check(self.lib.gtg_try_lambda(self.h, lam, int(diagonal_damping), min_diagonal, max_diagonal,
+                                            out.ctypes.data), "gtg_try_lambda")
+        return rc, out
+
+    def accept(self):
+        _check(self.lib.gtg_accept(self.h), "gtg_accept")
+
+    # measurement ---------------------------------------------------------------------------------------
+    def enable_timing(self, on=True): self.lib.gtg_enable_timing(self.h, int(on))
+    def reset_timing(self): self.lib.gtg_reset_timing(self.h)
+
+    def phase_ms(self):
+        ms = np.zeros(len(PHASES)); calls = np.zeros(len(PHASES), np.int64)
+        self.lib.gtg_get_phase_ms(self.h, ms.ctypes.data, calls.ctypes.data, len(PHASES))
+        return {p: (float(ms[i]), int(calls[i])) for i, p in enumerate(PHASES)}
+
+    def cholesky_flops(self): return self.lib.gtg_cholesky_flops(self.h)
+    def linearize_bytes(self): return self.lib.gtg_linearize_bytes(self.h)
+
+    def dense_cholesky(self, A, rhs=None):
+        """Unit-test hook: (status, L (lower), x) of the device Cholesky + solve on a host matrix."""
+        A = np.ascontiguousarray(A, np.float64).copy()
+        x = None if rhs is None else np.ascontiguousarray(rhs, np.float64).copy()
+        rc = _check(self.lib.gtg_dense_cholesky_host(self.h, A.ctypes.data, A.shape[0],
+                                                     None if x is None else x.ctypes.data), "gtg_dense_cholesky_host")
+        return rc, np.tril(A), x

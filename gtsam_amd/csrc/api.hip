@@ -217,9 +217,9 @@ static void analyze(gtg_context& c) {
 
   // ---- numeric buffers --------------------------------------------------------------------------
   const size_t NP = c.NP;
-  c.Hd.alloc(std::max<size_t>(81 * (size_t)c.n_red_vars, 1)); c.gred0.alloc(std::max<size_t>(9 * (size_t)c.n_red_vars, 1));
+  c.Hd.alloc(std::max<size_t>(81 * (size_t)c.n_red_vars, 81)); c.gred0.alloc(std::max<size_t>(9 * (size_t)c.n_red_vars, 9));
   c.hdiag_red.alloc(NP);
-  c.V.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.gp.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
+  c.V.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 9)); c.gp.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 3));
   c.Linv.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.ylm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.delta_lm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.E.alloc(std::max<size_t>(27 * (size_t)c.n_obs, 1));
@@ -504,7 +504,6 @@ int gtg_error(gtg_handle c, double* error) {
   GTG_TRY
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
-  c->timing = c->timing;
   { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});

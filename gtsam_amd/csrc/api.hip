@@ -38,6 +38,7 @@ template <class T> void DevBuf<T>::free() {
 template struct DevBuf<double>;
 template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
+template struct DevBuf<long long>;
 
 static inline int storage_size(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }
 static inline int tangent_dim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }
@@ -281,6 +282,7 @@ static void collect(gtg_context& c, std::initializer_list<int> phases) {
 
 }  // namespace gt
 
+namespace gt { long long* g_potrf_dbg_set(long long*); }
 using namespace gt;
 
 #define GTG_TRY try {
@@ -641,6 +643,20 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
 double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
+
+// debug only (not in the public header): cycle stamps of k_potrf128 stages on a 128x128 SPD matrix
+int gtg_debug_potrf_stamps(gtg_handle c, double* A128, long long* out15) {
+  GTG_TRY
+  DevBuf<long long> dbg; dbg.alloc(16);
+  check_hip(hipMemset(dbg.p, 0, 16 * sizeof(long long)), "memset");
+  g_potrf_dbg_set(dbg.p);
+  const int rc = gtg_dense_cholesky_host(c, A128, 128, nullptr);
+  g_potrf_dbg_set(nullptr);
+  check_hip(hipMemcpy(out15, dbg.p, 15 * sizeof(long long), hipMemcpyDeviceToHost), "D2H");
+  dbg.free();
+  return rc;
+  GTG_CATCH
+}
 
 int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   GTG_TRY

@@ -9,10 +9,15 @@
 // forward solve L y = g for free (the reference does the same with its augmented [H g; g^T f] matrix,
 // HessianFactor.cpp:239-252).
 //
-// Right-looking, tile = 128:
-//   k_potrf_inv   one workgroup: factor the 128x128 diagonal tile in LDS and invert the factor
-//   k_gemm_abt    FP64 MFMA (v_mfma_f64_16x16x4_f64) 128x128x128 tile products, used for both
-//                 TRSM (X = A * Linv^T) and the SYRK/GEMM trailing update (C -= X_I X_J^T)
+// Right-looking over 128-wide block columns, processed in PAIRS so that the big trailing update
+// contracts over K = 256 (arithmetic intensity 32 flop/B against the C tile traffic):
+//   k_potrf128   one workgroup: 128x128 diagonal tile in LDS, 32-blocked; the 32x32 diagonal blocks are
+//                factored and inverted in REGISTERS by one wavefront (lane = row, v_readlane broadcasts),
+//                the level-3 parts run on the FP64 matrix cores
+//   k_trsm128    one workgroup per 128-row tile: X = A L^-T by 4-phase block substitution with MFMA;
+//                only the 32x32 diagonal inverses are used (never a 128x128 inverse)
+//   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles, K = 128 or 256, LDS double-buffered,
+//                v_mfma_f64_16x16x4_f64
 // MFMA is used only here (dense contraction); everything else on the path is HBM-bound.
 #include "kernels.h"
 
@@ -21,196 +26,497 @@ namespace gt {
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int T = kTile;        // 128
-constexpr int LP = T + 1;       // LDS pitch of the diagonal tile (odd -> conflict-free column access)
+constexpr int SB = 32;          // sub-block of the diagonal tile
+constexpr int P = T + 2;        // LDS pitch of a full tile: (2*P) % 64 == 4 -> MFMA operand reads conflict-free
+constexpr int PX = SB + 2;      // LDS pitch of the 32x32 inverse
 
-// ---- diagonal tile: L = chol(A), Dinv = L^-1 ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_potrf_inv(double* __restrict__ S, int NP, int k, double* __restrict__ Dinv,
-                                                   double* __restrict__ fail) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* A = reinterpret_cast<double*>(smem_raw);   // [T][LP]
-  double* dinv = A + T * LP;                          // [T]
-  const int tid = threadIdx.x;
-  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
-  for (int e = tid; e < T * T; e += 256) {
-    const int i = e / T, j = e % T;
-    A[i * LP + j] = tile[(int64_t)i * NP + j];
-  }
-  __syncthreads();
-  // right-looking unblocked Cholesky on the lower triangle (Eigen LLT semantics: pivot <= 0 fails)
-  for (int j = 0; j < T; j++) {
-    if (tid == 0) {
-      const double p = A[j * LP + j];
-      if (!(p > 0.0)) *fail = 1.0;
-      const double d = sqrt(p);
-      A[j * LP + j] = d;
-      dinv[j] = 1.0 / d;
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+  return u.d;
+}
+
+// MFMA fragment helpers (cdna_hip_programming.md section 3, f64 16x16x4): lane l supplies
+// A[row = l&15][k = l>>4], B[k = l>>4][col = l&15]; accumulator reg r holds C[row = (l>>4) + 4r][col = l&15].
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// 128x128 tile (global, ld = NP) <-> LDS (pitch PL doubles); 16-byte accesses, 16 loads in flight per lane
+template <int PL>
+__device__ __forceinline__ void tile_to_lds(const double* __restrict__ tile, int NP, double* __restrict__ L, int tid) {
+#pragma unroll
+  for (int e0 = 0; e0 < T * (T / 2); e0 += 256 * 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 256 + tid;
+      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
     }
-    __syncthreads();
-    const double dj = dinv[j];
-    for (int i = j + 1 + tid; i < T; i += 256) A[i * LP + j] *= dj;
-    __syncthreads();
-    // trailing update: A[i][c] -= A[i][j] * A[c][j] for j < c <= i
-    const int m = T - 1 - j;  // rows/cols remaining
-    for (int e = tid; e < m * m; e += 256) {
-      const int i = j + 1 + e / m, c = j + 1 + e % m;
-      if (c <= i) A[i * LP + c] -= A[i * LP + j] * A[c * LP + j];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 256 + tid;
+      double* d = L + (e / (T / 2)) * PL + 2 * (e % (T / 2));
+      d[0] = v[u].x; d[1] = v[u].y;
     }
-    __syncthreads();
-  }
-  // inverse of the lower-triangular factor, one column per thread, stored transposed in the upper
-  // triangle of A (X[c][i], i > c); diagonal in dinv.  Loops are wave-uniform (predicated) so that
-  // A[i][j] is a broadcast read and A[c][j] (pitch 129) is conflict-free.
-  if (tid < T) {
-    const int c = tid;
-    for (int i = 1; i < T; i++) {
-      double acc = (i > c) ? A[i * LP + c] * dinv[c] : 0.0;
-      for (int j = 1; j < i; j++) {
-        const double l = A[i * LP + j];
-        const double x = A[c * LP + j];
-        if (j > c) acc += l * x;
-      }
-      if (i > c) A[c * LP + i] = -acc * dinv[i];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < T * T; e += 256) {
-    const int i = e / T, j = e % T;
-    tile[(int64_t)i * NP + j] = (j <= i) ? A[i * LP + j] : 0.0;
-    Dinv[e] = (j < i) ? A[j * LP + i] : (j == i ? dinv[i] : 0.0);
   }
 }
 
-// ---- 128x128x128 tile product on the FP64 matrix cores ----------------------------------------------
-// C_tile (op)= Apanel[128 x 128] * Bpanel[128 x 128]^T, both panels row-major with the contraction
-// index contiguous.  4 wavefronts in 2x2, each owns 64x64 = 4x4 MFMA tiles of 16x16.
-// v_mfma_f64_16x16x4_f64 operand layout (cdna_hip_programming.md section 3): lane l supplies
-// A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; result reg j holds C[row = (l>>4) + 4j][col = l&15].
-constexpr int KC = 32;          // contraction chunk staged through LDS
-constexpr int PP = KC + 2;      // LDS pitch (doubles): (2*PP) % 64 == 4 -> the 16 rows x 2 k of a half-wave hit 32 distinct banks
+// 1/sqrt(p) to full double precision: v_rsq_f64 seed + two Newton steps (no IEEE sqrt/div sequence on
+// the 128-pivot critical path).  p <= 0 or NaN propagates inf/NaN and the caller raises the fail flag.
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double r = __builtin_amdgcn_rsq(p);
+  const double h = 0.5 * p;
+  r = r * (1.5 - h * r * r);
+  r = r * (1.5 - h * r * r);
+  return r;
+}
 
-enum { MODE_TRSM = 0, MODE_SYRK = 1 };
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm_abt(double* __restrict__ S, int NP, int k,
-                                                  const double* __restrict__ Dinv) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* As = reinterpret_cast<double*>(smem_raw);
-  double* Bs = As + T * PP;
-  int I, J;
-  if (MODE == MODE_TRSM) { I = k + 1 + blockIdx.x; J = k; }
-  else {
-    J = k + 1 + blockIdx.y; I = k + 1 + blockIdx.x;
-    if (I < J) return;
+// ---- 32x32 Cholesky by ONE wavefront: lane i (mod 32) keeps row i in REGISTERS (a[0..31]); at step J every
+// lane publishes its column entry a[J] in a 32-double LDS line, reads the pivot and the entries below it
+// back as broadcasts (same address in all lanes) and updates its row.  The step index is a template
+// parameter so that every register index is static (a dynamically indexed row would live in scratch).
+// Same-wave LDS traffic is in order, so no barrier is needed between the steps.  dinv[J] = 1 / L(J,J).
+template <int J>
+struct PotrfStep {
+  static __device__ __forceinline__ void run(double (&a)[SB], double* col, double* dinv, int lane, int i, double* fail) {
+    if (lane < 32) col[i] = a[J];
+    const double piv = col[J];
+    if (!(piv > 0.0) && lane == 0) *fail = 1.0;   // Eigen LLT: non-positive pivot -> NumericalIssue
+    const double r = rsqrt_nr(piv);
+    const double u = a[J] * (r * r);
+#pragma unroll
+    for (int c = J + 1; c < SB; c++) a[c] -= u * col[c];
+    // pin the row here: without it hipcc defers the updates it does not need for the next pivot and keeps
+    // every step's broadcast values alive (hundreds of spilled registers)
+#pragma unroll
+    for (int c = J + 1; c < SB; c++) asm volatile("" : "+v"(a[c]));
+    a[J] = (i == J) ? piv * r : a[J] * r;
+    if (lane == J) dinv[J] = r;
+    PotrfStep<J + 1>::run(a, col, dinv, lane, i, fail);
   }
-  const double* Ap = S + ((int64_t)I * T) * NP + (int64_t)k * T;                          // L(I,k) / A(I,k)
-  const double* Bp = (MODE == MODE_TRSM) ? Dinv : S + ((int64_t)J * T) * NP + (int64_t)k * T;
-  const int ldb = (MODE == MODE_TRSM) ? T : NP;
+};
+template <>
+struct PotrfStep<SB> {
+  static __device__ __forceinline__ void run(double (&)[SB], double*, double*, int, int, double*) {}
+};
+
+__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv,
+                                            double* __restrict__ col, int o, int lane, double* fail) {
+  const int i = lane & 31;
+  double* row = A + (o + i) * P + o;
+  double a[SB];
+#pragma unroll
+  for (int c = 0; c < SB; c++) a[c] = row[c];
+  PotrfStep<0>::run(a, col, dinv + o, lane, i, fail);
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < SB; c++) row[c] = (c <= i) ? a[c] : 0.0;
+  }
+}
+
+// X = L_jj^-1 (used by k_trsm128 / k_bwd_step): lane c owns column c, L rows are broadcast LDS reads
+__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int o, int lane, double* Xout) {
+  const int i = lane & 31;
+  double x[SB];
+#pragma unroll
+  for (int r = 0; r < SB; r++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < r; m++) acc += A[(o + r) * P + o + m] * x[m];
+    const double dr = dinv[o + r];
+    x[r] = (r == i) ? dr : (r > i ? -acc * dr : 0.0);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int r = 0; r < SB; r++) Xout[r * SB + i] = x[r];
+  }
+}
+
+// rows of sub-block (ib, jb): forward substitution x L_jj^T = a, one lane per row
+__device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int o, int ib, int lane) {
+  const int i = lane & 31;
+  double x[SB];
+#pragma unroll
+  for (int c = 0; c < SB; c++) x[c] = A[(SB * ib + i) * P + o + c];
+#pragma unroll
+  for (int c = 0; c < SB; c++) {
+    double acc = x[c];
+#pragma unroll
+    for (int m = 0; m < c; m++) acc -= x[m] * A[(o + c) * P + o + m];
+    x[c] = acc * dinv[o + c];
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < SB; c++) A[(SB * ib + i) * P + o + c] = x[c];
+  }
+}
+
+// ---- diagonal tile ------------------------------------------------------------------------------------------
+#define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+__global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
+                                                  double* __restrict__ fail, long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);   // [T][P]
+  double* dinv = A + T * P;                           // [T]  1 / L(j,j)
+  double* col = dinv + T;                             // [SB] column broadcast line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-
-  v4f64 acc[4][4];
-  for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
-
-  for (int k0 = 0; k0 < T; k0 += KC) {
+  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  STAMP(0);
+  tile_to_lds<P>(tile, NP, A, tid);
+  __syncthreads();
+  STAMP(1);
+#pragma unroll 1
+  for (int jb = 0; jb < 4; jb++) {
+    const int o = SB * jb;
+    if (wave == 0) stage_potrf(A, dinv, col, o, lane, fail);   // critical path
     __syncthreads();
-    // stage a 128 x KC chunk of each panel: 16-byte pieces, 16 consecutive lanes cover one 256 B row
-    for (int p = tid; p < T * (KC / 2); p += 256) {
-      const int row = p / (KC / 2), pc = p % (KC / 2);
-      const double2 va = *reinterpret_cast<const double2*>(Ap + (int64_t)row * NP + k0 + 2 * pc);
-      const double2 vb = *reinterpret_cast<const double2*>(Bp + (int64_t)row * ldb + k0 + 2 * pc);
-      *reinterpret_cast<double2*>(&As[row * PP + 2 * pc]) = va;
-      *reinterpret_cast<double2*>(&Bs[row * PP + 2 * pc]) = vb;
-    }
+    STAMP(2 + 3 * jb);
+    if (wave == 0) stage_inverse(A, dinv, o, lane, Xinv + (int64_t)jb * SB * SB);
+    else if (jb + wave < 4) stage_rowtrsm(A, dinv, o, jb + wave, lane);
     __syncthreads();
+    STAMP(3 + 3 * jb);
+    // trailing update on the matrix cores: A(ib,cb) -= L(ib,jb) L(cb,jb)^T for jb < cb <= ib
+    const int nb = 3 - jb;
+    const int n4 = nb * (nb + 1) / 2 * 4;
+    for (int t = wave; t < n4; t += 4) {
+      const int blk = t / 4, ti = (t >> 1) & 1, tj = t & 1;
+      int bi = 0, rem = blk;
+      while (rem > bi) { rem -= bi + 1; bi++; }
+      const int ib = jb + 1 + bi, cb = jb + 1 + rem;
+      v4f64 acc;
 #pragma unroll
-    for (int kk = 0; kk < KC; kk += 4) {
-      double a[4], b[4];
+      for (int r = 0; r < 4; r++) acc[r] = A[(SB * ib + 16 * ti + lk + 4 * r) * P + SB * cb + 16 * tj + lr];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        a[t] = As[(wr * 64 + t * 16 + lr) * PP + kk + lk];
-        b[t] = Bs[(wc * 64 + t * 16 + lr) * PP + kk + lk];
+      for (int kk = 0; kk < SB; kk += 4) {
+        const double av = -A[(SB * ib + 16 * ti + lr) * P + o + kk + lk];
+        const double bv = A[(SB * cb + 16 * tj + lr) * P + o + kk + lk];
+        acc = MFMA(av, bv, acc);
       }
 #pragma unroll
-      for (int ti = 0; ti < 4; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 4; tj++)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      for (int r = 0; r < 4; r++) A[(SB * ib + 16 * ti + lk + 4 * r) * P + SB * cb + 16 * tj + lr] = acc[r];
     }
+    __syncthreads();
+    STAMP(4 + 3 * jb);
   }
-  __syncthreads();  // TRSM overwrites the A panel in place: every wave must be done reading it
+#pragma unroll 8
+  for (int e = tid; e < T * (T / 2); e += 256) {
+    const int ii = e / (T / 2), j = 2 * (e % (T / 2));
+    double2 v;
+    v.x = (j <= ii) ? A[ii * P + j] : 0.0;
+    v.y = (j + 1 <= ii) ? A[ii * P + j + 1] : 0.0;
+    *reinterpret_cast<double2*>(tile + (int64_t)ii * NP + j) = v;
+  }
+  STAMP(14);
+}
+
+// ---- TRSM: X = A(I,k) * L(k,k)^-T for every row tile I below the diagonal -----------------------------------
+// Rows are independent, so each wavefront owns 32 rows of the tile and never synchronises with the others.
+__global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ S, int NP, int k, int row_tile0,
+                                                 const double* __restrict__ Xinv) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Xs = reinterpret_cast<double*>(smem_raw);   // [T][P]
+  const int I = row_tile0 + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  double* tile = S + ((int64_t)I * T) * NP + (int64_t)k * T;
+  const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  tile_to_lds<P>(tile, NP, Xs, tid);
+  __syncthreads();
+  const int r0 = 32 * wave;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    v4f64 acc[2][2];
+    // A_p (this wave's 32 rows, columns of sub-block p)
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[ti][tj][r] = Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr];
+    // A_p -= sum_{q<p} X_q L(p,q)^T
+#pragma unroll
+    for (int q = 0; q < p; q++) {
+#pragma unroll
+      for (int kk = 0; kk < SB; kk += 4) {
+        double av[2], bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          av[t] = -Xs[(r0 + 16 * t + lr) * P + SB * q + kk + lk];
+          bv[t] = L[(int64_t)(SB * p + 16 * t + lr) * NP + SB * q + kk + lk];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++) acc[ti][tj] = MFMA(av[ti], bv[tj], acc[ti][tj]);
+      }
+    }
+    // R = updated A_p back to LDS (own rows only), then X_p = R * Xinv_pp^T
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr] = acc[ti][tj][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    v4f64 xr[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) xr[ti][tj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const double* Xp = Xinv + p * SB * SB;
+#pragma unroll
+    for (int kk = 0; kk < SB; kk += 4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        av[t] = Xs[(r0 + 16 * t + lr) * P + SB * p + kk + lk];
+        bv[t] = Xp[(16 * t + lr) * SB + kk + lk];
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) xr[ti][tj] = MFMA(av[ti], bv[tj], xr[ti][tj]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr] = xr[ti][tj][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+#pragma unroll 8
+  for (int e = tid; e < T * (T / 2); e += 256) {
+    const int row = e / (T / 2), pc = e % (T / 2);
+    double2 v;
+    v.x = Xs[row * P + 2 * pc]; v.y = Xs[row * P + 2 * pc + 1];
+    *reinterpret_cast<double2*>(tile + (int64_t)row * NP + 2 * pc) = v;
+  }
+}
+
+// ---- trailing update: C(I,J) -= sum_{kt} L(I,kt) L(J,kt)^T ---------------------------------------------------
+// 128x128 output tile per workgroup, 4 wavefronts in 2x2, each 64x64 = 4x4 MFMA tiles.  The contraction
+// runs over KT*128 columns in chunks of 32; each chunk of the two row panels (128 x 32 doubles = 32 KiB
+// each) goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, stays in flight
+// across the MFMA block), double buffered.  The LDS image is row-linear (256 B per row, as the DMA
+// requires) with the 16-byte slots XOR-swizzled by (row & 15): the swizzle is applied to the SOURCE
+// address of the DMA and to the operand reads, which makes the v_mfma operand reads (16 rows x 2 slots per
+// half-wave) bank-conflict free.  C is loaded into the accumulators up front (A operand negated) so the
+// epilogue is a pure store.
+constexpr int KC = 16;             // 2 x 2 x 16 KiB of LDS per workgroup -> two workgroups per CU
+constexpr int CHB = T * KC * 8;   // bytes of one panel chunk in LDS
+constexpr int ROWB = KC * 8;      // bytes per LDS row (128)
+constexpr int NSLOT = KC / 2;     // 16-byte slots per row (8)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); each XCD walks its own
+// sequence of 8x4-tile supertiles, so the 32 workgroups resident on one XCD share 8 row panels + 4 column
+// panels (3 MB at K = 256) in that XCD's 4 MiB L2 instead of streaming 2 x 256 KB per tile from HBM.
+constexpr int STI = 8, STJ = 4;
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_syrk(double* __restrict__ S, int NP, int ktile0, int row_tile0,
+                                              int col_tile0, int n_row_tiles, int n_col_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
+  const int nSI = (n_row_tiles + STI - 1) / STI, nSJ = (n_col_tiles + STJ - 1) / STJ;
+  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3;
+  const int st = (g / (STI * STJ)) * 8 + xcd, within = g % (STI * STJ);
+  if (st >= nSI * nSJ) return;
+  const int ri = (st % nSI) * STI + (within % STI), cj = (st / nSI) * STJ + (within / STI);
+  if (ri >= n_row_tiles || cj >= n_col_tiles) return;
+  const int I = row_tile0 + ri, J = col_tile0 + cj;
+  if (I < J) return;
+  const double* Ap = S + ((int64_t)I * T) * NP + (int64_t)ktile0 * T;
+  const double* Bp = S + ((int64_t)J * T) * NP + (int64_t)ktile0 * T;
   double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int NCH = KT * T / KC;
+
+  // DMA map: one instruction = 1 KiB = 8 rows x 8 slots; instruction q of wave w fills rows 8(4w+q) .. +7;
+  // lane l -> row + l/8, stored slot l%8, which holds logical slot (l%8) ^ ((row >> 1) & 7)
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto stage = [&](int ch, int buf) {
+    char* base = smem_raw + buf * 2 * CHB;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = 8 * (4 * wave + q) + drow;
+      const int logical = dslot ^ ((row >> 1) & 7);
+      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
+      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (4 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CHB + (4 * wave + q) * 1024), 16, 0, 0);
+    }
+  };
+
+  stage(0, 0);
+  v4f64 acc[4][4];
 #pragma unroll
   for (int ti = 0; ti < 4; ti++)
 #pragma unroll
     for (int tj = 0; tj < 4; tj++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = wr * 64 + ti * 16 + lk + 4 * r;
-        const int col = wc * 64 + tj * 16 + lr;
-        double* cp = C + (int64_t)row * NP + col;
-        if (MODE == MODE_TRSM) *cp = acc[ti][tj][r];
-        else *cp -= acc[ti][tj][r];
+      for (int r = 0; r < 4; r++)
+        acc[ti][tj][r] = C[(int64_t)(wr * 64 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr];
+  __syncthreads();
+  // operand byte offsets inside a chunk: row R = 64 w + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
+  // half-wave = 16 rows x 2 halves of one slot: bank = 32 (lr & 1) + 4 (slot ^ (lr >> 1)) + 2 (lk & 1): all distinct
+  const int a_row_off = (wr * 64 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
+  const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    const int cur = ch & 1;
+    if (ch + 1 < NCH) stage(ch + 1, cur ^ 1);
+    const char* Ac = smem_raw + cur * 2 * CHB;
+    const char* Bc = Ac + CHB;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+      const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
+        b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
       }
+#pragma unroll
+      for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]);
+    }
+    __syncthreads();   // drains the DMA of chunk ch+1 (vmcnt) and fences the buffer just read
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        C[(int64_t)(wr * 64 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr] = acc[ti][tj][r];
 }
 
-void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* Dinv, double* fail) {
+long long* g_potrf_dbg = nullptr;   // debug: cycle stamps of the last k_potrf128 (see gtg_debug_potrf_stamps)
+long long* g_potrf_dbg_set(long long* p) { g_potrf_dbg = p; return p; }
+
+static inline int syrk_grid(int n_row_tiles, int n_col_tiles) {
+  const int nst = ((n_row_tiles + STI - 1) / STI) * ((n_col_tiles + STJ - 1) / STJ);
+  return ((nst + 7) / 8) * 8 * STI * STJ;
+}
+
+void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* Xinv, double* fail) {
   const int nt = NP / T, ne = extra_rows / T;
-  const size_t smem = sizeof(double) * (T * LP + T);
-  const size_t gsmem = sizeof(double) * 2 * T * PP;
+  const size_t smem_potrf = sizeof(double) * (T * P + T + SB);
+  const size_t smem_trsm = sizeof(double) * (T * P);
+  const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;
   if (!attr_set) {
-    check_hip(hipFuncSetAttribute((const void*)k_potrf_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "smem attr");
-    check_hip(hipFuncSetAttribute((const void*)k_gemm_abt<MODE_TRSM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem), "smem attr");
-    check_hip(hipFuncSetAttribute((const void*)k_gemm_abt<MODE_SYRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gsmem), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_potrf128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_potrf), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_trsm128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_trsm), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_syrk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_syrk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     attr_set = true;
   }
-  for (int k = 0; k < nt; k++) {
-    double* Dk = Dinv + (size_t)k * T * T;
-    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), smem, c.stream, S, NP, k, Dk, fail);
-    const int rows_below = (nt - 1 - k) + ne;
-    if (rows_below > 0)
-      hipLaunchKernelGGL(k_gemm_abt<MODE_TRSM>, dim3(rows_below), dim3(256), gsmem, c.stream, S, NP, k, Dk);
-    const int cols = nt - 1 - k;
-    if (cols > 0)
-      hipLaunchKernelGGL(k_gemm_abt<MODE_SYRK>, dim3(rows_below, cols), dim3(256), gsmem, c.stream, S, NP, k, Dk);
+  const int nrows = nt + ne;   // row tiles including the extra (rhs) tile
+  auto panel = [&](int k) {    // factor block column k: diagonal tile, then every row tile below
+    double* Xk = Xinv + (size_t)k * T * T;
+    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, c.stream, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
+    if (nrows - (k + 1) > 0)
+      hipLaunchKernelGGL(k_trsm128, dim3(nrows - (k + 1)), dim3(256), smem_trsm, c.stream, S, NP, k, k + 1, Xk);
+  };
+  for (int k = 0; k < nt; k += 2) {
+    panel(k);
+    if (k + 1 < nt) {
+      // thin update of block column k+1 by column k, then factor it
+      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(nrows - (k + 1), 1)), dim3(256), smem_syrk, c.stream, S, NP, k, k + 1,
+                         k + 1, nrows - (k + 1), 1);
+      panel(k + 1);
+      // big update of everything right of k+1 by both columns (K = 256)
+      if (nt - (k + 2) > 0)
+        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 2), nt - (k + 2))), dim3(256), smem_syrk, c.stream, S,
+                           NP, k, k + 2, k + 2, nrows - (k + 2), nt - (k + 2));
+    }
   }
   check_hip(hipGetLastError(), "cholesky");
 }
 
 // ---- backward solve L^T x = y -------------------------------------------------------------------------
-// Step k (descending): every workgroup recomputes x_k = Dinv_k^T y_k (128x128 GEMV, trivial) and then
-// updates its 256-column slice of y:  y[j] -= sum_r L(k*128 + r, j) x_k[r]  for j < k*128.
-__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, int NP, int k,
-                                                  const double* __restrict__ Dinv, double* __restrict__ y,
+// Step k (descending), two small launches:
+//   k_bwd_diag    one workgroup: x_k = L(k,k)^-T y_k by 4-phase block back-substitution with the 32x32
+//                 diagonal inverses, L(k,k) staged in LDS
+//   k_bwd_update  y[j] -= sum_r L(k*128 + r, j) x_k[r]  for j < k*128  (row panel read coalesced along j)
+__global__ __launch_bounds__(256) void k_bwd_diag(const double* __restrict__ S, int NP, int k,
+                                                  const double* __restrict__ Xinv, const double* __restrict__ y,
                                                   double* __restrict__ x) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Ls = reinterpret_cast<double*>(smem_raw);   // [T][T] (lanes walk along a row: no padding needed)
   __shared__ double xs[T];
-  __shared__ double ys[T];
+  __shared__ double ts[SB];
   const int tid = threadIdx.x;
-  if (tid < T) ys[tid] = y[k * T + tid];
+  const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  tile_to_lds<T>(L, NP, Ls, tid);
+  if (tid < T) xs[tid] = y[k * T + tid];
   __syncthreads();
-  if (tid < T) {
-    double acc = 0.0;   // x_k[c] = sum_{i >= c} Dinv[i][c] * y_k[i]
-    for (int i = tid; i < T; i++) acc += Dinv[i * T + tid] * ys[i];
-    xs[tid] = acc;
-    if (blockIdx.x == 0) x[k * T + tid] = acc;
+  for (int p = 3; p >= 0; p--) {
+    if (tid < SB) {      // t = y_p - sum_{q>p} L(q,p)^T x_q
+      double t = xs[SB * p + tid];
+      for (int i = SB * (p + 1); i < T; i++) t -= Ls[i * T + SB * p + tid] * xs[i];
+      ts[tid] = t;
+    }
+    __syncthreads();
+    if (tid < SB) {      // x_p = Xinv_pp^T t
+      const double* Xp = Xinv + p * SB * SB;
+      double acc = 0.0;
+      for (int i = tid; i < SB; i++) acc += Xp[i * SB + tid] * ts[i];
+      xs[SB * p + tid] = acc;
+    }
+    __syncthreads();
   }
+  if (tid < T) x[k * T + tid] = xs[tid];
+}
+
+__global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S, int NP, int k,
+                                                    const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double xs[T];
+  const int tid = threadIdx.x;
+  if (tid < T) xs[tid] = x[k * T + tid];
   __syncthreads();
   const int j = blockIdx.x * 256 + tid;
   if (j < k * T) {
     const double* Lr = S + ((int64_t)k * T) * NP + j;
-    double acc = 0.0;
-    for (int r = 0; r < T; r++) acc += Lr[(int64_t)r * NP] * xs[r];
-    y[j] -= acc;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < T; r += 4) {
+      acc0 += Lr[(int64_t)r * NP] * xs[r];
+      acc1 += Lr[(int64_t)(r + 1) * NP] * xs[r + 1];
+      acc2 += Lr[(int64_t)(r + 2) * NP] * xs[r + 2];
+      acc3 += Lr[(int64_t)(r + 3) * NP] * xs[r + 3];
+    }
+    y[j] -= (acc0 + acc1) + (acc2 + acc3);
   }
 }
 
 void launch_backward_solve(gtg_context& c, double* S, int NP, double* x) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
+  const size_t smem = sizeof(double) * (T * T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    check_hip(hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "smem attr");
+    attr_set = true;
+  }
   for (int k = nt - 1; k >= 0; k--) {
-    const int blocks = k == 0 ? 1 : (k * T + 255) / 256;
-    hipLaunchKernelGGL(k_bwd_step, dim3(blocks), dim3(256), 0, c.stream, S, NP, k, c.Dinv.p + (size_t)k * T * T, y, x);
+    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), smem, c.stream, S, NP, k, c.Dinv.p + (size_t)k * T * T, y, x);
+    if (k > 0)
+      hipLaunchKernelGGL(k_bwd_update, dim3((k * T + 255) / 256), dim3(256), 0, c.stream, S, NP, k, x, y);
   }
   check_hip(hipGetLastError(), "backward_solve");
 }

@@ -1,0 +1,97 @@
+"""The per-factor DEVICE formulas (gtsam_amd/csrc/geom.h, factors.h) compiled for the host with plain g++
+(tests/hostmath/hostmath.cpp, test infrastructure) against the oracle: catches formula slips without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gtsam_amd.problem import Problem
+from oracle import gtsam_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hm():
+    so = os.path.join(ROOT, "tests", "_build", "libhostmath.so")
+    src = os.path.join(ROOT, "tests", "hostmath", "hostmath.cpp")
+    hdrs = [os.path.join(ROOT, "gtsam_amd", "csrc", h) for h in ("geom.h", "factors.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src], check=True)
+    return C.CDLL(so)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _cams(rng, n):
+    xi = rng.normal(size=(n, 6)); xi[:, :3] *= 1.2
+    R, t = O.pose3_expmap(xi)
+    cam = np.concatenate([O.pose_pack(R, t), np.stack([rng.uniform(400, 900, n), rng.normal(0, 1e-2, n), rng.normal(0, 1e-3, n),
+                                                       rng.normal(0, 3, n), rng.normal(0, 3, n)], 1)], 1)
+    pc = np.stack([rng.normal(0, 1, n), rng.normal(0, 1, n), rng.uniform(-0.5, 8, n)], 1)   # some behind the camera
+    return cam, np.einsum("nij,nj->ni", R, pc) + t
+
+
+@pytest.mark.parametrize("nk,nd", [(0, []), (1, [0.7]), (2, [0.5, 2.0]), (3, [1.2, 0.3, 0.0, 0.8])])
+def test_sfm_factor(hm, nk, nd):
+    rng = np.random.default_rng(3); n = 500
+    cam, pw = _cams(rng, n); z = rng.normal(0, 100, (n, 2))
+    p = Problem(var_type=np.array([1, 2], np.int32)); ni = p.add_noise(nk, 2, nd)
+    W = O.noise_sqrt_info(p, ni)
+    dev_nd = np.array({0: [0.0], 1: [1.0 / nd[0]] if nk == 1 else [0], 2: list(1.0 / np.array(nd)) if nk == 2 else [0], 3: nd}[nk], float)
+    J = np.zeros((n, 26)); hm.hm_sfm_linearize(C.c_long(n), P(cam), P(pw), P(z), C.c_int(nk), P(dev_nd), P(J))
+    pi, Dc, Dp, behind = O.sfm_project(cam, pw); b = z - pi; Dc[behind] = 0; Dp[behind] = 0; b[behind] = 0
+    assert behind.sum() > 0
+    ref = np.concatenate([np.einsum("ij,njk->nik", W, Dc).reshape(n, -1), np.einsum("ij,njk->nik", W, Dp).reshape(n, -1),
+                          np.einsum("ij,nj->ni", W, b)], 1)
+    assert rel(J, ref) <= 1e-13
+    e = np.zeros(n); hm.hm_sfm_error(C.c_long(n), P(cam), P(pw), P(z), C.c_int(nk), P(dev_nd), P(e))
+    assert rel(e, 0.5 * (ref[:, 24:] ** 2).sum(1)) <= 1e-13
+
+
+def test_between_prior_retract(hm):
+    rng = np.random.default_rng(4); n = 300
+    from gtsam_amd.problem import pose_graph_problem
+    R1, t1 = O.pose3_expmap(rng.normal(size=(n, 6)) * [1.5, 1.5, 1.5, 1, 1, 1]); R2, t2 = O.pose3_expmap(rng.normal(size=(n, 6)))
+    Rz, tz = O.pose3_expmap(rng.normal(size=(n, 6)) * [1.5, 1.5, 1.5, 1, 1, 1])
+    T1, T2, Z = O.pose_pack(R1, t1), O.pose_pack(R2, t2), O.pose_pack(Rz, tz)
+    A = rng.normal(size=(6, 6)); Rn = np.ascontiguousarray(np.linalg.cholesky(A @ A.T + 6 * np.eye(6)).T)
+    J = np.zeros((n, 78)); hm.hm_between_linearize(C.c_long(n), P(T1), P(T2), P(Z), C.c_int(3), P(Rn.reshape(-1)), P(J))
+    p = pose_graph_problem(2 * n, np.arange(n), np.arange(n) + n, Z, [3] * n, np.tile(Rn.reshape(-1), (n, 1)))
+    vals = np.concatenate([T1.reshape(-1), T2.reshape(-1)])
+    assert rel(J, O.jacobians_flat(p, vals, 2)) <= 1e-11
+    e = np.zeros(n); hm.hm_between_error(C.c_long(n), P(T1), P(T2), P(Z), C.c_int(3), P(Rn.reshape(-1)), P(e))
+    assert rel(e, 0.5 * (O.jacobians_flat(p, vals, 2)[:, 72:] ** 2).sum(1)) <= 1e-11
+    # retract / local for all three value types
+    cam = np.concatenate([T1, rng.normal(size=(n, 5))], 1)
+    for vt, x, dm in ((0, T1, 6), (1, cam, 9), (2, rng.normal(size=(n, 3)), 3)):
+        d = np.ascontiguousarray(rng.normal(size=(n, dm)) * 0.4)
+        x = np.ascontiguousarray(x); y = np.zeros_like(x)
+        hm.hm_retract(C.c_int(vt), C.c_long(n), P(x), P(d), P(y))
+        pp = Problem(var_type=np.full(n, vt, np.int32))
+        assert rel(y, O.retract(pp, x.reshape(-1), d.reshape(-1)).reshape(x.shape)) <= 1e-14
+        back = np.zeros((n, dm)); hm.hm_local(C.c_int(vt), C.c_long(n), P(x), P(y), P(back))
+        assert rel(back, d) <= 1e-10
+
+
+def test_logmap_branches(hm):
+    """SO3::Logmap's three regimes (near pi by largest diagonal, acos, Taylor) against the oracle restatement."""
+    rng = np.random.default_rng(5)
+    ws = []
+    for ang in [np.pi - 1e-5, np.pi - 5e-4, np.pi - 2e-2, 3.0, 1.0, 1e-3, 1e-5, 1e-9, 0.0]:
+        for _ in range(6):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ws.append(ax * ang)
+    R = np.ascontiguousarray(O.so3_expmap(np.array(ws)))
+    w = np.zeros((R.shape[0], 3)); hm.hm_so3_logmap(C.c_long(R.shape[0]), P(R), P(w))
+    assert np.abs(w - O.so3_logmap(R)).max() <= 1e-9
+    R2 = np.zeros_like(R); wa = np.ascontiguousarray(np.array(ws)); hm.hm_so3_expmap(C.c_long(R.shape[0]), P(wa), P(R2))
+    assert np.abs(R2 - R).max() <= 1e-15

@@ -1,0 +1,89 @@
+"""GPU: the library's sharded path (n_shards = 2) on ONE device: two handles, each owning half of the landmarks,
+driven by two host threads; the all-reduce callback sums the two device buffers in place.  The combined result
+must equal the single-handle run: same delta, same errors, same LM trajectory."""
+import threading
+
+import numpy as np
+import pytest
+
+from gtsam_amd.params import LevenbergMarquardtParams as LMP
+from tests import problems as PB
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class TwoWaySum:
+    """allreduce for two handles living in one process (test plumbing only)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.slots = [None, None]
+        self.barrier = threading.Barrier(2)
+
+    def fn(self, rank):
+        from gtsam_amd.distributed import _DevicePtr
+        torch = self.torch
+
+        def allreduce(ptr, n, stream):
+            torch.cuda.synchronize()
+            self.slots[rank] = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
+            self.barrier.wait()
+            if rank == 0:
+                s = self.slots[0] + self.slots[1]
+                self.slots[0].copy_(s); self.slots[1].copy_(s)
+                torch.cuda.synchronize()
+            self.barrier.wait()
+        return allreduce
+
+
+@pytest.mark.parametrize("case", ["dubrovnik_sfmex", "bal_small_unit", "posegraph_small"])
+def test_two_shards_equal_one(case):
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+    if case == "dubrovnik_sfmex":
+        p, v0 = PB.dubrovnik_sfmexample(load_golden("dubrovnik_3_7")); params = LMP()
+    elif case == "bal_small_unit":
+        p, v0 = PB.SYNTH[case](); params = LMP.CeresDefaults()
+    else:
+        p, v0 = PB.SYNTH[case](); params = LMP()
+    single = DeviceLevenbergMarquardt(p, v0, params)
+    single.dev.linearize()
+    rc1, out1 = single.dev.try_lambda(1e-3, params.diagonalDamping)
+    d1 = single.dev.delta()
+    single.optimize()
+
+    sumr = TwoWaySum()
+    res = [None, None]
+
+    def run(rank):
+        try:
+            opt = DeviceLevenbergMarquardt(p, v0, params, shard=rank, n_shards=2, allreduce=sumr.fn(rank))
+            opt.dev.linearize()
+            rc, out = opt.dev.try_lambda(1e-3, params.diagonalDamping)
+            d = opt.dev.delta()
+            opt.optimize()
+            res[rank] = (rc, out, d, np.array(opt.trace)[:, :3], opt.values_packed())
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+            sumr.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for rc, out, d, trace, vals in res:
+        assert rc == rc1
+        assert np.abs(d - d1).max() <= 1e-9 * np.abs(d1).max()
+        assert np.allclose(out[:3], out1[:3], rtol=1e-9)
+        ref = np.array(single.trace)[:, :3]
+        assert trace.shape == ref.shape and np.array_equal(trace[:, 0], ref[:, 0])
+        assert np.abs(trace[:, 1] - ref[:, 1]).max() <= 1e-7 * np.abs(ref[:, 1]).max()
+        assert np.abs(vals - single.values_packed()).max() <= 1e-6 * np.abs(vals).max()
+    # both shards hold identical values (lock-step)
+    assert np.array_equal(res[0][4], res[1][4])

@@ -1,0 +1,281 @@
+// GpuLevenbergMarquardtOptimizer.cpp -- extractor (NonlinearFactorGraph/Values -> SoA gtg_problem) and the
+// host LM state machine around the C ABI.  See the header for the reference anchors.
+#include "GpuLevenbergMarquardtOptimizer.h"
+
+#include <gtsam/geometry/Cal3Bundler.h>
+#include <gtsam/geometry/Cal3_S2.h>
+#include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/geometry/Pose3.h>
+#include <gtsam/linear/NoiseModel.h>
+#include <gtsam/nonlinear/PriorFactor.h>
+#include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
+#include <gtsam/slam/BetweenFactor.h>
+#include <gtsam/slam/GeneralSFMFactor.h>
+#include <gtsam/slam/ProjectionFactor.h>
+
+#include <cmath>
+#include <limits>
+#include <map>
+#include <stdexcept>
+
+using namespace gtsam;
+
+namespace gtsam_amd {
+
+typedef PinholeCamera<Cal3Bundler> SfmCamera;
+typedef GeneralSFMFactor<SfmCamera, Point3> SfmFactor;
+typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
+typedef internal::LevenbergMarquardtState State;
+
+struct GpuLevenbergMarquardtOptimizer::Impl {
+  gtg_handle h = nullptr;
+  std::vector<Key> keys;                 // variable id -> Key (Values order)
+  std::map<Key, int32_t> id;             // Key -> variable id
+  std::vector<int32_t> var_type;
+  std::vector<int64_t> val_off;
+  std::vector<double> packed;            // host copy of the packed values
+  bool host_values_stale = false;
+  // device-side copies of the LM state while optimize() keeps Values on the GPU
+  double error = 0, lambda = 0, factor = 0;
+  size_t iterations = 0; int inner = 0;
+  ~Impl() { if (h) gtg_destroy(h); }
+};
+
+namespace {
+void check(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + gtg_last_error());
+}
+void packPose(const Pose3& T, double* p) {
+  const Matrix3 R = T.rotation().matrix();
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p[3 * i + j] = R(i, j);
+  p[9] = T.x(); p[10] = T.y(); p[11] = T.z();
+}
+Pose3 unpackPose(const double* p) {
+  Matrix3 R;
+  R << p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8];
+  return Pose3(Rot3(R), Point3(p[9], p[10], p[11]));
+}
+void packCamera(const SfmCamera& c, double* p) {
+  packPose(c.pose(), p);
+  p[12] = c.calibration().fx(); p[13] = c.calibration().k1(); p[14] = c.calibration().k2();
+  p[15] = c.calibration().px(); p[16] = c.calibration().py();
+}
+
+struct NoiseTable {
+  std::vector<int32_t> kind, dim; std::vector<int64_t> off; std::vector<double> data;
+  std::map<const noiseModel::Base*, int32_t> seen;
+  int32_t add(const SharedNoiseModel& nm, size_t expect_dim) {
+    if (!nm) throw std::invalid_argument("factor without a noise model is not supported");
+    auto it = seen.find(nm.get());
+    if (it != seen.end()) return it->second;
+    if (nm->dim() != expect_dim) throw std::invalid_argument("NoiseModelFactor: NoiseModel has wrong dimension");
+    const int32_t idx = (int32_t)kind.size();
+    off.push_back((int64_t)data.size()); dim.push_back((int32_t)nm->dim());
+    if (nm->isConstrained() || std::dynamic_pointer_cast<noiseModel::Robust>(nm))
+      throw std::invalid_argument("Constrained / Robust noise models are outside the GPU path");
+    if (nm->isUnit()) kind.push_back(GTG_NOISE_UNIT);
+    else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { kind.push_back(GTG_NOISE_ISOTROPIC); data.push_back(iso->sigma()); }
+    else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { kind.push_back(GTG_NOISE_DIAGONAL); for (size_t i = 0; i < dg->dim(); i++) data.push_back(dg->sigma(i)); }
+    else if (auto ga = std::dynamic_pointer_cast<noiseModel::Gaussian>(nm)) {
+      kind.push_back(GTG_NOISE_GAUSSIAN);
+      const Matrix R = ga->R();
+      for (int i = 0; i < R.rows(); i++) for (int j = 0; j < R.cols(); j++) data.push_back(R(i, j));
+    } else throw std::invalid_argument("unsupported noise model type");
+    seen[nm.get()] = idx;
+    return idx;
+  }
+};
+}  // namespace
+
+GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
+                                                               const LevenbergMarquardtParams& params, int device)
+    : LevenbergMarquardtOptimizer(graph, initial, [&] {
+        // the reference's constructor runs COLAMD when no ordering is given (LevenbergMarquardtParams.h:112-117);
+        // the device path has its own elimination structure, so hand it a trivial ordering to skip that work
+        if (params.ordering) return params;
+        LevenbergMarquardtParams p = params; p.ordering = Ordering(initial.keys()); return p; }()),
+      impl_(new Impl) { init(initial, device); }
+
+GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
+                                                               const Ordering& ordering,
+                                                               const LevenbergMarquardtParams& params, int device)
+    : LevenbergMarquardtOptimizer(graph, initial, ordering, params), impl_(new Impl) { init(initial, device); }
+
+GpuLevenbergMarquardtOptimizer::~GpuLevenbergMarquardtOptimizer() = default;
+
+void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
+  Impl& m = *impl_;
+  // ---- variables: Values order (sorted by Key, Values.h:74-79) ---------------------------------------------
+  m.val_off.push_back(0);
+  for (const auto& kv : initial) {
+    int32_t t;
+    if (dynamic_cast<const GenericValue<Pose3>*>(&kv.value)) t = GTG_VAR_POSE3;
+    else if (dynamic_cast<const GenericValue<SfmCamera>*>(&kv.value)) t = GTG_VAR_SFM_CAMERA;
+    else if (dynamic_cast<const GenericValue<Point3>*>(&kv.value)) t = GTG_VAR_POINT3;
+    else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported value type for key " + DefaultKeyFormatter(kv.key));
+    m.id[kv.key] = (int32_t)m.keys.size();
+    m.keys.push_back(kv.key); m.var_type.push_back(t);
+    m.val_off.push_back(m.val_off.back() + (t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3));
+  }
+  m.packed.assign(m.val_off.back(), 0.0);
+  for (size_t v = 0; v < m.keys.size(); v++) {
+    double* p = m.packed.data() + m.val_off[v];
+    if (m.var_type[v] == GTG_VAR_POSE3) packPose(initial.at<Pose3>(m.keys[v]), p);
+    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) packCamera(initial.at<SfmCamera>(m.keys[v]), p);
+    else { const Point3 q = initial.at<Point3>(m.keys[v]); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
+  }
+  auto idOf = [&](Key k) { auto it = m.id.find(k); if (it == m.id.end()) throw ValuesKeyDoesNotExist("GpuLevenbergMarquardtOptimizer", k); return it->second; };
+
+  // ---- factors: one pass, dynamic_cast to the supported types (anything else is a hard error) ------------------
+  NoiseTable nt;
+  std::vector<int32_t> sfm_cam, sfm_pt, sfm_nz, pj_pose, pj_pt, pj_nz, pj_cal, pj_sen, bt_1, bt_2, bt_nz, pr_var, pr_nz;
+  std::vector<double> sfm_z, pj_z, calib, sensor, bt_z, pr_data;
+  std::vector<int64_t> pr_off;
+  std::map<const Cal3_S2*, int32_t> calib_id;
+  for (const auto& f : graph_) {
+    if (!f) continue;
+    if (auto s = std::dynamic_pointer_cast<SfmFactor>(f)) {
+      sfm_cam.push_back(idOf(s->key1())); sfm_pt.push_back(idOf(s->key2()));
+      sfm_z.push_back(s->measured().x()); sfm_z.push_back(s->measured().y());
+      sfm_nz.push_back(nt.add(s->noiseModel(), 2));
+    } else if (auto p = std::dynamic_pointer_cast<ProjFactor>(f)) {
+      if (p->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
+      pj_pose.push_back(idOf(p->key1())); pj_pt.push_back(idOf(p->key2()));
+      pj_z.push_back(p->measured().x()); pj_z.push_back(p->measured().y());
+      pj_nz.push_back(nt.add(p->noiseModel(), 2));
+      const Cal3_S2* K = p->calibration().get();
+      auto it = calib_id.find(K);
+      if (it == calib_id.end()) {
+        it = calib_id.emplace(K, (int32_t)(calib.size() / 5)).first;
+        calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
+      }
+      pj_cal.push_back(it->second);
+      if (p->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*p->body_P_sensor(), sensor.data() + sensor.size() - 12); }
+      else pj_sen.push_back(-1);
+    } else if (auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {
+      bt_1.push_back(idOf(b->key1())); bt_2.push_back(idOf(b->key2()));
+      bt_z.resize(bt_z.size() + 12); packPose(b->measured(), bt_z.data() + bt_z.size() - 12);
+      bt_nz.push_back(nt.add(b->noiseModel(), 6));
+    } else if (auto pp = std::dynamic_pointer_cast<PriorFactor<Pose3>>(f)) {
+      pr_var.push_back(idOf(pp->key())); pr_off.push_back((int64_t)pr_data.size());
+      pr_data.resize(pr_data.size() + 12); packPose(pp->prior(), pr_data.data() + pr_data.size() - 12);
+      pr_nz.push_back(nt.add(pp->noiseModel(), 6));
+    } else if (auto pc = std::dynamic_pointer_cast<PriorFactor<SfmCamera>>(f)) {
+      pr_var.push_back(idOf(pc->key())); pr_off.push_back((int64_t)pr_data.size());
+      pr_data.resize(pr_data.size() + 17); packCamera(pc->prior(), pr_data.data() + pr_data.size() - 17);
+      pr_nz.push_back(nt.add(pc->noiseModel(), 9));
+    } else if (auto p3 = std::dynamic_pointer_cast<PriorFactor<Point3>>(f)) {
+      pr_var.push_back(idOf(p3->key())); pr_off.push_back((int64_t)pr_data.size());
+      pr_data.insert(pr_data.end(), {p3->prior().x(), p3->prior().y(), p3->prior().z()});
+      pr_nz.push_back(nt.add(p3->noiseModel(), 3));
+    } else {
+      throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
+                                  "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>, "
+                                  "BetweenFactor<Pose3>, PriorFactor<Pose3|SfmCamera|Point3>)");
+    }
+  }
+  gtg_problem pb{};
+  pb.n_vars = (int32_t)m.keys.size(); pb.var_type = m.var_type.data();
+  pb.n_noise = (int32_t)nt.kind.size(); pb.noise_kind = nt.kind.data(); pb.noise_dim = nt.dim.data();
+  pb.noise_off = nt.off.data(); pb.noise_data = nt.data.data();
+  pb.n_sfm = (int64_t)sfm_cam.size(); pb.sfm_cam = sfm_cam.data(); pb.sfm_point = sfm_pt.data(); pb.sfm_z = sfm_z.data(); pb.sfm_noise = sfm_nz.data();
+  pb.n_proj = (int64_t)pj_pose.size(); pb.proj_pose = pj_pose.data(); pb.proj_point = pj_pt.data(); pb.proj_z = pj_z.data();
+  pb.proj_noise = pj_nz.data(); pb.proj_calib = pj_cal.data(); pb.proj_sensor = pj_sen.data();
+  pb.n_calib = (int32_t)(calib.size() / 5); pb.calib = calib.data(); pb.n_sensor = (int32_t)(sensor.size() / 12); pb.sensor = sensor.data();
+  pb.n_between = (int64_t)bt_1.size(); pb.between_v1 = bt_1.data(); pb.between_v2 = bt_2.data(); pb.between_z = bt_z.data(); pb.between_noise = bt_nz.data();
+  pb.n_prior = (int64_t)pr_var.size(); pb.prior_var = pr_var.data(); pb.prior_off = pr_off.data(); pb.prior_data = pr_data.data(); pb.prior_noise = pr_nz.data();
+
+  check(gtg_create(&m.h, device), "gtg_create");
+  check(gtg_upload_problem(m.h, &pb, 0, 1), "gtg_upload_problem");
+  check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
+  const State* s = static_cast<const State*>(state_.get());
+  m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;
+}
+
+void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
+  Impl& m = *impl_;
+  if (!m.host_values_stale && !force) return;
+  check(gtg_get_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_get_values");
+  Values vals;
+  for (size_t v = 0; v < m.keys.size(); v++) {
+    const double* p = m.packed.data() + m.val_off[v];
+    if (m.var_type[v] == GTG_VAR_POSE3) vals.insert(m.keys[v], unpackPose(p));
+    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) vals.insert(m.keys[v], SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16])));
+    else vals.insert(m.keys[v], Point3(p[0], p[1], p[2]));
+  }
+  state_.reset(new State(std::move(vals), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
+  m.host_values_stale = false;
+}
+
+// LevenbergMarquardtOptimizer::tryLambda (LM.cpp:121-270) with solve / error / retract on the device.
+bool GpuLevenbergMarquardtOptimizer::tryLambdaDevice() {
+  Impl& m = *impl_;
+  double out[4] = {0, 0, 0, 0};
+  const int rc = gtg_try_lambda(m.h, m.lambda, params_.diagonalDamping, params_.minDiagonal, params_.maxDiagonal, out);
+  check(rc, "gtg_try_lambda");
+  bool step_is_successful = false, stopSearchingLambda = false;
+  double modelFidelity = 0.0, newError = std::numeric_limits<double>::infinity();
+  if (rc != GTG_INDETERMINATE) {   // systemSolvedSuccessfully (else: IndeterminantLinearSystemException path, LM.cpp:158-160)
+    const double oldLinearizedError = out[0], newlinearizedError = out[1];
+    const double linearizedCostChange = oldLinearizedError - newlinearizedError;
+    if (linearizedCostChange >= 0) {
+      newError = out[2];
+      const double costChange = m.error - newError;
+      if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLinearizedError) {
+        modelFidelity = costChange / linearizedCostChange;
+        step_is_successful = modelFidelity > params_.minModelFidelity;
+      }
+      const double minAbsoluteTolerance = params_.relativeErrorTol * m.error;
+      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
+    }
+  }
+  if (step_is_successful) {   // decreaseLambda, LevenbergMarquardtState.h:81-94
+    double newLambda = m.lambda, newFactor = m.factor;
+    if (params_.useFixedLambdaFactor) newLambda /= m.factor;
+    else { newLambda *= std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * modelFidelity - 1.0, 3)); newFactor = 2.0 * m.factor; }
+    m.lambda = std::max(params_.lambdaLowerBound, newLambda); m.factor = newFactor;
+    check(gtg_accept(m.h), "gtg_accept");
+    m.error = newError; m.iterations += 1; m.inner += 1; m.host_values_stale = true;
+    return true;
+  } else if (!stopSearchingLambda) {   // increaseLambda, LevenbergMarquardtState.h:70-76
+    m.lambda *= m.factor; m.inner += 1;
+    if (!params_.useFixedLambdaFactor) m.factor *= 2.0;
+    return m.lambda >= params_.lambdaUpperBound;
+  }
+  return true;
+}
+
+GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::iterate() {
+  check(gtg_linearize(impl_->h), "gtg_linearize");
+  while (!tryLambdaDevice()) {}
+  syncValuesToHost(true);   // iterate() is a public entry point: values()/error()/lambda() must be current
+  return std::make_shared<GaussianFactorGraph>();
+}
+
+const Values& GpuLevenbergMarquardtOptimizer::optimize() {
+  Impl& m = *impl_;
+  const LevenbergMarquardtParams& p = params_;
+  double currentError = m.error;
+  if (currentError <= p.errorTol || m.iterations >= p.maxIterations) return values();
+  double newError = currentError;
+  do {   // NonlinearOptimizer::defaultOptimize, NonlinearOptimizer.cpp:86-105
+    currentError = newError;
+    check(gtg_linearize(m.h), "gtg_linearize");
+    while (!tryLambdaDevice()) {}
+    newError = m.error;
+    if (p.iterationHook) { syncValuesToHost(false); p.iterationHook(m.iterations, currentError, newError); }
+  } while (m.iterations < p.maxIterations &&
+           !checkConvergence(p.relativeErrorTol, p.absoluteErrorTol, p.errorTol, currentError, newError, p.verbosity) &&
+           std::isfinite(currentError));
+  syncValuesToHost(true);
+  return values();
+}
+
+std::vector<double> GpuLevenbergMarquardtOptimizer::phaseMilliseconds() const {
+  std::vector<double> ms(GTG_PH_COUNT, 0.0);
+  std::vector<int64_t> calls(GTG_PH_COUNT, 0);
+  gtg_get_phase_ms(impl_->h, ms.data(), calls.data(), GTG_PH_COUNT);
+  return ms;
+}
+
+}  // namespace gtsam_amd

@@ -1,0 +1,50 @@
+// GpuLevenbergMarquardtOptimizer.h -- the GTSAM-side drop-in: same constructors and accessors as
+// gtsam::LevenbergMarquardtOptimizer (nonlinear/LevenbergMarquardtOptimizer.h:59-71), so user code changes
+// one type name.  GTSAM has no plugin ABI; its extension point is subclassing the optimizer
+// (NonlinearOptimizer::iterate() pure virtual nonlinear/NonlinearOptimizer.h:136; precedent
+// tests/testNonlinearOptimizer.cpp:507-551).  This class overrides iterate() / optimize() and re-states
+// tryLambda()'s decisions (LevenbergMarquardtOptimizer.cpp:121-270) around calls through the C ABI
+// (include/gtsam_amd.h) into the HIP library; the graph, the values and the lambda state machine stay host
+// C++ with GTSAM's own types.
+#pragma once
+
+#include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
+
+#include <memory>
+#include <vector>
+
+#include "../../include/gtsam_amd.h"
+
+namespace gtsam_amd {
+
+class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer {
+ public:
+  GpuLevenbergMarquardtOptimizer(const gtsam::NonlinearFactorGraph& graph, const gtsam::Values& initialValues,
+                                 const gtsam::LevenbergMarquardtParams& params = gtsam::LevenbergMarquardtParams(),
+                                 int device = 0);
+  GpuLevenbergMarquardtOptimizer(const gtsam::NonlinearFactorGraph& graph, const gtsam::Values& initialValues,
+                                 const gtsam::Ordering& ordering,
+                                 const gtsam::LevenbergMarquardtParams& params = gtsam::LevenbergMarquardtParams(),
+                                 int device = 0);
+  ~GpuLevenbergMarquardtOptimizer() override;
+
+  /// One LM iteration on the GPU; state_ (values, error, lambda, counters) is updated exactly like the
+  /// reference does.  The linearised graph is never materialised on the host: returns an empty graph.
+  gtsam::GaussianFactorGraph::shared_ptr iterate() override;
+
+  /// defaultOptimize() (nonlinear/NonlinearOptimizer.cpp:62-117) with the Values kept on the device
+  /// between iterations and synchronised to the host once at the end (and for the iteration hook).
+  const gtsam::Values& optimize() override;
+
+  /// per-phase device timings (ms, accumulated) -- names via gtg_phase_name()
+  std::vector<double> phaseMilliseconds() const;
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+  void init(const gtsam::Values& initial, int device);
+  bool tryLambdaDevice();            // LevenbergMarquardtOptimizer::tryLambda restated
+  void syncValuesToHost(bool force);
+};
+
+}  // namespace gtsam_amd

@@ -127,6 +127,15 @@ def main():
 
     if rank == 0:
         achieved = chol_flops * chol_calls / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
+        # HBM bytes per factorisation from the committed PMC passes of this same command (profiles/README.md);
+        # PMC counters cannot be collected from inside the timed run
+        traffic = None
+        try:
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_cholesky_traffic.json"))
+            if pmc and args.workload == "ladybug1723" and world == 1:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["hbm_bytes"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         out = {
             "metric": "LM iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,9 +149,9 @@ def main():
             "time_to_converged_s": ttc, "converged_error": full.error(), "converged_iterations": full.iterations(),
             "converged_inner_iterations": full.getInnerIterations(), "initial_error": full.trace[0][1],
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
-            "roofline": {"bound": "mfma", "kernel": "dense FP64 Cholesky of the reduced camera system (k_gemm_abt + k_potrf_inv, one factorisation = one launch sequence)",
+            "roofline": {"bound": "mfma", "kernel": "dense FP64 Cholesky of the reduced camera system (k_potrf128 + k_trsm128 + k_syrk, one factorisation = one launch sequence)",
                          "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_launch": chol_flops, "ms_per_launch": chol_ms / max(chol_calls, 1)},
             "roofline_linearize": {"bound": "hbm", "achieved": opt.dev.linearize_bytes() * lin_calls / max((lin_ms + asm_ms) * 1e-3, 1e-12) / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",

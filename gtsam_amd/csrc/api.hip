@@ -282,7 +282,7 @@ static void collect(gtg_context& c, std::initializer_list<int> phases) {
 
 }  // namespace gt
 
-namespace gt { long long* g_potrf_dbg_set(long long*); }
+namespace gt { long long* g_potrf_dbg_set(long long*); float debug_time_syrk(gtg_context&, double*, int, int, int, int); }
 using namespace gt;
 
 #define GTG_TRY try {
@@ -643,6 +643,19 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
 double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
+
+// debug only (not in the public header): ms per K=256 trailing update over an m x m tile grid, with ablations
+double gtg_debug_syrk_ms(gtg_handle c, int m, int abl, int reps) {
+  try {
+    check_hip(hipSetDevice(c->device), "hipSetDevice");
+    const int NP = (m + 2) * kTile;
+    DevBuf<double> S; S.alloc((size_t)NP * NP);
+    check_hip(hipMemset(S.p, 0, sizeof(double) * S.n), "memset");
+    const double ms = debug_time_syrk(*c, S.p, NP, m, abl, reps);
+    S.free();
+    return ms;
+  } catch (const std::exception& e) { g_last_error = e.what(); return -1.0; }
+}
 
 // debug only (not in the public header): cycle stamps of k_potrf128 stages on a 128x128 SPD matrix
 int gtg_debug_potrf_stamps(gtg_handle c, double* A128, long long* out15) {

@@ -19,6 +19,8 @@
 //   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles, K = 128 or 256, LDS double-buffered,
 //                v_mfma_f64_16x16x4_f64
 // MFMA is used only here (dense contraction); everything else on the path is HBM-bound.
+#include <vector>
+
 #include "kernels.h"
 
 namespace gt {
@@ -28,7 +30,10 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int T = kTile;        // 128
 constexpr int SB = 32;          // sub-block of the diagonal tile
 constexpr int P = T + 2;        // LDS pitch of a full tile: (2*P) % 64 == 4 -> MFMA operand reads conflict-free
-constexpr int PX = SB + 2;      // LDS pitch of the 32x32 inverse
+constexpr int PB = SB + 2;      // LDS pitch inside a 32x32 sub-block of the packed diagonal tile
+// The diagonal tile lives in LDS as its 10 lower 32x32 sub-blocks (87 KB instead of 133 KB) so that k_potrf128 can
+// share a CU with a k_syrk workgroup of the overlapped trailing update (look-ahead).
+__device__ __forceinline__ constexpr int boff(int ib, int cb) { return (ib * (ib + 1) / 2 + cb) * SB * PB; }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   union { double d; int i[2]; } u;
@@ -102,9 +107,10 @@ struct PotrfStep<SB> {
 };
 
 __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv,
-                                            double* __restrict__ col, int o, int lane, double* fail) {
+                                            double* __restrict__ col, int jb, int lane, double* fail) {
   const int i = lane & 31;
-  double* row = A + (o + i) * P + o;
+  const int o = SB * jb;
+  double* row = A + boff(jb, jb) + i * PB;
   double a[SB];
 #pragma unroll
   for (int c = 0; c < SB; c++) a[c] = row[c];
@@ -116,14 +122,16 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
 }
 
 // X = L_jj^-1 (used by k_trsm128 / k_bwd_step): lane c owns column c, L rows are broadcast LDS reads
-__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int o, int lane, double* Xout) {
+__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int jb, int lane, double* Xout) {
   const int i = lane & 31;
+  const int o = SB * jb;
+  const double* D = A + boff(jb, jb);
   double x[SB];
 #pragma unroll
   for (int r = 0; r < SB; r++) {
     double acc = 0.0;
 #pragma unroll
-    for (int m = 0; m < r; m++) acc += A[(o + r) * P + o + m] * x[m];
+    for (int m = 0; m < r; m++) acc += D[r * PB + m] * x[m];
     const double dr = dinv[o + r];
     x[r] = (r == i) ? dr : (r > i ? -acc * dr : 0.0);
   }
@@ -134,21 +142,24 @@ __device__ __forceinline__ void stage_inverse(const double* A, const double* din
 }
 
 // rows of sub-block (ib, jb): forward substitution x L_jj^T = a, one lane per row
-__device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int o, int ib, int lane) {
+__device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int jb, int ib, int lane) {
   const int i = lane & 31;
+  const int o = SB * jb;
+  const double* D = A + boff(jb, jb);
+  double* R = A + boff(ib, jb) + i * PB;
   double x[SB];
 #pragma unroll
-  for (int c = 0; c < SB; c++) x[c] = A[(SB * ib + i) * P + o + c];
+  for (int c = 0; c < SB; c++) x[c] = R[c];
 #pragma unroll
   for (int c = 0; c < SB; c++) {
     double acc = x[c];
 #pragma unroll
-    for (int m = 0; m < c; m++) acc -= x[m] * A[(o + c) * P + o + m];
+    for (int m = 0; m < c; m++) acc -= x[m] * D[c * PB + m];
     x[c] = acc * dinv[o + c];
   }
   if (lane < 32) {
 #pragma unroll
-    for (int c = 0; c < SB; c++) A[(SB * ib + i) * P + o + c] = x[c];
+    for (int c = 0; c < SB; c++) R[c] = x[c];
   }
 }
 
@@ -157,24 +168,38 @@ __device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int
 __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
                                                   double* __restrict__ fail, long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* A = reinterpret_cast<double*>(smem_raw);   // [T][P]
-  double* dinv = A + T * P;                           // [T]  1 / L(j,j)
+  double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
+  double* dinv = A + 10 * SB * PB;                    // [T]  1 / L(j,j)
   double* col = dinv + T;                             // [SB] column broadcast line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
   STAMP(0);
-  tile_to_lds<P>(tile, NP, A, tid);
+  {  // lower sub-blocks -> LDS: 10 blocks x 512 16-byte pieces, 20 per lane, all loads in flight before the writes
+    double2 v[20];
+#pragma unroll
+    for (int u = 0; u < 20; u++) {
+      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
+      int ib = 0, rem = blk;
+      while (rem > ib) { rem -= ib + 1; ib++; }
+      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15));
+    }
+#pragma unroll
+    for (int u = 0; u < 20; u++) {
+      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
+      double* d = A + blk * SB * PB + (w >> 4) * PB + 2 * (w & 15);
+      d[0] = v[u].x; d[1] = v[u].y;
+    }
+  }
   __syncthreads();
   STAMP(1);
 #pragma unroll 1
   for (int jb = 0; jb < 4; jb++) {
-    const int o = SB * jb;
-    if (wave == 0) stage_potrf(A, dinv, col, o, lane, fail);   // critical path
+    if (wave == 0) stage_potrf(A, dinv, col, jb, lane, fail);   // critical path
     __syncthreads();
     STAMP(2 + 3 * jb);
-    if (wave == 0) stage_inverse(A, dinv, o, lane, Xinv + (int64_t)jb * SB * SB);
-    else if (jb + wave < 4) stage_rowtrsm(A, dinv, o, jb + wave, lane);
+    if (wave == 0) stage_inverse(A, dinv, jb, lane, Xinv + (int64_t)jb * SB * SB);
+    else if (jb + wave < 4) stage_rowtrsm(A, dinv, jb, jb + wave, lane);
     __syncthreads();
     STAMP(3 + 3 * jb);
     // trailing update on the matrix cores: A(ib,cb) -= L(ib,jb) L(cb,jb)^T for jb < cb <= ib
@@ -185,44 +210,73 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
       int bi = 0, rem = blk;
       while (rem > bi) { rem -= bi + 1; bi++; }
       const int ib = jb + 1 + bi, cb = jb + 1 + rem;
+      double* Cb = A + boff(ib, cb);
+      const double* Li = A + boff(ib, jb);
+      const double* Lc = A + boff(cb, jb);
       v4f64 acc;
 #pragma unroll
-      for (int r = 0; r < 4; r++) acc[r] = A[(SB * ib + 16 * ti + lk + 4 * r) * P + SB * cb + 16 * tj + lr];
+      for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
 #pragma unroll
       for (int kk = 0; kk < SB; kk += 4) {
-        const double av = -A[(SB * ib + 16 * ti + lr) * P + o + kk + lk];
-        const double bv = A[(SB * cb + 16 * tj + lr) * P + o + kk + lk];
+        const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+        const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
         acc = MFMA(av, bv, acc);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) A[(SB * ib + 16 * ti + lk + 4 * r) * P + SB * cb + 16 * tj + lr] = acc[r];
+      for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
     }
     __syncthreads();
     STAMP(4 + 3 * jb);
   }
-#pragma unroll 8
-  for (int e = tid; e < T * (T / 2); e += 256) {
-    const int ii = e / (T / 2), j = 2 * (e % (T / 2));
+  // write back: lower sub-blocks (diagonal ones with their upper part zeroed), then zero the 6 upper sub-blocks
+#pragma unroll 4
+  for (int e = tid; e < 10 * 512; e += 256) {
+    const int blk = e >> 9, w = e & 511, r = w >> 4, c = 2 * (w & 15);
+    int ib = 0, rem = blk;
+    while (rem > ib) { rem -= ib + 1; ib++; }
+    const double* sp = A + blk * SB * PB + r * PB + c;
     double2 v;
-    v.x = (j <= ii) ? A[ii * P + j] : 0.0;
-    v.y = (j + 1 <= ii) ? A[ii * P + j + 1] : 0.0;
-    *reinterpret_cast<double2*>(tile + (int64_t)ii * NP + j) = v;
+    v.x = (ib != rem || c <= r) ? sp[0] : 0.0;
+    v.y = (ib != rem || c + 1 <= r) ? sp[1] : 0.0;
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * rem + c) = v;
+  }
+  for (int e = tid; e < 6 * 512; e += 256) {
+    const int blk = e >> 9, w = e & 511, r = w >> 4, c = 2 * (w & 15);
+    int cbk = 1, rem = blk;                       // strictly-upper blocks (ib < cb): enumerate by column block
+    while (rem >= cbk) { rem -= cbk; cbk++; }
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * rem + r) * NP + SB * cbk + c) = double2{0.0, 0.0};
   }
   STAMP(14);
 }
 
 // ---- TRSM: X = A(I,k) * L(k,k)^-T for every row tile I below the diagonal -----------------------------------
-// Rows are independent, so each wavefront owns 32 rows of the tile and never synchronises with the others.
-__global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ S, int NP, int k, int row_tile0,
+// Rows are independent: a workgroup is 2 wavefronts = 64 rows (66 KB of LDS, so it can share a CU with a k_syrk
+// workgroup of the overlapped trailing update); each wavefront owns 32 rows and never synchronises with the other.
+constexpr int TR = 64;   // rows per TRSM workgroup
+__global__ __launch_bounds__(128) void k_trsm128(double* __restrict__ S, int NP, int k, int row_tile0,
                                                  const double* __restrict__ Xinv) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* Xs = reinterpret_cast<double*>(smem_raw);   // [T][P]
-  const int I = row_tile0 + blockIdx.x;
+  double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
+  const int I = row_tile0 + (blockIdx.x >> 1), half_rows = (blockIdx.x & 1) * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  double* tile = S + ((int64_t)I * T) * NP + (int64_t)k * T;
+  double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
   const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
-  tile_to_lds<P>(tile, NP, Xs, tid);
+#pragma unroll
+  for (int e0 = 0; e0 < TR * (T / 2); e0 += 128 * 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 128 + tid;
+      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 128 + tid;
+      double* d = Xs + (e / (T / 2)) * P + 2 * (e % (T / 2));
+      d[0] = v[u].x; d[1] = v[u].y;
+    }
+  }
   __syncthreads();
   const int r0 = 32 * wave;
 #pragma unroll
@@ -292,7 +346,7 @@ __global__ __launch_bounds__(256) void k_trsm128(double* __restrict__ S, int NP,
   }
   __syncthreads();
 #pragma unroll 8
-  for (int e = tid; e < T * (T / 2); e += 256) {
+  for (int e = tid; e < TR * (T / 2); e += 128) {
     const int row = e / (T / 2), pc = e % (T / 2);
     double2 v;
     v.x = Xs[row * P + 2 * pc]; v.y = Xs[row * P + 2 * pc + 1];
@@ -322,9 +376,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // panels (3 MB at K = 256) in that XCD's 4 MiB L2 instead of streaming 2 x 256 KB per tile from HBM.
 constexpr int STI = 8, STJ = 4;
 
-template <int KT>
-__global__ __launch_bounds__(256) void k_syrk(double* __restrict__ S, int NP, int ktile0, int row_tile0,
-                                              int col_tile0, int n_row_tiles, int n_col_tiles) {
+// Wave geometry: a wavefront can keep only ONE v_mfma_f64_16x16x4_f64 in flight (measured issue interval per wave
+// 138 cycles, tools/mfma_f64_peak.hip: 36 TFLOP/s at 1 wave/SIMD, 47 at 2, 70 at 4), so the matrix pipe needs
+// >= 4 waves per SIMD: 8 wavefronts per workgroup (4x2, each 32x64 = 2x4 MFMA tiles, 64 accumulator registers),
+// two workgroups per CU.
+template <int KT, int ABL = 0>   // ABL: ablation bits for tools/ (1 no DMA, 2 no C load, 4 no C store, 8 no MFMA)
+__global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0, int row_tile0,
+                                                 int col_tile0, int n_row_tiles, int n_col_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
   const int nSI = (n_row_tiles + STI - 1) / STI, nSJ = (n_col_tiles + STJ - 1) / STJ;
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3;
@@ -339,69 +397,68 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ S, int NP, in
   double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves: rows 32 wr .., cols 64 wc ..
   const int lr = lane & 15, lk = lane >> 4;
   constexpr int NCH = KT * T / KC;
 
-  // DMA map: one instruction = 1 KiB = 8 rows x 8 slots; instruction q of wave w fills rows 8(4w+q) .. +7;
+  // DMA map: one instruction = 1 KiB = 8 rows x 8 slots; instruction q of wave w fills rows 8(2w+q) .. +7;
   // lane l -> row + l/8, stored slot l%8, which holds logical slot (l%8) ^ ((row >> 1) & 7)
   const int drow = lane >> 3, dslot = lane & 7;
   auto stage = [&](int ch, int buf) {
     char* base = smem_raw + buf * 2 * CHB;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int row = 8 * (4 * wave + q) + drow;
+    for (int q = 0; q < 2; q++) {
+      const int row = 8 * (2 * wave + q) + drow;
       const int logical = dslot ^ ((row >> 1) & 7);
       const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
       const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (4 * wave + q) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CHB + (4 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CHB + (2 * wave + q) * 1024), 16, 0, 0);
     }
   };
 
-  stage(0, 0);
-  v4f64 acc[4][4];
+  if (!(ABL & 1)) stage(0, 0);
+  v4f64 acc[2][4];
 #pragma unroll
-  for (int ti = 0; ti < 4; ti++)
+  for (int ti = 0; ti < 2; ti++)
 #pragma unroll
     for (int tj = 0; tj < 4; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        acc[ti][tj][r] = C[(int64_t)(wr * 64 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr];
+        acc[ti][tj][r] = (ABL & 2) ? 0.0 : C[(int64_t)(wr * 32 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr];
   __syncthreads();
-  // operand byte offsets inside a chunk: row R = 64 w + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
+  // operand byte offsets inside a chunk: row R = 32 wr (or 64 wc) + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
   // half-wave = 16 rows x 2 halves of one slot: bank = 32 (lr & 1) + 4 (slot ^ (lr >> 1)) + 2 (lk & 1): all distinct
-  const int a_row_off = (wr * 64 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
+  const int a_row_off = (wr * 32 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
   const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     const int cur = ch & 1;
-    if (ch + 1 < NCH) stage(ch + 1, cur ^ 1);
+    if (ch + 1 < NCH && !(ABL & 1)) stage(ch + 1, cur ^ 1);
     const char* Ac = smem_raw + cur * 2 * CHB;
     const char* Bc = Ac + CHB;
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 4) {
       const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-      double a[4], b[4];
+      double a[2], b[4];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
-        b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
-      }
+      for (int t = 0; t < 2; t++) a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
 #pragma unroll
-      for (int ti = 0; ti < 4; ti++)
+      for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]);
+      for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) { if (ABL & 8) acc[ti][tj][0] += a[ti] * b[tj]; else acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]); }
     }
     __syncthreads();   // drains the DMA of chunk ch+1 (vmcnt) and fences the buffer just read
   }
 #pragma unroll
-  for (int ti = 0; ti < 4; ti++)
+  for (int ti = 0; ti < 2; ti++)
 #pragma unroll
     for (int tj = 0; tj < 4; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        C[(int64_t)(wr * 64 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr] = acc[ti][tj][r];
+        if (!(ABL & 4) || acc[ti][tj][r] == 123.456) C[(int64_t)(wr * 32 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr] = acc[ti][tj][r];
 }
 
 long long* g_potrf_dbg = nullptr;   // debug: cycle stamps of the last k_potrf128 (see gtg_debug_potrf_stamps)
@@ -412,10 +469,24 @@ static inline int syrk_grid(int n_row_tiles, int n_col_tiles) {
   return ((nst + 7) / 8) * 8 * STI * STJ;
 }
 
+// Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1):
+//   panel stream : potrf(k) trsm(k) | thin update of column k+1 | potrf(k+1) trsm(k+1)        -> event P[p]
+//   update stream: wait P[p]; update of the NEXT pair's two columns (k+2, k+3) by pair p        -> event N[p]
+//                  update of everything right of k+3 by pair p (the bulk of the flops)
+//   panel stream : wait N[p]; pair p+1's panel chain, concurrent with the bulk update of pair p.
+// k_potrf128 (87 KB LDS) and k_trsm128 (66 KB) fit next to one k_syrk workgroup (64 KB) on a CU, and the panel
+// stream has higher priority, so the serial panel chain is hidden behind the update instead of alternating with it.
+struct CholStreams {
+  hipStream_t panel = nullptr;
+  std::vector<hipEvent_t> P, N;
+  hipEvent_t start = nullptr;
+};
+static CholStreams g_cs;
+
 void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* Xinv, double* fail) {
   const int nt = NP / T, ne = extra_rows / T;
-  const size_t smem_potrf = sizeof(double) * (T * P + T + SB);
-  const size_t smem_trsm = sizeof(double) * (T * P);
+  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + SB);
+  const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;
   if (!attr_set) {
@@ -425,27 +496,80 @@ void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* 
     check_hip(hipFuncSetAttribute((const void*)k_syrk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     attr_set = true;
   }
+  const int npairs = (nt + 1) / 2;
+  if (!g_cs.panel) {
+    int lo = 0, hi = 0;
+    check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
+    check_hip(hipStreamCreateWithPriority(&g_cs.panel, hipStreamNonBlocking, hi), "panel stream");
+    check_hip(hipEventCreateWithFlags(&g_cs.start, hipEventDisableTiming), "event");
+  }
+  while ((int)g_cs.P.size() < npairs) {
+    hipEvent_t e1, e2;
+    check_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "event");
+    g_cs.P.push_back(e1); g_cs.N.push_back(e2);
+  }
+  hipStream_t su = c.stream, sp = g_cs.panel;
   const int nrows = nt + ne;   // row tiles including the extra (rhs) tile
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every row tile below
     double* Xk = Xinv + (size_t)k * T * T;
-    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, c.stream, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
+    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
     if (nrows - (k + 1) > 0)
-      hipLaunchKernelGGL(k_trsm128, dim3(nrows - (k + 1)), dim3(256), smem_trsm, c.stream, S, NP, k, k + 1, Xk);
+      hipLaunchKernelGGL(k_trsm128, dim3(2 * (nrows - (k + 1))), dim3(128), smem_trsm, sp, S, NP, k, k + 1, Xk);
   };
-  for (int k = 0; k < nt; k += 2) {
+  // everything queued on the update stream so far (building S) must precede the first panel
+  check_hip(hipEventRecord(g_cs.start, su), "record");
+  check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
+  for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
+    if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.N[pi - 1], 0), "wait");
     panel(k);
     if (k + 1 < nt) {
-      // thin update of block column k+1 by column k, then factor it
-      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(nrows - (k + 1), 1)), dim3(256), smem_syrk, c.stream, S, NP, k, k + 1,
+      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(nrows - (k + 1), 1)), dim3(512), smem_syrk, sp, S, NP, k, k + 1,
                          k + 1, nrows - (k + 1), 1);
       panel(k + 1);
-      // big update of everything right of k+1 by both columns (K = 256)
-      if (nt - (k + 2) > 0)
-        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 2), nt - (k + 2))), dim3(256), smem_syrk, c.stream, S,
-                           NP, k, k + 2, k + 2, nrows - (k + 2), nt - (k + 2));
+    }
+    check_hip(hipEventRecord(g_cs.P[pi], sp), "record");
+    check_hip(hipStreamWaitEvent(su, g_cs.P[pi], 0), "wait");
+    const int rest = nt - (k + 2);           // column tiles right of the pair
+    if (k + 1 < nt && rest > 0) {
+      const int narrow = rest < 2 ? rest : 2;
+      hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 2), narrow)), dim3(512), smem_syrk, su, S, NP, k, k + 2,
+                         k + 2, nrows - (k + 2), narrow);
+      check_hip(hipEventRecord(g_cs.N[pi], su), "record");
+      if (rest > narrow)
+        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 4), rest - narrow)), dim3(512), smem_syrk, su, S, NP,
+                           k, k + 4, k + 4, nrows - (k + 4), rest - narrow);
+    } else {
+      check_hip(hipEventRecord(g_cs.N[pi], su), "record");
     }
   }
   check_hip(hipGetLastError(), "cholesky");
+}
+
+// debug (tools/syrk_ablation.py): time `reps` launches of the K=256 update over an m x m tile grid with ablations
+float debug_time_syrk(gtg_context& c, double* S, int NP, int m, int abl, int reps) {
+  const size_t smem_syrk = 4 * (size_t)CHB;
+  auto set = [&](const void* f) { check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr"); };
+  set((const void*)k_syrk<2, 0>); set((const void*)k_syrk<2, 1>); set((const void*)k_syrk<2, 3>); set((const void*)k_syrk<2, 7>); set((const void*)k_syrk<2, 6>); set((const void*)k_syrk<2, 15>);
+  hipEvent_t e0, e1;
+  check_hip(hipEventCreate(&e0), "event"); check_hip(hipEventCreate(&e1), "event");
+  const dim3 grid(syrk_grid(m, m)), blk(512);
+  check_hip(hipEventRecord(e0, c.stream), "record");
+  for (int r = 0; r < reps; r++) {
+    switch (abl) {
+      case 0: hipLaunchKernelGGL((k_syrk<2, 0>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      case 1: hipLaunchKernelGGL((k_syrk<2, 1>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      case 3: hipLaunchKernelGGL((k_syrk<2, 3>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      case 6: hipLaunchKernelGGL((k_syrk<2, 6>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      case 7: hipLaunchKernelGGL((k_syrk<2, 7>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      default: hipLaunchKernelGGL((k_syrk<2, 15>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+    }
+  }
+  check_hip(hipEventRecord(e1, c.stream), "record"); check_hip(hipStreamSynchronize(c.stream), "sync");
+  float ms = 0;
+  check_hip(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ms / reps;
 }
 
 // ---- backward solve L^T x = y -------------------------------------------------------------------------
@@ -456,24 +580,48 @@ void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* 
 __global__ __launch_bounds__(256) void k_bwd_diag(const double* __restrict__ S, int NP, int k,
                                                   const double* __restrict__ Xinv, const double* __restrict__ y,
                                                   double* __restrict__ x) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* Ls = reinterpret_cast<double*>(smem_raw);   // [T][T] (lanes walk along a row: no padding needed)
+  // only the 6 strictly-lower 32x32 sub-blocks of L(k,k) and the 4 diagonal inverses are needed (80 KB)
+  __shared__ double Ls[6 * SB * SB];    // sub-block (q,p), q > p, at index q(q-1)/2 + p, row-major [i][c]
+  __shared__ double Xs[4 * SB * SB];
   __shared__ double xs[T];
   __shared__ double ts[SB];
   const int tid = threadIdx.x;
   const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
-  tile_to_lds<T>(L, NP, Ls, tid);
+  {  // 6 x 512 + 4 x 512 16-byte pieces = 5120 -> 20 per lane, all in flight before the LDS writes
+    double2 v[20];
+#pragma unroll
+    for (int u = 0; u < 20; u++) {
+      const int e = u * 256 + tid, blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
+      if (blk < 6) {
+        int q = 1, rem = blk;
+        while (rem >= q) { rem -= q; q++; }
+        v[u] = *reinterpret_cast<const double2*>(L + (int64_t)(SB * q + r) * NP + SB * rem + c2);
+      } else {
+        v[u] = *reinterpret_cast<const double2*>(Xinv + (blk - 6) * SB * SB + r * SB + c2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 20; u++) {
+      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
+      double* d = (blk < 6 ? Ls + blk * SB * SB : Xs + (blk - 6) * SB * SB) + 2 * w;
+      d[0] = v[u].x; d[1] = v[u].y;
+    }
+  }
   if (tid < T) xs[tid] = y[k * T + tid];
   __syncthreads();
   for (int p = 3; p >= 0; p--) {
     if (tid < SB) {      // t = y_p - sum_{q>p} L(q,p)^T x_q
       double t = xs[SB * p + tid];
-      for (int i = SB * (p + 1); i < T; i++) t -= Ls[i * T + SB * p + tid] * xs[i];
+      for (int q = p + 1; q < 4; q++) {
+        const double* Lb = Ls + (q * (q - 1) / 2 + p) * SB * SB;
+#pragma unroll 8
+        for (int i = 0; i < SB; i++) t -= Lb[i * SB + tid] * xs[SB * q + i];
+      }
       ts[tid] = t;
     }
     __syncthreads();
     if (tid < SB) {      // x_p = Xinv_pp^T t
-      const double* Xp = Xinv + p * SB * SB;
+      const double* Xp = Xs + p * SB * SB;
       double acc = 0.0;
       for (int i = tid; i < SB; i++) acc += Xp[i * SB + tid] * ts[i];
       xs[SB * p + tid] = acc;
@@ -483,40 +631,44 @@ __global__ __launch_bounds__(256) void k_bwd_diag(const double* __restrict__ S, 
   if (tid < T) x[k * T + tid] = xs[tid];
 }
 
+// y[j] -= sum_r L(k*128 + r, j) x_k[r]: a workgroup owns 64 columns, its 4 waves split the 128 rows and are
+// combined through LDS in wave order (deterministic)
 __global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S, int NP, int k,
                                                     const double* __restrict__ x, double* __restrict__ y) {
   __shared__ double xs[T];
-  const int tid = threadIdx.x;
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
   if (tid < T) xs[tid] = x[k * T + tid];
   __syncthreads();
-  const int j = blockIdx.x * 256 + tid;
+  const int j = blockIdx.x * 64 + c;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   if (j < k * T) {
-    const double* Lr = S + ((int64_t)k * T) * NP + j;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < T; r += 4) {
-      acc0 += Lr[(int64_t)r * NP] * xs[r];
-      acc1 += Lr[(int64_t)(r + 1) * NP] * xs[r + 1];
-      acc2 += Lr[(int64_t)(r + 2) * NP] * xs[r + 2];
-      acc3 += Lr[(int64_t)(r + 3) * NP] * xs[r + 3];
+    const double* Lr = S + ((int64_t)k * T + 32 * g) * NP + j;
+#pragma unroll
+    for (int r = 0; r < 32; r += 4) {
+      acc0 += Lr[(int64_t)r * NP] * xs[32 * g + r];
+      acc1 += Lr[(int64_t)(r + 1) * NP] * xs[32 * g + r + 1];
+      acc2 += Lr[(int64_t)(r + 2) * NP] * xs[32 * g + r + 2];
+      acc3 += Lr[(int64_t)(r + 3) * NP] * xs[32 * g + r + 3];
     }
-    y[j] -= (acc0 + acc1) + (acc2 + acc3);
   }
+  part[g][c] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (g == 0 && j < k * T) y[j] -= ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
 }
 
 void launch_backward_solve(gtg_context& c, double* S, int NP, double* x) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
-  const size_t smem = sizeof(double) * (T * T);
   static bool attr_set = false;
-  if (!attr_set) {
-    check_hip(hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), "smem attr");
+  if (!attr_set) {   // 80 KB + of static LDS
+    check_hip(hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 0), "smem attr");
     attr_set = true;
   }
   for (int k = nt - 1; k >= 0; k--) {
-    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), smem, c.stream, S, NP, k, c.Dinv.p + (size_t)k * T * T, y, x);
+    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), 0, c.stream, S, NP, k, c.Dinv.p + (size_t)k * T * T, y, x);
     if (k > 0)
-      hipLaunchKernelGGL(k_bwd_update, dim3((k * T + 255) / 256), dim3(256), 0, c.stream, S, NP, k, x, y);
+      hipLaunchKernelGGL(k_bwd_update, dim3((k * T + 63) / 64), dim3(256), 0, c.stream, S, NP, k, x, y);
   }
   check_hip(hipGetLastError(), "backward_solve");
 }

@@ -6,7 +6,11 @@
 // try (inference/VariableIndex-inl.h:27-49, EliminationTree-inst.h:77-155, JunctionTree-inst.h:63-151,
 // linear/Scatter.cpp:39-73).  All arithmetic of the hot path runs in the HIP kernels.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -64,8 +68,32 @@ template <class T> static void up(DevBuf<T>& b, const std::vector<T>& v, hipStre
   if (v.empty()) b.alloc(1);  // keep kernels' pointer arguments non-null
 }
 
+struct StageClock {   // GTG_DEBUG_TIMING=1 prints the host-side setup breakdown
+  bool on = std::getenv("GTG_DEBUG_TIMING") != nullptr;
+  std::chrono::high_resolution_clock::time_point t = std::chrono::high_resolution_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::high_resolution_clock::now();
+    std::fprintf(stderr, "[gtsam_amd setup] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
+template <class F> static void parallel_for(int64_t n, int max_threads, F f) {
+  int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), max_threads);
+  if (n < 4096 || nt <= 1) { f(0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; t++) {
+    const int64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b < e) th.emplace_back([=] { f(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
+
 // ---- symbolic analysis ------------------------------------------------------------------------------
 static void analyze(gtg_context& c) {
+  StageClock clk;
   HostIndex& hi = host_index(&c);
   const int nv = c.n_vars;
   const int64_t n_sfm = c.f.n_sfm, n_proj = c.f.n_proj, n_btw = c.f.n_between, n_pri = c.f.n_prior;
@@ -175,35 +203,58 @@ static void analyze(gtg_context& c) {
   hoff_ptr.push_back(n_btw);
   c.n_hoff = (int64_t)hoff_row.size();
 
-  // Schur block pairs: for every landmark, every pair of its observations
-  struct PT { int64_t key; int32_t oa, ob; };
-  std::vector<PT> pt;
-  { int64_t total = 0;
-    for (int l = 0; l < c.n_lm; l++) { const int64_t k = lm_obs_ptr[l + 1] - lm_obs_ptr[l]; total += k * (k + 1) / 2; }
-    pt.reserve(total); }
-  for (int l = 0; l < c.n_lm; l++) {
-    for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++)
-      for (int64_t b = lm_obs_ptr[l]; b <= a; b++) {
-        int32_t oa = lm_obs[a], ob = lm_obs[b];
-        int pa = c.h_red_pos[obs_red[oa]], pb = c.h_red_pos[obs_red[ob]];
-        if (pa < pb) { std::swap(oa, ob); std::swap(pa, pb); }
-        pt.push_back(PT{(int64_t)pa * c.n_red_vars + pb, oa, ob});
-        if (pa == pb && oa != ob) pt.push_back(PT{(int64_t)pa * c.n_red_vars + pb, ob, oa});  // same camera twice
-      }
+  clk.lap("incidence lists");
+  // Schur block pairs: for every landmark, every pair of its observations.  Terms are bucketed by the row
+  // position of the block (counting sort), then each row bucket is sorted by column position (stable: the
+  // generation order = landmark order is kept inside a block, so the summation order is reproducible).
+  struct PT { int32_t pb, oa, ob; };
+  const int nrv = c.n_red_vars;
+  std::vector<int64_t> row_ptr(nrv + 1, 0);
+  auto for_terms = [&](auto&& emit) {
+    for (int l = 0; l < c.n_lm; l++)
+      for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++)
+        for (int64_t b = lm_obs_ptr[l]; b <= a; b++) {
+          int32_t oa = lm_obs[a], ob = lm_obs[b];
+          int pa = c.h_red_pos[obs_red[oa]], pb = c.h_red_pos[obs_red[ob]];
+          if (pa < pb) { std::swap(oa, ob); std::swap(pa, pb); }
+          emit(pa, pb, oa, ob);
+          if (pa == pb && oa != ob) emit(pa, pb, ob, oa);   // same camera twice
+        }
+  };
+  for_terms([&](int pa, int, int32_t, int32_t) { row_ptr[pa + 1]++; });
+  for (int r = 0; r < nrv; r++) row_ptr[r + 1] += row_ptr[r];
+  std::vector<PT> pt(row_ptr[nrv]);
+  { std::vector<int64_t> w(row_ptr.begin(), row_ptr.end() - 1);
+    for_terms([&](int pa, int pb, int32_t oa, int32_t ob) { pt[w[pa]++] = PT{pb, oa, ob}; }); }
+  clk.lap("schur terms bucketed");
+  {  // counting sort by column position inside every row bucket (stable, O(terms))
+    std::vector<PT> tmp;
+    std::vector<int64_t> cnt(nrv + 1, 0);
+    for (int r = 0; r < nrv; r++) {
+      const int64_t b = row_ptr[r], e = row_ptr[r + 1], m = e - b;
+      if (m < 2) continue;
+      tmp.assign(pt.begin() + b, pt.begin() + e);
+      for (int64_t i = 0; i < m; i++) cnt[tmp[i].pb + 1]++;
+      for (int q = 0; q <= r; q++) cnt[q + 1] += cnt[q];          // columns of row r are <= r
+      for (int64_t i = 0; i < m; i++) pt[b + cnt[tmp[i].pb]++] = tmp[i];
+      std::fill(cnt.begin(), cnt.begin() + r + 2, 0);
+    }
   }
-  std::stable_sort(pt.begin(), pt.end(), [](const PT& a, const PT& b) { return a.key < b.key; });
+  clk.lap("schur terms sorted");
   std::vector<int32_t> pair_row, pair_col, pair_oa(pt.size()), pair_ob(pt.size());
   std::vector<int64_t> pair_ptr;
-  for (size_t i = 0; i < pt.size(); i++) {
-    if (i == 0 || pt[i].key != pt[i - 1].key) {
-      pair_ptr.push_back((int64_t)i);
-      pair_row.push_back(pos_to_red[pt[i].key / c.n_red_vars]);
-      pair_col.push_back(pos_to_red[pt[i].key % c.n_red_vars]);
+  for (int r = 0; r < nrv; r++)
+    for (int64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++) {
+      if (i == row_ptr[r] || pt[i].pb != pt[i - 1].pb) {
+        pair_ptr.push_back(i);
+        pair_row.push_back(pos_to_red[r]);
+        pair_col.push_back(pos_to_red[pt[i].pb]);
+      }
+      pair_oa[i] = pt[i].oa; pair_ob[i] = pt[i].ob;
     }
-    pair_oa[i] = pt[i].oa; pair_ob[i] = pt[i].ob;
-  }
   pair_ptr.push_back((int64_t)pt.size());
   c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = (int64_t)pt.size();
+  clk.lap("schur block list");
 
   // ---- upload -----------------------------------------------------------------------------------
   up(c.lm_var, c.h_lm_var, s); up(c.red_var, c.h_red_var, s); up(c.red_dim, c.h_red_dim, s);
@@ -235,6 +286,7 @@ static void analyze(gtg_context& c) {
   check_hip(hipMemsetAsync(c.xred.p, 0, sizeof(double) * NP, s), "memset");
   check_hip(hipMemsetAsync(c.delta_lm.p, 0, sizeof(double) * c.delta_lm.n, s), "memset");
   check_hip(hipStreamSynchronize(s), "sync");
+  clk.lap("upload + device buffers");
 
   const double n = (double)c.n_red;
   c.chol_flops = n * n * n / 3.0;

@@ -19,6 +19,8 @@
 //   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles, K = 128 or 256, LDS double-buffered,
 //                v_mfma_f64_16x16x4_f64
 // MFMA is used only here (dense contraction); everything else on the path is HBM-bound.
+#include <algorithm>
+#include <stdexcept>
 #include <vector>
 
 #include "kernels.h"
@@ -253,11 +255,11 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
 // Rows are independent: a workgroup is 2 wavefronts = 64 rows (66 KB of LDS, so it can share a CU with a k_syrk
 // workgroup of the overlapped trailing update); each wavefront owns 32 rows and never synchronises with the other.
 constexpr int TR = 64;   // rows per TRSM workgroup
-__global__ __launch_bounds__(128) void k_trsm128(double* __restrict__ S, int NP, int k, int row_tile0,
-                                                 const double* __restrict__ Xinv) {
+__global__ __launch_bounds__(128) void k_trsm128(double* __restrict__ S, int NP, int k,
+                                                 const int32_t* __restrict__ rows, const double* __restrict__ Xinv) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
-  const int I = row_tile0 + (blockIdx.x >> 1), half_rows = (blockIdx.x & 1) * TR;
+  const int I = rows[blockIdx.x >> 1], half_rows = (blockIdx.x & 1) * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
@@ -371,9 +373,10 @@ constexpr int NSLOT = KC / 2;     // 16-byte slots per row (8)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); each XCD walks its own
-// sequence of 8x4-tile supertiles, so the 32 workgroups resident on one XCD share 8 row panels + 4 column
-// panels (3 MB at K = 256) in that XCD's 4 MiB L2 instead of streaming 2 x 256 KB per tile from HBM.
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md).  The host emits the (I,J) tile list
+// of an update in 8x4-tile supertile order; each XCD takes one contiguous eighth of that list, so the 32
+// workgroups resident on one XCD share a few row/column panels in that XCD's 4 MiB L2 instead of streaming
+// 2 x 256 KB per tile from HBM.
 constexpr int STI = 8, STJ = 4;
 
 // Wave geometry: a wavefront can keep only ONE v_mfma_f64_16x16x4_f64 in flight (measured issue interval per wave
@@ -381,17 +384,13 @@ constexpr int STI = 8, STJ = 4;
 // >= 4 waves per SIMD: 8 wavefronts per workgroup (4x2, each 32x64 = 2x4 MFMA tiles, 64 accumulator registers),
 // two workgroups per CU.
 template <int KT, int ABL = 0>   // ABL: ablation bits for tools/ (1 no DMA, 2 no C load, 4 no C store, 8 no MFMA)
-__global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0, int row_tile0,
-                                                 int col_tile0, int n_row_tiles, int n_col_tiles) {
+__global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0,
+                                                 const int32_t* __restrict__ pairs, int npairs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
-  const int nSI = (n_row_tiles + STI - 1) / STI, nSJ = (n_col_tiles + STJ - 1) / STJ;
-  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3;
-  const int st = (g / (STI * STJ)) * 8 + xcd, within = g % (STI * STJ);
-  if (st >= nSI * nSJ) return;
-  const int ri = (st % nSI) * STI + (within % STI), cj = (st / nSI) * STJ + (within / STI);
-  if (ri >= n_row_tiles || cj >= n_col_tiles) return;
-  const int I = row_tile0 + ri, J = col_tile0 + cj;
-  if (I < J) return;
+  const int nper = (npairs + 7) >> 3;
+  const int idx = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= nper || idx >= npairs) return;
+  const int I = pairs[2 * idx], J = pairs[2 * idx + 1];
   const double* Ap = S + ((int64_t)I * T) * NP + (int64_t)ktile0 * T;
   const double* Bp = S + ((int64_t)J * T) * NP + (int64_t)ktile0 * T;
   double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
@@ -464,16 +463,102 @@ __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP,
 long long* g_potrf_dbg = nullptr;   // debug: cycle stamps of the last k_potrf128 (see gtg_debug_potrf_stamps)
 long long* g_potrf_dbg_set(long long* p) { g_potrf_dbg = p; return p; }
 
-static inline int syrk_grid(int n_row_tiles, int n_col_tiles) {
-  const int nst = ((n_row_tiles + STI - 1) / STI) * ((n_col_tiles + STJ - 1) / STJ);
-  return ((nst + 7) / 8) * 8 * STI * STJ;
+static inline int syrk_grid(int64_t npairs) { return (int)(((npairs + 7) / 8) * 8); }
+
+// ---- host: tile schedule ------------------------------------------------------------------------------------
+// Symbolic factorisation at the granularity of 256-wide column pairs (the unit the trailing update contracts
+// over), then the per-pair tile lists.  This is the reduced system's elimination structure: what the reference
+// rebuilds as EliminationTree + JunctionTree on every lambda try (inference/EliminationTree-inst.h:77-155,
+// JunctionTree-inst.h:63-151), computed once here.
+void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t stream) {
+  const int np = (nt + 1) / 2;
+  std::vector<uint8_t> B((size_t)np * np, 0);
+  for (int q = 0; q < np; q++)
+    for (int p = 0; p <= q; p++) B[(size_t)q * np + p] = pair_struct ? (*pair_struct)[(size_t)q * np + p] : 1;
+  for (int p = 0; p < np; p++) B[(size_t)p * np + p] = 1;
+  for (int p = 0; p < np; p++) {   // symbolic elimination: the rows of column p become a clique
+    std::vector<int> r;
+    for (int q = p + 1; q < np; q++) if (B[(size_t)q * np + p]) r.push_back(q);
+    for (size_t a = 0; a < r.size(); a++)
+      for (size_t b = 0; b <= a; b++) B[(size_t)r[a] * np + r[b]] = 1;
+  }
+  auto tiles_of = [&](int q, std::vector<int32_t>& out) { out.push_back(2 * q); if (2 * q + 1 < nt) out.push_back(2 * q + 1); };
+  std::vector<int32_t> rows, pairs, bcols;
+  plan.nt = nt;
+  plan.trsm_off.assign(nt, 0); plan.trsm_cnt.assign(nt, 0);
+  plan.s1_off.assign(np, 0); plan.s1_cnt.assign(np, 0); plan.nar_off.assign(np, 0); plan.nar_cnt.assign(np, 0);
+  plan.rest_off.assign(np, 0); plan.rest_cnt.assign(np, 0);
+  plan.bwd_off.assign(nt, 0); plan.bwd_cnt.assign(nt, 0);
+  const double t3 = (double)T * T * T;
+  double flops = 0.0; int64_t stored = 0;
+  auto emit_pairs = [&](std::vector<std::pair<int32_t, int32_t>>& v, int64_t& off, int64_t& cnt) {
+    // supertile order: (J / STJ, I / STI, J % STJ, I % STI)
+    std::sort(v.begin(), v.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+      const int64_t ka = (((int64_t)(a.second / STJ) * 65536 + a.first / STI) * STJ + a.second % STJ) * STI + a.first % STI;
+      const int64_t kb = (((int64_t)(b.second / STJ) * 65536 + b.first / STI) * STJ + b.second % STJ) * STI + b.first % STI;
+      return ka < kb; });
+    off = (int64_t)pairs.size() / 2; cnt = (int64_t)v.size();
+    for (auto& ij : v) { pairs.push_back(ij.first); pairs.push_back(ij.second); }
+  };
+  for (int p = 0; p < np; p++) {
+    const int k = 2 * p; const bool two = k + 1 < nt;
+    std::vector<int32_t> R;
+    for (int q = p + 1; q < np; q++) if (B[(size_t)q * np + p]) tiles_of(q, R);
+    stored += (two ? 3 : 1) + (int64_t)R.size() * (two ? 2 : 1);
+    // column k: rows below = [k+1] + R + [rhs]
+    plan.trsm_off[k] = (int64_t)rows.size();
+    if (two) rows.push_back(k + 1);
+    rows.insert(rows.end(), R.begin(), R.end()); rows.push_back(nt);
+    plan.trsm_cnt[k] = (int64_t)rows.size() - plan.trsm_off[k];
+    flops += t3 / 3.0 + (double)(plan.trsm_cnt[k] - 1) * t3;
+    if (two) {
+      std::vector<std::pair<int32_t, int32_t>> s1;
+      s1.emplace_back(k + 1, k + 1);
+      for (int32_t I : R) s1.emplace_back(I, k + 1);
+      s1.emplace_back(nt, k + 1);
+      emit_pairs(s1, plan.s1_off[p], plan.s1_cnt[p]);
+      flops += (double)(plan.s1_cnt[p] - 1) * 2.0 * t3;
+      plan.trsm_off[k + 1] = (int64_t)rows.size();
+      rows.insert(rows.end(), R.begin(), R.end()); rows.push_back(nt);
+      plan.trsm_cnt[k + 1] = (int64_t)rows.size() - plan.trsm_off[k + 1];
+      flops += t3 / 3.0 + (double)(plan.trsm_cnt[k + 1] - 1) * t3;
+    }
+    std::vector<std::pair<int32_t, int32_t>> nar, rest;
+    for (size_t b = 0; b < R.size(); b++) {
+      const int32_t J = R[b];
+      auto& dst = (J / 2 == p + 1) ? nar : rest;
+      for (size_t a = b; a < R.size(); a++) dst.emplace_back(R[a], J);
+      dst.emplace_back(nt, J);
+    }
+    emit_pairs(nar, plan.nar_off[p], plan.nar_cnt[p]);
+    emit_pairs(rest, plan.rest_off[p], plan.rest_cnt[p]);
+    const double kk = two ? 2.0 : 1.0;
+    flops += (double)((int64_t)R.size() * ((int64_t)R.size() + 1) / 2) * 2.0 * t3 * kk;   // rhs row excluded
+  }
+  for (int kt = 0; kt < nt; kt++) {   // backward solve: non-zero column tiles of row tile kt
+    plan.bwd_off[kt] = (int64_t)bcols.size();
+    const int q = kt / 2;
+    for (int p = 0; p < q; p++) if (B[(size_t)q * np + p]) tiles_of(p, bcols);
+    if (kt & 1) bcols.push_back(kt - 1);
+    plan.bwd_cnt[kt] = (int64_t)bcols.size() - plan.bwd_off[kt];
+  }
+  plan.flops = flops;
+  plan.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
+  if (rows.empty()) rows.push_back(0);
+  if (pairs.empty()) { pairs.push_back(0); pairs.push_back(0); }
+  if (bcols.empty()) bcols.push_back(0);
+  plan.rows.upload(rows.data(), rows.size(), stream);
+  plan.pairs.upload(pairs.data(), pairs.size(), stream);
+  plan.bcols.upload(bcols.data(), bcols.size(), stream);
+  check_hip(hipStreamSynchronize(stream), "plan upload");
 }
 
 // Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1):
 //   panel stream : potrf(k) trsm(k) | thin update of column k+1 | potrf(k+1) trsm(k+1)        -> event P[p]
 //   update stream: wait P[p]; update of the NEXT pair's two columns (k+2, k+3) by pair p        -> event N[p]
-//                  update of everything right of k+3 by pair p (the bulk of the flops)
+//                  update of the other stored tiles right of k+3 by pair p (the bulk of the flops)
 //   panel stream : wait N[p]; pair p+1's panel chain, concurrent with the bulk update of pair p.
+// (Earlier pairs' contributions to pair p+1's columns sit on the in-order update stream before N[p].)
 // k_potrf128 (87 KB LDS) and k_trsm128 (66 KB) fit next to one k_syrk workgroup (64 KB) on a CU, and the panel
 // stream has higher priority, so the serial panel chain is hidden behind the update instead of alternating with it.
 struct CholStreams {
@@ -483,8 +568,9 @@ struct CholStreams {
 };
 static CholStreams g_cs;
 
-void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* Xinv, double* fail) {
-  const int nt = NP / T, ne = extra_rows / T;
+void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
+  const int nt = NP / T;
+  if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
   const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + SB);
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
@@ -510,12 +596,13 @@ void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* 
     g_cs.P.push_back(e1); g_cs.N.push_back(e2);
   }
   hipStream_t su = c.stream, sp = g_cs.panel;
-  const int nrows = nt + ne;   // row tiles including the extra (rhs) tile
-  auto panel = [&](int k) {    // factor block column k: diagonal tile, then every row tile below
+  const int32_t* rows = plan.rows.p;
+  const int32_t* pairs = plan.pairs.p;
+  auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
     hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
-    if (nrows - (k + 1) > 0)
-      hipLaunchKernelGGL(k_trsm128, dim3(2 * (nrows - (k + 1))), dim3(128), smem_trsm, sp, S, NP, k, k + 1, Xk);
+    hipLaunchKernelGGL(k_trsm128, dim3(2 * (unsigned)plan.trsm_cnt[k]), dim3(128), smem_trsm, sp, S, NP, k,
+                       rows + plan.trsm_off[k], Xk);
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, su), "record");
@@ -524,21 +611,20 @@ void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* 
     if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.N[pi - 1], 0), "wait");
     panel(k);
     if (k + 1 < nt) {
-      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(nrows - (k + 1), 1)), dim3(512), smem_syrk, sp, S, NP, k, k + 1,
-                         k + 1, nrows - (k + 1), 1);
+      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, NP, k,
+                         pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
       panel(k + 1);
     }
     check_hip(hipEventRecord(g_cs.P[pi], sp), "record");
     check_hip(hipStreamWaitEvent(su, g_cs.P[pi], 0), "wait");
-    const int rest = nt - (k + 2);           // column tiles right of the pair
-    if (k + 1 < nt && rest > 0) {
-      const int narrow = rest < 2 ? rest : 2;
-      hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 2), narrow)), dim3(512), smem_syrk, su, S, NP, k, k + 2,
-                         k + 2, nrows - (k + 2), narrow);
+    if (k + 1 < nt) {
+      if (plan.nar_cnt[pi] > 0)
+        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(plan.nar_cnt[pi])), dim3(512), smem_syrk, su, S, NP, k,
+                           pairs + 2 * plan.nar_off[pi], (int)plan.nar_cnt[pi]);
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
-      if (rest > narrow)
-        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(nrows - (k + 4), rest - narrow)), dim3(512), smem_syrk, su, S, NP,
-                           k, k + 4, k + 4, nrows - (k + 4), rest - narrow);
+      if (plan.rest_cnt[pi] > 0)
+        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(plan.rest_cnt[pi])), dim3(512), smem_syrk, su, S, NP, k,
+                           pairs + 2 * plan.rest_off[pi], (int)plan.rest_cnt[pi]);
     } else {
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
     }
@@ -546,29 +632,34 @@ void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* 
   check_hip(hipGetLastError(), "cholesky");
 }
 
-// debug (tools/syrk_ablation.py): time `reps` launches of the K=256 update over an m x m tile grid with ablations
+// debug (tools/syrk_ablation.py): time `reps` launches of the K=256 update over a dense m x m tile grid with ablations
 float debug_time_syrk(gtg_context& c, double* S, int NP, int m, int abl, int reps) {
   const size_t smem_syrk = 4 * (size_t)CHB;
   auto set = [&](const void* f) { check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr"); };
   set((const void*)k_syrk<2, 0>); set((const void*)k_syrk<2, 1>); set((const void*)k_syrk<2, 3>); set((const void*)k_syrk<2, 7>); set((const void*)k_syrk<2, 6>); set((const void*)k_syrk<2, 15>);
+  std::vector<int32_t> lst;
+  for (int j = 0; j < m; j++) for (int i = j; i < m; i++) { lst.push_back(2 + i); lst.push_back(2 + j); }
+  DevBuf<int32_t> dl; dl.upload(lst.data(), lst.size(), c.stream);
+  const int np = (int)(lst.size() / 2);
   hipEvent_t e0, e1;
   check_hip(hipEventCreate(&e0), "event"); check_hip(hipEventCreate(&e1), "event");
-  const dim3 grid(syrk_grid(m, m)), blk(512);
+  const dim3 grid(syrk_grid(np)), blk(512);
   check_hip(hipEventRecord(e0, c.stream), "record");
   for (int r = 0; r < reps; r++) {
     switch (abl) {
-      case 0: hipLaunchKernelGGL((k_syrk<2, 0>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
-      case 1: hipLaunchKernelGGL((k_syrk<2, 1>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
-      case 3: hipLaunchKernelGGL((k_syrk<2, 3>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
-      case 6: hipLaunchKernelGGL((k_syrk<2, 6>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
-      case 7: hipLaunchKernelGGL((k_syrk<2, 7>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
-      default: hipLaunchKernelGGL((k_syrk<2, 15>), grid, blk, smem_syrk, c.stream, S, NP, 0, 2, 2, m, m); break;
+      case 0: hipLaunchKernelGGL((k_syrk<2, 0>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      case 1: hipLaunchKernelGGL((k_syrk<2, 1>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      case 3: hipLaunchKernelGGL((k_syrk<2, 3>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      case 6: hipLaunchKernelGGL((k_syrk<2, 6>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      case 7: hipLaunchKernelGGL((k_syrk<2, 7>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      default: hipLaunchKernelGGL((k_syrk<2, 15>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
     }
   }
   check_hip(hipEventRecord(e1, c.stream), "record"); check_hip(hipStreamSynchronize(c.stream), "sync");
   float ms = 0;
   check_hip(hipEventElapsedTime(&ms, e0, e1), "elapsed");
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dl.free();
   return ms / reps;
 }
 
@@ -634,15 +725,16 @@ __global__ __launch_bounds__(256) void k_bwd_diag(const double* __restrict__ S, 
 // y[j] -= sum_r L(k*128 + r, j) x_k[r]: a workgroup owns 64 columns, its 4 waves split the 128 rows and are
 // combined through LDS in wave order (deterministic)
 __global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S, int NP, int k,
-                                                    const double* __restrict__ x, double* __restrict__ y) {
+                                                    const int32_t* __restrict__ cols, const double* __restrict__ x,
+                                                    double* __restrict__ y) {
   __shared__ double xs[T];
   __shared__ double part[4][64];
   const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
   if (tid < T) xs[tid] = x[k * T + tid];
   __syncthreads();
-  const int j = blockIdx.x * 64 + c;
+  const int j = cols[blockIdx.x >> 1] * T + (blockIdx.x & 1) * 64 + c;   // stored column tiles only
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  if (j < k * T) {
+  {
     const double* Lr = S + ((int64_t)k * T + 32 * g) * NP + j;
 #pragma unroll
     for (int r = 0; r < 32; r += 4) {
@@ -654,21 +746,17 @@ __global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S
   }
   part[g][c] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
-  if (g == 0 && j < k * T) y[j] -= ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+  if (g == 0) y[j] -= ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
 }
 
-void launch_backward_solve(gtg_context& c, double* S, int NP, double* x) {
+void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
-  static bool attr_set = false;
-  if (!attr_set) {   // 80 KB + of static LDS
-    check_hip(hipFuncSetAttribute((const void*)k_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 0), "smem attr");
-    attr_set = true;
-  }
   for (int k = nt - 1; k >= 0; k--) {
-    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), 0, c.stream, S, NP, k, c.Dinv.p + (size_t)k * T * T, y, x);
-    if (k > 0)
-      hipLaunchKernelGGL(k_bwd_update, dim3((k * T + 63) / 64), dim3(256), 0, c.stream, S, NP, k, x, y);
+    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), 0, c.stream, S, NP, k, Xinv + (size_t)k * T * T, y, x);
+    if (plan.bwd_cnt[k] > 0)
+      hipLaunchKernelGGL(k_bwd_update, dim3(2 * (unsigned)plan.bwd_cnt[k]), dim3(256), 0, c.stream, S, NP, k,
+                         plan.bcols.p + plan.bwd_off[k], x, y);
   }
   check_hip(hipGetLastError(), "backward_solve");
 }

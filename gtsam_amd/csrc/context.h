@@ -34,6 +34,18 @@ struct DevBuf {
   void free();
 };
 
+// Tile-sparse schedule of the reduced-system Cholesky (built once per graph by the host symbolic analysis):
+// which 128x128 tiles exist after fill-in, at the granularity of 256-wide column pairs.
+struct CholPlan {
+  int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
+  DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
+  std::vector<int64_t> trsm_off, trsm_cnt;      // per column tile
+  std::vector<int64_t> s1_off, s1_cnt, nar_off, nar_cnt, rest_off, rest_cnt;   // per pair: thin update, look-ahead part, rest
+  std::vector<int64_t> bwd_off, bwd_cnt;        // per row tile
+  double flops = 0.0;                           // algorithmic flops of one factorisation over the stored tiles
+  double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles
+};
+
 struct FactorTables {
   // SFM
   int64_t n_sfm = 0;
@@ -110,7 +122,8 @@ struct gtg_context {
   gt::DevBuf<double> Hoff;                      // (81 per block)
   gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (27/obs), delta (3)
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
-  gt::DevBuf<double> Dinv;                      // kTile x kTile inverse of the current diagonal block
+  gt::DevBuf<double> Dinv;                      // per diagonal tile: the four 32x32 diagonal inverses
+  gt::CholPlan plan;
   gt::DevBuf<double> xred;                      // NP solution of the reduced system
   gt::DevBuf<double> partials;                  // block partial sums for reductions
   gt::DevBuf<double> scalars;                   // SC_COUNT

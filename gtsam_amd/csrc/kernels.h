@@ -1,5 +1,7 @@
 // kernels.h -- host-callable launchers of the HIP kernels (all stream-ordered on ctx.stream).
 #pragma once
+#include <vector>
+
 #include "context.h"
 
 namespace gt {
@@ -18,12 +20,14 @@ void launch_back_substitute(gtg_context& c);     // delta_lm from xred, ylm, E, 
 void launch_scatter_delta(gtg_context& c);       // delta (variable id order) from xred + delta_lm
 
 // cholesky.hip ------------------------------------------------------------------------------------
-// In-place blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying `extra_rows`
-// additional rows (multiple of kTile) through TRSM + trailing updates (the rhs row: forward solve for
-// free).  Non-positive pivots set *fail_flag (device double) to nonzero.
-void launch_cholesky(gtg_context& c, double* S, int NP, int extra_rows, double* Dinv, double* fail_flag);
-// x = L^-T y  with L the factor in S, y = row NP of S (first n entries). Result in xred[0..NP).
-void launch_backward_solve(gtg_context& c, double* S, int NP, double* x);
+// Host: build the tile schedule.  pair_struct = lower-triangular boolean structure over 256-wide column pairs
+// ((np x np) row-major bytes, np = ceil(nt/2); nullptr = dense); symbolic fill-in is computed here.
+void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t s);
+// In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
+// tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
+void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag);
+// x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
+void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
 
 void check_hip(hipError_t e, const char* what);
 

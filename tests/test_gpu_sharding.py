@@ -87,3 +87,22 @@ def test_two_shards_equal_one(case):
         assert np.abs(vals - single.values_packed()).max() <= 1e-6 * np.abs(vals).max()
     # both shards hold identical values (lock-step)
     assert np.array_equal(res[0][4], res[1][4])
+
+
+def test_nccl_allreduce_callback_on_a_raw_device_pointer():
+    """The callback bench.py registers for N > 1: a raw device pointer wrapped zero-copy and all-reduced with the
+    `nccl` (= RCCL) backend.  World size 1 here (one GPU on the box): checks the wrapping + collective plumbing."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gtsam_amd.distributed import make_allreduce
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        t = torch.arange(1000, dtype=torch.float64, device="cuda")
+        fn = make_allreduce()
+        fn(t.data_ptr(), t.numel(), 0)
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    finally:
+        dist.destroy_process_group()

@@ -74,49 +74,66 @@ __device__ __forceinline__ void tile_to_lds(const double* __restrict__ tile, int
 __device__ __forceinline__ double rsqrt_nr(double p) {
   double r = __builtin_amdgcn_rsq(p);
   const double h = 0.5 * p;
-  r = r * (1.5 - h * r * r);
-  r = r * (1.5 - h * r * r);
+  r = r * __builtin_fma(-h, r * r, 1.5);
+  r = r * __builtin_fma(-h, r * r, 1.5);
   return r;
 }
 
-// ---- 32x32 Cholesky by ONE wavefront: lane i (mod 32) keeps row i in REGISTERS (a[0..31]); at step J every
-// lane publishes its column entry a[J] in a 32-double LDS line, reads the pivot and the entries below it
-// back as broadcasts (same address in all lanes) and updates its row.  The step index is a template
-// parameter so that every register index is static (a dynamically indexed row would live in scratch).
-// Same-wave LDS traffic is in order, so no barrier is needed between the steps.  dinv[J] = 1 / L(J,J).
+// ---- 32x32 Cholesky by ONE wavefront: lane i (mod 32) keeps row i in REGISTERS (a[0..31]).  Column J's entries
+// reach every lane through a 32-double LDS line (written by the owning lanes, read back as broadcasts).  The
+// lines are double buffered and software pipelined: during step J each lane first finishes its entry of column
+// J+1, publishes it and issues the broadcast reads for step J+1, and only then does the remaining rank-1
+// updates -- the LDS round trip of the next pivot hides behind them.  The step index is a template parameter so
+// that every register index is static (a dynamically indexed row would live in scratch).  Same-wave LDS traffic
+// is in order, so no barrier is needed between the steps.  dinv[J] = 1 / L(J,J).
 template <int J>
 struct PotrfStep {
-  static __device__ __forceinline__ void run(double (&a)[SB], double* col, double* dinv, int lane, int i, double* fail) {
-    if (lane < 32) col[i] = a[J];
-    const double piv = col[J];
-    if (!(piv > 0.0) && lane == 0) *fail = 1.0;   // Eigen LLT: non-positive pivot -> NumericalIssue
+  static __device__ __forceinline__ void run(double (&a)[SB], const double (&cj)[SB], double* lines, double* dinv,
+                                             int lane, int i, bool& bad) {
+    // the pivot itself travels by v_readlane (a few cycles) so that the rsqrt chain of step J does not wait for
+    // the LDS round trip; the other column entries (needed only for the rank-1 update) come through the LDS line
+    const double piv = readlane_f64(a[J], J);
+    bad = bad || !(piv > 0.0);   // Eigen LLT: non-positive pivot -> NumericalIssue (flag stored once, branch-free steps)
     const double r = rsqrt_nr(piv);
     const double u = a[J] * (r * r);
+    double cn[SB];
+    if (J + 1 < SB) {
+      double* line = lines + ((J + 1) & 1) * SB;
+      a[(J + 1) % SB] -= u * cj[(J + 1) % SB];
+      if (lane < 32) line[i] = a[(J + 1) % SB];
 #pragma unroll
-    for (int c = J + 1; c < SB; c++) a[c] -= u * col[c];
+      for (int c = J + 1; c < SB; c++) cn[c] = line[c];
+    }
+#pragma unroll
+    for (int c = J + 2; c < SB; c++) a[c] -= u * cj[c];
     // pin the row here: without it hipcc defers the updates it does not need for the next pivot and keeps
     // every step's broadcast values alive (hundreds of spilled registers)
 #pragma unroll
-    for (int c = J + 1; c < SB; c++) asm volatile("" : "+v"(a[c]));
+    for (int c = J + 2; c < SB; c++) asm volatile("" : "+v"(a[c]));
     a[J] = (i == J) ? piv * r : a[J] * r;
     if (lane == J) dinv[J] = r;
-    PotrfStep<J + 1>::run(a, col, dinv, lane, i, fail);
+    PotrfStep<J + 1>::run(a, cn, lines, dinv, lane, i, bad);
   }
 };
 template <>
 struct PotrfStep<SB> {
-  static __device__ __forceinline__ void run(double (&)[SB], double*, double*, int, int, double*) {}
+  static __device__ __forceinline__ void run(double (&)[SB], const double (&)[SB], double*, double*, int, int, bool&) {}
 };
 
 __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv,
-                                            double* __restrict__ col, int jb, int lane, double* fail) {
+                                            double* __restrict__ lines, int jb, int lane, double* fail) {
   const int i = lane & 31;
   const int o = SB * jb;
   double* row = A + boff(jb, jb) + i * PB;
-  double a[SB];
+  double a[SB], c0[SB];
 #pragma unroll
   for (int c = 0; c < SB; c++) a[c] = row[c];
-  PotrfStep<0>::run(a, col, dinv + o, lane, i, fail);
+  if (lane < 32) lines[i] = a[0];
+#pragma unroll
+  for (int c = 0; c < SB; c++) c0[c] = lines[c];
+  bool bad = false;
+  PotrfStep<0>::run(a, c0, lines, dinv + o, lane, i, bad);
+  if (bad && lane == 0) *fail = 1.0;
   if (lane < 32) {
 #pragma unroll
     for (int c = 0; c < SB; c++) row[c] = (c <= i) ? a[c] : 0.0;
@@ -131,9 +148,13 @@ __device__ __forceinline__ void stage_inverse(const double* A, const double* din
   double x[SB];
 #pragma unroll
   for (int r = 0; r < SB; r++) {
-    double acc = 0.0;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;   // independent partial sums: no 31-deep dependent FMA chain
 #pragma unroll
-    for (int m = 0; m < r; m++) acc += D[r * PB + m] * x[m];
+    for (int m = 0; m < r; m++) {
+      const double t = D[r * PB + m] * x[m];
+      if ((m & 3) == 0) p0 += t; else if ((m & 3) == 1) p1 += t; else if ((m & 3) == 2) p2 += t; else p3 += t;
+    }
+    const double acc = (p0 + p1) + (p2 + p3);
     const double dr = dinv[o + r];
     x[r] = (r == i) ? dr : (r > i ? -acc * dr : 0.0);
   }
@@ -154,10 +175,13 @@ __device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int
   for (int c = 0; c < SB; c++) x[c] = R[c];
 #pragma unroll
   for (int c = 0; c < SB; c++) {
-    double acc = x[c];
+    double p0 = x[c], p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-    for (int m = 0; m < c; m++) acc -= x[m] * D[c * PB + m];
-    x[c] = acc * dinv[o + c];
+    for (int m = 0; m < c; m++) {
+      const double t = x[m] * D[c * PB + m];
+      if ((m & 3) == 0) p0 -= t; else if ((m & 3) == 1) p1 -= t; else if ((m & 3) == 2) p2 -= t; else p3 -= t;
+    }
+    x[c] = ((p0 + p1) + (p2 + p3)) * dinv[o + c];
   }
   if (lane < 32) {
 #pragma unroll
@@ -172,10 +196,11 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* dinv = A + 10 * SB * PB;                    // [T]  1 / L(j,j)
-  double* col = dinv + T;                             // [SB] column broadcast line
+  double* col = dinv + T;                             // [2][SB] double-buffered column broadcast lines
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  __builtin_amdgcn_s_setprio(3);   // critical-path kernel: win issue arbitration against co-resident k_syrk waves
   STAMP(0);
   {  // lower sub-blocks -> LDS: 10 blocks x 512 16-byte pieces, 20 per lane, all loads in flight before the writes
     double2 v[20];
@@ -200,8 +225,7 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
     if (wave == 0) stage_potrf(A, dinv, col, jb, lane, fail);   // critical path
     __syncthreads();
     STAMP(2 + 3 * jb);
-    if (wave == 0) stage_inverse(A, dinv, jb, lane, Xinv + (int64_t)jb * SB * SB);
-    else if (jb + wave < 4) stage_rowtrsm(A, dinv, jb, jb + wave, lane);
+    if (wave > 0 && jb + wave < 4) stage_rowtrsm(A, dinv, jb, jb + wave, lane);
     __syncthreads();
     STAMP(3 + 3 * jb);
     // trailing update on the matrix cores: A(ib,cb) -= L(ib,jb) L(cb,jb)^T for jb < cb <= ib
@@ -230,7 +254,11 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
     __syncthreads();
     STAMP(4 + 3 * jb);
   }
-  // write back: lower sub-blocks (diagonal ones with their upper part zeroed), then zero the 6 upper sub-blocks
+  // the four 32x32 diagonal inverses (used by k_trsm128 / k_bwd_diag, not by this kernel): off the critical
+  // path, one per wavefront
+  stage_inverse(A, dinv, wave, lane, Xinv + (int64_t)wave * SB * SB);
+  // write back the lower sub-blocks (diagonal ones with their upper part zeroed); the strictly-upper sub-blocks of
+  // the tile are never read by anyone and are left as they are
 #pragma unroll 4
   for (int e = tid; e < 10 * 512; e += 256) {
     const int blk = e >> 9, w = e & 511, r = w >> 4, c = 2 * (w & 15);
@@ -241,12 +269,6 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
     v.x = (ib != rem || c <= r) ? sp[0] : 0.0;
     v.y = (ib != rem || c + 1 <= r) ? sp[1] : 0.0;
     *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * rem + c) = v;
-  }
-  for (int e = tid; e < 6 * 512; e += 256) {
-    const int blk = e >> 9, w = e & 511, r = w >> 4, c = 2 * (w & 15);
-    int cbk = 1, rem = blk;                       // strictly-upper blocks (ib < cb): enumerate by column block
-    while (rem >= cbk) { rem -= cbk; cbk++; }
-    *reinterpret_cast<double2*>(tile + (int64_t)(SB * rem + r) * NP + SB * cbk + c) = double2{0.0, 0.0};
   }
   STAMP(14);
 }
@@ -260,6 +282,7 @@ __global__ __launch_bounds__(128) void k_trsm128(double* __restrict__ S, int NP,
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
   const int I = rows[blockIdx.x >> 1], half_rows = (blockIdx.x & 1) * TR;
+  __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
@@ -571,7 +594,7 @@ static CholStreams g_cs;
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
-  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + SB);
+  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + 2 * SB);
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;

@@ -324,7 +324,7 @@ static void analyze(gtg_context& c) {
     for (int r = 0; r < c.n_red_vars; r++) mark(r, r);
     for (size_t i = 0; i < pair_row.size(); i++) mark(pair_row[i], pair_col[i]);
     for (size_t i = 0; i < hoff_row.size(); i++) mark(hoff_row[i], hoff_col[i]);
-    build_chol_plan(c.plan, nt, &B2, s);
+    build_chol_plan(c.plan, nt, std::getenv("GTG_DENSE_PLAN") ? nullptr : &B2, s);
     clk.lap("cholesky tile schedule");
     if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation\n",
                              (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9);

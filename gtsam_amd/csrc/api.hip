@@ -458,7 +458,7 @@ int gtg_destroy(gtg_handle c) {
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
                             &c->pair_col, &c->pair_oa, &c->pair_ob};
   for (auto* b : i32) b->free();
-  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free();
+  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.stored.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr};
   for (auto* b : i64) b->free();
@@ -662,7 +662,13 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, g_events); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
-  exchange(*c, c->S.p, (int64_t)(c->NP + kTile) * c->NP);   // the one big exchange: reduced Hessian + rhs
+  if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs, stored lower tiles only
+    const int64_t nb = c->plan.n_stored * kTile * kTile;
+    if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
+    launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
+    exchange(*c, c->xbuf.p, nb);
+    launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
+  }
   { PhaseTimer t(*c, GTG_PH_CHOLESKY, g_events); launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
   { PhaseTimer t(*c, GTG_PH_SOLVE, g_events);
     launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p);
@@ -819,7 +825,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
-  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free();
+  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
   return hf != 0.0 ? GTG_INDETERMINATE : GTG_OK;
   GTG_CATCH
 }

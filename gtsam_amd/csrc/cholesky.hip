@@ -506,7 +506,7 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
       for (size_t b = 0; b <= a; b++) B[(size_t)r[a] * np + r[b]] = 1;
   }
   auto tiles_of = [&](int q, std::vector<int32_t>& out) { out.push_back(2 * q); if (2 * q + 1 < nt) out.push_back(2 * q + 1); };
-  std::vector<int32_t> rows, pairs, bcols;
+  std::vector<int32_t> rows, pairs, bcols, stored_list;
   plan.nt = nt;
   plan.trsm_off.assign(nt, 0); plan.trsm_cnt.assign(nt, 0);
   plan.s1_off.assign(np, 0); plan.s1_cnt.assign(np, 0); plan.nar_off.assign(np, 0); plan.nar_cnt.assign(np, 0);
@@ -528,6 +528,11 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
     std::vector<int32_t> R;
     for (int q = p + 1; q < np; q++) if (B[(size_t)q * np + p]) tiles_of(q, R);
     stored += (two ? 3 : 1) + (int64_t)R.size() * (two ? 2 : 1);
+    for (int cc = k; cc <= (two ? k + 1 : k); cc++) {
+      for (int rr = cc; rr <= (two ? k + 1 : k); rr++) { stored_list.push_back(rr); stored_list.push_back(cc); }
+      for (int32_t I : R) { stored_list.push_back(I); stored_list.push_back(cc); }
+      stored_list.push_back(nt); stored_list.push_back(cc);
+    }
     // column k: rows below = [k+1] + R + [rhs]
     plan.trsm_off[k] = (int64_t)rows.size();
     if (two) rows.push_back(k + 1);
@@ -573,7 +578,29 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
   plan.rows.upload(rows.data(), rows.size(), stream);
   plan.pairs.upload(pairs.data(), pairs.size(), stream);
   plan.bcols.upload(bcols.data(), bcols.size(), stream);
+  plan.n_stored = (int64_t)stored_list.size() / 2;
+  plan.stored.upload(stored_list.data(), stored_list.size(), stream);
   check_hip(hipStreamSynchronize(stream), "plan upload");
+}
+
+// Multi-GPU exchange helper: copy the stored tiles of S into / out of a contiguous buffer, so that the all-reduce of
+// the partial reduced systems carries only the stored lower tiles (not the dense (NP+128) x NP array).
+__global__ __launch_bounds__(256) void k_pack_tiles(double* __restrict__ S, int NP, const int32_t* __restrict__ tiles,
+                                                    double* __restrict__ buf, int unpack) {
+  const int I = tiles[2 * blockIdx.x], J = tiles[2 * blockIdx.x + 1];
+  double* tile = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  double* b = buf + (int64_t)blockIdx.x * T * T;
+#pragma unroll 8
+  for (int e = threadIdx.x; e < T * (T / 2); e += 256) {
+    const int r = e / (T / 2), c2 = 2 * (e % (T / 2));
+    double2* g = reinterpret_cast<double2*>(tile + (int64_t)r * NP + c2);
+    double2* p = reinterpret_cast<double2*>(b + r * T + c2);
+    if (unpack) *g = *p; else *p = *g;
+  }
+}
+void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack) {
+  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_stored), dim3(256), 0, c.stream, S, NP, plan.stored.p, buf, unpack ? 1 : 0);
+  check_hip(hipGetLastError(), "pack_tiles");
 }
 
 // Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1):

@@ -39,6 +39,8 @@ struct DevBuf {
 struct CholPlan {
   int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
   DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
+  DevBuf<int32_t> stored;                       // every stored tile (I,J) incl. the rhs row: what a multi-GPU exchange must carry
+  int64_t n_stored = 0;
   std::vector<int64_t> trsm_off, trsm_cnt;      // per column tile
   std::vector<int64_t> s1_off, s1_cnt, nar_off, nar_cnt, rest_off, rest_cnt;   // per pair: thin update, look-ahead part, rest
   std::vector<int64_t> bwd_off, bwd_cnt;        // per row tile
@@ -124,6 +126,7 @@ struct gtg_context {
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
   gt::DevBuf<double> Dinv;                      // per diagonal tile: the four 32x32 diagonal inverses
   gt::CholPlan plan;
+  gt::DevBuf<double> xbuf;                      // multi-GPU: stored tiles of S packed contiguously for the all-reduce
   gt::DevBuf<double> xred;                      // NP solution of the reduced system
   gt::DevBuf<double> partials;                  // block partial sums for reductions
   gt::DevBuf<double> scalars;                   // SC_COUNT

@@ -27,6 +27,7 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag);
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
+void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
 
 void check_hip(hipError_t e, const char* what);

@@ -37,6 +37,11 @@ def build_workload(name):
         return bal_problem(*D.venice_1778()), "BAL Venice problem-1778-993923 shape (synthetic, seed 42)"
     if name == "dubrovnik16":
         return bal_problem(*D.dubrovnik_16()), "BAL Dubrovnik-16-22106 shape (synthetic, seed 42)"
+    if name == "sphere2500":
+        import numpy as _np
+        from tests import problems as PB
+        g = dict(_np.load(os.path.join(ROOT, "tests", "golden", "sphere2500.npz")))
+        return PB.sphere2500(g), "sphere2500 pose graph (reference's examples/Data/sphere2500.txt via the golden fixture), prior on pose 0, odometry-chain init"
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -76,6 +81,8 @@ def main():
 
     (problem, values0), desc = build_workload(args.workload)
     params = LevenbergMarquardtParams.CeresDefaults()       # timing/timeSFMBAL.h:69-70
+    if args.workload == "sphere2500":
+        params = LevenbergMarquardtParams()                  # Pose3SLAMExample_g2o protocol with legacy LM
 
     def fresh():
         return DeviceLevenbergMarquardt(problem, values0, params, device=local_rank, shard=rank, n_shards=world,
@@ -159,8 +166,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "protocol": "timeSFMBAL: GeneralSFMFactor Unit(2) noise, no priors, Ceres LM params, Schur ordering",
+            "config": {"workload": desc, "protocol": ("timeSFMBAL: GeneralSFMFactor Unit(2) noise, no priors, Ceres LM params, Schur ordering" if problem.n_sfm
+                                    else "Pose3SLAMExample_g2o with LevenbergMarquardt (legacy params), BetweenFactor<Pose3> + prior"),
                        "cameras": int((problem.var_type == 1).sum()), "points": int((problem.var_type == 2).sum()),
+                       "poses": int((problem.var_type == 0).sum()), "between_factors": int(problem.n_between),
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
                        "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU"},
             "lambda_tries_per_s": tries / elapsed,
@@ -190,7 +199,8 @@ def main():
                 from oracle import ref
                 if ref.available():
                     g = ref.RefGraph(problem)
-                    rc, ms = g.iteration_phases(values0, params.lambdaInitial, params.diagonalDamping, 1)
+                    rc, ms = g.iteration_phases(values0, params.lambdaInitial, params.diagonalDamping,
+                                                1 if problem.n_sfm else 0)
                     cpu = {"value": 1e3 / ms[7], "unit": "iterations/s", "cores": 1, "kind": "reference",
                            "sample": "1 LM iteration (linearize, hessianDiagonal, damp, eliminateMultifrontal+solve with the Schur ordering, "
                                      "2x linear error, retract, nonlinear error) of the SAME problem with gtsam built from /root/reference "

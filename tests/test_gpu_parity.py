@@ -125,9 +125,9 @@ def test_lm_trajectory_vs_reference_golden(gpu, name, preset, prefix):
     assert rel(opt.values_packed(), g[prefix + ("values" if prefix else "final_values")]) <= 1e-5
 
 
-def test_sphere2500_first_iterations_and_solve(gpu):
-    """configs[3]: sphere2500 pose graph.  One damped solve on identical inputs and the first outer
-    iterations of the golden trace; the full 21-iteration run is the bench's job."""
+def test_sphere2500_solve_and_full_trajectory(gpu):
+    """configs[3]: sphere2500 pose graph (tile-sparse path, 8 % of the tiles stored).  One damped solve on identical
+    inputs, then the full LM run against the reference's golden trace."""
     from gtsam_amd.optimizer import DeviceLevenbergMarquardt
     g = load_golden("sphere2500")
     p, v0 = PB.sphere2500(g)
@@ -141,13 +141,19 @@ def test_sphere2500_first_iterations_and_solve(gpu):
     assert rel(dev.delta(), g["solve_delta"]) <= 1e-6
     assert abs(out[1] - g["solve_linerr"][1]) <= 1e-6 * abs(g["solve_linerr"][1])
     dev.close()
-    params = LMP(); params.maxIterations = 6
-    opt = DeviceLevenbergMarquardt(p, v0, params)
+    # the whole run of BASELINE.md's golden trace: 21 outer / 45 inner iterations, 12 280 978.77 -> 1 136.95214.
+    # The first 11 outer iterations (no rejected lambda) must match step for step; from outer 12 on several lambdas
+    # are rejected per iteration and the accept/reject decisions are FP-marginal -- there the final
+    # error is the criterion (and, as measured, the whole sequence does coincide).
+    opt = DeviceLevenbergMarquardt(p, v0, LMP())
     opt.optimize()
     tr = np.array(opt.trace)[:, :3]
-    ref_trace = g["trace"][: tr.shape[0]]
-    assert np.array_equal(tr[:, 0], ref_trace[:, 0])
-    assert rel(tr[:, 1], ref_trace[:, 1]) <= 1e-6
+    ref_trace = g["trace"]
+    assert np.array_equal(tr[:12, 0], ref_trace[:12, 0])
+    assert rel(tr[:12, 1], ref_trace[:12, 1]) <= 1e-6
+    assert abs(opt.error() - ref_trace[-1, 1]) <= 1e-5 * ref_trace[-1, 1]
+    assert abs(opt.error() - 1136.95214) < 0.05
+    print("sphere2500 outer/inner:", opt.iterations(), opt.getInnerIterations(), "reference:", int(g["iterations"]), int(ref_trace[-1, 0]))
 
 
 @pytest.mark.parametrize("n", [5, 100, 128, 300, 1000])

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ladybug1723")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--skip-dense-roofline", action="store_true", help="do not run the extra dense-schedule factorisations (used for clean profiles)")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +128,7 @@ def main():
     # MFMA kernel quality in isolation: the same factorisation with the tile schedule forced dense (no reordering,
     # every tile stored) -- the regime where the trailing update (k_syrk) dominates and the MFMA roofline applies.
     dense = None
-    if world == 1:
+    if world == 1 and not args.skip_dense_roofline:
         os.environ["GTG_NO_REORDER"] = "1"; os.environ["GTG_DENSE_PLAN"] = "1"
         try:
             od = fresh()

@@ -1,0 +1,125 @@
+"""Host-side dataset readers: the two wire formats either side of the hot path.
+
+Restated from the reference's loaders so that a file parsed here gives the same numbers the reference's own
+loader hands to its optimizer:
+  * read_bal     <-> SfmData::FromBalFile   gtsam/sfm/SfmData.cpp:189-246  (numbers go through float32 temporaries;
+                                            Rodrigues rotation, openGL2gtsam :79-85, measurement (u, -v))
+  * read_g2o3d   <-> load3D / readG2o(is3D) gtsam/slam/dataset.cpp:738-944  (VERTEX3 / VERTEX_SE3:QUAT /
+                                            EDGE3 (roll pitch yaw) / EDGE_SE3:QUAT incl. the t,R -> R,t information
+                                            reshuffle :848-853; Gaussian::Information's smart down-casting
+                                            gtsam/linear/NoiseModel.cpp:97-110,283-308,624-633)
+Pure host bookkeeping (numpy); nothing here runs per iteration.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .problem import NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT
+
+
+def _rodrigues(w):
+    """Rot3::Rodrigues = SO3::Expmap (geometry/SO3.cpp:50-88)."""
+    w = np.asarray(w, np.float64)
+    theta2 = float(w @ w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if theta2 <= np.finfo(np.float64).eps:
+        return np.eye(3) + W
+    theta = np.sqrt(theta2)
+    K = W / theta
+    s2 = np.sin(theta / 2.0)
+    return np.eye(3) + np.sin(theta) * K + (2.0 * s2 * s2) * (K @ K)
+
+
+def read_bal(path):
+    """-> (cams17, pts3, obs_cam, obs_pt, obs_z); observations ordered by track then file order."""
+    toks = open(path).read().split()
+    n_cam, n_pt, n_obs = int(toks[0]), int(toks[1]), int(toks[2])
+    pos = 3
+    f32 = lambda s: float(np.float32(s))      # noqa: E731  (`float u; is >> u`)
+    oc = np.zeros(n_obs, np.int64); op = np.zeros(n_obs, np.int64); oz = np.zeros((n_obs, 2))
+    for k in range(n_obs):
+        oc[k] = int(toks[pos]); op[k] = int(toks[pos + 1])
+        oz[k] = (f32(toks[pos + 2]), -f32(toks[pos + 3]))
+        pos += 4
+    cams = np.zeros((n_cam, 17))
+    R90 = np.diag([1.0, -1.0, -1.0])
+    for i in range(n_cam):
+        v = [f32(t) for t in toks[pos:pos + 9]]; pos += 9
+        R = _rodrigues(v[0:3])
+        wRc = R.T @ R90                                       # openGL2gtsam: (R.inverse()).compose(R90)
+        t = R.T @ (-np.array(v[3:6]))                         # R.unrotate(-t)
+        cams[i, :9] = wRc.reshape(-1); cams[i, 9:12] = t
+        cams[i, 12:15] = v[6:9]                               # Cal3Bundler(f, k1, k2), u0 = v0 = 0
+    pts = np.array([[f32(t) for t in toks[pos + 3 * j:pos + 3 * j + 3]] for j in range(n_pt)]).reshape(n_pt, 3)
+    order = np.argsort(op, kind="stable")                     # tracks[j].measurements in file order
+    return cams, pts, oc[order].astype(np.int32), op[order].astype(np.int32), oz[order]
+
+
+def _ypr(yaw, pitch, roll):
+    """Rot3::Ypr(y,p,r) = RzRyRx(r, p, y) (geometry/Rot3.h)."""
+    cx, sx, cy, sy, cz, sz = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _quat(x, y, z, w):
+    """operator>>(Quaternion) normalises (dataset.cpp:738-744); Eigen quaternion -> rotation matrix."""
+    n = np.sqrt(w * w + x * x + y * y + z * z); x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def information_to_noise(m):
+    """noiseModel::Gaussian::Information(m, smart=true): diagonal -> Diagonal::Precisions -> Variances ->
+    (all equal -> Isotropic::Variance -> (|var-1|<1e-9 -> Unit)); else R = upper Cholesky factor of m.
+    Returns (kind, 36 parameters)."""
+    out = np.zeros(36)
+    if np.all(m == np.diag(np.diag(m))):
+        var = 1.0 / np.diag(m)
+        if np.all(var == var[0]):
+            if abs(var[0] - 1.0) < 1e-9:
+                return NOISE_UNIT, out
+            out[0] = np.sqrt(var[0])
+            return NOISE_ISOTROPIC, out
+        out[:6] = np.sqrt(var)
+        return NOISE_DIAGONAL, out
+    out[:] = np.linalg.cholesky(m).T.reshape(-1)
+    return NOISE_GAUSSIAN, out
+
+
+def read_g2o3d(path):
+    """-> dict(v1, v2, z [n,12], noise_kind, noise [n,36], vertex_keys, vertex_poses [m,12]) like the reference's
+    load3D: vertices only when the file has VERTEX lines (it does *not* create missing ones, dataset.cpp:922-944)."""
+    v1, v2, zs, nk, nd, vk, vp = [], [], [], [], [], [], []
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        tag = t[0]
+        if tag in ("VERTEX3", "VERTEX_SE3:QUAT"):
+            x, y, z = (float(a) for a in t[2:5])
+            R = _ypr(float(t[7]), float(t[6]), float(t[5])) if tag == "VERTEX3" else _quat(*(float(a) for a in t[5:9]))
+            vk.append(int(t[1])); vp.append(np.concatenate([R.reshape(-1), [x, y, z]]))
+        elif tag in ("EDGE3", "EDGE_SE3:QUAT"):
+            x, y, z = (float(a) for a in t[3:6])
+            if tag == "EDGE3":
+                R = _ypr(float(t[8]), float(t[7]), float(t[6])); rest = t[9:30]
+            else:
+                R = _quat(*(float(a) for a in t[6:10])); rest = t[10:31]
+            m = np.zeros((6, 6)); k = 0
+            for i in range(6):
+                for j in range(i, 6):
+                    m[i, j] = m[j, i] = float(rest[k]); k += 1
+            if tag == "EDGE_SE3:QUAT":                        # g2o stores t,R order (dataset.cpp:848-853)
+                mg = np.zeros((6, 6))
+                mg[:3, :3] = m[3:, 3:]; mg[3:, 3:] = m[:3, :3]; mg[3:, :3] = m[:3, 3:]; mg[:3, 3:] = m[3:, :3]
+                m = mg
+            kind, params = information_to_noise(m)
+            v1.append(int(t[1])); v2.append(int(t[2])); zs.append(np.concatenate([R.reshape(-1), [x, y, z]]))
+            nk.append(kind); nd.append(params)
+    order = np.argsort(vk, kind="stable") if vk else np.zeros(0, int)
+    return dict(v1=np.array(v1, np.int64), v2=np.array(v2, np.int64), z=np.array(zs).reshape(-1, 12),
+                noise_kind=np.array(nk, np.int32), noise=np.array(nd).reshape(-1, 36),
+                vertex_keys=np.array(vk, np.int64)[order], vertex_poses=np.array(vp).reshape(-1, 12)[order])

@@ -1,0 +1,77 @@
+"""Dataset readers (gtsam_amd/io.py) against the reference's own loaders: the golden fixtures hold what
+SfmData::FromBalFile / readG2o returned for the reference's shipped files; when /root/reference and oracle/_ref are
+present (build container) the live loaders are compared as well."""
+import os
+
+import numpy as np
+import pytest
+
+from gtsam_amd import io
+from tests.conftest import load_golden
+
+DATA = "/root/reference/examples/Data/"
+
+
+def test_bal_reader_matches_reference_loader():
+    path = DATA + "dubrovnik-3-7-pre.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    g = load_golden("dubrovnik_3_7")
+    cams, pts, oc, op, oz = io.read_bal(path)
+    assert np.array_equal(oc, g["obs_cam"]) and np.array_equal(op, g["obs_pt"])
+    assert np.array_equal(oz, g["obs_z"]) and np.array_equal(pts, g["pts"])          # float32 temporaries: exact
+    assert np.abs(cams - g["cams"]).max() <= 1e-14 * np.abs(g["cams"]).max()
+
+
+def test_toro_reader_matches_reference_loader():
+    path = DATA + "sphere2500.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    g = load_golden("sphere2500")
+    d = io.read_g2o3d(path)
+    assert np.array_equal(d["v1"], g["v1"]) and np.array_equal(d["v2"], g["v2"])
+    assert np.array_equal(d["noise_kind"], g["noise_kind"])
+    assert np.abs(d["z"] - g["z"]).max() <= 1e-15
+    assert np.abs(d["noise"] - g["noise"]).max() <= 1e-15
+    assert d["vertex_keys"].size == 0        # load3D does not create missing vertices
+
+
+@pytest.mark.parametrize("name", ["pose3example.txt", "pose3example-offdiagonal.txt", "pose3example-grid.txt"])
+def test_g2o_quat_reader_matches_live_reference(name, live_ref):
+    path = DATA + name
+    if live_ref is None or not os.path.exists(path):
+        pytest.skip("live reference not present")
+    r = live_ref.load_g2o3d(path)
+    d = io.read_g2o3d(path)
+    for k in ("v1", "v2", "noise_kind", "vertex_keys"):
+        assert np.array_equal(d[k], r[k]), k
+    assert np.abs(d["z"] - r["z"]).max() <= 1e-14
+    assert np.abs(d["vertex_poses"] - r["vertex_poses"]).max() <= 1e-14
+    assert np.abs(d["noise"] - r["noise"]).max() <= 1e-12 * max(1.0, np.abs(r["noise"]).max())
+
+
+def test_bal_reader_on_a_written_file(tmp_path):
+    """Format round trip on a file written here (BAL text layout: header, observations, cameras, points)."""
+    rng = np.random.default_rng(0)
+    nc, npt = 3, 5
+    obs = [(i, j, rng.normal() * 100, rng.normal() * 100) for j in range(npt) for i in range(nc) if (i + j) % 2 == 0]
+    cam = rng.normal(size=(nc, 9)) * [0.1, 0.1, 0.1, 1, 1, 1, 0, 0, 0] + [0, 0, 0, 0, 0, 0, 500, 1e-3, 1e-6]
+    pts = rng.normal(size=(npt, 3))
+    p = tmp_path / "tiny-bal.txt"
+    with open(p, "w") as f:
+        f.write(f"{nc} {npt} {len(obs)}\n")
+        for i, j, u, v in obs:
+            f.write(f"{i} {j} {u:.6e} {v:.6e}\n")
+        for row in cam:
+            f.write("\n".join(f"{x:.16e}" for x in row) + "\n")
+        for row in pts:
+            f.write("\n".join(f"{x:.16e}" for x in row) + "\n")
+    cams, P, oc, op, oz = io.read_bal(str(p))
+    assert cams.shape == (nc, 17) and P.shape == (npt, 3) and oc.size == len(obs)
+    assert np.all(np.diff(op) >= 0)                                   # grouped by track
+    assert np.allclose(P, pts.astype(np.float32)) and np.allclose(cams[:, 12], cam[:, 6].astype(np.float32))
+    R = cams[:, :9].reshape(nc, 3, 3)
+    assert np.abs(R @ np.swapaxes(R, 1, 2) - np.eye(3)).max() < 1e-14
+    u0 = np.float32(f"{obs[0][2]:.6e}"); v0 = np.float32(f"{obs[0][3]:.6e}")
+    k = np.where((oc == obs[0][0]) & (op == obs[0][1]))[0][0]
+    assert oz[k, 0] == float(u0) and oz[k, 1] == -float(v0)           # (u, -v)

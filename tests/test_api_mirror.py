@@ -1,0 +1,75 @@
+"""The host API mirror (gtsam_amd/api.py): extractor + noise-model factories on CPU; on the GPU an LM run written the
+way examples/SFMExample_bal.cpp / tests/testGeneralSFMFactorB.cpp write it."""
+import numpy as np
+import pytest
+
+from gtsam_amd import api
+from gtsam_amd.problem import NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT
+from tests import problems as PB
+from tests.conftest import load_golden
+
+C, P, X = api.symbol_shorthand.C, api.symbol_shorthand.P, api.symbol_shorthand.X
+
+
+def _dubrovnik_graph(priors):
+    """examples/SFMExample_bal.cpp:52-76, from the golden copy of what SfmData::FromBalFile returned."""
+    g = load_golden("dubrovnik_3_7")
+    graph = api.NonlinearFactorGraph(); initial = api.Values()
+    noise = api.noiseModel.Isotropic.Sigma(2, 1.0)          # smart -> Unit, as in the reference
+    for i, j, uv in zip(g["obs_cam"], g["obs_pt"], g["obs_z"]):
+        graph.add(api.GeneralSFMFactorCal3Bundler(uv, noise, C(int(i)), P(int(j))))
+    cams = [api.PinholeCameraCal3Bundler.from_packed(c) for c in g["cams"]]
+    if priors:
+        graph.addPriorPinholeCameraCal3Bundler(C(0), cams[0], api.noiseModel.Isotropic.Sigma(9, 0.1))
+        graph.addPriorPoint3(P(0), g["pts"][0], api.noiseModel.Isotropic.Sigma(3, 0.1))
+    for i, c in enumerate(cams):
+        initial.insert(C(i), c)
+    for j, p in enumerate(g["pts"]):
+        initial.insert(P(j), np.array(p))
+    return g, graph, initial
+
+
+def test_symbol_and_noise_factories():
+    assert C(3) == (ord("c") << 56) | 3 and P(0) > C(10 ** 6)          # Values order: cameras before points
+    nm = api.noiseModel
+    assert nm.Isotropic.Sigma(2, 1.0).kind == NOISE_UNIT and nm.Isotropic.Sigma(2, 0.5).kind == NOISE_ISOTROPIC
+    assert nm.Diagonal.Sigmas([0.1, 0.1, 0.1]).kind == NOISE_ISOTROPIC and nm.Diagonal.Sigmas([1, 1]).kind == NOISE_UNIT
+    d = nm.Diagonal.Variances([1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4])
+    assert d.kind == NOISE_DIAGONAL and np.allclose(d.params, np.sqrt([1e-6] * 3 + [1e-4] * 3))
+    info = np.diag([10.0, 10, 10, 100, 100, 25])
+    assert nm.Gaussian.Information(info).kind == NOISE_DIAGONAL        # sphere2500's edges
+    info[0, 1] = info[1, 0] = 1.0
+    ga = nm.Gaussian.Information(info)
+    assert ga.kind == NOISE_GAUSSIAN and np.allclose(ga.params.reshape(6, 6).T @ ga.params.reshape(6, 6), info)
+    with pytest.raises(ValueError):
+        nm.Diagonal.Sigmas([0.1, 1e-9])                                  # constrained: out of scope, rejected loudly
+
+
+def test_extractor_reproduces_the_soa_problem():
+    g, graph, initial = _dubrovnik_graph(priors=True)
+    p, v0, keys = api.extract(graph, initial)
+    q, w0 = PB.dubrovnik_sfmexample(g)
+    assert keys == [C(i) for i in range(3)] + [P(j) for j in range(7)]
+    assert np.array_equal(p.var_type, q.var_type) and np.array_equal(v0, w0)
+    assert np.array_equal(p.sfm_cam, q.sfm_cam) and np.array_equal(p.sfm_point, q.sfm_point) and np.array_equal(p.sfm_z, q.sfm_z)
+    assert p.n_prior == 2 and np.array_equal(p.prior_data, q.prior_data)
+    assert [int(k) for k in p.noise_kind] == [NOISE_UNIT, NOISE_ISOTROPIC, NOISE_ISOTROPIC]
+    bad = api.NonlinearFactorGraph(); bad.add(api.BetweenFactorPose3(X(0), X(1), api.Pose3(), api.noiseModel.Unit.Create(5)))
+    vals = api.Values(); vals.insert(X(0), api.Pose3()); vals.insert(X(1), api.Pose3())
+    with pytest.raises(ValueError):
+        api.extract(bad, vals)                                           # noise dimension mismatch (NonlinearFactor.cpp:97-104)
+    with pytest.raises(KeyError):
+        g2 = api.NonlinearFactorGraph(); g2.add(api.BetweenFactorPose3(X(0), X(7), api.Pose3(), api.noiseModel.Unit.Create(6)))
+        api.extract(g2, vals)
+
+
+@pytest.mark.gpu
+def test_general_sfm_factor_B_written_like_the_reference():
+    """tests/testGeneralSFMFactorB.cpp:44-63: default LM on dubrovnik-3-7-pre, no priors -> 0.0199833 +- 1e-5."""
+    g, graph, initial = _dubrovnik_graph(priors=False)
+    assert abs(graph.error(initial) - 2764.21929281) < 1e-6
+    lm = api.LevenbergMarquardtOptimizer(graph, initial)
+    actual = lm.optimize()
+    assert abs(lm.error() - 0.0199833) < 1e-5 and abs(graph.error(actual) - lm.error()) < 1e-12
+    assert lm.iterations() == int(g["default_iterations"])
+    assert isinstance(actual.at(C(0)), api.PinholeCameraCal3Bundler) and actual.at(P(0)).shape == (3,)

@@ -90,12 +90,25 @@ class PinholeCameraCal3Bundler:
 
 
 # ---- noise models ------------------------------------------------------------------------------------------------
+def _robust_weight(kind, k, d):
+    a = abs(d)
+    if kind == 1: return 1.0 / (1.0 + a / k)
+    if kind == 2: return 1.0 if a <= k else k / a
+    if kind == 3: return k * k / (k * k + d * d)
+    if kind == 4: return (1.0 - d * d / (k * k)) ** 2 if a <= k else 0.0
+    if kind == 5: return float(np.exp(-(d * d) / (k * k)))
+    if kind == 6: return k ** 4 / (k * k + d * d) ** 2
+    return 1.0
+
+
 class _Noise:
     def __init__(self, kind, dim, params=()):
         self.kind, self._dim, self.params = kind, int(dim), np.asarray(params, np.float64).reshape(-1)
 
+    robust = (0, 0.0)       # (ROBUST_*, parameter): set by noiseModel.Robust.Create
+
     def dim(self): return self._dim
-    def key(self): return (self.kind, self._dim, self.params.tobytes())
+    def key(self): return (self.kind, self._dim, self.params.tobytes(), self.robust)
 
 
 class noiseModel:
@@ -159,6 +172,33 @@ class noiseModel:
             if smart and np.all(S == np.diag(np.diag(S))):
                 return noiseModel.Diagonal.Variances(np.diag(S), True)
             return noiseModel.Gaussian.Information(np.linalg.inv(S), False)
+
+    class mEstimator:
+        """linear/LossFunctions.h: the six m-estimators of the GPU path (Block re-weighting, the default scheme)."""
+        class _Est:
+            kind = 0
+            def __init__(self, k):
+                if not k > 0:
+                    raise ValueError("mEstimator parameter must be > 0")        # LossFunctions.cpp constructors
+                self.k = float(k)
+            @classmethod
+            def Create(cls, k): return cls(k)
+            def weight(self, distance):
+                return _robust_weight(self.kind, self.k, float(distance))
+        class Fair(_Est): kind = 1
+        class Huber(_Est): kind = 2
+        class Cauchy(_Est): kind = 3
+        class Tukey(_Est): kind = 4
+        class Welsch(_Est): kind = 5
+        class GemanMcClure(_Est): kind = 6
+
+    class Robust:
+        @staticmethod
+        def Create(robust, noise):
+            """noiseModel::Robust::Create(robust, noise) (linear/NoiseModel.cpp:731-734)."""
+            n = _Noise(noise.kind, noise.dim(), noise.params)
+            n.robust = (robust.kind, robust.k)
+            return n
 
 
 # ---- factors ---------------------------------------------------------------------------------------------------------
@@ -248,7 +288,7 @@ def extract(graph: NonlinearFactorGraph, values: Values):
             raise ValueError("NoiseModelFactor: NoiseModel has wrong dimension")     # NonlinearFactor.cpp:97-104
         key = model.key()
         if key not in noise_ids:
-            noise_ids[key] = p.add_noise(model.kind, model.dim(), model.params)
+            noise_ids[key] = p.add_noise(model.kind, model.dim(), model.params, model.robust)
         return noise_ids[key]
 
     def vid(k):

@@ -449,10 +449,10 @@ int gtg_destroy(gtg_handle c) {
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
                            &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->delta_lm, &c->S,
-                           &c->Dinv, &c->xred, &c->partials, &c->scalars};
+                           &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
-                            &c->noise_kind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.proj_pose, &f.proj_point,
+                            &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.proj_pose, &f.proj_point,
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
                             &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
@@ -507,7 +507,18 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
         default: throw std::invalid_argument("unsupported noise model kind (Robust/Constrained are out of scope)");
       }
     }
+    std::vector<int32_t> rkind(p->n_noise, GTG_ROBUST_NONE);
+    std::vector<double> rk(p->n_noise, 0.0);
+    for (int i = 0; i < p->n_noise; i++) {
+      if (p->noise_robust) rkind[i] = p->noise_robust[i];
+      if (rkind[i] < GTG_ROBUST_NONE || rkind[i] > GTG_ROBUST_GEMANMCCLURE) throw std::invalid_argument("unsupported m-estimator");
+      if (rkind[i] != GTG_ROBUST_NONE) {
+        rk[i] = p->noise_robust_param ? p->noise_robust_param[i] : 0.0;
+        if (!(rk[i] > 0.0)) throw std::invalid_argument("m-estimator parameter must be > 0");   // LossFunctions.cpp ctor checks
+      }
+    }
     up(c->noise_kind, kind, s); up(c->noise_off, noff, s); up(c->noise_data, data, s);
+    up(c->noise_rkind, rkind, s); up(c->noise_rk, rk, s);
   }
   auto check_noise = [&](int idx, int dim, const char* what) {
     if (idx < 0 || idx >= p->n_noise || p->noise_dim[idx] != dim)

@@ -98,7 +98,8 @@ struct gtg_context {
   gt::DevBuf<int64_t> red_off;
 
   // ---- noise table (inverse sigmas precomputed like the reference constructors) ------------------
-  gt::DevBuf<int32_t> noise_kind;
+  gt::DevBuf<int32_t> noise_kind, noise_rkind;
+  gt::DevBuf<double> noise_rk;
   gt::DevBuf<int64_t> noise_off;
   gt::DevBuf<double> noise_data;
 

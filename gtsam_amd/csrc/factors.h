@@ -13,6 +13,48 @@
 
 namespace gt {
 
+// A noise-table entry as the factor evaluators see it: base model + optional m-estimator.
+struct NoiseRef {
+  int kind; const double* data;   // GTG_NOISE_*, device data (inverse sigmas / R)
+  int rkind; double rk;           // GTG_ROBUST_* (0 = none) and its parameter
+};
+
+// m-estimators (linear/LossFunctions.cpp): weight(distance) and loss(distance), distance = ||whitened residual||
+GT_HD double robust_weight(int rkind, double k, double d) {
+  const double a = fabs(d);
+  switch (rkind) {
+    case 1: return 1.0 / (1.0 + a / k);                                    // Fair   :146-148
+    case 2: return (a <= k) ? 1.0 : (k / a);                               // Huber  :179-182
+    case 3: return (k * k) / (k * k + d * d);                              // Cauchy :217-219
+    case 4: { if (a <= k) { const double t = 1.0 - d * d / (k * k); return t * t; } return 0.0; }   // Tukey :250-256
+    case 5: return exp(-(d * d) / (k * k));                                // Welsch :289-292
+    case 6: { const double c2 = k * k, c4 = c2 * c2, ce = c2 + d * d; return c4 / (ce * ce); }     // Geman-McClure :320-325
+    default: return 1.0;
+  }
+}
+GT_HD double robust_loss(int rkind, double k, double d) {
+  const double a = fabs(d);
+  switch (rkind) {
+    case 1: { const double ne = a / k; return k * k * (ne - log1p(ne)); }                            // :150-155
+    case 2: return (a <= k) ? d * d / 2 : k * (a - (k / 2));                                         // :184-191
+    case 3: return k * k * log1p(d * d / (k * k)) * 0.5;                                             // :221-224
+    case 4: { if (a <= k) { const double t = 1.0 - d * d / (k * k); return k * k * (1 - t * t * t) / 6.0; } return k * k / 6.0; }  // :258-267
+    case 5: return k * k * 0.5 * -expm1(-(d * d) / (k * k));                                         // :294-297
+    case 6: { const double c2 = k * k, e2 = d * d; return 0.5 * (c2 * e2) / (c2 + e2); }             // :327-331
+    default: return 0.5 * d * d;
+  }
+}
+// NoiseModelFactor::error: noiseModel_->loss(squaredMahalanobisDistance(r)) (NonlinearFactor.cpp:136-147);
+// plain models 0.5 d^2, Robust robust_->loss(sqrt(d^2)) (NoiseModel.h:716-718)
+GT_HD double factor_loss(const NoiseRef& n, double sq) { return n.rkind ? robust_loss(n.rkind, n.rk, sqrt(sq)) : 0.5 * sq; }
+// Robust::WhitenSystem = noise_->WhitenSystem then robust_->reweight (Block scheme): scale by sqrt(weight(||b||))
+GT_HD double reweight_factor(const NoiseRef& n, const double* b, int m) {
+  if (!n.rkind) return 1.0;
+  double s = 0.0;
+  for (int i = 0; i < m; i++) s += b[i] * b[i];
+  return sqrt(robust_weight(n.rkind, n.rk, sqrt(s)));
+}
+
 // row lengths of the per-factor Jacobian records (doubles)
 constexpr int kSfmRec = 2 * 9 + 2 * 3 + 2;   // [A1 2x9 | A2 2x3 | b 2]
 constexpr int kProjRec = 2 * 6 + 2 * 3 + 2;  // [A1 2x6 | A2 2x3 | b 2]
@@ -20,8 +62,11 @@ constexpr int kBetweenRec = 36 + 36 + 6;     // [A1 6x6 | A2 6x6 | b 6]
 constexpr int kPriorRec = 81 + 9;            // [A dxd packed | pad ... | b d at 81]
 
 // ---- GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3> ---------------------------------------
-GT_HD void sfm_linearize(const double* cam, const double* pt, const double* z, int nkind,
-                         const double* nd, double* J) {
+// NOTE (reference behaviour, reproduced on purpose): GeneralSFMFactor::linearize whitens H1, H2 and b through
+// noiseModel->Whiten(Matrix) separately (GeneralSFMFactor.h:162-168); for a Robust model that path re-weights with
+// an EMPTY error vector, i.e. weight 1 -- the m-estimator changes this factor's error(), not its linear system.
+GT_HD void sfm_linearize(const double* cam, const double* pt, const double* z, const NoiseRef& n, double* J) {
+  const int nkind = n.kind; const double* nd = n.data;
   double pi[2];
   if (!sfm_project(cam, pt, pi, J, J + 18)) {  // CheiralityException: H1,H2,b = 0 (:153-158)
     for (int i = 0; i < kSfmRec; i++) J[i] = 0.0;
@@ -33,17 +78,18 @@ GT_HD void sfm_linearize(const double* cam, const double* pt, const double* z, i
   whiten_cols<2>(nkind, nd, J + 18, 3);
   whiten_cols<2>(nkind, nd, J + 24, 1);
 }
-GT_HD double sfm_error(const double* cam, const double* pt, const double* z, int nkind, const double* nd) {
+GT_HD double sfm_error(const double* cam, const double* pt, const double* z, const NoiseRef& n) {
   double pi[2];
-  if (!sfm_project(cam, pt, pi, nullptr, nullptr)) return 0.0;  // evaluateError returns Z_2x1 (:131-137)
+  if (!sfm_project(cam, pt, pi, nullptr, nullptr)) return factor_loss(n, 0.0);  // evaluateError returns Z_2x1 (:131-137)
   double r[2] = {pi[0] - z[0], pi[1] - z[1]};
-  whiten_cols<2>(nkind, nd, r, 1);
-  return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+  whiten_cols<2>(n.kind, n.data, r, 1);
+  return factor_loss(n, r[0] * r[0] + r[1] * r[1]);
 }
 
 // ---- GenericProjectionFactor<Pose3,Point3,Cal3_S2> ---------------------------------------------
 GT_HD void proj_linearize(const double* pose, const double* K, const double* sensor, const double* pt,
-                          const double* z, int nkind, const double* nd, double* J) {
+                          const double* z, const NoiseRef& n, double* J) {
+  const int nkind = n.kind; const double* nd = n.data;
   double pi[2];
   bool ok;
   if (sensor) {  // pose.compose(body_P_sensor, H0); H1 = H1 * H0, H0 = sensor^-1 AdjointMap (Lie.h:56-61)
@@ -72,9 +118,10 @@ GT_HD void proj_linearize(const double* pose, const double* K, const double* sen
   whiten_cols<2>(nkind, nd, J, 6);
   whiten_cols<2>(nkind, nd, J + 12, 3);
   whiten_cols<2>(nkind, nd, J + 18, 1);
+  if (n.rkind) { const double w = reweight_factor(n, J + 18, 2); for (int i = 0; i < kProjRec; i++) J[i] *= w; }
 }
 GT_HD double proj_error(const double* pose, const double* K, const double* sensor, const double* pt,
-                        const double* z, int nkind, const double* nd) {
+                        const double* z, const NoiseRef& n) {
   double pi[2], r[2];
   bool ok;
   if (sensor) {
@@ -86,8 +133,8 @@ GT_HD double proj_error(const double* pose, const double* K, const double* senso
   }
   if (ok) { r[0] = pi[0] - z[0]; r[1] = pi[1] - z[1]; }
   else { r[0] = 2.0 * K[0]; r[1] = 2.0 * K[0]; }
-  whiten_cols<2>(nkind, nd, r, 1);
-  return 0.5 * (r[0] * r[0] + r[1] * r[1]);
+  whiten_cols<2>(n.kind, n.data, r, 1);
+  return factor_loss(n, r[0] * r[0] + r[1] * r[1]);
 }
 
 // ---- BetweenFactor<Pose3> ---------------------------------------------------------------------
@@ -97,8 +144,8 @@ GT_HD void between_residual(const double* T1, const double* T2, const double* Z,
   pose_between(T1, T2, h);
   pose_local(Z, h, r);
 }
-GT_HD void between_linearize(const double* T1, const double* T2, const double* Z, int nkind,
-                             const double* nd, double* J) {
+GT_HD void between_linearize(const double* T1, const double* T2, const double* Z, const NoiseRef& n, double* J) {
+  const int nkind = n.kind; const double* nd = n.data;
   double h[12], hi[12], r[6];
   between_residual(T1, T2, Z, h, r);
   pose_inverse(h, hi);
@@ -110,20 +157,22 @@ GT_HD void between_linearize(const double* T1, const double* T2, const double* Z
   whiten_cols<6>(nkind, nd, J, 6);
   whiten_cols<6>(nkind, nd, J + 36, 6);
   whiten_cols<6>(nkind, nd, J + 72, 1);
+  if (n.rkind) { const double w = reweight_factor(n, J + 72, 6); for (int i = 0; i < kBetweenRec; i++) J[i] *= w; }
 }
-GT_HD double between_error(const double* T1, const double* T2, const double* Z, int nkind, const double* nd) {
+GT_HD double between_error(const double* T1, const double* T2, const double* Z, const NoiseRef& n) {
   double h[12], r[6];
   between_residual(T1, T2, Z, h, r);
-  whiten_cols<6>(nkind, nd, r, 1);
+  whiten_cols<6>(n.kind, n.data, r, 1);
   double e = 0.0;
   for (int i = 0; i < 6; i++) e += r[i] * r[i];
-  return 0.5 * e;
+  return factor_loss(n, e);
 }
 
 // ---- PriorFactor<T> ---------------------------------------------------------------------------
 // r = -Local(x, prior), H = I (approximate on purpose, PriorFactor.h:99).  d = tangent dim.
 template <int D>
-GT_HD void prior_linearize_d(int vtype, const double* x, const double* z, int nkind, const double* nd, double* J) {
+GT_HD void prior_linearize_d(int vtype, const double* x, const double* z, const NoiseRef& n, double* J) {
+  const int nkind = n.kind; const double* nd = n.data;
   double loc[9];
   value_local(vtype, x, z, loc);
   for (int i = 0; i < kPriorRec; i++) J[i] = 0.0;
@@ -131,22 +180,23 @@ GT_HD void prior_linearize_d(int vtype, const double* x, const double* z, int nk
   for (int i = 0; i < D; i++) J[81 + i] = loc[i];  // b = -r = Local(x, prior)
   whiten_cols<D>(nkind, nd, J, D);
   whiten_cols<D>(nkind, nd, J + 81, 1);
+  if (n.rkind) { const double w = reweight_factor(n, J + 81, D); for (int i = 0; i < kPriorRec; i++) J[i] *= w; }
 }
-GT_HD void prior_linearize(int vtype, const double* x, const double* z, int nkind, const double* nd, double* J) {
-  if (vtype == 0) prior_linearize_d<6>(vtype, x, z, nkind, nd, J);
-  else if (vtype == 1) prior_linearize_d<9>(vtype, x, z, nkind, nd, J);
-  else prior_linearize_d<3>(vtype, x, z, nkind, nd, J);
+GT_HD void prior_linearize(int vtype, const double* x, const double* z, const NoiseRef& n, double* J) {
+  if (vtype == 0) prior_linearize_d<6>(vtype, x, z, n, J);
+  else if (vtype == 1) prior_linearize_d<9>(vtype, x, z, n, J);
+  else prior_linearize_d<3>(vtype, x, z, n, J);
 }
-GT_HD double prior_error(int vtype, const double* x, const double* z, int nkind, const double* nd) {
+GT_HD double prior_error(int vtype, const double* x, const double* z, const NoiseRef& n) {
   double r[9];
   value_local(vtype, x, z, r);
   const int d = vtype == 0 ? 6 : vtype == 1 ? 9 : 3;
-  if (d == 6) whiten_cols<6>(nkind, nd, r, 1);
-  else if (d == 9) whiten_cols<9>(nkind, nd, r, 1);
-  else whiten_cols<3>(nkind, nd, r, 1);
+  if (d == 6) whiten_cols<6>(n.kind, n.data, r, 1);
+  else if (d == 9) whiten_cols<9>(n.kind, n.data, r, 1);
+  else whiten_cols<3>(n.kind, n.data, r, 1);
   double e = 0.0;
   for (int i = 0; i < d; i++) e += r[i] * r[i];
-  return 0.5 * e;
+  return factor_loss(n, e);
 }
 
 }  // namespace gt

@@ -40,6 +40,9 @@ struct NoiseTab {
   const int32_t* kind;
   const int64_t* off;
   const double* data;
+  const int32_t* rkind;
+  const double* rk;
+  __device__ __forceinline__ NoiseRef ref(int i) const { return NoiseRef{kind[i], data + off[i], rkind[i], rk[i]}; }
 };
 
 // ---- linearize ------------------------------------------------------------------------------------
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __
     for (int k = 0; k < 3; k++) p[k] = pp[k];
     zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
     const int ni = nz[i];
-    sfm_linearize(c, p, zz, nt.kind[ni], nt.data + nt.off[ni], rec);
+    sfm_linearize(c, p, zz, nt.ref(ni), rec);
     double* out = J + (int64_t)kSfmRec * i;
     for (int k = 0; k < kSfmRec; k++) out[k] = rec[k];
   }
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
     if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
     zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
     const int ni = nz[i];
-    proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.kind[ni], nt.data + nt.off[ni], rec);
+    proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(ni), rec);
     double* out = J + (int64_t)kProjRec * i;
     for (int k = 0; k < kProjRec; k++) out[k] = rec[k];
   }
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_between(int64_t n, const int32_t
     const double* b = values + val_off[v2[i]];
     for (int k = 0; k < 12; k++) { T1[k] = a[k]; T2[k] = b[k]; Z[k] = z[12 * i + k]; }
     const int ni = nz[i];
-    between_linearize(T1, T2, Z, nt.kind[ni], nt.data + nt.off[ni], J + (int64_t)kBetweenRec * i);
+    between_linearize(T1, T2, Z, nt.ref(ni), J + (int64_t)kBetweenRec * i);
   }
 }
 
@@ -105,8 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_prior(int64_t n, const int32_t* 
   for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const int v = var[i];
     const int ni = nz[i];
-    prior_linearize(var_type[v], values + val_off[v], pdata + poff[i], nt.kind[ni], nt.data + nt.off[ni],
-                    J + (int64_t)kPriorRec * i);
+    prior_linearize(var_type[v], values + val_off[v], pdata + poff[i], nt.ref(ni), J + (int64_t)kPriorRec * i);
   }
 }
 
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     for (int k = 0; k < 3; k++) p[k] = pp[k];
     zz[0] = a.sfm_z[2 * i]; zz[1] = a.sfm_z[2 * i + 1];
     const int ni = a.sfm_nz[i];
-    acc += sfm_error(c, p, zz, nt.kind[ni], nt.data + nt.off[ni]);
+    acc += sfm_error(c, p, zz, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_proj; i += stride) {
     double T[12], p[3], zz[2], K[5], S[12];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     if (si >= 0) for (int k = 0; k < 12; k++) S[k] = a.sensor[12 * si + k];
     zz[0] = a.proj_z[2 * i]; zz[1] = a.proj_z[2 * i + 1];
     const int ni = a.proj_nz[i];
-    acc += proj_error(T, K, si >= 0 ? S : nullptr, p, zz, nt.kind[ni], nt.data + nt.off[ni]);
+    acc += proj_error(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_between; i += stride) {
     double T1[12], T2[12], Z[12];
@@ -154,13 +156,12 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     const double* y = values + a.val_off[a.bt_v2[i]];
     for (int k = 0; k < 12; k++) { T1[k] = x[k]; T2[k] = y[k]; Z[k] = a.bt_z[12 * i + k]; }
     const int ni = a.bt_nz[i];
-    acc += between_error(T1, T2, Z, nt.kind[ni], nt.data + nt.off[ni]);
+    acc += between_error(T1, T2, Z, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_prior; i += stride) {
     const int v = a.pr_var[i];
     const int ni = a.pr_nz[i];
-    acc += prior_error(a.var_type[v], values + a.val_off[v], a.pr_data + a.pr_off[i], nt.kind[ni],
-                       nt.data + nt.off[ni]);
+    acc += prior_error(a.var_type[v], values + a.val_off[v], a.pr_data + a.pr_off[i], nt.ref(ni));
   }
   const double s = block_sum(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(int64_t n, const double* __res
 }
 
 // ---- launchers --------------------------------------------------------------------------------------
-static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p}; }
+static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p, c.noise_rkind.p, c.noise_rk.p}; }
 
 void launch_linearize(gtg_context& c) {
   auto& f = c.f;

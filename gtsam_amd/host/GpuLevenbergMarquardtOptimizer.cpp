@@ -62,17 +62,37 @@ void packCamera(const SfmCamera& c, double* p) {
 }
 
 struct NoiseTable {
-  std::vector<int32_t> kind, dim; std::vector<int64_t> off; std::vector<double> data;
+  std::vector<int32_t> kind, dim, rkind; std::vector<int64_t> off; std::vector<double> data, rparam;
   std::map<const noiseModel::Base*, int32_t> seen;
-  int32_t add(const SharedNoiseModel& nm, size_t expect_dim) {
-    if (!nm) throw std::invalid_argument("factor without a noise model is not supported");
-    auto it = seen.find(nm.get());
+  // noiseModel::Robust (NoiseModel.h:670-760) -> (GTG_ROBUST_*, parameter) beside the base model's row
+  static void estimator(const noiseModel::Robust& rb, int32_t* rk, double* k) {
+    namespace me = noiseModel::mEstimator;
+    const auto& e = rb.robust();
+    if (!e) throw std::invalid_argument("Robust noise model without an m-estimator");
+    if (std::dynamic_pointer_cast<me::Null>(e)) { *rk = GTG_ROBUST_NONE; *k = 0.0; return; }
+    if (e->reweightScheme() != me::Base::Block)
+      throw std::invalid_argument("m-estimators with the Scalar re-weighting scheme are outside the GPU path");
+    if (auto p = std::dynamic_pointer_cast<me::Fair>(e)) { *rk = GTG_ROBUST_FAIR; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::Huber>(e)) { *rk = GTG_ROBUST_HUBER; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::Cauchy>(e)) { *rk = GTG_ROBUST_CAUCHY; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::Tukey>(e)) { *rk = GTG_ROBUST_TUKEY; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::Welsch>(e)) { *rk = GTG_ROBUST_WELSCH; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::GemanMcClure>(e)) { *rk = GTG_ROBUST_GEMANMCCLURE; *k = p->modelParameter(); }
+    else throw std::invalid_argument("m-estimator outside the GPU path (supported: Fair, Huber, Cauchy, Tukey, Welsch, GemanMcClure)");
+  }
+  int32_t add(const SharedNoiseModel& outer, size_t expect_dim) {
+    if (!outer) throw std::invalid_argument("factor without a noise model is not supported");
+    auto it = seen.find(outer.get());
     if (it != seen.end()) return it->second;
-    if (nm->dim() != expect_dim) throw std::invalid_argument("NoiseModelFactor: NoiseModel has wrong dimension");
+    if (outer->dim() != expect_dim) throw std::invalid_argument("NoiseModelFactor: NoiseModel has wrong dimension");
+    SharedNoiseModel nm = outer;
+    int32_t rk = GTG_ROBUST_NONE; double rp = 0.0;
+    if (auto rb = std::dynamic_pointer_cast<noiseModel::Robust>(outer)) { estimator(*rb, &rk, &rp); nm = rb->noise(); }
     const int32_t idx = (int32_t)kind.size();
     off.push_back((int64_t)data.size()); dim.push_back((int32_t)nm->dim());
+    rkind.push_back(rk); rparam.push_back(rp);
     if (nm->isConstrained() || std::dynamic_pointer_cast<noiseModel::Robust>(nm))
-      throw std::invalid_argument("Constrained / Robust noise models are outside the GPU path");
+      throw std::invalid_argument("Constrained / nested Robust noise models are outside the GPU path");
     if (nm->isUnit()) kind.push_back(GTG_NOISE_UNIT);
     else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { kind.push_back(GTG_NOISE_ISOTROPIC); data.push_back(iso->sigma()); }
     else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { kind.push_back(GTG_NOISE_DIAGONAL); for (size_t i = 0; i < dg->dim(); i++) data.push_back(dg->sigma(i)); }
@@ -81,7 +101,7 @@ struct NoiseTable {
       const Matrix R = ga->R();
       for (int i = 0; i < R.rows(); i++) for (int j = 0; j < R.cols(); j++) data.push_back(R(i, j));
     } else throw std::invalid_argument("unsupported noise model type");
-    seen[nm.get()] = idx;
+    seen[outer.get()] = idx;
     return idx;
   }
 };
@@ -178,6 +198,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
   pb.n_vars = (int32_t)m.keys.size(); pb.var_type = m.var_type.data();
   pb.n_noise = (int32_t)nt.kind.size(); pb.noise_kind = nt.kind.data(); pb.noise_dim = nt.dim.data();
   pb.noise_off = nt.off.data(); pb.noise_data = nt.data.data();
+  pb.noise_robust = nt.rkind.data(); pb.noise_robust_param = nt.rparam.data();
   pb.n_sfm = (int64_t)sfm_cam.size(); pb.sfm_cam = sfm_cam.data(); pb.sfm_point = sfm_pt.data(); pb.sfm_z = sfm_z.data(); pb.sfm_noise = sfm_nz.data();
   pb.n_proj = (int64_t)pj_pose.size(); pb.proj_pose = pj_pose.data(); pb.proj_point = pj_pt.data(); pb.proj_z = pj_z.data();
   pb.proj_noise = pj_nz.data(); pb.proj_calib = pj_cal.data(); pb.proj_sensor = pj_sen.data();

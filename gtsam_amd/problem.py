@@ -16,6 +16,7 @@ import numpy as np
 VAR_POSE3, VAR_SFM_CAMERA, VAR_POINT3 = 0, 1, 2
 FAC_GENERAL_SFM, FAC_PROJECTION, FAC_BETWEEN_POSE3, FAC_PRIOR = 0, 1, 2, 3
 NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN = 0, 1, 2, 3
+ROBUST_NONE, ROBUST_FAIR, ROBUST_HUBER, ROBUST_CAUCHY, ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE = range(7)
 
 STORAGE = {VAR_POSE3: 12, VAR_SFM_CAMERA: 17, VAR_POINT3: 3}
 TANGENT = {VAR_POSE3: 6, VAR_SFM_CAMERA: 9, VAR_POINT3: 3}
@@ -26,7 +27,7 @@ class gtg_problem(C.Structure):
     _fields_ = [
         ("n_vars", C.c_int32), ("var_type", _i32p),
         ("n_noise", C.c_int32), ("noise_kind", _i32p), ("noise_dim", _i32p), ("noise_off", _i64p),
-        ("noise_data", _f64p),
+        ("noise_data", _f64p), ("noise_robust", _i32p), ("noise_robust_param", _f64p),
         ("n_sfm", C.c_int64), ("sfm_cam", _i32p), ("sfm_point", _i32p), ("sfm_z", _f64p),
         ("sfm_noise", _i32p),
         ("n_proj", C.c_int64), ("proj_pose", _i32p), ("proj_point", _i32p), ("proj_z", _f64p),
@@ -51,6 +52,8 @@ class Problem:
     noise_dim: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     noise_off: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))
     noise_data: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
+    noise_robust: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    noise_robust_param: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
     sfm_cam: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     sfm_point: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     sfm_z: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
@@ -75,6 +78,7 @@ class Problem:
     def __post_init__(self):
         for name, dt in (("var_type", np.int32), ("noise_kind", np.int32), ("noise_dim", np.int32),
                          ("noise_off", np.int64), ("noise_data", np.float64),
+                         ("noise_robust", np.int32), ("noise_robust_param", np.float64),
                          ("sfm_cam", np.int32), ("sfm_point", np.int32), ("sfm_z", np.float64),
                          ("sfm_noise", np.int32), ("proj_pose", np.int32), ("proj_point", np.int32),
                          ("proj_z", np.float64), ("proj_noise", np.int32), ("proj_calib", np.int32),
@@ -106,8 +110,9 @@ class Problem:
         return np.concatenate([[0], np.cumsum(s)]).astype(np.int64)
 
     # ---- noise table -------------------------------------------------------------------------
-    def add_noise(self, kind: int, dim: int, data=()) -> int:
-        """Append a noise model; ``data`` = () | [sigma] | sigmas[dim] | R[dim*dim] row-major."""
+    def add_noise(self, kind: int, dim: int, data=(), robust=(ROBUST_NONE, 0.0)) -> int:
+        """Append a noise model; ``data`` = () | [sigma] | sigmas[dim] | R[dim*dim] row-major;
+        ``robust`` = (ROBUST_*, parameter) wraps it in noiseModel::Robust."""
         data = _a(data, np.float64)
         want = {NOISE_UNIT: 0, NOISE_ISOTROPIC: 1, NOISE_DIAGONAL: dim, NOISE_GAUSSIAN: dim * dim}[kind]
         if data.size != want:
@@ -117,6 +122,11 @@ class Problem:
         self.noise_kind = np.append(self.noise_kind, np.int32(kind))
         self.noise_dim = np.append(self.noise_dim, np.int32(dim))
         self.noise_data = np.concatenate([self.noise_data, data])
+        if self.noise_robust.size < idx:      # tables created before robust support / loaded without it
+            self.noise_robust = np.concatenate([self.noise_robust, np.zeros(idx - self.noise_robust.size, np.int32)])
+            self.noise_robust_param = np.concatenate([self.noise_robust_param, np.zeros(idx - self.noise_robust_param.size)])
+        self.noise_robust = np.append(self.noise_robust, np.int32(robust[0]))
+        self.noise_robust_param = np.append(self.noise_robust_param, np.float64(robust[1]))
         return idx
 
     # ---- ctypes view (keeps the arrays alive through the returned object) ---------------------
@@ -135,6 +145,11 @@ class Problem:
         p.noise_dim = ptr(self.noise_dim, C.c_int32)
         p.noise_off = ptr(self.noise_off, C.c_int64)
         p.noise_data = ptr(self.noise_data, C.c_double)
+        if self.noise_robust.size != self.noise_kind.size:
+            self.noise_robust = np.zeros(self.noise_kind.size, np.int32)
+            self.noise_robust_param = np.zeros(self.noise_kind.size, np.float64)
+        p.noise_robust = ptr(self.noise_robust, C.c_int32)
+        p.noise_robust_param = ptr(self.noise_robust_param, C.c_double)
         p.n_sfm = self.n_sfm
         p.sfm_cam = ptr(self.sfm_cam, C.c_int32)
         p.sfm_point = ptr(self.sfm_point, C.c_int32)

@@ -51,6 +51,16 @@ enum { GTG_FAC_GENERAL_SFM = 0,   /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>
  * invsigma = 1.0/sigma exactly like the reference constructors do (NoiseModel.cpp:275-281). */
 enum { GTG_NOISE_UNIT = 0, GTG_NOISE_ISOTROPIC = 1, GTG_NOISE_DIAGONAL = 2, GTG_NOISE_GAUSSIAN = 3 };
 
+/* Optional m-estimator wrapped around a noise-table entry = noiseModel::Robust(robust, noise)
+ * (linear/NoiseModel.h:678-740, linear/LossFunctions.cpp), Block re-weighting scheme (the default):
+ * whitened system scaled by sqrt(weight(||whitened b||)) (LossFunctions.cpp:51-124), factor error =
+ * loss(||whitened r||) (NoiseModel.h:716-718).  Parameter = the estimator's modelParameter() (c or k).
+ * As in the reference, GTG_FAC_GENERAL_SFM factors are NOT re-weighted when they linearize (their own linearize()
+ * whitens H1, H2, b one at a time through Robust::Whiten(Matrix), slam/GeneralSFMFactor.h:162-168, where the
+ * weight evaluates to 1); the m-estimator only enters their error(). */
+enum { GTG_ROBUST_NONE = 0, GTG_ROBUST_FAIR = 1, GTG_ROBUST_HUBER = 2, GTG_ROBUST_CAUCHY = 3, GTG_ROBUST_TUKEY = 4,
+       GTG_ROBUST_WELSCH = 5, GTG_ROBUST_GEMANMCCLURE = 6 };
+
 /* The factor graph in structure-of-arrays form: what the extractor produces by walking a
  * gtsam::NonlinearFactorGraph once (FactorGraph.h:92 factors_, Factor.h keys_). Variable ids are
  * dense 0..n_vars-1 (the shim maps gtsam::Key -> id in Values order, Values.h:74-79). */
@@ -63,6 +73,8 @@ typedef struct gtg_problem {
   const int32_t* noise_dim;      /* [n_noise] */
   const int64_t* noise_off;      /* [n_noise] offset into noise_data */
   const double* noise_data;
+  const int32_t* noise_robust;   /* [n_noise] GTG_ROBUST_* or NULL (no robust models) */
+  const double* noise_robust_param; /* [n_noise] c / k of the m-estimator */
 
   int64_t n_sfm;                 /* GTG_FAC_GENERAL_SFM */
   const int32_t* sfm_cam;        /* [n_sfm] variable id of the SFM_CAMERA */
@@ -113,7 +125,8 @@ int gtg_upload_problem(gtg_handle h, const gtg_problem* p, int shard, int n_shar
 
 /* Optional: position of each non-landmark variable in the reduced system (a fill-reducing
  * ordering, inference/Ordering.cpp:42-124).  order[i] = variable id placed i-th; n = number of
- * non-landmark variables.  Default: increasing variable id. */
+ * non-landmark variables.  Must be called before gtg_upload_problem.  Default: a reverse
+ * Cuthill-McKee ordering of the reduced graph computed at upload (band-limits the tile fill). */
 int gtg_set_reduced_ordering(gtg_handle h, const int32_t* order, int32_t n);
 
 /* Values in packed storage, variable id order (see GTG_VAR_*).  Values.h:74-79. */

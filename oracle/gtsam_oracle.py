@@ -24,6 +24,8 @@ import numpy as np
 
 from gtsam_amd.problem import (FAC_BETWEEN_POSE3, FAC_GENERAL_SFM, FAC_PRIOR, FAC_PROJECTION,
                                NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT,
+                               ROBUST_CAUCHY, ROBUST_FAIR, ROBUST_GEMANMCCLURE, ROBUST_HUBER, ROBUST_NONE,
+                               ROBUST_TUKEY, ROBUST_WELSCH,
                                STORAGE, TANGENT, VAR_POINT3, VAR_POSE3, VAR_SFM_CAMERA, Problem)
 
 EPS = np.finfo(np.float64).eps
@@ -270,7 +272,101 @@ def _gather(values, off, ids, size):
     return values[idx]
 
 
+# ------------------------------------------------------------------------------------------------
+# m-estimators   (linear/LossFunctions.cpp) and noiseModel::Robust (linear/NoiseModel.h:670-760)
+# ------------------------------------------------------------------------------------------------
+def robust_weight(rkind, k, d):
+    """mEstimator::*::weight(distance): Fair :146, Huber :179, Cauchy :217, Tukey :250, Welsch :289, GemanMcClure :320."""
+    d = np.asarray(d, np.float64); a = np.abs(d)
+    if rkind == ROBUST_FAIR:
+        return 1.0 / (1.0 + a / k)
+    if rkind == ROBUST_HUBER:
+        return np.where(a <= k, 1.0, k / np.where(a > 0, a, 1.0))
+    if rkind == ROBUST_CAUCHY:
+        return (k * k) / (k * k + d * d)
+    if rkind == ROBUST_TUKEY:
+        return np.where(a <= k, (1.0 - d * d / (k * k)) ** 2, 0.0)
+    if rkind == ROBUST_WELSCH:
+        return np.exp(-(d * d) / (k * k))
+    if rkind == ROBUST_GEMANMCCLURE:
+        return (k ** 4) / (k * k + d * d) ** 2
+    return np.ones_like(d)
+
+
+def robust_loss(rkind, k, d):
+    """mEstimator::*::loss(distance): Fair :150, Huber :184, Cauchy :221, Tukey :258, Welsch :294, GemanMcClure :327."""
+    d = np.asarray(d, np.float64); a = np.abs(d)
+    if rkind == ROBUST_FAIR:
+        return k * k * (a / k - np.log1p(a / k))
+    if rkind == ROBUST_HUBER:
+        return np.where(a <= k, d * d / 2, k * (a - k / 2))
+    if rkind == ROBUST_CAUCHY:
+        return k * k * np.log1p(d * d / (k * k)) * 0.5
+    if rkind == ROBUST_TUKEY:
+        return np.where(a <= k, k * k * (1 - (1 - d * d / (k * k)) ** 3) / 6.0, k * k / 6.0)
+    if rkind == ROBUST_WELSCH:
+        return k * k * 0.5 * -np.expm1(-(d * d) / (k * k))
+    if rkind == ROBUST_GEMANMCCLURE:
+        return 0.5 * (k * k * d * d) / (k * k + d * d)
+    return 0.5 * d * d
+
+
+def _robust_of(p, ni):
+    rk = getattr(p, "noise_robust", None)
+    if rk is None or ni >= len(rk):
+        return ROBUST_NONE, 0.0
+    return int(rk[ni]), float(p.noise_robust_param[ni])
+
+
+def _reweight_many(p, noise_idx, A1, A2, b):
+    """Robust::WhitenSystem = base WhitenSystem, then robust_->reweight(A.., b) with the Block scheme
+    (LossFunctions.cpp:43-88): every block and b times sqrt(weight(||b||)).  In place on whitened data."""
+    for ni in np.unique(noise_idx):
+        rk, k = _robust_of(p, int(ni))
+        if rk == ROBUST_NONE:
+            continue
+        sel = noise_idx == ni
+        w = np.sqrt(robust_weight(rk, k, np.linalg.norm(b[sel], axis=1)))
+        A1[sel] *= w[:, None, None]
+        if A2 is not None:
+            A2[sel] *= w[:, None, None]
+        b[sel] *= w[:, None]
+
+
+def _loss_many(p, noise_idx, b):
+    """sum of noiseModel->loss(squaredMahalanobisDistance) over factors; b = whitened (un-reweighted) residual."""
+    sq = np.sum(b * b, axis=1)
+    e = 0.0
+    for ni in np.unique(noise_idx):
+        sel = noise_idx == ni
+        rk, k = _robust_of(p, int(ni))
+        if rk == ROBUST_NONE:
+            e += 0.5 * float(np.sum(sq[sel]))
+        else:                                                    # NoiseModel.h:716-718: robust_->loss(sqrt(d2))
+            e += float(np.sum(robust_loss(rk, k, np.sqrt(sq[sel]))))
+    return e
+
+
 def linearize(p: Problem, values):
+    """As _linearize_whitened, followed by the m-estimator re-weighting of Robust noise models for the factors that
+    linearize through NoiseModelFactor::linearize -> WhitenSystem (NonlinearFactor.cpp:150-182).  GeneralSFMFactor is
+    NOT re-weighted: its own linearize whitens H1, H2, b one by one through Robust::Whiten(Matrix), whose internal
+    WhitenSystem sees an empty b and hence weight 1 (GeneralSFMFactor.h:162-168, NoiseModel.h:705-709; measured on
+    the live reference)."""
+    lin = _linearize_whitened(p, values)
+    if getattr(p, "noise_robust", None) is None or not np.any(p.noise_robust):
+        return lin
+    if FAC_PROJECTION in lin:
+        _reweight_many(p, p.proj_noise, *lin[FAC_PROJECTION])
+    if FAC_BETWEEN_POSE3 in lin:
+        _reweight_many(p, p.between_noise, *lin[FAC_BETWEEN_POSE3])
+    if FAC_PRIOR in lin:
+        A, _, b, dims = lin[FAC_PRIOR]
+        _reweight_many(p, p.prior_noise, A, None, b)
+    return lin
+
+
+def _linearize_whitened(p: Problem, values):
     """NonlinearFactorGraph::linearize (nonlinear/NonlinearFactorGraph.cpp:239-278): per factor the
     whitened [A1 A2 b] of NoiseModelFactor::linearize (NonlinearFactor.cpp:150-182) /
     GeneralSFMFactor::linearize (slam/GeneralSFMFactor.h:141-177).
@@ -354,12 +450,14 @@ def jacobians_flat(p: Problem, values, ftype):
 
 def error(p: Problem, values):
     """NonlinearFactorGraph::error (NonlinearFactorGraph.cpp:170-179) = sum 0.5*||whiten(r)||^2
-    (NonlinearFactor.cpp:136-147).  b of linearize() is -whiten(r), so the sum of 0.5*|b|^2 is it."""
-    lin = linearize(p, values)
+    (NonlinearFactor.cpp:136-147), or the m-estimator loss of ||whiten(r)|| for Robust models.  b of the un-reweighted
+    linearization is -whiten(r)."""
+    lin = _linearize_whitened(p, values)
+    nz = {FAC_GENERAL_SFM: p.sfm_noise, FAC_PROJECTION: p.proj_noise, FAC_BETWEEN_POSE3: p.between_noise,
+          FAC_PRIOR: p.prior_noise}
     e = 0.0
     for ft, tup in lin.items():
-        b = tup[2]
-        e += 0.5 * float(np.sum(b * b))
+        e += _loss_many(p, nz[ft], tup[2])
     return e
 
 

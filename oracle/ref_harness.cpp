@@ -125,7 +125,7 @@ struct RefGraph {
   }
 };
 
-SharedNoiseModel makeNoise(const gtg_problem* p, int idx) {
+SharedNoiseModel makeBaseNoise(const gtg_problem* p, int idx) {
   const int kind = p->noise_kind[idx], dim = p->noise_dim[idx];
   const double* d = p->noise_data + p->noise_off[idx];
   switch (kind) {
@@ -138,6 +138,22 @@ SharedNoiseModel makeNoise(const gtg_problem* p, int idx) {
       return noiseModel::Gaussian::SqrtInformation(R, false);
     }
   }
+}
+SharedNoiseModel makeNoise(const gtg_problem* p, int idx) {
+  SharedNoiseModel base = makeBaseNoise(p, idx);
+  const int rk = p->noise_robust ? p->noise_robust[idx] : GTG_ROBUST_NONE;
+  if (rk == GTG_ROBUST_NONE) return base;
+  const double c = p->noise_robust_param[idx];
+  noiseModel::mEstimator::Base::shared_ptr est;
+  switch (rk) {
+    case GTG_ROBUST_FAIR: est = noiseModel::mEstimator::Fair::Create(c); break;
+    case GTG_ROBUST_HUBER: est = noiseModel::mEstimator::Huber::Create(c); break;
+    case GTG_ROBUST_CAUCHY: est = noiseModel::mEstimator::Cauchy::Create(c); break;
+    case GTG_ROBUST_TUKEY: est = noiseModel::mEstimator::Tukey::Create(c); break;
+    case GTG_ROBUST_WELSCH: est = noiseModel::mEstimator::Welsch::Create(c); break;
+    default: est = noiseModel::mEstimator::GemanMcClure::Create(c); break;
+  }
+  return noiseModel::Robust::Create(est, base);
 }
 
 }  // namespace

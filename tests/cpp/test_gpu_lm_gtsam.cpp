@@ -109,14 +109,32 @@ int main() {
     graph.addPrior(X(0), truth[0], noiseModel::Diagonal::Variances((Vector(6) << 1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4).finished()));
     for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract((Vector(6) << 0.1 * N(rng), 0.1 * N(rng), 0.1 * N(rng), 0.3 * N(rng), 0.3 * N(rng), 0.3 * N(rng)).finished()));
     compare("Pose3 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    // same graph with outlier loop closures and noiseModel::Robust on the loops (Huber) and the odometry (Cauchy)
+    NonlinearFactorGraph robust;
+    auto rodo = noiseModel::Robust::Create(noiseModel::mEstimator::Cauchy::Create(2.0), odo);
+    auto rloop = noiseModel::Robust::Create(noiseModel::mEstimator::Huber::Create(1.345), loop);
+    for (const auto& f : graph) {
+      auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f);
+      if (!b) { robust.push_back(f); continue; }
+      const bool isLoop = b->noiseModel().get() == loop.get();
+      robust.emplace_shared<BetweenFactor<Pose3>>(b->key1(), b->key2(), b->measured(), isLoop ? SharedNoiseModel(rloop) : SharedNoiseModel(rodo));
+    }
+    robust.emplace_shared<BetweenFactor<Pose3>>(X(2), X(30), Pose3(Rot3::RzRyRx(0.5, -0.4, 1.0), Point3(4, -3, 2)), rloop);   // gross outliers
+    robust.emplace_shared<BetweenFactor<Pose3>>(X(7), X(21), Pose3(Rot3::RzRyRx(-1.0, 0.2, 0.3), Point3(-5, 1, 1)), rloop);
+    compare("Pose3 graph robust (Huber + Cauchy)", robust, initial, LevenbergMarquardtParams(), 1e-6);
   }
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;
     initial.insert(X(0), Pose3()); initial.insert(X(1), Pose3());
-    graph.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Robust::Create(noiseModel::mEstimator::Huber::Create(1.0), noiseModel::Unit::Create(6)));
+    graph.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Robust::Create(noiseModel::mEstimator::DCS::Create(1.0), noiseModel::Unit::Create(6)));
     bool threw = false;
     try { gtsam_amd::GpuLevenbergMarquardtOptimizer bad(graph, initial); } catch (const std::invalid_argument&) { threw = true; }
-    EXPECT(threw, "robust noise model must be rejected");
+    EXPECT(threw, "m-estimators outside the supported six must be rejected");
+    NonlinearFactorGraph g2;
+    g2.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Constrained::All(6));
+    threw = false;
+    try { gtsam_amd::GpuLevenbergMarquardtOptimizer bad(g2, initial); } catch (const std::invalid_argument&) { threw = true; }
+    EXPECT(threw, "constrained noise model must be rejected");
   }
   std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;

@@ -123,5 +123,26 @@ def main():
         print(name, "init", out["error"], "final", r["trace"][-1])
 
 
+def robust():
+    """m-estimator fixtures: graphs of tests/problems.py ROBUST_SYNTH through the real noiseModel::Robust."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems as PB
+    for name in PB.ROBUST_SYNTH:
+        p, v0 = PB.SYNTH[name]()
+        ok = PB.SYNTH_ORDERING[name]
+        g = ref.RefGraph(p)
+        out = {"values0": v0}
+        out.update(probes(g, p, v0, ordering_kind=ok))
+        prm = LMP()
+        r = g.lm(v0, prm, ordering_kind=ok)
+        out["trace"] = r["trace"][:, :3]; out["final_values"] = r["values"]; out["iterations"] = r["iterations"]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "init", out["error"], "final", r["trace"][-1], "outer", r["iterations"])
+
+
 if __name__ == "__main__":
-    main()
+    if "--robust-only" in sys.argv:
+        robust()
+    else:
+        main()
+        robust()

@@ -3,27 +3,28 @@
 // g++ so that `-m "not gpu"` tests can pin them against the oracle without a GPU.  This library is
 // never loaded by the product (gtsam_amd/), which has no CPU path.
 #include "../../gtsam_amd/csrc/factors.h"
+static gt::NoiseRef NR(int nk, const double* nd) { return gt::NoiseRef{nk, nd, 0, 0.0}; }
 extern "C" {
 void hm_sfm_linearize(long n, const double* cam, const double* pt, const double* z, int nk, const double* nd, double* J) {
-  for (long i = 0; i < n; i++) gt::sfm_linearize(cam + 17 * i, pt + 3 * i, z + 2 * i, nk, nd, J + gt::kSfmRec * i);
+  for (long i = 0; i < n; i++) gt::sfm_linearize(cam + 17 * i, pt + 3 * i, z + 2 * i, NR(nk, nd), J + gt::kSfmRec * i);
 }
 void hm_sfm_error(long n, const double* cam, const double* pt, const double* z, int nk, const double* nd, double* e) {
-  for (long i = 0; i < n; i++) e[i] = gt::sfm_error(cam + 17 * i, pt + 3 * i, z + 2 * i, nk, nd);
+  for (long i = 0; i < n; i++) e[i] = gt::sfm_error(cam + 17 * i, pt + 3 * i, z + 2 * i, NR(nk, nd));
 }
 void hm_proj_linearize(long n, const double* pose, const double* K, const double* sensor, const double* pt, const double* z, int nk, const double* nd, double* J) {
-  for (long i = 0; i < n; i++) gt::proj_linearize(pose + 12 * i, K, sensor, pt + 3 * i, z + 2 * i, nk, nd, J + gt::kProjRec * i);
+  for (long i = 0; i < n; i++) gt::proj_linearize(pose + 12 * i, K, sensor, pt + 3 * i, z + 2 * i, NR(nk, nd), J + gt::kProjRec * i);
 }
 void hm_proj_error(long n, const double* pose, const double* K, const double* sensor, const double* pt, const double* z, int nk, const double* nd, double* e) {
-  for (long i = 0; i < n; i++) e[i] = gt::proj_error(pose + 12 * i, K, sensor, pt + 3 * i, z + 2 * i, nk, nd);
+  for (long i = 0; i < n; i++) e[i] = gt::proj_error(pose + 12 * i, K, sensor, pt + 3 * i, z + 2 * i, NR(nk, nd));
 }
 void hm_between_linearize(long n, const double* T1, const double* T2, const double* Z, int nk, const double* nd, double* J) {
-  for (long i = 0; i < n; i++) gt::between_linearize(T1 + 12 * i, T2 + 12 * i, Z + 12 * i, nk, nd, J + gt::kBetweenRec * i);
+  for (long i = 0; i < n; i++) gt::between_linearize(T1 + 12 * i, T2 + 12 * i, Z + 12 * i, NR(nk, nd), J + gt::kBetweenRec * i);
 }
 void hm_between_error(long n, const double* T1, const double* T2, const double* Z, int nk, const double* nd, double* e) {
-  for (long i = 0; i < n; i++) e[i] = gt::between_error(T1 + 12 * i, T2 + 12 * i, Z + 12 * i, nk, nd);
+  for (long i = 0; i < n; i++) e[i] = gt::between_error(T1 + 12 * i, T2 + 12 * i, Z + 12 * i, NR(nk, nd));
 }
-void hm_prior_linearize(int vtype, const double* x, const double* z, int nk, const double* nd, double* J) { gt::prior_linearize(vtype, x, z, nk, nd, J); }
-double hm_prior_error(int vtype, const double* x, const double* z, int nk, const double* nd) { return gt::prior_error(vtype, x, z, nk, nd); }
+void hm_prior_linearize(int vtype, const double* x, const double* z, int nk, const double* nd, double* J) { gt::prior_linearize(vtype, x, z, NR(nk, nd), J); }
+double hm_prior_error(int vtype, const double* x, const double* z, int nk, const double* nd) { return gt::prior_error(vtype, x, z, NR(nk, nd)); }
 void hm_retract(int vtype, long n, const double* x, const double* d, double* y) {
   const int st = vtype == 0 ? 12 : vtype == 1 ? 17 : 3, dm = vtype == 0 ? 6 : vtype == 1 ? 9 : 3;
   for (long i = 0; i < n; i++) gt::value_retract(vtype, x + st * i, d + dm * i, y + st * i);
@@ -32,6 +33,8 @@ void hm_local(int vtype, long n, const double* x, const double* z, double* d) {
   const int st = vtype == 0 ? 12 : vtype == 1 ? 17 : 3, dm = vtype == 0 ? 6 : vtype == 1 ? 9 : 3;
   for (long i = 0; i < n; i++) gt::value_local(vtype, x + st * i, z + st * i, d + dm * i);
 }
+double hm_robust_weight(int rk, double k, double d) { return gt::robust_weight(rk, k, d); }
+double hm_robust_loss(int rk, double k, double d) { return gt::robust_loss(rk, k, d); }
 void hm_so3_logmap(long n, const double* R, double* w) { for (long i = 0; i < n; i++) gt::so3_logmap(R + 9 * i, w + 3 * i); }
 void hm_so3_expmap(long n, const double* w, double* R) { for (long i = 0; i < n; i++) gt::so3_expmap(w + 3 * i, R + 9 * i); }
 }

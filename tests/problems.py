@@ -2,7 +2,8 @@
 import numpy as np
 
 from gtsam_amd import datasets as D
-from gtsam_amd.problem import (NOISE_DIAGONAL, NOISE_ISOTROPIC, NOISE_UNIT, bal_problem, pose_graph_problem)
+from gtsam_amd.problem import (NOISE_DIAGONAL, NOISE_ISOTROPIC, NOISE_UNIT, ROBUST_CAUCHY, ROBUST_FAIR, ROBUST_HUBER,
+                               ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE, bal_problem, pose_graph_problem)
 
 
 def dubrovnik_timesfm(g):
@@ -27,11 +28,38 @@ def sphere2500(g):
     return p, g["values0"]
 
 
+def robustify(pv, rkind, k):
+    """Wrap every noise model of the graph in noiseModel::Robust(mEstimator(k), base) (linear/NoiseModel.h:670-760)."""
+    p, v0 = pv
+    p.noise_robust = np.full(p.noise_kind.size, rkind, np.int32)
+    p.noise_robust_param = np.full(p.noise_kind.size, k, np.float64)
+    return p, v0
+
+
+def _dubrovnik_robust(rkind, k):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dubrovnik_3_7.npz"))
+    return robustify(dubrovnik_timesfm(g), rkind, k)
+
+
 SYNTH = {
     "posegraph_small": lambda: D.random_pose_graph(14, 6, seed=3),
     "posegraph_bigrot": lambda: D.random_pose_graph(10, 4, seed=5, rot_scale=1.8, init_noise=0.4),
     "projection_small": lambda: D.random_projection_graph(seed=2),
     "bal_small_unit": lambda: bal_problem(*D.synthetic_bal(12, 300, seed=1, n_loops=1), (NOISE_UNIT, ())),
     "bal_small_iso": lambda: bal_problem(*D.synthetic_bal(12, 300, seed=1, n_loops=1), (NOISE_ISOTROPIC, [0.7])),
+    # m-estimators (section 8(f) #2): every loss function of linear/LossFunctions.cpp on some graph
+    "posegraph_huber": lambda: robustify(D.random_pose_graph(14, 6, seed=3), ROBUST_HUBER, 1.345),
+    "posegraph_fair": lambda: robustify(D.random_pose_graph(14, 6, seed=3), ROBUST_FAIR, 1.3998),
+    "posegraph_welsch": lambda: robustify(D.random_pose_graph(14, 6, seed=3), ROBUST_WELSCH, 2.9846),
+    "projection_cauchy": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_CAUCHY, 3.0),
+    "projection_tukey": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_TUKEY, 4.6851),
+    "projection_gm": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_GEMANMCCLURE, 5.0),
+    "dubrovnik_huber": lambda: _dubrovnik_robust(ROBUST_HUBER, 1.345),
+    "dubrovnik_cauchy": lambda: _dubrovnik_robust(ROBUST_CAUCHY, 5.0),
 }
-SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "bal_small_unit": 1, "bal_small_iso": 1}
+ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projection_cauchy", "projection_tukey",
+                "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy")
+SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "bal_small_unit": 1, "bal_small_iso": 1,
+                  "posegraph_huber": 0, "posegraph_fair": 0, "posegraph_welsch": 0, "projection_cauchy": 1,
+                  "projection_tukey": 1, "projection_gm": 1, "dubrovnik_huber": 1, "dubrovnik_cauchy": 1}

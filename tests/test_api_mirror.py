@@ -45,6 +45,27 @@ def test_symbol_and_noise_factories():
         nm.Diagonal.Sigmas([0.1, 1e-9])                                  # constrained: out of scope, rejected loudly
 
 
+def test_robust_noise_model_mirror():
+    """noiseModel.Robust.Create(mEstimator.Huber.Create(k), base) -> (ROBUST_HUBER, k) on the base model's table row;
+    literals of linear/tests/testNoiseModel.cpp:466-485 (robust_Huber / robust_Tukey weights)."""
+    nm = api.noiseModel
+    hub = nm.mEstimator.Huber.Create(5.0)
+    assert abs(hub.weight(1.0) - 1.0) < 1e-8 and abs(hub.weight(10.0) - 0.5) < 1e-8
+    tuk = nm.mEstimator.Tukey.Create(5.0)
+    assert abs(tuk.weight(1.0) - 0.9216) < 1e-8 and abs(tuk.weight(10.0) - 0.0) < 1e-8
+    with pytest.raises(ValueError):
+        nm.mEstimator.Cauchy.Create(0.0)
+    graph = api.NonlinearFactorGraph(); vals = api.Values()
+    vals.insert(X(0), api.Pose3()); vals.insert(X(1), api.Pose3())
+    base = nm.Diagonal.Sigmas([0.1, 0.1, 0.1, 0.3, 0.3, 0.2])
+    graph.add(api.BetweenFactorPose3(X(0), X(1), api.Pose3(), nm.Robust.Create(hub, base)))
+    graph.add(api.BetweenFactorPose3(X(0), X(1), api.Pose3(), base))
+    graph.add(api.BetweenFactorPose3(X(1), X(0), api.Pose3(), nm.Robust.Create(nm.mEstimator.Huber.Create(5.0), base)))
+    p, _, _ = api.extract(graph, vals)
+    assert list(p.noise_robust) == [2, 0] and list(p.noise_robust_param) == [5.0, 0.0]
+    assert list(p.between_noise) == [0, 1, 0]
+
+
 def test_extractor_reproduces_the_soa_problem():
     g, graph, initial = _dubrovnik_graph(priors=True)
     p, v0, keys = api.extract(graph, initial)

@@ -95,3 +95,46 @@ def test_logmap_branches(hm):
     assert np.abs(w - O.so3_logmap(R)).max() <= 1e-9
     R2 = np.zeros_like(R); wa = np.ascontiguousarray(np.array(ws)); hm.hm_so3_expmap(C.c_long(R.shape[0]), P(wa), P(R2))
     assert np.abs(R2 - R).max() <= 1e-15
+
+
+def test_m_estimators_host_compile_vs_oracle(hm):
+    """robust_weight / robust_loss of csrc/factors.h (the device code, compiled for the host) against the oracle's
+    restatement of linear/LossFunctions.cpp, across the threshold of every estimator."""
+    hm.hm_robust_weight.restype = C.c_double; hm.hm_robust_loss.restype = C.c_double
+    d = np.concatenate([np.linspace(0, 12, 97), [1e-12, 1.345, 4.6851, 1e3]])
+    for rk in range(1, 7):
+        for k in (0.5, 1.345, 4.6851):
+            w = np.array([hm.hm_robust_weight(C.c_int(rk), C.c_double(k), C.c_double(x)) for x in d])
+            l = np.array([hm.hm_robust_loss(C.c_int(rk), C.c_double(k), C.c_double(x)) for x in d])
+            assert np.allclose(w, O.robust_weight(rk, k, d), rtol=1e-14, atol=0)
+            assert np.allclose(l, O.robust_loss(rk, k, d), rtol=1e-13, atol=1e-300)
+            # loss'(d) = d * weight(d)   (the defining relation, LossFunctions.h:33-60)
+            h = 1e-6; dd = d[(d > 0.01) & (np.abs(d - k) > 0.01)]
+            num = (O.robust_loss(rk, k, dd + h) - O.robust_loss(rk, k, dd - h)) / (2 * h)
+            assert np.allclose(num, dd * O.robust_weight(rk, k, dd), rtol=1e-6, atol=1e-8)
+
+
+# literals of linear/tests/testNoiseModel.cpp:460-569 (robustFunctionFair/Huber/Cauchy/GemanMcClure/Welsch/Tukey):
+# (kind, k, [(error, weight, loss)...])
+M_ESTIMATOR_LITERALS = [
+    (1, 5.0, [(1.0, 0.8333333333333333, 0.441961080151135), (10.0, 0.3333333333333333, 22.534692783297260),
+              (-10.0, 0.3333333333333333, 22.534692783297260), (-1.0, 0.8333333333333333, 0.441961080151135)]),
+    (2, 5.0, [(1.0, 1.0, 0.5), (10.0, 0.5, 37.5), (-10.0, 0.5, 37.5), (-1.0, 1.0, 0.5)]),
+    (3, 5.0, [(1.0, 0.961538461538461, 0.490258914416017), (10.0, 0.2, 20.117973905426254),
+              (-10.0, 0.2, 20.117973905426254), (-1.0, 0.961538461538461, 0.490258914416017)]),
+    (6, 1.0, [(1.0, 0.25, 0.25), (10.0, 9.80296e-5, 0.495049504950495), (-10.0, 9.80296e-5, 0.495049504950495),
+              (-1.0, 0.25, 0.25)]),
+    (5, 5.0, [(1.0, 0.960789439152323, 0.490132010595960), (10.0, 0.018315638888734, 12.271054513890823),
+              (-10.0, 0.018315638888734, 12.271054513890823), (-1.0, 0.960789439152323, 0.490132010595960)]),
+    (4, 5.0, [(1.0, 0.9216, 0.480266666666667), (10.0, 0.0, 4.166666666666667), (-10.0, 0.0, 4.166666666666667),
+              (-1.0, 0.9216, 0.480266666666667)]),
+]
+
+
+def test_m_estimators_reference_literals(hm):
+    hm.hm_robust_weight.restype = C.c_double; hm.hm_robust_loss.restype = C.c_double
+    for rk, k, rows in M_ESTIMATOR_LITERALS:
+        for e, w, l in rows:
+            assert abs(hm.hm_robust_weight(C.c_int(rk), C.c_double(k), C.c_double(e)) - w) < 1e-8
+            assert abs(hm.hm_robust_loss(C.c_int(rk), C.c_double(k), C.c_double(e)) - l) < 1e-8
+            assert abs(float(O.robust_weight(rk, k, e)) - w) < 1e-8 and abs(float(O.robust_loss(rk, k, e)) - l) < 1e-8

@@ -45,6 +45,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GtsamAmdError(f"{LIB_PATH} not found: build the HIP extension first "
                             "(python -c 'import __graft_entry__ as g; g.build()' or make -C gtsam_amd/csrc)")
+    # torch first: its wheel bundles its own libamdhip64.so.7 / libhsa-runtime64; whichever HIP runtime is mapped
+    # first serves the whole process (same soname), and torch cannot see the GPU through /opt/rocm's copy.  The
+    # library itself has no torch dependency -- a C/C++ host (gtsam_amd/host) links /opt/rocm's runtime directly.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.gtg_last_error.restype = C.c_char_p
     lib.gtg_version.restype = C.c_char_p

@@ -51,7 +51,7 @@ static void compare(const char* name, const NonlinearFactorGraph& graph, const V
   EXPECT(cpu.iterations() == gpu.iterations(), "iterations %zu vs %zu", cpu.iterations(), gpu.iterations());
   EXPECT(cpu.getInnerIterations() == gpu.getInnerIterations(), "inner iterations");
   EXPECT(std::abs(cpu.error() - gpu.error()) <= tol * std::abs(cpu.error()) + 1e-12, "final error %.15g vs %.15g", cpu.error(), gpu.error());
-  EXPECT(std::abs(cpu.lambda() - gpu.lambda()) <= 1e-4 * cpu.lambda(), "lambda %.12g vs %.12g", cpu.lambda(), gpu.lambda());  // Ceres policy: lambda is a smooth function of the model fidelity
+  EXPECT(std::abs(cpu.lambda() - gpu.lambda()) <= 1e-3 * cpu.lambda(), "lambda %.12g vs %.12g", cpu.lambda(), gpu.lambda());  // Ceres policy: lambda is the PRODUCT over all iterations of a cubic in the model fidelity, so 1e-8 differences in the errors of a noisy, slowly converging problem show up at 1e-4 here
   EXPECT(std::abs(graph.error(rg) - gpu.error()) <= 1e-9 * std::abs(gpu.error()) + 1e-12, "values()/error() out of sync");
   EXPECT(valuesDiff(rc, rg) <= 1e-5, "optimised values differ by %.3g", valuesDiff(rc, rg));
   // iterate() one step at a time keeps the host state current

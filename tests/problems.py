@@ -63,3 +63,13 @@ ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projec
 SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "bal_small_unit": 1, "bal_small_iso": 1,
                   "posegraph_huber": 0, "posegraph_fair": 0, "posegraph_welsch": 0, "projection_cauchy": 1,
                   "projection_tukey": 1, "projection_gm": 1, "dubrovnik_huber": 1, "dubrovnik_cauchy": 1}
+
+
+def robust_prior_literal():
+    """tests/testRobust.cpp:31-49 (RobustNoise.loss) carried to the path's types: a PriorFactor<Point3> at the origin
+    with Robust(GemanMcClure(1.0), Unit) evaluated at (10, 0, 0): whitened distance 10 -> error 0.49505 (+-1e-5)."""
+    from gtsam_amd.problem import Problem, VAR_POINT3
+    p = Problem(var_type=np.array([VAR_POINT3], np.int32))
+    n = p.add_noise(NOISE_UNIT, 3, (), robust=(ROBUST_GEMANMCCLURE, 1.0))
+    p.add_prior(0, np.zeros(3), n)
+    return p, np.array([10.0, 0.0, 0.0])

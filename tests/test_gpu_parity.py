@@ -102,7 +102,7 @@ LM_CASES = [
 @pytest.mark.parametrize("name,preset,prefix", LM_CASES, ids=[c[0] for c in LM_CASES])
 def test_lm_trajectory_vs_reference_golden(gpu, name, preset, prefix):
     from gtsam_amd.optimizer import DeviceLevenbergMarquardt
-    if name.startswith("dubrovnik"):
+    if name.startswith("dubrovnik") and name not in PB.SYNTH:
         g = load_golden("dubrovnik_3_7")
         p, v0 = PB.dubrovnik_sfmexample(g) if name == "dubrovnik_sfmex" else PB.dubrovnik_timesfm(g)
     else:
@@ -123,6 +123,14 @@ def test_lm_trajectory_vs_reference_golden(gpu, name, preset, prefix):
     assert rel(tr[:, 1], ref_trace[:, 1]) <= 1e-6
     assert np.allclose(tr[:, 2], ref_trace[:, 2], rtol=1e-6, atol=0)
     assert rel(opt.values_packed(), g[prefix + ("values" if prefix else "final_values")]) <= 1e-5
+
+
+def test_robust_loss_literal(gpu):
+    p, v = PB.robust_prior_literal()
+    dev = gpu.DeviceGraph(p)
+    dev.set_values(v)
+    assert abs(dev.error() - 0.49505) < 1e-5                       # tests/testRobust.cpp:45-47
+    dev.close()
 
 
 def test_sphere2500_solve_and_full_trajectory(gpu):

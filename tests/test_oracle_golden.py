@@ -84,6 +84,11 @@ def test_cholesky_partial_literal():
     assert not O.cholesky_partial(bad, 3)[0]
 
 
+def test_robust_loss_literal():
+    p, v = PB.robust_prior_literal()
+    assert abs(O.error(p, v) - 0.49505) < 1e-5                     # tests/testRobust.cpp:45-47
+
+
 def test_between_factor_zero_error_and_jacobian_structure():
     """testBetweenFactor.cpp: zero error when measured == between; H2 = I, H1 = -Ad(h^-1) (Lie.h:63-69)."""
     rng = np.random.default_rng(0)

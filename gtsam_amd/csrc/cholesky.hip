@@ -141,7 +141,16 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
 }
 
 // X = L_jj^-1 (used by k_trsm128 / k_bwd_step): lane c owns column c, L rows are broadcast LDS reads
-__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int jb, int lane, double* Xout) {
+// MFMA-operand image of a 32x32 block M as k_trsm128 consumes it (B operand of X * M^T, k split as 8 lk + s):
+// half tj, lane = 16 lk + lr keeps M[16 tj + lr][8 lk + 0..7] in 8 consecutive doubles, so a wavefront fetches its
+// operands of a block with four fully coalesced 16-byte loads per lane.
+__device__ __forceinline__ int opnd_off(int blk, int row, int col) {
+  return ((blk * 2 + (row >> 4)) * 64 + 16 * (col >> 3) + (row & 15)) * 8 + (col & 7);
+}
+constexpr int kOpndBase = 4 * SB * SB;   // doubles: the operand images follow the four plain inverses in the Xinv slot
+
+__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int jb, int lane, double* Xout,
+                                              double* Xop) {
   const int i = lane & 31;
   const int o = SB * jb;
   const double* D = A + boff(jb, jb);
@@ -161,6 +170,8 @@ __device__ __forceinline__ void stage_inverse(const double* A, const double* din
   if (lane < 32) {
 #pragma unroll
     for (int r = 0; r < SB; r++) Xout[r * SB + i] = x[r];
+#pragma unroll
+    for (int r = 0; r < SB; r++) Xop[opnd_off(6 + jb, r, i)] = x[r];
   }
 }
 
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
   }
   // the four 32x32 diagonal inverses (used by k_trsm128 / k_bwd_diag, not by this kernel): off the critical
   // path, one per wavefront
-  stage_inverse(A, dinv, wave, lane, Xinv + (int64_t)wave * SB * SB);
+  stage_inverse(A, dinv, wave, lane, Xinv + (int64_t)wave * SB * SB, Xinv + kOpndBase);
   // write back the lower sub-blocks (diagonal ones with their upper part zeroed); the strictly-upper sub-blocks of
   // the tile are never read by anyone and are left as they are
 #pragma unroll 4
@@ -269,109 +280,80 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
     v.x = (ib != rem || c <= r) ? sp[0] : 0.0;
     v.y = (ib != rem || c + 1 <= r) ? sp[1] : 0.0;
     *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * rem + c) = v;
+    if (ib != rem)   // L(p,q), q < p: operand image for k_trsm128, block index p(p-1)/2 + q
+      *reinterpret_cast<double2*>(Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + rem, r, c)) = v;
   }
   STAMP(14);
 }
 
 // ---- TRSM: X = A(I,k) * L(k,k)^-T for every row tile I below the diagonal -----------------------------------
-// Rows are independent: a workgroup is 2 wavefronts = 64 rows (66 KB of LDS, so it can share a CU with a k_syrk
-// workgroup of the overlapped trailing update); each wavefront owns 32 rows and never synchronises with the other.
+// 4-phase block substitution over the 32-column sub-blocks p: R_p = A_p - sum_{q<p} X_q L(p,q)^T, X_p = R_p Xinv_pp^T.
+// The kernel sits on the serial panel chain and is bound by MFMA latency, not throughput (a wavefront keeps a single
+// v_mfma_f64 in flight, ~140 cycles each), so the work is spread as thin as the 16x16 MFMA tile allows: a workgroup
+// is 64 rows (66 KB of LDS: fits next to a k_syrk workgroup of the overlapped update) and 8 wavefronts, wavefront
+// (rg, tj) owning the 16x16 tiles of rows 16 rg.. and column half tj of every sub-block: 80 MFMAs per wavefront
+// instead of 320.  The L(p,q) / Xinv operands of a wavefront (80 doubles per lane) are fetched into registers up
+// front, in flight together with the tile load.
 constexpr int TR = 64;   // rows per TRSM workgroup
-__global__ __launch_bounds__(128) void k_trsm128(double* __restrict__ S, int NP, int k,
-                                                 const int32_t* __restrict__ rows, const double* __restrict__ Xinv) {
+__global__ __launch_bounds__(512, 2) void k_trsm128(double* __restrict__ S, int NP, int k,
+                                                    const int32_t* __restrict__ rows, const double* __restrict__ Xinv) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
   const int I = rows[blockIdx.x >> 1], half_rows = (blockIdx.x & 1) * TR;
   __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
+  const int r0 = 16 * (wave >> 1), tj = wave & 1;
   double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
-  const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  double bl[10][8];   // blocks 0..5: L(p,q) at p(p-1)/2 + q; 6..9: Xinv_pp  (operand images written by k_potrf128)
 #pragma unroll
-  for (int e0 = 0; e0 < TR * (T / 2); e0 += 128 * 16) {
-    double2 v[16];
+  for (int b = 0; b < 10; b++) {
+    const double2* op = reinterpret_cast<const double2*>(Xinv + kOpndBase + ((b * 2 + tj) * 64 + lane) * 8);
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int e = e0 + u * 128 + tid;
+    for (int h = 0; h < 4; h++) { const double2 t = op[h]; bl[b][2 * h] = t.x; bl[b][2 * h + 1] = t.y; }
+  }
+  {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = u * 512 + tid;
       v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int e = e0 + u * 128 + tid;
+    for (int u = 0; u < 8; u++) {
+      const int e = u * 512 + tid;
       double* d = Xs + (e / (T / 2)) * P + 2 * (e % (T / 2));
       d[0] = v[u].x; d[1] = v[u].y;
     }
   }
   __syncthreads();
-  const int r0 = 32 * wave;
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    v4f64 acc[2][2];
-    // A_p (this wave's 32 rows, columns of sub-block p)
+    double* mine = Xs + (r0 + lk) * P + SB * p + 16 * tj + lr;   // accumulator layout: reg r <-> row r0 + lk + 4 r
+    if (p > 0) {   // R_p = A_p - sum_{q<p} X_q L(p,q)^T   (p = 0: R_0 = A_0 is already in LDS)
+      v4f64 acc;
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+      for (int r = 0; r < 4; r++) acc[r] = mine[4 * r * P];
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++)
+      for (int q = 0; q < p; q++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[ti][tj][r] = Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr];
-    // A_p -= sum_{q<p} X_q L(p,q)^T
+        for (int s8 = 0; s8 < 8; s8++)
+          acc = MFMA(-Xs[(r0 + lr) * P + SB * q + 8 * lk + s8], bl[p * (p - 1) / 2 + q][s8], acc);
 #pragma unroll
-    for (int q = 0; q < p; q++) {
-#pragma unroll
-      for (int kk = 0; kk < SB; kk += 4) {
-        double av[2], bv[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          av[t] = -Xs[(r0 + 16 * t + lr) * P + SB * q + kk + lk];
-          bv[t] = L[(int64_t)(SB * p + 16 * t + lr) * NP + SB * q + kk + lk];
-        }
-#pragma unroll
-        for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-          for (int tj = 0; tj < 2; tj++) acc[ti][tj] = MFMA(av[ti], bv[tj], acc[ti][tj]);
-      }
+      for (int r = 0; r < 4; r++) mine[4 * r * P] = acc[r];
+      __syncthreads();
     }
-    // R = updated A_p back to LDS (own rows only), then X_p = R * Xinv_pp^T
+    v4f64 xr = (v4f64){0.0, 0.0, 0.0, 0.0};   // X_p = R_p Xinv_pp^T
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+    for (int s8 = 0; s8 < 8; s8++) xr = MFMA(Xs[(r0 + lr) * P + SB * p + 8 * lk + s8], bl[6 + p][s8], xr);
+    __syncthreads();   // both column halves have read R_p before it is overwritten
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr] = acc[ti][tj][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    v4f64 xr[2][2];
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-      for (int tj = 0; tj < 2; tj++) xr[ti][tj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const double* Xp = Xinv + p * SB * SB;
-#pragma unroll
-    for (int kk = 0; kk < SB; kk += 4) {
-      double av[2], bv[2];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        av[t] = Xs[(r0 + 16 * t + lr) * P + SB * p + kk + lk];
-        bv[t] = Xp[(16 * t + lr) * SB + kk + lk];
-      }
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) xr[ti][tj] = MFMA(av[ti], bv[tj], xr[ti][tj]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-      for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Xs[(r0 + 16 * ti + lk + 4 * r) * P + SB * p + 16 * tj + lr] = xr[ti][tj][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < 4; r++) mine[4 * r * P] = xr[r];
+    __syncthreads();
   }
-  __syncthreads();
-#pragma unroll 8
-  for (int e = tid; e < TR * (T / 2); e += 128) {
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int e = u * 512 + tid;
     const int row = e / (T / 2), pc = e % (T / 2);
     double2 v;
     v.x = Xs[row * P + 2 * pc]; v.y = Xs[row * P + 2 * pc + 1];
@@ -406,87 +388,97 @@ constexpr int STI = 8, STJ = 4;
 // 138 cycles, tools/mfma_f64_peak.hip: 36 TFLOP/s at 1 wave/SIMD, 47 at 2, 70 at 4), so the matrix pipe needs
 // >= 4 waves per SIMD: 8 wavefronts per workgroup (4x2, each 32x64 = 2x4 MFMA tiles, 64 accumulator registers),
 // two workgroups per CU.
-template <int KT, int ABL = 0>   // ABL: ablation bits for tools/ (1 no DMA, 2 no C load, 4 no C store, 8 no MFMA)
+// Q = 2 is the latency variant for the small launches on the serial panel chain (thin update, look-ahead columns):
+// a workgroup owns a 64x64 quadrant (wavefront = 16x32), four times as many workgroups each a quarter as long.
+template <int KT, int ABL = 0, int Q = 1>   // ABL: ablation bits for tools/ (1 no DMA, 2 no C load, 4 no C store, 8 no MFMA)
 __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0,
                                                  const int32_t* __restrict__ pairs, int npairs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
-  const int nper = (npairs + 7) >> 3;
-  const int idx = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= nper || idx >= npairs) return;
+  constexpr int RW = T / Q;              // rows (and columns) of the output block of a workgroup
+  constexpr int TI = 2 / Q, TJ = 4 / Q;  // MFMA tiles per wavefront
+  constexpr int CH = RW * KC * 8;        // bytes of one panel chunk in LDS
+  constexpr int NQ = RW / 8 / 8;         // DMA instructions per wavefront and panel chunk
+  const int nitems = npairs * Q * Q;
+  const int nper = (nitems + 7) >> 3;
+  const int item = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= nper || item >= nitems) return;
+  const int idx = item / (Q * Q), qi = (item % (Q * Q)) / Q, qj = item % Q;
   const int I = pairs[2 * idx], J = pairs[2 * idx + 1];
-  const double* Ap = S + ((int64_t)I * T) * NP + (int64_t)ktile0 * T;
-  const double* Bp = S + ((int64_t)J * T) * NP + (int64_t)ktile0 * T;
-  double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  if (Q > 1 && I == J && qj > qi) return;   // strictly-upper quadrant of a diagonal tile: never read
+  const double* Ap = S + ((int64_t)I * T + qi * RW) * NP + (int64_t)ktile0 * T;
+  const double* Bp = S + ((int64_t)J * T + qj * RW) * NP + (int64_t)ktile0 * T;
+  double* C = S + ((int64_t)I * T + qi * RW) * NP + (int64_t)J * T + qj * RW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves: rows 32 wr .., cols 64 wc ..
+  const int wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves: rows 16 TI wr .., cols 16 TJ wc ..
   const int lr = lane & 15, lk = lane >> 4;
   constexpr int NCH = KT * T / KC;
 
-  // DMA map: one instruction = 1 KiB = 8 rows x 8 slots; instruction q of wave w fills rows 8(2w+q) .. +7;
+  // DMA map: one instruction = 1 KiB = 8 rows x 8 slots; instruction q of wave w fills rows 8(NQ w+q) .. +7;
   // lane l -> row + l/8, stored slot l%8, which holds logical slot (l%8) ^ ((row >> 1) & 7)
   const int drow = lane >> 3, dslot = lane & 7;
   auto stage = [&](int ch, int buf) {
-    char* base = smem_raw + buf * 2 * CHB;
+    char* base = smem_raw + buf * 2 * CH;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int row = 8 * (2 * wave + q) + drow;
+    for (int q = 0; q < NQ; q++) {
+      const int row = 8 * (NQ * wave + q) + drow;
       const int logical = dslot ^ ((row >> 1) & 7);
       const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
       const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CHB + (2 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (NQ * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (NQ * wave + q) * 1024), 16, 0, 0);
     }
   };
 
   if (!(ABL & 1)) stage(0, 0);
-  v4f64 acc[2][4];
+  v4f64 acc[TI][TJ];
 #pragma unroll
-  for (int ti = 0; ti < 2; ti++)
+  for (int ti = 0; ti < TI; ti++)
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tj = 0; tj < TJ; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        acc[ti][tj][r] = (ABL & 2) ? 0.0 : C[(int64_t)(wr * 32 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr];
+        acc[ti][tj][r] = (ABL & 2) ? 0.0 : C[(int64_t)(wr * 16 * TI + ti * 16 + lk + 4 * r) * NP + wc * 16 * TJ + tj * 16 + lr];
   __syncthreads();
-  // operand byte offsets inside a chunk: row R = 32 wr (or 64 wc) + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
+  // operand byte offsets inside a chunk: row R = 16 TI wr (or 16 TJ wc) + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
   // half-wave = 16 rows x 2 halves of one slot: bank = 32 (lr & 1) + 4 (slot ^ (lr >> 1)) + 2 (lk & 1): all distinct
-  const int a_row_off = (wr * 32 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
+  const int a_row_off = (wr * 16 * TI + lr) * ROWB, b_row_off = (wc * 16 * TJ + lr) * ROWB;
   const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     const int cur = ch & 1;
     if (ch + 1 < NCH && !(ABL & 1)) stage(ch + 1, cur ^ 1);
-    const char* Ac = smem_raw + cur * 2 * CHB;
-    const char* Bc = Ac + CHB;
+    const char* Ac = smem_raw + cur * 2 * CH;
+    const char* Bc = Ac + CH;
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 4) {
       const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-      double a[2], b[4];
+      double a[TI], b[TJ];
 #pragma unroll
-      for (int t = 0; t < 2; t++) a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
+      for (int t = 0; t < TI; t++) a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
 #pragma unroll
-      for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
+      for (int t = 0; t < TJ; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
 #pragma unroll
-      for (int ti = 0; ti < 2; ti++)
+      for (int ti = 0; ti < TI; ti++)
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) { if (ABL & 8) acc[ti][tj][0] += a[ti] * b[tj]; else acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]); }
+        for (int tj = 0; tj < TJ; tj++) { if (ABL & 8) acc[ti][tj][0] += a[ti] * b[tj]; else acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]); }
     }
     __syncthreads();   // drains the DMA of chunk ch+1 (vmcnt) and fences the buffer just read
   }
 #pragma unroll
-  for (int ti = 0; ti < 2; ti++)
+  for (int ti = 0; ti < TI; ti++)
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tj = 0; tj < TJ; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (!(ABL & 4) || acc[ti][tj][r] == 123.456) C[(int64_t)(wr * 32 + ti * 16 + lk + 4 * r) * NP + wc * 64 + tj * 16 + lr] = acc[ti][tj][r];
+        if (!(ABL & 4) || acc[ti][tj][r] == 123.456) C[(int64_t)(wr * 16 * TI + ti * 16 + lk + 4 * r) * NP + wc * 16 * TJ + tj * 16 + lr] = acc[ti][tj][r];
 }
 
 long long* g_potrf_dbg = nullptr;   // debug: cycle stamps of the last k_potrf128 (see gtg_debug_potrf_stamps)
 long long* g_potrf_dbg_set(long long* p) { g_potrf_dbg = p; return p; }
 
 static inline int syrk_grid(int64_t npairs) { return (int)(((npairs + 7) / 8) * 8); }
+constexpr int64_t kLatencyTiles = 320;   // launches up to this many tiles use the quadrant (latency) variant of k_syrk
 
 // ---- host: tile schedule ------------------------------------------------------------------------------------
 // Symbolic factorisation at the granularity of 256-wide column pairs (the unit the trailing update contracts
@@ -613,6 +605,9 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 // stream has higher priority, so the serial panel chain is hidden behind the update instead of alternating with it.
 struct CholStreams {
   hipStream_t panel = nullptr;
+  hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
+  hipEvent_t done = nullptr;
+  int reserve = -1;
   std::vector<hipEvent_t> P, N;
   hipEvent_t start = nullptr;
 };
@@ -630,6 +625,8 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     check_hip(hipFuncSetAttribute((const void*)k_trsm128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_trsm), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_syrk<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk / 2), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_syrk<2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk / 2), "smem attr");
     attr_set = true;
   }
   const int npairs = (nt + 1) / 2;
@@ -645,30 +642,54 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     check_hip(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "event");
     g_cs.P.push_back(e1); g_cs.N.push_back(e2);
   }
-  hipStream_t su = c.stream, sp = g_cs.panel;
+  if (g_cs.reserve < 0) {
+    // Optionally reserve a few CUs for the serial panel chain: the trailing updates then run on a stream whose CU
+    // mask leaves `reserve` CUs out, so k_potrf128 / k_trsm128 never wait for, nor share a CU with, k_syrk workgroups
+    // (measured on L1723: 15.3 ms -> 14.7 ms with 32 CUs reserved; off by default).
+    const char* e = getenv("GTG_CU_RESERVE");
+    g_cs.reserve = e ? atoi(e) : 0;
+    if (g_cs.reserve > 0) {
+      hipDeviceProp_t prop;
+      check_hip(hipGetDeviceProperties(&prop, c.device), "props");
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu - g_cs.reserve; i++) mask[i >> 5] |= 1u << (i & 31);
+      check_hip(hipExtStreamCreateWithCUMask(&g_cs.update, (uint32_t)mask.size(), mask.data()), "masked stream");
+      check_hip(hipEventCreateWithFlags(&g_cs.done, hipEventDisableTiming), "event");
+    }
+  }
+  hipStream_t su = g_cs.update ? g_cs.update : c.stream, sp = g_cs.panel;
   const int32_t* rows = plan.rows.p;
   const int32_t* pairs = plan.pairs.p;
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
     hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
-    hipLaunchKernelGGL(k_trsm128, dim3(2 * (unsigned)plan.trsm_cnt[k]), dim3(128), smem_trsm, sp, S, NP, k,
+    hipLaunchKernelGGL(k_trsm128, dim3(2 * (unsigned)plan.trsm_cnt[k]), dim3(512), smem_trsm, sp, S, NP, k,
                        rows + plan.trsm_off[k], Xk);
   };
   // everything queued on the update stream so far (building S) must precede the first panel
-  check_hip(hipEventRecord(g_cs.start, su), "record");
+  check_hip(hipEventRecord(g_cs.start, c.stream), "record");
   check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
+  if (g_cs.update) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
   for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
     if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.N[pi - 1], 0), "wait");
     panel(k);
     if (k + 1 < nt) {
-      hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, NP, k,
-                         pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
+      if (plan.s1_cnt[pi] <= kLatencyTiles)
+        hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, sp, S, NP, k,
+                           pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
+      else
+        hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, NP, k,
+                           pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
       panel(k + 1);
     }
     check_hip(hipEventRecord(g_cs.P[pi], sp), "record");
     check_hip(hipStreamWaitEvent(su, g_cs.P[pi], 0), "wait");
     if (k + 1 < nt) {
-      if (plan.nar_cnt[pi] > 0)
+      if (plan.nar_cnt[pi] > 0 && plan.nar_cnt[pi] <= kLatencyTiles)
+        hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * plan.nar_cnt[pi])), dim3(512), smem_syrk / 2, su, S, NP, k,
+                           pairs + 2 * plan.nar_off[pi], (int)plan.nar_cnt[pi]);
+      else if (plan.nar_cnt[pi] > 0)
         hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(plan.nar_cnt[pi])), dim3(512), smem_syrk, su, S, NP, k,
                            pairs + 2 * plan.nar_off[pi], (int)plan.nar_cnt[pi]);
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
@@ -678,6 +699,10 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     } else {
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
     }
+  }
+  if (g_cs.update) {
+    check_hip(hipEventRecord(g_cs.done, su), "record");
+    check_hip(hipStreamWaitEvent(c.stream, g_cs.done, 0), "wait");
   }
   check_hip(hipGetLastError(), "cholesky");
 }

@@ -79,68 +79,23 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   return r;
 }
 
-// ---- 32x32 Cholesky by ONE wavefront: lane i (mod 32) keeps row i in REGISTERS (a[0..31]).  Column J's entries
-// reach every lane through a 32-double LDS line (written by the owning lanes, read back as broadcasts).  The
-// lines are double buffered and software pipelined: during step J each lane first finishes its entry of column
-// J+1, publishes it and issues the broadcast reads for step J+1, and only then does the remaining rank-1
-// updates -- the LDS round trip of the next pivot hides behind them.  The step index is a template parameter so
-// that every register index is static (a dynamically indexed row would live in scratch).  Same-wave LDS traffic
-// is in order, so no barrier is needed between the steps.  dinv[J] = 1 / L(J,J).
-template <int J>
-struct PotrfStep {
-  static __device__ __forceinline__ void run(double (&a)[SB], const double (&cj)[SB], double* lines, double* dinv,
-                                             int lane, int i, bool& bad) {
-    // the pivot itself travels by v_readlane (a few cycles) so that the rsqrt chain of step J does not wait for
-    // the LDS round trip; the other column entries (needed only for the rank-1 update) come through the LDS line
-    const double piv = readlane_f64(a[J], J);
-    bad = bad || !(piv > 0.0);   // Eigen LLT: non-positive pivot -> NumericalIssue (flag stored once, branch-free steps)
-    const double r = rsqrt_nr(piv);
-    const double u = a[J] * (r * r);
-    double cn[SB];
-    if (J + 1 < SB) {
-      double* line = lines + ((J + 1) & 1) * SB;
-      a[(J + 1) % SB] -= u * cj[(J + 1) % SB];
-      if (lane < 32) line[i] = a[(J + 1) % SB];
-#pragma unroll
-      for (int c = J + 1; c < SB; c++) cn[c] = line[c];
-    }
-#pragma unroll
-    for (int c = J + 2; c < SB; c++) a[c] -= u * cj[c];
-    // pin the row here: without it hipcc defers the updates it does not need for the next pivot and keeps
-    // every step's broadcast values alive (hundreds of spilled registers)
-#pragma unroll
-    for (int c = J + 2; c < SB; c++) asm volatile("" : "+v"(a[c]));
-    a[J] = (i == J) ? piv * r : a[J] * r;
-    if (lane == J) dinv[J] = r;
-    PotrfStep<J + 1>::run(a, cn, lines, dinv, lane, i, bad);
-  }
-};
-template <>
-struct PotrfStep<SB> {
-  static __device__ __forceinline__ void run(double (&)[SB], const double (&)[SB], double*, double*, int, int, bool&) {}
-};
-
-__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv,
-                                            double* __restrict__ lines, int jb, int lane, double* fail) {
-  const int i = lane & 31;
-  const int o = SB * jb;
-  double* row = A + boff(jb, jb) + i * PB;
-  double a[SB], c0[SB];
-#pragma unroll
-  for (int c = 0; c < SB; c++) a[c] = row[c];
-  if (lane < 32) lines[i] = a[0];
-#pragma unroll
-  for (int c = 0; c < SB; c++) c0[c] = lines[c];
-  bool bad = false;
-  PotrfStep<0>::run(a, c0, lines, dinv + o, lane, i, bad);
-  if (bad && lane == 0) *fail = 1.0;
-  if (lane < 32) {
-#pragma unroll
-    for (int c = 0; c < SB; c++) row[c] = (c <= i) ? a[c] : 0.0;
-  }
+// ---- cross-half helpers (gfx950 v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second)
+// value of the same lane (mod 32) of half H (0: lanes 0-31, 1: lanes 32-63), delivered to both halves
+template <int H>
+__device__ __forceinline__ double half_bcast(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[H], (int)a[H]);
+}
+// v(lane) + v(lane ^ 32), identical in both halves
+__device__ __forceinline__ double half_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
-// X = L_jj^-1 (used by k_trsm128 / k_bwd_step): lane c owns column c, L rows are broadcast LDS reads
 // MFMA-operand image of a 32x32 block M as k_trsm128 consumes it (B operand of X * M^T, k split as 8 lk + s):
 // half tj, lane = 16 lk + lr keeps M[16 tj + lr][8 lk + 0..7] in 8 consecutive doubles, so a wavefront fetches its
 // operands of a block with four fully coalesced 16-byte loads per lane.
@@ -149,82 +104,224 @@ __device__ __forceinline__ int opnd_off(int blk, int row, int col) {
 }
 constexpr int kOpndBase = 4 * SB * SB;   // doubles: the operand images follow the four plain inverses in the Xinv slot
 
-__device__ __forceinline__ void stage_inverse(const double* A, const double* dinv, int jb, int lane, double* Xout,
-                                              double* Xop) {
-  const int i = lane & 31;
-  const int o = SB * jb;
-  const double* D = A + boff(jb, jb);
-  double x[SB];
+// 1/p to full double precision: v_rcp_f64 seed + two Newton steps (4 dependent FMAs: the shortest way from a pivot
+// to the multiplier of its rank-1 update)
+__device__ __forceinline__ double rcp_nr(double p) {
+  double x = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-p, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  return x;
+}
+
+// ---- the 32-column panel of the diagonal tile, streamed --------------------------------------------------------
+// Register layout (every wavefront of the panel): lane l keeps row i = l & 31 of its 32x32 block, the columns of
+// parity h = l >> 5 (a[cl] = A[i][2 cl + h]): a rank-1 step costs at most 16 FMAs per lane and all 64 lanes work.
+//
+// Wavefront 0 owns the diagonal block and walks the pivots (PotrfStep).  For pivot J it needs 1/piv (v_readlane +
+// rcp_nr: the serial chain, ~100 cycles) to finish column J+1, whose entries it PUBLISHES unscaled as line J+1
+// [stored in (parity, index) order pos(c) = 16 (c & 1) + c / 2 so that a half reads its 16 values as 16-byte
+// broadcasts], then it applies the rest of the rank-1 update, computes r = 1/sqrt(piv) off the chain, scales column
+// J, stores dinv[J] = r and bumps the progress counter.  All 32 lines stay in LDS.
+//
+// Every other 32-row block below (rows of L(ib,jb), i.e. the TRSM X L^T = A) and the rows of the identity (which
+// turn into L^-T, i.e. the inverse needed by k_trsm128 / k_bwd_diag) are FOLLOWERS (FollowStep): they replay the same
+// elimination on their own rows from the published (line J, r_J), a few pivots behind wavefront 0, and are done a
+// few hundred cycles after it.  They never feed back into the chain, so the chain wavefront never waits.
+// The step index is a template parameter: every register index is static.  The chain wavefront's code is branch
+// free (selects, trash address for the non-owner half) so that the scheduler can overlap the chain with the updates.
+constexpr int kLineTrash = SB * SB;   // doubles: lines[32][32], then 64 trash slots
+// explicit LDS pointers for the volatile accesses (address-space inference leaves volatile accesses as flat_*)
+typedef __attribute__((address_space(3))) volatile double* lds_vdouble_p;
+typedef __attribute__((address_space(3))) volatile int* lds_vint_p;
+
+template <int J>
+struct PotrfStep {
+  static __device__ __forceinline__ void run(double (&a)[16], const double (&cj)[16], double* lines,
+                                             lds_vdouble_p dinv, lds_vint_p prog, int progbase, int lane, int i,
+                                             int h, bool& bad) {
+    constexpr int hJ = J & 1, cJ = J >> 1;
+    const double piv = readlane_f64(a[cJ], J + 32 * hJ);
+    bad = bad || !(piv > 0.0);   // Eigen LLT: non-positive pivot -> NumericalIssue (flag stored once, branch-free steps)
+    const double rinv = rcp_nr(piv);
+    const double own = half_bcast<hJ>(a[cJ]);   // A[i][J] for both halves of row i
+    double cn[16];
+    if constexpr (J + 1 < SB) {
+      constexpr int hN = (J + 1) & 1, cN = (J + 1) >> 1;
+      // finish column J+1 (J even: only the odd half holds it in a[cN]; the even half's a[cN] is column J itself)
+      const double t = own * cj[cN];
+      if constexpr (hN == 1) a[cN] = __builtin_fma(-((h == 1) ? t : 0.0), rinv, a[cN]);
+      else a[cN] = __builtin_fma(-t, rinv, a[cN]);
+      double* line = lines + (J + 1) * SB;
+      *(lds_vdouble_p)((h == hN) ? line + 16 * (i & 1) + (i >> 1) : lines + kLineTrash + lane) = a[cN];
 #pragma unroll
-  for (int r = 0; r < SB; r++) {
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;   // independent partial sums: no 31-deep dependent FMA chain
-#pragma unroll
-    for (int m = 0; m < r; m++) {
-      const double t = D[r * PB + m] * x[m];
-      if ((m & 3) == 0) p0 += t; else if ((m & 3) == 1) p1 += t; else if ((m & 3) == 2) p2 += t; else p3 += t;
+      for (int cl = cN; cl < 16; cl++) cn[cl] = line[16 * h + cl];
     }
-    const double acc = (p0 + p1) + (p2 + p3);
-    const double dr = dinv[o + r];
-    x[r] = (r == i) ? dr : (r > i ? -acc * dr : 0.0);
+    // software-pipeline cut: nothing moves across, so a scheduling region = [rest of update J, scaling of column J]
+    // + [pivot chain of J+1, column J+2]: the chain overlaps the updates, and register pressure stays bounded
+    __builtin_amdgcn_sched_barrier(0);
+    const double u = own * rinv;
+    constexpr int c0 = (J & 1) ? cJ + 2 : cJ + 1;
+#pragma unroll
+    for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, cj[cl], a[cl]);
+    // pin the row: keeps hipcc from deferring these updates across many steps (every step's broadcast values alive)
+#pragma unroll
+    for (int cl = c0; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    const double r = rsqrt_nr(piv);
+    {
+      const double v = (i == J) ? piv * r : a[cJ] * r;
+      a[cJ] = (h == hJ) ? v : a[cJ];
+    }
+    dinv[J] = r;                    // every lane stores the same value: no exec games on the chain wavefront
+    *prog = progbase + J + 1;       // LDS operations of one wavefront complete in order
+    PotrfStep<J + 1>::run(a, cn, lines, dinv, prog, progbase, lane, i, h, bad);
   }
-  if (lane < 32) {
+};
+template <>
+struct PotrfStep<SB> {
+  static __device__ __forceinline__ void run(double (&)[16], const double (&)[16], double*, lds_vdouble_p, lds_vint_p,
+                                             int, int, int, int, bool&) {}
+};
+
+// factor the diagonal sub-block jb in place (upper part zeroed)
+__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv, double* __restrict__ lines,
+                                            int* prog, int jb, int lane, double* fail) {
+  const int i = lane & 31, h = lane >> 5;
+  double* row = A + boff(jb, jb) + i * PB;
+  double a[16], c0[16];
 #pragma unroll
-    for (int r = 0; r < SB; r++) Xout[r * SB + i] = x[r];
+  for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
+  *(lds_vdouble_p)((h == 0) ? lines + 16 * (i & 1) + (i >> 1) : lines + kLineTrash + lane) = a[0];
 #pragma unroll
-    for (int r = 0; r < SB; r++) Xop[opnd_off(6 + jb, r, i)] = x[r];
+  for (int cl = 0; cl < 16; cl++) c0[cl] = lines[16 * h + cl];
+  bool bad = false;
+  PotrfStep<0>::run(a, c0, lines, (lds_vdouble_p)(dinv + SB * jb), (lds_vint_p)prog, SB * jb, lane, i, h, bad);
+  if (bad && lane == 0) *fail = 1.0;
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
+}
+
+template <int J>
+struct FollowStep {
+  static __device__ __forceinline__ void run(double (&a)[16], const double* lines, const double* dinv,
+                                             lds_vint_p prog, int progbase, int h) {
+    if constexpr ((J & 3) == 0) {   // pivots J .. J+3 published?
+      while (*prog < progbase + J + 4) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    constexpr int hJ = J & 1, cJ = J >> 1;
+    const double r = dinv[J];
+    const double own = half_bcast<hJ>(a[cJ]);
+    const double u = own * (r * r);
+    const double* line = lines + J * SB + 16 * h;
+    if constexpr (J + 1 < SB && ((J + 1) & 1) == 1)
+      a[cJ] = __builtin_fma(-((h == 1) ? u : 0.0), line[cJ], a[cJ]);   // column J+1 lives in the odd half's a[cJ]
+    constexpr int c0 = cJ + 1;
+#pragma unroll
+    for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, line[cl], a[cl]);
+    a[cJ] = (h == hJ) ? a[cJ] * r : a[cJ];
+    // pin the row: otherwise the updates are sunk below the next wait loops and every step's u / line stays alive
+#pragma unroll
+    for (int cl = cJ; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    FollowStep<J + 1>::run(a, lines, dinv, prog, progbase, h);
+  }
+};
+template <>
+struct FollowStep<SB> {
+  static __device__ __forceinline__ void run(double (&)[16], const double*, const double*, lds_vint_p, int, int) {}
+};
+
+// follower of the diagonal sub-block jb: ib > jb -> the rows of A(ib,jb) become L(ib,jb) (in LDS);
+// ib < 0 -> the rows of the identity become L(jb,jb)^-T: lane i ends up with column i of the inverse, written
+// plain (Xout, row-major) and as the MFMA operand image (Xop)
+__device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* dinv, const int* prog, int jb,
+                                             int ib, int lane, double* Xout, double* Xop) {
+  const int i = lane & 31, h = lane >> 5;
+  const bool inv = ib < 0;
+  double* R = A + boff(inv ? jb : ib, jb) + i * PB;
+  double a[16];
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) a[cl] = inv ? ((2 * cl + h == i) ? 1.0 : 0.0) : R[2 * cl + h];
+  FollowStep<0>::run(a, lines, dinv + SB * jb, (lds_vint_p)prog, SB * jb, h);
+  if (inv) {
+#pragma unroll
+    for (int cl = 0; cl < 16; cl++) {
+      Xout[(2 * cl + h) * SB + i] = a[cl];
+      Xop[opnd_off(6 + jb, 2 * cl + h, i)] = a[cl];
+    }
+  } else {
+#pragma unroll
+    for (int cl = 0; cl < 16; cl++) R[2 * cl + h] = a[cl];
   }
 }
 
-// rows of sub-block (ib, jb): forward substitution x L_jj^T = a, one lane per row
-__device__ __forceinline__ void stage_rowtrsm(double* A, const double* dinv, int jb, int ib, int lane) {
-  const int i = lane & 31;
-  const int o = SB * jb;
-  const double* D = A + boff(jb, jb);
-  double* R = A + boff(ib, jb) + i * PB;
-  double x[SB];
+// one 16x16 MFMA tile (ti, tj) of the update A(ib,cb) -= L(ib,jb) L(cb,jb)^T inside the diagonal tile
+__device__ __forceinline__ void tile_task(double* A, int jb, int ib, int cb, int ti, int tj, int lr, int lk) {
+  double* Cb = A + boff(ib, cb);
+  const double* Li = A + boff(ib, jb);
+  const double* Lc = A + boff(cb, jb);
+  v4f64 acc;
 #pragma unroll
-  for (int c = 0; c < SB; c++) x[c] = R[c];
+  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
 #pragma unroll
-  for (int c = 0; c < SB; c++) {
-    double p0 = x[c], p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-    for (int m = 0; m < c; m++) {
-      const double t = x[m] * D[c * PB + m];
-      if ((m & 3) == 0) p0 -= t; else if ((m & 3) == 1) p1 -= t; else if ((m & 3) == 2) p2 -= t; else p3 -= t;
-    }
-    x[c] = ((p0 + p1) + (p2 + p3)) * dinv[o + c];
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
+    acc = MFMA(av, bv, acc);
   }
-  if (lane < 32) {
 #pragma unroll
-    for (int c = 0; c < SB; c++) R[c] = x[c];
+  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
+}
+
+// write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
+// strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
+__device__ __forceinline__ void store_column(const double* A, double* tile, int NP, double* Xinv, int jb, int t, int nthreads) {
+  for (int e = t; e < (4 - jb) * 512; e += nthreads) {
+    const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
+    const double* sp = A + boff(ib, jb) + r * PB + c;
+    double2 v;
+    v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
+    v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * jb + c) = v;
+    if (ib != jb) *reinterpret_cast<double2*>(Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c)) = v;
   }
 }
 
 // ---- diagonal tile ------------------------------------------------------------------------------------------
+// One workgroup of 8 wavefronts; per 32-column panel jb of the tile:
+//   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 4: follower
+//       producing the inverse | the remaining waves: everything of panel jb-1 that nobody is waiting for (the
+//       off-chain MFMA updates and the write-back of its finished blocks)
+//   P3  the update of the NEXT panel (diagonal block + the blocks below it), all waves.
 #define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-__global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
-                                                  double* __restrict__ fail, long long* __restrict__ dbg) {
+__global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
+                                                     double* __restrict__ fail, long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* dinv = A + 10 * SB * PB;                    // [T]  1 / L(j,j)
-  double* col = dinv + T;                             // [2][SB] double-buffered column broadcast lines
+  double* lines = dinv + T;                           // [SB][SB] published columns of the current panel + 64 trash
+  int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // pivots published so far (monotonic over the tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
-  __builtin_amdgcn_s_setprio(3);   // critical-path kernel: win issue arbitration against co-resident k_syrk waves
+  // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
+  // its own followers
+  if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+  if (tid == 0) *prog = 0;
   STAMP(0);
-  {  // lower sub-blocks -> LDS: 10 blocks x 512 16-byte pieces, 20 per lane, all loads in flight before the writes
-    double2 v[20];
+  {  // lower sub-blocks -> LDS: 10 blocks x 512 16-byte pieces, 10 per lane, all loads in flight before the writes
+    double2 v[10];
 #pragma unroll
-    for (int u = 0; u < 20; u++) {
-      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
+    for (int u = 0; u < 10; u++) {
+      const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
       int ib = 0, rem = blk;
       while (rem > ib) { rem -= ib + 1; ib++; }
       v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15));
     }
 #pragma unroll
-    for (int u = 0; u < 20; u++) {
-      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
+    for (int u = 0; u < 10; u++) {
+      const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
       double* d = A + blk * SB * PB + (w >> 4) * PB + 2 * (w & 15);
       d[0] = v[u].x; d[1] = v[u].y;
     }
@@ -233,56 +330,34 @@ __global__ __launch_bounds__(256) void k_potrf128(double* __restrict__ S, int NP
   STAMP(1);
 #pragma unroll 1
   for (int jb = 0; jb < 4; jb++) {
-    if (wave == 0) stage_potrf(A, dinv, col, jb, lane, fail);   // critical path
+    const int nfol = 3 - jb;   // row blocks below
+    if (wave == 0) {
+      stage_potrf(A, dinv, lines, prog, jb, lane, fail);
+    } else if (wave <= nfol || wave == 4) {
+      stage_follow(A, lines, dinv, prog, jb, wave == 4 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase);
+    } else if (jb > 0) {
+      const int pj = jb - 1;                            // deferred work of panel pj
+      const int nh = 3 + jb, hw = wave >= 5 ? wave - 5 : 3 + (wave - nfol - 1);
+      // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
+      // started): blocks (ib, cb), pj+2 <= cb <= ib
+      const int nb = 3 - pj, ntask = (nb * (nb - 1) / 2) * 4;
+      for (int t = hw; t < ntask; t += nh) {
+        const int blk = t >> 2;
+        int bi = 0, rem = blk;                           // (bi, rem): 0 <= rem <= bi < nb - 1
+        while (rem > bi) { rem -= bi + 1; bi++; }
+        tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
+      }
+      store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64);
+    }
     __syncthreads();
     STAMP(2 + 3 * jb);
-    if (wave > 0 && jb + wave < 4) stage_rowtrsm(A, dinv, jb, jb + wave, lane);
-    __syncthreads();
     STAMP(3 + 3 * jb);
-    // trailing update on the matrix cores: A(ib,cb) -= L(ib,jb) L(cb,jb)^T for jb < cb <= ib
-    const int nb = 3 - jb;
-    const int n4 = nb * (nb + 1) / 2 * 4;
-    for (int t = wave; t < n4; t += 4) {
-      const int blk = t / 4, ti = (t >> 1) & 1, tj = t & 1;
-      int bi = 0, rem = blk;
-      while (rem > bi) { rem -= bi + 1; bi++; }
-      const int ib = jb + 1 + bi, cb = jb + 1 + rem;
-      double* Cb = A + boff(ib, cb);
-      const double* Li = A + boff(ib, jb);
-      const double* Lc = A + boff(cb, jb);
-      v4f64 acc;
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
-#pragma unroll
-      for (int kk = 0; kk < SB; kk += 4) {
-        const double av = -Li[(16 * ti + lr) * PB + kk + lk];
-        const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
-        acc = MFMA(av, bv, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
-    }
+    // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start
+    for (int t = wave; t < 4 * (3 - jb); t += 8) tile_task(A, jb, jb + 1 + (t >> 2), jb + 1, (t >> 1) & 1, t & 1, lr, lk);
     __syncthreads();
     STAMP(4 + 3 * jb);
   }
-  // the four 32x32 diagonal inverses (used by k_trsm128 / k_bwd_diag, not by this kernel): off the critical
-  // path, one per wavefront
-  stage_inverse(A, dinv, wave, lane, Xinv + (int64_t)wave * SB * SB, Xinv + kOpndBase);
-  // write back the lower sub-blocks (diagonal ones with their upper part zeroed); the strictly-upper sub-blocks of
-  // the tile are never read by anyone and are left as they are
-#pragma unroll 4
-  for (int e = tid; e < 10 * 512; e += 256) {
-    const int blk = e >> 9, w = e & 511, r = w >> 4, c = 2 * (w & 15);
-    int ib = 0, rem = blk;
-    while (rem > ib) { rem -= ib + 1; ib++; }
-    const double* sp = A + blk * SB * PB + r * PB + c;
-    double2 v;
-    v.x = (ib != rem || c <= r) ? sp[0] : 0.0;
-    v.y = (ib != rem || c + 1 <= r) ? sp[1] : 0.0;
-    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * rem + c) = v;
-    if (ib != rem)   // L(p,q), q < p: operand image for k_trsm128, block index p(p-1)/2 + q
-      *reinterpret_cast<double2*>(Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + rem, r, c)) = v;
-  }
+  store_column(A, tile, NP, Xinv, 3, tid, 512);
   STAMP(14);
 }
 
@@ -616,7 +691,7 @@ static CholStreams g_cs;
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
-  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + 2 * SB);
+  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + SB * SB + 64 + 2);
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;
@@ -663,7 +738,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   const int32_t* pairs = plan.pairs.p;
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
-    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
+    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(512), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
     hipLaunchKernelGGL(k_trsm128, dim3(2 * (unsigned)plan.trsm_cnt[k]), dim3(512), smem_trsm, sp, S, NP, k,
                        rows + plan.trsm_off[k], Xk);
   };

@@ -138,93 +138,105 @@ typedef __attribute__((address_space(3))) volatile int* lds_vint_p;
 
 template <int J>
 struct PotrfStep {
-  static __device__ __forceinline__ void run(double (&a)[16], const double (&cj)[16], double* lines,
-                                             lds_vdouble_p dinv, lds_vint_p prog, int progbase, int lane, int i,
-                                             int h, bool& bad) {
+  static __device__ __forceinline__ void run(double (&a)[16], const double (&cj)[16], double own, double* lines,
+                                             lds_vdouble_p rinvs, lds_vint_p prog, int progbase, int lane, int i, int h) {
     constexpr int hJ = J & 1, cJ = J >> 1;
+    // ---- the serial chain: pivot -> 1/pivot -> column J+1 finished in its owner half -> next pivot.  The pivot and
+    // A[J+1][J] travel by v_readlane; the lane's own A[i][J] (`own`) was read back from line J one step ago, and that
+    // LDS round trip (~130 cycles) is shorter than the ~250 cycles of instruction issue of a step (measured with
+    // tools/potrf_chain_probe.hip: the bare readlane-rcp-fma chain is 90 cycles, a full step 250-300).
     const double piv = readlane_f64(a[cJ], J + 32 * hJ);
-    bad = bad || !(piv > 0.0);   // Eigen LLT: non-positive pivot -> NumericalIssue (flag stored once, branch-free steps)
     const double rinv = rcp_nr(piv);
-    const double own = half_bcast<hJ>(a[cJ]);   // A[i][J] for both halves of row i
-    double cn[16];
+    double cn[16], ownN = 0.0;
     if constexpr (J + 1 < SB) {
       constexpr int hN = (J + 1) & 1, cN = (J + 1) >> 1;
-      // finish column J+1 (J even: only the odd half holds it in a[cN]; the even half's a[cN] is column J itself)
-      const double t = own * cj[cN];
-      if constexpr (hN == 1) a[cN] = __builtin_fma(-((h == 1) ? t : 0.0), rinv, a[cN]);
-      else a[cN] = __builtin_fma(-t, rinv, a[cN]);
+      const double s1 = readlane_f64(a[cJ], J + 1 + 32 * hJ);   // A[J+1][J]
+      a[cN] = __builtin_fma(-((h == hN) ? own * s1 : 0.0), rinv, a[cN]);
+      // publish column J+1 (unscaled) and fetch it back for the rest of step J+1's update
       double* line = lines + (J + 1) * SB;
-      *(lds_vdouble_p)((h == hN) ? line + 16 * (i & 1) + (i >> 1) : lines + kLineTrash + lane) = a[cN];
+      const int pos = 16 * (i & 1) + (i >> 1);
+      *(lds_vdouble_p)((h == hN) ? line + pos : lines + kLineTrash + lane) = a[cN];
 #pragma unroll
       for (int cl = cN; cl < 16; cl++) cn[cl] = line[16 * h + cl];
+      ownN = line[pos];               // A[i][J+1], written by the lane of row i in the owner half
     }
-    // software-pipeline cut: nothing moves across, so a scheduling region = [rest of update J, scaling of column J]
-    // + [pivot chain of J+1, column J+2]: the chain overlaps the updates, and register pressure stays bounded
+    // software-pipeline cut: nothing moves across, so a scheduling region = [rest of update J] + [chain of J+1]:
+    // the chain overlaps the updates and register pressure stays bounded
     __builtin_amdgcn_sched_barrier(0);
+    // ---- rest of the rank-1 update, fed by line J (read one step ago): off the chain
     const double u = own * rinv;
+    if constexpr ((J & 1) == 1 && J + 1 < SB)   // J odd: the odd half's a[cJ+1] is column J+2
+      a[cJ + 1] = __builtin_fma(-((h == 1) ? u : 0.0), cj[cJ + 1], a[cJ + 1]);
     constexpr int c0 = (J & 1) ? cJ + 2 : cJ + 1;
 #pragma unroll
     for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, cj[cl], a[cl]);
     // pin the row: keeps hipcc from deferring these updates across many steps (every step's broadcast values alive)
 #pragma unroll
-    for (int cl = c0; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
-    const double r = rsqrt_nr(piv);
-    {
-      const double v = (i == J) ? piv * r : a[cJ] * r;
-      a[cJ] = (h == hJ) ? v : a[cJ];
-    }
-    dinv[J] = r;                    // every lane stores the same value: no exec games on the chain wavefront
-    *prog = progbase + J + 1;       // LDS operations of one wavefront complete in order
-    PotrfStep<J + 1>::run(a, cn, lines, dinv, prog, progbase, lane, i, h, bad);
+    for (int cl = cJ + 1; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    rinvs[J] = rinv;                // every lane stores the same value: no exec games on the chain wavefront
+    if constexpr ((J & 3) == 3) *prog = progbase + J + 1;   // LDS operations of one wavefront complete in order
+    PotrfStep<J + 1>::run(a, cn, ownN, lines, rinvs, prog, progbase, lane, i, h);
   }
 };
 template <>
 struct PotrfStep<SB> {
-  static __device__ __forceinline__ void run(double (&)[16], const double (&)[16], double*, lds_vdouble_p, lds_vint_p,
-                                             int, int, int, int, bool&) {}
+  static __device__ __forceinline__ void run(double (&)[16], const double (&)[16], double, double*, lds_vdouble_p, lds_vint_p,
+                                             int, int, int, int) {}
 };
 
+// The columns stay UNSCALED through the elimination (only 1/pivot is on the chain).  At the end of a panel the chain
+// wavefront computes the 32 values r_c = 1/sqrt(pivot_c) = sqrt(1/pivot_c) in parallel (lane c), publishes them in
+// (parity, index) order and raises rready; every wavefront then scales its columns.
+__device__ __forceinline__ void scale_columns(double (&a)[16], const double* rs, int h) {
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) a[cl] *= rs[16 * h + cl];
+}
+
 // factor the diagonal sub-block jb in place (upper part zeroed)
-__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ dinv, double* __restrict__ lines,
-                                            int* prog, int jb, int lane, double* fail) {
+__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ rinvs, double* __restrict__ rs,
+                                            double* __restrict__ lines, int* prog, int jb, int lane, double* fail) {
   const int i = lane & 31, h = lane >> 5;
   double* row = A + boff(jb, jb) + i * PB;
   double a[16], c0[16];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
-  *(lds_vdouble_p)((h == 0) ? lines + 16 * (i & 1) + (i >> 1) : lines + kLineTrash + lane) = a[0];
+  const int pos = 16 * (i & 1) + (i >> 1);
+  *(lds_vdouble_p)((h == 0) ? lines + pos : lines + kLineTrash + lane) = a[0];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) c0[cl] = lines[16 * h + cl];
-  bool bad = false;
-  PotrfStep<0>::run(a, c0, lines, (lds_vdouble_p)(dinv + SB * jb), (lds_vint_p)prog, SB * jb, lane, i, h, bad);
-  if (bad && lane == 0) *fail = 1.0;
+  const double own0 = lines[pos];
+  PotrfStep<0>::run(a, c0, own0, lines, (lds_vdouble_p)(rinvs + SB * jb), (lds_vint_p)prog, SB * jb, lane, i, h);
+  const double rv = rinvs[SB * jb + i];
+  // Eigen LLT: non-positive pivot -> NumericalIssue (NaN compares false too); checked once per panel, off the chain
+  if (__builtin_amdgcn_ballot_w64(!(rv > 0.0 && rv < __builtin_inf())) != 0 && lane == 0) *fail = 1.0;
+  *(lds_vdouble_p)(rs + SB * jb + pos) = rv * rsqrt_nr(rv);
+  *(lds_vint_p)(prog + 1) = jb + 1;
+  scale_columns(a, rs + SB * jb, h);
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
 }
 
 template <int J>
 struct FollowStep {
-  static __device__ __forceinline__ void run(double (&a)[16], const double* lines, const double* dinv,
+  static __device__ __forceinline__ void run(double (&a)[16], const double* lines, const double* rinvs,
                                              lds_vint_p prog, int progbase, int h) {
     if constexpr ((J & 3) == 0) {   // pivots J .. J+3 published?
       while (*prog < progbase + J + 4) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     constexpr int hJ = J & 1, cJ = J >> 1;
-    const double r = dinv[J];
     const double own = half_bcast<hJ>(a[cJ]);
-    const double u = own * (r * r);
+    const double u = own * rinvs[J];
     const double* line = lines + J * SB + 16 * h;
     if constexpr (J + 1 < SB && ((J + 1) & 1) == 1)
       a[cJ] = __builtin_fma(-((h == 1) ? u : 0.0), line[cJ], a[cJ]);   // column J+1 lives in the odd half's a[cJ]
     constexpr int c0 = cJ + 1;
 #pragma unroll
     for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, line[cl], a[cl]);
-    a[cJ] = (h == hJ) ? a[cJ] * r : a[cJ];
     // pin the row: otherwise the updates are sunk below the next wait loops and every step's u / line stays alive
 #pragma unroll
     for (int cl = cJ; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
-    FollowStep<J + 1>::run(a, lines, dinv, prog, progbase, h);
+    FollowStep<J + 1>::run(a, lines, rinvs, prog, progbase, h);
   }
 };
 template <>
@@ -235,15 +247,18 @@ struct FollowStep<SB> {
 // follower of the diagonal sub-block jb: ib > jb -> the rows of A(ib,jb) become L(ib,jb) (in LDS);
 // ib < 0 -> the rows of the identity become L(jb,jb)^-T: lane i ends up with column i of the inverse, written
 // plain (Xout, row-major) and as the MFMA operand image (Xop)
-__device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* dinv, const int* prog, int jb,
-                                             int ib, int lane, double* Xout, double* Xop) {
+__device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* rinvs, const double* rs,
+                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop) {
   const int i = lane & 31, h = lane >> 5;
   const bool inv = ib < 0;
   double* R = A + boff(inv ? jb : ib, jb) + i * PB;
   double a[16];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) a[cl] = inv ? ((2 * cl + h == i) ? 1.0 : 0.0) : R[2 * cl + h];
-  FollowStep<0>::run(a, lines, dinv + SB * jb, (lds_vint_p)prog, SB * jb, h);
+  FollowStep<0>::run(a, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, h);
+  while (*(lds_vint_p)(prog + 1) < jb + 1) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  scale_columns(a, rs + SB * jb, h);
   if (inv) {
 #pragma unroll
     for (int cl = 0; cl < 16; cl++) {
@@ -290,25 +305,26 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, int 
 
 // ---- diagonal tile ------------------------------------------------------------------------------------------
 // One workgroup of 8 wavefronts; per 32-column panel jb of the tile:
-//   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 4: follower
-//       producing the inverse | the remaining waves: everything of panel jb-1 that nobody is waiting for (the
-//       off-chain MFMA updates and the write-back of its finished blocks)
+//   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 5: follower
+//       producing the inverse | wave 4 idle (same SIMD as wave 0) | the remaining waves: everything of panel jb-1
+//       that nobody is waiting for (the off-chain MFMA updates and the write-back of its finished blocks)
 //   P3  the update of the NEXT panel (diagonal block + the blocks below it), all waves.
 #define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 __global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
                                                      double* __restrict__ fail, long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
-  double* dinv = A + 10 * SB * PB;                    // [T]  1 / L(j,j)
-  double* lines = dinv + T;                           // [SB][SB] published columns of the current panel + 64 trash
-  int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // pivots published so far (monotonic over the tile)
+  double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
+  double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
+  double* lines = rs + T;                             // [SB][SB] published columns of the current panel + 64 trash
+  int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-  if (tid == 0) *prog = 0;
+  if (tid == 0) { prog[0] = 0; prog[1] = 0; }
   STAMP(0);
   {  // lower sub-blocks -> LDS: 10 blocks x 512 16-byte pieces, 10 per lane, all loads in flight before the writes
     double2 v[10];
@@ -332,12 +348,14 @@ __global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int
   for (int jb = 0; jb < 4; jb++) {
     const int nfol = 3 - jb;   // row blocks below
     if (wave == 0) {
-      stage_potrf(A, dinv, lines, prog, jb, lane, fail);
-    } else if (wave <= nfol || wave == 4) {
-      stage_follow(A, lines, dinv, prog, jb, wave == 4 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase);
+      stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail);
+    } else if (wave == 4) {
+      // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
+    } else if (wave <= nfol || wave == 5) {
+      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase);
     } else if (jb > 0) {
       const int pj = jb - 1;                            // deferred work of panel pj
-      const int nh = 3 + jb, hw = wave >= 5 ? wave - 5 : 3 + (wave - nfol - 1);
+      const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
       // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
       // started): blocks (ib, cb), pj+2 <= cb <= ib
       const int nb = 3 - pj, ntask = (nb * (nb - 1) / 2) * 4;
@@ -691,7 +709,7 @@ static CholStreams g_cs;
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
-  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + T + SB * SB + 64 + 2);
+  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;

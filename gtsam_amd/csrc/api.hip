@@ -352,6 +352,8 @@ static void analyze(gtg_context& c) {
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
   c.S.alloc((NP + kTile) * NP);
   c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
+  check_hip(hipMemsetAsync(c.Dinv.p, 0, sizeof(double) * c.Dinv.n, c.stream), "memset");
+  c.chol_epoch = 0;
   c.xred.alloc(NP);
   c.partials.alloc(2 * 2048);
   c.scalars.alloc(SC_COUNT);
@@ -821,6 +823,8 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   const int NP = (n + kTile - 1) / kTile * kTile;
   DevBuf<double> S, Dinv, x, fail;
   S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(1);
+  check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
+  const long long saved_epoch = c->chol_epoch; c->chol_epoch = 0;
   check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");
   check_hip(hipMemsetAsync(fail.p, 0, sizeof(double), c->stream), "memset");
   check_hip(hipMemcpy2DAsync(S.p, sizeof(double) * NP, A, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream), "H2D 2D");
@@ -837,6 +841,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
+  c->chol_epoch = saved_epoch;
   return hf != 0.0 ? GTG_INDETERMINATE : GTG_OK;
   GTG_CATCH
 }

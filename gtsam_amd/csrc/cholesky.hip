@@ -310,9 +310,9 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, int 
 //       that nobody is waiting for (the off-chain MFMA updates and the write-back of its finished blocks)
 //   P3  the update of the NEXT panel (diagonal block + the blocks below it), all waves.
 #define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-__global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
-                                                     double* __restrict__ fail, long long* __restrict__ dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress word of the tile, after the operand images
+__device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
+                                           double* __restrict__ fail, long long* __restrict__ dbg, long long flagbase) {
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
@@ -368,6 +368,11 @@ __global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int
       store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64);
     }
     __syncthreads();
+    // panel jb is complete in global memory (its inverse, and every L(jb, q<jb) operand image): release it to the
+    // TRSM workgroups of this launch, which are waiting for exactly that to run their phase jb
+    if (tid == 0)
+      __hip_atomic_store(reinterpret_cast<long long*>(Xinv + kFlagOff), flagbase + jb + 1, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
     STAMP(2 + 3 * jb);
     STAMP(3 + 3 * jb);
     // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start
@@ -388,23 +393,17 @@ __global__ __launch_bounds__(512, 2) void k_potrf128(double* __restrict__ S, int
 // instead of 320.  The L(p,q) / Xinv operands of a wavefront (80 doubles per lane) are fetched into registers up
 // front, in flight together with the tile load.
 constexpr int TR = 64;   // rows per TRSM workgroup
-__global__ __launch_bounds__(512, 2) void k_trsm128(double* __restrict__ S, int NP, int k,
-                                                    const int32_t* __restrict__ rows, const double* __restrict__ Xinv) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S, int NP, int k, int wg,
+                                          const int32_t* __restrict__ rows, double* __restrict__ Xinv,
+                                          double* __restrict__ fail, long long flagbase) {
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
-  const int I = rows[blockIdx.x >> 1], half_rows = (blockIdx.x & 1) * TR;
+  const int I = rows[wg >> 1], half_rows = (wg & 1) * TR;
   __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int r0 = 16 * (wave >> 1), tj = wave & 1;
   double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
-  double bl[10][8];   // blocks 0..5: L(p,q) at p(p-1)/2 + q; 6..9: Xinv_pp  (operand images written by k_potrf128)
-#pragma unroll
-  for (int b = 0; b < 10; b++) {
-    const double2* op = reinterpret_cast<const double2*>(Xinv + kOpndBase + ((b * 2 + tj) * 64 + lane) * 8);
-#pragma unroll
-    for (int h = 0; h < 4; h++) { const double2 t = op[h]; bl[b][2 * h] = t.x; bl[b][2 * h + 1] = t.y; }
-  }
+  const long long* flag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
   {
     double2 v[8];
 #pragma unroll
@@ -419,9 +418,30 @@ __global__ __launch_bounds__(512, 2) void k_trsm128(double* __restrict__ S, int 
       d[0] = v[u].x; d[1] = v[u].y;
     }
   }
-  __syncthreads();
 #pragma unroll
   for (int p = 0; p < 4; p++) {
+    // wait until workgroup 0 has released panel p of the diagonal tile (bounded: a lost release must not hang the GPU)
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < flagbase + p + 1) {
+        if (++spins > (1 << 20)) { *fail = 1.0; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();   // also: the tile is in LDS (p = 0) / X_{p-1} is visible (p > 0)
+    // this phase's operands (images written by workgroup 0): L(p,q), q < p, and Xinv_pp
+    double bl[3][8], bx[8];
+#pragma unroll
+    for (int q = 0; q < p; q++) {
+      const double2* op = reinterpret_cast<const double2*>(Xinv + kOpndBase + (((p * (p - 1) / 2 + q) * 2 + tj) * 64 + lane) * 8);
+#pragma unroll
+      for (int h = 0; h < 4; h++) { const double2 t = op[h]; bl[q][2 * h] = t.x; bl[q][2 * h + 1] = t.y; }
+    }
+    {
+      const double2* op = reinterpret_cast<const double2*>(Xinv + kOpndBase + (((6 + p) * 2 + tj) * 64 + lane) * 8);
+#pragma unroll
+      for (int h = 0; h < 4; h++) { const double2 t = op[h]; bx[2 * h] = t.x; bx[2 * h + 1] = t.y; }
+    }
     double* mine = Xs + (r0 + lk) * P + SB * p + 16 * tj + lr;   // accumulator layout: reg r <-> row r0 + lk + 4 r
     if (p > 0) {   // R_p = A_p - sum_{q<p} X_q L(p,q)^T   (p = 0: R_0 = A_0 is already in LDS)
       v4f64 acc;
@@ -431,19 +451,19 @@ __global__ __launch_bounds__(512, 2) void k_trsm128(double* __restrict__ S, int 
       for (int q = 0; q < p; q++)
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++)
-          acc = MFMA(-Xs[(r0 + lr) * P + SB * q + 8 * lk + s8], bl[p * (p - 1) / 2 + q][s8], acc);
+          acc = MFMA(-Xs[(r0 + lr) * P + SB * q + 8 * lk + s8], bl[q][s8], acc);
 #pragma unroll
       for (int r = 0; r < 4; r++) mine[4 * r * P] = acc[r];
       __syncthreads();
     }
     v4f64 xr = (v4f64){0.0, 0.0, 0.0, 0.0};   // X_p = R_p Xinv_pp^T
 #pragma unroll
-    for (int s8 = 0; s8 < 8; s8++) xr = MFMA(Xs[(r0 + lr) * P + SB * p + 8 * lk + s8], bl[6 + p][s8], xr);
+    for (int s8 = 0; s8 < 8; s8++) xr = MFMA(Xs[(r0 + lr) * P + SB * p + 8 * lk + s8], bx[s8], xr);
     __syncthreads();   // both column halves have read R_p before it is overwritten
 #pragma unroll
     for (int r = 0; r < 4; r++) mine[4 * r * P] = xr[r];
-    __syncthreads();
   }
+  __syncthreads();
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const int e = u * 512 + tid;
@@ -452,6 +472,19 @@ __global__ __launch_bounds__(512, 2) void k_trsm128(double* __restrict__ S, int 
     v.x = Xs[row * P + 2 * pc]; v.y = Xs[row * P + 2 * pc + 1];
     *reinterpret_cast<double2*>(tile + (int64_t)row * NP + 2 * pc) = v;
   }
+}
+
+// ---- one block column = ONE launch: workgroup 0 factors the diagonal tile, workgroups 1.. are the 64-row TRSM
+// workgroups of the stored tiles below.  They run their phase p (32 columns) as soon as workgroup 0 has released panel
+// p of the diagonal tile, so that when the diagonal tile is done only the last phase of the TRSM is left: the TRSM's
+// latency leaves the serial panel chain.  Workgroup 0 never waits for the others (no deadlock, whatever the dispatch
+// order), the release/acquire pair is agent scope (L2 write-back / invalidate across XCDs).
+__global__ __launch_bounds__(512, 2) void k_panel128(double* __restrict__ S, int NP, int k, const int32_t* __restrict__ rows,
+                                                     double* __restrict__ Xinv, double* __restrict__ fail,
+                                                     long long* __restrict__ dbg, long long flagbase) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, flagbase);
+  else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, flagbase);
 }
 
 // ---- trailing update: C(I,J) -= sum_{kt} L(I,kt) L(J,kt)^T ---------------------------------------------------
@@ -689,15 +722,17 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 }
 
 // Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1):
-//   panel stream : potrf(k) trsm(k) | thin update of column k+1 | potrf(k+1) trsm(k+1)        -> event P[p]
-//   update stream: wait P[p]; update of the NEXT pair's two columns (k+2, k+3) by pair p        -> event N[p]
-//                  update of the other stored tiles right of k+3 by pair p (the bulk of the flops)
-//   panel stream : wait N[p]; pair p+1's panel chain, concurrent with the bulk update of pair p.
+//   panel stream (high priority): [wait N[p-1]] panel(k) | thin update of column k+1 | panel(k+1)   -> event P[p]
+//   update stream: wait P[p]; nar(p) = update of the NEXT pair's two columns by pair p             -> event N[p]
+//                  rest(p) = update of the other stored tiles right of them (the bulk of the flops)
 // (Earlier pairs' contributions to pair p+1's columns sit on the in-order update stream before N[p].)
-// k_potrf128 (87 KB LDS) and k_trsm128 (66 KB) fit next to one k_syrk workgroup (64 KB) on a CU, and the panel
-// stream has higher priority, so the serial panel chain is hidden behind the update instead of alternating with it.
+// panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM of the tiles below.
+// Tried and dropped (measured slower on L1723): nar on the panel stream or on a third stream with a second look-ahead
+// class for pair p+2 -- two small MFMA launches side by side double each other's latency, and every extra event costs
+// ~10 us on the waiting stream.
 struct CholStreams {
   hipStream_t panel = nullptr;
+
   hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
   hipEvent_t done = nullptr;
   int reserve = -1;
@@ -714,8 +749,8 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   const size_t smem_syrk = 4 * (size_t)CHB;
   static bool attr_set = false;
   if (!attr_set) {
-    check_hip(hipFuncSetAttribute((const void*)k_potrf128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_potrf), "smem attr");
-    check_hip(hipFuncSetAttribute((const void*)k_trsm128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_trsm), "smem attr");
+    check_hip(hipFuncSetAttribute((const void*)k_panel128, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)std::max(smem_potrf, smem_trsm)), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk / 2), "smem attr");
@@ -723,6 +758,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     attr_set = true;
   }
   const int npairs = (nt + 1) / 2;
+  const long long flagbase = (++c.chol_epoch) * 8;   // progress words are monotonic: no reset between factorisations
   if (!g_cs.panel) {
     int lo = 0, hi = 0;
     check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
@@ -736,34 +772,43 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     g_cs.P.push_back(e1); g_cs.N.push_back(e2);
   }
   if (g_cs.reserve < 0) {
-    // Optionally reserve a few CUs for the serial panel chain: the trailing updates then run on a stream whose CU
-    // mask leaves `reserve` CUs out, so k_potrf128 / k_trsm128 never wait for, nor share a CU with, k_syrk workgroups
-    // (measured on L1723: 15.3 ms -> 14.7 ms with 32 CUs reserved; off by default).
+    // Reserve a quarter of the CUs for the serial chain when the factorisation is chain bound (tile-sparse plans): the
+    // bulk updates then run on a stream whose CU mask leaves `reserve` CUs out, so the workgroups of k_panel128 and of
+    // the look-ahead updates are dispatched at once instead of waiting for k_syrk workgroups to retire
+    // (GTG_CU_RESERVE=n overrides, 0 disables).
     const char* e = getenv("GTG_CU_RESERVE");
-    g_cs.reserve = e ? atoi(e) : 0;
+    g_cs.reserve = e ? atoi(e) : 64;
     if (g_cs.reserve > 0) {
       hipDeviceProp_t prop;
       check_hip(hipGetDeviceProperties(&prop, c.device), "props");
       const int ncu = prop.multiProcessorCount;
       std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int i = 0; i < ncu - g_cs.reserve; i++) mask[i >> 5] |= 1u << (i & 31);
+      for (int i = 0; i < ncu - std::min(g_cs.reserve, ncu / 2); i++) mask[i >> 5] |= 1u << (i & 31);
       check_hip(hipExtStreamCreateWithCUMask(&g_cs.update, (uint32_t)mask.size(), mask.data()), "masked stream");
       check_hip(hipEventCreateWithFlags(&g_cs.done, hipEventDisableTiming), "event");
     }
   }
-  hipStream_t su = g_cs.update ? g_cs.update : c.stream, sp = g_cs.panel;
+  const bool masked = g_cs.update && plan.dense_fraction < 0.75;   // dense plans are throughput bound: all CUs to the update
+  hipStream_t su = masked ? g_cs.update : c.stream, sp = g_cs.panel;
   const int32_t* rows = plan.rows.p;
   const int32_t* pairs = plan.pairs.p;
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
-    hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(512), smem_potrf, sp, S, NP, k, Xk, fail, (long long*)g_potrf_dbg);
-    hipLaunchKernelGGL(k_trsm128, dim3(2 * (unsigned)plan.trsm_cnt[k]), dim3(512), smem_trsm, sp, S, NP, k,
-                       rows + plan.trsm_off[k], Xk);
+    hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), sp,
+                       S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase);
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
   check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
-  if (g_cs.update) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
+  if (masked) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
+  auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi) {
+    if (cnt[pi] <= 0) return;
+    if (cnt[pi] <= kLatencyTiles)
+      hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * cnt[pi])), dim3(512), smem_syrk / 2, st, S, NP, k,
+                         pairs + 2 * off[pi], (int)cnt[pi]);
+    else
+      hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, NP, k, pairs + 2 * off[pi], (int)cnt[pi]);
+  };
   for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
     if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.N[pi - 1], 0), "wait");
     panel(k);
@@ -779,21 +824,14 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     check_hip(hipEventRecord(g_cs.P[pi], sp), "record");
     check_hip(hipStreamWaitEvent(su, g_cs.P[pi], 0), "wait");
     if (k + 1 < nt) {
-      if (plan.nar_cnt[pi] > 0 && plan.nar_cnt[pi] <= kLatencyTiles)
-        hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * plan.nar_cnt[pi])), dim3(512), smem_syrk / 2, su, S, NP, k,
-                           pairs + 2 * plan.nar_off[pi], (int)plan.nar_cnt[pi]);
-      else if (plan.nar_cnt[pi] > 0)
-        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(plan.nar_cnt[pi])), dim3(512), smem_syrk, su, S, NP, k,
-                           pairs + 2 * plan.nar_off[pi], (int)plan.nar_cnt[pi]);
+      update(su, k, plan.nar_off, plan.nar_cnt, pi);
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
-      if (plan.rest_cnt[pi] > 0)
-        hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(plan.rest_cnt[pi])), dim3(512), smem_syrk, su, S, NP, k,
-                           pairs + 2 * plan.rest_off[pi], (int)plan.rest_cnt[pi]);
+      update(su, k, plan.rest_off, plan.rest_cnt, pi);
     } else {
       check_hip(hipEventRecord(g_cs.N[pi], su), "record");
     }
   }
-  if (g_cs.update) {
+  if (masked) {
     check_hip(hipEventRecord(g_cs.done, su), "record");
     check_hip(hipStreamWaitEvent(c.stream, g_cs.done, 0), "wait");
   }

@@ -125,7 +125,9 @@ struct gtg_context {
   gt::DevBuf<double> Hoff;                      // (81 per block)
   gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (27/obs), delta (3)
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
-  gt::DevBuf<double> Dinv;                      // per diagonal tile: the four 32x32 diagonal inverses
+  gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand
+                                                // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
+  long long chol_epoch = 0;                     // factorisations launched so far (base of the progress words)
   gt::CholPlan plan;
   gt::DevBuf<double> xbuf;                      // multi-GPU: stored tiles of S packed contiguously for the all-reduce
   gt::DevBuf<double> xred;                      // NP solution of the reduced system

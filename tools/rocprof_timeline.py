@@ -12,7 +12,7 @@ end = "end" if "end" in cols else "end_timestamp"
 extra = [c for c in ("stream_id", "queue_id", "grid_x", "grid_size_x", "workgroup_x") if c in cols]
 q = f"select name, {start}, {end}" + "".join(", " + c for c in extra) + f" from kernels order by {start}"
 rows = db.execute(q).fetchall()
-pot = [i for i, r in enumerate(rows) if "k_potrf128" in r[0]]
+pot = [i for i, r in enumerate(rows) if "k_potrf128" in r[0] or "k_panel128" in r[0]]
 # last factorisation = last run of potrf launches; a factorisation has nt of them, find nt from gaps > 1 ms
 runs, cur = [], [pot[0]]
 for a, b in zip(pot, pot[1:]):

@@ -870,74 +870,113 @@ float debug_time_syrk(gtg_context& c, double* S, int NP, int m, int abl, int rep
 }
 
 // ---- backward solve L^T x = y -------------------------------------------------------------------------
-// Step k (descending), two small launches:
-//   k_bwd_diag    one workgroup: x_k = L(k,k)^-T y_k by 4-phase block back-substitution with the 32x32
-//                 diagonal inverses, L(k,k) staged in LDS
-//   k_bwd_update  y[j] -= sum_r L(k*128 + r, j) x_k[r]  for j < k*128  (row panel read coalesced along j)
-__global__ __launch_bounds__(256) void k_bwd_diag(const double* __restrict__ S, int NP, int k,
-                                                  const double* __restrict__ Xinv, const double* __restrict__ y,
-                                                  double* __restrict__ x) {
-  // only the 6 strictly-lower 32x32 sub-blocks of L(k,k) and the 4 diagonal inverses are needed (80 KB)
-  __shared__ double Ls[6 * SB * SB];    // sub-block (q,p), q > p, at index q(q-1)/2 + p, row-major [i][c]
-  __shared__ double Xs[4 * SB * SB];
-  __shared__ double xs[T];
-  __shared__ double ts[SB];
-  const int tid = threadIdx.x;
-  const double* L = S + ((int64_t)k * T) * NP + (int64_t)k * T;
-  {  // 6 x 512 + 4 x 512 16-byte pieces = 5120 -> 20 per lane, all in flight before the LDS writes
-    double2 v[20];
-#pragma unroll
-    for (int u = 0; u < 20; u++) {
-      const int e = u * 256 + tid, blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
-      if (blk < 6) {
-        int q = 1, rem = blk;
-        while (rem >= q) { rem -= q; q++; }
-        v[u] = *reinterpret_cast<const double2*>(L + (int64_t)(SB * q + r) * NP + SB * rem + c2);
-      } else {
-        v[u] = *reinterpret_cast<const double2*>(Xinv + (blk - 6) * SB * SB + r * SB + c2);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 20; u++) {
-      const int e = u * 256 + tid, blk = e >> 9, w = e & 511;
-      double* d = (blk < 6 ? Ls + blk * SB * SB : Xs + (blk - 6) * SB * SB) + 2 * w;
-      d[0] = v[u].x; d[1] = v[u].y;
-    }
-  }
-  if (tid < T) xs[tid] = y[k * T + tid];
-  __syncthreads();
-  for (int p = 3; p >= 0; p--) {
-    if (tid < SB) {      // t = y_p - sum_{q>p} L(q,p)^T x_q
-      double t = xs[SB * p + tid];
-      for (int q = p + 1; q < 4; q++) {
-        const double* Lb = Ls + (q * (q - 1) / 2 + p) * SB * SB;
+// The 122 steps (block rows, descending) are inherently serial, so each step is ONE small launch and does as little
+// as possible:
+//   k_inv_tiles   once per factorisation, all diagonal tiles in parallel: the strictly-lower 32x32 blocks of
+//                 L(k,k)^-1 (the diagonal ones come out of k_panel128), written into the UPPER sub-blocks of the
+//                 diagonal tile of S, which nobody reads: block position (q,p) holds Linv(p,q), p > q
+//   k_bwd_step    step k: every workgroup first forms x_k = L(k,k)^-T y_k itself (a 128x128 mat-vec out of L2: cheaper
+//                 than a second launch or a grid-wide dependency), then updates its 64 columns
+//                 y[j] -= sum_r L(k*128 + r, j) x_k[r]  (row panel read coalesced along j); workgroup 0 stores x_k
+__device__ __forceinline__ void blk_mul(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B,
+                                        double alpha, bool accumulate, int tid) {   // C (+)= alpha A B, 32x32 row-major
+  const int i = tid >> 3, c0 = (tid & 7) * 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 8
-        for (int i = 0; i < SB; i++) t -= Lb[i * SB + tid] * xs[SB * q + i];
-      }
-      ts[tid] = t;
-    }
-    __syncthreads();
-    if (tid < SB) {      // x_p = Xinv_pp^T t
-      const double* Xp = Xs + p * SB * SB;
-      double acc = 0.0;
-      for (int i = tid; i < SB; i++) acc += Xp[i * SB + tid] * ts[i];
-      xs[SB * p + tid] = acc;
-    }
-    __syncthreads();
+  for (int kk = 0; kk < SB; kk++) {
+    const double av = A[i * SB + kk];
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] += av * B[kk * SB + c0 + u];
   }
-  if (tid < T) x[k * T + tid] = xs[tid];
+#pragma unroll
+  for (int u = 0; u < 4; u++) C[i * SB + c0 + u] = (accumulate ? C[i * SB + c0 + u] : 0.0) + alpha * acc[u];
 }
 
-// y[j] -= sum_r L(k*128 + r, j) x_k[r]: a workgroup owns 64 columns, its 4 waves split the 128 rows and are
-// combined through LDS in wave order (deterministic)
-__global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S, int NP, int k,
-                                                    const int32_t* __restrict__ cols, const double* __restrict__ x,
-                                                    double* __restrict__ y) {
+__global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int NP, const double* __restrict__ Xinv_all) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Lb = reinterpret_cast<double*>(smem_raw);   // [6] L(p,q), p > q, at p(p-1)/2 + q
+  double* Xb = Lb + 6 * SB * SB;                       // [4] Linv(p,p)
+  double* Wb = Xb + 4 * SB * SB;                       // [6] Linv(p,q), p > q
+  double* Tm = Wb + 6 * SB * SB;                       // scratch
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  const double* Xinv = Xinv_all + (size_t)k * T * T;
+  for (int e = tid; e < 10 * 512; e += 256) {
+    const int blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
+    double2 v;
+    if (blk < 6) {
+      int p = 1, q = blk;
+      while (q >= p) { q -= p; p++; }
+      v = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * p + r) * NP + SB * q + c2);
+      Lb[blk * SB * SB + r * SB + c2] = v.x; Lb[blk * SB * SB + r * SB + c2 + 1] = v.y;
+    } else {
+      v = *reinterpret_cast<const double2*>(Xinv + (blk - 6) * SB * SB + r * SB + c2);
+      Xb[(blk - 6) * SB * SB + r * SB + c2] = v.x; Xb[(blk - 6) * SB * SB + r * SB + c2 + 1] = v.y;
+    }
+  }
+  __syncthreads();
+  // Linv(p,q) = -Linv(p,p) sum_{r=q}^{p-1} L(p,r) Linv(r,q), by increasing distance p - q
+  for (int d = 1; d < 4; d++)
+    for (int q = 0; q + d < 4; q++) {
+      const int p = q + d;
+      for (int r = q; r < p; r++) {
+        const double* Lpr = Lb + (p * (p - 1) / 2 + r) * SB * SB;
+        const double* Irq = (r == q) ? Xb + q * SB * SB : Wb + (r * (r - 1) / 2 + q) * SB * SB;
+        blk_mul(Tm, Lpr, Irq, 1.0, r > q, tid);
+        __syncthreads();
+      }
+      blk_mul(Wb + (p * (p - 1) / 2 + q) * SB * SB, Xb + p * SB * SB, Tm, -1.0, false, tid);
+      __syncthreads();
+    }
+  for (int e = tid; e < 6 * 512; e += 256) {
+    const int blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
+    int p = 1, q = blk;
+    while (q >= p) { q -= p; p++; }
+    double2 v;
+    v.x = Wb[blk * SB * SB + r * SB + c2]; v.y = Wb[blk * SB * SB + r * SB + c2 + 1];
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * q + r) * NP + SB * p + c2) = v;   // upper position (q,p)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, int NP, int k, const int32_t* __restrict__ cols,
+                                                  int ncols, const double* __restrict__ Xinv, double* __restrict__ y,
+                                                  double* __restrict__ x) {
+  __shared__ double ys[T];
+  __shared__ double xh[2][T];
   __shared__ double xs[T];
   __shared__ double part[4][64];
-  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
-  if (tid < T) xs[tid] = x[k * T + tid];
+  const int tid = threadIdx.x;
+  const double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  if (tid < T) ys[tid] = y[k * T + tid];
   __syncthreads();
+  {  // x_q[cc] = sum_i Linv(q,q)[i][cc] y_q[i] + sum_{p>q} sum_i Linv(p,q)[i][cc] y_p[i]; two threads per entry (i halves)
+    const int c = tid & (T - 1), hf = tid >> 7, q = c >> 5, cc = c & 31;
+    double a0 = 0.0, a1 = 0.0;
+    const double* Xq = Xinv + q * SB * SB + cc;
+#pragma unroll 8
+    for (int i = 16 * hf; i < 16 * hf + 16; i += 2) {
+      a0 += Xq[i * SB] * ys[SB * q + i];
+      a1 += Xq[(i + 1) * SB] * ys[SB * q + i + 1];
+    }
+    for (int p = q + 1; p < 4; p++) {
+      const double* Wp = tile + (int64_t)(SB * q) * NP + SB * p + cc;   // Linv(p,q) sits at upper position (q,p)
+#pragma unroll 8
+      for (int i = 16 * hf; i < 16 * hf + 16; i += 2) {
+        a0 += Wp[(int64_t)i * NP] * ys[SB * p + i];
+        a1 += Wp[(int64_t)(i + 1) * NP] * ys[SB * p + i + 1];
+      }
+    }
+    xh[hf][c] = a0 + a1;
+  }
+  __syncthreads();
+  if (tid < T) {
+    const double v = xh[0][tid] + xh[1][tid];
+    xs[tid] = v;
+    if (blockIdx.x == 0) x[k * T + tid] = v;
+  }
+  __syncthreads();
+  if (ncols == 0) return;
+  const int c = tid & 63, g = tid >> 6;
   const int j = cols[blockIdx.x >> 1] * T + (blockIdx.x & 1) * 64 + c;   // stored column tiles only
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   {
@@ -958,11 +997,17 @@ __global__ __launch_bounds__(256) void k_bwd_update(const double* __restrict__ S
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
+  const size_t smem_inv = sizeof(double) * 17 * SB * SB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    check_hip(hipFuncSetAttribute((const void*)k_inv_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_inv), "smem attr");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_inv_tiles, dim3((unsigned)nt), dim3(256), smem_inv, c.stream, S, NP, Xinv);
   for (int k = nt - 1; k >= 0; k--) {
-    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(256), 0, c.stream, S, NP, k, Xinv + (size_t)k * T * T, y, x);
-    if (plan.bwd_cnt[k] > 0)
-      hipLaunchKernelGGL(k_bwd_update, dim3(2 * (unsigned)plan.bwd_cnt[k]), dim3(256), 0, c.stream, S, NP, k,
-                         plan.bcols.p + plan.bwd_off[k], x, y);
+    const int ncols = (int)plan.bwd_cnt[k];
+    hipLaunchKernelGGL(k_bwd_step, dim3(ncols > 0 ? 2 * (unsigned)ncols : 1u), dim3(256), 0, c.stream, S, NP, k,
+                       plan.bcols.p + plan.bwd_off[k], ncols, Xinv + (size_t)k * T * T, y, x);
   }
   check_hip(hipGetLastError(), "backward_solve");
 }

@@ -248,29 +248,42 @@ __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int
   S[(red_off[row[blk]] + i) * (int64_t)NP + red_off[col[blk]] + j] = Hoff[(int64_t)81 * blk + threadIdx.x];
 }
 
-// One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the
-// landmarks seen by both.  Lanes own output entries; every term is a wave-uniform 2 x 216 B read.
-__global__ __launch_bounds__(64) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
+// One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the landmarks seen
+// by both.  The n terms of a pair are ONE contraction [E_a(1) .. E_a(n)] (d_a x 3n) times [E_b(1) .. E_b(n)]^T over
+// K = 3n, run on the FP64 matrix core in steps of 4 (16x16 tile, rows/columns >= d masked to zero): per step a lane
+// gathers one entry of E_a and one of E_b (the 16 lanes of a k-slice read one 216-byte block), i.e. 1.5 loads per
+// term and lane instead of 12 with lanes owning output entries.  Fixed summation order: deterministic.
+typedef double v4f64s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
     const double* __restrict__ E, double* __restrict__ S, int NP) {
-  const int64_t p = blockIdx.x;
+  const int64_t p = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
   if (p >= n_pairs) return;
   const int ra = prow[p], rb = pcol[p];
   const int da = red_dim[ra], db = red_dim[rb];
-  const int lane = threadIdx.x;
-  const int e0 = lane, e1 = lane + 64, ne = da * db;
-  const int i0 = e0 / db, j0 = e0 % db, i1 = e1 / db, j1 = e1 % db;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int64_t k = pptr[p]; k < pptr[p + 1]; k++) {
-    const double* Ea = E + 27 * (int64_t)oa[k];
-    const double* Eb = E + 27 * (int64_t)ob[k];
-    if (e0 < ne) acc0 += Ea[3 * i0] * Eb[3 * j0] + Ea[3 * i0 + 1] * Eb[3 * j0 + 1] + Ea[3 * i0 + 2] * Eb[3 * j0 + 2];
-    if (e1 < ne) acc1 += Ea[3 * i1] * Eb[3 * j1] + Ea[3 * i1 + 1] * Eb[3 * j1 + 1] + Ea[3 * i1 + 2] * Eb[3 * j1 + 2];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int64_t k0 = pptr[p];
+  const int K = 3 * (int)(pptr[p + 1] - k0);
+  const bool ina = lr < da, inb = lr < db;
+  v4f64s acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int s4 = 0; s4 < K; s4 += 4) {
+    const int kk = s4 + lk;
+    const bool valid = kk < K;
+    const int t = kk / 3, cc = kk - 3 * t;
+    double av = 0.0, bv = 0.0;
+    if (valid && ina) av = E[27 * (int64_t)oa[k0 + t] + 3 * lr + cc];
+    if (valid && inb) bv = E[27 * (int64_t)ob[k0 + t] + 3 * lr + cc];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
   }
+  // accumulator register r holds C[row = lk + 4 r][col = lr]
   const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
-  if (e0 < ne) S[(oa_ + i0) * (int64_t)NP + ob_ + j0] -= acc0;
-  if (e1 < ne) S[(oa_ + i1) * (int64_t)NP + ob_ + j1] -= acc1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = lk + 4 * r;
+    if (row < da && inb) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= acc[r];
+  }
 }
 
 // identity on the padded diagonal NP > n
@@ -363,7 +376,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
   if (c.n_pairs)
-    hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)c.n_pairs), dim3(64), 0, c.stream, c.n_pairs, c.pair_row.p,
+    hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)((c.n_pairs + 3) / 4)), dim3(256), 0, c.stream, c.n_pairs, c.pair_row.p,
                        c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
   if (NP > c.n_red && c.shard == 0)
     hipLaunchKernelGGL(k_pad_diag, dim3((NP - c.n_red + 63) / 64), dim3(64), 0, c.stream, c.S.p, c.n_red, NP);

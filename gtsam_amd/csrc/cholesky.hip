@@ -18,7 +18,8 @@
 //                only the 32x32 diagonal inverses are used (never a 128x128 inverse)
 //   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles, K = 128 or 256, LDS double-buffered,
 //                v_mfma_f64_16x16x4_f64
-// MFMA is used only here (dense contraction); everything else on the path is HBM-bound.
+// MFMA is used here and for the per-pair contraction of the Schur complement (assemble.hip); everything else on the
+// path is HBM-bound.
 #include <algorithm>
 #include <stdexcept>
 #include <vector>

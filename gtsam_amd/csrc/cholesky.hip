@@ -722,15 +722,15 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
   check_hip(hipGetLastError(), "pack_tiles");
 }
 
-// Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1):
-//   panel stream (high priority): [wait N[p-1]] panel(k) | thin update of column k+1 | panel(k+1)   -> event P[p]
-//   update stream: wait P[p]; nar(p) = update of the NEXT pair's two columns by pair p             -> event N[p]
-//                  rest(p) = update of the other stored tiles right of them (the bulk of the flops)
-// (Earlier pairs' contributions to pair p+1's columns sit on the in-order update stream before N[p].)
-// panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM of the tiles below.
-// Tried and dropped (measured slower on L1723): nar on the panel stream or on a third stream with a second look-ahead
-// class for pair p+2 -- two small MFMA launches side by side double each other's latency, and every extra event costs
-// ~10 us on the waiting stream.
+// Two-stream schedule with look-ahead.  Pair p = block columns (k, k+1); its trailing update is split by target column
+// into nar(p) (the columns of pair p+1) and rest(p) (everything right of them: the bulk of the flops):
+//   panel stream (high priority): panel(k) | thin update of column k+1 | panel(k+1) | wait P[p-1] | nar(p) -> event N[p]
+//   update stream               : wait N[p]; rest(p)                                                  -> event P[p]
+// The whole serial chain (panel, thin update, panel, look-ahead update, next panel) is in stream order on the panel
+// stream.  Its only cross-stream dependency, "rest(p-1) has finished the columns of pair p+1", is a whole pair old
+// when it is needed, so it costs one barrier packet (~3 us measured) instead of a fresh signal round trip (~13 us).
+// rest(p) starts after nar(p) so that the two never share CUs (two small MFMA launches side by side double each
+// other's latency).  panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM below.
 struct CholStreams {
   hipStream_t panel = nullptr;
 
@@ -773,12 +773,11 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     g_cs.P.push_back(e1); g_cs.N.push_back(e2);
   }
   if (g_cs.reserve < 0) {
-    // Reserve a quarter of the CUs for the serial chain when the factorisation is chain bound (tile-sparse plans): the
-    // bulk updates then run on a stream whose CU mask leaves `reserve` CUs out, so the workgroups of k_panel128 and of
-    // the look-ahead updates are dispatched at once instead of waiting for k_syrk workgroups to retire
-    // (GTG_CU_RESERVE=n overrides, 0 disables).
+    // Optional (GTG_CU_RESERVE=n): keep n CUs out of the bulk updates' stream (CU mask), so that the workgroups of the
+    // serial chain are dispatched at once instead of waiting for k_syrk workgroups to retire.  Measured on L1723 with
+    // the chain in stream order: no gain (8.0 ms with 0, 8.1 ms with 32 reserved), hence off by default.
     const char* e = getenv("GTG_CU_RESERVE");
-    g_cs.reserve = e ? atoi(e) : 64;
+    g_cs.reserve = e ? atoi(e) : 0;
     if (g_cs.reserve > 0) {
       hipDeviceProp_t prop;
       check_hip(hipGetDeviceProperties(&prop, c.device), "props");
@@ -802,16 +801,15 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
   check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
   if (masked) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
-  auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi) {
+  auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi, bool latency) {
     if (cnt[pi] <= 0) return;
-    if (cnt[pi] <= kLatencyTiles)
+    if (latency && cnt[pi] <= kLatencyTiles)
       hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * cnt[pi])), dim3(512), smem_syrk / 2, st, S, NP, k,
                          pairs + 2 * off[pi], (int)cnt[pi]);
     else
       hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, NP, k, pairs + 2 * off[pi], (int)cnt[pi]);
   };
   for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
-    if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.N[pi - 1], 0), "wait");
     panel(k);
     if (k + 1 < nt) {
       if (plan.s1_cnt[pi] <= kLatencyTiles)
@@ -821,16 +819,15 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
         hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, NP, k,
                            pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
       panel(k + 1);
+      // the next pair's columns: everything older pairs owe them (rest(<= p-1), update stream) must be in; that event
+      // is a whole pair old by now, so the wait costs a packet (~3 us), not a cross-stream round trip (~13 us)
+      if (pi > 0) check_hip(hipStreamWaitEvent(sp, g_cs.P[pi - 1], 0), "wait");
+      update(sp, k, plan.nar_off, plan.nar_cnt, pi, true);
     }
-    check_hip(hipEventRecord(g_cs.P[pi], sp), "record");
-    check_hip(hipStreamWaitEvent(su, g_cs.P[pi], 0), "wait");
-    if (k + 1 < nt) {
-      update(su, k, plan.nar_off, plan.nar_cnt, pi);
-      check_hip(hipEventRecord(g_cs.N[pi], su), "record");
-      update(su, k, plan.rest_off, plan.rest_cnt, pi);
-    } else {
-      check_hip(hipEventRecord(g_cs.N[pi], su), "record");
-    }
+    check_hip(hipEventRecord(g_cs.N[pi], sp), "record");
+    check_hip(hipStreamWaitEvent(su, g_cs.N[pi], 0), "wait");
+    if (k + 1 < nt) update(su, k, plan.rest_off, plan.rest_cnt, pi, false);
+    check_hip(hipEventRecord(g_cs.P[pi], su), "record");
   }
   if (masked) {
     check_hip(hipEventRecord(g_cs.done, su), "record");

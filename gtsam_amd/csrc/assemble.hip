@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
 
 // One lane per observation: E = Jc^T (Jp L^-T)   (dc x 3, the clique's S block transposed)
 __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n_obs, const int32_t* __restrict__ obs_lm, JTabs t,
-    const double* __restrict__ Linv, double* __restrict__ E) {
+    const double* __restrict__ Linv, const int32_t* __restrict__ eslot, double* __restrict__ E) {
   for (int64_t o = blockIdx.x * (int64_t)kBlock + threadIdx.x; o < n_obs; o += (int64_t)gridDim.x * kBlock) {
     const double *Jc, *Jp, *b; int dc;
     obs_rec(t, o, Jc, Jp, b, dc);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n_obs, const int32_t* 
         for (int k = 0; k <= m; k++) acc += Jp[3 * r + k] * Li[3 * m + k];
         T[3 * r + m] = acc;
       }
-    double* Eo = E + 27 * o;
+    double* Eo = E + kEStride * (int64_t)eslot[o];
     for (int i = 0; i < dc; i++)
       for (int m = 0; m < 3; m++) Eo[3 * i + m] = Jc[i] * T[m] + Jc[dc + i] * T[3 + m];
   }
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
-    const double* __restrict__ E, const double* __restrict__ ylm, double invsigma, int diag, double dmin,
-    double dmax, int add_damping, double* __restrict__ S, int NP) {
+    const double* __restrict__ E, const int32_t* __restrict__ eslot, const double* __restrict__ ylm, double invsigma,
+    int diag, double dmin, double dmax, int add_damping, double* __restrict__ S, int NP) {
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int kind = inc_kind[k];
     if (kind > INC_PROJ) continue;
     const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
-    const double* Eo = E + 27 * o;
+    const double* Eo = E + kEStride * (int64_t)eslot[o];
     const double* y = ylm + 3 * (int64_t)obs_lm[o];
     for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * y[0] + Eo[3 * i + 1] * y[1] + Eo[3 * i + 2] * y[2];
   }
@@ -249,40 +249,50 @@ __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int
 }
 
 // One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the landmarks seen
-// by both.  The n terms of a pair are ONE contraction [E_a(1) .. E_a(n)] (d_a x 3n) times [E_b(1) .. E_b(n)]^T over
-// K = 3n, run on the FP64 matrix core in steps of 4 (16x16 tile, rows/columns >= d masked to zero): per step a lane
-// gathers one entry of E_a and one of E_b (the 16 lanes of a k-slice read one 216-byte block), i.e. 1.5 loads per
-// term and lane instead of 12 with lanes owning output entries.  Fixed summation order: deterministic.
+// by both, on the FP64 matrix core: one v_mfma_f64_16x16x4 per term, the contraction index being the 3 landmark
+// coordinates (k = 3 is a zero lane group; rows/columns >= d masked to zero).  Lane (row lr, k lk) reads entry
+// 3 lr + lk of the 9x3 block, so the 64 lanes of a load cover exactly ONE 216-byte E slot (two 128-byte lines): the
+// kernel is bound by vector-memory instruction issue, and this is the cheapest form of it (an earlier version with
+// lanes gathering from up to 8 slots per load was 1.4x slower; one with lanes owning output entries 2x).  The term's
+// slot indices are wave-uniform scalar loads.  Fixed summation order: deterministic.
 typedef double v4f64s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
     const double* __restrict__ E, double* __restrict__ S, int NP) {
-  const int64_t p = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t p = blockIdx.x * (int64_t)4 + wv;
   if (p >= n_pairs) return;
   const int ra = prow[p], rb = pcol[p];
   const int da = red_dim[ra], db = red_dim[rb];
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  const int64_t k0 = pptr[p];
-  const int K = 3 * (int)(pptr[p + 1] - k0);
-  const bool ina = lr < da, inb = lr < db;
+  const int64_t k0 = pptr[p], k1 = pptr[p + 1];
+  const bool ina = lr < da && lk < 3, inb = lr < db && lk < 3;
+  // branch-free operand fetch: masked lanes read entry 0 of the slot (same lines) and select zero afterwards
+  const int ea = ina ? 3 * lr + lk : 0, eb = inb ? 3 * lr + lk : 0;
   v4f64s acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int s4 = 0; s4 < K; s4 += 4) {
-    const int kk = s4 + lk;
-    const bool valid = kk < K;
-    const int t = kk / 3, cc = kk - 3 * t;
-    double av = 0.0, bv = 0.0;
-    if (valid && ina) av = E[27 * (int64_t)oa[k0 + t] + 3 * lr + cc];
-    if (valid && inb) bv = E[27 * (int64_t)ob[k0 + t] + 3 * lr + cc];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  int64_t t = k0;
+  for (; t + 4 <= k1; t += 4) {   // 4 terms in flight: 8 scalar index loads, 8 coalesced vector loads, 4 MFMAs
+    int ia[4], ib[4];
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { ia[u] = oa[t + u]; ib[u] = ob[t + u]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { av[u] = E[kEStride * (int64_t)ia[u] + ea]; bv[u] = E[kEStride * (int64_t)ib[u] + eb]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? av[u] : 0.0, inb ? bv[u] : 0.0, acc, 0, 0, 0);
+  }
+  for (; t < k1; t++) {
+    const double av = E[kEStride * (int64_t)oa[t] + ea], bv = E[kEStride * (int64_t)ob[t] + eb];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? av : 0.0, inb ? bv : 0.0, acc, 0, 0, 0);
   }
   // accumulator register r holds C[row = lk + 4 r][col = lr]
   const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = lk + 4 * r;
-    if (row < da && inb) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= acc[r];
+    if (row < da && lr < db) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= acc[r];
   }
 }
 
@@ -297,8 +307,8 @@ __global__ void k_pad_diag(double* __restrict__ S, int64_t n, int NP) {
 __global__ __launch_bounds__(kBlock) void k_backsub_lm(int32_t n_lm, const int32_t* __restrict__ owned,
     const int64_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs, const int32_t* __restrict__ obs_red,
     const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off, const double* __restrict__ E,
-    const double* __restrict__ Linv, const double* __restrict__ ylm, const double* __restrict__ x,
-    double* __restrict__ dlm) {
+    const int32_t* __restrict__ eslot, const double* __restrict__ Linv, const double* __restrict__ ylm,
+    const double* __restrict__ x, double* __restrict__ dlm) {
   for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
     if (!owned[l]) { dlm[3 * l] = 0; dlm[3 * l + 1] = 0; dlm[3 * l + 2] = 0; continue; }
     double a0 = ylm[3 * l], a1 = ylm[3 * l + 1], a2 = ylm[3 * l + 2];
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_lm(int32_t n_lm, const int32
       const int r = obs_red[o];
       const int d = red_dim[r];
       const double* xr = x + red_off[r];
-      const double* Eo = E + 27 * o;
+      const double* Eo = E + kEStride * (int64_t)eslot[o];
       for (int i = 0; i < d; i++) { a0 -= Eo[3 * i] * xr[i]; a1 -= Eo[3 * i + 1] * xr[i]; a2 -= Eo[3 * i + 2] * xr[i]; }
     }
     const double* Li = Linv + 9 * l;
@@ -360,7 +370,7 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
                      c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL);
   if (c.n_obs)
     hipLaunchKernelGGL(k_obs_E, dim3(grid1(c.n_obs)), dim3(kBlock), 0, c.stream, c.n_obs, c.obs_lm.p, jtabs(c),
-                       c.Linv.p, c.E.p);
+                       c.Linv.p, c.eslot.p, c.E.p);
   check_hip(hipGetLastError(), "point_eliminate");
 }
 
@@ -371,7 +381,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   if (c.n_red_vars)
     hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
-                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
+                       c.gred0.p, c.hdiag_red.p, c.E.p, c.eslot.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
@@ -386,7 +396,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
 void launch_back_substitute(gtg_context& c) {
   if (c.n_lm)
     hipLaunchKernelGGL(k_backsub_lm, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p,
-                       c.lm_obs_ptr.p, c.lm_obs.p, c.obs_red.p, c.red_dim.p, c.red_off.p, c.E.p, c.Linv.p, c.ylm.p,
+                       c.lm_obs_ptr.p, c.lm_obs.p, c.obs_red.p, c.red_dim.p, c.red_off.p, c.E.p, c.eslot.p, c.Linv.p, c.ylm.p,
                        c.xred.p, c.delta_lm.p);
   check_hip(hipGetLastError(), "back_substitute");
 }

@@ -36,6 +36,8 @@ struct DevBuf {
 
 // Tile-sparse schedule of the reduced-system Cholesky (built once per graph by the host symbolic analysis):
 // which 128x128 tiles exist after fill-in, at the granularity of 256-wide column pairs.
+constexpr int kEStride = 32;                    // doubles per E slot: 9x3 block padded to 256 bytes
+
 struct CholPlan {
   int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
   DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
@@ -109,6 +111,7 @@ struct gtg_context {
   // observations: obs id o < n_sfm -> sfm factor o; else projection factor o - n_sfm
   int64_t n_obs = 0;
   gt::DevBuf<int32_t> obs_red, obs_lm;          // reduced index / landmark index of each observation
+  gt::DevBuf<int32_t> eslot;                    // slot of each observation's E block (camera-major order)
   gt::DevBuf<int64_t> lm_obs_ptr;  gt::DevBuf<int32_t> lm_obs;      // landmark -> observations
   gt::DevBuf<int64_t> lm_pri_ptr;  gt::DevBuf<int32_t> lm_pri;      // landmark -> prior factors
   gt::DevBuf<int64_t> red_inc_ptr; gt::DevBuf<int32_t> red_inc_kind, red_inc_idx;  // reduced var -> contributions

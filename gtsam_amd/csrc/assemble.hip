@@ -42,44 +42,52 @@ __device__ __forceinline__ void obs_rec(const JTabs& t, int64_t o, const double*
 }
 
 // ---- lambda-invariant assembly --------------------------------------------------------------------
-// One workgroup per reduced variable; lanes own output entries (d*d Hessian entries, then d gradient
-// entries), the 4 waves split the contribution list and are combined through LDS in wave order.
+// One workgroup per reduced variable: H_dd = sum A^T A and g_d = sum A^T b over its contributions (whitened Jacobian
+// rows of every factor touching it).  The sum over rows is a contraction, run on the FP64 matrix core with b as one
+// more column: per step a lane loads one entry, the 64 lanes cover up to 4 rows of [A | b] of ONE contribution
+// (contiguous in the factor's record), and C[i][j] = sum_q A[q][i] [A | b][q][j].  The 4 waves split the contribution
+// list and are combined through LDS in wave order (deterministic).
+typedef double v4f64a __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void k_red_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, JTabs t, double* __restrict__ Hd, double* __restrict__ g,
     double* __restrict__ hdiag) {
-  __shared__ double part[4][96];
+  __shared__ double part[4][256];
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
   const int nent = d * d + d;
-  double acc0 = 0.0, acc1 = 0.0;  // entries lane and lane+64
-  const int e0 = lane, e1 = lane + 64;
   const int64_t beg = inc_ptr[r], end = inc_ptr[r + 1];
+  v4f64a acc = {0.0, 0.0, 0.0, 0.0};
   for (int64_t k = beg + wave; k < end; k += 4) {
     const double* A; const double* b; int rows;
     contribution(t, inc_kind[k], inc_idx[k], d, A, rows, b);
-    if (e0 < nent) {
-      if (e0 < d * d) { const int i = e0 / d, j = e0 % d; for (int q = 0; q < rows; q++) acc0 += A[q * d + i] * A[q * d + j]; }
-      else { const int i = e0 - d * d; for (int q = 0; q < rows; q++) acc0 += A[q * d + i] * b[q]; }
-    }
-    if (e1 < nent) {
-      if (e1 < d * d) { const int i = e1 / d, j = e1 % d; for (int q = 0; q < rows; q++) acc1 += A[q * d + i] * A[q * d + j]; }
-      else { const int i = e1 - d * d; for (int q = 0; q < rows; q++) acc1 += A[q * d + i] * b[q]; }
+    const int boff = (int)(b - A);
+    for (int q0 = 0; q0 < rows; q0 += 4) {
+      const int q = q0 + lk;
+      const bool valid = q < rows && lr <= d;
+      const int off = valid ? (lr < d ? q * d + lr : boff + q) : 0;   // branch-free: masked lanes re-read entry 0
+      const double v = A[off];
+      const double bv = valid ? v : 0.0;
+      const double av = lr < d ? bv : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
   }
-  if (e0 < 96) part[wave][e0] = acc0;
-  if (e1 < 96) part[wave][e1] = acc1;
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) part[wave][rr * 64 + lane] = acc[rr];   // C[row = lk + 4 rr][col = lr]
   __syncthreads();
   const int e = threadIdx.x;
   if (e < nent) {
-    const double s = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    const int i = e < d * d ? e / d : e - d * d, j = e < d * d ? e % d : d;
+    const int idx = (i >> 2) * 64 + 16 * (i & 3) + j;
+    const double s = ((part[0][idx] + part[1][idx]) + part[2][idx]) + part[3][idx];
     if (e < d * d) {
       Hd[(int64_t)81 * r + e] = s;
-      if (e / d == e % d) hdiag[red_off[r] + e / d] = s;
+      if (i == j) hdiag[red_off[r] + i] = s;
     } else {
-      g[(int64_t)9 * r + (e - d * d)] = s;
+      g[(int64_t)9 * r + i] = s;
     }
   }
 }

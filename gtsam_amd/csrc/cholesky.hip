@@ -521,6 +521,9 @@ template <int KT, int ABL = 0, int Q = 1>   // ABL: ablation bits for tools/ (1 
 __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0,
                                                  const int32_t* __restrict__ pairs, int npairs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
+  // the quadrant variant only runs on the serial chain: its waves win issue arbitration (MFMA pipe, LDS) against the
+  // co-resident waves of the bulk update, which would otherwise double its latency
+  if (Q > 1) __builtin_amdgcn_s_setprio(3);
   constexpr int RW = T / Q;              // rows (and columns) of the output block of a workgroup
   constexpr int TI = 2 / Q, TJ = 4 / Q;  // MFMA tiles per wavefront
   constexpr int CH = RW * KC * 8;        // bytes of one panel chunk in LDS

@@ -339,18 +339,6 @@ static void analyze(gtg_context& c) {
   up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
   up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
   up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s); up(c.pair_ptr, pair_ptr, s);
-  {  // E is stored camera-major (one 256-byte slot per observation, the slots of a camera contiguous): the Schur pair
-     // kernel walks rows of block pairs (a, .), so camera a's ~100 KB segment stays in L2 and every slot is exactly two
-     // 128-byte lines.  eslot = counting sort of the observations by their camera / pose.
-    std::vector<int64_t> cnt((size_t)c.n_red_vars + 1, 0);
-    for (int64_t o = 0; o < c.n_obs; o++) cnt[obs_red[o] + 1]++;
-    for (int r = 0; r < c.n_red_vars; r++) cnt[r + 1] += cnt[r];
-    std::vector<int32_t> eslot(c.n_obs);
-    for (int64_t o = 0; o < c.n_obs; o++) eslot[o] = (int32_t)cnt[obs_red[o]]++;
-    for (auto& v : pair_oa) v = eslot[v];
-    for (auto& v : pair_ob) v = eslot[v];
-    up(c.eslot, eslot, s);
-  }
   up(c.pair_oa, pair_oa, s); up(c.pair_ob, pair_ob, s);
 
   // ---- numeric buffers --------------------------------------------------------------------------
@@ -361,6 +349,7 @@ static void analyze(gtg_context& c) {
   c.Linv.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.ylm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.delta_lm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.E.alloc(std::max<size_t>(kEStride * (size_t)c.n_obs, 1));
+  c.vobs.alloc(std::max<size_t>(3 * (size_t)c.n_obs, 1));
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
   c.S.alloc((NP + kTile) * NP);
   c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
@@ -462,13 +451,13 @@ int gtg_destroy(gtg_handle c) {
   auto& f = c->f;
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
-                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->delta_lm, &c->S,
+                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->delta_lm, &c->S,
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
                             &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.proj_pose, &f.proj_point,
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
-                            &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->eslot, &c->lm_obs, &c->lm_pri,
+                            &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
                             &c->pair_col, &c->pair_oa, &c->pair_ob};
   for (auto* b : i32) b->free();

@@ -13,6 +13,7 @@
 // floating-point atomics, results are bit-reproducible run to run.
 #include "factors.h"
 #include "kernels.h"
+#include "recio.h"
 
 namespace gt {
 
@@ -193,23 +194,71 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
   }
 }
 
-// One lane per observation: E = Jc^T (Jp L^-T)   (dc x 3, the clique's S block transposed)
-__global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n_obs, const int32_t* __restrict__ obs_lm, JTabs t,
-    const double* __restrict__ Linv, const int32_t* __restrict__ eslot, double* __restrict__ E) {
-  for (int64_t o = blockIdx.x * (int64_t)kBlock + threadIdx.x; o < n_obs; o += (int64_t)gridDim.x * kBlock) {
-    const double *Jc, *Jp, *b; int dc;
-    obs_rec(t, o, Jc, Jp, b, dc);
-    const double* Li = Linv + 9 * (int64_t)obs_lm[o];
-    double T[6];
-    for (int r = 0; r < 2; r++)
-      for (int m = 0; m < 3; m++) {
-        double acc = 0.0;
-        for (int k = 0; k <= m; k++) acc += Jp[3 * r + k] * Li[3 * m + k];
-        T[3 * r + m] = acc;
-      }
-    double* Eo = E + kEStride * (int64_t)eslot[o];
-    for (int i = 0; i < dc; i++)
-      for (int m = 0; m < 3; m++) Eo[3 * i + m] = Jc[i] * T[m] + Jc[dc + i] * T[3 + m];
+// E_o = Jc^T (Jp L^-T) for the observations [0, n) of one factor type, one observation per lane.  The Jacobian records
+// are read and the 256-byte E slots written through the wavefront's LDS image (recio.h): 1 KiB contiguous per memory
+// instruction in both directions.
+template <int REC, int DC>
+__global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __restrict__ J, const int32_t* __restrict__ obs_lm,
+    const double* __restrict__ Linv, double* __restrict__ E) {
+  typedef RecIO<REC> IN;
+  typedef RecIO<kEStride> OUT;
+  __shared__ double img[kBlock / 64][OUT::LDS_DOUBLES > IN::LDS_DOUBLES ? OUT::LDS_DOUBLES : IN::LDS_DOUBLES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* my = img[wave];
+  const int64_t nchunks = (n + 63) / 64, stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
+    const int64_t o = ch * 64 + lane, left = n - ch * 64;
+    const int nrec = left < 64 ? (int)left : 64;
+    IN::load(my, J + (int64_t)REC * ch * 64, nrec, lane);
+    double Eo[kEStride];
+#pragma unroll
+    for (int k = 0; k < kEStride; k++) Eo[k] = 0.0;
+    if (o < n) {
+      const double* rec = my + lane * IN::PITCH;     // [Jc 2 x DC | Jp 2 x 3 | b 2]
+      const double* Li = Linv + 9 * (int64_t)obs_lm[o];
+      double T[6];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k <= m; k++) acc += rec[2 * DC + 3 * r + k] * Li[3 * m + k];
+          T[3 * r + m] = acc;
+        }
+#pragma unroll
+      for (int i = 0; i < DC; i++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) Eo[3 * i + m] = rec[i] * T[m] + rec[DC + i] * T[3 + m];
+    }
+    IN::wave_sync();   // every lane has read its record: the image becomes the E block
+#pragma unroll
+    for (int k = 0; k < kEStride; k++) my[lane * OUT::PITCH + k] = Eo[k];
+    OUT::store(my, E + (int64_t)kEStride * ch * 64, nrec, lane);
+  }
+}
+
+// v_o = Jp^T (Jc x_cam) for the back-substitution, one observation per lane, records through LDS as above
+template <int REC, int DC>
+__global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __restrict__ J, const int32_t* __restrict__ obs_red,
+    const int64_t* __restrict__ red_off, const double* __restrict__ x, double* __restrict__ v) {
+  typedef RecIO<REC> IN;
+  __shared__ double img[kBlock / 64][IN::LDS_DOUBLES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* my = img[wave];
+  const int64_t nchunks = (n + 63) / 64, stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
+    const int64_t o = ch * 64 + lane, left = n - ch * 64;
+    IN::load(my, J + (int64_t)REC * ch * 64, left < 64 ? (int)left : 64, lane);
+    if (o < n) {
+      const double* rec = my + lane * IN::PITCH;
+      const double* xr = x + red_off[obs_red[o]];
+      double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < DC; i++) { w0 += rec[i] * xr[i]; w1 += rec[DC + i] * xr[i]; }
+      const double* Jp = rec + 2 * DC;
+      v[3 * o] = Jp[0] * w0 + Jp[3] * w1; v[3 * o + 1] = Jp[1] * w0 + Jp[4] * w1; v[3 * o + 2] = Jp[2] * w0 + Jp[5] * w1;
+    }
   }
 }
 
@@ -219,7 +268,7 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
-    const double* __restrict__ E, const int32_t* __restrict__ eslot, const double* __restrict__ ylm, double invsigma,
+    const double* __restrict__ E, const double* __restrict__ ylm, double invsigma,
     int diag, double dmin, double dmax, int add_damping, double* __restrict__ S, int NP) {
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
@@ -237,7 +286,7 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int kind = inc_kind[k];
     if (kind > INC_PROJ) continue;
     const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
-    const double* Eo = E + kEStride * (int64_t)eslot[o];
+    const double* Eo = E + kEStride * o;
     const double* y = ylm + 3 * (int64_t)obs_lm[o];
     for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * y[0] + Eo[3 * i + 1] * y[1] + Eo[3 * i + 2] * y[2];
   }
@@ -311,24 +360,23 @@ __global__ void k_pad_diag(double* __restrict__ S, int64_t n, int NP) {
 }
 
 // ---- back-substitution ---------------------------------------------------------------------------------
-// One lane per landmark: delta_p = L^-T (y - sum_obs E^T x_cam)   (x_F = R^-1 (d - S x_S))
+// delta_p = L^-T (y - sum_obs E^T x_cam)   (x_F = R^-1 (d - S x_S)).  With E = Jc^T Jp L^-T the sum is
+// L^-1 sum_obs Jp^T (Jc x_cam): k_obs_v forms the summands from the Jacobian records (coalesced, one observation per
+// lane), this kernel (one landmark per lane) adds them in the landmark's observation order and finishes.
 __global__ __launch_bounds__(kBlock) void k_backsub_lm(int32_t n_lm, const int32_t* __restrict__ owned,
-    const int64_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs, const int32_t* __restrict__ obs_red,
-    const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off, const double* __restrict__ E,
-    const int32_t* __restrict__ eslot, const double* __restrict__ Linv, const double* __restrict__ ylm,
-    const double* __restrict__ x, double* __restrict__ dlm) {
+    const int64_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs, const double* __restrict__ v,
+    const double* __restrict__ Linv, const double* __restrict__ ylm, double* __restrict__ dlm) {
   for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
     if (!owned[l]) { dlm[3 * l] = 0; dlm[3 * l + 1] = 0; dlm[3 * l + 2] = 0; continue; }
-    double a0 = ylm[3 * l], a1 = ylm[3 * l + 1], a2 = ylm[3 * l + 2];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int64_t k = obs_ptr[l]; k < obs_ptr[l + 1]; k++) {
-      const int64_t o = obs[k];
-      const int r = obs_red[o];
-      const int d = red_dim[r];
-      const double* xr = x + red_off[r];
-      const double* Eo = E + kEStride * (int64_t)eslot[o];
-      for (int i = 0; i < d; i++) { a0 -= Eo[3 * i] * xr[i]; a1 -= Eo[3 * i + 1] * xr[i]; a2 -= Eo[3 * i + 2] * xr[i]; }
+      const double* vo = v + 3 * (int64_t)obs[k];
+      s0 += vo[0]; s1 += vo[1]; s2 += vo[2];
     }
-    const double* Li = Linv + 9 * l;
+    const double* Li = Linv + 9 * l;     // row-major lower-triangular L^-1
+    const double a0 = ylm[3 * l] - Li[0] * s0;
+    const double a1 = ylm[3 * l + 1] - (Li[3] * s0 + Li[4] * s1);
+    const double a2 = ylm[3 * l + 2] - (Li[6] * s0 + Li[7] * s1 + Li[8] * s2);
     dlm[3 * l] = Li[0] * a0 + Li[3] * a1 + Li[6] * a2;
     dlm[3 * l + 1] = Li[4] * a1 + Li[7] * a2;
     dlm[3 * l + 2] = Li[8] * a2;
@@ -376,9 +424,12 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
   const double is = inv_sigma(lambda);
   hipLaunchKernelGGL(k_point_factor, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.V.p,
                      c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL);
-  if (c.n_obs)
-    hipLaunchKernelGGL(k_obs_E, dim3(grid1(c.n_obs)), dim3(kBlock), 0, c.stream, c.n_obs, c.obs_lm.p, jtabs(c),
-                       c.Linv.p, c.eslot.p, c.E.p);
+  if (c.f.n_sfm)
+    hipLaunchKernelGGL((k_obs_E<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
+                       c.obs_lm.p, c.Linv.p, c.E.p);
+  if (c.f.n_proj)
+    hipLaunchKernelGGL((k_obs_E<kProjRec, 6>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
+                       c.f.proj_J.p, c.obs_lm.p + c.f.n_sfm, c.Linv.p, c.E.p + (int64_t)kEStride * c.f.n_sfm);
   check_hip(hipGetLastError(), "point_eliminate");
 }
 
@@ -389,7 +440,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   if (c.n_red_vars)
     hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
-                       c.gred0.p, c.hdiag_red.p, c.E.p, c.eslot.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
+                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
@@ -402,10 +453,15 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
 }
 
 void launch_back_substitute(gtg_context& c) {
+  if (c.f.n_sfm && c.n_lm)
+    hipLaunchKernelGGL((k_obs_v<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
+                       c.obs_red.p, c.red_off.p, c.xred.p, c.vobs.p);
+  if (c.f.n_proj && c.n_lm)
+    hipLaunchKernelGGL((k_obs_v<kProjRec, 6>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
+                       c.f.proj_J.p, c.obs_red.p + c.f.n_sfm, c.red_off.p, c.xred.p, c.vobs.p + 3 * c.f.n_sfm);
   if (c.n_lm)
     hipLaunchKernelGGL(k_backsub_lm, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p,
-                       c.lm_obs_ptr.p, c.lm_obs.p, c.obs_red.p, c.red_dim.p, c.red_off.p, c.E.p, c.eslot.p, c.Linv.p, c.ylm.p,
-                       c.xred.p, c.delta_lm.p);
+                       c.lm_obs_ptr.p, c.lm_obs.p, c.vobs.p, c.Linv.p, c.ylm.p, c.delta_lm.p);
   check_hip(hipGetLastError(), "back_substitute");
 }
 

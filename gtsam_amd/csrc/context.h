@@ -36,7 +36,7 @@ struct DevBuf {
 
 // Tile-sparse schedule of the reduced-system Cholesky (built once per graph by the host symbolic analysis):
 // which 128x128 tiles exist after fill-in, at the granularity of 256-wide column pairs.
-constexpr int kEStride = 32;                    // doubles per E slot: 9x3 block padded to 256 bytes
+constexpr int kEStride = 32;                    // doubles per E slot (one per observation): 9x3 block padded to 256 bytes = two 128-byte lines
 
 struct CholPlan {
   int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
@@ -111,7 +111,6 @@ struct gtg_context {
   // observations: obs id o < n_sfm -> sfm factor o; else projection factor o - n_sfm
   int64_t n_obs = 0;
   gt::DevBuf<int32_t> obs_red, obs_lm;          // reduced index / landmark index of each observation
-  gt::DevBuf<int32_t> eslot;                    // slot of each observation's E block (camera-major order)
   gt::DevBuf<int64_t> lm_obs_ptr;  gt::DevBuf<int32_t> lm_obs;      // landmark -> observations
   gt::DevBuf<int64_t> lm_pri_ptr;  gt::DevBuf<int32_t> lm_pri;      // landmark -> prior factors
   gt::DevBuf<int64_t> red_inc_ptr; gt::DevBuf<int32_t> red_inc_kind, red_inc_idx;  // reduced var -> contributions
@@ -126,7 +125,8 @@ struct gtg_context {
   gt::DevBuf<double> Hd, gred0, hdiag_red;      // reduced diag blocks (81), gradient (9), diagonal (n_red)
   gt::DevBuf<double> V, gp;                     // landmark blocks (9) and gradient (3)
   gt::DevBuf<double> Hoff;                      // (81 per block)
-  gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (27/obs), delta (3)
+  gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (32/obs), delta (3)
+  gt::DevBuf<double> vobs;                      // per try: Jp^T (Jc x_cam) of every observation (3), for the back-substitution
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
   gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)

@@ -9,6 +9,7 @@
 // and Values::retract (nonlinear/Values.cpp:52-63).
 #include "factors.h"
 #include "kernels.h"
+#include "recio.h"
 
 namespace gt {
 
@@ -46,21 +47,30 @@ struct NoiseTab {
 };
 
 // ---- linearize ------------------------------------------------------------------------------------
+// chunk c of 64 consecutive factors belongs to wavefront c of the grid (grid-stride over chunks)
 __global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __restrict__ cam,
     const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz,
     const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
     double* __restrict__ J) {
-  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    double c[17], p[3], zz[2], rec[kSfmRec];
-    const double* cp = values + val_off[cam[i]];
-    const double* pp = values + val_off[pt[i]];
-    for (int k = 0; k < 17; k++) c[k] = cp[k];
-    for (int k = 0; k < 3; k++) p[k] = pp[k];
-    zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
-    const int ni = nz[i];
-    sfm_linearize(c, p, zz, nt.ref(ni), rec);
-    double* out = J + (int64_t)kSfmRec * i;
-    for (int k = 0; k < kSfmRec; k++) out[k] = rec[k];
+  typedef RecIO<kSfmRec> IO;
+  __shared__ double img[kBlock / 64][IO::LDS_DOUBLES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* my = img[wave];
+  const int64_t nchunks = (n + 63) / 64, stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
+    const int64_t i = ch * 64 + lane;
+    if (i < n) {
+      double c[17], p[3], zz[2], rec[kSfmRec];
+      const double* cp = values + val_off[cam[i]];
+      const double* pp = values + val_off[pt[i]];
+      for (int k = 0; k < 17; k++) c[k] = cp[k];
+      for (int k = 0; k < 3; k++) p[k] = pp[k];
+      zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
+      sfm_linearize(c, p, zz, nt.ref(nz[i]), rec);
+      for (int k = 0; k < kSfmRec; k++) my[lane * IO::PITCH + k] = rec[k];
+    }
+    const int64_t left = n - ch * 64;
+    IO::store(my, J + (int64_t)kSfmRec * ch * 64, left < 64 ? (int)left : 64, lane);
   }
 }
 
@@ -70,20 +80,28 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
     const double* __restrict__ calib, const double* __restrict__ sensor,
     const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
     double* __restrict__ J) {
-  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    double T[12], p[3], zz[2], K[5], S[12], rec[kProjRec];
-    const double* tp = values + val_off[pose[i]];
-    const double* pp = values + val_off[pt[i]];
-    for (int k = 0; k < 12; k++) T[k] = tp[k];
-    for (int k = 0; k < 3; k++) p[k] = pp[k];
-    for (int k = 0; k < 5; k++) K[k] = calib[5 * calib_idx[i] + k];
-    const int si = sensor_idx[i];
-    if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
-    zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
-    const int ni = nz[i];
-    proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(ni), rec);
-    double* out = J + (int64_t)kProjRec * i;
-    for (int k = 0; k < kProjRec; k++) out[k] = rec[k];
+  typedef RecIO<kProjRec> IO;
+  __shared__ double img[kBlock / 64][IO::LDS_DOUBLES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* my = img[wave];
+  const int64_t nchunks = (n + 63) / 64, stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
+    const int64_t i = ch * 64 + lane;
+    if (i < n) {
+      double T[12], p[3], zz[2], K[5], S[12], rec[kProjRec];
+      const double* tp = values + val_off[pose[i]];
+      const double* pp = values + val_off[pt[i]];
+      for (int k = 0; k < 12; k++) T[k] = tp[k];
+      for (int k = 0; k < 3; k++) p[k] = pp[k];
+      for (int k = 0; k < 5; k++) K[k] = calib[5 * calib_idx[i] + k];
+      const int si = sensor_idx[i];
+      if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
+      zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
+      proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(nz[i]), rec);
+      for (int k = 0; k < kProjRec; k++) my[lane * IO::PITCH + k] = rec[k];
+    }
+    const int64_t left = n - ch * 64;
+    IO::store(my, J + (int64_t)kProjRec * ch * 64, left < 64 ? (int)left : 64, lane);
   }
 }
 

@@ -11,15 +11,19 @@
 //
 // Right-looking over 128-wide block columns, processed in PAIRS so that the big trailing update
 // contracts over K = 256 (arithmetic intensity 32 flop/B against the C tile traffic):
-//   k_potrf128   one workgroup: 128x128 diagonal tile in LDS, 32-blocked; the 32x32 diagonal blocks are
-//                factored and inverted in REGISTERS by one wavefront (lane = row, v_readlane broadcasts),
-//                the level-3 parts run on the FP64 matrix cores
-//   k_trsm128    one workgroup per 128-row tile: X = A L^-T by 4-phase block substitution with MFMA;
-//                only the 32x32 diagonal inverses are used (never a 128x128 inverse)
-//   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles, K = 128 or 256, LDS double-buffered,
-//                v_mfma_f64_16x16x4_f64
-// MFMA is used here and for the per-pair contraction of the Schur complement (assemble.hip); everything else on the
-// path is HBM-bound.
+//   k_panel128   ONE launch per block column.  Workgroup 0 factors the 128x128 diagonal tile in LDS as a stream of four
+//                32-column panels: one chain wavefront walks the pivots with only v_readlane + 1/pivot on the serial
+//                path and publishes (column, 1/pivot) per pivot; follower wavefronts replay the elimination on the
+//                32-row blocks below and on the identity, which yields the TRSM inside the tile and the 32x32
+//                inverses for free; the level-3 parts run on the FP64 matrix cores.  The other workgroups are the
+//                64-row TRSM workgroups of the stored tiles below (X = A L^-T by 4-phase block substitution with
+//                MFMA); they run phase p as soon as workgroup 0 releases panel p (agent-scope release/acquire), so
+//                only the last phase is left when the diagonal tile is done.
+//   k_syrk       C(I,J) -= sum_k L(I,k) L(J,k)^T, 128x128 tiles (or 64x64 quadrants for the small launches on the
+//                serial chain), K = 128 or 256, LDS-DMA double-buffered, v_mfma_f64_16x16x4_f64
+//   k_inv_tiles, k_bwd_step   backward solve: batched 128x128 tile inverses, then one small launch per block row
+// MFMA is used here and for the small contractions of the assembly (Schur pairs, camera blocks: assemble.hip);
+// everything else on the path is HBM-bound.
 #include <algorithm>
 #include <stdexcept>
 #include <vector>

@@ -42,6 +42,11 @@ def build_workload(name):
         from tests import problems as PB
         g = dict(_np.load(os.path.join(ROOT, "tests", "golden", "sphere2500.npz")))
         return PB.sphere2500(g), "sphere2500 pose graph (reference's examples/Data/sphere2500.txt via the golden fixture), prior on pose 0, odometry-chain init"
+    if name == "w20000":
+        import numpy as _np
+        from tests import problems as PB
+        g = dict(_np.load(os.path.join(ROOT, "tests", "golden", "pose2_w20000.npz")))
+        return PB.pose2_graph(g), "w20000 Pose2 pose graph (reference's examples/Data/w20000.txt via the golden fixture; BASELINE configs[0] with the absent w10000 replaced), prior on pose 0, load2D init"
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -82,7 +87,7 @@ def main():
 
     (problem, values0), desc = build_workload(args.workload)
     params = LevenbergMarquardtParams.CeresDefaults()       # timing/timeSFMBAL.h:69-70
-    if args.workload == "sphere2500":
+    if args.workload in ("sphere2500", "w20000"):
         params = LevenbergMarquardtParams()                  # Pose3SLAMExample_g2o protocol with legacy LM
 
     def fresh():
@@ -168,9 +173,10 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "protocol": ("timeSFMBAL: GeneralSFMFactor Unit(2) noise, no priors, Ceres LM params, Schur ordering" if problem.n_sfm
+                                    else "Pose2SLAMExample_g2o with LevenbergMarquardt (legacy params), BetweenFactor<Pose2> + prior" if (problem.var_type == 3).any()
                                     else "Pose3SLAMExample_g2o with LevenbergMarquardt (legacy params), BetweenFactor<Pose3> + prior"),
                        "cameras": int((problem.var_type == 1).sum()), "points": int((problem.var_type == 2).sum()),
-                       "poses": int((problem.var_type == 0).sum()), "between_factors": int(problem.n_between),
+                       "poses": int(((problem.var_type == 0) | (problem.var_type == 3)).sum()), "between_factors": int(problem.n_between),
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
                        "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU"},
             "lambda_tries_per_s": tries / elapsed,

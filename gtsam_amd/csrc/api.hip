@@ -44,7 +44,7 @@ template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<long long>;
 
-static inline int storage_size(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }
+static inline int storage_size(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }   // POINT3, POSE2: 3
 static inline int tangent_dim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }
 
 // host copy of the (shard-filtered) factor index arrays needed by the symbolic analysis
@@ -115,9 +115,9 @@ static void analyze(gtg_context& c) {
     if (c.h_var_type[hi.proj_pose[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.proj_point[i]] != GTG_VAR_POINT3)
       throw std::invalid_argument("GenericProjectionFactor keys must be (POSE3, POINT3)");
   for (int64_t i = 0; i < n_btw; i++)
-    if (c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.between_v2[i]] != GTG_VAR_POSE3 ||
-        hi.between_v1[i] == hi.between_v2[i])
-      throw std::invalid_argument("BetweenFactor<Pose3> keys must be two distinct POSE3 variables");
+    if (c.h_var_type[hi.between_v1[i]] != c.h_var_type[hi.between_v2[i]] || hi.between_v1[i] == hi.between_v2[i] ||
+        (c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE3 && c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE2))
+      throw std::invalid_argument("BetweenFactor keys must be two distinct POSE3 (or two distinct POSE2) variables");
 
   // ordering of the reduced variables
   c.h_red_pos.assign(c.n_red_vars, -1);
@@ -483,7 +483,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   c->h_val_off.assign(p->n_vars + 1, 0); c->h_dim_off.assign(p->n_vars + 1, 0);
   for (int v = 0; v < p->n_vars; v++) {
     const int t = p->var_type[v];
-    if (t < 0 || t > 2) throw std::invalid_argument("unknown variable type");
+    if (t < 0 || t > GTG_VAR_POSE2) throw std::invalid_argument("unknown variable type");
     c->h_val_off[v + 1] = c->h_val_off[v] + storage_size(t);
     c->h_dim_off[v + 1] = c->h_dim_off[v] + tangent_dim(t);
   }
@@ -572,7 +572,8 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   { // between
     std::vector<int32_t> v1, v2, nz; std::vector<double> z;
     for (int64_t i = 0; i < p->n_between; i++) {
-      check_var(p->between_v1[i]); check_var(p->between_v2[i]); check_noise(p->between_noise[i], 6, "BetweenFactor<Pose3>");
+      check_var(p->between_v1[i]); check_var(p->between_v2[i]);
+      check_noise(p->between_noise[i], tangent_dim(p->var_type[p->between_v1[i]]), "BetweenFactor");
       if (n_shards > 1 && (i % n_shards) != shard) continue;
       v1.push_back(p->between_v1[i]); v2.push_back(p->between_v2[i]); nz.push_back(p->between_noise[i]);
       for (int k = 0; k < 12; k++) z.push_back(p->between_z[12 * i + k]);

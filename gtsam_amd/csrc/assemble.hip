@@ -30,8 +30,8 @@ __device__ __forceinline__ void contribution(const JTabs& t, int kind, int idx, 
                                              int& rows, const double*& b) {
   if (kind == INC_SFM) { const double* J = t.sfm_J + (int64_t)kSfmRec * idx; A = J; rows = 2; b = J + 24; }
   else if (kind == INC_PROJ) { const double* J = t.proj_J + (int64_t)kProjRec * idx; A = J; rows = 2; b = J + 18; }
-  else if (kind == INC_BTW_A) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J; rows = 6; b = J + 72; }
-  else if (kind == INC_BTW_B) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J + 36; rows = 6; b = J + 72; }
+  else if (kind == INC_BTW_A) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J; rows = d; b = J + 72; }   // d = 6 Pose3, 3 Pose2
+  else if (kind == INC_BTW_B) { const double* J = t.bt_J + (int64_t)kBetweenRec * idx; A = J + 36; rows = d; b = J + 72; }
   else { const double* J = t.pr_J + (int64_t)kPriorRec * idx; A = J; rows = d; b = J + 81; }
 }
 
@@ -119,14 +119,17 @@ __global__ __launch_bounds__(kBlock) void k_lm_diag(int32_t n_lm, const int64_t*
   }
 }
 
-// One wavefront per off-diagonal pose-pose block (6x6): sum over the BetweenFactors joining the pair.
+// One wavefront per off-diagonal pose-pose block (d x d, d = 6 Pose3 / 3 Pose2): sum over the BetweenFactors joining
+// the pair.
 __global__ __launch_bounds__(64) void k_hoff(int64_t n_blocks, const int64_t* __restrict__ ptr,
-    const int32_t* __restrict__ fac, const double* __restrict__ bt_J, double* __restrict__ Hoff) {
+    const int32_t* __restrict__ fac, const int32_t* __restrict__ row, const int32_t* __restrict__ red_dim,
+    const double* __restrict__ bt_J, double* __restrict__ Hoff) {
   const int64_t blk = blockIdx.x;
   if (blk >= n_blocks) return;
+  const int d = red_dim[row[blk]];
   const int e = threadIdx.x;
-  if (e >= 36) return;
-  const int i = e / 6, j = e % 6;
+  if (e >= d * d) return;
+  const int i = e / d, j = e % d;
   double acc = 0.0;
   for (int64_t k = ptr[blk]; k < ptr[blk + 1]; k++) {
     const int code = fac[k];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) void k_hoff(int64_t n_blocks, const int64_t* __
     const double* J = bt_J + (int64_t)kBetweenRec * f;
     const double* X = swap ? J + 36 : J;
     const double* Y = swap ? J : J + 36;
-    for (int q = 0; q < 6; q++) acc += X[6 * q + i] * Y[6 * q + j];
+    for (int q = 0; q < d; q++) acc += X[d * q + i] * Y[d * q + j];
   }
   Hoff[(int64_t)81 * blk + e] = acc;
 }
@@ -297,11 +300,13 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
 }
 
 __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int32_t* __restrict__ row,
-    const int32_t* __restrict__ col, const int64_t* __restrict__ red_off, const double* __restrict__ Hoff,
-    double* __restrict__ S, int NP) {
+    const int32_t* __restrict__ col, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+    const double* __restrict__ Hoff, double* __restrict__ S, int NP) {
   const int64_t blk = blockIdx.x;
-  if (blk >= n_blocks || threadIdx.x >= 36) return;
-  const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+  if (blk >= n_blocks) return;
+  const int d = red_dim[row[blk]];
+  if ((int)threadIdx.x >= d * d) return;
+  const int i = threadIdx.x / d, j = threadIdx.x % d;
   S[(red_off[row[blk]] + i) * (int64_t)NP + red_off[col[blk]] + j] = Hoff[(int64_t)81 * blk + threadIdx.x];
 }
 
@@ -409,7 +414,7 @@ void launch_assemble(gtg_context& c) {
                        c.lm_pri_ptr.p, c.lm_pri.p, t, c.V.p, c.gp.p);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_ptr.p, c.hoff_fac.p,
-                       c.f.between_J.p, c.Hoff.p);
+                       c.hoff_row.p, c.red_dim.p, c.f.between_J.p, c.Hoff.p);
   check_hip(hipGetLastError(), "assemble");
 }
 
@@ -436,14 +441,14 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
 void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax) {
   const double is = inv_sigma(lambda);
   const int NP = c.NP;
-  check_hip(hipMemsetAsync(c.S.p, 0, sizeof(double) * (size_t)(NP + kTile) * NP, c.stream), "memset S");
+  launch_zero_tiles(c, c.S.p, NP, c.plan);
   if (c.n_red_vars)
     hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
                        c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
-                       c.hoff_col.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
+                       c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
   if (c.n_pairs)
     hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)((c.n_pairs + 3) / 4)), dim3(256), 0, c.stream, c.n_pairs, c.pair_row.p,
                        c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);

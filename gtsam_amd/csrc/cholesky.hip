@@ -724,6 +724,20 @@ __global__ __launch_bounds__(256) void k_pack_tiles(double* __restrict__ S, int 
     if (unpack) *g = *p; else *p = *g;
   }
 }
+// zero the stored tiles of S (the others are never read): what the per-try rebuild of the reduced system needs
+// instead of a memset of the whole (NP + 128) x NP array (29 GB for a 20 000-pose 2-D graph, 99 % of it unused)
+__global__ __launch_bounds__(256) void k_zero_tiles(double* __restrict__ S, int NP, const int32_t* __restrict__ tiles) {
+  const int I = tiles[2 * blockIdx.x], J = tiles[2 * blockIdx.x + 1];
+  double* tile = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  const double2 z = {0.0, 0.0};
+#pragma unroll 8
+  for (int e = threadIdx.x; e < T * (T / 2); e += 256)
+    *reinterpret_cast<double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2))) = z;
+}
+void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan) {
+  hipLaunchKernelGGL(k_zero_tiles, dim3((unsigned)plan.n_stored), dim3(256), 0, c.stream, S, NP, plan.stored.p);
+  check_hip(hipGetLastError(), "zero_tiles");
+}
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack) {
   hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_stored), dim3(256), 0, c.stream, S, NP, plan.stored.p, buf, unpack ? 1 : 0);
   check_hip(hipGetLastError(), "pack_tiles");

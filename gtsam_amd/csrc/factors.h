@@ -168,6 +168,40 @@ GT_HD double between_error(const double* T1, const double* T2, const double* Z, 
   return factor_loss(n, e);
 }
 
+// ---- BetweenFactor<Pose2> ---------------------------------------------------------------------
+// Same generic LieGroup::between (Lie.h:63-69): h = p1^-1 p2, H1 = -Ad(h^-1) (Pose2.cpp:126-135), H2 = I;
+// r = Local(z, h) = (x, y, theta) of z^-1 h, Jacobians not multiplied by the chart derivative (default flags).
+// Record = the BetweenFactor<Pose3> record with 3x3 blocks: A1 at [0..8], A2 at [36..44], b at [72..74].
+GT_HD void between2_residual(const double* p1, const double* p2, const double* z, double* h, double* r) {
+  pose2_between_cs(p1[0], p1[1], cos(p1[2]), sin(p1[2]), p2[0], p2[1], cos(p2[2]), sin(p2[2]), h);
+  double g[4];
+  pose2_between_cs(z[0], z[1], cos(z[2]), sin(z[2]), h[0], h[1], h[2], h[3], g);
+  r[0] = g[0]; r[1] = g[1]; r[2] = atan2(g[3], g[2]);
+}
+GT_HD void between2_linearize(const double* p1, const double* p2, const double* z, const NoiseRef& n, double* J) {
+  double h[4], r[3];
+  between2_residual(p1, p2, z, h, r);
+  for (int i = 0; i < kBetweenRec; i++) J[i] = 0.0;
+  // h^-1 = (c, -s, unrotate(-t_h)); Ad(pose) = [c -s y; s c -x; 0 0 1]
+  const double c = h[2], s = -h[3];
+  const double x = h[2] * (-h[0]) + h[3] * (-h[1]), y = -h[3] * (-h[0]) + h[2] * (-h[1]);
+  J[0] = -c; J[1] = s; J[2] = -y;
+  J[3] = -s; J[4] = -c; J[5] = x;
+  J[6] = 0.0; J[7] = 0.0; J[8] = -1.0;
+  J[36] = 1.0; J[40] = 1.0; J[44] = 1.0;
+  for (int i = 0; i < 3; i++) J[72 + i] = -r[i];
+  whiten_cols<3>(n.kind, n.data, J, 3);
+  whiten_cols<3>(n.kind, n.data, J + 36, 3);
+  whiten_cols<3>(n.kind, n.data, J + 72, 1);
+  if (n.rkind) { const double w = reweight_factor(n, J + 72, 3); for (int i = 0; i < kBetweenRec; i++) J[i] *= w; }
+}
+GT_HD double between2_error(const double* p1, const double* p2, const double* z, const NoiseRef& n) {
+  double h[4], r[3];
+  between2_residual(p1, p2, z, h, r);
+  whiten_cols<3>(n.kind, n.data, r, 1);
+  return factor_loss(n, r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+}
+
 // ---- PriorFactor<T> ---------------------------------------------------------------------------
 // r = -Local(x, prior), H = I (approximate on purpose, PriorFactor.h:99).  d = tangent dim.
 template <int D>

@@ -105,17 +105,24 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
   }
 }
 
+// BetweenFactor<Pose3> or BetweenFactor<Pose2>: decided by the type of the factor's variables (both of one type)
 __global__ __launch_bounds__(kBlock) void k_lin_between(int64_t n, const int32_t* __restrict__ v1,
     const int32_t* __restrict__ v2, const double* __restrict__ z, const int32_t* __restrict__ nz,
-    const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
-    double* __restrict__ J) {
+    const int32_t* __restrict__ var_type, const double* __restrict__ values, const int64_t* __restrict__ val_off,
+    NoiseTab nt, double* __restrict__ J) {
   for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    double T1[12], T2[12], Z[12];
     const double* a = values + val_off[v1[i]];
     const double* b = values + val_off[v2[i]];
-    for (int k = 0; k < 12; k++) { T1[k] = a[k]; T2[k] = b[k]; Z[k] = z[12 * i + k]; }
     const int ni = nz[i];
-    between_linearize(T1, T2, Z, nt.ref(ni), J + (int64_t)kBetweenRec * i);
+    if (var_type[v1[i]] == 3) {
+      double p1[3], p2[3], zz[3];
+      for (int k = 0; k < 3; k++) { p1[k] = a[k]; p2[k] = b[k]; zz[k] = z[12 * i + k]; }
+      between2_linearize(p1, p2, zz, nt.ref(ni), J + (int64_t)kBetweenRec * i);
+    } else {
+      double T1[12], T2[12], Z[12];
+      for (int k = 0; k < 12; k++) { T1[k] = a[k]; T2[k] = b[k]; Z[k] = z[12 * i + k]; }
+      between_linearize(T1, T2, Z, nt.ref(ni), J + (int64_t)kBetweenRec * i);
+    }
   }
 }
 
@@ -169,9 +176,15 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     acc += proj_error(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_between; i += stride) {
-    double T1[12], T2[12], Z[12];
     const double* x = values + a.val_off[a.bt_v1[i]];
     const double* y = values + a.val_off[a.bt_v2[i]];
+    if (a.var_type[a.bt_v1[i]] == 3) {
+      double p1[3], p2[3], zz[3];
+      for (int k = 0; k < 3; k++) { p1[k] = x[k]; p2[k] = y[k]; zz[k] = a.bt_z[12 * i + k]; }
+      acc += between2_error(p1, p2, zz, nt.ref(a.bt_nz[i]));
+      continue;
+    }
+    double T1[12], T2[12], Z[12];
     for (int k = 0; k < 12; k++) { T1[k] = x[k]; T2[k] = y[k]; Z[k] = a.bt_z[12 * i + k]; }
     const int ni = a.bt_nz[i];
     acc += between_error(T1, T2, Z, nt.ref(ni));
@@ -237,10 +250,11 @@ __global__ __launch_bounds__(kBlock) void k_linear_error(LinErrArgs a, const dou
     const double* J = a.bt_J + (int64_t)kBetweenRec * i;
     const double* d1 = delta + a.dim_off[a.bt_v1[i]];
     const double* d2 = delta + a.dim_off[a.bt_v2[i]];
-    for (int r = 0; r < 6; r++) {
+    const int d = a.var_type[a.bt_v1[i]] == 3 ? 3 : 6;   // Pose2 : Pose3
+    for (int r = 0; r < d; r++) {
       const double b = J[72 + r];
       double v = -b;
-      for (int k = 0; k < 6; k++) v += J[6 * r + k] * d1[k] + J[36 + 6 * r + k] * d2[k];
+      for (int k = 0; k < d; k++) v += J[d * r + k] * d1[k] + J[36 + d * r + k] * d2[k];
       e0 += b * b; e1 += v * v;
     }
   }
@@ -292,8 +306,8 @@ void launch_linearize(gtg_context& c) {
                        f.sensor.p, c.values.p, c.val_off.p, nt, f.proj_J.p);
   if (f.n_between)
     hipLaunchKernelGGL(k_lin_between, dim3(grid_for(f.n_between)), dim3(kBlock), 0, c.stream, f.n_between,
-                       f.between_v1.p, f.between_v2.p, f.between_z.p, f.between_noise.p, c.values.p, c.val_off.p,
-                       nt, f.between_J.p);
+                       f.between_v1.p, f.between_v2.p, f.between_z.p, f.between_noise.p, c.var_type.p, c.values.p,
+                       c.val_off.p, nt, f.between_J.p);
   if (f.n_prior)
     hipLaunchKernelGGL(k_lin_prior, dim3(grid_for(f.n_prior)), dim3(kBlock), 0, c.stream, f.n_prior, f.prior_var.p,
                        f.prior_off.p, f.prior_data.p, f.prior_noise.p, c.var_type.p, c.values.p, c.val_off.p, nt,

@@ -298,18 +298,58 @@ GT_HD void whiten_cols(int kind, const double* nd, double* A, int ncols) {
   }
 }
 
+// ---- Pose2 (geometry/Pose2.{h,cpp}, Rot2.{h,cpp}) --------------------------------------------------------------
+// Stored as (x, y, theta); the reference keeps (c, s) instead of theta and multiplies rotations as complex numbers
+// (Rot2.h:116-118: fromCosSin(c1 c2 - s1 s2, s1 c2 + c1 s2), re-normalised only when |c^2+s^2-1| > 1e-10,
+// Rot2.cpp:56-64); theta() = atan2(s, c) (Rot2.h:186-188).  h = a^-1 b with
+//   a^-1 = (R_a^T, R_a^T (-t_a))                       Pose2.cpp:201-203
+//   p q  = (R_p R_q, t_p + R_p t_q)                    Pose2.h:131-133
+// returned as (x, y, c, s).
+GT_HD void rot2_normalize(double& c, double& s) {
+  double scale = c * c + s * s;
+  if (fabs(scale - 1.0) > 1e-10) { scale = 1.0 / sqrt(scale); c *= scale; s *= scale; }
+}
+GT_HD void pose2_between_cs(double xa, double ya, double ca, double sa, double xb, double yb, double cb, double sb,
+                            double* h) {
+  // inverse of a: rotation (ca, -sa), translation unrotate(-t_a)
+  const double ix = ca * (-xa) + sa * (-ya), iy = -sa * (-xa) + ca * (-ya);
+  double c = ca * cb - (-sa) * sb, s = (-sa) * cb + ca * sb;
+  rot2_normalize(c, s);
+  h[0] = ix + (ca * xb + sa * yb);        // t_inv + R_inv t_b   (Rot2::rotate with (c, s) = (ca, -sa), Rot2.cpp:100-106)
+  h[1] = iy + (-sa * xb + ca * yb);
+  h[2] = c; h[3] = s;
+}
+// Local(a, b) = ChartAtOrigin::Local(between(a, b)) = (x, y, theta) of a^-1 b  (Lie.h:136-138, Pose2.cpp:111-121,
+// GTSAM_SLOW_BUT_CORRECT_EXPMAP off)
+GT_HD void pose2_local(const double* a, const double* b, double* d) {
+  double h[4];
+  pose2_between_cs(a[0], a[1], cos(a[2]), sin(a[2]), b[0], b[1], cos(b[2]), sin(b[2]), h);
+  d[0] = h[0]; d[1] = h[1]; d[2] = atan2(h[3], h[2]);
+}
+// Retract(a, v) = a * Pose2(v0, v1, v2)  (Lie.h:131-133, Pose2.cpp:99-109)
+GT_HD void pose2_retract(const double* a, const double* v, double* y) {
+  const double ca = cos(a[2]), sa = sin(a[2]), cv = cos(v[2]), sv = sin(v[2]);
+  double c = ca * cv - sa * sv, s = sa * cv + ca * sv;
+  rot2_normalize(c, s);
+  y[0] = a[0] + (ca * v[0] + -sa * v[1]);
+  y[1] = a[1] + (sa * v[0] + ca * v[1]);
+  y[2] = atan2(s, c);
+}
+
 // traits<T>::Local(x, z) for the supported value types (PriorFactor.h:98-102):
 // Pose3 Logmap(between); PinholeCamera [pose local; calib diff] (PinholeCamera.h:208-213,
-// Cal3Bundler.h:150-152); Point3 z - x.   vtype: 0 POSE3, 1 SFM_CAMERA, 2 POINT3.
+// Cal3Bundler.h:150-152); Point3 z - x; Pose2 above.   vtype: 0 POSE3, 1 SFM_CAMERA, 2 POINT3, 3 POSE2.
 GT_HD void value_local(int vtype, const double* x, const double* z, double* d) {
   if (vtype == 2) { d[0] = z[0] - x[0]; d[1] = z[1] - x[1]; d[2] = z[2] - x[2]; return; }
+  if (vtype == 3) { pose2_local(x, z, d); return; }
   pose_local(x, z, d);
   if (vtype == 1) { d[6] = z[12] - x[12]; d[7] = z[13] - x[13]; d[8] = z[14] - x[14]; }
 }
 // traits<T>::Retract(x, d): Pose3 (Lie.h:131-133), PinholeCamera::retract (PinholeCamera.h:199-205)
-// with Cal3Bundler::retract (Cal3Bundler.h:145-147), Point3 x + d.
+// with Cal3Bundler::retract (Cal3Bundler.h:145-147), Point3 x + d, Pose2 above.
 GT_HD void value_retract(int vtype, const double* x, const double* d, double* y) {
   if (vtype == 2) { y[0] = x[0] + d[0]; y[1] = x[1] + d[1]; y[2] = x[2] + d[2]; return; }
+  if (vtype == 3) { pose2_retract(x, d, y); return; }
   pose_retract(x, d, y);
   if (vtype == 1) { y[12] = x[12] + d[6]; y[13] = x[13] + d[7]; y[14] = x[14] + d[8]; y[15] = x[15]; y[16] = x[16]; }
 }

@@ -25,6 +25,7 @@ void launch_scatter_delta(gtg_context& c);       // delta (variable id order) fr
 void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t s);
 // In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
+void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan);
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag);
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);

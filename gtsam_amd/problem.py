@@ -13,13 +13,13 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-VAR_POSE3, VAR_SFM_CAMERA, VAR_POINT3 = 0, 1, 2
+VAR_POSE3, VAR_SFM_CAMERA, VAR_POINT3, VAR_POSE2 = 0, 1, 2, 3
 FAC_GENERAL_SFM, FAC_PROJECTION, FAC_BETWEEN_POSE3, FAC_PRIOR = 0, 1, 2, 3
 NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN = 0, 1, 2, 3
 ROBUST_NONE, ROBUST_FAIR, ROBUST_HUBER, ROBUST_CAUCHY, ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE = range(7)
 
-STORAGE = {VAR_POSE3: 12, VAR_SFM_CAMERA: 17, VAR_POINT3: 3}
-TANGENT = {VAR_POSE3: 6, VAR_SFM_CAMERA: 9, VAR_POINT3: 3}
+STORAGE = {VAR_POSE3: 12, VAR_SFM_CAMERA: 17, VAR_POINT3: 3, VAR_POSE2: 3}    # Pose2 = (x, y, theta)
+TANGENT = {VAR_POSE3: 6, VAR_SFM_CAMERA: 9, VAR_POINT3: 3, VAR_POSE2: 3}
 
 
 class gtg_problem(C.Structure):
@@ -228,6 +228,31 @@ def pose_graph_problem(n_poses, v1, v2, z12, noise_kind, noise_params):
         key = (kind, noise_params[k, :n].tobytes())
         if key not in table:
             table[key] = p.add_noise(kind, 6, noise_params[k, :n])
+        idx[k] = table[key]
+    p.between_noise = idx
+    return p
+
+
+def pose2_graph_problem(n_poses, v1, v2, z3, noise_kind, noise_params):
+    """Pose2 pose graph: BetweenFactor<Pose2> per edge (slam/dataset.cpp load2D).  z3 = (x, y, theta) per edge;
+    noise_kind[k], noise_params[k] (9 doubles: sigma | sigmas[3] | R 3x3 row-major).  On the C ABI a Pose2 between factor
+    uses the BetweenFactor table with its measurement in the first 3 of the 12 doubles (the factor's type follows
+    from its variables' type)."""
+    p = Problem(var_type=np.full(n_poses, VAR_POSE2, np.int32))
+    p.between_v1 = _a(v1, np.int32)
+    p.between_v2 = _a(v2, np.int32)
+    z = np.zeros((p.between_v1.size, 12))
+    z[:, :3] = np.asarray(z3, np.float64).reshape(-1, 3)
+    p.between_z = _a(z, np.float64)
+    noise_params = np.asarray(noise_params, np.float64).reshape(-1, 9)
+    table = {}
+    idx = np.zeros(p.between_v1.size, np.int32)
+    for k in range(p.between_v1.size):
+        kind = int(noise_kind[k])
+        n = {NOISE_UNIT: 0, NOISE_ISOTROPIC: 1, NOISE_DIAGONAL: 3, NOISE_GAUSSIAN: 9}[kind]
+        key = (kind, noise_params[k, :n].tobytes())
+        if key not in table:
+            table[key] = p.add_noise(kind, 3, noise_params[k, :n])
         idx[k] = table[key]
     p.between_noise = idx
     return p

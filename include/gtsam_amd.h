@@ -36,7 +36,7 @@ enum { GTG_OK = 0, GTG_INDETERMINATE = 1, GTG_ERR_USAGE = -1, GTG_ERR_HIP = -2,
  *   SFM_CAMERA gtsam::PinholeCamera<Cal3Bundler> (geometry/PinholeCamera.h, Cal3Bundler.h):
  *              17 doubles = pose (12) then f,k1,k2,u0,v0; tangent 9 = [pose(6); f,k1,k2]
  *   POINT3     gtsam::Point3: 3 doubles; tangent 3                                              */
-enum { GTG_VAR_POSE3 = 0, GTG_VAR_SFM_CAMERA = 1, GTG_VAR_POINT3 = 2 };
+enum { GTG_VAR_POSE3 = 0, GTG_VAR_SFM_CAMERA = 1, GTG_VAR_POINT3 = 2, GTG_VAR_POSE2 = 3 };
 
 /* Factor types on the path. */
 enum { GTG_FAC_GENERAL_SFM = 0,   /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  slam/GeneralSFMFactor.h:127-177 */

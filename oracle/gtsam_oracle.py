@@ -26,7 +26,7 @@ from gtsam_amd.problem import (FAC_BETWEEN_POSE3, FAC_GENERAL_SFM, FAC_PRIOR, FA
                                NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT,
                                ROBUST_CAUCHY, ROBUST_FAIR, ROBUST_GEMANMCCLURE, ROBUST_HUBER, ROBUST_NONE,
                                ROBUST_TUKEY, ROBUST_WELSCH,
-                               STORAGE, TANGENT, VAR_POINT3, VAR_POSE3, VAR_SFM_CAMERA, Problem)
+                               STORAGE, TANGENT, VAR_POINT3, VAR_POSE2, VAR_POSE3, VAR_SFM_CAMERA, Problem)
 
 EPS = np.finfo(np.float64).eps
 
@@ -227,6 +227,40 @@ def s2_project(R, t, K5, pw):
 
 
 # ------------------------------------------------------------------------------------------------
+# Pose2   (geometry/Pose2.{h,cpp}, Rot2.{h,cpp}); values are (x, y, theta), the reference keeps (c, s)
+# ------------------------------------------------------------------------------------------------
+def _rot2_normalize(c, s):
+    """Rot2::normalize (Rot2.cpp:56-64): only when |c^2+s^2-1| > 1e-10."""
+    scale = c * c + s * s
+    bad = np.abs(scale - 1.0) > 1e-10
+    k = np.where(bad, 1.0 / np.sqrt(np.where(bad, scale, 1.0)), 1.0)
+    return c * k, s * k
+
+
+def pose2_between_cs(xa, ya, ca, sa, xb, yb, cb, sb):
+    """a^-1 b as (x, y, c, s): inverse (Pose2.cpp:201-203), compose (Pose2.h:131-133), Rot2 product through
+    fromCosSin (Rot2.h:116-118), rotate / unrotate (Rot2.cpp:100-116)."""
+    ix = ca * (-xa) + sa * (-ya); iy = -sa * (-xa) + ca * (-ya)
+    c, s = _rot2_normalize(ca * cb - (-sa) * sb, (-sa) * cb + ca * sb)
+    return ix + (ca * xb + sa * yb), iy + (-sa * xb + ca * yb), c, s
+
+
+def pose2_local(a, b):
+    """traits<Pose2>::Local(a, b) = ChartAtOrigin::Local(between(a, b)) = (x, y, theta) (Lie.h:136-138,
+    Pose2.cpp:111-121 with GTSAM_SLOW_BUT_CORRECT_EXPMAP off)."""
+    x, y, c, s = pose2_between_cs(a[:, 0], a[:, 1], np.cos(a[:, 2]), np.sin(a[:, 2]),
+                                  b[:, 0], b[:, 1], np.cos(b[:, 2]), np.sin(b[:, 2]))
+    return np.stack([x, y, np.arctan2(s, c)], 1)
+
+
+def pose2_retract(a, v):
+    """a * Pose2(v0, v1, v2) (Lie.h:131-133, Pose2.cpp:99-109)."""
+    ca, sa = np.cos(a[:, 2]), np.sin(a[:, 2]); cv, sv = np.cos(v[:, 2]), np.sin(v[:, 2])
+    c, s = _rot2_normalize(ca * cv - sa * sv, sa * cv + ca * sv)
+    return np.stack([a[:, 0] + (ca * v[:, 0] + -sa * v[:, 1]), a[:, 1] + (sa * v[:, 0] + ca * v[:, 1]), np.arctan2(s, c)], 1)
+
+
+# ------------------------------------------------------------------------------------------------
 # noise models   (linear/NoiseModel.cpp)
 # ------------------------------------------------------------------------------------------------
 def noise_sqrt_info(p: Problem, idx: int):
@@ -398,7 +432,28 @@ def _linearize_whitened(p: Problem, values):
         err[behind] = (2.0 * K5[behind, 0])[:, None]
         Dpose, Dpt, b = _whiten_many(p, p.proj_noise, Dpose, Dpt, -err)
         out[FAC_PROJECTION] = (Dpose, Dpt, b)
-    if p.n_between:
+    if p.n_between and np.all(p.var_type[p.between_v1] == VAR_POSE2):
+        # BetweenFactor<Pose2>: generic LieGroup::between (Lie.h:63-69), H1 = -Ad(h^-1) (Pose2.cpp:126-135), H2 = I,
+        # r = Local(z, h); measurement = first 3 of the factor's 12 doubles
+        a = _gather(values, off, p.between_v1, 3); b2 = _gather(values, off, p.between_v2, 3)
+        z = p.between_z.reshape(-1, 12)[:, :3]
+        hx, hy, hc, hs = pose2_between_cs(a[:, 0], a[:, 1], np.cos(a[:, 2]), np.sin(a[:, 2]),
+                                          b2[:, 0], b2[:, 1], np.cos(b2[:, 2]), np.sin(b2[:, 2]))
+        gx, gy, gc, gs = pose2_between_cs(z[:, 0], z[:, 1], np.cos(z[:, 2]), np.sin(z[:, 2]), hx, hy, hc, hs)
+        err = np.stack([gx, gy, np.arctan2(gs, gc)], 1)
+        ic, isn = hc, -hs                                           # h^-1
+        ixx = hc * (-hx) + hs * (-hy); iyy = -hs * (-hx) + hc * (-hy)
+        n = a.shape[0]
+        H1 = np.zeros((n, 3, 3))
+        H1[:, 0, 0] = -ic; H1[:, 0, 1] = isn; H1[:, 0, 2] = -iyy
+        H1[:, 1, 0] = -isn; H1[:, 1, 1] = -ic; H1[:, 1, 2] = ixx
+        H1[:, 2, 2] = -1.0
+        H2 = np.broadcast_to(np.eye(3), H1.shape).copy()
+        H1, H2, b = _whiten_many(p, p.between_noise, H1, H2, -err)
+        out[FAC_BETWEEN_POSE3] = (H1, H2, b)
+    elif p.n_between:
+        if np.any(p.var_type[p.between_v1] == VAR_POSE2):
+            raise NotImplementedError("oracle: a graph mixing BetweenFactor<Pose2> and <Pose3>")
         R1, t1 = pose_unpack(_gather(values, off, p.between_v1, 12))
         R2, t2 = pose_unpack(_gather(values, off, p.between_v2, 12))
         hR, ht = pose_compose(*pose_inverse(R1, t1), R2, t2)     # Lie.h:63-69 between
@@ -426,6 +481,8 @@ def local_coordinates(vtype, x, z):
     (PinholeCamera.h:208-213, Cal3Bundler.h:150-152); Point3 z - x."""
     if vtype == VAR_POSE3:
         return pose_local(x[None, :12], z[None, :12])[0]
+    if vtype == VAR_POSE2:
+        return pose2_local(x[None, :3], z[None, :3])[0]
     if vtype == VAR_SFM_CAMERA:
         return np.concatenate([pose_local(x[None, :12], z[None, :12])[0], z[12:15] - x[12:15]])
     return z - x
@@ -445,6 +502,10 @@ def jacobians_flat(p: Problem, values, ftype):
         return out
     A1, A2, b = lin[ftype]
     n = A1.shape[0]
+    if ftype == FAC_BETWEEN_POSE3 and A1.shape[1] == 3:     # Pose2: 3x3 blocks inside the 78-double between record
+        out = np.zeros((n, 78))
+        out[:, 0:9] = A1.reshape(n, -1); out[:, 36:45] = A2.reshape(n, -1); out[:, 72:75] = b
+        return out
     return np.concatenate([A1.reshape(n, -1), A2.reshape(n, -1), b], 1)
 
 
@@ -617,13 +678,15 @@ def retract(p: Problem, values, delta):
     Cal3Bundler::retract (PinholeCamera.h:199-205, Cal3Bundler.h:145-147); Point3 p + d."""
     values = np.asarray(values, np.float64); out = values.copy()
     off = p.val_offsets(); doff = p.dim_offsets()
-    for t, st, dm in ((VAR_POSE3, 12, 6), (VAR_SFM_CAMERA, 17, 9), (VAR_POINT3, 3, 3)):
+    for t, st, dm in ((VAR_POSE3, 12, 6), (VAR_SFM_CAMERA, 17, 9), (VAR_POINT3, 3, 3), (VAR_POSE2, 3, 3)):
         ids = np.where(p.var_type == t)[0]
         if not ids.size:
             continue
         x = _gather(values, off, ids, st); d = _gather(delta, doff, ids, dm)
         if t == VAR_POINT3:
             y = x + d
+        elif t == VAR_POSE2:
+            y = pose2_retract(x, d)
         else:
             y = x.copy(); y[:, :12] = pose_retract(x[:, :12], d[:, :6])
             if t == VAR_SFM_CAMERA:

@@ -157,6 +157,17 @@ def load_g2o3d(path):
     return dict(v1=v1, v2=v2, z=z, noise_kind=nk, noise=nd, vertex_keys=vk, vertex_poses=vp)
 
 
+def load_2d(path):
+    """load2D(path) (slam/dataset.cpp:208-330) -> dict of arrays (Pose2 graph)."""
+    nb, nv = C.c_int64(), C.c_int64()
+    lib().ref_load_2d(path.encode(), C.byref(nb), C.byref(nv))
+    v1 = np.zeros(nb.value, np.int64); v2 = np.zeros(nb.value, np.int64)
+    z = np.zeros((nb.value, 3)); nk = np.zeros(nb.value, np.int32); nd = np.zeros((nb.value, 9))
+    vk = np.zeros(nv.value, np.int64); vp = np.zeros((nv.value, 3))
+    lib().ref_2d_fill(_p(v1), _p(v2), _p(z), _p(nk), _p(nd), _p(vk), _p(vp))
+    return dict(v1=v1, v2=v2, z=z, noise_kind=nk, noise=nd, vertex_keys=vk, vertex_poses=vp)
+
+
 def cholesky_partial(ABC, n_frontal):
     A = np.ascontiguousarray(ABC, np.float64).copy()
     ok = lib().ref_cholesky_partial(_p(A), C.c_int(A.shape[0]), C.c_int(n_frontal))

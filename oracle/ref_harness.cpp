@@ -20,6 +20,7 @@
 #include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/geometry/Point3.h>
+#include <gtsam/geometry/Pose2.h>
 #include <gtsam/geometry/Pose3.h>
 #include <gtsam/inference/Ordering.h>
 #include <gtsam/linear/GaussianFactorGraph.h>
@@ -71,7 +72,7 @@ void packCamera(const Camera& c, double* p) {
   p[15] = c.calibration().px(); p[16] = c.calibration().py();
 }
 int storageSize(int t) { return t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3; }
-int tangentDim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }
+int tangentDim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3; }   // POINT3, POSE2: 3
 
 struct RefGraph {
   int n_vars = 0;
@@ -87,6 +88,7 @@ struct RefGraph {
       const double* p = v + val_off[i];
       if (var_type[i] == GTG_VAR_POSE3) vals.insert(Key(i), unpackPose(p));
       else if (var_type[i] == GTG_VAR_SFM_CAMERA) vals.insert(Key(i), unpackCamera(p));
+      else if (var_type[i] == GTG_VAR_POSE2) vals.insert(Key(i), Pose2(p[0], p[1], p[2]));
       else vals.insert(Key(i), Point3(p[0], p[1], p[2]));
     }
     return vals;
@@ -96,6 +98,7 @@ struct RefGraph {
       double* p = v + val_off[i];
       if (var_type[i] == GTG_VAR_POSE3) packPose(vals.at<Pose3>(Key(i)), p);
       else if (var_type[i] == GTG_VAR_SFM_CAMERA) packCamera(vals.at<Camera>(Key(i)), p);
+      else if (var_type[i] == GTG_VAR_POSE2) { const Pose2 q = vals.at<Pose2>(Key(i)); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
       else { const Point3 q = vals.at<Point3>(Key(i)); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
     }
   }
@@ -191,10 +194,16 @@ void* ref_graph_create(const gtg_problem* p) {
                                          Key(p->proj_point[i]), calibs[p->proj_calib[i]], sensor);
   }
   g->end[1] = g->beg[2] = g->graph.size();
-  for (int64_t i = 0; i < p->n_between; i++)
-    g->graph.emplace_shared<BetweenFactor<Pose3>>(Key(p->between_v1[i]), Key(p->between_v2[i]),
-                                                   unpackPose(p->between_z + 12 * i),
-                                                   noise[p->between_noise[i]]);
+  for (int64_t i = 0; i < p->n_between; i++) {
+    if (p->var_type[p->between_v1[i]] == GTG_VAR_POSE2) {   // measurement = first 3 of the 12 doubles
+      const double* z = p->between_z + 12 * i;
+      g->graph.emplace_shared<BetweenFactor<Pose2>>(Key(p->between_v1[i]), Key(p->between_v2[i]), Pose2(z[0], z[1], z[2]),
+                                                     noise[p->between_noise[i]]);
+    } else {
+      g->graph.emplace_shared<BetweenFactor<Pose3>>(Key(p->between_v1[i]), Key(p->between_v2[i]),
+                                                     unpackPose(p->between_z + 12 * i), noise[p->between_noise[i]]);
+    }
+  }
   g->end[2] = g->beg[3] = g->graph.size();
   for (int64_t i = 0; i < p->n_prior; i++) {
     const int v = p->prior_var[i];
@@ -202,6 +211,7 @@ void* ref_graph_create(const gtg_problem* p) {
     const SharedNoiseModel& nm = noise[p->prior_noise[i]];
     if (p->var_type[v] == GTG_VAR_POSE3) g->graph.addPrior(Key(v), unpackPose(d), nm);
     else if (p->var_type[v] == GTG_VAR_SFM_CAMERA) g->graph.addPrior(Key(v), unpackCamera(d), nm);
+    else if (p->var_type[v] == GTG_VAR_POSE2) g->graph.addPrior(Key(v), Pose2(d[0], d[1], d[2]), nm);
     else g->graph.addPrior(Key(v), Point3(d[0], d[1], d[2]), nm);
   }
   g->end[3] = g->graph.size();
@@ -234,6 +244,18 @@ int ref_graph_jacobians(void* h, const double* values, int type, double* out, in
       for (int r = 0; r < d; r++) for (int c = 0; c < d; c++) out[pos + r * d + c] = A(r, c);
       for (int r = 0; r < d; r++) out[pos + 81 + r] = b(r);
       pos += 90;
+    } else if (type == GTG_FAC_BETWEEN_POSE3 && jf->getA(jf->begin()).rows() == 3) {
+      // BetweenFactor<Pose2>: 3x3 blocks inside the 78-double between record (A1 at 0, A2 at 36, b at 72)
+      if (pos + 78 > n_out) return -2;
+      std::fill(out + pos, out + pos + 78, 0.0);
+      int blk = 0;
+      for (auto it = jf->begin(); it != jf->end(); ++it, ++blk) {
+        const Matrix A = jf->getA(it);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[pos + 36 * blk + 3 * r + c] = A(r, c);
+      }
+      const Vector b = jf->getb();
+      for (int r = 0; r < 3; r++) out[pos + 72 + r] = b(r);
+      pos += 78;
     } else {
       for (auto it = jf->begin(); it != jf->end(); ++it) {
         const Matrix A = jf->getA(it);
@@ -460,6 +482,45 @@ int ref_g2o3d_fill(int64_t* v1, int64_t* v2, double* z12, int32_t* noise_kind, d
   for (const auto& kv : *g_pg_init) {
     vertex_keys[i] = (int64_t)kv.key;
     packPose(kv.value.cast<Pose3>(), vertex_poses12 + 12 * i);
+    i++;
+  }
+  return 0;
+}
+
+// 2D pose graph via load2D (slam/dataset.cpp:208-330: VERTEX2 / VERTEX_SE2, EDGE2 / EDGE_SE2 / ODOMETRY).
+static NonlinearFactorGraph::shared_ptr g_pg2;
+static Values::shared_ptr g_pg2_init;
+int ref_load_2d(const char* path, int64_t* n_between, int64_t* n_vertices) {
+  auto gv = load2D(path);
+  g_pg2 = gv.first; g_pg2_init = gv.second;
+  int64_t nb = 0;
+  for (const auto& f : *g_pg2) if (std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f)) nb++;
+  *n_between = nb; *n_vertices = g_pg2_init->size();
+  return 0;
+}
+// noise out: kind per factor + 9 doubles (sigma / sigmas / R row-major)
+int ref_2d_fill(int64_t* v1, int64_t* v2, double* z3, int32_t* noise_kind, double* noise9, int64_t* vertex_keys,
+                double* vertex_poses3) {
+  int64_t k = 0;
+  for (const auto& f : *g_pg2) {
+    auto bf = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f);
+    if (!bf) continue;
+    v1[k] = (int64_t)bf->key1(); v2[k] = (int64_t)bf->key2();
+    z3[3 * k] = bf->measured().x(); z3[3 * k + 1] = bf->measured().y(); z3[3 * k + 2] = bf->measured().theta();
+    double* nd = noise9 + 9 * k;
+    std::fill(nd, nd + 9, 0.0);
+    auto nm = bf->noiseModel();
+    if (nm->isUnit()) noise_kind[k] = GTG_NOISE_UNIT;
+    else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { noise_kind[k] = GTG_NOISE_ISOTROPIC; nd[0] = iso->sigma(); }
+    else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { noise_kind[k] = GTG_NOISE_DIAGONAL; for (int i = 0; i < 3; i++) nd[i] = dg->sigma(i); }
+    else { auto ga = std::dynamic_pointer_cast<noiseModel::Gaussian>(nm); noise_kind[k] = GTG_NOISE_GAUSSIAN; const Matrix R = ga->R(); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) nd[3 * i + j] = R(i, j); }
+    k++;
+  }
+  int64_t i = 0;
+  for (const auto& kv : *g_pg2_init) {
+    vertex_keys[i] = (int64_t)kv.key;
+    const Pose2 q = kv.value.cast<Pose2>();
+    vertex_poses3[3 * i] = q.x(); vertex_poses3[3 * i + 1] = q.y(); vertex_poses3[3 * i + 2] = q.theta();
     i++;
   }
   return 0;

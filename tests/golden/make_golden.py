@@ -140,9 +140,40 @@ def robust():
         print(name, "init", out["error"], "final", r["trace"][-1], "outer", r["iterations"])
 
 
+def pose2():
+    """Pose2 pose graphs (BASELINE configs[0]: Pose2SLAMExample_g2o protocol, LM instead of GN): the reference's
+    shipped w100.graph and noisyToyGraph.txt in full, and w20000.txt (the substitute for the absent w10000, SURVEY.md
+    section 8(d) config 1; golden 32 626 834.02 -> 13 520 404.37, gives up at lambda max after 24 inner iterations)."""
+    from gtsam_amd.problem import pose2_graph_problem
+    for name, fn, full in (("pose2_w100", "w100.graph", True), ("pose2_toy", "noisyToyGraph.txt", True),
+                           ("pose2_w20000", "w20000.txt", False)):
+        d = ref.load_2d(DATA + fn)
+        n = int(max(d["v1"].max(), d["v2"].max())) + 1
+        p = pose2_graph_problem(n, d["v1"], d["v2"], d["z"], d["noise_kind"], d["noise"])
+        npri = p.add_noise(NOISE_DIAGONAL, 3, np.sqrt([1e-6, 1e-6, 1e-8]))          # Pose2SLAMExample_g2o.cpp:65-67
+        p.add_prior(0, np.zeros(3), npri)
+        v0 = np.zeros((n, 3)); v0[d["vertex_keys"]] = d["vertex_poses"]; v0 = v0.reshape(-1)
+        g = ref.RefGraph(p)
+        out = dict(v1=d["v1"].astype(np.int32), v2=d["v2"].astype(np.int32), z=d["z"], noise_kind=d["noise_kind"],
+                   noise=d["noise"], values0=v0)
+        if full:
+            out.update(probes(g, p, v0, ordering_kind=0))
+        else:
+            out["error"] = g.error(v0)
+            out["jac2_head"] = g.jacobians(v0, 2)[:512]
+        r = g.lm(v0, LMP(), ordering_kind=0)
+        out["trace"] = r["trace"][:, :3]; out["final_values"] = r["values"]; out["iterations"] = r["iterations"]
+        out["ref_seconds"] = r["seconds"]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "init", out["error"], "final", r["trace"][-1], "outer", r["iterations"])
+
+
 if __name__ == "__main__":
-    if "--robust-only" in sys.argv:
+    if "--pose2-only" in sys.argv:
+        pose2()
+    elif "--robust-only" in sys.argv:
         robust()
     else:
         main()
         robust()
+        pose2()

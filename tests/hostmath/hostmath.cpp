@@ -23,6 +23,12 @@ void hm_between_linearize(long n, const double* T1, const double* T2, const doub
 void hm_between_error(long n, const double* T1, const double* T2, const double* Z, int nk, const double* nd, double* e) {
   for (long i = 0; i < n; i++) e[i] = gt::between_error(T1 + 12 * i, T2 + 12 * i, Z + 12 * i, NR(nk, nd));
 }
+void hm_between2_linearize(long n, const double* p1, const double* p2, const double* z, int nk, const double* nd, double* J) {
+  for (long i = 0; i < n; i++) gt::between2_linearize(p1 + 3 * i, p2 + 3 * i, z + 3 * i, NR(nk, nd), J + gt::kBetweenRec * i);
+}
+void hm_between2_error(long n, const double* p1, const double* p2, const double* z, int nk, const double* nd, double* e) {
+  for (long i = 0; i < n; i++) e[i] = gt::between2_error(p1 + 3 * i, p2 + 3 * i, z + 3 * i, NR(nk, nd));
+}
 void hm_prior_linearize(int vtype, const double* x, const double* z, int nk, const double* nd, double* J) { gt::prior_linearize(vtype, x, z, NR(nk, nd), J); }
 double hm_prior_error(int vtype, const double* x, const double* z, int nk, const double* nd) { return gt::prior_error(vtype, x, z, NR(nk, nd)); }
 void hm_retract(int vtype, long n, const double* x, const double* d, double* y) {

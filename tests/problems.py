@@ -73,3 +73,14 @@ def robust_prior_literal():
     n = p.add_noise(NOISE_UNIT, 3, (), robust=(ROBUST_GEMANMCCLURE, 1.0))
     p.add_prior(0, np.zeros(3), n)
     return p, np.array([10.0, 0.0, 0.0])
+
+
+def pose2_graph(g):
+    """Pose2SLAMExample_g2o.cpp:46-67 protocol: BetweenFactor<Pose2> edges from load2D + prior Variances(1e-6, 1e-6, 1e-8)
+    on key 0."""
+    from gtsam_amd.problem import pose2_graph_problem
+    n = int(max(g["v1"].max(), g["v2"].max())) + 1
+    p = pose2_graph_problem(n, g["v1"], g["v2"], g["z"], g["noise_kind"], g["noise"])
+    npri = p.add_noise(NOISE_DIAGONAL, 3, np.sqrt([1e-6, 1e-6, 1e-8]))
+    p.add_prior(0, np.zeros(3), npri)
+    return p, g["values0"]

@@ -138,3 +138,30 @@ def test_m_estimators_reference_literals(hm):
             assert abs(hm.hm_robust_weight(C.c_int(rk), C.c_double(k), C.c_double(e)) - w) < 1e-8
             assert abs(hm.hm_robust_loss(C.c_int(rk), C.c_double(k), C.c_double(e)) - l) < 1e-8
             assert abs(float(O.robust_weight(rk, k, e)) - w) < 1e-8 and abs(float(O.robust_loss(rk, k, e)) - l) < 1e-8
+
+
+def test_pose2_between_prior_retract(hm):
+    """BetweenFactor<Pose2> / PriorFactor<Pose2> / Pose2 retract+local of the device code against the oracle (which is
+    pinned to the live reference: identical LM trajectories on w100.graph and noisyToyGraph.txt)."""
+    from gtsam_amd.problem import (NOISE_DIAGONAL, VAR_POSE2, pose2_graph_problem)
+    rng = np.random.default_rng(5); n = 300
+    poses = np.stack([rng.normal(0, 5, n), rng.normal(0, 5, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    v1 = rng.integers(0, n, 400); v2 = (v1 + rng.integers(1, n, 400)) % n
+    z = np.stack([rng.normal(0, 2, 400), rng.normal(0, 2, 400), rng.uniform(-np.pi, np.pi, 400)], 1)
+    sig = np.array([0.3, 0.5, 0.1])
+    p = pose2_graph_problem(n, v1, v2, z, np.full(400, NOISE_DIAGONAL), np.tile(np.concatenate([sig, np.zeros(6)]), (400, 1)))
+    v = poses.reshape(-1)
+    Jo = O.jacobians_flat(p, v, 2)
+    a = np.ascontiguousarray(poses[v1]); b = np.ascontiguousarray(poses[v2]); zc = np.ascontiguousarray(z)
+    inv = np.ascontiguousarray(1.0 / sig)
+    J = np.zeros((400, 78)); hm.hm_between2_linearize(C.c_long(400), P(a), P(b), P(zc), C.c_int(2), P(inv), P(J))
+    assert rel(J, Jo) <= 1e-13
+    e = np.zeros(400); hm.hm_between2_error(C.c_long(400), P(a), P(b), P(zc), C.c_int(2), P(inv), P(e))
+    assert abs(e.sum() - O.error(p, v)) <= 1e-12 * e.sum()
+    d = rng.normal(0, 0.4, (n, 3)); d[:, 2] = rng.uniform(-3.5, 3.5, n)
+    y = np.zeros((n, 3)); hm.hm_retract(C.c_int(3), C.c_long(n), P(poses), P(np.ascontiguousarray(d)), P(y))
+    assert rel(y, O.pose2_retract(poses, d)) <= 1e-14
+    back = np.zeros((n, 3)); hm.hm_local(C.c_int(3), C.c_long(n), P(poses), P(y), P(back))
+    assert rel(back, O.pose2_local(poses, y)) <= 1e-13
+    # local(retract(x, d)) = d up to the wrap of theta: Pose2's chart is first order, exact for this composition
+    assert np.allclose(np.angle(np.exp(1j * (back[:, 2] - d[:, 2]))), 0, atol=1e-12) and np.allclose(back[:, :2], d[:, :2], atol=1e-12)

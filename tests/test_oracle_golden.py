@@ -187,3 +187,21 @@ def test_oracle_vs_live_reference(live_ref):
         rc, d, le = g.solve(v0, 1e-3, False, ordering_kind=1 if p.n_proj else 0)
         st, d2, _, _, lin = O.solve_damped(p, v0, 1e-3, False)
         assert rc == st == 0 and rel(d2, d) <= 1e-8
+
+
+# ---- (3) Pose2 pose graphs: BASELINE configs[0] (Pose2SLAMExample_g2o protocol with LM) --------------------------------
+@pytest.mark.parametrize("name", ["pose2_w100", "pose2_toy"])
+def test_oracle_pose2_matches_reference_golden(name):
+    gold = dict(load_golden(name)); gold["values"] = gold["final_values"]
+    test_oracle_matches_reference_golden(name, PB.pose2_graph(gold), gold, LMP())
+
+
+def test_oracle_pose2_w20000_error_and_jacobians():
+    """w20000.txt (20 061 Pose2, 26 831 EDGE2): the substitute for the absent w10000.  The
+    reference's numbers: initial error 32 626 834.02, LM stops at 13 520 404.4 after 24 inner iterations at lambda max."""
+    g = load_golden("pose2_w20000")
+    p, v0 = PB.pose2_graph(g)
+    assert abs(float(g["error"]) - 32626834.02) < 0.01 and abs(g["trace"][-1, 1] - 13520404.4) < 0.1
+    assert int(g["trace"][-1, 0]) == 24 and g["trace"][-1, 2] == 1e5
+    assert abs(O.error(p, v0) - float(g["error"])) <= 1e-11 * float(g["error"])
+    assert rel(O.jacobians_flat(p, v0, 2)[:512], g["jac2_head"]) <= 1e-12

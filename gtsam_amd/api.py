@@ -18,7 +18,7 @@ import numpy as np
 
 from .optimizer import DeviceLevenbergMarquardt
 from .params import LevenbergMarquardtParams
-from .problem import (NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT, STORAGE, VAR_POINT3, VAR_POSE3,
+from .problem import (NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT, STORAGE, TANGENT, VAR_POINT3, VAR_POSE2, VAR_POSE3,
                       VAR_SFM_CAMERA, Problem)
 
 
@@ -59,6 +59,21 @@ class Pose3:
 
     @staticmethod
     def from_packed(p): return Pose3(Rot3(np.asarray(p[:9]).reshape(3, 3)), p[9:12])
+
+
+class Pose2:
+    """gtsam.Pose2(x, y, theta) (geometry/Pose2.h); packed as (x, y, theta)."""
+
+    def __init__(self, x=0.0, y=0.0, theta=0.0):
+        self.v = np.array([x, y, theta], np.float64)
+
+    def x(self): return self.v[0]
+    def y(self): return self.v[1]
+    def theta(self): return self.v[2]
+    def packed(self): return self.v.copy()
+
+    @staticmethod
+    def from_packed(p): return Pose2(p[0], p[1], p[2])
 
 
 class Cal3Bundler:
@@ -217,11 +232,17 @@ class BetweenFactorPose3:
         self.keys_, self.z, self.model = (key1, key2), measured, model
 
 
+class BetweenFactorPose2:
+    def __init__(self, key1, key2, measured: Pose2, model):
+        self.keys_, self.z, self.model = (key1, key2), measured, model
+
+
 class _Prior:
     def __init__(self, key, prior, model): self.keys_, self.prior, self.model = (key,), prior, model
 
 
 class PriorFactorPose3(_Prior): pass
+class PriorFactorPose2(_Prior): pass
 class PriorFactorPoint3(_Prior): pass
 class PriorFactorPinholeCameraCal3Bundler(_Prior): pass
 
@@ -254,6 +275,7 @@ class NonlinearFactorGraph:
     push_back = add
     def size(self): return len(self.factors)
     def addPriorPose3(self, key, prior, model): self.add(PriorFactorPose3(key, prior, model))
+    def addPriorPose2(self, key, prior, model): self.add(PriorFactorPose2(key, prior, model))
     def addPriorPoint3(self, key, prior, model): self.add(PriorFactorPoint3(key, prior, model))
     def addPriorPinholeCameraCal3Bundler(self, key, prior, model): self.add(PriorFactorPinholeCameraCal3Bundler(key, prior, model))
 
@@ -276,6 +298,7 @@ def extract(graph: NonlinearFactorGraph, values: Values):
     for k in keys:
         v = values.at(k)
         if isinstance(v, Pose3): vt.append(VAR_POSE3); packed.append(v.packed())
+        elif isinstance(v, Pose2): vt.append(VAR_POSE2); packed.append(v.packed())
         elif isinstance(v, PinholeCameraCal3Bundler): vt.append(VAR_SFM_CAMERA); packed.append(v.packed())
         elif isinstance(v, np.ndarray) and v.size == 3: vt.append(VAR_POINT3); packed.append(v.astype(np.float64))
         else:
@@ -311,12 +334,14 @@ def extract(graph: NonlinearFactorGraph, values: Values):
             proj.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z, nid(f.model, 2), calibs[ck][0], si))
         elif isinstance(f, BetweenFactorPose3):
             btw.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z.packed(), nid(f.model, 6)))
+        elif isinstance(f, BetweenFactorPose2):   # same table: the measurement sits in the first 3 of the 12 doubles
+            btw.append((vid(f.keys_[0]), vid(f.keys_[1]), np.concatenate([f.z.packed(), np.zeros(9)]), nid(f.model, 3)))
         elif isinstance(f, _Prior):
             v = vid(f.keys_[0]); t = vt[v]
             data = f.prior.packed() if hasattr(f.prior, "packed") else np.asarray(f.prior, np.float64)
             if data.size != STORAGE[t]:
                 raise ValueError("prior type does not match the variable")
-            p.add_prior(v, data, nid(f.model, {VAR_POSE3: 6, VAR_SFM_CAMERA: 9, VAR_POINT3: 3}[t]))
+            p.add_prior(v, data, nid(f.model, TANGENT[t]))
         else:
             raise ValueError(f"factor type outside the GPU hot path: {type(f).__name__}")
     if sfm:
@@ -360,6 +385,6 @@ class LevenbergMarquardtOptimizer:
         for i, k in enumerate(self._keys):
             seg = packed[off[i]:off[i + 1]]
             proto = self._types[i]
-            out.insert(k, Pose3.from_packed(seg) if isinstance(proto, Pose3)
+            out.insert(k, Pose3.from_packed(seg) if isinstance(proto, Pose3) else Pose2.from_packed(seg) if isinstance(proto, Pose2)
                        else PinholeCameraCal3Bundler.from_packed(seg) if isinstance(proto, PinholeCameraCal3Bundler) else seg.copy())
         return out

@@ -5,6 +5,7 @@
 #include <gtsam/geometry/Cal3Bundler.h>
 #include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/geometry/Pose2.h>
 #include <gtsam/geometry/Pose3.h>
 #include <gtsam/linear/NoiseModel.h>
 #include <gtsam/nonlinear/PriorFactor.h>
@@ -132,6 +133,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
     if (dynamic_cast<const GenericValue<Pose3>*>(&kv.value)) t = GTG_VAR_POSE3;
     else if (dynamic_cast<const GenericValue<SfmCamera>*>(&kv.value)) t = GTG_VAR_SFM_CAMERA;
     else if (dynamic_cast<const GenericValue<Point3>*>(&kv.value)) t = GTG_VAR_POINT3;
+    else if (dynamic_cast<const GenericValue<Pose2>*>(&kv.value)) t = GTG_VAR_POSE2;
     else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported value type for key " + DefaultKeyFormatter(kv.key));
     m.id[kv.key] = (int32_t)m.keys.size();
     m.keys.push_back(kv.key); m.var_type.push_back(t);
@@ -142,6 +144,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
     double* p = m.packed.data() + m.val_off[v];
     if (m.var_type[v] == GTG_VAR_POSE3) packPose(initial.at<Pose3>(m.keys[v]), p);
     else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) packCamera(initial.at<SfmCamera>(m.keys[v]), p);
+    else if (m.var_type[v] == GTG_VAR_POSE2) { const Pose2 q = initial.at<Pose2>(m.keys[v]); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
     else { const Point3 q = initial.at<Point3>(m.keys[v]); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
   }
   auto idOf = [&](Key k) { auto it = m.id.find(k); if (it == m.id.end()) throw ValuesKeyDoesNotExist("GpuLevenbergMarquardtOptimizer", k); return it->second; };
@@ -176,6 +179,16 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
       bt_1.push_back(idOf(b->key1())); bt_2.push_back(idOf(b->key2()));
       bt_z.resize(bt_z.size() + 12); packPose(b->measured(), bt_z.data() + bt_z.size() - 12);
       bt_nz.push_back(nt.add(b->noiseModel(), 6));
+    } else if (auto b2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f)) {
+      // same table as BetweenFactor<Pose3>: the factor's type follows from its variables', (x, y, theta) in the first 3 doubles
+      bt_1.push_back(idOf(b2->key1())); bt_2.push_back(idOf(b2->key2()));
+      const Pose2& z = b2->measured();
+      bt_z.insert(bt_z.end(), {z.x(), z.y(), z.theta(), 0, 0, 0, 0, 0, 0, 0, 0, 0});
+      bt_nz.push_back(nt.add(b2->noiseModel(), 3));
+    } else if (auto q2 = std::dynamic_pointer_cast<PriorFactor<Pose2>>(f)) {
+      pr_var.push_back(idOf(q2->key())); pr_off.push_back((int64_t)pr_data.size());
+      pr_data.insert(pr_data.end(), {q2->prior().x(), q2->prior().y(), q2->prior().theta()});
+      pr_nz.push_back(nt.add(q2->noiseModel(), 3));
     } else if (auto pp = std::dynamic_pointer_cast<PriorFactor<Pose3>>(f)) {
       pr_var.push_back(idOf(pp->key())); pr_off.push_back((int64_t)pr_data.size());
       pr_data.resize(pr_data.size() + 12); packPose(pp->prior(), pr_data.data() + pr_data.size() - 12);
@@ -191,7 +204,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
     } else {
       throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
                                   "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>, "
-                                  "BetweenFactor<Pose3>, PriorFactor<Pose3|SfmCamera|Point3>)");
+                                  "BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
     }
   }
   gtg_problem pb{};
@@ -222,6 +235,7 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
     const double* p = m.packed.data() + m.val_off[v];
     if (m.var_type[v] == GTG_VAR_POSE3) vals.insert(m.keys[v], unpackPose(p));
     else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) vals.insert(m.keys[v], SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16])));
+    else if (m.var_type[v] == GTG_VAR_POSE2) vals.insert(m.keys[v], Pose2(p[0], p[1], p[2]));
     else vals.insert(m.keys[v], Point3(p[0], p[1], p[2]));
   }
   state_.reset(new State(std::move(vals), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));

@@ -123,3 +123,74 @@ def read_g2o3d(path):
     return dict(v1=np.array(v1, np.int64), v2=np.array(v2, np.int64), z=np.array(zs).reshape(-1, 12),
                 noise_kind=np.array(nk, np.int32), noise=np.array(nd).reshape(-1, 36),
                 vertex_keys=np.array(vk, np.int64)[order], vertex_poses=np.array(vp).reshape(-1, 12)[order])
+
+
+def _gaussian3_to_noise(M, covariance):
+    """noiseModel::Gaussian::{Information, Covariance}(M, smart=true) for a 3x3 matrix (linear/NoiseModel.cpp:83-131): a
+    diagonal matrix becomes Diagonal::Variances (-> Isotropic -> Unit when all equal / equal to 1), otherwise the upper
+    Cholesky factor R of the information matrix.  Returns (kind, 9 parameters: sigma | sigmas[3] | R row-major)."""
+    out = np.zeros(9)
+    if np.all(M == np.diag(np.diag(M))):
+        var = np.diag(M) if covariance else 1.0 / np.diag(M)
+        if np.all(var == var[0]):
+            if abs(var[0] - 1.0) < 1e-9:
+                return NOISE_UNIT, out
+            out[0] = np.sqrt(var[0])
+            return NOISE_ISOTROPIC, out
+        out[:3] = np.sqrt(var)
+        return NOISE_DIAGONAL, out
+    info = np.linalg.inv(M) if covariance else M
+    out[:] = np.linalg.cholesky(info).T.reshape(-1)
+    return NOISE_GAUSSIAN, out
+
+
+def read_2d(path):
+    """load2D (slam/dataset.cpp:179-330, defaults: maxIndex 0, smart noise, NoiseFormatAUTO, no kernel): VERTEX2 /
+    VERTEX_SE2 / VERTEX lines -> initial Pose2 (x, y, theta); EDGE2 / EDGE / EDGE_SE2 / ODOMETRY lines ->
+    BetweenFactor<Pose2> with the 6 noise numbers interpreted by their zero pattern (dataset.cpp:218-232): GRAPH order
+    (covariance, [v0 v1 v4; v1 v2 v5; v4 v5 v3]) or COV order (covariance, [v0 v1 v2; v1 v3 v4; v2 v4 v5]).
+    -> dict(v1, v2, z [n,3], noise_kind, noise [n,9], vertex_keys, vertex_poses [m,3])."""
+    import math
+    v1, v2, zs, nk, nd = [], [], [], [], []
+    poses = {}          # key -> (x, y, cos, sin): first pass = the VERTEX lines (dataset.cpp:511-522)
+    lines = [line.split() for line in open(path)]
+    for t in lines:
+        if t and t[0] in ("VERTEX2", "VERTEX_SE2", "VERTEX"):
+            poses.setdefault(int(t[1]), (float(t[2]), float(t[3]), math.cos(float(t[4])), math.sin(float(t[4]))))
+    for t in lines:
+        if not t:
+            continue
+        tag = t[0]
+        if tag in ("EDGE2", "EDGE", "EDGE_SE2", "ODOMETRY"):
+            v = [float(a) for a in t[6:12]]
+            if v[0] != 0 and v[1] == 0 and v[2] != 0 and v[3] != 0 and v[4] == 0 and v[5] == 0:
+                M = np.array([[v[0], v[1], v[4]], [v[1], v[2], v[5]], [v[4], v[5], v[3]]])          # NoiseFormatGRAPH
+            elif v[0] != 0 and v[1] == 0 and v[2] == 0 and v[3] != 0 and v[4] == 0 and v[5] != 0:
+                M = np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])          # NoiseFormatCOV
+            else:
+                raise ValueError("load2D: unrecognized covariance matrix format in dataset file")
+            kind, params = _gaussian3_to_noise(M, covariance=True)
+            k1, k2 = int(t[1]), int(t[2])
+            zx, zy, zt = float(t[3]), float(t[4]), float(t[5])
+            v1.append(k1); v2.append(k2); zs.append([zx, zy, zt])
+            nk.append(kind); nd.append(params)
+            # vertices a pure odometry file does not list: identity for key1, key1's pose * measurement for key2
+            # (dataset.cpp:541-546; Pose2 product: Rot2 through fromCosSin, Pose2.h:131-133)
+            if k1 not in poses:
+                poses[k1] = (0.0, 0.0, 1.0, 0.0)
+            if k2 not in poses:
+                x, y, c, s_ = poses[k1]
+                zc, zsn = math.cos(zt), math.sin(zt)
+                nc, ns = c * zc - s_ * zsn, s_ * zc + c * zsn
+                scale = nc * nc + ns * ns
+                if abs(scale - 1.0) > 1e-10:
+                    scale = 1.0 / math.sqrt(scale); nc *= scale; ns *= scale
+                poses[k2] = (x + (c * zx + -s_ * zy), y + (s_ * zx + c * zy), nc, ns)
+    # Pose2(x, y, yaw) keeps (cos, sin): theta() = atan2(sin yaw, cos yaw) is the file's angle wrapped into (-pi, pi]
+    zs = np.array(zs, np.float64).reshape(-1, 3); zs[:, 2] = np.arctan2(np.sin(zs[:, 2]), np.cos(zs[:, 2]))
+    vk = sorted(poses)                                                                        # Values iterate by key
+    vp = np.array([[poses[k][0], poses[k][1], math.atan2(poses[k][3], poses[k][2])] for k in vk], np.float64).reshape(-1, 3)
+    order = np.arange(len(vk))
+    return dict(v1=np.array(v1, np.int64), v2=np.array(v2, np.int64), z=zs,
+                noise_kind=np.array(nk, np.int32), noise=np.array(nd, np.float64).reshape(-1, 9),
+                vertex_keys=np.array(vk, np.int64)[order], vertex_poses=vp[order])

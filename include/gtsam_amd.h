@@ -35,13 +35,16 @@ enum { GTG_OK = 0, GTG_INDETERMINATE = 1, GTG_ERR_USAGE = -1, GTG_ERR_HIP = -2,
  *   POSE3      gtsam::Pose3 (geometry/Pose3.h): 12 doubles = R row-major (9) then t (3); tangent 6 = [omega; v]
  *   SFM_CAMERA gtsam::PinholeCamera<Cal3Bundler> (geometry/PinholeCamera.h, Cal3Bundler.h):
  *              17 doubles = pose (12) then f,k1,k2,u0,v0; tangent 9 = [pose(6); f,k1,k2]
- *   POINT3     gtsam::Point3: 3 doubles; tangent 3                                              */
+ *   POINT3     gtsam::Point3: 3 doubles; tangent 3
+ *   POSE2      gtsam::Pose2 (geometry/Pose2.h): 3 doubles = x, y, theta (theta() = atan2(s, c), wrapped); tangent 3,
+ *              retract = compose with Pose2(v0, v1, v2) (Pose2.cpp:99-109, GTSAM_SLOW_BUT_CORRECT_EXPMAP off)    */
 enum { GTG_VAR_POSE3 = 0, GTG_VAR_SFM_CAMERA = 1, GTG_VAR_POINT3 = 2, GTG_VAR_POSE2 = 3 };
 
 /* Factor types on the path. */
 enum { GTG_FAC_GENERAL_SFM = 0,   /* GeneralSFMFactor<PinholeCamera<Cal3Bundler>,Point3>  slam/GeneralSFMFactor.h:127-177 */
        GTG_FAC_PROJECTION = 1,    /* GenericProjectionFactor<Pose3,Point3,Cal3_S2>        slam/ProjectionFactor.h:138-166 */
-       GTG_FAC_BETWEEN_POSE3 = 2, /* BetweenFactor<Pose3>                                  slam/BetweenFactor.h:111-124 */
+       GTG_FAC_BETWEEN_POSE3 = 2, /* BetweenFactor<Pose3>, or BetweenFactor<Pose2> when its  slam/BetweenFactor.h:111-124
+                                     two variables are POSE2 (same table, see between_z)                                  */
        GTG_FAC_PRIOR = 3 };       /* PriorFactor<T>                                        nonlinear/PriorFactor.h:98-102 */
 
 /* Noise models (linear/NoiseModel.cpp).  whiten(v) is
@@ -97,8 +100,9 @@ typedef struct gtg_problem {
   int64_t n_between;             /* GTG_FAC_BETWEEN_POSE3 */
   const int32_t* between_v1;     /* [n_between] */
   const int32_t* between_v2;     /* [n_between] */
-  const double* between_z;       /* [n_between*12] measured relative pose */
-  const int32_t* between_noise;  /* [n_between] (dim 6) */
+  const double* between_z;       /* [n_between*12] measured relative pose (Pose3 packing; for a POSE2 pair x, y, theta
+                                    in the first 3 doubles of the factor's 12) */
+  const int32_t* between_noise;  /* [n_between] (dim 6, or 3 for a POSE2 pair) */
 
   int64_t n_prior;               /* GTG_FAC_PRIOR */
   const int32_t* prior_var;      /* [n_prior] */

@@ -7,6 +7,7 @@
 #include <GpuLevenbergMarquardtOptimizer.h>
 #include <gtsam/geometry/Cal3Bundler.h>
 #include <gtsam/geometry/PinholeCamera.h>
+#include <gtsam/geometry/Pose2.h>
 #include <gtsam/inference/Symbol.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/slam/BetweenFactor.h>
@@ -122,6 +123,24 @@ int main() {
     robust.emplace_shared<BetweenFactor<Pose3>>(X(2), X(30), Pose3(Rot3::RzRyRx(0.5, -0.4, 1.0), Point3(4, -3, 2)), rloop);   // gross outliers
     robust.emplace_shared<BetweenFactor<Pose3>>(X(7), X(21), Pose3(Rot3::RzRyRx(-1.0, 0.2, 0.3), Point3(-5, 1, 1)), rloop);
     compare("Pose3 graph robust (Huber + Cauchy)", robust, initial, LevenbergMarquardtParams(), 1e-6);
+  }
+  {  // ---- Pose2 pose graph, as examples/Pose2SLAMExample_g2o.cpp (with LM) on a Manhattan-like loop ----------------------
+    NonlinearFactorGraph graph; Values initial;
+    const int n = 60;
+    std::vector<Pose2> truth;
+    for (int i = 0; i < n; i++) truth.emplace_back(4 * std::cos(0.25 * i) + 0.05 * i, 4 * std::sin(0.25 * i), 0.25 * i + M_PI / 2);
+    auto odo = noiseModel::Diagonal::Sigmas(Vector3(0.05, 0.05, 0.02));
+    Matrix3 info = Matrix3::Identity() * 30; info(0, 1) = info(1, 0) = 3; info(2, 2) = 200;
+    auto loop = noiseModel::Gaussian::Information(info);
+    auto addEdge = [&](int a, int b, const SharedNoiseModel& nm) {
+      const Pose2 z = truth[a].between(truth[b]).retract(Vector3(0.03 * N(rng), 0.03 * N(rng), 0.01 * N(rng)));
+      graph.emplace_shared<BetweenFactor<Pose2>>(X(a), X(b), z, nm);
+    };
+    for (int i = 0; i + 1 < n; i++) addEdge(i, i + 1, odo);
+    for (int i = 0; i + 25 < n; i += 2) addEdge(i, i + 25, loop);
+    graph.addPrior(X(0), truth[0], noiseModel::Diagonal::Variances(Vector3(1e-6, 1e-6, 1e-8)));
+    for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract(Vector3(0.2 * N(rng), 0.2 * N(rng), 0.1 * N(rng))));
+    compare("Pose2 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
   }
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;

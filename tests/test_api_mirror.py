@@ -94,3 +94,32 @@ def test_general_sfm_factor_B_written_like_the_reference():
     assert abs(lm.error() - 0.0199833) < 1e-5 and abs(graph.error(actual) - lm.error()) < 1e-12
     assert lm.iterations() == int(g["default_iterations"])
     assert isinstance(actual.at(C(0)), api.PinholeCameraCal3Bundler) and actual.at(P(0)).shape == (3,)
+
+
+def test_pose2_slam_example_written_like_the_reference():
+    """examples/Pose2SLAMExample.cpp:60-105 built through the mirror; the extractor must give the same SoA problem as
+    the direct builder (gtsam_amd.problem.pose2_graph_problem)."""
+    from gtsam_amd.problem import VAR_POSE2, pose2_graph_problem
+    nm = api.noiseModel
+    graph = api.NonlinearFactorGraph()
+    graph.addPriorPose2(1, api.Pose2(0, 0, 0), nm.Diagonal.Sigmas([0.3, 0.3, 0.1]))
+    model = nm.Diagonal.Sigmas([0.2, 0.2, 0.1])
+    edges = [(1, 2, (2, 0, 0)), (2, 3, (2, 0, np.pi / 2)), (3, 4, (2, 0, np.pi / 2)), (4, 5, (2, 0, np.pi / 2)), (5, 2, (2, 0, np.pi / 2))]
+    for a, b, z in edges:
+        graph.add(api.BetweenFactorPose2(a, b, api.Pose2(*z), model))
+    initial = api.Values()
+    guess = [(0.5, 0.0, 0.2), (2.3, 0.1, -0.2), (4.1, 0.1, np.pi / 2), (4.0, 2.0, np.pi), (2.1, 2.1, -np.pi / 2)]
+    for k, g in enumerate(guess):
+        initial.insert(k + 1, api.Pose2(*g))
+    p, v0, keys = api.extract(graph, initial)
+    assert keys == [1, 2, 3, 4, 5] and list(p.var_type) == [VAR_POSE2] * 5 and np.allclose(v0, np.array(guess).reshape(-1))
+    q = pose2_graph_problem(5, [e[0] - 1 for e in edges], [e[1] - 1 for e in edges], [e[2] for e in edges],
+                            [NOISE_DIAGONAL] * 5, [[0.2, 0.2, 0.1, 0, 0, 0, 0, 0, 0]] * 5)
+    assert np.array_equal(p.between_v1, q.between_v1) and np.array_equal(p.between_z, q.between_z)
+    assert p.n_prior == 1 and list(p.noise_dim) == [3, 3]
+    from oracle import gtsam_oracle as O
+    from gtsam_amd.params import LevenbergMarquardtParams as LMP
+    r = O.lm_optimize(p, v0, LMP())
+    final = r["values"].reshape(5, 3)
+    # the example's known answer (Pose2SLAMExample.cpp output): a square with side 2
+    assert np.allclose(final[:, :2], [[0, 0], [2, 0], [4, 0], [4, 2], [2, 2]], atol=1e-3)

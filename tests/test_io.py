@@ -75,3 +75,35 @@ def test_bal_reader_on_a_written_file(tmp_path):
     u0 = np.float32(f"{obs[0][2]:.6e}"); v0 = np.float32(f"{obs[0][3]:.6e}")
     k = np.where((oc == obs[0][0]) & (op == obs[0][1]))[0][0]
     assert oz[k, 0] == float(u0) and oz[k, 1] == -float(v0)           # (u, -v)
+
+
+@pytest.mark.parametrize("fn,name", [("w100.graph", "pose2_w100"), ("noisyToyGraph.txt", "pose2_toy"), ("w20000.txt", "pose2_w20000")])
+def test_load2d_reader_matches_reference_loader(fn, name):
+    """io.read_2d against what the reference's load2D returned for its shipped 2-D files (golden fixtures)."""
+    path = DATA + fn
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    g = load_golden(name)
+    d = io.read_2d(path)
+    assert np.array_equal(d["v1"], g["v1"]) and np.array_equal(d["v2"], g["v2"])
+    assert np.array_equal(d["noise_kind"], g["noise_kind"])
+    assert np.abs(d["z"] - g["z"]).max() <= 1e-15 and np.abs(d["noise"] - g["noise"]).max() <= 1e-15
+    n = int(max(d["v1"].max(), d["v2"].max())) + 1
+    v0 = np.zeros((n, 3)); v0[d["vertex_keys"]] = d["vertex_poses"]
+    # w20000.txt has no VERTEX lines: load2D chains 20 060 measurements (dataset.cpp:541-546), values up to 700
+    assert np.abs(v0.reshape(-1) - g["values0"]).max() <= 1e-12 * max(1.0, np.abs(g["values0"]).max())
+
+
+def test_load2d_reader_g2o_order_on_a_written_file(tmp_path, live_ref):
+    """EDGE_SE2 with a full covariance in COV order (v0 v1 v2 v3 v4 v5 = upper triangle) and a TORO-order line."""
+    p = tmp_path / "tiny2d.g2o"
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0.1 0.2\nVERTEX_SE2 2 2 0.3 -0.1\n"
+                 "EDGE_SE2 0 1 1.0 0.1 0.2 4 0 0 5 0 6\nEDGE2 1 2 1.0 0.2 -0.3 2 0 3 7 0 0\n")
+    d = io.read_2d(str(p))
+    assert list(d["noise_kind"]) == [2, 2]
+    assert np.allclose(d["noise"][0, :3], np.sqrt([4, 5, 6])) and np.allclose(d["noise"][1, :3], np.sqrt([2, 3, 7]))
+    if live_ref is not None:
+        r = live_ref.load_2d(str(p))
+        for k in ("v1", "v2", "noise_kind", "vertex_keys"):
+            assert np.array_equal(d[k], r[k]), k
+        assert np.abs(d["noise"] - r["noise"]).max() <= 1e-15 and np.abs(d["z"] - r["z"]).max() <= 1e-15

@@ -6,6 +6,7 @@
 // try (inference/VariableIndex-inl.h:27-49, EliminationTree-inst.h:77-155, JunctionTree-inst.h:63-151,
 // linear/Scatter.cpp:39-73).  All arithmetic of the hot path runs in the HIP kernels.
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -260,6 +261,17 @@ static void analyze(gtg_context& c) {
   // The reference gets its elimination order from COLAMD (inference/Ordering.cpp:42-124) unless the user passes
   // one; here the order only decides where each camera/pose block sits in S.  A banded / loop-closing block
   // pattern then leaves most 128x128 tiles of the factor empty, and the tile schedule skips them.
+  // ---- ordering of the reduced variables + Cholesky schedule.  Default: RCM (one serial chain).  GTG_ND_DEPTH=n asks for
+  // n levels of nested dissection (independent chains, tree schedule in cholesky.hip): correct, but measured slower or
+  // equal on every workload of this round (sphere2500 5.3 -> 5.3..8.9 ms, w20000 21.8 -> 20.4..31.6 ms, L1723 +60 % flops),
+  // because a chain is issued at ~45 us of host time per column pair and the separators cost fill. ----
+  const char* nd_env = std::getenv("GTG_ND_DEPTH");
+  const bool nd_forced = nd_env != nullptr;
+  for (int attempt = 0; attempt < 2; attempt++) {
+  const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : 0) : 0;   // opt-in (GTG_ND_DEPTH=levels), see DESIGN.md
+  bool retry_rcm = false;
+  std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
+  std::vector<int32_t> part_parent;          // parent part (-1: root) of every part, parts numbered in elimination order
   if (hi.user_order.empty() && c.n_red_vars >= 16 && !std::getenv("GTG_NO_REORDER")) {
     const int nrv2 = c.n_red_vars;
     std::vector<std::vector<int32_t>> adj(nrv2);
@@ -267,36 +279,110 @@ static void analyze(gtg_context& c) {
     for (size_t i = 0; i < pair_row.size(); i++) edge(pair_row[i], pair_col[i]);
     for (size_t i = 0; i < hoff_row.size(); i++) edge(hoff_row[i], hoff_col[i]);
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-    std::vector<int32_t> order; order.reserve(nrv2);
     std::vector<int32_t> level(nrv2, -1);
-    std::vector<char> done(nrv2, 0);
-    auto bfs_far = [&](int start) {   // last node of a BFS from start (restricted to not-yet-ordered nodes)
-      std::vector<int32_t> q{start}; std::fill(level.begin(), level.end(), -1); level[start] = 0;
+    std::vector<char> active(nrv2, 0);     // node belongs to the subgraph being processed and is not ordered yet
+    auto bfs_levels = [&](int start, std::vector<int32_t>& q) {   // BFS over active nodes, fills level[], returns order
+      q.assign(1, start);
+      for (int32_t v = 0; v < nrv2; v++) level[v] = -1;
+      level[start] = 0;
       for (size_t h = 0; h < q.size(); h++)
-        for (int32_t w : adj[q[h]]) if (!done[w] && level[w] < 0) { level[w] = level[q[h]] + 1; q.push_back(w); }
+        for (int32_t w : adj[q[h]]) if (active[w] && level[w] < 0) { level[w] = level[q[h]] + 1; q.push_back(w); }
+    };
+    auto far_node = [&](int start) {
+      std::vector<int32_t> q; bfs_levels(start, q);
       int best = q.back();
       for (int32_t v : q) if (level[v] == level[q.back()] && adj[v].size() < adj[best].size()) best = v;
       return best;
     };
-    for (int seed = 0; seed < nrv2; seed++) {
-      if (done[seed]) continue;
-      int start = seed;
-      for (int v = seed; v < nrv2; v++) if (!done[v] && adj[v].size() < adj[start].size()) start = v;
-      // only nodes of seed's component matter; two sweeps towards a pseudo-peripheral node
-      start = bfs_far(bfs_far(seed));
-      std::vector<int32_t> q{start}; done[start] = 1;
-      for (size_t h = 0; h < q.size(); h++) {
-        std::vector<int32_t> nb;
-        for (int32_t w : adj[q[h]]) if (!done[w]) { done[w] = 1; nb.push_back(w); }
-        std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return adj[a].size() < adj[b].size() || (adj[a].size() == adj[b].size() && a < b); });
-        q.insert(q.end(), nb.begin(), nb.end());
+    // reverse Cuthill-McKee of a node set (all its components)
+    auto rcm = [&](const std::vector<int32_t>& nodes, std::vector<int32_t>& out) {
+      for (int32_t v : nodes) active[v] = 1;
+      std::vector<int32_t> ord; ord.reserve(nodes.size());
+      for (int32_t seed : nodes) {
+        if (!active[seed]) continue;
+        const int start = far_node(far_node(seed));   // two sweeps towards a pseudo-peripheral node of the component
+        std::vector<int32_t> q{start}; active[start] = 0;
+        for (size_t h = 0; h < q.size(); h++) {
+          std::vector<int32_t> nb;
+          for (int32_t w : adj[q[h]]) if (active[w]) { active[w] = 0; nb.push_back(w); }
+          std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return adj[a].size() < adj[b].size() || (adj[a].size() == adj[b].size() && a < b); });
+          q.insert(q.end(), nb.begin(), nb.end());
+        }
+        ord.insert(ord.end(), q.begin(), q.end());
       }
-      order.insert(order.end(), q.begin(), q.end());
+      std::reverse(ord.begin(), ord.end());
+      out.insert(out.end(), ord.begin(), ord.end());
+    };
+    // Nested dissection by level-set separators: the elimination tree gets independent subtrees, i.e. the tile
+    // Cholesky gets several serial chains that run side by side instead of one (cholesky.hip).  A separator is the
+    // smallest BFS level (from a pseudo-peripheral node) that leaves at least a quarter of the nodes on each side.
+    struct PartRec { std::vector<int32_t> nodes; int parent; };
+    std::vector<PartRec> parts;
+    std::function<int(const std::vector<int32_t>&, int)> dissect = [&](const std::vector<int32_t>& nodes, int depth) -> int {
+      // returns the index of the part that roots this subtree (its last part in elimination order)
+      if (depth > 0 && nodes.size() >= 256) {
+        for (int32_t v : nodes) active[v] = 1;
+        std::vector<int32_t> q;
+        const int start = far_node(far_node(nodes[0]));
+        bfs_levels(start, q);
+        const int L = level[q.back()];
+        std::vector<int64_t> cnt(L + 2, 0);
+        for (int32_t v : q) cnt[level[v]]++;
+        const int64_t n = (int64_t)nodes.size();
+        int best = -1; int64_t below = 0;
+        std::vector<int64_t> pre(L + 2, 0);
+        for (int l = 0; l <= L; l++) pre[l + 1] = pre[l] + cnt[l];
+        for (int l = 1; l < L; l++) {
+          below = pre[l];
+          const int64_t above = n - pre[l + 1];   // nodes not reached by the BFS count as "above"
+          if (std::min(below, above) * 4 < n) continue;
+          if (best < 0 || cnt[l] < cnt[best]) best = l;
+        }
+        for (int32_t v : nodes) active[v] = 0;
+        if (best > 0 && cnt[best] * 3 < n) {
+          std::vector<int32_t> A, Bn, Sn;
+          for (int32_t v : nodes) {
+            if (level[v] >= 0 && level[v] < best) A.push_back(v);
+            else if (level[v] == best) Sn.push_back(v);
+            else Bn.push_back(v);
+          }
+          const int ra = dissect(A, depth - 1);
+          const int rb = dissect(Bn, depth - 1);
+          PartRec sp; sp.parent = -1;
+          rcm(Sn, sp.nodes);
+          parts.push_back(std::move(sp));
+          const int me = (int)parts.size() - 1;
+          parts[ra].parent = me; parts[rb].parent = me;
+          return me;
+        }
+      }
+      PartRec leaf; leaf.parent = -1;
+      rcm(nodes, leaf.nodes);
+      parts.push_back(std::move(leaf));
+      return (int)parts.size() - 1;
+    };
+    const int nd_depth = nd_depth_try;
+    std::vector<int32_t> all(nrv2);
+    for (int i = 0; i < nrv2; i++) all[i] = i;
+    dissect(all, nd_depth);
+    std::vector<int32_t> order; order.reserve(nrv2);
+    for (size_t pi = 0; pi < parts.size(); pi++) {
+      for (int32_t v : parts[pi].nodes) { order.push_back(v); part_of_pos.push_back((int32_t)pi); }
+      part_parent.push_back(parts[pi].parent);
     }
-    std::reverse(order.begin(), order.end());
+    if (parts.size() == 1) { part_of_pos.clear(); part_parent.clear(); }
     for (int i = 0; i < nrv2; i++) { c.h_red_pos[order[i]] = i; pos_to_red[i] = order[i]; }
+    // offsets: every part starts on a 256-column pair boundary, so that a pair of block columns belongs to one part
     int64_t o2 = 0;
-    for (int pp = 0; pp < nrv2; pp++) { const int r = pos_to_red[pp]; c.h_red_off[r] = o2; o2 += c.h_red_dim[r]; }
+    c.h_pad_index.clear();
+    for (int pp = 0; pp < nrv2; pp++) {
+      if (!part_of_pos.empty() && (pp == 0 || part_of_pos[pp] != part_of_pos[pp - 1]))
+        while (o2 % (2 * kTile)) c.h_pad_index.push_back(o2++);
+      const int r = pos_to_red[pp]; c.h_red_off[r] = o2; o2 += c.h_red_dim[r];
+    }
+    const int64_t align = part_of_pos.empty() ? kTile : 2 * kTile;
+    while (o2 % align) c.h_pad_index.push_back(o2++);
+    c.NP = (int)o2;
     // re-orient the blocks: the row variable is the one placed later
     for (size_t i = 0; i < pair_row.size(); i++)
       if (c.h_red_pos[pair_row[i]] < c.h_red_pos[pair_col[i]]) {
@@ -308,8 +394,17 @@ static void analyze(gtg_context& c) {
         std::swap(hoff_row[i], hoff_col[i]);
         for (int64_t t = hoff_ptr[i]; t < hoff_ptr[i + 1]; t++) hoff_fac[t] ^= (1 << 30);
       }
-    clk.lap("RCM ordering");
+    if (clk.on) {
+      std::fprintf(stderr, "[gtsam_amd setup] nested dissection: %zu parts:", parts.size());
+      for (size_t pi = 0; pi < parts.size(); pi++) std::fprintf(stderr, " %zu(^%d)", parts[pi].nodes.size(), parts[pi].parent);
+      std::fprintf(stderr, "\n");
+    }
+    clk.lap("ordering (nested dissection + RCM)");
+  } else {
+    c.h_pad_index.clear();
+    for (int64_t i = c.n_red; i < c.NP; i++) c.h_pad_index.push_back(i);
   }
+  up(c.pad_index, c.h_pad_index, s);
 
   // ---- tile structure of the reduced system -> Cholesky schedule ------------------------------------------------
   {
@@ -324,10 +419,23 @@ static void analyze(gtg_context& c) {
     for (int r = 0; r < c.n_red_vars; r++) mark(r, r);
     for (size_t i = 0; i < pair_row.size(); i++) mark(pair_row[i], pair_col[i]);
     for (size_t i = 0; i < hoff_row.size(); i++) mark(hoff_row[i], hoff_col[i]);
-    build_chol_plan(c.plan, nt, std::getenv("GTG_DENSE_PLAN") ? nullptr : &B2, s);
+    std::vector<int32_t> pair_part;
+    if (!part_of_pos.empty()) {
+      pair_part.assign(np2, -1);
+      for (int pp = 0; pp < c.n_red_vars; pp++) pair_part[c.h_red_off[pos_to_red[pp]] / (2 * kTile)] = part_of_pos[pp];
+      for (int q = 0; q < np2; q++) if (pair_part[q] < 0) throw std::runtime_error("nested dissection: a column pair without variables");
+    }
+    build_chol_plan(c.plan, nt, std::getenv("GTG_DENSE_PLAN") ? nullptr : &B2, s, &pair_part, &part_parent);
     clk.lap("cholesky tile schedule");
-    if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation\n",
-                             (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9);
+    if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation, critical path %d of %d column pairs\n",
+                             (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9, c.plan.critical_pairs, np2);
+    // keep the nested-dissection ordering only where it pays: the chains must get clearly shorter and the problem must be
+    // in the latency-bound regime (separators cost fill: on the L1723 shape +60 % flops for a 30 % shorter path)
+    if (!part_of_pos.empty() && !nd_forced &&
+        !(c.plan.critical_pairs * 10 <= np2 * 8 && c.plan.flops <= 6e10)) { retry_rcm = true; }
+  }
+
+  if (!retry_rcm) break;
   }
 
   // ---- upload -----------------------------------------------------------------------------------
@@ -354,7 +462,8 @@ static void analyze(gtg_context& c) {
   c.S.alloc((NP + kTile) * NP);
   c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
   check_hip(hipMemsetAsync(c.Dinv.p, 0, sizeof(double) * c.Dinv.n, c.stream), "memset");
-  c.chol_epoch = 0;
+  c.chol_epoch_dev.alloc(1);
+  check_hip(hipMemsetAsync(c.chol_epoch_dev.p, 0, sizeof(long long), c.stream), "memset");
   c.xred.alloc(NP);
   c.partials.alloc(2 * 2048);
   c.scalars.alloc(SC_COUNT);
@@ -463,8 +572,9 @@ int gtg_destroy(gtg_handle c) {
   for (auto* b : i32) b->free();
   c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.stored.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
-                            &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr};
+                            &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
+  c->chol_epoch_dev.free();
   (void)hipStreamDestroy(c->stream);
   drop_index(c);
   delete c;
@@ -765,8 +875,17 @@ int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
 int gtg_get_reduced_matrix(gtg_handle c, double* S, int64_t n_elems) {
   GTG_TRY
   if (!c || !c->uploaded || n_elems != c->n_red * c->n_red) throw std::invalid_argument("gtg_get_reduced_matrix: wrong size");
-  const int64_t n = c->n_red;
-  check_hip(hipMemcpy2D(S, sizeof(double) * n, c->S.p, sizeof(double) * c->NP, sizeof(double) * n, n, hipMemcpyDeviceToHost), "D2H 2D");
+  // S carries alignment gaps (identity rows) between the nested-dissection parts: copy the square part and compact it
+  const int64_t n = c->n_red, NP = c->NP;
+  std::vector<double> full((size_t)NP * NP);
+  check_hip(hipMemcpy(full.data(), c->S.p, sizeof(double) * full.size(), hipMemcpyDeviceToHost), "D2H");
+  std::vector<char> is_pad((size_t)NP, 0);
+  for (int64_t i : c->h_pad_index) is_pad[(size_t)i] = 1;
+  std::vector<int64_t> keep; keep.reserve((size_t)n);
+  for (int64_t i = 0; i < NP; i++) if (!is_pad[(size_t)i]) keep.push_back(i);
+  if ((int64_t)keep.size() != n) throw std::runtime_error("gtg_get_reduced_matrix: padding bookkeeping is inconsistent");
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t j = 0; j < n; j++) S[i * n + j] = full[(size_t)keep[(size_t)i] * NP + keep[(size_t)j]];
   return GTG_OK;
   GTG_CATCH
 }
@@ -826,7 +945,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   DevBuf<double> S, Dinv, x, fail;
   S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(1);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
-  const long long saved_epoch = c->chol_epoch; c->chol_epoch = 0;
+  if (!c->chol_epoch_dev.p) { c->chol_epoch_dev.alloc(1); check_hip(hipMemset(c->chol_epoch_dev.p, 0, sizeof(long long)), "memset"); }
   check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");
   check_hip(hipMemsetAsync(fail.p, 0, sizeof(double), c->stream), "memset");
   check_hip(hipMemcpy2DAsync(S.p, sizeof(double) * NP, A, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream), "H2D 2D");
@@ -843,7 +962,6 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
-  c->chol_epoch = saved_epoch;
   return hf != 0.0 ? GTG_INDETERMINATE : GTG_OK;
   GTG_CATCH
 }

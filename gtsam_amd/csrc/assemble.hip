@@ -358,10 +358,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int3
   }
 }
 
-// identity on the padded diagonal NP > n
-__global__ void k_pad_diag(double* __restrict__ S, int64_t n, int NP) {
-  const int64_t i = n + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < NP) S[i * NP + i] = 1.0;
+// identity on the padded rows / columns of S (tail padding to the tile size, alignment gaps between the parts)
+__global__ void k_pad_diag(double* __restrict__ S, const int64_t* __restrict__ pad, int64_t npad, int NP) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < npad) { const int64_t i = pad[t]; S[i * NP + i] = 1.0; }
 }
 
 // ---- back-substitution ---------------------------------------------------------------------------------
@@ -452,8 +452,9 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   if (c.n_pairs)
     hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)((c.n_pairs + 3) / 4)), dim3(256), 0, c.stream, c.n_pairs, c.pair_row.p,
                        c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
-  if (NP > c.n_red && c.shard == 0)
-    hipLaunchKernelGGL(k_pad_diag, dim3((NP - c.n_red + 63) / 64), dim3(64), 0, c.stream, c.S.p, c.n_red, NP);
+  const int64_t npad = (int64_t)c.h_pad_index.size();
+  if (npad > 0 && c.shard == 0)
+    hipLaunchKernelGGL(k_pad_diag, dim3((unsigned)((npad + 63) / 64)), dim3(64), 0, c.stream, c.S.p, c.pad_index.p, npad, NP);
   check_hip(hipGetLastError(), "build_reduced");
 }
 

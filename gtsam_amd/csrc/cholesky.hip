@@ -25,6 +25,8 @@
 // MFMA is used here and for the small contractions of the assembly (Schur pairs, camera blocks: assemble.hip);
 // everything else on the path is HBM-bound.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -317,7 +319,9 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, int 
 #define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress word of the tile, after the operand images
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
-                                           double* __restrict__ fail, long long* __restrict__ dbg, long long flagbase) {
+                                           double* __restrict__ fail, long long* __restrict__ dbg,
+                                           const long long* __restrict__ epoch) {
+  const long long flagbase = *epoch * 8;   // progress words are monotonic over factorisations: no reset, graph-replayable
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
@@ -400,7 +404,8 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
 constexpr int TR = 64;   // rows per TRSM workgroup
 __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S, int NP, int k, int wg,
                                           const int32_t* __restrict__ rows, double* __restrict__ Xinv,
-                                          double* __restrict__ fail, long long flagbase) {
+                                          double* __restrict__ fail, const long long* __restrict__ epoch) {
+  const long long flagbase = *epoch * 8;
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
   const int I = rows[wg >> 1], half_rows = (wg & 1) * TR;
   __builtin_amdgcn_s_setprio(2);
@@ -486,11 +491,12 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
 // order), the release/acquire pair is agent scope (L2 write-back / invalidate across XCDs).
 __global__ __launch_bounds__(512, 2) void k_panel128(double* __restrict__ S, int NP, int k, const int32_t* __restrict__ rows,
                                                      double* __restrict__ Xinv, double* __restrict__ fail,
-                                                     long long* __restrict__ dbg, long long flagbase) {
+                                                     long long* __restrict__ dbg, const long long* __restrict__ epoch) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, flagbase);
-  else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, flagbase);
+  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch);
+  else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, epoch);
 }
+__global__ void k_bump_epoch(long long* epoch) { *epoch += 1; }
 
 // ---- trailing update: C(I,J) -= sum_{kt} L(I,kt) L(J,kt)^T ---------------------------------------------------
 // 128x128 output tile per workgroup, 4 wavefronts in 2x2, each 64x64 = 4x4 MFMA tiles.  The contraction
@@ -619,8 +625,13 @@ constexpr int64_t kLatencyTiles = 320;   // launches up to this many tiles use t
 // over), then the per-pair tile lists.  This is the reduced system's elimination structure: what the reference
 // rebuilds as EliminationTree + JunctionTree on every lambda try (inference/EliminationTree-inst.h:77-155,
 // JunctionTree-inst.h:63-151), computed once here.
-void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t stream) {
+void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t stream,
+                     const std::vector<int32_t>* pair_part, const std::vector<int32_t>* part_parent) {
   const int np = (nt + 1) / 2;
+  const bool tree = pair_part && !pair_part->empty();
+  plan.pair_part.clear(); plan.part_parent.clear();
+  if (tree) { plan.pair_part = *pair_part; plan.part_parent = *part_parent; }
+  plan.anc_off.assign(np, 0); plan.anc_cnt.assign(np, 0);
   std::vector<uint8_t> B((size_t)np * np, 0);
   for (int q = 0; q < np; q++)
     for (int p = 0; p <= q; p++) B[(size_t)q * np + p] = pair_struct ? (*pair_struct)[(size_t)q * np + p] : 1;
@@ -677,15 +688,17 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
       plan.trsm_cnt[k + 1] = (int64_t)rows.size() - plan.trsm_off[k + 1];
       flops += t3 / 3.0 + (double)(plan.trsm_cnt[k + 1] - 1) * t3;
     }
-    std::vector<std::pair<int32_t, int32_t>> nar, rest;
+    std::vector<std::pair<int32_t, int32_t>> nar, rest, anc;
     for (size_t b = 0; b < R.size(); b++) {
       const int32_t J = R[b];
-      auto& dst = (J / 2 == p + 1) ? nar : rest;
+      // with parts: targets in another part can only be in an ancestor (no tiles between independent subtrees)
+      auto& dst = (tree && plan.pair_part[J / 2] != plan.pair_part[p]) ? anc : (J / 2 == p + 1) ? nar : rest;
       for (size_t a = b; a < R.size(); a++) dst.emplace_back(R[a], J);
       dst.emplace_back(nt, J);
     }
     emit_pairs(nar, plan.nar_off[p], plan.nar_cnt[p]);
     emit_pairs(rest, plan.rest_off[p], plan.rest_cnt[p]);
+    emit_pairs(anc, plan.anc_off[p], plan.anc_cnt[p]);
     const double kk = two ? 2.0 : 1.0;
     flops += (double)((int64_t)R.size() * ((int64_t)R.size() + 1) / 2) * 2.0 * t3 * kk;   // rhs row excluded
   }
@@ -695,6 +708,19 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
     for (int p = 0; p < q; p++) if (B[(size_t)q * np + p]) tiles_of(p, bcols);
     if (kt & 1) bcols.push_back(kt - 1);
     plan.bwd_cnt[kt] = (int64_t)bcols.size() - plan.bwd_off[kt];
+  }
+  plan.critical_pairs = np;
+  if (tree) {   // longest leaf-to-root path in pairs
+    const int nparts = (int)plan.part_parent.size();
+    std::vector<int> len(nparts, 0), path(nparts, 0);
+    for (int p = 0; p < np; p++) len[plan.pair_part[p]]++;
+    int best = 0;
+    for (int x = nparts - 1; x >= 0; x--) {   // parents have larger indices: walk down from the root
+      const int par = plan.part_parent[x];
+      path[x] = len[x] + (par >= 0 ? path[par] : 0);
+      best = std::max(best, path[x]);
+    }
+    plan.critical_pairs = best;
   }
   plan.flops = flops;
   plan.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
@@ -756,12 +782,19 @@ struct CholStreams {
   hipStream_t panel = nullptr;
 
   hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, done_tree = nullptr;
   int reserve = -1;
   std::vector<hipEvent_t> P, N;
   hipEvent_t start = nullptr;
 };
 static CholStreams g_cs;
+
+struct TreeStreams {
+  std::vector<hipStream_t> panel, update;   // one pair of streams per concurrently running chain
+  hipStream_t anc = nullptr;                // the updates that cross into ancestor parts: one stream, fixed order
+  std::vector<hipEvent_t> part_ev, join_ev;
+};
+static TreeStreams g_ts;
 
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
   const int nt = NP / T;
@@ -780,12 +813,14 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     attr_set = true;
   }
   const int npairs = (nt + 1) / 2;
-  const long long flagbase = (++c.chol_epoch) * 8;   // progress words are monotonic: no reset between factorisations
+  const long long* flagbase = c.chol_epoch_dev.p;
+  hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p);
   if (!g_cs.panel) {
     int lo = 0, hi = 0;
     check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
     check_hip(hipStreamCreateWithPriority(&g_cs.panel, hipStreamNonBlocking, hi), "panel stream");
     check_hip(hipEventCreateWithFlags(&g_cs.start, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&g_cs.done_tree, hipEventDisableTiming), "event");
   }
   while ((int)g_cs.P.size() < npairs) {
     hipEvent_t e1, e2;
@@ -820,8 +855,10 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
-  check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
-  if (masked) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
+  if (plan.pair_part.empty()) {   // (the tree schedule has its own streams: a stream that joins a capture must rejoin it)
+    check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
+    if (masked) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
+  }
   auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi, bool latency) {
     if (cnt[pi] <= 0) return;
     if (latency && cnt[pi] <= kLatencyTiles)
@@ -830,6 +867,109 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     else
       hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, NP, k, pairs + 2 * off[pi], (int)cnt[pi]);
   };
+  if (!plan.pair_part.empty()) {
+    // ---- elimination-tree schedule: the parts of a nested-dissection ordering are independent serial chains.  Every
+    // leaf chain gets its own (panel, update) stream pair and they run side by side; a separator starts when the
+    // updates its descendants owe it are in.  Those cross-part updates (anc) all go through ONE stream in issue order:
+    // two subtrees update the same separator tiles, and the fixed order keeps the sums deterministic.
+    const int nparts = (int)plan.part_parent.size();
+    std::vector<int> first(nparts, -1), last(nparts, -1), slot(nparts, -1), nchild(nparts, 0);
+    for (int p = 0; p < npairs; p++) { const int x = plan.pair_part[p]; if (first[x] < 0) first[x] = p; last[x] = p; }
+    for (int x = 0; x < nparts; x++) if (plan.part_parent[x] >= 0) nchild[plan.part_parent[x]]++;
+    int nslots = 0;
+    for (int x = 0; x < nparts; x++) {           // children come before parents: a leaf opens a slot, a separator
+      if (nchild[x] == 0) slot[x] = nslots++;    // inherits the slot of its first child
+      else for (int y = 0; y < x; y++) if (plan.part_parent[y] == x) { slot[x] = slot[y]; break; }
+    }
+    int lo = 0, hi = 0;
+    check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
+    while ((int)g_ts.panel.size() < nslots) {
+      hipStream_t a, b;
+      if (getenv("GTG_TREE_NOPRIO")) check_hip(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "panel stream");
+      else check_hip(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, hi), "panel stream");
+      check_hip(hipStreamCreateWithFlags(&b, hipStreamNonBlocking), "update stream");
+      g_ts.panel.push_back(a); g_ts.update.push_back(b);
+    }
+    if (!g_ts.anc) check_hip(hipStreamCreateWithFlags(&g_ts.anc, hipStreamNonBlocking), "anc stream");
+    while ((int)g_ts.part_ev.size() < nparts) {
+      hipEvent_t e1, e2;
+      check_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "event");
+      check_hip(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "event");
+      g_ts.part_ev.push_back(e1); g_ts.join_ev.push_back(e2);
+    }
+    hipStream_t sa = g_ts.anc;
+    check_hip(hipStreamWaitEvent(sa, g_cs.start, 0), "wait");
+    auto panel_on = [&](hipStream_t st, int k) {
+      double* Xk = Xinv + (size_t)k * T * T;
+      hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), st,
+                         S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase);
+    };
+    // Issue order: round-robin over the chains that are ready, one pair of block columns at a time.  The host needs
+    // ~45 us to issue a pair (9-10 API calls) and a chain executes one in ~100 us, so a single host thread can keep two
+    // to three chains busy; issued chain after chain, the second chain would only start when the first is nearly done.
+    // A separator becomes ready when all its children are completely issued: the anc stream's position at that
+    // moment marks "every update into its columns is in" (the stream is in order).  The order is a pure function of
+    // the plan: the cross-part sums are deterministic.
+    std::vector<int> next(nparts, 0), pending(nparts, 0);
+    for (int x = 0; x < nparts; x++) { next[x] = first[x]; pending[x] = nchild[x]; }
+    std::vector<int> active;
+    auto activate = [&](int x) {
+      hipStream_t xp = g_ts.panel[slot[x]], xu = g_ts.update[slot[x]];
+      if (nchild[x] == 0) {
+        check_hip(hipStreamWaitEvent(xp, g_cs.start, 0), "wait");
+        check_hip(hipStreamWaitEvent(xu, g_cs.start, 0), "wait");
+      } else {
+        check_hip(hipEventRecord(g_ts.part_ev[x], sa), "record");
+        check_hip(hipStreamWaitEvent(xp, g_ts.part_ev[x], 0), "wait");
+      }
+      active.push_back(x);
+    };
+    for (int x = 0; x < nparts; x++) if (nchild[x] == 0 && first[x] >= 0) activate(x);
+    while (!active.empty()) {
+      std::vector<int> round = active;
+      for (int x : round) {
+        hipStream_t xp = g_ts.panel[slot[x]], xu = g_ts.update[slot[x]];
+        const int pi = next[x]++;
+        const int k = 2 * pi;
+        panel_on(xp, k);
+        if (k + 1 < nt) {
+          if (plan.s1_cnt[pi] <= kLatencyTiles)
+            hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, xp, S, NP, k,
+                               pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
+          else
+            hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, xp, S, NP, k,
+                               pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
+          panel_on(xp, k + 1);
+          if (pi > first[x]) check_hip(hipStreamWaitEvent(xp, g_cs.P[pi - 1], 0), "wait");
+          update(xp, k, plan.nar_off, plan.nar_cnt, pi, true);
+        }
+        check_hip(hipEventRecord(g_cs.N[pi], xp), "record");
+        if (plan.rest_cnt[pi] > 0 || pi == last[x]) {
+          check_hip(hipStreamWaitEvent(xu, g_cs.N[pi], 0), "wait");
+          if (k + 1 < nt) update(xu, k, plan.rest_off, plan.rest_cnt, pi, false);
+        }
+        check_hip(hipEventRecord(g_cs.P[pi], xu), "record");
+        if (plan.anc_cnt[pi] > 0) {
+          check_hip(hipStreamWaitEvent(sa, g_cs.N[pi], 0), "wait");
+          update(sa, k, plan.anc_off, plan.anc_cnt, pi, false);
+        }
+        if (pi == last[x]) {   // chain completely issued
+          active.erase(std::find(active.begin(), active.end(), x));
+          const int par = plan.part_parent[x];
+          if (par >= 0 && --pending[par] == 0 && first[par] >= 0) activate(par);
+        }
+      }
+    }
+    // join: the caller's stream continues after every chain and after the anc stream
+    for (int sl = 0; sl < nslots; sl++) {
+      check_hip(hipEventRecord(g_ts.join_ev[sl], g_ts.update[sl]), "record");   // update[sl] waited for its panel stream's last N
+      check_hip(hipStreamWaitEvent(c.stream, g_ts.join_ev[sl], 0), "wait");
+    }
+    check_hip(hipEventRecord(g_cs.done_tree, sa), "record");
+    check_hip(hipStreamWaitEvent(c.stream, g_cs.done_tree, 0), "wait");
+    check_hip(hipGetLastError(), "cholesky (tree schedule)");
+    return;
+  }
   for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
     panel(k);
     if (k + 1 < nt) {

@@ -46,6 +46,11 @@ struct CholPlan {
   std::vector<int64_t> trsm_off, trsm_cnt;      // per column tile
   std::vector<int64_t> s1_off, s1_cnt, nar_off, nar_cnt, rest_off, rest_cnt;   // per pair: thin update, look-ahead part, rest
   std::vector<int64_t> bwd_off, bwd_cnt;        // per row tile
+  // nested dissection: part of every 256-column pair (parts numbered in elimination order, children before parents),
+  // parent part (-1: root); updates of a pair whose target columns lie in an ancestor part
+  std::vector<int32_t> pair_part, part_parent;
+  std::vector<int64_t> anc_off, anc_cnt;
+  int critical_pairs = 0;                       // pairs on the longest leaf-to-root path (= all pairs without parts)
   double flops = 0.0;                           // algorithmic flops of one factorisation over the stored tiles
   double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles
 };
@@ -90,7 +95,9 @@ struct gtg_context {
   // classification: landmark (POINT3 eliminated first) or reduced variable
   int32_t n_lm = 0, n_red_vars = 0;
   int64_t n_red = 0;                            // scalar dimension of the reduced system
-  int32_t NP = 0;                               // n_red rounded up to kTile
+  int32_t NP = 0;                               // padded dimension of S: n_red + alignment gaps (parts start on 256-column boundaries), multiple of kTile
+  std::vector<int64_t> h_pad_index;             // the padded (identity) rows/columns of S
+  gt::DevBuf<int64_t> pad_index;
   std::vector<int32_t> h_lm_index, h_red_index; // per variable: index among landmarks / reduced (or -1)
   std::vector<int32_t> h_lm_var, h_red_var;     // inverse maps
   std::vector<int32_t> h_red_pos;               // reduced index -> position in the ordering
@@ -130,7 +137,7 @@ struct gtg_context {
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
   gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
-  long long chol_epoch = 0;                     // factorisations launched so far (base of the progress words)
+  gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words), bumped on the device
   gt::CholPlan plan;
   gt::DevBuf<double> xbuf;                      // multi-GPU: stored tiles of S packed contiguously for the all-reduce
   gt::DevBuf<double> xred;                      // NP solution of the reduced system

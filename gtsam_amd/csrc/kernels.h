@@ -22,7 +22,8 @@ void launch_scatter_delta(gtg_context& c);       // delta (variable id order) fr
 // cholesky.hip ------------------------------------------------------------------------------------
 // Host: build the tile schedule.  pair_struct = lower-triangular boolean structure over 256-wide column pairs
 // ((np x np) row-major bytes, np = ceil(nt/2); nullptr = dense); symbolic fill-in is computed here.
-void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t s);
+void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t s,
+                     const std::vector<int32_t>* pair_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 // In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
 void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan);

@@ -162,6 +162,28 @@ def test_pose2_w20000_full_trajectory(gpu):
     assert rel(opt.values_packed(), g["final_values"]) <= 1e-4
 
 
+def test_nested_dissection_tree_schedule_is_equivalent(gpu, monkeypatch):
+    """GTG_ND_DEPTH=2: nested-dissection ordering (parts aligned to 256-column pairs, identity padding between them) and
+    the elimination-tree schedule of the tile Cholesky (independent chains on their own streams, cross-part updates on
+    one in-order stream).  Same damped solve and same LM trajectory as the reference, on a graph large enough to split
+    (sphere2500: 7 parts)."""
+    from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+    monkeypatch.setenv("GTG_ND_DEPTH", "2")
+    g = load_golden("sphere2500")
+    p, v0 = PB.sphere2500(g)
+    dev = gpu.DeviceGraph(p)
+    dev.set_values(v0)
+    dev.linearize()
+    rc, out = dev.try_lambda(1e-5, False)
+    assert rc == 0 and rel(dev.delta(), g["solve_delta"]) <= 1e-6
+    dev.close()
+    opt = DeviceLevenbergMarquardt(p, v0, LMP())
+    opt.optimize()
+    tr = np.array(opt.trace)[:, :3]
+    assert tr.shape == g["trace"].shape and np.array_equal(tr[:, 0], g["trace"][:, 0])
+    assert rel(tr[:, 1], g["trace"][:, 1]) <= 1e-6
+
+
 def test_robust_loss_literal(gpu):
     p, v = PB.robust_prior_literal()
     dev = gpu.DeviceGraph(p)

@@ -426,6 +426,29 @@ static void analyze(gtg_context& c) {
       for (int q = 0; q < np2; q++) if (pair_part[q] < 0) throw std::runtime_error("nested dissection: a column pair without variables");
     }
     build_chol_plan(c.plan, nt, std::getenv("GTG_DENSE_PLAN") ? nullptr : &B2, s, &pair_part, &part_parent);
+    {  // tiles that hold something before the factorisation: diagonal blocks, pose-pose blocks, Schur pairs, rhs row
+      std::vector<uint8_t> T1((size_t)nt * nt, 0);
+      std::vector<uint8_t> rhs((size_t)nt, 0);
+      auto mark1 = [&](int ra, int rb) {
+        const int64_t a0 = c.h_red_off[ra] / kTile, a1 = (c.h_red_off[ra] + c.h_red_dim[ra] - 1) / kTile;
+        const int64_t b0 = c.h_red_off[rb] / kTile, b1 = (c.h_red_off[rb] + c.h_red_dim[rb] - 1) / kTile;
+        for (int64_t a = a0; a <= a1; a++)
+          for (int64_t b = b0; b <= b1; b++) T1[(size_t)std::max(a, b) * nt + std::min(a, b)] = 1;
+        for (int64_t a = a0; a <= a1; a++) rhs[(size_t)a] = 1;
+      };
+      for (int r = 0; r < c.n_red_vars; r++) mark1(r, r);
+      for (size_t i = 0; i < pair_row.size(); i++) mark1(pair_row[i], pair_col[i]);
+      for (size_t i = 0; i < hoff_row.size(); i++) mark1(hoff_row[i], hoff_col[i]);
+      for (int64_t i : c.h_pad_index) T1[(size_t)(i / kTile) * nt + (size_t)(i / kTile)] = 1;
+      std::vector<int32_t> ex;
+      const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
+      for (int a = 0; a < nt; a++)
+        for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
+      for (int b = 0; b < nt; b++) if (dense || rhs[(size_t)b]) { ex.push_back(nt); ex.push_back(b); }
+      c.plan.n_exch = (int64_t)ex.size() / 2;
+      if (ex.empty()) { ex.push_back(0); ex.push_back(0); }
+      up(c.plan.exch, ex, s);
+    }
     clk.lap("cholesky tile schedule");
     if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation, critical path %d of %d column pairs\n",
                              (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9, c.plan.critical_pairs, np2);
@@ -570,7 +593,7 @@ int gtg_destroy(gtg_handle c) {
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
                             &c->pair_col, &c->pair_oa, &c->pair_ob};
   for (auto* b : i32) b->free();
-  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.stored.free(); c->xbuf.free();
+  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
@@ -788,7 +811,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, g_events); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
   if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs, stored lower tiles only
-    const int64_t nb = c->plan.n_stored * kTile * kTile;
+    const int64_t nb = c->plan.n_exch * kTile * kTile;
     if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
     launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
     exchange(*c, c->xbuf.p, nb);

@@ -46,14 +46,15 @@ __device__ __forceinline__ void obs_rec(const JTabs& t, int64_t o, const double*
 // One workgroup per reduced variable: H_dd = sum A^T A and g_d = sum A^T b over its contributions (whitened Jacobian
 // rows of every factor touching it).  The sum over rows is a contraction, run on the FP64 matrix core with b as one
 // more column: per step a lane loads one entry, the 64 lanes cover up to 4 rows of [A | b] of ONE contribution
-// (contiguous in the factor's record), and C[i][j] = sum_q A[q][i] [A | b][q][j].  The 4 waves split the contribution
-// list and are combined through LDS in wave order (deterministic).
+// (contiguous in the factor's record), and C[i][j] = sum_q A[q][i] [A | b][q][j].  The 16 waves split the
+// contribution list and are combined through LDS in wave order (deterministic).
 typedef double v4f64a __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kBlock) void k_red_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
+constexpr int kRedWaves = 16;   // waves per reduced variable: a 16-camera problem still has 256 wavefronts of work
+__global__ __launch_bounds__(64 * kRedWaves) void k_red_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, JTabs t, double* __restrict__ Hd, double* __restrict__ g,
     double* __restrict__ hdiag) {
-  __shared__ double part[4][256];
+  __shared__ double part[kRedWaves][256];
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void k_red_diag(int32_t n_red_vars, const i
   const int nent = d * d + d;
   const int64_t beg = inc_ptr[r], end = inc_ptr[r + 1];
   v4f64a acc = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t k = beg + wave; k < end; k += 4) {
+  for (int64_t k = beg + wave; k < end; k += kRedWaves) {
     const double* A; const double* b; int rows;
     contribution(t, inc_kind[k], inc_idx[k], d, A, rows, b);
     const int boff = (int)(b - A);
@@ -83,7 +84,9 @@ __global__ __launch_bounds__(kBlock) void k_red_diag(int32_t n_red_vars, const i
   if (e < nent) {
     const int i = e < d * d ? e / d : e - d * d, j = e < d * d ? e % d : d;
     const int idx = (i >> 2) * 64 + 16 * (i & 3) + j;
-    const double s = ((part[0][idx] + part[1][idx]) + part[2][idx]) + part[3][idx];
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kRedWaves; w++) s += part[w][idx];   // wave order: deterministic
     if (e < d * d) {
       Hd[(int64_t)81 * r + e] = s;
       if (i == j) hdiag[red_off[r] + i] = s;
@@ -358,6 +361,49 @@ __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int3
   }
 }
 
+// The same contraction for graphs with few cameras and thousands of common landmarks per pair (Dubrovnik-16 shape: 136
+// pairs, ~2 000 terms each): one workgroup per pair, its 16 waves take every 16th group of 4 terms, partial tiles are
+// combined through LDS in wave order (deterministic).
+constexpr int kPairWaves = 16;
+__global__ __launch_bounds__(64 * kPairWaves) void k_schur_pairs_heavy(int64_t n_pairs, const int32_t* __restrict__ prow,
+    const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
+    const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+    const double* __restrict__ E, double* __restrict__ S, int NP) {
+  __shared__ double part[kPairWaves][256];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t p = blockIdx.x;
+  const int ra = prow[p], rb = pcol[p];
+  const int da = red_dim[ra], db = red_dim[rb];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int64_t k0 = pptr[p], k1 = pptr[p + 1];
+  const bool ina = lr < da && lk < 3, inb = lr < db && lk < 3;
+  const int ea = ina ? 3 * lr + lk : 0, eb = inb ? 3 * lr + lk : 0;
+  v4f64s acc = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t t = k0 + 4 * wv; t < k1; t += 4 * kPairWaves) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (t + u < k1) {
+        const double av = E[kEStride * (int64_t)oa[t + u] + ea], bv = E[kEStride * (int64_t)ob[t + u] + eb];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? av : 0.0, inb ? bv : 0.0, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) part[wv][r * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wv == 0) {
+    const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = lk + 4 * r;
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < kPairWaves; w++) sum += part[w][r * 64 + lane];
+      if (row < da && lr < db) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= sum;
+    }
+  }
+}
+
 // identity on the padded rows / columns of S (tail padding to the tile size, alignment gaps between the parts)
 __global__ void k_pad_diag(double* __restrict__ S, const int64_t* __restrict__ pad, int64_t npad, int NP) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -407,7 +453,7 @@ static JTabs jtabs(gtg_context& c) { return JTabs{c.f.sfm_J.p, c.f.proj_J.p, c.f
 void launch_assemble(gtg_context& c) {
   JTabs t = jtabs(c);
   if (c.n_red_vars)
-    hipLaunchKernelGGL(k_red_diag, dim3(c.n_red_vars), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
+    hipLaunchKernelGGL(k_red_diag, dim3(c.n_red_vars), dim3(64 * kRedWaves), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, t, c.Hd.p, c.gred0.p, c.hdiag_red.p);
   if (c.n_lm)
     hipLaunchKernelGGL(k_lm_diag, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_obs_ptr.p, c.lm_obs.p,
@@ -449,7 +495,10 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
-  if (c.n_pairs)
+  if (c.n_pairs && c.n_pair_terms > 512 * c.n_pairs)   // few pairs, thousands of terms each
+    hipLaunchKernelGGL(k_schur_pairs_heavy, dim3((unsigned)c.n_pairs), dim3(64 * kPairWaves), 0, c.stream, c.n_pairs, c.pair_row.p,
+                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
+  else if (c.n_pairs)
     hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)((c.n_pairs + 3) / 4)), dim3(256), 0, c.stream, c.n_pairs, c.pair_row.p,
                        c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
   const int64_t npad = (int64_t)c.h_pad_index.size();

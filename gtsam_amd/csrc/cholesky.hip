@@ -765,7 +765,7 @@ void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan) 
   check_hip(hipGetLastError(), "zero_tiles");
 }
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack) {
-  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_stored), dim3(256), 0, c.stream, S, NP, plan.stored.p, buf, unpack ? 1 : 0);
+  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_exch), dim3(256), 0, c.stream, S, NP, plan.exch.p, buf, unpack ? 1 : 0);
   check_hip(hipGetLastError(), "pack_tiles");
 }
 

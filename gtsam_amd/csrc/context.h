@@ -43,6 +43,8 @@ struct CholPlan {
   DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
   DevBuf<int32_t> stored;                       // every stored tile (I,J) incl. the rhs row: what a multi-GPU exchange must carry
   int64_t n_stored = 0;
+  DevBuf<int32_t> exch;                         // the stored tiles that can be non-zero BEFORE the factorisation (no fill): what a multi-GPU
+  int64_t n_exch = 0;                           // exchange of the partial reduced systems has to carry (L1723: 19 % fewer than `stored`)
   std::vector<int64_t> trsm_off, trsm_cnt;      // per column tile
   std::vector<int64_t> s1_off, s1_cnt, nar_off, nar_cnt, rest_off, rest_cnt;   // per pair: thin update, look-ahead part, rest
   std::vector<int64_t> bwd_off, bwd_cnt;        // per row tile

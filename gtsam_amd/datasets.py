@@ -131,8 +131,40 @@ def venice_1778(seed=42):
     return synthetic_bal(1778, 993923, mean_track=5.03, seed=seed)
 
 
+def synthetic_bal_convergent(n_cams, n_points, mean_track, seed=42, pixel_noise=0.5):
+    """A few cameras on a ring looking at one scene (the geometry of the small Dubrovnik problems): every camera sees
+    every point, a point is observed by 2 + Exp cameras.  Same return convention as synthetic_bal."""
+    rng = np.random.default_rng(seed)
+    a = np.linspace(0, 2 * np.pi, n_cams, endpoint=False) + rng.normal(0, 0.05, n_cams)
+    centers = np.stack([30 * np.cos(a), 30 * np.sin(a), rng.normal(0, 2.0, n_cams)], 1)
+    target = rng.normal(0, 1.0, (n_cams, 3))
+    fwd = target - centers; fwd /= np.linalg.norm(fwd, axis=1)[:, None]
+    down = np.tile(np.array([0, 0, -1.0]), (n_cams, 1))
+    right = np.cross(down, fwd); right /= np.linalg.norm(right, axis=1)[:, None]
+    down = np.cross(fwd, right)
+    Rwc = np.stack([right, down, fwd], 2)
+    f = rng.uniform(400, 900, n_cams); k1 = rng.normal(0, 1e-2, n_cams); k2 = rng.normal(0, 1e-4, n_cams)
+    pts = rng.normal(0, 4.0, (n_points, 3))
+    k = np.minimum(2 + np.floor(rng.exponential(mean_track - 2.0, n_points)).astype(np.int64), n_cams)
+    obs_cam = np.concatenate([np.sort(rng.choice(n_cams, kk, replace=False)) for kk in k])
+    obs_pt = np.repeat(np.arange(n_points), k)
+    Rcw = np.swapaxes(Rwc, 1, 2)
+    q = np.einsum("nij,nj->ni", Rcw[obs_cam], pts[obs_pt] - centers[obs_cam])
+    x, y = q[:, 0] / q[:, 2], q[:, 1] / q[:, 2]
+    r2 = x * x + y * y
+    g = 1 + (k1[obs_cam] + k2[obs_cam] * r2) * r2
+    z = np.stack([f[obs_cam] * g * x, f[obs_cam] * g * y], 1) + rng.normal(0, pixel_noise, (obs_cam.size, 2))
+    dR = _rodrigues(rng.normal(0, 2e-3, (n_cams, 3)))
+    cams = np.zeros((n_cams, 17))
+    cams[:, :9] = (Rwc @ dR).reshape(-1, 9)
+    cams[:, 9:12] = centers + rng.normal(0, 2e-2, (n_cams, 3))
+    cams[:, 12] = f + rng.normal(0, 1.0, n_cams); cams[:, 13] = k1; cams[:, 14] = k2
+    return cams, pts + rng.normal(0, 5e-2, pts.shape), obs_cam.astype(np.int32), obs_pt.astype(np.int32), z
+
+
 def dubrovnik_16(seed=42):
-    return synthetic_bal(16, 22106, mean_track=3.8, seed=seed, long_frac=0.0, n_loops=1)
+    """BAL Dubrovnik problem-16-22106 shape (16 cameras, 22 106 points, ~83 718 observations)."""
+    return synthetic_bal_convergent(16, 22106, mean_track=4.29, seed=seed)
 
 
 def random_pose_graph(n, n_closures, seed=0, noise="mixed", rot_scale=1.0, init_noise=0.2):

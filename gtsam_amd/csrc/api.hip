@@ -583,7 +583,7 @@ int gtg_destroy(gtg_handle c) {
   auto& f = c->f;
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
-                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->delta_lm, &c->S,
+                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->pcg_vec, &c->pcg_bj, &c->pcg_y, &c->delta_lm, &c->S,
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
@@ -831,6 +831,40 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
   if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq)) return GTG_INDETERMINATE;
+  out[0] = c->h_scalars[SC_LIN0];
+  out[1] = c->h_scalars[SC_LIN1];
+  out[2] = (out[0] - out[1] >= 0) ? c->h_scalars[SC_TRIAL_ERROR] : std::numeric_limits<double>::infinity();
+  out[3] = std::sqrt(dsq);
+  return GTG_OK;
+  GTG_CATCH
+}
+
+// Same contract as gtg_try_lambda, the damped system solved by block-Jacobi PCG on the implicit Schur complement
+// (NonlinearOptimizerParams::Iterative + PCGSolverParameters in the reference, NonlinearOptimizer.cpp:154-172).
+int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, double dmax, const double cg[4], double out[4],
+                       int32_t* iterations) {
+  GTG_TRY
+  if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda_pcg: call gtg_linearize first");
+  if (!(lambda > 0.0) || !cg) throw std::invalid_argument("gtg_try_lambda_pcg: lambda must be > 0, cg = {max, min, eps_rel, eps_abs}");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
+  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+  double g0 = 0.0, g1 = 0.0;
+  int its = 0;
+  { PhaseTimer t(*c, GTG_PH_CHOLESKY, g_events);
+    its = launch_pcg(*c, lambda, diag, dmin, dmax, (int)cg[0], (int)cg[1], cg[2], cg[3], &g0, &g1); }
+  if (iterations) *iterations = its;
+  { PhaseTimer t(*c, GTG_PH_SOLVE, g_events);
+    launch_back_substitute(*c);
+    launch_scatter_delta(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, g_events); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_RETRACT, g_events); launch_retract(*c); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  read_scalars(*c);
+  collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
+  c->have_trial = true;
+  const double dsq = c->h_scalars[SC_DELTA_SQ];
+  if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq) || !std::isfinite(g1)) return GTG_INDETERMINATE;
   out[0] = c->h_scalars[SC_LIN0];
   out[1] = c->h_scalars[SC_LIN1];
   out[2] = (out[0] - out[1] >= 0) ? c->h_scalars[SC_TRIAL_ERROR] : std::numeric_limits<double>::infinity();

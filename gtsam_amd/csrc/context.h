@@ -135,6 +135,7 @@ struct gtg_context {
   gt::DevBuf<double> V, gp;                     // landmark blocks (9) and gradient (3)
   gt::DevBuf<double> Hoff;                      // (81 per block)
   gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (32/obs), delta (3)
+  gt::DevBuf<double> pcg_vec, pcg_bj, pcg_y;    // PCG solver: r, p, q1, q2, b (5 x NP); block-Jacobi factors (81 / reduced variable); y_l (3 / landmark)
   gt::DevBuf<double> vobs;                      // per try: Jp^T (Jc x_cam) of every observation (3), for the back-substitution
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
   gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand

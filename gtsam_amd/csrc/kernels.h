@@ -32,6 +32,11 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
 
+// pcg.hip -----------------------------------------------------------------------------------------
+// Block-Jacobi PCG on the implicit Schur complement (needs launch_point_eliminate first): c.xred = S^-1 b.
+int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax, int max_iterations, int min_iterations,
+               double epsilon_rel, double epsilon_abs, double* gamma0, double* gamma_end);
+
 void check_hip(hipError_t e, const char* what);
 
 }  // namespace gt

@@ -22,7 +22,7 @@ PHASES = ["linearize", "assemble", "point_eliminate", "schur", "cholesky", "solv
 # every symbol include/gtsam_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_upload_problem",
            "gtg_set_reduced_ordering", "gtg_values_size", "gtg_tangent_size", "gtg_set_values",
-           "gtg_get_values", "gtg_get_trial_values", "gtg_error", "gtg_linearize", "gtg_try_lambda",
+           "gtg_get_values", "gtg_get_trial_values", "gtg_error", "gtg_linearize", "gtg_try_lambda", "gtg_try_lambda_pcg",
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
@@ -71,6 +71,8 @@ def load():
     lib.gtg_error.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.gtg_linearize.argtypes = [C.c_void_p]
     lib.gtg_try_lambda.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    lib.gtg_try_lambda_pcg.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_int32)]
     lib.gtg_accept.argtypes = [C.c_void_p]
     lib.gtg_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     lib.gtg_enable_timing.argtypes = [C.c_void_p, C.c_int]
@@ -176,6 +178,16 @@ class DeviceGraph:
         rc = _check(self.lib.gtg_try_lambda(self.h, lam, int(diagonal_damping), min_diagonal, max_diagonal,
                                             out.ctypes.data), "gtg_try_lambda")
         return rc, out
+
+    def try_lambda_pcg(self, lam, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, max_iterations=500,
+                       min_iterations=1, epsilon_rel=1e-3, epsilon_abs=1e-3):
+        """gtg_try_lambda_pcg -> (status, out[4] as try_lambda, CG iterations)."""
+        out = np.zeros(4)
+        cg = np.array([max_iterations, min_iterations, epsilon_rel, epsilon_abs], np.float64)
+        its = C.c_int32(0)
+        rc = _check(self.lib.gtg_try_lambda_pcg(self.h, lam, int(diagonal_damping), min_diagonal, max_diagonal,
+                                                cg.ctypes.data, out.ctypes.data, C.byref(its)), "gtg_try_lambda_pcg")
+        return rc, out, its.value
 
     def accept(self):
         _check(self.lib.gtg_accept(self.h), "gtg_accept")

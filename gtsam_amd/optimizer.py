@@ -59,7 +59,13 @@ class DeviceLevenbergMarquardt:
     def _try_lambda(self):
         """One tryLambda (LM.cpp:121-270); returns True when the lambda search of this iteration ends."""
         p = self.params
-        rc, out = self.dev.try_lambda(self._lambda, p.diagonalDamping, p.minDiagonal, p.maxDiagonal)
+        if p.linearSolverType == "Iterative":            # NonlinearOptimizer::solve, Iterative branch (NonlinearOptimizer.cpp:154-172)
+            it = p.iterativeParams
+            rc, out, self.last_cg_iterations = self.dev.try_lambda_pcg(
+                self._lambda, p.diagonalDamping, p.minDiagonal, p.maxDiagonal, it.maxIterations, it.minIterations,
+                it.epsilon_rel, it.epsilon_abs)
+        else:
+            rc, out = self.dev.try_lambda(self._lambda, p.diagonalDamping, p.minDiagonal, p.maxDiagonal)
         step_is_successful = False
         stop_searching_lambda = False
         model_fidelity = 0.0

@@ -7,6 +7,16 @@ nonlinear/nonlinear.i).
 from __future__ import annotations
 
 
+class PCGSolverParameters:
+    """linear/PCGSolver.h + ConjugateGradientSolver.h:34-50 defaults; the preconditioner of the GPU path is block Jacobi
+    (PreconditionerParameters BLOCK_JACOBI) on the implicit Schur complement."""
+
+    def __init__(self, maxIterations=500, minIterations=1, epsilon_rel=1e-3, epsilon_abs=1e-3):
+        self.maxIterations, self.minIterations = int(maxIterations), int(minIterations)
+        self.epsilon_rel, self.epsilon_abs = float(epsilon_rel), float(epsilon_abs)
+        self.preconditioner = "BLOCK_JACOBI"
+
+
 class LevenbergMarquardtParams:
     def __init__(self):
         # NonlinearOptimizerParams.h:43-48
@@ -18,6 +28,8 @@ class LevenbergMarquardtParams:
         self.orderingType = "COLAMD"
         self.ordering = None
         self.iterationHook = None
+        self.linearSolverType = "MULTIFRONTAL_CHOLESKY"   # or "Iterative" (NonlinearOptimizerParams.h:92-101) with iterativeParams
+        self.iterativeParams = PCGSolverParameters()
         # LevenbergMarquardtParams.h:62-66
         self.verbosityLM = "SILENT"
         self.diagonalDamping = False

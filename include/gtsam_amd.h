@@ -163,6 +163,15 @@ int gtg_linearize(gtg_handle h);
 int gtg_try_lambda(gtg_handle h, double lambda, int diagonal_damping, double min_diagonal,
                    double max_diagonal, double out[4]);
 
+/* Same contract as gtg_try_lambda, but the damped reduced system is solved by the reference's preconditioned
+ * conjugate gradients (linear/ConjugateGradientSolver.h:106-169; NonlinearOptimizerParams::Iterative with
+ * PCGSolverParameters, NonlinearOptimizer.cpp:154-172) with a block-Jacobi preconditioner, applied to the IMPLICIT Schur
+ * complement of the landmarks (never formed).  cg = {maxIterations, minIterations, epsilon_rel, epsilon_abs}
+ * (ConjugateGradientParameters defaults: 500, 1, 1e-3, 1e-3); *iterations receives the CG iteration count.
+ * Single-shard graphs only. */
+int gtg_try_lambda_pcg(gtg_handle h, double lambda, int diagonal_damping, double min_diagonal, double max_diagonal,
+                       const double cg[4], double out[4], int32_t* iterations);
+
 /* state_ = decreaseLambda(... newValues ...) (LevenbergMarquardtState.h:81-94): trial -> current. */
 int gtg_accept(gtg_handle h);
 

@@ -604,7 +604,44 @@ def cholesky_partial(ABC, n_frontal):
     return (e1 > -12), M
 
 
-def solve_damped(p: Problem, values, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32):
+def preconditioned_conjugate_gradient(A, b, blocks, max_iterations=500, min_iterations=1, epsilon_rel=1e-3, epsilon_abs=1e-3):
+    """preconditionedConjugateGradient (linear/ConjugateGradientSolver.h:106-169) from x0 = 0 with a block-Jacobi
+    preconditioner M = L L^T, L = Cholesky factors of the diagonal blocks `blocks` = [(start, stop)] of A
+    (linear/Preconditioner.cpp BlockJacobiPreconditioner): split form r = L^-1 (b - A x), p = L^-T r; stop when
+    |r|^2 <= max(epsilon_abs, epsilon_rel^2 |r0|^2).  Returns (x, iterations, gamma0, gamma)."""
+    Ls = [np.linalg.cholesky(A[a:b_, a:b_]) for a, b_ in blocks]
+
+    def left(v):
+        out = np.zeros_like(v)
+        for (a, b_), L in zip(blocks, Ls):
+            out[a:b_] = np.linalg.solve(L, v[a:b_])
+        return out
+
+    def right(v):
+        out = np.zeros_like(v)
+        for (a, b_), L in zip(blocks, Ls):
+            out[a:b_] = np.linalg.solve(L.T, v[a:b_])
+        return out
+
+    x = np.zeros_like(b)
+    r = left(b - A @ x)
+    pdir = right(r)
+    gamma = float(r @ r); gamma0 = gamma
+    threshold = max(epsilon_abs, epsilon_rel * epsilon_rel * gamma)
+    k = 1
+    while k <= max_iterations and (gamma > threshold or k <= min_iterations):
+        q1 = A @ pdir
+        alpha = gamma / float(pdir @ q1)
+        x = x + alpha * pdir
+        r = r - alpha * left(q1)
+        prev = gamma
+        gamma = float(r @ r)
+        pdir = right(r) + (gamma / prev) * pdir
+        k += 1
+    return x, k - 1, gamma0, gamma
+
+
+def solve_damped(p: Problem, values, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32, pcg=None):
     """One solve of LevenbergMarquardtOptimizer::tryLambda (LM.cpp:146-160):
     buildDampedSystem (internal/LevenbergMarquardtState.h:125-156: one prior per variable, sigma =
     1/sqrt(lambda), A = I or diag(sqrt(clamp(hessianDiagonal))) ) then
@@ -643,7 +680,23 @@ def solve_damped(p: Problem, values, lam, diagonal_damping=False, min_diag=1e-6,
         gr[sep] -= Sp.T @ dp
         elim.append((ip, sep, Rp, Sp, dp))
     delta = np.zeros(n)
-    if idx_rest.size:
+    if idx_rest.size and pcg is not None:
+        # NonlinearOptimizerParams::Iterative: PCG with block Jacobi on the Schur complement of the landmarks (the GPU path
+        # applies it implicitly).  pcg = dict(max_iterations, min_iterations, epsilon_rel, epsilon_abs); the iteration
+        # count is left in pcg["iterations"].
+        blocks = []; o = 0
+        for v in rest:
+            d = int(doff[v + 1] - doff[v]); blocks.append((o, o + d)); o += d
+        try:
+            xr, its, g0, g1 = preconditioned_conjugate_gradient(S, gr, blocks, pcg.get("max_iterations", 500), pcg.get("min_iterations", 1),
+                                                                pcg.get("epsilon_rel", 1e-3), pcg.get("epsilon_abs", 1e-3))
+        except np.linalg.LinAlgError:
+            return 1, None, H, g, lin
+        pcg["iterations"] = its; pcg["gamma0"] = g0; pcg["gamma"] = g1
+        if not np.all(np.isfinite(xr)):
+            return 1, None, H, g, lin
+        delta[idx_rest] = xr
+    elif idx_rest.size:
         m = idx_rest.size
         aug = np.zeros((m + 1, m + 1)); aug[:m, :m] = S; aug[:m, m] = gr
         ok, aug = cholesky_partial(aug, m)

@@ -111,6 +111,16 @@ class RefGraph:
                                    _p(d), _p(le))
         return rc, d, le
 
+    def solve_pcg(self, values, lam, diagonal_damping=False, min_diagonal=1e-6, max_diagonal=1e32, max_iterations=500,
+                  epsilon_rel=1e-3, epsilon_abs=1e-3):
+        """The reference's PCGSolver + BlockJacobi on the full damped system -> delta."""
+        v = np.ascontiguousarray(values, np.float64)
+        d = np.zeros(self.dim_size)
+        lib().ref_graph_solve_pcg(self.h, _p(v), C.c_double(lam), C.c_int(int(diagonal_damping)), C.c_double(min_diagonal),
+                                  C.c_double(max_diagonal), C.c_int(max_iterations), C.c_double(epsilon_rel),
+                                  C.c_double(epsilon_abs), _p(d))
+        return d
+
     def retract(self, values, delta):
         v = np.ascontiguousarray(values, np.float64)
         d = np.ascontiguousarray(delta, np.float64)

@@ -26,6 +26,8 @@
 #include <gtsam/linear/GaussianFactorGraph.h>
 #include <gtsam/linear/JacobianFactor.h>
 #include <gtsam/linear/NoiseModel.h>
+#include <gtsam/linear/PCGSolver.h>
+#include <gtsam/linear/Preconditioner.h>
 #include <gtsam/linear/VectorValues.h>
 #include <gtsam/linear/linearExceptions.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
@@ -315,6 +317,36 @@ int ref_graph_solve(void* h, const double* values, double lambda, int diagonal_d
   } catch (const IndeterminantLinearSystemException&) {
     return 1;
   }
+  return 0;
+}
+
+// The reference's own iterative path on the same damped system: PCGSolver with a block-Jacobi preconditioner on the FULL
+// system (NonlinearOptimizer.cpp:154-172 Iterative branch, PCGSolver.cpp:51-64).  It is not the Schur system the GPU path
+// iterates on, so iteration counts differ; with tight tolerances both converge to the direct solution.
+int ref_graph_solve_pcg(void* h, const double* values, double lambda, int diagonal_damping, double min_diag, double max_diag,
+                        int max_iterations, double epsilon_rel, double epsilon_abs, double* delta) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  const Values vals = g->unpack(values);
+  auto lin = g->graph.linearize(vals);
+  internal::LevenbergMarquardtState state(vals, 0.0, lambda, 10.0);
+  GaussianFactorGraph damped;
+  if (diagonal_damping) {
+    VectorValues sq = lin->hessianDiagonal();
+    for (auto& [key, value] : sq) value = value.cwiseMax(min_diag).cwiseMin(max_diag).cwiseSqrt();
+    damped = state.buildDampedSystem(*lin, sq);
+  } else {
+    damped = state.buildDampedSystem(*lin);
+  }
+  auto params = std::make_shared<PCGSolverParameters>();
+  params->preconditioner = std::make_shared<BlockJacobiPreconditionerParameters>();
+  params->maxIterations = max_iterations; params->epsilon_rel = epsilon_rel; params->epsilon_abs = epsilon_abs;
+  PCGSolver solver(*params);
+  Ordering ord;
+  for (int i = 0; i < g->n_vars; i++) ord.push_back(Key(i));
+  const KeyInfo info(damped, ord);
+  const std::map<Key, Vector> no_lambda;
+  const VectorValues d = solver.optimize(damped, info, no_lambda, info.x0());
+  g->packDelta(d, delta);
   return 0;
 }
 

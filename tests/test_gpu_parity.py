@@ -184,6 +184,56 @@ def test_nested_dissection_tree_schedule_is_equivalent(gpu, monkeypatch):
     assert rel(tr[:, 1], g["trace"][:, 1]) <= 1e-6
 
 
+@pytest.mark.parametrize("name", ["dubrovnik_sfmex", "bal_small_iso", "posegraph_small", "projection_small", "pose2_w100"])
+def test_pcg_solver_vs_oracle_and_direct(gpu, name):
+    """gtg_try_lambda_pcg (block-Jacobi PCG on the implicit Schur complement) against the oracle's restatement of the
+    reference's preconditionedConjugateGradient on the explicit Schur complement: same algorithm, so the same step and
+    (within one) the same iteration count; with tight tolerances both equal the Cholesky step."""
+    from oracle import gtsam_oracle as O
+    if name == "dubrovnik_sfmex":
+        p, v0 = PB.dubrovnik_sfmexample(load_golden("dubrovnik_3_7"))
+    elif name == "pose2_w100":
+        p, v0 = PB.pose2_graph(load_golden(name))
+    else:
+        p, v0 = PB.SYNTH[name]()
+    dev = gpu.DeviceGraph(p)
+    dev.set_values(v0)
+    dev.linearize()
+    # (the undamped-diagonal system of the BAL shape at lambda = 1e-3 is indefinite for the direct solver too: Levenberg there)
+    for lam, dd, er, ea in ((1e-3, name == "bal_small_iso", 1e-3, 1e-3), (1e-4, True, 1e-13, 1e-26)):
+        rc, out, its = dev.try_lambda_pcg(lam, dd, max_iterations=3000, epsilon_rel=er, epsilon_abs=ea)
+        assert rc == 0
+        d = dev.delta()
+        info = dict(max_iterations=3000, epsilon_rel=er, epsilon_abs=ea)
+        st, d_or, H, g, lin = O.solve_damped(p, v0, lam, dd, pcg=info)
+        assert st == 0
+        scale = max(np.abs(d_or).max(), 1e-300)
+        if er > 1e-6:        # loose tolerance: identical stopping rule -> (almost) identical iterate
+            assert abs(its - info["iterations"]) <= 1, (its, info["iterations"])
+            assert np.abs(d - d_or).max() <= 1e-4 * scale
+        else:                # tight: both are the direct solution (to the conditioning of the BAL shape: 5e-7 in the oracle)
+            assert abs(its - info["iterations"]) <= 3, (its, info["iterations"])
+            rc2, out2 = dev.try_lambda(lam, dd)
+            assert rc2 == 0 and np.abs(d - dev.delta()).max() <= 1e-5 * scale and np.abs(d_or - dev.delta()).max() <= 1e-5 * scale
+    dev.close()
+
+
+def test_pcg_lm_trajectory_matches_direct(gpu):
+    """LM with linearSolverType = Iterative (tight CG tolerances) walks the same accept/reject sequence as with the
+    Cholesky solve: dubrovnik-3-7, tests/testGeneralSFMFactorB.cpp protocol -> 0.0199833."""
+    from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+    from gtsam_amd.params import PCGSolverParameters
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_timesfm(g)
+    prm = LMP(); prm.linearSolverType = "Iterative"; prm.iterativeParams = PCGSolverParameters(3000, 1, 1e-12, 1e-24)
+    opt = DeviceLevenbergMarquardt(p, v0, prm)
+    opt.optimize()
+    tr = np.array(opt.trace)[:, :3]
+    ref_tr = g["default_trace"]
+    assert tr.shape == ref_tr.shape and np.array_equal(tr[:, 0], ref_tr[:, 0])
+    assert rel(tr[:, 1], ref_tr[:, 1]) <= 1e-5 and abs(opt.error() - 0.0199833) < 1e-5
+
+
 def test_robust_loss_literal(gpu):
     p, v = PB.robust_prior_literal()
     dev = gpu.DeviceGraph(p)

@@ -205,3 +205,38 @@ def test_oracle_pose2_w20000_error_and_jacobians():
     assert int(g["trace"][-1, 0]) == 24 and g["trace"][-1, 2] == 1e5
     assert abs(O.error(p, v0) - float(g["error"])) <= 1e-11 * float(g["error"])
     assert rel(O.jacobians_flat(p, v0, 2)[:512], g["jac2_head"]) <= 1e-12
+
+
+# ---- (4) iterative solver: block-Jacobi PCG on the Schur complement -------------------------
+def test_oracle_pcg_converges_to_the_direct_solution():
+    """preconditionedConjugateGradient restated (ConjugateGradientSolver.h:106-169): with tight tolerances the step equals
+    the Cholesky step; with the reference's default tolerances it stops early at |r|^2 <= max(eps_abs, eps_rel^2 |r0|^2)."""
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_sfmexample(g)
+    st, d_direct, *_ = O.solve_damped(p, v0, 1e-3, False)
+    info = dict(max_iterations=500, epsilon_rel=1e-12, epsilon_abs=1e-24)
+    st2, d_pcg, *_ = O.solve_damped(p, v0, 1e-3, False, pcg=info)
+    assert st == 0 and st2 == 0 and rel(d_pcg, d_direct) <= 1e-9
+    assert 1 <= info["iterations"] <= 200                          # 27 unknowns, badly conditioned (focal lengths vs rotations)
+    loose = dict()                                                  # defaults 500, 1, 1e-3, 1e-3
+    O.solve_damped(p, v0, 1e-3, False, pcg=loose)
+    assert loose["iterations"] < info["iterations"] and loose["gamma"] <= max(1e-3, 1e-6 * loose["gamma0"])
+    # pose graph: between-factor couplings instead of landmarks
+    pg, vg = PB.SYNTH["posegraph_small"]()
+    _, dg, *_ = O.solve_damped(pg, vg, 1e-4, True)
+    _, dgp, *_ = O.solve_damped(pg, vg, 1e-4, True, pcg=dict(epsilon_rel=1e-12, epsilon_abs=1e-24))
+    assert rel(dgp, dg) <= 1e-8
+
+
+def test_oracle_pcg_vs_the_reference_pcg_solver(live_ref):
+    """The reference's own PCGSolver + BlockJacobiPreconditioner on the full damped system (NonlinearOptimizer.cpp:154-172)
+    and the restated PCG on the Schur complement converge to the same step."""
+    if live_ref is None:
+        pytest.skip("live reference not present")
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_sfmexample(g)
+    rg = live_ref.RefGraph(p)
+    _, d_direct, _ = rg.solve(v0, 1e-3, False, ordering_kind=1)
+    d_ref = rg.solve_pcg(v0, 1e-3, False, max_iterations=2000, epsilon_rel=1e-14, epsilon_abs=1e-28)
+    _, d_or, *_ = O.solve_damped(p, v0, 1e-3, False, pcg=dict(epsilon_rel=1e-12, epsilon_abs=1e-24))
+    assert rel(d_ref, d_direct) <= 1e-8 and rel(d_or, d_direct) <= 1e-8 and rel(d_or, d_ref) <= 1e-8

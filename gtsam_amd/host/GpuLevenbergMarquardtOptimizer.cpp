@@ -8,6 +8,8 @@
 #include <gtsam/geometry/Pose2.h>
 #include <gtsam/geometry/Pose3.h>
 #include <gtsam/linear/NoiseModel.h>
+#include <gtsam/linear/PCGSolver.h>
+#include <gtsam/linear/Preconditioner.h>
 #include <gtsam/nonlinear/PriorFactor.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/slam/BetweenFactor.h>
@@ -246,8 +248,25 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
 bool GpuLevenbergMarquardtOptimizer::tryLambdaDevice() {
   Impl& m = *impl_;
   double out[4] = {0, 0, 0, 0};
-  const int rc = gtg_try_lambda(m.h, m.lambda, params_.diagonalDamping, params_.minDiagonal, params_.maxDiagonal, out);
-  check(rc, "gtg_try_lambda");
+  int rc;
+  if (params_.isIterative()) {
+    // NonlinearOptimizer::solve, Iterative branch (NonlinearOptimizer.cpp:154-172): PCGSolverParameters only, and the
+    // device solver is block-Jacobi PCG on the implicit Schur complement (a Dummy preconditioner or a SubgraphSolver is
+    // outside the GPU path).
+    if (!params_.iterativeParams) throw std::runtime_error("NonlinearOptimizer::solve: cg parameter has to be assigned ...");
+    auto pcg = std::dynamic_pointer_cast<PCGSolverParameters>(params_.iterativeParams);
+    if (!pcg) throw std::runtime_error("GpuLevenbergMarquardtOptimizer: only PCGSolverParameters are handled by the GPU path");
+    if (!std::dynamic_pointer_cast<BlockJacobiPreconditionerParameters>(pcg->preconditioner))
+      throw std::runtime_error("GpuLevenbergMarquardtOptimizer: the GPU PCG solver is block-Jacobi preconditioned "
+                               "(set PCGSolverParameters::preconditioner to BlockJacobiPreconditionerParameters)");
+    const double cg[4] = {(double)pcg->maxIterations, (double)pcg->minIterations, pcg->epsilon_rel, pcg->epsilon_abs};
+    int32_t cg_iterations = 0;
+    rc = gtg_try_lambda_pcg(m.h, m.lambda, params_.diagonalDamping, params_.minDiagonal, params_.maxDiagonal, cg, out, &cg_iterations);
+    check(rc, "gtg_try_lambda_pcg");
+  } else {
+    rc = gtg_try_lambda(m.h, m.lambda, params_.diagonalDamping, params_.minDiagonal, params_.maxDiagonal, out);
+    check(rc, "gtg_try_lambda");
+  }
   bool step_is_successful = false, stopSearchingLambda = false;
   double modelFidelity = 0.0, newError = std::numeric_limits<double>::infinity();
   if (rc != GTG_INDETERMINATE) {   // systemSolvedSuccessfully (else: IndeterminantLinearSystemException path, LM.cpp:158-160)

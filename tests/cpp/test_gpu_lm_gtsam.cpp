@@ -9,6 +9,8 @@
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/geometry/Pose2.h>
 #include <gtsam/inference/Symbol.h>
+#include <gtsam/linear/PCGSolver.h>
+#include <gtsam/linear/Preconditioner.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
@@ -32,6 +34,16 @@ static double valuesDiff(const Values& a, const Values& b) {
   double worst = 0;
   for (const auto& kv : a) worst = std::max(worst, kv.value.localCoordinates_(b.at(kv.key)).cwiseAbs().maxCoeff());
   return worst;
+}
+
+// NonlinearOptimizerParams::Iterative with a block-Jacobi PCGSolver, converged tightly: the reference runs CG on the
+// full damped system, the GPU path on its Schur complement -- both then take the step of the direct solvers.
+static LevenbergMarquardtParams iterativeParams(LevenbergMarquardtParams params) {
+  auto pcg = std::make_shared<PCGSolverParameters>(std::make_shared<BlockJacobiPreconditionerParameters>());
+  pcg->maxIterations = 5000; pcg->epsilon_rel = 1e-13; pcg->epsilon_abs = 1e-26;
+  params.linearSolverType = NonlinearOptimizerParams::Iterative;
+  params.iterativeParams = pcg;
+  return params;
 }
 
 static void compare(const char* name, const NonlinearFactorGraph& graph, const Values& initial, const LevenbergMarquardtParams& params,
@@ -86,6 +98,7 @@ int main() {
     for (int i = 0; i < nc; i++) initial.insert(C(i), cams[i].retract((Vector(9) << 0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng), 0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng), N(rng), 0, 0).finished()));
     for (int j = 0; j < np; j++) initial.insert(P(j), Point3(pts[j] + Point3(0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng))));
     compare("BAL legacy/COLAMD", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    compare("BAL legacy/Iterative PCG", graph, initial, iterativeParams(LevenbergMarquardtParams()), 1e-6);
     LevenbergMarquardtParams ceres; LevenbergMarquardtParams::SetCeresDefaults(&ceres);
     Ordering ordering;   // Schur ordering of timing/timeSFMBAL.h:74-83
     for (int j = 0; j < np; j++) ordering.push_back(P(j));
@@ -110,6 +123,7 @@ int main() {
     graph.addPrior(X(0), truth[0], noiseModel::Diagonal::Variances((Vector(6) << 1e-6, 1e-6, 1e-6, 1e-4, 1e-4, 1e-4).finished()));
     for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract((Vector(6) << 0.1 * N(rng), 0.1 * N(rng), 0.1 * N(rng), 0.3 * N(rng), 0.3 * N(rng), 0.3 * N(rng)).finished()));
     compare("Pose3 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    compare("Pose3 graph Iterative PCG", graph, initial, iterativeParams(LevenbergMarquardtParams()), 1e-6);
     // same graph with outlier loop closures and noiseModel::Robust on the loops (Huber) and the odometry (Cauchy)
     NonlinearFactorGraph robust;
     auto rodo = noiseModel::Robust::Create(noiseModel::mEstimator::Cauchy::Create(2.0), odo);

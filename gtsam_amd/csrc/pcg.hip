@@ -13,7 +13,7 @@
 //     y_l = sum_{o in l} w_o        one landmark per lane
 //     out_r = (H_rr + damping) x_r - sum_{o in r} E_o y_l(o) + sum_{between factors (r,s)} A_r^T A_s x_s
 //                                   four wavefronts per camera / pose (E read a second time)
-// i.e. three streaming kernels, 0.35 GB of traffic for the L1723 shape (678 718 observations x 256-byte E slots, twice).
+// i.e. three streaming kernels, 0.35 GB of traffic for the L1723 shape (676 773 observations x 256-byte E slots, twice).
 // The CG scalars stay on the device (no host round trip inside a batch of iterations); the preconditioner is kept as
 // the inverse factors L_r^-1 and applied one lane per (variable, row).  All reductions run in a fixed order.
 // Vectors live in the layout of the reduced system (offset red_off[r], length NP, alignment gaps stay zero).

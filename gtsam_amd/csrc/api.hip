@@ -14,6 +14,7 @@
 #include <thread>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 
 #include "factors.h"
@@ -54,12 +55,15 @@ struct HostIndex {
   std::vector<int32_t> user_order;  // optional reduced ordering (variable ids)
 };
 static std::vector<std::pair<gtg_context*, HostIndex*>> g_index;  // tiny registry (handles are few)
+static std::mutex g_index_mutex;                                   // handles may be created / destroyed from several host threads
 static HostIndex& host_index(gtg_context* c) {
+  std::lock_guard<std::mutex> lock(g_index_mutex);
   for (auto& kv : g_index) if (kv.first == c) return *kv.second;
   g_index.emplace_back(c, new HostIndex);
   return *g_index.back().second;
 }
 static void drop_index(gtg_context* c) {
+  std::lock_guard<std::mutex> lock(g_index_mutex);
   for (size_t i = 0; i < g_index.size(); i++)
     if (g_index[i].first == c) { delete g_index[i].second; g_index.erase(g_index.begin() + i); return; }
 }
@@ -527,16 +531,16 @@ struct PhaseTimer {
   }
   ~PhaseTimer() { if (c.timing) (void)hipEventRecord(b, c.stream); }
 };
-static hipEvent_t g_events[2 * GTG_PH_COUNT];
-static bool g_events_ready = false;
-static void ensure_events() {
-  if (!g_events_ready) { for (auto& e : g_events) check_hip(hipEventCreate(&e), "event"); g_events_ready = true; }
+static void ensure_events(gtg_context& c) {   // the handle's own events, on its device
+  if (!c.phase_events.empty()) return;
+  c.phase_events.resize(2 * GTG_PH_COUNT, nullptr);
+  for (auto& e : c.phase_events) check_hip(hipEventCreate(&e), "event");
 }
 static void collect(gtg_context& c, std::initializer_list<int> phases) {
   if (!c.timing) return;
   for (int ph : phases) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, g_events[2 * ph], g_events[2 * ph + 1]) == hipSuccess) { c.phase_ms[ph] += ms; c.phase_calls[ph]++; }
+    if (hipEventElapsedTime(&ms, c.phase_events[2 * ph], c.phase_events[2 * ph + 1]) == hipSuccess) { c.phase_ms[ph] += ms; c.phase_calls[ph]++; }
   }
 }
 
@@ -570,7 +574,7 @@ int gtg_create(gtg_handle* out, int device_id) {
   gtg_context* c = new gtg_context;
   c->device = device_id;
   check_hip(hipStreamCreate(&c->stream), "hipStreamCreate");
-  ensure_events();
+  ensure_events(*c);
   *out = c;
   return GTG_OK;
   GTG_CATCH
@@ -598,6 +602,8 @@ int gtg_destroy(gtg_handle c) {
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
   c->chol_epoch_dev.free();
+  destroy_chol_streams(*c);
+  for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   drop_index(c);
   delete c;
@@ -780,7 +786,7 @@ int gtg_error(gtg_handle c, double* error) {
   GTG_TRY
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
-  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->values.p, SC_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});
   *error = c->h_scalars[SC_ERROR];
@@ -792,8 +798,8 @@ int gtg_linearize(gtg_handle c) {
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
-  { PhaseTimer t(*c, GTG_PH_LINEARIZE, g_events); launch_linearize(*c); }
-  { PhaseTimer t(*c, GTG_PH_ASSEMBLE, g_events); launch_assemble(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_linearize(*c); }
+  { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c); }
   exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
   check_hip(hipStreamSynchronize(c->stream), "sync");
   collect(*c, {GTG_PH_LINEARIZE, GTG_PH_ASSEMBLE});
@@ -808,8 +814,8 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
-  { PhaseTimer t(*c, GTG_PH_SCHUR, g_events); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
+  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+  { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
   if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs, stored lower tiles only
     const int64_t nb = c->plan.n_exch * kTile * kTile;
     if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
@@ -817,15 +823,15 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     exchange(*c, c->xbuf.p, nb);
     launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
   }
-  { PhaseTimer t(*c, GTG_PH_CHOLESKY, g_events); launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
-  { PhaseTimer t(*c, GTG_PH_SOLVE, g_events);
+  { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data()); launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
+  { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
     launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p);
     launch_back_substitute(*c);
     if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
     launch_scatter_delta(*c); }
-  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, g_events); launch_linear_error(*c); }
-  { PhaseTimer t(*c, GTG_PH_RETRACT, g_events); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
@@ -848,18 +854,18 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
   if (!(lambda > 0.0) || !cg) throw std::invalid_argument("gtg_try_lambda_pcg: lambda must be > 0, cg = {max, min, eps_rel, eps_abs}");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, g_events); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   double g0 = 0.0, g1 = 0.0;
   int its = 0;
-  { PhaseTimer t(*c, GTG_PH_CHOLESKY, g_events);
+  { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
     its = launch_pcg(*c, lambda, diag, dmin, dmax, (int)cg[0], (int)cg[1], cg[2], cg[3], &g0, &g1); }
   if (iterations) *iterations = its;
-  { PhaseTimer t(*c, GTG_PH_SOLVE, g_events);
+  { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
     launch_back_substitute(*c);
     launch_scatter_delta(*c); }
-  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, g_events); launch_linear_error(*c); }
-  { PhaseTimer t(*c, GTG_PH_RETRACT, g_events); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, g_events); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;

@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "kernels.h"
@@ -778,40 +780,27 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 // when it is needed, so it costs one barrier packet (~3 us measured) instead of a fresh signal round trip (~13 us).
 // rest(p) starts after nar(p) so that the two never share CUs (two small MFMA launches side by side double each
 // other's latency).  panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM below.
-struct CholStreams {
-  hipStream_t panel = nullptr;
-
-  hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
-  hipEvent_t done = nullptr, done_tree = nullptr;
-  int reserve = -1;
-  std::vector<hipEvent_t> P, N;
-  hipEvent_t start = nullptr;
-};
-static CholStreams g_cs;
-
-struct TreeStreams {
-  std::vector<hipStream_t> panel, update;   // one pair of streams per concurrently running chain
-  hipStream_t anc = nullptr;                // the updates that cross into ancestor parts: one stream, fixed order
-  std::vector<hipEvent_t> part_ev, join_ev;
-};
-static TreeStreams g_ts;
-
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
+  CholStreams& g_cs = c.cs;
+  TreeStreams& g_ts = c.ts;
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
   const size_t smem_potrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::set<int> attr_set;   // function attributes are per device
+  static std::mutex attr_mutex;
+  std::unique_lock<std::mutex> attr_lock(attr_mutex);
+  if (!attr_set.count(c.device)) {
     check_hip(hipFuncSetAttribute((const void*)k_panel128, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)std::max(smem_potrf, smem_trsm)), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk / 2), "smem attr");
     check_hip(hipFuncSetAttribute((const void*)k_syrk<2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk / 2), "smem attr");
-    attr_set = true;
+    attr_set.insert(c.device);
   }
+  attr_lock.unlock();
   const int npairs = (nt + 1) / 2;
   const long long* flagbase = c.chol_epoch_dev.p;
   hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p);
@@ -1153,14 +1142,30 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
   if (g == 0) y[j] -= ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
 }
 
+// gtg_destroy: the handle's schedule streams and events
+void destroy_chol_streams(gtg_context& c) {
+  CholStreams& cs = c.cs;
+  TreeStreams& ts = c.ts;
+  for (hipStream_t st : {cs.panel, cs.update, ts.anc}) if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : ts.panel) (void)hipStreamDestroy(st);
+  for (hipStream_t st : ts.update) (void)hipStreamDestroy(st);
+  for (hipEvent_t e : {cs.done, cs.done_tree, cs.start}) if (e) (void)hipEventDestroy(e);
+  for (auto* v : {&cs.P, &cs.N, &ts.part_ev, &ts.join_ev}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+  cs = CholStreams(); ts = TreeStreams();
+}
+
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
   const size_t smem_inv = sizeof(double) * 17 * SB * SB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    check_hip(hipFuncSetAttribute((const void*)k_inv_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_inv), "smem attr");
-    attr_set = true;
+  {
+    static std::set<int> attr_set;
+    static std::mutex attr_mutex;
+    std::lock_guard<std::mutex> attr_lock(attr_mutex);
+    if (!attr_set.count(c.device)) {
+      check_hip(hipFuncSetAttribute((const void*)k_inv_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_inv), "smem attr");
+      attr_set.insert(c.device);
+    }
   }
   hipLaunchKernelGGL(k_inv_tiles, dim3((unsigned)nt), dim3(256), smem_inv, c.stream, S, NP, Xinv);
   for (int k = nt - 1; k >= 0; k--) {

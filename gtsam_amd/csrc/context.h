@@ -79,9 +79,29 @@ struct FactorTables {
 
 }  // namespace gt
 
+namespace gt {
+// Streams and events of the factorisation schedule (cholesky.hip) -- owned by the handle: streams and events belong to
+// the device they were created on, and two handles driven from two host threads must not share them.
+struct CholStreams {
+  hipStream_t panel = nullptr;    // high-priority stream of the serial panel chain
+  hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
+  hipEvent_t done = nullptr, done_tree = nullptr, start = nullptr;
+  int reserve = -1;
+  std::vector<hipEvent_t> P, N;   // per column pair: rest(p) finished / chain of pair p finished
+};
+struct TreeStreams {              // elimination-tree schedule (GTG_ND_DEPTH > 0)
+  std::vector<hipStream_t> panel, update;   // one pair of streams per concurrently running chain
+  hipStream_t anc = nullptr;                // the updates that cross into ancestor parts: one stream, fixed order
+  std::vector<hipEvent_t> part_ev, join_ev;
+};
+}  // namespace gt
+
 struct gtg_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  gt::CholStreams cs;
+  gt::TreeStreams ts;
+  std::vector<hipEvent_t> phase_events;   // 2 per phase (gtg_enable_timing)
   int shard = 0, n_shards = 1;
   bool uploaded = false, linearized = false, have_trial = false;
 

@@ -31,6 +31,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
+void destroy_chol_streams(gtg_context& c);
 
 // pcg.hip -----------------------------------------------------------------------------------------
 // Block-Jacobi PCG on the implicit Schur complement (needs launch_point_eliminate first): c.xred = S^-1 b.

@@ -275,6 +275,30 @@ def test_sphere2500_solve_and_full_trajectory(gpu):
     print("sphere2500 outer/inner:", opt.iterations(), opt.getInnerIterations(), "reference:", int(g["iterations"]), int(ref_trace[-1, 0]))
 
 
+def test_two_handles_on_two_host_threads(gpu):
+    """The factorisation schedule's streams and events belong to the handle: two optimizers driven concurrently from
+    two host threads (ctypes releases the GIL inside the library) walk exactly the single-thread trajectories."""
+    import threading
+    from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+    g = load_golden("sphere2500")
+    p, v0 = PB.sphere2500(g)
+
+    def run(out, i):
+        opt = DeviceLevenbergMarquardt(p, v0, LMP())
+        opt.optimize()
+        out[i] = np.array(opt.trace)[:, :3]
+
+    single = [None]
+    run(single, 0)
+    both = [None, None]
+    threads = [threading.Thread(target=run, args=(both, i)) for i in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for tr in both:
+        assert tr is not None and tr.shape == single[0].shape and np.array_equal(tr, single[0])
+    assert abs(single[0][-1, 1] - 1136.95214) < 0.05
+
+
 @pytest.mark.parametrize("n", [5, 100, 128, 300, 1000])
 def test_dense_cholesky_vs_lapack(gpu, n):
     """The frontal kernel alone: L L^T reconstruction 1e-9 like gtsam/base/tests/testCholesky.cpp:26-67,

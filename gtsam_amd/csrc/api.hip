@@ -6,6 +6,8 @@
 // try (inference/VariableIndex-inl.h:27-49, EliminationTree-inst.h:77-155, JunctionTree-inst.h:63-151,
 // linear/Scatter.cpp:39-73).  All arithmetic of the hot path runs in the HIP kernels.
 #include <algorithm>
+#include <atomic>
+#include <exception>
 #include <functional>
 #include <chrono>
 #include <cmath>
@@ -14,6 +16,7 @@
 #include <thread>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 
@@ -84,16 +87,24 @@ struct StageClock {   // GTG_DEBUG_TIMING=1 prints the host-side setup breakdown
   }
 };
 
-template <class F> static void parallel_for(int64_t n, int max_threads, F f) {
-  int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), max_threads);
-  if (n < 4096 || nt <= 1) { f(0, n); return; }
+// host threads of the symbolic analysis: GTG_HOST_THREADS, else the hardware concurrency capped at 32
+static int host_threads() {
+  static const int n = [] {
+    const char* e = std::getenv("GTG_HOST_THREADS");
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    return e ? std::max(1, std::atoi(e)) : std::min(hw, 32);
+  }();
+  return n;
+}
+template <class F> static void run_threads(int nt, F f) {   // f(thread index) on nt threads (the caller is thread 0)
+  if (nt <= 1) { f(0); return; }
   std::vector<std::thread> th;
-  const int64_t chunk = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; t++) {
-    const int64_t b = t * chunk, e = std::min(n, b + chunk);
-    if (b < e) th.emplace_back([=] { f(b, e); });
-  }
+  std::exception_ptr err = nullptr; std::mutex m;
+  auto guarded = [&](int t) { try { f(t); } catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); } };
+  for (int t = 1; t < nt; t++) th.emplace_back(guarded, t);
+  guarded(0);
   for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 // ---- symbolic analysis ------------------------------------------------------------------------------
@@ -209,56 +220,90 @@ static void analyze(gtg_context& c) {
   c.n_hoff = (int64_t)hoff_row.size();
 
   clk.lap("incidence lists");
-  // Schur block pairs: for every landmark, every pair of its observations.  Terms are bucketed by the row
-  // position of the block (counting sort), then each row bucket is sorted by column position (stable: the
-  // generation order = landmark order is kept inside a block, so the summation order is reproducible).
+  // Schur block pairs: for every landmark, every pair of its observations is one term E_a E_b^T of the block
+  // (row = the later position, column = the earlier one).  Terms are bucketed by the row position of their block
+  // (counting sort), then every row bucket is sorted by column position (stable: the generation order = landmark
+  // order is kept inside a block, so the summation order is reproducible).  All passes run on host threads and the
+  // result does not depend on their number: a thread owns a contiguous range of landmarks and writes behind the
+  // terms of the threads before it in every row bucket; rows are sorted independently.
   struct PT { int32_t pb, oa, ob; };
   const int nrv = c.n_red_vars;
-  std::vector<int64_t> row_ptr(nrv + 1, 0);
-  auto for_terms = [&](auto&& emit) {
-    for (int l = 0; l < c.n_lm; l++)
-      for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++)
+  const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), c.n_obs / 16384));
+  std::vector<int32_t> obs_pos(c.n_obs);
+  for (int64_t o = 0; o < c.n_obs; o++) obs_pos[o] = c.h_red_pos[obs_red[o]];
+  auto for_terms = [&](int l0, int l1, auto&& emit) {
+    for (int l = l0; l < l1; l++)
+      for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++) {
+        const int32_t oa0 = lm_obs[a]; const int pa0 = obs_pos[oa0];
         for (int64_t b = lm_obs_ptr[l]; b <= a; b++) {
-          int32_t oa = lm_obs[a], ob = lm_obs[b];
-          int pa = c.h_red_pos[obs_red[oa]], pb = c.h_red_pos[obs_red[ob]];
+          int32_t oa = oa0, ob = lm_obs[b];
+          int pa = pa0, pb = obs_pos[ob];
           if (pa < pb) { std::swap(oa, ob); std::swap(pa, pb); }
           emit(pa, pb, oa, ob);
           if (pa == pb && oa != ob) emit(pa, pb, ob, oa);   // same camera twice
         }
-  };
-  for_terms([&](int pa, int, int32_t, int32_t) { row_ptr[pa + 1]++; });
-  for (int r = 0; r < nrv; r++) row_ptr[r + 1] += row_ptr[r];
-  std::vector<PT> pt(row_ptr[nrv]);
-  { std::vector<int64_t> w(row_ptr.begin(), row_ptr.end() - 1);
-    for_terms([&](int pa, int pb, int32_t oa, int32_t ob) { pt[w[pa]++] = PT{pb, oa, ob}; }); }
-  clk.lap("schur terms bucketed");
-  {  // counting sort by column position inside every row bucket (stable, O(terms))
-    std::vector<PT> tmp;
-    std::vector<int64_t> cnt(nrv + 1, 0);
-    for (int r = 0; r < nrv; r++) {
-      const int64_t b = row_ptr[r], e = row_ptr[r + 1], m = e - b;
-      if (m < 2) continue;
-      tmp.assign(pt.begin() + b, pt.begin() + e);
-      for (int64_t i = 0; i < m; i++) cnt[tmp[i].pb + 1]++;
-      for (int q = 0; q <= r; q++) cnt[q + 1] += cnt[q];          // columns of row r are <= r
-      for (int64_t i = 0; i < m; i++) pt[b + cnt[tmp[i].pb]++] = tmp[i];
-      std::fill(cnt.begin(), cnt.begin() + r + 2, 0);
-    }
-  }
-  clk.lap("schur terms sorted");
-  std::vector<int32_t> pair_row, pair_col, pair_oa(pt.size()), pair_ob(pt.size());
-  std::vector<int64_t> pair_ptr;
-  for (int r = 0; r < nrv; r++)
-    for (int64_t i = row_ptr[r]; i < row_ptr[r + 1]; i++) {
-      if (i == row_ptr[r] || pt[i].pb != pt[i - 1].pb) {
-        pair_ptr.push_back(i);
-        pair_row.push_back(pos_to_red[r]);
-        pair_col.push_back(pos_to_red[pt[i].pb]);
       }
-      pair_oa[i] = pt[i].oa; pair_ob[i] = pt[i].ob;
-    }
-  pair_ptr.push_back((int64_t)pt.size());
-  c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = (int64_t)pt.size();
+  };
+  std::vector<int> lm_cut(nth + 1, c.n_lm);      // landmark ranges with equal numbers of terms
+  {
+    std::vector<int64_t> cum(c.n_lm + 1, 0);
+    for (int l = 0; l < c.n_lm; l++) { const int64_t k = lm_obs_ptr[l + 1] - lm_obs_ptr[l]; cum[l + 1] = cum[l] + k * (k + 1) / 2; }
+    lm_cut[0] = 0;
+    for (int t = 1; t < nth; t++) lm_cut[t] = (int)(std::lower_bound(cum.begin(), cum.end(), cum[c.n_lm] / nth * t) - cum.begin());
+    for (int t = 1; t <= nth; t++) lm_cut[t] = std::min(c.n_lm, std::max(lm_cut[t], lm_cut[t - 1]));
+    lm_cut[nth] = c.n_lm;
+  }
+  std::vector<std::vector<int64_t>> cursor(nth, std::vector<int64_t>(nrv + 1, 0));
+  run_threads(nth, [&](int t) { auto& cnt = cursor[t]; for_terms(lm_cut[t], lm_cut[t + 1], [&](int pa, int, int32_t, int32_t) { cnt[pa]++; }); });
+  std::vector<int64_t> row_ptr(nrv + 1, 0);
+  for (int r = 0; r < nrv; r++) {
+    int64_t at = row_ptr[r];
+    for (int t = 0; t < nth; t++) { const int64_t k = cursor[t][r]; cursor[t][r] = at; at += k; }   // count -> write cursor
+    row_ptr[r + 1] = at;
+  }
+  const int64_t n_terms = row_ptr[nrv];
+  std::unique_ptr<PT[]> pt(new PT[std::max<int64_t>(n_terms, 1)]);       // not value-initialised: first touched by the writers
+  run_threads(nth, [&](int t) { auto& w = cursor[t]; for_terms(lm_cut[t], lm_cut[t + 1], [&](int pa, int pb, int32_t oa, int32_t ob) { pt[w[pa]++] = PT{pb, oa, ob}; }); });
+  clk.lap("schur terms bucketed");
+  // per row bucket: stable counting sort by column position straight into the final term lists + the row's blocks
+  std::unique_ptr<int32_t[]> pair_oa(new int32_t[std::max<int64_t>(n_terms, 1)]), pair_ob(new int32_t[std::max<int64_t>(n_terms, 1)]);
+  struct RowBlocks { std::vector<int32_t> col; std::vector<int64_t> start; };
+  std::vector<RowBlocks> row_blocks(nrv);
+  {
+    std::atomic<int> next{0};
+    run_threads(nth, [&](int) {
+      std::vector<int64_t> cnt(nrv + 2, 0);
+      for (;;) {
+        const int r0 = next.fetch_add(4), r1 = std::min(nrv, r0 + 4);
+        if (r0 >= nrv) break;
+        for (int r = r0; r < r1; r++) {
+          const int64_t b = row_ptr[r], e = row_ptr[r + 1];
+          if (e == b) continue;
+          for (int64_t i = b; i < e; i++) cnt[pt[i].pb + 1]++;
+          RowBlocks& rb = row_blocks[r];
+          for (int q = 0; q <= r; q++) {                       // columns of row r are <= r
+            if (cnt[q + 1]) { rb.col.push_back(q); rb.start.push_back(b + cnt[q]); }
+            cnt[q + 1] += cnt[q];
+          }
+          for (int64_t i = b; i < e; i++) { const int64_t d = b + cnt[pt[i].pb]++; pair_oa[d] = pt[i].oa; pair_ob[d] = pt[i].ob; }
+          std::fill(cnt.begin(), cnt.begin() + r + 2, 0);
+        }
+      }
+    });
+  }
+  pt.reset();
+  clk.lap("schur terms sorted");
+  std::vector<int32_t> pair_row, pair_col;
+  std::vector<int64_t> pair_ptr;
+  { size_t nb = 0;
+    for (int r = 0; r < nrv; r++) nb += row_blocks[r].col.size();
+    pair_row.reserve(nb); pair_col.reserve(nb); pair_ptr.reserve(nb + 1);
+    for (int r = 0; r < nrv; r++)
+      for (size_t k = 0; k < row_blocks[r].col.size(); k++) {
+        pair_row.push_back(pos_to_red[r]); pair_col.push_back(pos_to_red[row_blocks[r].col[k]]); pair_ptr.push_back(row_blocks[r].start[k]);
+      }
+    pair_ptr.push_back(n_terms); }
+  c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = n_terms;
   clk.lap("schur block list");
 
   // ---- fill-reducing ordering of the reduced variables (reverse Cuthill-McKee on the block graph) -------------
@@ -474,7 +519,8 @@ static void analyze(gtg_context& c) {
   up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
   up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
   up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s); up(c.pair_ptr, pair_ptr, s);
-  up(c.pair_oa, pair_oa, s); up(c.pair_ob, pair_ob, s);
+  c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);
+  if (c.n_pair_terms == 0) { c.pair_oa.alloc(1); c.pair_ob.alloc(1); }
 
   // ---- numeric buffers --------------------------------------------------------------------------
   const size_t NP = c.NP;
@@ -615,6 +661,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   if (!c || !p) throw std::invalid_argument("null argument");
   if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::invalid_argument("bad shard / n_shards");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
+  StageClock clk;
   hipStream_t s = c->stream;
   c->shard = shard; c->n_shards = n_shards;
   c->n_vars = p->n_vars;
@@ -677,16 +724,21 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
 
   { // SFM
     std::vector<int32_t> cam, pt, nz; std::vector<double> z;
-    for (int64_t i = 0; i < p->n_sfm; i++) {
-      check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor");
-      if (n_shards > 1 && !own_lm(p->sfm_point[i])) continue;
-      cam.push_back(p->sfm_cam[i]); pt.push_back(p->sfm_point[i]); nz.push_back(p->sfm_noise[i]);
-      z.push_back(p->sfm_z[2 * i]); z.push_back(p->sfm_z[2 * i + 1]);
+    for (int64_t i = 0; i < p->n_sfm; i++) { check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor"); }
+    if (n_shards == 1) {   // the whole table: block copies
+      cam.assign(p->sfm_cam, p->sfm_cam + p->n_sfm); pt.assign(p->sfm_point, p->sfm_point + p->n_sfm);
+      nz.assign(p->sfm_noise, p->sfm_noise + p->n_sfm); z.assign(p->sfm_z, p->sfm_z + 2 * p->n_sfm);
+    } else {
+      for (int64_t i = 0; i < p->n_sfm; i++) {
+        if (!own_lm(p->sfm_point[i])) continue;
+        cam.push_back(p->sfm_cam[i]); pt.push_back(p->sfm_point[i]); nz.push_back(p->sfm_noise[i]);
+        z.push_back(p->sfm_z[2 * i]); z.push_back(p->sfm_z[2 * i + 1]);
+      }
     }
     f.n_sfm = (int64_t)cam.size();
     up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
     f.sfm_J.alloc(std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
-    hi.sfm_cam = cam; hi.sfm_point = pt;
+    hi.sfm_cam = std::move(cam); hi.sfm_point = std::move(pt);
   }
   { // projection
     std::vector<int32_t> pose, pt, nz, cal, sen; std::vector<double> z;
@@ -738,6 +790,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
     f.prior_J.alloc(std::max<size_t>((size_t)kPriorRec * f.n_prior, 1));
     hi.prior_var = var;
   }
+  clk.lap("factor tables (shard filter + upload)");
   analyze(*c);
   c->uploaded = true; c->linearized = false; c->have_trial = false;
   return GTG_OK;

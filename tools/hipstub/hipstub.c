@@ -1,0 +1,133 @@
+/* hipstub.c -- a DRY-RUN HIP runtime for profiling and testing the HOST side of libgtsam_amd.so in a container that has
+ * no GPU (symbolic analysis, schedule construction, launch issue order, host cost per launch).
+ *
+ * TEST / PROFILING INFRASTRUCTURE ONLY.  It is never linked into, loaded by or shipped with the product: it only takes
+ * effect when a developer preloads it explicitly (LD_PRELOAD=tools/hipstub/libhipstub.so, see tools/host_profile.py and
+ * tests/test_host_analysis.py).  "Device" memory is host memory, copies are memcpy, kernels DO NOT RUN (hipLaunchKernel
+ * only counts), so nothing numeric comes out of a process that runs under it -- it is not a CPU fallback.
+ *
+ * The entry points are the ones `nm -D --undefined-only gtsam_amd/lib/libgtsam_amd.so | grep hip` lists.
+ * Counters: hipstub_launches(), hipstub_bytes_h2d(), hipstub_allocated() (plain C, read through ctypes).
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef struct { unsigned x, y, z; } dim3s;
+
+static long long g_launches, g_h2d, g_alloc, g_streams, g_events;
+
+/* every host-to-device copy is recorded as (bytes, FNV-1a hash of the bytes): two builds of the library that produce the same
+ * multiset of records for the same problem have uploaded identical tables (tests/test_host_analysis.py) */
+#define HIPSTUB_MAX_REC 8192
+static struct { long long n; unsigned long long h; } g_rec[HIPSTUB_MAX_REC];
+static int g_nrec;
+static void record_h2d(const void* s, size_t n) {
+  static int off = -1;   /* HIPSTUB_NO_HASH=1: timing runs (hashing ~100 MB of uploads costs tens of ms) */
+  if (off < 0) off = getenv("HIPSTUB_NO_HASH") != NULL;
+  if (off) return;
+  const unsigned char* p = (const unsigned char*)s;
+  unsigned long long h = 1469598103934665603ull;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) { unsigned long long w; memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; }
+  for (; i < n; i++) h = (h ^ p[i]) * 1099511628211ull;
+  int k = __atomic_fetch_add(&g_nrec, 1, __ATOMIC_RELAXED);
+  if (k < HIPSTUB_MAX_REC) { g_rec[k].n = (long long)n; g_rec[k].h = h; }
+}
+int hipstub_h2d_count(void) { return g_nrec < HIPSTUB_MAX_REC ? g_nrec : HIPSTUB_MAX_REC; }
+void hipstub_h2d_record(int i, long long* n, unsigned long long* h) { *n = g_rec[i].n; *h = g_rec[i].h; }
+
+long long hipstub_launches(void) { return g_launches; }
+long long hipstub_bytes_h2d(void) { return g_h2d; }
+long long hipstub_allocated(void) { return g_alloc; }
+void hipstub_reset(void) { g_launches = 0; g_h2d = 0; g_nrec = 0; }
+
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* ---- module registration (what hipcc's host stubs call at load time) ---- */
+void** __hipRegisterFatBinary(const void* data) { (void)data; static void* h; return &h; }
+void __hipUnregisterFatBinary(void** h) { (void)h; }
+void __hipRegisterFunction(void** m, const void* host, char* dev, const char* name, unsigned tl, void* tid, void* bid,
+                           void* bd, void* gd, int* ws) {
+  (void)m; (void)host; (void)dev; (void)name; (void)tl; (void)tid; (void)bid; (void)bd; (void)gd; (void)ws;
+}
+void __hipRegisterVar(void** m, void* var, char* hv, char* dv, int ext, size_t size, int c, int g) {
+  (void)m; (void)var; (void)hv; (void)dv; (void)ext; (void)size; (void)c; (void)g;
+}
+
+/* <<<>>> launches: push/pop of the call configuration, then hipLaunchKernel */
+static __thread struct { dim3s g, b; size_t shmem; hipStream_t s; } g_cfg;
+hipError_t __hipPushCallConfiguration(dim3s grid, dim3s block, size_t shmem, hipStream_t s) {
+  g_cfg.g = grid; g_cfg.b = block; g_cfg.shmem = shmem; g_cfg.s = s; return 0;
+}
+hipError_t __hipPopCallConfiguration(dim3s* grid, dim3s* block, size_t* shmem, hipStream_t* s) {
+  *grid = g_cfg.g; *block = g_cfg.b; *shmem = g_cfg.shmem; *s = g_cfg.s; return 0;
+}
+hipError_t hipLaunchKernel(const void* f, dim3s grid, dim3s block, void** args, size_t shmem, hipStream_t s) {
+  (void)f; (void)grid; (void)block; (void)args; (void)shmem; (void)s;
+  __atomic_add_fetch(&g_launches, 1, __ATOMIC_RELAXED);
+  return 0;
+}
+hipError_t hipFuncSetAttribute(const void* f, int attr, int v) { (void)f; (void)attr; (void)v; return 0; }
+
+/* ---- devices ---- */
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+hipError_t hipSetDevice(int d) { (void)d; return 0; }
+hipError_t hipGetLastError(void) { return 0; }
+const char* hipGetErrorString(hipError_t e) { (void)e; return "hipstub: no error"; }
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { if (lo) *lo = 0; if (hi) *hi = -1; return 0; }
+/* hipDeviceProp_t (R0600) is large; the library reads multiProcessorCount only.  Fill the whole struct with a value
+ * that is sensible for every int field it could look at (256 CUs). */
+hipError_t hipGetDevicePropertiesR0600(void* prop, int dev) {
+  (void)dev;
+  int* p = (int*)prop;
+  for (size_t i = 0; i < 1472 / sizeof(int); i++) p[i] = 256;
+  return 0;
+}
+
+/* ---- memory ---- */
+hipError_t hipMalloc(void** p, size_t n) {
+  *p = calloc(n ? n : 1, 1);
+  __atomic_add_fetch(&g_alloc, (long long)n, __ATOMIC_RELAXED);
+  return *p ? 0 : 2;
+}
+hipError_t hipFree(void* p) { free(p); return 0; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, int kind) {
+  memcpy(d, s, n);
+  if (kind == 1) { __atomic_add_fetch(&g_h2d, (long long)n, __ATOMIC_RELAXED); record_h2d(s, n); }
+  return 0;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int kind, hipStream_t st) { (void)st; return hipMemcpy(d, s, n, kind); }
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, int kind, hipStream_t st) {
+  (void)st; (void)kind;
+  for (size_t r = 0; r < h; r++) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+  return 0;
+}
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) { (void)st; memset(d, v, n); return 0; }
+
+/* ---- streams and events ---- */
+static hipError_t new_stream(hipStream_t* s) { *s = malloc(8); g_streams++; return 0; }
+hipError_t hipStreamCreate(hipStream_t* s) { return new_stream(s); }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned f) { (void)f; return new_stream(s); }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int p) { (void)f; (void)p; return new_stream(s); }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned n, const unsigned* m) { (void)n; (void)m; return new_stream(s); }
+hipError_t hipStreamDestroy(hipStream_t s) { free(s); return 0; }
+hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return 0; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned f) { (void)s; (void)e; (void)f; return 0; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = calloc(1, sizeof(double)); g_events++; return 0; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned f) { (void)f; return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) { free(e); return 0; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { (void)s; if (e) *(double*)e = now_ms(); return 0; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double*)b - *(double*)a); return 0; }
+hipError_t hipEventSynchronize(hipEvent_t e) { (void)e; return 0; }
+hipError_t hipDeviceSynchronize(void) { return 0; }

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Host-side profile of gtg_create + gtg_upload_problem (symbolic analysis, schedule construction, table uploads) WITHOUT a GPU.
+
+Runs the product library under tools/hipstub (a dry-run HIP runtime: device memory = host memory, kernels do not run), so
+only host code executes.  Prints the setup breakdown (GTG_DEBUG_TIMING) and a signature of everything the library
+uploaded (sorted (bytes, hash) records): two builds that print the same signature built identical device tables.
+
+    python tools/host_profile.py [ladybug1723|venice1778|dubrovnik16|sphere2500|w20000|dubrovnik_3_7] [--shards N] [--sig-only]
+
+Development tool only -- never used by the product path, the tests' GPU legs, smoke() or bench.py.
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tools", "hipstub", "libhipstub.so")
+
+
+def build_stub():
+    src = os.path.join(ROOT, "tools", "hipstub", "hipstub.c")
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-o", STUB, src], check=True)
+    return STUB
+
+
+def problem_for(name):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import bal_problem
+    from tests import problems as PB
+    gold = os.path.join(ROOT, "tests", "golden")
+    if name == "ladybug1723": return bal_problem(*D.ladybug_1723())
+    if name == "venice1778": return bal_problem(*D.venice_1778())
+    if name == "dubrovnik16": return bal_problem(*D.dubrovnik_16())
+    if name == "sphere2500": return PB.sphere2500(dict(np.load(os.path.join(gold, "sphere2500.npz"))))
+    if name == "w20000": return PB.pose2_graph(dict(np.load(os.path.join(gold, "pose2_w20000.npz"))))
+    if name == "dubrovnik_3_7": return PB.dubrovnik_timesfm(dict(np.load(os.path.join(gold, "dubrovnik_3_7.npz"))))
+    if name.startswith("bal:"):   # bal:<cams>:<points>:<seed>
+        _, nc, npt, seed = name.split(":")
+        return bal_problem(*D.synthetic_bal(int(nc), int(npt), seed=int(seed)))
+    if name.startswith("baldup:"):   # the same, with every 7th observation duplicated (a camera seeing a landmark twice)
+        _, nc, npt, seed = name.split(":")
+        pr, v0 = bal_problem(*D.synthetic_bal(int(nc), int(npt), seed=int(seed)))
+        idx = np.arange(0, pr.n_sfm, 7)
+        pr.sfm_cam = np.concatenate([pr.sfm_cam, pr.sfm_cam[idx]]); pr.sfm_point = np.concatenate([pr.sfm_point, pr.sfm_point[idx]])
+        pr.sfm_noise = np.concatenate([pr.sfm_noise, pr.sfm_noise[idx]])
+        pr.sfm_z = np.concatenate([pr.sfm_z, (pr.sfm_z.reshape(-1, 2)[idx] + 0.25).reshape(-1)])
+        return pr, v0
+    raise SystemExit(f"unknown workload {name}")
+
+
+def child(args):
+    """Runs inside the LD_PRELOAD=libhipstub.so process."""
+    stub = ctypes.CDLL(STUB)
+    stub.hipstub_h2d_record.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_ulonglong)]
+    problem, _ = problem_for(args.workload)
+    from gtsam_amd import lib as L
+    out = {"workload": args.workload, "shards": args.shards, "runs": []}
+    for shard in range(args.shards):
+        best = None
+        for rep in range(args.reps):
+            stub.hipstub_reset()
+            t = time.perf_counter()
+            g = L.DeviceGraph(problem, shard=shard, n_shards=args.shards, allreduce=(lambda p, n, s: None) if args.shards > 1 else None)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+            recs = []
+            n = ctypes.c_longlong(); h = ctypes.c_ulonglong()
+            for i in range(stub.hipstub_h2d_count()):
+                stub.hipstub_h2d_record(i, ctypes.byref(n), ctypes.byref(h))
+                recs.append((n.value, h.value))
+            info = {"reduced_dim": int(g.reduced_dim), "cholesky_gflop": g.cholesky_flops() / 1e9, "h2d_bytes": int(stub.hipstub_bytes_h2d())}
+            g.close()
+        sig = hashlib.sha256(json.dumps(sorted(recs)).encode()).hexdigest()[:16]
+        out["runs"].append({"shard": shard, "setup_ms_best": best * 1e3, "uploads": len(recs), "signature": sig, **info})
+    print("HOSTPROFILE " + json.dumps(out), flush=True)
+
+
+def run(workload, shards=1, reps=3, env_extra=None, quiet=False):
+    """Spawn the dry-run child; returns the parsed record."""
+    build_stub()
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = STUB
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), workload, "--shards", str(shards), "--reps", str(reps), "--child"],
+                       env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host profile child failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
+    if not quiet:
+        sys.stderr.write(r.stderr)
+    for line in r.stdout.splitlines():
+        if line.startswith("HOSTPROFILE "):
+            return json.loads(line[len("HOSTPROFILE "):])
+    raise RuntimeError("no HOSTPROFILE line:\n" + r.stdout[-2000:])
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", nargs="?", default="ladybug1723")
+    ap.add_argument("--shards", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--child", action="store_true")
+    ap.add_argument("--sig-only", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        child(a)
+    else:
+        rec = run(a.workload, a.shards, a.reps, env_extra=None if a.sig_only else {"GTG_DEBUG_TIMING": "1", "HIPSTUB_NO_HASH": "1"}, quiet=a.sig_only)
+        print(json.dumps(rec, indent=1))

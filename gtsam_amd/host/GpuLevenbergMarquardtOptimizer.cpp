@@ -16,7 +16,11 @@
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
 
+#include <chrono>
 #include <cmath>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
 #include <limits>
 #include <map>
 #include <stdexcept>
@@ -41,6 +45,7 @@ struct GpuLevenbergMarquardtOptimizer::Impl {
   // device-side copies of the LM state while optimize() keeps Values on the GPU
   double error = 0, lambda = 0, factor = 0;
   size_t iterations = 0; int inner = 0;
+  std::chrono::high_resolution_clock::time_point start = std::chrono::high_resolution_clock::now();   // logFile's seconds column
   ~Impl() { if (h) gtg_destroy(h); }
 };
 
@@ -247,6 +252,11 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
 // LevenbergMarquardtOptimizer::tryLambda (LM.cpp:121-270) with solve / error / retract on the device.
 bool GpuLevenbergMarquardtOptimizer::tryLambdaDevice() {
   Impl& m = *impl_;
+  using std::cout; using std::endl;
+  const bool verbose = params_.verbosityLM >= LevenbergMarquardtParams::TRYLAMBDA;
+  const auto tryStart = std::chrono::high_resolution_clock::now();
+  if (verbose) cout << "trying lambda = " << m.lambda << endl;
+  if (params_.verbosityLM >= LevenbergMarquardtParams::DAMPED) cout << "building damped system with lambda " << m.lambda << endl;
   double out[4] = {0, 0, 0, 0};
   int rc;
   if (params_.isIterative()) {
@@ -268,20 +278,37 @@ bool GpuLevenbergMarquardtOptimizer::tryLambdaDevice() {
     check(rc, "gtg_try_lambda");
   }
   bool step_is_successful = false, stopSearchingLambda = false;
-  double modelFidelity = 0.0, newError = std::numeric_limits<double>::infinity();
-  if (rc != GTG_INDETERMINATE) {   // systemSolvedSuccessfully (else: IndeterminantLinearSystemException path, LM.cpp:158-160)
+  double modelFidelity = 0.0, newError = std::numeric_limits<double>::infinity(), costChange = 0.0;
+  const bool systemSolvedSuccessfully = rc != GTG_INDETERMINATE;   // else: IndeterminantLinearSystemException path, LM.cpp:158-160
+  if (systemSolvedSuccessfully) {
+    if (verbose) cout << "linear delta norm = " << out[3] << endl;
     const double oldLinearizedError = out[0], newlinearizedError = out[1];
     const double linearizedCostChange = oldLinearizedError - newlinearizedError;
+    if (verbose) cout << "newlinearizedError = " << newlinearizedError << "  linearizedCostChange = " << linearizedCostChange << endl;
     if (linearizedCostChange >= 0) {
       newError = out[2];
-      const double costChange = m.error - newError;
+      if (verbose) cout << "calculating error:" << endl << "old error (" << m.error << ") new (tentative) error (" << newError << ")" << endl;
+      costChange = m.error - newError;
       if (linearizedCostChange > std::numeric_limits<double>::epsilon() * oldLinearizedError) {
         modelFidelity = costChange / linearizedCostChange;
         step_is_successful = modelFidelity > params_.minModelFidelity;
+        if (verbose) cout << "modelFidelity: " << modelFidelity << endl;
       }
       const double minAbsoluteTolerance = params_.relativeErrorTol * m.error;
-      if (std::abs(costChange) < minAbsoluteTolerance) stopSearchingLambda = true;
+      if (std::abs(costChange) < minAbsoluteTolerance) {
+        if (verbose)
+          cout << "abs(costChange)=" << std::abs(costChange) << "  minAbsoluteTolerance=" << minAbsoluteTolerance
+               << " (relativeErrorTol=" << params_.relativeErrorTol << ")" << endl;
+        stopSearchingLambda = true;
+      }
     }
+  }
+  if (params_.verbosityLM == LevenbergMarquardtParams::SUMMARY) {   // LM.cpp:223-242
+    const double iterationTime = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - tryStart).count() / 1e6;
+    if (m.iterations == 0) cout << "iter      cost      cost_change    lambda  success iter_time" << endl;
+    cout << std::setw(4) << m.iterations << " " << std::setw(12) << newError << " " << std::setw(12) << std::setprecision(2)
+         << costChange << " " << std::setw(10) << std::setprecision(2) << m.lambda << " " << std::setw(6)
+         << systemSolvedSuccessfully << " " << std::setw(10) << std::setprecision(2) << iterationTime << endl;
   }
   if (step_is_successful) {   // decreaseLambda, LevenbergMarquardtState.h:81-94
     double newLambda = m.lambda, newFactor = m.factor;
@@ -292,16 +319,44 @@ bool GpuLevenbergMarquardtOptimizer::tryLambdaDevice() {
     m.error = newError; m.iterations += 1; m.inner += 1; m.host_values_stale = true;
     return true;
   } else if (!stopSearchingLambda) {   // increaseLambda, LevenbergMarquardtState.h:70-76
+    if (verbose) cout << "increasing lambda" << endl;
     m.lambda *= m.factor; m.inner += 1;
     if (!params_.useFixedLambdaFactor) m.factor *= 2.0;
-    return m.lambda >= params_.lambdaUpperBound;
+    if (m.lambda >= params_.lambdaUpperBound) {
+      if (params_.verbosity >= NonlinearOptimizerParams::TERMINATION || params_.verbosityLM == LevenbergMarquardtParams::SUMMARY)
+        cout << "Warning:  Levenberg-Marquardt giving up because cannot decrease error with maximum lambda" << endl;
+      return true;
+    }
+    return false;
   }
+  if (verbose) cout << "Levenberg-Marquardt: stopping as relative cost reduction is small" << endl;
   return true;
 }
 
+// writeLogFile, LM.cpp:101-118: inner iterations, seconds, error, lambda, outer iterations
+void GpuLevenbergMarquardtOptimizer::writeLogFileDevice(double currentError) {
+  const Impl& m = *impl_;
+  if (params_.logFile.empty()) return;
+  std::ofstream os(params_.logFile.c_str(), std::ios::app);
+  const double timeSpent = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - m.start).count() / 1e6;
+  os << m.inner << "," << timeSpent << "," << currentError << "," << m.lambda << "," << m.iterations << std::endl;
+}
+
+// LevenbergMarquardtOptimizer::iterate (LM.cpp:273-308) on the device state
+void GpuLevenbergMarquardtOptimizer::iterateDevice() {
+  Impl& m = *impl_;
+  if (params_.verbosityLM >= LevenbergMarquardtParams::DAMPED) std::cout << "linearizing = " << std::endl;
+  check(gtg_linearize(m.h), "gtg_linearize");
+  if (m.inner == 0) {   // write initial error
+    writeLogFileDevice(m.error);
+    if (params_.verbosityLM == LevenbergMarquardtParams::SUMMARY)
+      std::cout << "Initial error: " << m.error << ", values: " << m.keys.size() << std::endl;
+  }
+  while (!tryLambdaDevice()) writeLogFileDevice(m.error);
+}
+
 GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::iterate() {
-  check(gtg_linearize(impl_->h), "gtg_linearize");
-  while (!tryLambdaDevice()) {}
+  iterateDevice();
   syncValuesToHost(true);   // iterate() is a public entry point: values()/error()/lambda() must be current
   return std::make_shared<GaussianFactorGraph>();
 }
@@ -309,18 +364,33 @@ GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::iterate() {
 const Values& GpuLevenbergMarquardtOptimizer::optimize() {
   Impl& m = *impl_;
   const LevenbergMarquardtParams& p = params_;
+  using std::cout; using std::endl;
   double currentError = m.error;
-  if (currentError <= p.errorTol || m.iterations >= p.maxIterations) return values();
+  if (currentError <= p.errorTol) {
+    if (p.verbosity >= NonlinearOptimizerParams::ERROR) cout << "Exiting, as error = " << currentError << " < " << p.errorTol << endl;
+    return values();
+  }
+  if (p.verbosity >= NonlinearOptimizerParams::VALUES) values().print("Initial values");
+  if (p.verbosity >= NonlinearOptimizerParams::ERROR) cout << "Initial error: " << currentError << endl;
+  if (m.iterations >= p.maxIterations) {
+    if (p.verbosity >= NonlinearOptimizerParams::TERMINATION) cout << "iterations: " << m.iterations << " >? " << p.maxIterations << endl;
+    return values();
+  }
   double newError = currentError;
   do {   // NonlinearOptimizer::defaultOptimize, NonlinearOptimizer.cpp:86-105
     currentError = newError;
-    check(gtg_linearize(m.h), "gtg_linearize");
-    while (!tryLambdaDevice()) {}
+    iterateDevice();
     newError = m.error;
     if (p.iterationHook) { syncValuesToHost(false); p.iterationHook(m.iterations, currentError, newError); }
+    if (p.verbosity >= NonlinearOptimizerParams::VALUES) { syncValuesToHost(false); values().print("newValues"); }
+    if (p.verbosity >= NonlinearOptimizerParams::ERROR) cout << "newError: " << newError << endl;
   } while (m.iterations < p.maxIterations &&
            !checkConvergence(p.relativeErrorTol, p.absoluteErrorTol, p.errorTol, currentError, newError, p.verbosity) &&
            std::isfinite(currentError));
+  if (p.verbosity >= NonlinearOptimizerParams::TERMINATION) {
+    cout << "iterations: " << m.iterations << " >? " << p.maxIterations << endl;
+    if (m.iterations >= p.maxIterations) cout << "Terminating because reached maximum iterations" << endl;
+  }
   syncValuesToHost(true);
   return values();
 }

@@ -44,6 +44,8 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   std::unique_ptr<Impl> impl_;
   void init(const gtsam::Values& initial, int device);
   bool tryLambdaDevice();            // LevenbergMarquardtOptimizer::tryLambda restated
+  void iterateDevice();              // LevenbergMarquardtOptimizer::iterate restated (logFile rows, SUMMARY header)
+  void writeLogFileDevice(double currentError);
   void syncValuesToHost(bool force);
 };
 

@@ -128,6 +128,20 @@ class RefGraph:
         lib().ref_graph_retract(self.h, _p(v), _p(d), _p(out))
         return out
 
+    def lm_logfile(self, values0, params, ordering_kind=0):
+        """The reference's optimize() with params.logFile set -> rows (inner, seconds, error, lambda, outer) of the CSV
+        written by LevenbergMarquardtOptimizer::writeLogFile."""
+        import os, tempfile
+        v = np.ascontiguousarray(values0, np.float64)
+        rp = lm_params_struct(params, ordering_kind)
+        fd, path = tempfile.mkstemp(suffix=".csv"); os.close(fd); os.unlink(path)
+        try:
+            lib().ref_graph_lm_logfile(self.h, _p(v), C.byref(rp), path.encode(), None)
+            return np.loadtxt(path, delimiter=",", ndmin=2)
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+
     def lm(self, values0, params, ordering_kind=0, max_trace=1000):
         """Reference LM.  Returns dict(values, trace[n,4]=(inner, error, lambda, seconds), iterations, seconds)."""
         v = np.ascontiguousarray(values0, np.float64)

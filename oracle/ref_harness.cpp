@@ -363,6 +363,38 @@ struct ref_lm_params {
   int32_t ordering_kind;  // 0 COLAMD, 1 Schur (points first)
 };
 
+static LevenbergMarquardtParams lm_params_from(const ref_lm_params* rp) {
+  LevenbergMarquardtParams params;
+  params.maxIterations = rp->max_iterations;
+  params.relativeErrorTol = rp->relative_error_tol;
+  params.absoluteErrorTol = rp->absolute_error_tol;
+  params.errorTol = rp->error_tol;
+  params.lambdaInitial = rp->lambda_initial;
+  params.lambdaFactor = rp->lambda_factor;
+  params.lambdaUpperBound = rp->lambda_upper_bound;
+  params.lambdaLowerBound = rp->lambda_lower_bound;
+  params.minModelFidelity = rp->min_model_fidelity;
+  params.diagonalDamping = rp->diagonal_damping;
+  params.useFixedLambdaFactor = rp->use_fixed_lambda_factor;
+  params.minDiagonal = rp->min_diagonal;
+  params.maxDiagonal = rp->max_diagonal;
+  return params;
+}
+
+// The reference's own optimize() with LevenbergMarquardtParams::logFile set: the CSV that
+// LevenbergMarquardtOptimizer::writeLogFile (LevenbergMarquardtOptimizer.cpp:101-118) appends to `log_path`
+// (inner iterations, seconds, error, lambda, outer iterations).  Returns the outer iteration count.
+int ref_graph_lm_logfile(void* h, const double* values0, const ref_lm_params* rp, const char* log_path, double* values_out) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  LevenbergMarquardtParams params = lm_params_from(rp);
+  params.logFile = log_path;
+  if (rp->ordering_kind == 1) params.ordering = g->ordering(1);
+  LevenbergMarquardtOptimizer lm(g->graph, g->unpack(values0), params);
+  lm.optimize();
+  if (values_out) g->pack(lm.values(), values_out);
+  return (int)lm.iterations();
+}
+
 // Runs the reference's LM (defaultOptimize loop restated around lm.iterate() so that a
 // per-outer-iteration trace can be recorded). trace rows: [inner_iterations, error, lambda, seconds].
 int ref_graph_lm(void* h, const double* values0, const ref_lm_params* rp, double* values_out,

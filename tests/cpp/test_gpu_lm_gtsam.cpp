@@ -18,7 +18,11 @@
 
 #include <chrono>
 #include <cstdio>
+#include <fstream>
+#include <array>
 #include <random>
+#include <sstream>
+#include <unistd.h>
 
 using namespace gtsam;
 using symbol_shorthand::C;
@@ -72,6 +76,26 @@ static void compare(const char* name, const NonlinearFactorGraph& graph, const V
   step.iterate();
   EXPECT(std::abs(graph.error(step.values()) - step.error()) <= 1e-9 * step.error() + 1e-12, "iterate(): state not synced");
   EXPECT(step.iterations() == 1, "iterate(): iterations()");
+  // LevenbergMarquardtParams::logFile: both optimizers append the same rows (the seconds column aside)
+  auto logRows = [](const std::string& path) {
+    std::vector<std::array<double, 5>> rows; std::ifstream is(path); std::string line;
+    while (std::getline(is, line)) { std::array<double, 5> r{}; char c; std::istringstream ss(line); ss >> r[0] >> c >> r[1] >> c >> r[2] >> c >> r[3] >> c >> r[4]; rows.push_back(r); }
+    return rows;
+  };
+  const std::string base = "/tmp/gtsam_amd_log_" + std::to_string((long)getpid());
+  LevenbergMarquardtParams lp = params;
+  lp.logFile = base + "_cpu.csv"; std::remove(lp.logFile.c_str());
+  { LevenbergMarquardtOptimizer o(graph, initial, lp); o.optimize(); }
+  const auto rowsCpu = logRows(lp.logFile); std::remove(lp.logFile.c_str());
+  lp.logFile = base + "_gpu.csv"; std::remove(lp.logFile.c_str());
+  { gtsam_amd::GpuLevenbergMarquardtOptimizer o(graph, initial, lp); o.optimize(); }
+  const auto rowsGpu = logRows(lp.logFile); std::remove(lp.logFile.c_str());
+  EXPECT(!rowsCpu.empty() && rowsCpu.size() == rowsGpu.size(), "logFile rows %zu vs %zu", rowsCpu.size(), rowsGpu.size());
+  for (size_t i = 0; i < std::min(rowsCpu.size(), rowsGpu.size()); i++) {
+    EXPECT(rowsCpu[i][0] == rowsGpu[i][0] && rowsCpu[i][4] == rowsGpu[i][4], "logFile row %zu: counters", i);
+    EXPECT(std::abs(rowsCpu[i][2] - rowsGpu[i][2]) <= 1e-4 * std::abs(rowsCpu[i][2]) + 1e-12, "logFile row %zu: error %g vs %g", i, rowsCpu[i][2], rowsGpu[i][2]);
+    EXPECT(std::abs(rowsCpu[i][3] - rowsGpu[i][3]) <= 1e-3 * std::abs(rowsCpu[i][3]), "logFile row %zu: lambda %g vs %g", i, rowsCpu[i][3], rowsGpu[i][3]);
+  }
 }
 
 int main() {

@@ -168,8 +168,28 @@ def pose2():
         print(name, "init", out["error"], "final", r["trace"][-1], "outer", r["iterations"])
 
 
+def logfile():
+    """LevenbergMarquardtParams::logFile: the CSV the reference's own optimize() writes (LevenbergMarquardtOptimizer.cpp:
+    101-118, rows appended in iterate() :283-303) on dubrovnik-3-7-pre and on the noisy pose graph; columns
+    (inner iterations, seconds, error, lambda, outer iterations) at the stream's default precision."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests import problems as PB
+    g = dict(np.load(os.path.join(OUT, "dubrovnik_3_7.npz")))
+    out = {}
+    p, v0 = PB.dubrovnik_timesfm(g)
+    out["timesfm_ceres"] = ref.RefGraph(p).lm_logfile(v0, LMP.CeresDefaults(), 1)
+    out["timesfm_legacy"] = ref.RefGraph(p).lm_logfile(v0, LMP(), 0)
+    p, v0 = PB.dubrovnik_sfmexample(g)
+    out["sfmex_legacy"] = ref.RefGraph(p).lm_logfile(v0, LMP(), 0)
+    np.savez_compressed(os.path.join(OUT, "lm_logfile.npz"), **out)
+    for k, v in out.items():
+        print("logfile", k, v.shape, "last row", v[-1])
+
+
 if __name__ == "__main__":
-    if "--pose2-only" in sys.argv:
+    if "--logfile-only" in sys.argv:
+        logfile()
+    elif "--pose2-only" in sys.argv:
         pose2()
     elif "--robust-only" in sys.argv:
         robust()
@@ -177,3 +197,4 @@ if __name__ == "__main__":
         main()
         robust()
         pose2()
+        logfile()

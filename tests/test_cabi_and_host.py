@@ -121,3 +121,42 @@ def test_check_convergence_semantics():
     assert cc(1e-5, 1e-5, 1.0, 10.0, 0.5)                   # error below errorTol
     assert cc(1e-5, 1e-5, 0.0, 10.0, 11.0)                  # error increased -> "converged" (stops)
     assert not cc(0.0, -1.0, 0.0, 10.0, 10.0)               # relTol 0 disables the relative test
+
+
+@pytest.mark.parametrize("key,which,preset", [("timesfm_ceres", "timesfm", "ceres"), ("timesfm_legacy", "timesfm", "legacy"),
+                                              ("sfmex_legacy", "sfmex", "legacy")])
+def test_logfile_matches_the_reference_csv(monkeypatch, tmp_path, key, which, preset):
+    """LevenbergMarquardtParams::logFile (LevenbergMarquardtOptimizer.cpp:101-118, rows appended at :283-303): same rows
+    as the CSV the real reference wrote for the same problem (fixture lm_logfile.npz from tests/golden/make_golden.py);
+    the seconds column is the only one that may differ."""
+    from gtsam_amd import optimizer
+    monkeypatch.setattr(optimizer, "DeviceGraph", FakeDevice)
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_sfmexample(g) if which == "sfmex" else PB.dubrovnik_timesfm(g)
+    params = LMP.CeresDefaults() if preset == "ceres" else LMP()
+    params.setLogFile(str(tmp_path / "lm.csv"))
+    optimizer.DeviceLevenbergMarquardt(p, v0, params).optimize()
+    mine = np.loadtxt(params.logFile, delimiter=",", ndmin=2)
+    ref = load_golden("lm_logfile")[key]
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine[:, [0, 4]], ref[:, [0, 4]])               # inner / outer iteration counters
+    assert np.allclose(mine[:, [2, 3]], ref[:, [2, 3]], rtol=2e-6)        # error, lambda at the stream's 6 significant digits
+    assert (np.diff(mine[:, 1]) >= 0).all()
+
+
+def test_verbosity_messages(monkeypatch, capsys):
+    """SUMMARY / TRYLAMBDA / TERMINATION print what the reference prints (LM.cpp:137-261, NonlinearOptimizer.cpp:62-231)."""
+    from gtsam_amd import optimizer
+    monkeypatch.setattr(optimizer, "DeviceGraph", FakeDevice)
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_timesfm(g)
+    params = LMP.CeresDefaults(); params.setVerbosityLM("SUMMARY"); params.setVerbosity("TERMINATION")
+    optimizer.DeviceLevenbergMarquardt(p, v0, params).optimize()
+    out = capsys.readouterr().out
+    assert "Initial error: 2764.22, values: 10" in out and "iter      cost      cost_change    lambda  success iter_time" in out
+    assert "iterations: 50 >? 50" in out and "Terminating because reached maximum iterations" in out   # the golden Ceres run ends there
+    params = LMP(); params.setVerbosityLM("TRYLAMBDA"); params.setVerbosity("TERMINATION")
+    optimizer.DeviceLevenbergMarquardt(p, v0, params).optimize()
+    out = capsys.readouterr().out
+    assert "trying lambda = 1e-05" in out and "increasing lambda" in out and "modelFidelity: " in out
+    assert "converged" in out and "relativeDecrease: " in out and "iterations: 13 >? 100" in out

@@ -8,7 +8,13 @@ loader hands to its optimizer:
                                             EDGE3 (roll pitch yaw) / EDGE_SE3:QUAT incl. the t,R -> R,t information
                                             reshuffle :848-853; Gaussian::Information's smart down-casting
                                             gtsam/linear/NoiseModel.cpp:97-110,283-308,624-633)
-Pure host bookkeeping (numpy); nothing here runs per iteration.
+  * read_2d      <-> load2D                 gtsam/slam/dataset.cpp:179-330
+and the writers of results:
+  * write_bal    <-> writeBAL               gtsam/sfm/SfmData.cpp:249-327
+  * write_g2o    <-> writeG2o               gtsam/slam/dataset.cpp:636-735
+BAL files are large (Ladybug-1723: 2.7 M numbers, Venice-1778: 20 M): read_bal / write_bal go through the native parser of
+the C ABI (gtg_io_read_bal / gtg_io_write_bal, gtsam_amd/csrc/io.cpp); read_bal_py is the token-by-token restatement the
+native one is tested against.  Pure host bookkeeping; nothing here runs per iteration.
 """
 from __future__ import annotations
 
@@ -31,7 +37,36 @@ def _rodrigues(w):
 
 
 def read_bal(path):
-    """-> (cams17, pts3, obs_cam, obs_pt, obs_z); observations ordered by track then file order."""
+    """-> (cams17, pts3, obs_cam, obs_pt, obs_z); observations ordered by track then file order.  Native parser
+    (gtg_io_read_bal); raises like SfmData::FromBalFile when the file is missing."""
+    import ctypes as C
+    from . import lib as L
+    lib = L.load()
+    nc, npt, nobs = C.c_int64(), C.c_int64(), C.c_int64()
+    if lib.gtg_io_bal_sizes(str(path).encode(), C.byref(nc), C.byref(npt), C.byref(nobs)) != 0:
+        raise RuntimeError(lib.gtg_io_last_error().decode())
+    cams = np.zeros((nc.value, 17)); pts = np.zeros((npt.value, 3))
+    oc = np.zeros(nobs.value, np.int32); op = np.zeros(nobs.value, np.int32); oz = np.zeros((nobs.value, 2))
+    if lib.gtg_io_read_bal(str(path).encode(), nc.value, npt.value, nobs.value, cams.ctypes.data, pts.ctypes.data,
+                           oc.ctypes.data, op.ctypes.data, oz.ctypes.data) != 0:
+        raise RuntimeError(lib.gtg_io_last_error().decode())
+    return cams, pts, oc, op, oz
+
+
+def write_bal(path, cams, pts, obs_cam, obs_pt, obs_z):
+    """writeBAL (sfm/SfmData.cpp:249-327) of packed SfmCameras (n,17), points (n,3) and track-ordered observations."""
+    from . import lib as L
+    lib = L.load()
+    cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 17); pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    oz = np.ascontiguousarray(obs_z, np.float64).reshape(-1, 2)
+    if lib.gtg_io_write_bal(str(path).encode(), cams.shape[0], pts.shape[0], oc.size, cams.ctypes.data, pts.ctypes.data,
+                            oc.ctypes.data, op.ctypes.data, oz.ctypes.data) != 0:
+        raise RuntimeError(lib.gtg_io_last_error().decode())
+
+
+def read_bal_py(path):
+    """Token-by-token restatement of SfmData::FromBalFile (the check of the native parser; slow on large files)."""
     toks = open(path).read().split()
     n_cam, n_pt, n_obs = int(toks[0]), int(toks[1]), int(toks[2])
     pos = 3
@@ -194,3 +229,67 @@ def read_2d(path):
     return dict(v1=np.array(v1, np.int64), v2=np.array(v2, np.int64), z=zs,
                 noise_kind=np.array(nk, np.int32), noise=np.array(nd, np.float64).reshape(-1, 9),
                 vertex_keys=np.array(vk, np.int64)[order], vertex_poses=vp[order])
+
+
+def _quaternion(R):
+    """Rot3::toQuaternion = Eigen::Quaternion(Matrix3) (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl):
+    -> (x, y, z, w)."""
+    R = np.asarray(R, np.float64).reshape(3, 3)
+    q = np.zeros(4)                                           # x y z w
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0:
+        t = np.sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t
+        q[0] = (R[2, 1] - R[1, 2]) * t; q[1] = (R[0, 2] - R[2, 0]) * t; q[2] = (R[1, 0] - R[0, 1]) * t
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t
+        q[3] = (R[k, j] - R[j, k]) * t; q[j] = (R[j, i] + R[i, j]) * t; q[k] = (R[k, i] + R[i, k]) * t
+    return q
+
+
+def _information(kind, params, dim):
+    """R^T R of a noise-table row (kind, parameters as read_g2o3d / read_2d return them)."""
+    params = np.asarray(params, np.float64)
+    if kind == NOISE_UNIT:
+        return np.eye(dim)
+    if kind == NOISE_ISOTROPIC:
+        return np.eye(dim) / (params[0] * params[0])
+    if kind == NOISE_DIAGONAL:
+        return np.diag(1.0 / (params[:dim] * params[:dim]))
+    R = params[:dim * dim].reshape(dim, dim)
+    return R.T @ R
+
+
+def write_g2o(path, d, vertex_keys=None, vertex_poses=None):
+    """writeG2o (slam/dataset.cpp:636-735): VERTEX_SE2 / VERTEX_SE3:QUAT lines of the estimate, then EDGE_SE2 /
+    EDGE_SE3:QUAT lines of the BetweenFactors with the upper triangle of their information matrix (EDGE_SE3:QUAT in g2o's
+    t,R block order), numbers at the stream's default precision.  `d` is what read_2d / read_g2o3d return; the estimate
+    defaults to d's vertices (pass the optimised poses to write a result)."""
+    vk = d["vertex_keys"] if vertex_keys is None else np.asarray(vertex_keys)
+    vp = d["vertex_poses"] if vertex_poses is None else np.asarray(vertex_poses, np.float64)
+    is3d = d["z"].shape[1] == 12
+    g = lambda x: f"{float(x):g}"      # noqa: E731  (`stream << double`)
+    with open(path, "w") as f:
+        for k, p in zip(vk, vp.reshape(len(vk), 12 if is3d else 3)):
+            if is3d:
+                q = _quaternion(p[:9])
+                f.write("VERTEX_SE3:QUAT " + " ".join([str(int(k))] + [g(x) for x in (p[9], p[10], p[11], q[0], q[1], q[2], q[3])]) + "\n")
+            else:
+                f.write("VERTEX_SE2 " + " ".join([str(int(k))] + [g(x) for x in p[:3]]) + "\n")
+        for a, b, z, kind, params in zip(d["v1"], d["v2"], d["z"], d["noise_kind"], d["noise"]):
+            if is3d:
+                info = _information(int(kind), params, 6)
+                ig = np.eye(6)
+                ig[:3, :3] = info[3:, 3:]; ig[3:, 3:] = info[:3, :3]; ig[:3, 3:] = info[3:, :3]; ig[3:, :3] = info[:3, 3:]
+                q = _quaternion(z[:9])
+                nums = [z[9], z[10], z[11], q[0], q[1], q[2], q[3]] + [ig[i, j] for i in range(6) for j in range(i, 6)]
+                f.write("EDGE_SE3:QUAT " + " ".join([str(int(a)), str(int(b))] + [g(x) for x in nums]) + "\n")
+            else:
+                info = _information(int(kind), params, 3)
+                nums = [z[0], z[1], z[2]] + [info[i, j] for i in range(3) for j in range(i, 3)]
+                f.write("EDGE_SE2 " + " ".join([str(int(a)), str(int(b))] + [g(x) for x in nums]) + "\n")

@@ -26,7 +26,8 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
-           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host"]
+           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host",
+           "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
@@ -79,6 +80,10 @@ def load():
     lib.gtg_reset_timing.argtypes = [C.c_void_p]
     lib.gtg_get_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.gtg_dense_cholesky_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.gtg_io_last_error.restype = C.c_char_p
+    lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
+    lib.gtg_io_write_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
     _lib = lib
     return lib
 

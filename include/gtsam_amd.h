@@ -214,6 +214,21 @@ double gtg_linearize_bytes(gtg_handle h);
  * non-positive pivot (Eigen LLT info, base/cholesky.cpp:124-127). */
 int gtg_dense_cholesky_host(gtg_handle h, double* A, int32_t n, double* rhs_inout /* may be NULL */);
 
+/* ---- wire format on the bundle-adjustment side of the path: BAL text files straight to / from the
+ * SoA arrays of gtg_problem.  Host-only (no GPU needed).  Replaces SfmData::FromBalFile (gtsam/sfm/SfmData.cpp:189-246: every
+ * number goes through a `float`, pose = openGL2gtsam(Rodrigues(w), t), measurement (u, -v), observations grouped by point in
+ * file order) and writeBAL (gtsam/sfm/SfmData.cpp:249-327: precision 20, gtsam2openGL, Rot3::Logmap).
+ *   cams17  : n_cams x 17 = Pose3 (R row-major 9, t 3) + Cal3Bundler (f, k1, k2, u0, v0)   -- the packed SfmCamera value
+ *   points3 : n_points x 3
+ *   obs_*   : n_obs observations (camera index, point index, (u, v)), grouped by point
+ * Errors: GTG_ERR_USAGE with gtg_io_last_error() (file missing = the reference's runtime_error text). */
+const char* gtg_io_last_error(void);
+int gtg_io_bal_sizes(const char* path, int64_t* n_cams, int64_t* n_points, int64_t* n_obs);
+int gtg_io_read_bal(const char* path, int64_t n_cams, int64_t n_points, int64_t n_obs, double* cams17, double* points3,
+                    int32_t* obs_cam, int32_t* obs_point, double* obs_z);
+int gtg_io_write_bal(const char* path, int64_t n_cams, int64_t n_points, int64_t n_obs, const double* cams17,
+                     const double* points3, const int32_t* obs_cam, const int32_t* obs_point, const double* obs_z);
+
 #ifdef __cplusplus
 }
 #endif

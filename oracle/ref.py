@@ -170,6 +170,22 @@ def load_bal(path):
     return cams, pts, oc, op, oz
 
 
+def rewrite_bal(path_in, path_out):
+    """SfmData::FromBalFile(path_in) -> writeBAL(path_out) (sfm/SfmData.cpp:249-327), the reference's own writer."""
+    nc, npt, nobs = C.c_int64(), C.c_int64(), C.c_int64()
+    lib().ref_load_bal(path_in.encode(), C.byref(nc), C.byref(npt), C.byref(nobs))
+    return lib().ref_write_bal(path_out.encode())
+
+
+def rewrite_g2o(path_in, path_out, is3d):
+    """readG2o / load2D(path_in) -> writeG2o(graph, initial, path_out) (slam/dataset.cpp:636-735)."""
+    nb, nv = C.c_int64(), C.c_int64()
+    if is3d:
+        lib().ref_load_g2o3d(path_in.encode(), C.byref(nb), C.byref(nv)); lib().ref_write_g2o3d(path_out.encode())
+    else:
+        lib().ref_load_2d(path_in.encode(), C.byref(nb), C.byref(nv)); lib().ref_write_g2o2d(path_out.encode())
+
+
 def load_g2o3d(path):
     """readG2o(path, is3D=true) (slam/dataset.cpp:621-633) -> dict of arrays."""
     nb, nv = C.c_int64(), C.c_int64()

@@ -513,6 +513,9 @@ int ref_bal_fill(double* cams17, double* pts3, int32_t* obs_cam, int32_t* obs_pt
   return 0;
 }
 
+// writeBAL of what ref_load_bal loaded (sfm/SfmData.cpp:249-327)
+int ref_write_bal(const char* path) { return writeBAL(path, g_bal) ? 0 : 1; }
+
 // 3D pose graph via readG2o(file, is3D=true) (slam/dataset.cpp:621-633, load3D :922-944).
 static NonlinearFactorGraph::shared_ptr g_pg;
 static Values::shared_ptr g_pg_init;
@@ -550,6 +553,10 @@ int ref_g2o3d_fill(int64_t* v1, int64_t* v2, double* z12, int32_t* noise_kind, d
   }
   return 0;
 }
+
+// writeG2o (slam/dataset.cpp:636-735) of the graph + initial estimate that ref_load_g2o3d / ref_load_2d loaded
+int ref_write_g2o3d(const char* path) { writeG2o(*g_pg, *g_pg_init, path); return 0; }
+int ref_write_g2o2d(const char* path);
 
 // 2D pose graph via load2D (slam/dataset.cpp:208-330: VERTEX2 / VERTEX_SE2, EDGE2 / EDGE_SE2 / ODOMETRY).
 static NonlinearFactorGraph::shared_ptr g_pg2;
@@ -589,6 +596,8 @@ int ref_2d_fill(int64_t* v1, int64_t* v2, double* z3, int32_t* noise_kind, doubl
   }
   return 0;
 }
+
+int ref_write_g2o2d(const char* path) { writeG2o(*g_pg2, *g_pg2_init, path); return 0; }
 
 // ---- small-matrix probes used to pin the restated linear algebra --------------------------------
 // gtsam::choleskyPartial (base/cholesky.cpp:107-158) on a col-major... we pass row-major symmetric.

@@ -107,3 +107,90 @@ def test_load2d_reader_g2o_order_on_a_written_file(tmp_path, live_ref):
         for k in ("v1", "v2", "noise_kind", "vertex_keys"):
             assert np.array_equal(d[k], r[k]), k
         assert np.abs(d["noise"] - r["noise"]).max() <= 1e-15 and np.abs(d["z"] - r["z"]).max() <= 1e-15
+
+
+# ---- native BAL parser / writers (gtsam_amd/csrc/io.cpp behind the C ABI; host-only, no GPU) -----------------------------
+def _tokens(path):
+    out = []
+    for t in open(path).read().split():
+        try:
+            out.append(float(t))
+        except ValueError:
+            out.append(t)
+    return out
+
+
+def _same_tokens(a, b, rtol):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        if isinstance(x, str) or isinstance(y, str):
+            assert x == y
+        else:
+            assert abs(x - y) <= rtol * max(abs(x), abs(y)) + 1e-300, (x, y)
+
+
+def test_native_bal_reader_matches_restatement_and_reference():
+    path = DATA + "dubrovnik-3-7-pre.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    nat = io.read_bal(path); py = io.read_bal_py(path)
+    for a, b in zip(nat, py):
+        assert a.shape == b.shape and a.dtype == b.dtype
+    assert np.array_equal(nat[2], py[2]) and np.array_equal(nat[3], py[3]) and np.array_equal(nat[4], py[4])
+    assert np.array_equal(nat[1], py[1]) and np.abs(nat[0] - py[0]).max() <= 1e-15 * np.abs(py[0]).max()
+    g = load_golden("dubrovnik_3_7")                      # what SfmData::FromBalFile returned
+    assert np.array_equal(nat[2], g["obs_cam"]) and np.array_equal(nat[4], g["obs_z"]) and np.array_equal(nat[1], g["pts"])
+    assert np.abs(nat[0] - g["cams"]).max() <= 1e-14 * np.abs(g["cams"]).max()
+
+
+def test_native_bal_roundtrip_and_errors(tmp_path):
+    from gtsam_amd import datasets as D
+    cams, pts, oc, op, oz = D.synthetic_bal(7, 60, seed=5)[:5]
+    order = np.argsort(op, kind="stable")
+    oc, op, oz = np.asarray(oc)[order], np.asarray(op)[order], np.asarray(oz).reshape(-1, 2)[order]
+    p = str(tmp_path / "rt.txt")
+    io.write_bal(p, cams, pts, oc, op, oz)
+    c2, p2, oc2, op2, oz2 = io.read_bal(p)
+    # the reader parses through float32 like the reference; the writer prints 20 digits
+    assert np.array_equal(oc2, oc) and np.array_equal(op2, op)
+    assert np.allclose(oz2, oz, rtol=1e-6, atol=1e-4) and np.allclose(p2, np.asarray(pts).reshape(-1, 3), rtol=1e-6, atol=1e-6)
+    assert np.abs(c2[:, :12] - np.asarray(cams).reshape(-1, 17)[:, :12]).max() <= 1e-5
+    assert np.allclose(c2[:, 12:15], np.asarray(cams).reshape(-1, 17)[:, 12:15], rtol=1e-6)
+    with pytest.raises(RuntimeError, match="can not find the file"):
+        io.read_bal(str(tmp_path / "missing.txt"))
+    (tmp_path / "short.txt").write_text("2 2 3\n0 0 1.0 2.0\n")
+    with pytest.raises(RuntimeError, match="truncated"):
+        io.read_bal(str(tmp_path / "short.txt"))
+    with pytest.raises(RuntimeError, match="grouped by point"):
+        io.write_bal(p, cams, pts, oc[::-1].copy(), op[::-1].copy(), oz[::-1].copy())
+
+
+def test_bal_writer_matches_reference_writer(tmp_path, live_ref):
+    path = DATA + "dubrovnik-3-7-pre.txt"
+    if live_ref is None or not os.path.exists(path):
+        pytest.skip("live reference not present")
+    ref_out = str(tmp_path / "ref.txt"); my_out = str(tmp_path / "mine.txt")
+    assert live_ref.rewrite_bal(path, ref_out) == 0
+    io.write_bal(my_out, *io.read_bal(path))
+    _same_tokens(_tokens(my_out), _tokens(ref_out), 1e-12)
+    # and the reference's loader reads our file back to the same SfmData
+    a = live_ref.load_bal(my_out); b = live_ref.load_bal(path)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.allclose(a[4], b[4], rtol=1e-6)
+    assert np.abs(a[0] - b[0]).max() <= 1e-5 and np.allclose(a[1], b[1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,is3d", [("pose3example.txt", True), ("pose3example-offdiagonal.txt", True), ("sphere2500.txt", True),
+                                       ("noisyToyGraph.txt", False), ("w100.graph", False)])
+def test_g2o_writer_matches_reference_writer(tmp_path, live_ref, name, is3d):
+    path = DATA + name
+    if live_ref is None or not os.path.exists(path):
+        pytest.skip("live reference not present")
+    ref_out = str(tmp_path / "ref.g2o"); my_out = str(tmp_path / "mine.g2o")
+    live_ref.rewrite_g2o(path, ref_out, is3d)
+    d = io.read_g2o3d(path) if is3d else io.read_2d(path)
+    io.write_g2o(my_out, d)
+    _same_tokens(_tokens(my_out), _tokens(ref_out), 2e-5)     # 6 significant digits in the file
+    # reading our own output back gives the graph we wrote (to the printed precision)
+    d2 = io.read_g2o3d(my_out) if is3d else io.read_2d(my_out)
+    assert np.array_equal(d2["v1"], d["v1"]) and np.array_equal(d2["v2"], d["v2"])
+    assert np.abs(d2["z"] - d["z"]).max() <= 2e-5 * max(1.0, np.abs(d["z"]).max())

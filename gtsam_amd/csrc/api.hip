@@ -56,6 +56,10 @@ static inline int tangent_dim(int t) { return t == GTG_VAR_POSE3 ? 6 : t == GTG_
 struct HostIndex {
   std::vector<int32_t> sfm_cam, sfm_point, proj_pose, proj_point, between_v1, between_v2, prior_var;
   std::vector<int32_t> user_order;  // optional reduced ordering (variable ids)
+  // n_shards > 1: the keys of EVERY observation and between factor of the whole graph (all shards).  The structure of
+  // the reduced system -- ordering, offsets, tile schedule, exchange list -- must be identical on every shard, so it is
+  // derived from the whole graph; only the numeric lists (terms, incidence) are the shard's own.
+  std::vector<int32_t> all_obs_red_var, all_obs_point, all_between_v1, all_between_v2;
 };
 static std::vector<std::pair<gtg_context*, HostIndex*>> g_index;  // tiny registry (handles are few)
 static std::mutex g_index_mutex;                                   // handles may be created / destroyed from several host threads
@@ -106,6 +110,8 @@ template <class F> static void run_threads(int nt, F f) {   // f(thread index) o
   for (auto& x : th) x.join();
   if (err) std::rethrow_exception(err);
 }
+
+static void exchange(gtg_context& c, double* ptr, int64_t n);
 
 // ---- symbolic analysis ------------------------------------------------------------------------------
 static void analyze(gtg_context& c) {
@@ -306,6 +312,54 @@ static void analyze(gtg_context& c) {
   c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = n_terms;
   clk.lap("schur block list");
 
+  // ---- block structure of the reduced system: this handle's own blocks, or -- sharded -- those of the WHOLE graph ----
+  // (a shard only has the Schur blocks of its own landmarks; an ordering or a tile list derived from them would differ
+  // from shard to shard and the exchanged buffers would not line up)
+  std::vector<int32_t> sb_row, sb_col;
+  if (c.n_shards > 1) {
+    const size_t words = ((size_t)nrv + 63) / 64;
+    if ((double)nrv * (double)words * 8.0 > 2e9) throw std::invalid_argument("sharded analysis: too many reduced variables for the block bitmap");
+    std::vector<uint64_t> bits((size_t)nrv * words, 0);
+    auto set_block = [&](int ra, int rb) {
+      if (ra == rb) return;
+      const int hi_ = std::max(ra, rb), lo_ = std::min(ra, rb);
+      __atomic_fetch_or(&bits[(size_t)hi_ * words + (size_t)(lo_ >> 6)], (uint64_t)1 << (lo_ & 63), __ATOMIC_RELAXED);
+    };
+    const int64_t n_all = (int64_t)hi.all_obs_point.size();
+    std::vector<int64_t> aptr(c.n_lm + 1, 0);
+    for (int64_t o = 0; o < n_all; o++) {
+      const int l = c.h_lm_index[hi.all_obs_point[o]], r = c.h_red_index[hi.all_obs_red_var[o]];
+      if (l < 0 || r < 0) throw std::invalid_argument("observation factor keys must be (camera / pose, POINT3)");
+      aptr[l + 1]++;
+    }
+    for (int l = 0; l < c.n_lm; l++) aptr[l + 1] += aptr[l];
+    std::vector<int32_t> acam(n_all);
+    { std::vector<int64_t> w(aptr.begin(), aptr.end() - 1);
+      for (int64_t o = 0; o < n_all; o++) acam[w[c.h_lm_index[hi.all_obs_point[o]]]++] = c.h_red_index[hi.all_obs_red_var[o]]; }
+    const int nt_s = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_all / 16384));
+    run_threads(nt_s, [&](int t) {
+      const int l0 = (int)((int64_t)c.n_lm * t / nt_s), l1 = (int)((int64_t)c.n_lm * (t + 1) / nt_s);
+      for (int l = l0; l < l1; l++)
+        for (int64_t a = aptr[l]; a < aptr[l + 1]; a++)
+          for (int64_t b = aptr[l]; b < a; b++) set_block(acam[a], acam[b]);
+    });
+    for (size_t i = 0; i < hi.all_between_v1.size(); i++) {
+      const int r1 = c.h_red_index[hi.all_between_v1[i]], r2 = c.h_red_index[hi.all_between_v2[i]];
+      if (r1 >= 0 && r2 >= 0) set_block(r1, r2);
+    }
+    for (int r = 0; r < nrv; r++)
+      for (size_t w = 0; w < words; w++) {
+        uint64_t m = bits[(size_t)r * words + w];
+        while (m) { const int b = __builtin_ctzll(m); m &= m - 1; sb_row.push_back(r); sb_col.push_back((int)(w * 64 + b)); }
+      }
+    clk.lap("whole-graph block structure (sharded)");
+  }
+  auto for_each_block = [&](auto&& f) {   // every off-diagonal block of the reduced system's structure (reduced indices)
+    if (c.n_shards > 1) { for (size_t i = 0; i < sb_row.size(); i++) f(sb_row[i], sb_col[i]); return; }
+    for (size_t i = 0; i < pair_row.size(); i++) f(pair_row[i], pair_col[i]);
+    for (size_t i = 0; i < hoff_row.size(); i++) f(hoff_row[i], hoff_col[i]);
+  };
+
   // ---- fill-reducing ordering of the reduced variables (reverse Cuthill-McKee on the block graph) -------------
   // The reference gets its elimination order from COLAMD (inference/Ordering.cpp:42-124) unless the user passes
   // one; here the order only decides where each camera/pose block sits in S.  A banded / loop-closing block
@@ -325,8 +379,7 @@ static void analyze(gtg_context& c) {
     const int nrv2 = c.n_red_vars;
     std::vector<std::vector<int32_t>> adj(nrv2);
     auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
-    for (size_t i = 0; i < pair_row.size(); i++) edge(pair_row[i], pair_col[i]);
-    for (size_t i = 0; i < hoff_row.size(); i++) edge(hoff_row[i], hoff_col[i]);
+    for_each_block(edge);
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
     std::vector<int32_t> level(nrv2, -1);
     std::vector<char> active(nrv2, 0);     // node belongs to the subgraph being processed and is not ordered yet
@@ -466,8 +519,7 @@ static void analyze(gtg_context& c) {
         for (int64_t b = b0; b <= b1; b++) B2[(size_t)std::max(a, b) * np2 + std::min(a, b)] = 1;
     };
     for (int r = 0; r < c.n_red_vars; r++) mark(r, r);
-    for (size_t i = 0; i < pair_row.size(); i++) mark(pair_row[i], pair_col[i]);
-    for (size_t i = 0; i < hoff_row.size(); i++) mark(hoff_row[i], hoff_col[i]);
+    for_each_block(mark);
     std::vector<int32_t> pair_part;
     if (!part_of_pos.empty()) {
       pair_part.assign(np2, -1);
@@ -486,8 +538,7 @@ static void analyze(gtg_context& c) {
         for (int64_t a = a0; a <= a1; a++) rhs[(size_t)a] = 1;
       };
       for (int r = 0; r < c.n_red_vars; r++) mark1(r, r);
-      for (size_t i = 0; i < pair_row.size(); i++) mark1(pair_row[i], pair_col[i]);
-      for (size_t i = 0; i < hoff_row.size(); i++) mark1(hoff_row[i], hoff_col[i]);
+      for_each_block(mark1);
       for (int64_t i : c.h_pad_index) T1[(size_t)(i / kTile) * nt + (size_t)(i / kTile)] = 1;
       std::vector<int32_t> ex;
       const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
@@ -497,6 +548,14 @@ static void analyze(gtg_context& c) {
       c.plan.n_exch = (int64_t)ex.size() / 2;
       if (ex.empty()) { ex.push_back(0); ex.push_back(0); }
       up(c.plan.exch, ex, s);
+      // identity of the layout of the reduced system (every shard of a job must arrive at the same one)
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](const void* ptr, size_t bytes) { const unsigned char* q = (const unsigned char*)ptr; for (size_t i = 0; i < bytes; i++) h = (h ^ q[i]) * 1099511628211ull; };
+      const int64_t head[3] = {c.NP, c.n_red, (int64_t)c.n_red_vars};
+      mix(head, sizeof(head)); mix(c.h_red_off.data(), c.h_red_off.size() * sizeof(int64_t));
+      mix(c.h_pad_index.data(), c.h_pad_index.size() * sizeof(int64_t)); mix(B2.data(), B2.size());
+      mix(ex.data(), ex.size() * sizeof(int32_t)); mix(pair_part.data(), pair_part.size() * sizeof(int32_t));
+      c.structure_hash = h;
     }
     clk.lap("cholesky tile schedule");
     if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation, critical path %d of %d column pairs\n",
@@ -546,6 +605,22 @@ static void analyze(gtg_context& c) {
   check_hip(hipMemsetAsync(c.delta_lm.p, 0, sizeof(double) * c.delta_lm.n, s), "memset");
   check_hip(hipStreamSynchronize(s), "sync");
   clk.lap("upload + device buffers");
+
+  // sharded: the buffers the shards exchange only line up if every shard derived the same layout -- check it once, through
+  // the exchange itself (three 20-bit pieces of the layout hash and a 1: the sums must be n_shards times this shard's)
+  if (c.n_shards > 1 && c.allreduce) {
+    double mine[4] = {(double)(c.structure_hash & 0xFFFFF), (double)((c.structure_hash >> 20) & 0xFFFFF), (double)((c.structure_hash >> 40) & 0xFFFFF), 1.0};
+    double sum[4] = {0, 0, 0, 0};
+    check_hip(hipMemcpyAsync(c.scalars.p, mine, sizeof(mine), hipMemcpyHostToDevice, s), "H2D");
+    exchange(c, c.scalars.p, 4);
+    check_hip(hipMemcpyAsync(sum, c.scalars.p, sizeof(sum), hipMemcpyDeviceToHost, s), "D2H");
+    check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * SC_COUNT, s), "memset");
+    check_hip(hipStreamSynchronize(s), "sync");
+    for (int i = 0; i < 4; i++)
+      if (sum[i] != mine[i] * c.n_shards)
+        throw std::runtime_error("sharded upload: the shards disagree on the layout of the reduced system (or the all-reduce spans a "
+                                 "different number of ranks than n_shards)");
+  }
 
   c.chol_flops = c.plan.flops;
   // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements +
@@ -722,6 +797,15 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   { int k = 0; for (int v = 0; v < p->n_vars; v++) if (p->var_type[v] == GTG_VAR_POINT3) lm_rank[v] = k++; }
   auto own_lm = [&](int v) { return lm_rank[v] >= 0 && (lm_rank[v] % n_shards) == shard; };
 
+  hi.all_obs_red_var.clear(); hi.all_obs_point.clear(); hi.all_between_v1.clear(); hi.all_between_v2.clear();
+  if (n_shards > 1) {
+    for (int64_t i = 0; i < p->n_sfm; i++) { check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); }
+    for (int64_t i = 0; i < p->n_proj; i++) { check_var(p->proj_pose[i]); check_var(p->proj_point[i]); }
+    for (int64_t i = 0; i < p->n_between; i++) { check_var(p->between_v1[i]); check_var(p->between_v2[i]); }
+    hi.all_obs_red_var.assign(p->sfm_cam, p->sfm_cam + p->n_sfm); hi.all_obs_red_var.insert(hi.all_obs_red_var.end(), p->proj_pose, p->proj_pose + p->n_proj);
+    hi.all_obs_point.assign(p->sfm_point, p->sfm_point + p->n_sfm); hi.all_obs_point.insert(hi.all_obs_point.end(), p->proj_point, p->proj_point + p->n_proj);
+    hi.all_between_v1.assign(p->between_v1, p->between_v1 + p->n_between); hi.all_between_v2.assign(p->between_v2, p->between_v2 + p->n_between);
+  }
   { // SFM
     std::vector<int32_t> cam, pt, nz; std::vector<double> z;
     for (int64_t i = 0; i < p->n_sfm; i++) { check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor"); }
@@ -1024,6 +1108,7 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
   return GTG_OK;
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
+int64_t gtg_structure_hash(gtg_handle c) { return c ? (int64_t)(c->structure_hash & 0x7FFFFFFFFFFFFFFFull) : -1; }
 double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
 
 // debug only (not in the public header): ms per K=256 trailing update over an m x m tile grid, with ablations

@@ -117,6 +117,7 @@ struct gtg_context {
   // classification: landmark (POINT3 eliminated first) or reduced variable
   int32_t n_lm = 0, n_red_vars = 0;
   int64_t n_red = 0;                            // scalar dimension of the reduced system
+  uint64_t structure_hash = 0;                  // identity of the layout below (ordering, offsets, padding, tile structure): equal on every shard of a job
   int32_t NP = 0;                               // padded dimension of S: n_red + alignment gaps (parts start on 256-column boundaries), multiple of kTile
   std::vector<int64_t> h_pad_index;             // the padded (identity) rows/columns of S
   gt::DevBuf<int64_t> pad_index;

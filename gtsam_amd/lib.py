@@ -26,7 +26,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
-           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host",
+           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -54,7 +54,7 @@ def load():
     lib.gtg_last_error.restype = C.c_char_p
     lib.gtg_version.restype = C.c_char_p
     lib.gtg_phase_name.restype = C.c_char_p
-    for name in ("gtg_values_size", "gtg_tangent_size", "gtg_reduced_dim"):
+    for name in ("gtg_values_size", "gtg_tangent_size", "gtg_reduced_dim", "gtg_structure_hash"):
         getattr(lib, name).restype = C.c_int64
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.gtg_cholesky_flops.restype = C.c_double
@@ -207,6 +207,7 @@ class DeviceGraph:
         return {p: (float(ms[i]), int(calls[i])) for i, p in enumerate(PHASES)}
 
     def cholesky_flops(self): return self.lib.gtg_cholesky_flops(self.h)
+    def structure_hash(self): return int(self.lib.gtg_structure_hash(self.h))
     def linearize_bytes(self): return self.lib.gtg_linearize_bytes(self.h)
 
     def dense_cholesky(self, A, rhs=None):

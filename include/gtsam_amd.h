@@ -207,6 +207,10 @@ const char* gtg_phase_name(int phase);
 /* flops of the dense Cholesky factorisation of the last try (n^3/3 + lower order) and the
  * algorithmic HBM bytes of one linearize pass (DESIGN.md section "rooflines") */
 double gtg_cholesky_flops(gtg_handle h);
+/* identity (63-bit hash) of the layout of the reduced system: elimination order of the reduced variables, their offsets,
+ * padding, tile structure and the list of exchanged tiles.  It is derived from the WHOLE graph, so every shard of one job
+ * reports the same value; gtg_upload_problem verifies that through the all-reduce callback and fails if they differ. */
+int64_t gtg_structure_hash(gtg_handle h);
 double gtg_linearize_bytes(gtg_handle h);
 
 /* standalone kernels exposed for unit parity tests (tests/ only): dense FP64 Cholesky of an

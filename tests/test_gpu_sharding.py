@@ -38,7 +38,7 @@ class TwoWaySum:
         return allreduce
 
 
-@pytest.mark.parametrize("case", ["dubrovnik_sfmex", "bal_small_unit", "posegraph_small"])
+@pytest.mark.parametrize("case", ["dubrovnik_sfmex", "bal_small_unit", "posegraph_small", "bal_60_cameras", "posegraph_200"])
 def test_two_shards_equal_one(case):
     import torch
     assert torch.cuda.is_available()
@@ -47,6 +47,15 @@ def test_two_shards_equal_one(case):
         p, v0 = PB.dubrovnik_sfmexample(load_golden("dubrovnik_3_7")); params = LMP()
     elif case == "bal_small_unit":
         p, v0 = PB.SYNTH[case](); params = LMP.CeresDefaults()
+    elif case == "bal_60_cameras":
+        # 540 reduced dimensions = 5 tiles, RCM-reordered: the shards' layouts only agree because they are derived from
+        # the whole graph (each shard has the Schur blocks of half of the landmarks)
+        from gtsam_amd import datasets as D
+        from gtsam_amd.problem import bal_problem
+        p, v0 = bal_problem(*D.synthetic_bal(60, 6000, seed=7)); params = LMP.CeresDefaults(); params.setMaxIterations(8)
+    elif case == "posegraph_200":
+        from gtsam_amd import datasets as D
+        p, v0 = D.random_pose_graph(200, 60, seed=4); params = LMP(); params.setMaxIterations(10)   # 1200 dimensions, 10 tiles
     else:
         p, v0 = PB.SYNTH[case](); params = LMP()
     single = DeviceLevenbergMarquardt(p, v0, params)
@@ -77,14 +86,18 @@ def test_two_shards_equal_one(case):
         t.join(300)
     for r in res:
         assert not isinstance(r, Exception), r
+    # the sums over shards associate differently from the single handle's: rounding differences are amplified by the
+    # conditioning of the damped system (the two larger cases: thousands of landmarks / a 1200-dimensional pose graph)
+    big = case in ("bal_60_cameras", "posegraph_200")
+    tol_d, tol_e, tol_v = (1e-6, 1e-6, 1e-4) if big else (1e-9, 1e-7, 1e-6)
     for rc, out, d, trace, vals in res:
         assert rc == rc1
-        assert np.abs(d - d1).max() <= 1e-9 * np.abs(d1).max()
-        assert np.allclose(out[:3], out1[:3], rtol=1e-9)
+        assert np.abs(d - d1).max() <= tol_d * np.abs(d1).max()
+        assert np.allclose(out[:3], out1[:3], rtol=max(tol_d, 1e-9))
         ref = np.array(single.trace)[:, :3]
         assert trace.shape == ref.shape and np.array_equal(trace[:, 0], ref[:, 0])
-        assert np.abs(trace[:, 1] - ref[:, 1]).max() <= 1e-7 * np.abs(ref[:, 1]).max()
-        assert np.abs(vals - single.values_packed()).max() <= 1e-6 * np.abs(vals).max()
+        assert np.abs(trace[:, 1] - ref[:, 1]).max() <= tol_e * np.abs(ref[:, 1]).max()
+        assert np.abs(vals - single.values_packed()).max() <= tol_v * np.abs(vals).max()
     # both shards hold identical values (lock-step)
     assert np.array_equal(res[0][4], res[1][4])
 

@@ -65,3 +65,29 @@ def test_camera_seeing_a_landmark_twice(stub):
     # duplicate some observations: the same (camera, landmark) pair twice exercises the diagonal-block terms
     # (E_a E_b^T and E_b E_a^T) of the generator; must not depend on the thread count either
     assert _signature("baldup:40:3000:3", threads=1) == _signature("baldup:40:3000:3", threads=4)
+
+
+def test_world_size_2_gloo_sharded_upload_with_the_real_library(stub):
+    """The N > 1 set-up path end to end on CPU: two `gloo` ranks run the library's sharded gtg_upload_problem under the
+    stub with the REAL all-reduce callback (gtsam_amd.distributed.make_allreduce).  Every shard only has the Schur
+    blocks of its own landmarks, but ordering, offsets, padding, tile schedule and exchange list are derived from the
+    whole graph: both ranks must report the layout of the single-handle run, and the library's own consistency
+    exchange must pass.  (A layout derived from the shard's own blocks differs between shards as soon as the reduced
+    system is reordered, i.e. from 16 cameras up -- the summed buffers would not line up.)"""
+    w = "bal:60:6000:7"
+    recs = HP.run_gloo(w, world=2)
+    assert [r["ok"] for r in recs] == [True, True]
+    single = HP.run(w, shards=1, reps=1, quiet=True)["runs"][0]
+    assert recs[0]["structure_hash"] == recs[1]["structure_hash"] == single["structure_hash"]
+    assert recs[0]["cholesky_gflop"] == recs[1]["cholesky_gflop"] == single["cholesky_gflop"]
+
+
+def test_sharded_upload_fails_loudly_when_ranks_and_shards_do_not_match(stub):
+    recs = HP.run_gloo("bal:60:6000:7", world=2, claim_shards=3)     # the all-reduce spans 2 ranks, the library is told 3
+    assert all(not r["ok"] and "disagree on the layout" in r["error"] for r in recs)
+
+
+def test_three_shards_and_pose_graph_layouts(stub):
+    recs = HP.run_gloo("sphere2500", world=3)                         # between factors go round-robin
+    single = HP.run("sphere2500", shards=1, reps=1, quiet=True)["runs"][0]
+    assert all(r["ok"] and r["structure_hash"] == single["structure_hash"] for r in recs)

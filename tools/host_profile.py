@@ -63,12 +63,20 @@ def child(args):
     problem, _ = problem_for(args.workload)
     from gtsam_amd import lib as L
     out = {"workload": args.workload, "shards": args.shards, "runs": []}
+
+    def lockstep(ptr, n, stream):
+        """Stand-in all-reduce for shards analysed one after the other in this process: as if every shard contributed
+        the same buffer (true for the layout check of gtg_upload_problem, the only exchange of the set-up path)."""
+        buf = np.frombuffer((ctypes.c_double * n).from_address(ptr), dtype=np.float64)
+        buf *= args.shards
+
+    import numpy as np
     for shard in range(args.shards):
         best = None
         for rep in range(args.reps):
             stub.hipstub_reset()
             t = time.perf_counter()
-            g = L.DeviceGraph(problem, shard=shard, n_shards=args.shards, allreduce=(lambda p, n, s: None) if args.shards > 1 else None)
+            g = L.DeviceGraph(problem, shard=shard, n_shards=args.shards, allreduce=lockstep if args.shards > 1 else None)
             dt = time.perf_counter() - t
             best = dt if best is None else min(best, dt)
             recs = []
@@ -76,11 +84,55 @@ def child(args):
             for i in range(stub.hipstub_h2d_count()):
                 stub.hipstub_h2d_record(i, ctypes.byref(n), ctypes.byref(h))
                 recs.append((n.value, h.value))
-            info = {"reduced_dim": int(g.reduced_dim), "cholesky_gflop": g.cholesky_flops() / 1e9, "h2d_bytes": int(stub.hipstub_bytes_h2d())}
+            info = {"reduced_dim": int(g.reduced_dim), "cholesky_gflop": g.cholesky_flops() / 1e9, "h2d_bytes": int(stub.hipstub_bytes_h2d()),
+                    "structure_hash": g.structure_hash()}
             g.close()
         sig = hashlib.sha256(json.dumps(sorted(recs)).encode()).hexdigest()[:16]
         out["runs"].append({"shard": shard, "setup_ms_best": best * 1e3, "uploads": len(recs), "signature": sig, **info})
     print("HOSTPROFILE " + json.dumps(out), flush=True)
+
+
+def gloo_child(args):
+    """One rank of a world_size-N `gloo` job: the library's sharded upload with the REAL all-reduce callback of
+    gtsam_amd.distributed (under the stub the "device" pointers it is handed are host pointers, which is what the gloo
+    path of make_allreduce takes).  Exercises the N > 1 set-up path end to end on CPU: shard filter, whole-graph
+    structure, layout-consistency exchange."""
+    import torch.distributed as dist
+    problem, _ = problem_for(args.workload)
+    from gtsam_amd import lib as L
+    from gtsam_amd.distributed import make_allreduce
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
+    dist.init_process_group("gloo", rank=args.gloo_rank, world_size=args.world)
+    try:
+        n_shards = args.claim_shards or args.world
+        try:
+            g = L.DeviceGraph(problem, shard=args.gloo_rank % n_shards, n_shards=n_shards, allreduce=make_allreduce())
+            out = {"rank": args.gloo_rank, "ok": True, "structure_hash": g.structure_hash(), "reduced_dim": int(g.reduced_dim),
+                   "cholesky_gflop": g.cholesky_flops() / 1e9}
+            g.close()
+        except L.GtsamAmdError as e:
+            out = {"rank": args.gloo_rank, "ok": False, "error": str(e)}
+        print("HOSTPROFILE " + json.dumps(out), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_gloo(workload, world=2, claim_shards=0, timeout=300):
+    """Launch `world` ranks of gloo_child under the stub; returns their records (rank order)."""
+    import socket
+    build_stub()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ); env["LD_PRELOAD"] = STUB
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), workload, "--gloo-rank", str(r), "--world", str(world),
+                               "--port", str(port), "--claim-shards", str(claim_shards)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    recs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=timeout)
+        if pr.returncode != 0:
+            raise RuntimeError(f"gloo rank failed:\n{so[-2000:]}\n{se[-4000:]}")
+        recs += [json.loads(line[len("HOSTPROFILE "):]) for line in so.splitlines() if line.startswith("HOSTPROFILE ")]
+    return sorted(recs, key=lambda r: r["rank"])
 
 
 def run(workload, shards=1, reps=3, env_extra=None, quiet=False):
@@ -108,8 +160,14 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--sig-only", action="store_true")
+    ap.add_argument("--gloo-rank", type=int, default=-1)
+    ap.add_argument("--world", type=int, default=2)
+    ap.add_argument("--port", type=int, default=0)
+    ap.add_argument("--claim-shards", type=int, default=0, help="n_shards passed to the library (default: the world size)")
     a = ap.parse_args()
-    if a.child:
+    if a.gloo_rank >= 0:
+        gloo_child(a)
+    elif a.child:
         child(a)
     else:
         rec = run(a.workload, a.shards, a.reps, env_extra=None if a.sig_only else {"GTG_DEBUG_TIMING": "1", "HIPSTUB_NO_HASH": "1"}, quiet=a.sig_only)

@@ -17,6 +17,8 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <new>
+#include <sys/mman.h>
 #include <mutex>
 #include <stdexcept>
 
@@ -89,6 +91,25 @@ struct StageClock {   // GTG_DEBUG_TIMING=1 prints the host-side setup breakdown
     std::fprintf(stderr, "[gtsam_amd setup] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
     t = n;
   }
+};
+
+// Large scratch arrays of the analysis (tens of MB, first touched by many threads at once): 2 MB aligned and advised to
+// transparent huge pages, so that the first touch is a few dozen page faults instead of tens of thousands serialised on
+// the process' address-space lock.  Not value-initialised.
+template <class T> struct HugeBuf {
+  T* p = nullptr;
+  explicit HugeBuf(size_t n) {
+    const size_t bytes = std::max<size_t>((n * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1), (size_t)2 << 20);
+    p = static_cast<T*>(std::aligned_alloc((size_t)2 << 20, bytes));
+    if (!p) throw std::bad_alloc();
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+  }
+  ~HugeBuf() { std::free(p); }
+  HugeBuf(const HugeBuf&) = delete;
+  HugeBuf& operator=(const HugeBuf&) = delete;
+  T& operator[](size_t i) { return p[i]; }
+  T* get() { return p; }
+  void reset() { std::free(p); p = nullptr; }
 };
 
 // host threads of the symbolic analysis: GTG_HOST_THREADS, else the hardware concurrency capped at 32
@@ -268,11 +289,11 @@ static void analyze(gtg_context& c) {
     row_ptr[r + 1] = at;
   }
   const int64_t n_terms = row_ptr[nrv];
-  std::unique_ptr<PT[]> pt(new PT[std::max<int64_t>(n_terms, 1)]);       // not value-initialised: first touched by the writers
+  HugeBuf<PT> pt((size_t)std::max<int64_t>(n_terms, 1));                 // first touched by the writers
   run_threads(nth, [&](int t) { auto& w = cursor[t]; for_terms(lm_cut[t], lm_cut[t + 1], [&](int pa, int pb, int32_t oa, int32_t ob) { pt[w[pa]++] = PT{pb, oa, ob}; }); });
   clk.lap("schur terms bucketed");
   // per row bucket: stable counting sort by column position straight into the final term lists + the row's blocks
-  std::unique_ptr<int32_t[]> pair_oa(new int32_t[std::max<int64_t>(n_terms, 1)]), pair_ob(new int32_t[std::max<int64_t>(n_terms, 1)]);
+  HugeBuf<int32_t> pair_oa((size_t)std::max<int64_t>(n_terms, 1)), pair_ob((size_t)std::max<int64_t>(n_terms, 1));
   struct RowBlocks { std::vector<int32_t> col; std::vector<int64_t> start; };
   std::vector<RowBlocks> row_blocks(nrv);
   {
@@ -555,6 +576,36 @@ static void analyze(gtg_context& c) {
       mix(head, sizeof(head)); mix(c.h_red_off.data(), c.h_red_off.size() * sizeof(int64_t));
       mix(c.h_pad_index.data(), c.h_pad_index.size() * sizeof(int64_t)); mix(B2.data(), B2.size());
       mix(ex.data(), ex.size() * sizeof(int32_t)); mix(pair_part.data(), pair_part.size() * sizeof(int32_t));
+      // sharded: the block-granular exchange list (diagonal blocks, then the off-diagonal blocks of the whole graph)
+      c.n_xb = 0;
+      {
+        std::vector<int64_t> xro, xco; std::vector<int32_t> xd;
+        for (int r = 0; r < c.n_red_vars; r++) { xro.push_back(c.h_red_off[r]); xco.push_back(c.h_red_off[r]); xd.push_back(c.h_red_dim[r] | (c.h_red_dim[r] << 8)); }
+        for_each_block([&](int ra, int rb) {
+          if (ra == rb) return;                                  // a camera's Schur terms with itself: the diagonal block above
+          const bool a_later = c.h_red_pos[ra] > c.h_red_pos[rb];
+          const int rr = a_later ? ra : rb, rc = a_later ? rb : ra;
+          xro.push_back(c.h_red_off[rr]); xco.push_back(c.h_red_off[rc]); xd.push_back(c.h_red_dim[rr] | (c.h_red_dim[rc] << 8));
+        });
+        if (c.n_shards > 1) { c.n_xb = (int64_t)xd.size(); up(c.xb_row_off, xro, s); up(c.xb_col_off, xco, s); up(c.xb_dim, xd, s); }
+        else if (!pair_row.empty() && !hoff_row.empty()) {   // a pose pair can carry a Schur block AND a between block: one entry in the set
+          std::vector<size_t> idx(xd.size());
+          for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+          std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return xro[a] != xro[b] ? xro[a] < xro[b] : xco[a] < xco[b]; });
+          std::vector<int64_t> r2, c2; std::vector<int32_t> d2;
+          for (size_t k = 0; k < idx.size(); k++)
+            if (k == 0 || xro[idx[k]] != xro[idx[k - 1]] || xco[idx[k]] != xco[idx[k - 1]]) { r2.push_back(xro[idx[k]]); c2.push_back(xco[idx[k]]); d2.push_back(xd[idx[k]]); }
+          xro.swap(r2); xco.swap(c2); xd.swap(d2);
+        }
+        // the block SET identifies the layout; a sharded handle lists it in bitmap order, a single one in term order
+        uint64_t hb = 0;
+        for (size_t i = 0; i < xd.size(); i++) {
+          uint64_t z = (uint64_t)xro[i] * 0x9E3779B97F4A7C15ull ^ ((uint64_t)xco[i] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)xd[i];
+          z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+          hb += z;
+        }
+        mix(&hb, sizeof(hb));
+      }
       c.structure_hash = h;
     }
     clk.lap("cholesky tile schedule");
@@ -722,7 +773,7 @@ int gtg_destroy(gtg_handle c) {
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
-  c->chol_epoch_dev.free();
+  c->chol_epoch_dev.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   destroy_chol_streams(*c);
   for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -953,12 +1004,21 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
-  if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs, stored lower tiles only
-    const int64_t nb = c->plan.n_exch * kTile * kTile;
-    if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
-    launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
-    exchange(*c, c->xbuf.p, nb);
-    launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
+  if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
+    static const bool by_tiles = std::getenv("GTG_EXCHANGE_TILES") != nullptr;   // whole 128x128 tiles (the first version) instead of blocks
+    if (by_tiles || c->n_xb == 0) {
+      const int64_t nb = c->plan.n_exch * kTile * kTile;
+      if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
+      launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
+      exchange(*c, c->xbuf.p, nb);
+      launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
+    } else {                // only the structurally non-zero d x d blocks (the same list on every shard) + rhs row + padding
+      const int64_t nb = exchange_block_doubles(*c);
+      if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
+      launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, false);
+      exchange(*c, c->xbuf.p, nb);
+      launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
+    }
   }
   { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data()); launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
   { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());

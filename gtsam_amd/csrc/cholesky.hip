@@ -752,6 +752,36 @@ __global__ __launch_bounds__(256) void k_pack_tiles(double* __restrict__ S, int 
     if (unpack) *g = *p; else *p = *g;
   }
 }
+// The same exchange at block granularity: the structurally non-zero d x d blocks of the reduced system (81-double slots),
+// then the rhs row (NP doubles), then the padding diagonal.  HBM-bound gather / scatter of 72-byte row segments.
+__global__ __launch_bounds__(256) void k_pack_blocks(double* __restrict__ S, int NP, int64_t n_xb, const int64_t* __restrict__ row_off,
+                                                     const int64_t* __restrict__ col_off, const int32_t* __restrict__ dims,
+                                                     const int64_t* __restrict__ pad, int64_t npad, double* __restrict__ buf, int unpack) {
+  const int64_t nblk = 81 * n_xb, total = nblk + NP + npad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    double* s;
+    if (idx < nblk) {
+      const int64_t b = idx / 81;
+      const int e = (int)(idx - 81 * b), i = e / 9, j = e - 9 * i, d = dims[b];
+      if (i >= (d & 255) || j >= (d >> 8)) { if (!unpack) buf[idx] = 0.0; continue; }
+      s = S + (row_off[b] + i) * (int64_t)NP + col_off[b] + j;
+    } else if (idx < nblk + NP) {
+      s = S + (int64_t)NP * NP + (idx - nblk);
+    } else {
+      const int64_t q = pad[idx - nblk - NP];
+      s = S + q * (int64_t)NP + q;
+    }
+    if (unpack) *s = buf[idx]; else buf[idx] = *s;
+  }
+}
+int64_t exchange_block_doubles(const gtg_context& c) { return 81 * c.n_xb + c.NP + (int64_t)c.h_pad_index.size(); }
+void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack) {
+  const int64_t total = exchange_block_doubles(c);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(k_pack_blocks, dim3(grid), dim3(256), 0, c.stream, S, NP, c.n_xb, c.xb_row_off.p, c.xb_col_off.p, c.xb_dim.p,
+                     c.pad_index.p, (int64_t)c.h_pad_index.size(), buf, unpack ? 1 : 0);
+  check_hip(hipGetLastError(), "pack_blocks");
+}
 // zero the stored tiles of S (the others are never read): what the per-try rebuild of the reduced system needs
 // instead of a memset of the whole (NP + 128) x NP array (29 GB for a 20 000-pose 2-D graph, 99 % of it unused)
 __global__ __launch_bounds__(256) void k_zero_tiles(double* __restrict__ S, int NP, const int32_t* __restrict__ tiles) {

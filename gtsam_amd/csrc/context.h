@@ -163,7 +163,13 @@ struct gtg_context {
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
   gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words), bumped on the device
   gt::CholPlan plan;
-  gt::DevBuf<double> xbuf;                      // multi-GPU: stored tiles of S packed contiguously for the all-reduce
+  gt::DevBuf<double> xbuf;                      // multi-GPU: the exchanged part of S packed contiguously for the all-reduce
+  // multi-GPU exchange at block granularity: every structurally non-zero d x d block of the reduced system (diagonal blocks +
+  // the off-diagonal blocks of the WHOLE graph, identical on every shard), 81 doubles per block, then the rhs row and the
+  // padding diagonal.  3x less than whole 128x128 tiles on the L1723 shape (0.13 GB against 0.38 GB).
+  int64_t n_xb = 0;
+  gt::DevBuf<int64_t> xb_row_off, xb_col_off;   // scalar offsets of the block in S (row >= col)
+  gt::DevBuf<int32_t> xb_dim;                   // rows | cols << 8
   gt::DevBuf<double> xred;                      // NP solution of the reduced system
   gt::DevBuf<double> partials;                  // block partial sums for reductions
   gt::DevBuf<double> scalars;                   // SC_COUNT

@@ -30,6 +30,8 @@ void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan);
 void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag);
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
+int64_t exchange_block_doubles(const gtg_context& c);                    // size of the block-granular exchange buffer
+void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack);
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
 void destroy_chol_streams(gtg_context& c);
 

@@ -134,6 +134,22 @@ template <class F> static void run_threads(int nt, F f) {   // f(thread index) o
 
 static void exchange(gtg_context& c, double* ptr, int64_t n);
 
+// Three 20-bit pieces of the layout hash and a 1 go through the all-reduce: the sums must be n_shards times this shard's
+// own values (every shard derived the same layout AND the communicator spans n_shards ranks).
+static void verify_layout(gtg_context& c) {
+  c.layout_verified = true;
+  double mine[4] = {(double)(c.structure_hash & 0xFFFFF), (double)((c.structure_hash >> 20) & 0xFFFFF), (double)((c.structure_hash >> 40) & 0xFFFFF), 1.0};
+  double sum[4] = {0, 0, 0, 0};
+  check_hip(hipMemcpyAsync(c.layout_probe.p, mine, sizeof(mine), hipMemcpyHostToDevice, c.stream), "H2D");
+  if (c.allreduce(c.layout_probe.p, 4, (void*)c.stream, c.allreduce_user) != 0) throw std::runtime_error("allreduce callback failed");
+  check_hip(hipMemcpyAsync(sum, c.layout_probe.p, sizeof(sum), hipMemcpyDeviceToHost, c.stream), "D2H");
+  check_hip(hipStreamSynchronize(c.stream), "sync");
+  for (int i = 0; i < 4; i++)
+    if (sum[i] != mine[i] * c.n_shards)
+      throw std::runtime_error("sharded upload: the shards disagree on the layout of the reduced system (or the all-reduce spans a "
+                               "different number of ranks than n_shards)");
+}
+
 // ---- symbolic analysis ------------------------------------------------------------------------------
 static void analyze(gtg_context& c) {
   StageClock clk;
@@ -657,21 +673,11 @@ static void analyze(gtg_context& c) {
   check_hip(hipStreamSynchronize(s), "sync");
   clk.lap("upload + device buffers");
 
-  // sharded: the buffers the shards exchange only line up if every shard derived the same layout -- check it once, through
-  // the exchange itself (three 20-bit pieces of the layout hash and a 1: the sums must be n_shards times this shard's)
-  if (c.n_shards > 1 && c.allreduce) {
-    double mine[4] = {(double)(c.structure_hash & 0xFFFFF), (double)((c.structure_hash >> 20) & 0xFFFFF), (double)((c.structure_hash >> 40) & 0xFFFFF), 1.0};
-    double sum[4] = {0, 0, 0, 0};
-    check_hip(hipMemcpyAsync(c.scalars.p, mine, sizeof(mine), hipMemcpyHostToDevice, s), "H2D");
-    exchange(c, c.scalars.p, 4);
-    check_hip(hipMemcpyAsync(sum, c.scalars.p, sizeof(sum), hipMemcpyDeviceToHost, s), "D2H");
-    check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * SC_COUNT, s), "memset");
-    check_hip(hipStreamSynchronize(s), "sync");
-    for (int i = 0; i < 4; i++)
-      if (sum[i] != mine[i] * c.n_shards)
-        throw std::runtime_error("sharded upload: the shards disagree on the layout of the reduced system (or the all-reduce spans a "
-                                 "different number of ranks than n_shards)");
-  }
+  // sharded: the buffers the shards exchange only line up if every shard derived the same layout -- checked once, through
+  // the exchange itself: now if the callback is already registered, else in front of the first exchange
+  c.layout_probe.alloc(4);
+  c.layout_verified = false;
+  if (c.n_shards > 1 && c.allreduce) verify_layout(c);
 
   c.chol_flops = c.plan.flops;
   // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements +
@@ -684,6 +690,7 @@ static void analyze(gtg_context& c) {
 static void exchange(gtg_context& c, double* ptr, int64_t n) {
   if (c.n_shards > 1) {
     if (!c.allreduce) throw std::runtime_error("n_shards > 1 but no allreduce callback was set (gtg_set_allreduce)");
+    if (!c.layout_verified) verify_layout(c);   // the callback was registered after the upload
     const int rc = c.allreduce(ptr, n, (void*)c.stream, c.allreduce_user);
     if (rc != 0) throw std::runtime_error("allreduce callback failed");
   }
@@ -773,7 +780,7 @@ int gtg_destroy(gtg_handle c) {
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
-  c->chol_epoch_dev.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
+  c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   destroy_chol_streams(*c);
   for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);

@@ -176,6 +176,8 @@ struct gtg_context {
   double h_scalars[gt::SC_COUNT] = {0};
 
   // ---- multi-GPU exchange --------------------------------------------------------------------------
+  gt::DevBuf<double> layout_probe;              // 4 doubles: pieces of structure_hash summed across the shards (verify_layout)
+  bool layout_verified = false;
   gtg_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
 

@@ -87,7 +87,87 @@ def test_sharded_upload_fails_loudly_when_ranks_and_shards_do_not_match(stub):
     assert all(not r["ok"] and "disagree on the layout" in r["error"] for r in recs)
 
 
+def test_layout_check_runs_before_the_first_exchange_when_the_callback_comes_late(stub):
+    ok = HP.run_gloo("bal:60:6000:7", world=2, late_callback=True)
+    assert all(r["ok"] for r in ok) and ok[0]["structure_hash"] == ok[1]["structure_hash"]
+    bad = HP.run_gloo("bal:60:6000:7", world=2, claim_shards=3, late_callback=True)
+    assert all(not r["ok"] and "disagree on the layout" in r["error"] for r in bad)
+
+
 def test_three_shards_and_pose_graph_layouts(stub):
     recs = HP.run_gloo("sphere2500", world=3)                         # between factors go round-robin
     single = HP.run("sphere2500", shards=1, reps=1, quiet=True)["runs"][0]
     assert all(r["ok"] and r["structure_hash"] == single["structure_hash"] for r in recs)
+
+
+_PROTOCOL = r'''
+import ctypes as C, json
+import numpy as np
+from gtsam_amd import lib as L
+from gtsam_amd.problem import NOISE_UNIT, NOISE_ISOTROPIC, Problem, VAR_POINT3, VAR_POSE3, VAR_SFM_CAMERA, bal_problem
+from gtsam_amd import datasets as D
+lib = L.load()
+out = {}
+def err(): return lib.gtg_last_error().decode()
+def upload(p, shard=0, n=1):
+    h = C.c_void_p(); assert lib.gtg_create(C.byref(h), 0) == 0
+    cp = p.to_ctypes(); rc = lib.gtg_upload_problem(h, C.byref(cp), shard, n); e = err()
+    return h, rc, e
+good, v0 = bal_problem(*D.synthetic_bal(6, 40, seed=1))
+# --- call protocol on a good problem ---------------------------------------------------------------
+h, rc, e = upload(good); out["upload_ok"] = rc
+o4 = np.zeros(4)
+out["try_before_linearize"] = [lib.gtg_try_lambda(h, 1e-3, 0, 1e-6, 1e32, o4.ctypes.data), err()]
+out["accept_before_try"] = [lib.gtg_accept(h), err()]
+bad = np.zeros(3); out["set_values_wrong_size"] = [lib.gtg_set_values(h, bad.ctypes.data, 3), err()]
+out["set_values"] = lib.gtg_set_values(h, v0.ctypes.data, v0.size)
+out["linearize"] = lib.gtg_linearize(h)
+out["lambda_zero"] = [lib.gtg_try_lambda(h, 0.0, 0, 1e-6, 1e32, o4.ctypes.data), err()]
+out["gradient_wrong_size"] = [lib.gtg_get_gradient(h, bad.ctypes.data, 3), err()]
+out["jacobians_unknown_type"] = [lib.gtg_get_jacobians(h, 9, bad.ctypes.data, 3), err()]
+nc = int((good.var_type == VAR_SFM_CAMERA).sum())
+order = np.arange(nc, dtype=np.int32)[::-1].copy()
+out["reorder_ok"] = lib.gtg_set_reduced_ordering(h, order.ctypes.data, nc)
+out["try_after_reorder_needs_linearize"] = [lib.gtg_try_lambda(h, 1e-3, 0, 1e-6, 1e32, o4.ctypes.data), err()]
+dup = np.zeros(nc, np.int32); out["reorder_not_permutation"] = [lib.gtg_set_reduced_ordering(h, dup.ctypes.data, nc), err()]
+out["destroy"] = lib.gtg_destroy(h); out["destroy_null"] = lib.gtg_destroy(None)
+out["values_size_null"] = int(lib.gtg_values_size(None))
+# --- content the upload must reject (the reference's exceptions) --------------------------------------
+def variant(fn):
+    q, _ = bal_problem(*D.synthetic_bal(6, 40, seed=1)); fn(q); hh, rc, e = upload(q); lib.gtg_destroy(hh); return [rc, e]
+def wrong_dim(q): q.noise_dim = q.noise_dim.copy(); q.noise_dim[q.sfm_noise[0]] = 3
+def bad_key(q): q.sfm_point = q.sfm_point.copy(); q.sfm_point[0] = 10 ** 6
+def cam_as_point(q): q.sfm_point = q.sfm_point.copy(); q.sfm_point[0] = q.sfm_cam[0]
+def bad_type(q): q.var_type = q.var_type.copy(); q.var_type[0] = 17
+def bad_noise(q): q.noise_kind = q.noise_kind.copy(); q.noise_kind[0] = 9
+def bad_estimator(q): q.noise_robust = np.full(q.noise_kind.size, 2, np.int32); q.noise_robust_param = np.zeros(q.noise_kind.size)
+for name, fn in [("wrong_dim", wrong_dim), ("bad_key", bad_key), ("cam_as_point", cam_as_point), ("bad_type", bad_type),
+                 ("bad_noise", bad_noise), ("bad_estimator", bad_estimator)]:
+    out[name] = variant(fn)
+hh, rc, e = upload(good, shard=2, n=2); out["bad_shard"] = [rc, e]; lib.gtg_destroy(hh)
+hh, rc, e = upload(good, shard=0, n=2); lib.gtg_set_values(hh, v0.ctypes.data, v0.size)
+out["sharded_without_allreduce"] = [rc, lib.gtg_linearize(hh), err()]; lib.gtg_destroy(hh)
+hh = C.c_void_p(); out["bad_device"] = [lib.gtg_create(C.byref(hh), 5), err()]
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_c_abi_protocol_and_error_behaviour(stub):
+    """The boundary's error behaviour without a GPU: wrong call order, wrong sizes, content the reference rejects with an
+    exception (noise dimension NonlinearFactor.cpp:97-104, unknown key, estimator parameter LossFunctions.cpp) come back as
+    GTG_ERR_USAGE (-1) with a message, never as a crash or a silent success; a sharded upload without an all-reduce
+    callback is a runtime error (-2)."""
+    r = HP.run_snippet(_PROTOCOL)
+    assert r["upload_ok"] == 0 and r["set_values"] == 0 and r["linearize"] == 0 and r["reorder_ok"] == 0
+    assert r["destroy"] == 0 and r["destroy_null"] == 0 and r["values_size_null"] == -1
+    for key, text in [("try_before_linearize", "call gtg_linearize first"), ("accept_before_try", "no trial values"),
+                      ("set_values_wrong_size", "wrong size"), ("lambda_zero", "lambda must be > 0"),
+                      ("gradient_wrong_size", "wrong size"), ("jacobians_unknown_type", "unknown factor type"),
+                      ("try_after_reorder_needs_linearize", "call gtg_linearize first"),
+                      ("reorder_not_permutation", "not a permutation"), ("wrong_dim", "NoiseModel has wrong dimension"),
+                      ("bad_key", "not in Values"), ("cam_as_point", "keys must be (SFM_CAMERA, POINT3)"),
+                      ("bad_type", "unknown variable type"), ("bad_noise", "unsupported noise model kind"),
+                      ("bad_estimator", "m-estimator parameter must be > 0"), ("bad_shard", "bad shard"), ("bad_device", "bad device id")]:
+        assert r[key][0] == -1 and text in r[key][1], (key, r[key])
+    # the callback may be registered after the upload; the first exchange without one is a runtime error (-2)
+    assert r["sharded_without_allreduce"][:2] == [0, -2] and "no allreduce callback" in r["sharded_without_allreduce"][2]

@@ -187,3 +187,28 @@ def test_noise_model_constructors_literals(hm):
     # smart constructors down-cast (NoiseModel.cpp:97-110, 283-308, 624-633)
     assert nm.Gaussian.Information(I3 * 0.25).kind == NOISE_ISOTROPIC and nm.Gaussian.Information(I3).kind == 0
     assert nm.Isotropic.Variance(3, 1.0).kind == 0
+
+
+def test_cholesky_underconstrained_and_bad_scaling_literals(live_ref):
+    """gtsam/base/tests/testCholesky.cpp:70-81 (BadScalingCholesky: diag(1e-80, 1) factors with R00 / R11 = 1e-40) and :101-139
+    (underconstrained: L D L^T with a 1e-12 pivot, with zero pivots, with negative pivots -- choleskyPartial must report
+    failure for all three: the rank test of base/cholesky.cpp:144-157 and Eigen's LLT info).  On the oracle's restatement
+    and, where it is built, on the reference's own choleskyPartial."""
+    A = np.diag([1e-40, 1.0]); A = A.T @ A
+    ok, R = O.cholesky_partial(A, 2)
+    assert ok and abs(R[0, 0] / R[1, 1] - 1e-40) <= 1e-41
+    L = np.array([[1, 0, 0, 0, 0, 0],
+                  [1.11177808157954, 1.06204809504665, 0.507342638873381, 1.34953401829486, 1, 0],
+                  [0.155864888199928, 1.10933048588373, 0.501255576961674, 1, 0, 0],
+                  [1.12108665967793, 1.01584408366945, 1, 0, 0, 0],
+                  [0.776164062474843, 0.117617236580373, -0.0236628691347294, 0.814118199972143, 0.694309975328922, 1],
+                  [0.1197220685104, 1, 0, 0, 0, 0]])
+    d = [0.814723686393179, 0.811780089277421, 1.82596950680844, 0.240287537694585]
+    for tail in ([1.34342584865901, 1e-12], [0.0, 0.0], [-0.5, -0.6]):
+        M = L @ np.diag(d + tail) @ L.T
+        assert not O.cholesky_partial(M, 6)[0], tail
+        if live_ref is not None:
+            assert not live_ref.cholesky_partial(M, 6)[0], tail
+    if live_ref is not None:
+        ok, R = live_ref.cholesky_partial(A, 2)
+        assert ok and abs(R[0, 0] / R[1, 1] - 1e-40) <= 1e-41

@@ -98,7 +98,7 @@ def gloo_child(args):
     path of make_allreduce takes).  Exercises the N > 1 set-up path end to end on CPU: shard filter, whole-graph
     structure, layout-consistency exchange."""
     import torch.distributed as dist
-    problem, _ = problem_for(args.workload)
+    problem, values0 = problem_for(args.workload)
     from gtsam_amd import lib as L
     from gtsam_amd.distributed import make_allreduce
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
@@ -106,7 +106,11 @@ def gloo_child(args):
     try:
         n_shards = args.claim_shards or args.world
         try:
-            g = L.DeviceGraph(problem, shard=args.gloo_rank % n_shards, n_shards=n_shards, allreduce=make_allreduce())
+            if args.late_callback:   # callback registered after the upload: the layout check runs in front of the first exchange
+                g = L.DeviceGraph(problem, shard=args.gloo_rank % n_shards, n_shards=n_shards)
+                g.set_allreduce(make_allreduce()); g.set_values(values0); g.linearize()
+            else:
+                g = L.DeviceGraph(problem, shard=args.gloo_rank % n_shards, n_shards=n_shards, allreduce=make_allreduce())
             out = {"rank": args.gloo_rank, "ok": True, "structure_hash": g.structure_hash(), "reduced_dim": int(g.reduced_dim),
                    "cholesky_gflop": g.cholesky_flops() / 1e9}
             g.close()
@@ -117,14 +121,14 @@ def gloo_child(args):
         dist.destroy_process_group()
 
 
-def run_gloo(workload, world=2, claim_shards=0, timeout=300):
+def run_gloo(workload, world=2, claim_shards=0, timeout=300, late_callback=False):
     """Launch `world` ranks of gloo_child under the stub; returns their records (rank order)."""
     import socket
     build_stub()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ); env["LD_PRELOAD"] = STUB
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), workload, "--gloo-rank", str(r), "--world", str(world),
-                               "--port", str(port), "--claim-shards", str(claim_shards)], env=env, stdout=subprocess.PIPE,
+                               "--port", str(port), "--claim-shards", str(claim_shards)] + (["--late-callback"] if late_callback else []), env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(world)]
     recs = []
     for pr in procs:
@@ -133,6 +137,21 @@ def run_gloo(workload, world=2, claim_shards=0, timeout=300):
             raise RuntimeError(f"gloo rank failed:\n{so[-2000:]}\n{se[-4000:]}")
         recs += [json.loads(line[len("HOSTPROFILE "):]) for line in so.splitlines() if line.startswith("HOSTPROFILE ")]
     return sorted(recs, key=lambda r: r["rank"])
+
+
+def run_snippet(code, timeout=300, env_extra=None):
+    """Run a Python snippet in a child process under the stub (host code of the library only); the snippet prints one
+    line `RESULT <json>`; returns the parsed object."""
+    build_stub()
+    env = dict(os.environ); env["LD_PRELOAD"] = STUB; env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"snippet failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
+    for line in r.stdout.splitlines():
+        if line.startswith("RESULT "):
+            return json.loads(line[len("RESULT "):])
+    raise RuntimeError("no RESULT line:\n" + r.stdout[-2000:])
 
 
 def run(workload, shards=1, reps=3, env_extra=None, quiet=False):
@@ -164,6 +183,7 @@ if __name__ == "__main__":
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--port", type=int, default=0)
     ap.add_argument("--claim-shards", type=int, default=0, help="n_shards passed to the library (default: the world size)")
+    ap.add_argument("--late-callback", action="store_true")
     a = ap.parse_args()
     if a.gloo_rank >= 0:
         gloo_child(a)

@@ -1205,6 +1205,37 @@ int gtg_debug_potrf_stamps(gtg_handle c, double* A128, long long* out15) {
   GTG_CATCH
 }
 
+// tests: the tile schedule of the reduced-system Cholesky as the kernels read it (index lists only)
+int gtg_debug_plan_sizes(gtg_handle c, int64_t sizes[8]) {
+  GTG_TRY
+  if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_plan_sizes: no problem uploaded");
+  const CholPlan& pl = c->plan;
+  sizes[0] = pl.nt; sizes[1] = (int64_t)pl.rows.n; sizes[2] = (int64_t)pl.pairs.n; sizes[3] = (int64_t)pl.bcols.n;
+  sizes[4] = pl.n_stored; sizes[5] = pl.n_exch; sizes[6] = (int64_t)pl.s1_off.size(); sizes[7] = (int64_t)pl.part_parent.size();
+  return GTG_OK;
+  GTG_CATCH
+}
+int gtg_debug_plan_lists(gtg_handle c, int32_t* rows, int32_t* pairs, int32_t* bcols, int32_t* stored, int32_t* exch,
+                         int64_t* per_tile, int64_t* per_pair, int32_t* pair_part, int32_t* part_parent) {
+  GTG_TRY
+  if (!c || !c->uploaded) throw std::invalid_argument("gtg_debug_plan_lists: no problem uploaded");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  const CholPlan& pl = c->plan;
+  auto down = [&](int32_t* dst, const DevBuf<int32_t>& b, size_t n) { if (dst && n) check_hip(hipMemcpy(dst, b.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost), "D2H"); };
+  down(rows, pl.rows, pl.rows.n); down(pairs, pl.pairs, pl.pairs.n); down(bcols, pl.bcols, pl.bcols.n);
+  down(stored, pl.stored, 2 * (size_t)pl.n_stored); down(exch, pl.exch, 2 * (size_t)pl.n_exch);
+  if (per_tile) for (int k = 0; k < pl.nt; k++) { per_tile[4 * k] = pl.trsm_off[k]; per_tile[4 * k + 1] = pl.trsm_cnt[k]; per_tile[4 * k + 2] = pl.bwd_off[k]; per_tile[4 * k + 3] = pl.bwd_cnt[k]; }
+  if (per_pair) for (size_t p = 0; p < pl.s1_off.size(); p++) {
+    int64_t* q = per_pair + 8 * p;
+    q[0] = pl.s1_off[p]; q[1] = pl.s1_cnt[p]; q[2] = pl.nar_off[p]; q[3] = pl.nar_cnt[p]; q[4] = pl.rest_off[p]; q[5] = pl.rest_cnt[p];
+    q[6] = pl.anc_off[p]; q[7] = pl.anc_cnt[p];
+  }
+  if (pair_part) for (size_t p = 0; p < pl.pair_part.size(); p++) pair_part[p] = pl.pair_part[p];
+  if (part_parent) for (size_t x = 0; x < pl.part_parent.size(); x++) part_parent[x] = pl.part_parent[x];
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   GTG_TRY
   if (!c || !A || n < 1) throw std::invalid_argument("gtg_dense_cholesky_host: bad arguments");

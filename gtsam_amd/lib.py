@@ -27,6 +27,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -80,6 +81,8 @@ def load():
     lib.gtg_reset_timing.argtypes = [C.c_void_p]
     lib.gtg_get_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.gtg_dense_cholesky_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.gtg_debug_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gtg_debug_plan_lists.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.gtg_io_last_error.restype = C.c_char_p
     lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
@@ -209,6 +212,20 @@ class DeviceGraph:
     def cholesky_flops(self): return self.lib.gtg_cholesky_flops(self.h)
     def structure_hash(self): return int(self.lib.gtg_structure_hash(self.h))
     def linearize_bytes(self): return self.lib.gtg_linearize_bytes(self.h)
+
+    def cholesky_plan(self):
+        """Test hook: the tile schedule (dict of numpy index arrays), see gtg_debug_plan_lists."""
+        sz = np.zeros(8, np.int64)
+        _check(self.lib.gtg_debug_plan_sizes(self.h, sz.ctypes.data), "gtg_debug_plan_sizes")
+        nt, nrows, npairs_e, nbcols, nstored, nexch, np_, nparts = (int(x) for x in sz)
+        d = dict(nt=nt, rows=np.zeros(nrows, np.int32), pairs=np.zeros(npairs_e, np.int32), bcols=np.zeros(nbcols, np.int32),
+                 stored=np.zeros(2 * nstored, np.int32), exch=np.zeros(2 * nexch, np.int32), per_tile=np.zeros((nt, 4), np.int64),
+                 per_pair=np.zeros((np_, 8), np.int64), pair_part=np.zeros(np_ if nparts else 0, np.int32),
+                 part_parent=np.zeros(nparts, np.int32))
+        _check(self.lib.gtg_debug_plan_lists(self.h, *(d[k].ctypes.data for k in ("rows", "pairs", "bcols", "stored", "exch", "per_tile",
+                                                                                  "per_pair", "pair_part", "part_parent"))), "gtg_debug_plan_lists")
+        d["stored"] = d["stored"].reshape(-1, 2); d["exch"] = d["exch"].reshape(-1, 2)
+        return d
 
     def dense_cholesky(self, A, rhs=None):
         """Unit-test hook: (status, L (lower), x) of the device Cholesky + solve on a host matrix."""

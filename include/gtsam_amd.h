@@ -218,6 +218,14 @@ double gtg_linearize_bytes(gtg_handle h);
  * non-positive pivot (Eigen LLT info, base/cholesky.cpp:124-127). */
 int gtg_dense_cholesky_host(gtg_handle h, double* A, int32_t n, double* rhs_inout /* may be NULL */);
 
+/* tests only: the tile schedule of the reduced-system Cholesky exactly as the kernels read it (index lists, no numbers), so
+ * that the symbolic phase (fill, update lists, elimination-tree parts, backward-solve lists) can be executed and checked
+ * on the CPU (tests/test_chol_plan.py).  sizes = {nt, |rows|, |pairs| (int32 entries), |bcols|, n_stored, n_exch, n_pairs
+ * of columns, n_parts}; per_tile[nt][4] = trsm_off, trsm_cnt, bwd_off, bwd_cnt; per_pair[np][8] = s1, nar, rest, anc (off, cnt). */
+int gtg_debug_plan_sizes(gtg_handle h, int64_t sizes[8]);
+int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* bcols, int32_t* stored, int32_t* exch,
+                         int64_t* per_tile, int64_t* per_pair, int32_t* pair_part, int32_t* part_parent);
+
 /* ---- wire format on the bundle-adjustment side of the path: BAL text files straight to / from the
  * SoA arrays of gtg_problem.  Host-only (no GPU needed).  Replaces SfmData::FromBalFile (gtsam/sfm/SfmData.cpp:189-246: every
  * number goes through a `float`, pose = openGL2gtsam(Rodrigues(w), t), measurement (u, -v), observations grouped by point in

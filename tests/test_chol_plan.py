@@ -1,0 +1,168 @@
+"""The symbolic phase of the reduced-system Cholesky, executed on the CPU.
+
+The library's tile schedule (csrc/cholesky.hip::build_chol_plan: symbolic fill at column-pair granularity, TRSM row lists,
+thin / look-ahead / bulk / cross-part update lists, backward-solve lists, elimination-tree parts) is a set of index lists
+that do not depend on the tile size.  Here the real library builds them for real graphs -- in a child process under
+tools/hipstub, host code only -- and a numpy interpreter executes them, step for step what the kernels do, on a random
+SPD matrix with exactly the tile pattern the graph produces (8x8 tiles instead of 128x128):
+
+    panel(k): L_kk = chol(A_kk); L_Ik = A_Ik L_kk^-T for I in the TRSM rows (the rhs row included: forward solve for free)
+    thin update (second column of a pair), then per pair the K = 2 tiles updates  A_IJ -= L_I,k:k+2 L_J,k:k+2^T
+    backward solve by block rows with the stored column lists
+
+The result must equal a dense Cholesky / solve: every tile the factor fills in is in the schedule (no missing fill, no
+missing update, also across nested-dissection parts), and nothing outside the stored tiles is touched.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import host_profile as HP  # noqa: E402
+
+_CHILD = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from tools import host_profile as HP
+from gtsam_amd import lib as L
+problem, _ = HP.problem_for(%(workload)r)
+g = L.DeviceGraph(problem)
+pl = g.cholesky_plan()
+out = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in pl.items()}
+out["dense_fraction_flops"] = g.cholesky_flops()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _plan(workload, nd_depth=0):
+    env = {"GTG_ND_DEPTH": str(nd_depth)} if nd_depth else {}
+    d = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra=env)
+    for k in ("rows", "pairs", "bcols", "pair_part", "part_parent"):
+        d[k] = np.array(d[k], np.int64)
+    for k in ("stored", "exch"):
+        d[k] = np.array(d[k], np.int64).reshape(-1, 2)
+    d["per_tile"] = np.array(d["per_tile"], np.int64).reshape(-1, 4); d["per_pair"] = np.array(d["per_pair"], np.int64).reshape(-1, 8)
+    return d
+
+
+def _execute(pl, t=8, seed=0):
+    """Run the schedule on a random SPD matrix with the graph's tile pattern; returns the worst deviations from dense."""
+    rng = np.random.default_rng(seed)
+    nt = int(pl["nt"]); n = nt * t
+    # the matrix before the factorisation: something in every tile of the exchange list (= structurally non-zero), rhs row incl.
+    A = np.zeros((n, n)); g = np.zeros(n)
+    for I, J in pl["exch"]:
+        if I == nt:
+            g[J * t:(J + 1) * t] = rng.normal(size=t)
+        elif I != J:
+            A[I * t:(I + 1) * t, J * t:(J + 1) * t] = rng.normal(size=(t, t)) * 0.3
+    A = A + A.T
+    A += np.diag(np.abs(A).sum(1) + 1.0 + rng.uniform(0, 1, n))                    # strictly diagonally dominant: SPD
+    Ld = np.linalg.cholesky(A); yd = np.linalg.solve(Ld, g); xd = np.linalg.solve(Ld.T, yd)
+    # tile store: only the stored tiles exist; touching anything else is a schedule error
+    stored = {(int(I), int(J)) for I, J in pl["stored"]}
+    tile = {}
+    for (I, J) in stored:
+        tile[(I, J)] = (g[J * t:(J + 1) * t][None, :].copy() if I == nt else A[I * t:(I + 1) * t, J * t:(J + 1) * t].copy())
+    for I in range(nt):
+        for J in range(I + 1):
+            if (I, J) not in stored:
+                assert not A[I * t:(I + 1) * t, J * t:(J + 1) * t].any(), "a non-zero tile of the graph is not stored"
+
+    def T(I, J):
+        if (I, J) not in tile:
+            raise AssertionError(f"the schedule reads / writes tile ({I},{J}) which is not stored")
+        return tile[(I, J)]
+    rows, pairs = pl["rows"], pl["pairs"].reshape(-1, 2)
+    pt, pp = pl["per_tile"], pl["per_pair"]
+
+    def panel(k):
+        Lkk = np.linalg.cholesky(np.tril(T(k, k)) + np.tril(T(k, k), -1).T)
+        tile[(k, k)] = Lkk
+        for I in rows[pt[k, 0]:pt[k, 0] + pt[k, 1]]:
+            tile[(int(I), k)] = np.linalg.solve(Lkk, T(int(I), k).T).T
+
+    def update(k, off, cnt, width):
+        for I, J in pairs[off:off + cnt]:
+            I, J = int(I), int(J)
+            acc = T(I, J)
+            for kk in range(k, k + width):
+                acc = acc - T(I, kk) @ T(J, kk).T
+            tile[(I, J)] = acc
+    npairs = pp.shape[0]
+    for p in range(npairs):
+        k = 2 * p
+        panel(k)
+        if k + 1 < nt:
+            update(k, pp[p, 0], pp[p, 1], 1)          # thin update of column k+1
+            panel(k + 1)
+            for off, cnt in ((pp[p, 2], pp[p, 3]), (pp[p, 4], pp[p, 5]), (pp[p, 6], pp[p, 7])):   # look-ahead, bulk, cross-part
+                update(k, off, cnt, 2)
+    # compare the factor: stored tiles equal dense L, dense L is zero elsewhere
+    worst = 0.0
+    for I in range(nt):
+        for J in range(I + 1):
+            blk = Ld[I * t:(I + 1) * t, J * t:(J + 1) * t]
+            if (I, J) in stored:
+                got = np.tril(tile[(I, J)]) if I == J else tile[(I, J)]
+                worst = max(worst, float(np.abs(got - blk).max()))
+            else:
+                assert np.abs(blk).max() <= 1e-13, f"fill-in at tile ({I},{J}) is missing from the schedule"
+    y = np.concatenate([T(nt, J)[0] for J in range(nt)])
+    worst_y = float(np.abs(y - yd).max())
+    # backward solve by block rows: x_k = L_kk^-T y_k, then y_c -= L_kc^T x_k for the stored column tiles c of row k
+    y = y.copy(); x = np.zeros(n)
+    bc = pl["bcols"]
+    for k in range(nt - 1, -1, -1):
+        xk = np.linalg.solve(tile[(k, k)].T, y[k * t:(k + 1) * t]); x[k * t:(k + 1) * t] = xk
+        for c in bc[pt[k, 2]:pt[k, 2] + pt[k, 3]]:
+            c = int(c)
+            y[c * t:(c + 1) * t] -= T(k, c).T @ xk
+    return worst, worst_y, float(np.abs(x - xd).max() / max(np.abs(xd).max(), 1e-300)), len(stored)
+
+
+@pytest.fixture(scope="module")
+def stub():
+    if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
+        pytest.skip("libgtsam_amd.so not built")
+    return HP.build_stub()
+
+
+@pytest.mark.parametrize("workload,nd", [("bal:60:6000:7", 0), ("dubrovnik16", 0), ("sphere2500", 0), ("sphere2500", 2),
+                                         ("sphere2500", 3), ("bal:300:20000:3", 0), ("bal:300:20000:3", 2),
+                                         ("ladybug1723", 0), ("ladybug1723", 2), ("w20000", 0), ("w20000", 3)])
+def test_schedule_reproduces_a_dense_cholesky(stub, workload, nd):
+    pl = _plan(workload, nd)
+    if nd:
+        assert len(pl["part_parent"]) > 1, "nested dissection was requested but the plan has a single part"
+        # children precede their parent, a pair of columns belongs to exactly one part
+        assert all(pl["part_parent"][x] == -1 or pl["part_parent"][x] > x for x in range(len(pl["part_parent"])))
+        assert len(pl["pair_part"]) == pl["per_pair"].shape[0] and (np.diff(pl["pair_part"]) >= 0).all()
+    else:
+        assert len(pl["part_parent"]) == 0 and not pl["per_pair"][:, 7].any()
+    worst, worst_y, worst_x, n_stored = _execute(pl)
+    assert worst <= 1e-10 and worst_y <= 1e-10 and worst_x <= 1e-10, (worst, worst_y, worst_x)
+    nt = int(pl["nt"])
+    assert n_stored <= (nt + 1) * (nt + 2) // 2
+    # the exchange list (structure before the factorisation) is a subset of the stored tiles
+    stored = {(int(i), int(j)) for i, j in pl["stored"]}
+    assert all((int(i), int(j)) in stored for i, j in pl["exch"])
+
+
+def test_forced_dense_schedule(stub):
+    d = HP.run_snippet(_CHILD % {"root": ROOT, "workload": "bal:60:6000:7"}, env_extra={"GTG_DENSE_PLAN": "1", "GTG_NO_REORDER": "1"})
+    pl = dict(d)
+    for k in ("rows", "pairs", "bcols", "pair_part", "part_parent"):
+        pl[k] = np.array(d[k], np.int64)
+    for k in ("stored", "exch"):
+        pl[k] = np.array(d[k], np.int64).reshape(-1, 2)
+    pl["per_tile"] = np.array(d["per_tile"], np.int64).reshape(-1, 4); pl["per_pair"] = np.array(d["per_pair"], np.int64).reshape(-1, 8)
+    nt = int(pl["nt"])
+    assert len(pl["stored"]) == nt * (nt + 1) // 2 + nt          # every lower tile + the rhs row
+    worst, worst_y, worst_x, _ = _execute(pl)
+    assert max(worst, worst_y, worst_x) <= 1e-10

@@ -71,7 +71,8 @@ void packCamera(const SfmCamera& c, double* p) {
 
 struct NoiseTable {
   std::vector<int32_t> kind, dim, rkind; std::vector<int64_t> off; std::vector<double> data, rparam;
-  std::map<const noiseModel::Base*, int32_t> seen;
+  std::map<const noiseModel::Base*, int32_t> seen;        // by object: the usual case of one shared_ptr on many factors
+  std::map<std::vector<double>, int32_t> seen_value;      // by value: loaders create one model object per factor (load2D / load3D)
   // noiseModel::Robust (NoiseModel.h:670-760) -> (GTG_ROBUST_*, parameter) beside the base model's row
   static void estimator(const noiseModel::Robust& rb, int32_t* rk, double* k) {
     namespace me = noiseModel::mEstimator;
@@ -96,19 +97,27 @@ struct NoiseTable {
     SharedNoiseModel nm = outer;
     int32_t rk = GTG_ROBUST_NONE; double rp = 0.0;
     if (auto rb = std::dynamic_pointer_cast<noiseModel::Robust>(outer)) { estimator(*rb, &rk, &rp); nm = rb->noise(); }
+    if (nm->isConstrained() || std::dynamic_pointer_cast<noiseModel::Robust>(nm))
+      throw std::invalid_argument("Constrained / nested Robust noise models are outside the GPU path");
+    int32_t k; std::vector<double> params;
+    if (nm->isUnit()) k = GTG_NOISE_UNIT;
+    else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { k = GTG_NOISE_ISOTROPIC; params.push_back(iso->sigma()); }
+    else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { k = GTG_NOISE_DIAGONAL; for (size_t i = 0; i < dg->dim(); i++) params.push_back(dg->sigma(i)); }
+    else if (auto ga = std::dynamic_pointer_cast<noiseModel::Gaussian>(nm)) {
+      k = GTG_NOISE_GAUSSIAN;
+      const Matrix R = ga->R();
+      for (int i = 0; i < R.rows(); i++) for (int j = 0; j < R.cols(); j++) params.push_back(R(i, j));
+    } else throw std::invalid_argument("unsupported noise model type");
+    // identical models share a row of the table (first-occurrence order), however many objects they are
+    std::vector<double> key{(double)k, (double)nm->dim(), (double)rk, rp};
+    key.insert(key.end(), params.begin(), params.end());
+    auto byValue = seen_value.find(key);
+    if (byValue != seen_value.end()) { seen[outer.get()] = byValue->second; return byValue->second; }
     const int32_t idx = (int32_t)kind.size();
     off.push_back((int64_t)data.size()); dim.push_back((int32_t)nm->dim());
     rkind.push_back(rk); rparam.push_back(rp);
-    if (nm->isConstrained() || std::dynamic_pointer_cast<noiseModel::Robust>(nm))
-      throw std::invalid_argument("Constrained / nested Robust noise models are outside the GPU path");
-    if (nm->isUnit()) kind.push_back(GTG_NOISE_UNIT);
-    else if (auto iso = std::dynamic_pointer_cast<noiseModel::Isotropic>(nm)) { kind.push_back(GTG_NOISE_ISOTROPIC); data.push_back(iso->sigma()); }
-    else if (auto dg = std::dynamic_pointer_cast<noiseModel::Diagonal>(nm)) { kind.push_back(GTG_NOISE_DIAGONAL); for (size_t i = 0; i < dg->dim(); i++) data.push_back(dg->sigma(i)); }
-    else if (auto ga = std::dynamic_pointer_cast<noiseModel::Gaussian>(nm)) {
-      kind.push_back(GTG_NOISE_GAUSSIAN);
-      const Matrix R = ga->R();
-      for (int i = 0; i < R.rows(); i++) for (int j = 0; j < R.cols(); j++) data.push_back(R(i, j));
-    } else throw std::invalid_argument("unsupported noise model type");
+    kind.push_back(k); data.insert(data.end(), params.begin(), params.end());
+    seen_value[key] = idx;
     seen[outer.get()] = idx;
     return idx;
   }

@@ -16,6 +16,26 @@
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
 
+#include <gtsam/config.h>
+
+// The compile-time options of the linked GTSAM change the mathematics of this path (gtsam/config.h.in:31-90).  The device code
+// implements the DEFAULT-flag semantics; refuse to build the shim against a GTSAM configured otherwise.
+#if defined(GTSAM_USE_QUATERNIONS)
+#error "gtsam_amd: built for Rot3 as a rotation matrix (GTSAM_USE_QUATERNIONS off): Rot3 retract / Logmap differ with quaternions"
+#endif
+#if !defined(GTSAM_POSE3_EXPMAP) || !defined(GTSAM_ROT3_EXPMAP)
+#error "gtsam_amd: the device retracts Pose3 / Rot3 with the full exponential map (GTSAM_POSE3_EXPMAP and GTSAM_ROT3_EXPMAP on)"
+#endif
+#if defined(GTSAM_SLOW_BUT_CORRECT_BETWEENFACTOR)
+#error "gtsam_amd: BetweenFactor Jacobians are not multiplied by dLog on the device (GTSAM_SLOW_BUT_CORRECT_BETWEENFACTOR off)"
+#endif
+#if defined(GTSAM_SLOW_BUT_CORRECT_EXPMAP)
+#error "gtsam_amd: Pose2 uses the first-order chart on the device (GTSAM_SLOW_BUT_CORRECT_EXPMAP off)"
+#endif
+#if !defined(GTSAM_THROW_CHEIRALITY_EXCEPTION)
+#error "gtsam_amd: a point behind the camera zeroes the factor, as the reference does when it throws CheiralityException (flag on)"
+#endif
+
 #include <chrono>
 #include <cmath>
 #include <fstream>

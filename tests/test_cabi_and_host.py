@@ -160,3 +160,27 @@ def test_verbosity_messages(monkeypatch, capsys):
     out = capsys.readouterr().out
     assert "trying lambda = 1e-05" in out and "increasing lambda" in out and "modelFidelity: " in out
     assert "converged" in out and "relativeDecrease: " in out and "iterations: 13 >? 100" in out
+
+
+@pytest.mark.parametrize("preset", ["legacy", "ceres"])
+def test_restart_from_values_and_lambda_continues_the_same_trajectory(monkeypatch, preset):
+    """Checkpoint / resume as the reference offers it: the optimizer state is values() + lambda()
+    (+ the current lambda factor for the Ceres policy); a new optimizer constructed from them continues on the
+    uninterrupted run's trajectory."""
+    import copy
+    from gtsam_amd import optimizer
+    monkeypatch.setattr(optimizer, "DeviceGraph", FakeDevice)
+    g = load_golden("dubrovnik_3_7")
+    p, v0 = PB.dubrovnik_timesfm(g)
+    params = LMP.CeresDefaults() if preset == "ceres" else LMP()
+    params.setMaxIterations(9)
+    whole = optimizer.DeviceLevenbergMarquardt(p, v0, params); whole.optimize()
+    first = optimizer.DeviceLevenbergMarquardt(p, v0, params)
+    for _ in range(4):
+        first.iterate()
+    ckpt = dict(values=first.values_packed(), lam=first.lambda_(), factor=first._factor, done=first.iterations())
+    p2 = copy.copy(params); p2.lambdaInitial = ckpt["lam"]; p2.lambdaFactor = ckpt["factor"]; p2.setMaxIterations(9 - ckpt["done"])
+    second = optimizer.DeviceLevenbergMarquardt(p, ckpt["values"], p2); second.optimize()
+    assert second.iterations() + ckpt["done"] == whole.iterations()
+    assert abs(second.error() - whole.error()) <= 1e-12 * whole.error() and abs(second.lambda_() - whole.lambda_()) <= 1e-12 * whole.lambda_()
+    assert np.abs(second.values_packed() - whole.values_packed()).max() <= 1e-12 * np.abs(whole.values_packed()).max()

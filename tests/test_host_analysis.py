@@ -171,3 +171,16 @@ def test_c_abi_protocol_and_error_behaviour(stub):
         assert r[key][0] == -1 and text in r[key][1], (key, r[key])
     # the callback may be registered after the upload; the first exchange without one is a runtime error (-2)
     assert r["sharded_without_allreduce"][:2] == [0, -2] and "no allreduce callback" in r["sharded_without_allreduce"][2]
+
+
+def test_degenerate_graphs_through_the_host_path(stub):
+    """A single pose, a variable without factors, no factors at all, landmarks only, a landmark with one observation,
+    camera counts around the reordering threshold (16) and the tile boundary: upload, analysis, one linearize / try_lambda
+    issue sequence and the plan getters run through (the same driver runs under ASan / TSan in tools/sanitize)."""
+    import subprocess
+    env = dict(os.environ); env["LD_PRELOAD"] = stub
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize", "run_host_paths.py"), "edge"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ok = [line for line in r.stdout.splitlines() if line.startswith("ok ")]
+    assert len(ok) == 10 and any("bal 17 cameras nt 2" in line for line in ok)

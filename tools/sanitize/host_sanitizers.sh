@@ -8,7 +8,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 RT=$(dirname "$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)")
-WORK=${WORK:-bal:60:6000:7 bal:300:20000:3 sphere2500 ladybug1723}
+WORK=${WORK:-edge bal:60:6000:7 bal:300:20000:3 sphere2500 ladybug1723}
 [ $# -gt 0 ] && WORK="$*"
 gcc -O2 -fPIC -shared -o "$ROOT/tools/hipstub/libhipstub.so" "$ROOT/tools/hipstub/hipstub.c"
 for SAN in address thread; do

@@ -212,3 +212,16 @@ def test_cholesky_underconstrained_and_bad_scaling_literals(live_ref):
     if live_ref is not None:
         ok, R = live_ref.cholesky_partial(A, 2)
         assert ok and abs(R[0, 0] / R[1, 1] - 1e-40) <= 1e-41
+
+
+def test_general_sfm_factor_cal3bundler_error_literal(hm):
+    """gtsam/slam/tests/testGeneralSFMFactor_Cal3Bundler.cpp:96-110 (TEST(GeneralSFMFactor_Cal3Bundler, error)): measurement
+    (3, 0), default Cal3Bundler camera at (0, 0, -6) looking at the origin -> unwhitenedError = (-3, 0).  The linearized
+    factor carries b = -error (GeneralSFMFactor.h:150-152)."""
+    cam = np.concatenate([np.eye(3).reshape(-1), [0, 0, -6.0], [1.0, 0, 0, 0, 0]])
+    pi, Dcam, Dpoint, behind = O.sfm_project(cam, np.zeros((1, 3)))
+    assert not behind[0] and np.abs(pi[0] - np.array([3.0, 0.0]) - [-3.0, 0.0]).max() <= 1e-15
+    J = np.zeros((1, 26)); z = np.array([[3.0, 0.0]]); pt = np.zeros((1, 3)); camc = np.ascontiguousarray(cam[None]); nd = np.zeros(1)
+    hm.hm_sfm_linearize(C.c_long(1), P(camc), P(pt), P(z), C.c_int(0), P(nd), P(J))
+    assert np.abs(J[0, 24:] - [3.0, 0.0]).max() <= 1e-15                       # b = z - h(x) = -(unwhitened error)
+    assert np.abs(J[0, :18].reshape(2, 9) - Dcam[0]).max() <= 1e-14 and np.abs(J[0, 18:24].reshape(2, 3) - Dpoint[0]).max() <= 1e-14

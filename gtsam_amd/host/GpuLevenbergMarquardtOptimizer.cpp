@@ -145,22 +145,24 @@ struct NoiseTable {
 }  // namespace
 
 GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
-                                                               const LevenbergMarquardtParams& params, int device)
+                                                               const LevenbergMarquardtParams& params, int device,
+                                                               const ShardSpec& shards)
     : LevenbergMarquardtOptimizer(graph, initial, [&] {
         // the reference's constructor runs COLAMD when no ordering is given (LevenbergMarquardtParams.h:112-117);
         // the device path has its own elimination structure, so hand it a trivial ordering to skip that work
         if (params.ordering) return params;
         LevenbergMarquardtParams p = params; p.ordering = Ordering(initial.keys()); return p; }()),
-      impl_(new Impl) { init(initial, device); }
+      impl_(new Impl) { init(initial, device, shards); }
 
 GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
                                                                const Ordering& ordering,
-                                                               const LevenbergMarquardtParams& params, int device)
-    : LevenbergMarquardtOptimizer(graph, initial, ordering, params), impl_(new Impl) { init(initial, device); }
+                                                               const LevenbergMarquardtParams& params, int device,
+                                                               const ShardSpec& shards)
+    : LevenbergMarquardtOptimizer(graph, initial, ordering, params), impl_(new Impl) { init(initial, device, shards); }
 
 GpuLevenbergMarquardtOptimizer::~GpuLevenbergMarquardtOptimizer() = default;
 
-void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
+void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, const ShardSpec& shards) {
   Impl& m = *impl_;
   // ---- variables: Values order (sorted by Key, Values.h:74-79) ---------------------------------------------
   m.val_off.push_back(0);
@@ -255,8 +257,12 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device) {
   pb.n_between = (int64_t)bt_1.size(); pb.between_v1 = bt_1.data(); pb.between_v2 = bt_2.data(); pb.between_z = bt_z.data(); pb.between_noise = bt_nz.data();
   pb.n_prior = (int64_t)pr_var.size(); pb.prior_var = pr_var.data(); pb.prior_off = pr_off.data(); pb.prior_data = pr_data.data(); pb.prior_noise = pr_nz.data();
 
+  if (shards.n_shards < 1 || shards.shard < 0 || shards.shard >= shards.n_shards) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: bad ShardSpec");
+  if (shards.n_shards > 1 && !shards.allreduce) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: n_shards > 1 needs an all-reduce callback");
+  if (shards.n_shards > 1 && params_.isIterative()) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: the PCG solver is single-shard");
   check(gtg_create(&m.h, device), "gtg_create");
-  check(gtg_upload_problem(m.h, &pb, 0, 1), "gtg_upload_problem");
+  if (shards.allreduce) check(gtg_set_allreduce(m.h, shards.allreduce, shards.user), "gtg_set_allreduce");   // before the upload: it verifies the layout across the shards
+  check(gtg_upload_problem(m.h, &pb, shards.shard, shards.n_shards), "gtg_upload_problem");
   check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
   const State* s = static_cast<const State*>(state_.get());
   m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;

@@ -17,15 +17,25 @@
 
 namespace gtsam_amd {
 
+/// Multi-GPU (one process per GPU): this process owns shard `shard` of `n_shards` (landmarks by rank modulo n_shards with all
+/// their factors; every shard keeps all cameras / poses).  `allreduce` sums a DEVICE buffer of doubles in place across the
+/// shards on the given stream (e.g. ncclAllReduce(ptr, ptr, n, ncclDouble, ncclSum, comm, (hipStream_t)stream), see
+/// RcclExchange.h); every process builds the same graph and runs the same optimizer calls in lock step.
+struct ShardSpec {
+  int shard = 0, n_shards = 1;
+  gtg_allreduce_fn allreduce = nullptr;
+  void* user = nullptr;
+};
+
 class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer {
  public:
   GpuLevenbergMarquardtOptimizer(const gtsam::NonlinearFactorGraph& graph, const gtsam::Values& initialValues,
                                  const gtsam::LevenbergMarquardtParams& params = gtsam::LevenbergMarquardtParams(),
-                                 int device = 0);
+                                 int device = 0, const ShardSpec& shards = ShardSpec());
   GpuLevenbergMarquardtOptimizer(const gtsam::NonlinearFactorGraph& graph, const gtsam::Values& initialValues,
                                  const gtsam::Ordering& ordering,
                                  const gtsam::LevenbergMarquardtParams& params = gtsam::LevenbergMarquardtParams(),
-                                 int device = 0);
+                                 int device = 0, const ShardSpec& shards = ShardSpec());
   ~GpuLevenbergMarquardtOptimizer() override;
 
   /// One LM iteration on the GPU; state_ (values, error, lambda, counters) is updated exactly like the
@@ -42,7 +52,7 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
-  void init(const gtsam::Values& initial, int device);
+  void init(const gtsam::Values& initial, int device, const ShardSpec& shards);
   bool tryLambdaDevice();            // LevenbergMarquardtOptimizer::tryLambda restated
   void iterateDevice();              // LevenbergMarquardtOptimizer::iterate restated (logFile rows, SUMMARY header)
   void writeLogFileDevice(double currentError);

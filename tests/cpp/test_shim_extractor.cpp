@@ -32,6 +32,11 @@ void hipstub_h2d_record(int i, long long* n, unsigned long long* h) __attribute_
 void hipstub_reset(void) __attribute__((weak));
 }
 
+// all-reduce stand-ins for shards that are set up one after the other in this process (under the stub a "device" pointer is
+// host memory): as if every shard contributed the same buffer -- true for the layout check of the upload -- or nothing
+static int lockstepSum(void* ptr, int64_t n, void*, void* user) { double* p = static_cast<double*>(ptr); for (int64_t i = 0; i < n; i++) p[i] *= *static_cast<int*>(user); return 0; }
+static int noSum(void*, int64_t, void*, void*) { return 0; }
+
 static void report(const char* name) {
   std::printf("CASE %s", name);
   for (int i = 0; i < hipstub_h2d_count(); i++) { long long n; unsigned long long h; hipstub_h2d_record(i, &n, &h); std::printf(" %lld:%llu", n, h); }
@@ -61,6 +66,20 @@ int main(int argc, char** argv) {
     gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial);
     report("sfmexample_bal_dubrovnik_3_7");
     if (std::abs(lm.error() - graph.error(initial)) > 1e-9 * lm.error()) { failures++; std::printf("FAIL initial error\n"); }
+    // the same graph as shard s of 2 (ShardSpec): set-up incl. the layout verification through the callback
+    int world = 2;
+    for (int sh = 0; sh < world; sh++) {
+      try { gtsam_amd::GpuLevenbergMarquardtOptimizer part(graph, initial, LevenbergMarquardtParams(), 0, gtsam_amd::ShardSpec{sh, world, &lockstepSum, &world}); }
+      catch (const std::exception& e) { failures++; std::printf("FAIL sharded construction %d: %s\n", sh, e.what()); }
+    }
+    bool threw = false;   // an all-reduce that does not span the shards is detected at construction
+    try { gtsam_amd::GpuLevenbergMarquardtOptimizer part(graph, initial, LevenbergMarquardtParams(), 0, gtsam_amd::ShardSpec{0, world, &noSum, nullptr}); }
+    catch (const std::runtime_error&) { threw = true; }
+    if (!threw) { failures++; std::printf("FAIL a communicator that does not span n_shards must be rejected\n"); }
+    threw = false;
+    try { gtsam_amd::GpuLevenbergMarquardtOptimizer part(graph, initial, LevenbergMarquardtParams(), 0, gtsam_amd::ShardSpec{0, world, nullptr, nullptr}); }
+    catch (const std::invalid_argument&) { threw = true; }
+    if (!threw) { failures++; std::printf("FAIL n_shards > 1 without a callback must be rejected\n"); }
   }
   {  // examples/Pose2SLAMExample_g2o.cpp:46-67 protocol on w100.graph (load2D creates one noise model object per edge)
     auto gv = load2D(data + "w100.graph");

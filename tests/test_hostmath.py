@@ -165,3 +165,78 @@ def test_pose2_between_prior_retract(hm):
     assert rel(back, O.pose2_local(poses, y)) <= 1e-13
     # local(retract(x, d)) = d up to the wrap of theta: Pose2's chart is first order, exact for this composition
     assert np.allclose(np.angle(np.exp(1j * (back[:, 2] - d[:, 2]))), 0, atol=1e-12) and np.allclose(back[:, :2], d[:, :2], atol=1e-12)
+
+
+def _numerical_columns(f_b, x, vtype, dim, hm, eps=1e-6):
+    """-d b / d delta of a record's right-hand side b(x (+) delta) by central differences through the device's own retract."""
+    cols = []
+    for i in range(dim):
+        d = np.zeros((1, dim)); d[0, i] = eps
+        xp = np.zeros_like(x); xm = np.zeros_like(x)
+        hm.hm_retract(C.c_int(vtype), C.c_long(1), P(x), P(d), P(xp))
+        d[0, i] = -eps
+        hm.hm_retract(C.c_int(vtype), C.c_long(1), P(x), P(d), P(xm))
+        cols.append(-(f_b(xp) - f_b(xm)) / (2 * eps))
+    return np.stack(cols, 1)
+
+
+def test_device_jacobians_against_numerical_derivatives(hm):
+    """The reference's own way of testing a factor (EXPECT_CORRECT_FACTOR_JACOBIANS, numericalDerivative: SURVEY section 4),
+    applied to the device formulas: central differences of the residual through the device's retract against the analytic
+    blocks of the record.  GeneralSFMFactor and GenericProjectionFactor (with and without body_P_sensor) at random
+    configurations in front of the camera; BetweenFactor<Pose3> / <Pose2> at zero error, where the reference's Jacobians
+    (not multiplied by dLog, BetweenFactor.h:115-123) are exact -- the configuration testBetweenFactor.cpp:99-113 uses."""
+    rng = np.random.default_rng(11)
+    unit = np.zeros(1)
+    for trial in range(20):
+        # ---- GeneralSFMFactor<PinholeCamera<Cal3Bundler>, Point3>
+        xi = rng.normal(size=(1, 6)) * [0.8, 0.8, 0.8, 1, 1, 1]
+        R, t = O.pose3_expmap(xi)
+        cam = np.ascontiguousarray(np.concatenate([O.pose_pack(R, t), [[rng.uniform(400, 900), rng.normal(0, 1e-2), rng.normal(0, 1e-3), 0, 0]]], 1))
+        pc = np.array([rng.normal(0, 1), rng.normal(0, 1), rng.uniform(2, 8)])
+        pw = np.ascontiguousarray((R[0] @ pc + t[0])[None]); z = np.ascontiguousarray(rng.normal(0, 50, (1, 2)))
+
+        def sfm_b(c, p=pw):
+            J = np.zeros((1, 26)); hm.hm_sfm_linearize(C.c_long(1), P(np.ascontiguousarray(c)), P(np.ascontiguousarray(p)), P(z), C.c_int(0), P(unit), P(J)); return J[0, 24:].copy()
+        J = np.zeros((1, 26)); hm.hm_sfm_linearize(C.c_long(1), P(cam), P(pw), P(z), C.c_int(0), P(unit), P(J))
+        A1, A2 = J[0, :18].reshape(2, 9), J[0, 18:24].reshape(2, 3)
+        N1 = _numerical_columns(sfm_b, cam, 1, 9, hm)
+        N2 = _numerical_columns(lambda p: sfm_b(cam, p), pw, 2, 3, hm)
+        assert np.abs(N1 - A1).max() <= 1e-6 * max(1.0, np.abs(A1).max()) and np.abs(N2 - A2).max() <= 1e-6 * max(1.0, np.abs(A2).max())
+        # ---- GenericProjectionFactor<Pose3, Point3, Cal3_S2>, optional body_P_sensor
+        pose = np.ascontiguousarray(O.pose_pack(R, t)); K = np.array([rng.uniform(400, 900), rng.uniform(400, 900), rng.normal(0, 0.5), 320.0, 240.0])
+        Rs, ts = O.pose3_expmap(rng.normal(size=(1, 6)) * 0.1); sensor = np.ascontiguousarray(O.pose_pack(Rs, ts)[0])
+        for sen in (None, sensor):
+            sp = P(sen) if sen is not None else None
+            pw2 = pw if sen is None else np.ascontiguousarray((R[0] @ (Rs[0] @ pc + ts[0]) + t[0])[None])
+
+            def proj_b(x, p=pw2):
+                J = np.zeros((1, 20)); hm.hm_proj_linearize(C.c_long(1), P(np.ascontiguousarray(x)), P(K), sp, P(np.ascontiguousarray(p)), P(z), C.c_int(0), P(unit), P(J)); return J[0, 18:].copy()
+            J = np.zeros((1, 20)); hm.hm_proj_linearize(C.c_long(1), P(pose), P(K), sp, P(pw2), P(z), C.c_int(0), P(unit), P(J))
+            A1, A2 = J[0, :12].reshape(2, 6), J[0, 12:18].reshape(2, 3)
+            N1 = _numerical_columns(proj_b, pose, 0, 6, hm)
+            N2 = _numerical_columns(lambda p: proj_b(pose, p), pw2, 2, 3, hm)
+            assert np.abs(N1 - A1).max() <= 1e-6 * max(1.0, np.abs(A1).max()) and np.abs(N2 - A2).max() <= 1e-6 * max(1.0, np.abs(A2).max())
+        # ---- BetweenFactor<Pose3> at zero error
+        R2, t2 = O.pose3_expmap(rng.normal(size=(1, 6))); T1 = pose; T2 = np.ascontiguousarray(O.pose_pack(R2, t2))
+        Ri, ti = O.pose_inverse(R, t); Rz, tz = O.pose_compose(Ri, ti, R2, t2); Z = np.ascontiguousarray(O.pose_pack(Rz, tz))
+
+        def btw_b(a, b):
+            J = np.zeros((1, 78)); hm.hm_between_linearize(C.c_long(1), P(np.ascontiguousarray(a)), P(np.ascontiguousarray(b)), P(Z), C.c_int(0), P(unit), P(J)); return J[0, 72:].copy()
+        J = np.zeros((1, 78)); hm.hm_between_linearize(C.c_long(1), P(T1), P(T2), P(Z), C.c_int(0), P(unit), P(J))
+        assert np.abs(J[0, 72:]).max() <= 1e-12
+        assert np.abs(_numerical_columns(lambda a: btw_b(a, T2), T1, 0, 6, hm) - J[0, :36].reshape(6, 6)).max() <= 1e-6 * max(1.0, np.abs(J[0, :36]).max())
+        assert np.abs(_numerical_columns(lambda b: btw_b(T1, b), T2, 0, 6, hm) - J[0, 36:72].reshape(6, 6)).max() <= 1e-6
+        # ---- BetweenFactor<Pose2> at zero error (3x3 blocks inside the 78-double record, rows of 6)
+        a = np.ascontiguousarray(np.array([[rng.normal(0, 3), rng.normal(0, 3), rng.uniform(-3, 3)]])); b = np.ascontiguousarray(np.array([[rng.normal(0, 3), rng.normal(0, 3), rng.uniform(-3, 3)]]))
+        ca, sa = np.cos(a[0, 2]), np.sin(a[0, 2]); dx, dy = b[0, 0] - a[0, 0], b[0, 1] - a[0, 1]
+        zz = np.ascontiguousarray(np.array([[ca * dx + sa * dy, -sa * dx + ca * dy, b[0, 2] - a[0, 2]]]))       # a^-1 b
+
+        def btw2(aa, bb):
+            J = np.zeros((1, 78)); hm.hm_between2_linearize(C.c_long(1), P(np.ascontiguousarray(aa)), P(np.ascontiguousarray(bb)), P(zz), C.c_int(0), P(unit), P(J)); return J[0]
+        J2 = btw2(a, b)                                   # H1 at [0:9], H2 at [36:45] (3x3 row-major), b at [72:75]
+        assert np.abs(J2[72:75]).max() <= 1e-12
+        N1 = _numerical_columns(lambda aa: btw2(aa, b)[72:75], a, 3, 3, hm)
+        N2 = _numerical_columns(lambda bb: btw2(a, bb)[72:75], b, 3, 3, hm)
+        assert np.abs(N1 - J2[0:9].reshape(3, 3)).max() <= 1e-6 * max(1.0, np.abs(J2[0:9]).max())
+        assert np.abs(N2 - J2[36:45].reshape(3, 3)).max() <= 1e-6

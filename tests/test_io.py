@@ -194,3 +194,31 @@ def test_g2o_writer_matches_reference_writer(tmp_path, live_ref, name, is3d):
     d2 = io.read_g2o3d(my_out) if is3d else io.read_2d(my_out)
     assert np.array_equal(d2["v1"], d["v1"]) and np.array_equal(d2["v2"], d["v2"])
     assert np.abs(d2["z"] - d["z"]).max() <= 2e-5 * max(1.0, np.abs(d["z"]).max())
+
+
+def test_sfmdata_tests_of_the_reference_restated(tmp_path):
+    """gtsam/sfm/tests/testSfmData.cpp:66-160 on the native reader / writer: readBAL_Dubrovnik (3 cameras, 7 tracks, track 0
+    has 3 measurements starting with camera 0, its point projects within 12 px of the measurement), writeBAL_Dubrovnik
+    (what is written reads back to the same cameras, points and measurements)."""
+    path = DATA + "dubrovnik-3-7-pre.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    from oracle import gtsam_oracle as O
+    cams, pts, oc, op, oz = io.read_bal(path)
+    assert cams.shape == (3, 17) and pts.shape == (7, 3)
+    assert int((op == 0).sum()) == 3 and oc[0] == 0
+    pi, _, _, behind = O.sfm_project(cams[0], pts[0][None])
+    assert not behind[0] and np.abs(pi[0] - oz[0]).max() <= 12
+    out = str(tmp_path / "rewritten.txt")
+    io.write_bal(out, cams, pts, oc, op, oz)
+    c2, p2, oc2, op2, oz2 = io.read_bal(out)
+    assert np.array_equal(oc2, oc) and np.array_equal(op2, op)
+    # assert_equal's 1e-9 on what went through the file's float parsing: the reader rounds to binary32 like the reference
+    assert np.abs(c2 - cams).max() <= 1e-5 * np.abs(cams).max() and np.allclose(p2, pts, rtol=1e-6) and np.allclose(oz2, oz, rtol=1e-6)
+    # openGL2gtsam / gtsam2openGL are inverse to each other (testSfmData.cpp:84-112): a camera written and read back keeps
+    # its pose to the file's precision, for a pose with all three rotation components
+    R = O.so3_expmap(np.array([[0.2, 0.7, 1.1]]))[0]
+    cam = np.concatenate([R.reshape(-1), [1.0, 20.0, 10.0], [500.0, 1e-3, 1e-6, 0, 0]])[None]
+    io.write_bal(out, cam, np.array([[0.0, 0.0, 30.0]]), np.array([0], np.int32), np.array([0], np.int32), np.array([[1.0, 2.0]]))
+    c3 = io.read_bal(out)[0]
+    assert np.abs(c3[0, :12] - cam[0, :12]).max() <= 2e-6 * 20 and abs(c3[0, 12] - 500.0) <= 1e-4

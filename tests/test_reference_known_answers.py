@@ -225,3 +225,28 @@ def test_general_sfm_factor_cal3bundler_error_literal(hm):
     hm.hm_sfm_linearize(C.c_long(1), P(camc), P(pt), P(z), C.c_int(0), P(nd), P(J))
     assert np.abs(J[0, 24:] - [3.0, 0.0]).max() <= 1e-15                       # b = z - h(x) = -(unwhitened error)
     assert np.abs(J[0, :18].reshape(2, 9) - Dcam[0]).max() <= 1e-14 and np.abs(J[0, 18:24].reshape(2, 3) - Dpoint[0]).max() <= 1e-14
+
+
+def test_pcg_solver_test_literals():
+    """tests/testPCGSolver.cpp:42-74 (llt: R^T R factors back to R, back substitution gives (6.5, 2.5, 3)) and :78-120
+    (GaussianFactorGraphSystem::multiply / getb on a 3-variable graph with Diagonal sigmas (0.5, 0.3): A^T b and A^T A p
+    literals for the first CG direction p = b); then the oracle's preconditioned CG (block Jacobi) on that system reaches the
+    direct solution."""
+    R = np.array([[1.0, -1, -1], [0, 2, -1], [0, 0, 1]]); AtA = R.T @ R
+    ok, M = O.cholesky_partial(np.block([[AtA, np.array([[1.0], [2.0], [3.0]])], [np.zeros((1, 3)), np.zeros((1, 1))]]), 3)
+    assert ok and np.abs(np.triu(M[:3, :3]) - R).max() <= 1e-12
+    assert np.abs(np.linalg.solve(np.triu(M[:3, :3]), np.array([1.0, 2, 3])) - [6.5, 2.5, 3.0]).max() <= 1e-12
+    # the factor graph of the test: (keys, blocks, b), every row whitened by 1 / sigma
+    I2 = np.eye(2); w = np.diag([1 / 0.5, 1 / 0.3])
+    factors = [({2: 10 * I2}, [-1, -1]), ({2: -10 * I2, 0: 10 * I2}, [2, -1]), ({2: -5 * I2, 1: 5 * I2}, [0, 1]),
+               ({0: -5 * I2, 1: 5 * I2}, [-1, 1.5]), ({0: I2}, [0, 0]), ({1: I2}, [0, 0]), ({2: I2}, [0, 0])]
+    A = np.zeros((2 * len(factors), 6)); b = np.zeros(2 * len(factors))
+    for i, (blocks, rhs) in enumerate(factors):
+        for key, blk in blocks.items():
+            A[2 * i:2 * i + 2, 2 * key:2 * key + 2] = w @ blk
+        b[2 * i:2 * i + 2] = w @ np.array(rhs, float)
+    Atb = A.T @ b; AtA = A.T @ A
+    assert np.abs(Atb - [100.0, -194.444, -20.0, 138.889, -120.0, -55.556]).max() <= 1e-3
+    assert np.abs(AtA @ Atb - [100400, -249074.074, -2080, 148148.148, -146480, 37962.963]).max() <= 1e-3
+    x, its, g0, g1 = O.preconditioned_conjugate_gradient(AtA, Atb, [(0, 2), (2, 4), (4, 6)], 500, 1, 1e-14, 1e-28)
+    assert np.abs(x - np.linalg.solve(AtA, Atb)).max() <= 1e-10 and 1 <= its <= 6

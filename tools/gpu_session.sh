@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/gpu_session.sh [tag] -- one gpurun call's worth of checks in priority order (each step time-boxed, results under
+# gpurun_out/<tag>_*): GPU test suite, fuzz parity against the oracle, bench line with the set-up breakdown, the multi-GPU
+# exchange in both granularities on one GPU (two-shard tests), then the rocprofv3 / PMC passes of tools/profile_round.sh.
+#   gpurun --timeout 600 -- 'bash tools/gpu_session.sh r02a'
+TAG=${1:-session}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO; export TMPDIR=/tmp
+(timeout 120 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -15) > $OUT/${TAG}_gpu_tests.log; head -3 $OUT/${TAG}_gpu_tests.log
+(timeout 120 python tools/gpu_fuzz.py --seeds 16 2>&1 | tail -70) > $OUT/${TAG}_gpu_fuzz.jsonl; tail -1 $OUT/${TAG}_gpu_fuzz.jsonl
+GTG_DEBUG_TIMING=1 timeout 120 python bench.py --steps 8 --warmup 2 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+tail -c 400 $OUT/${TAG}_bench.json; grep "setup\]" $OUT/${TAG}_bench.err | tail -10 > $OUT/${TAG}_host_setup_breakdown.txt
+(GTG_EXCHANGE_TILES=1 timeout 60 python -m pytest tests/test_gpu_sharding.py -q -p no:cacheprovider 2>&1 | tail -3) > $OUT/${TAG}_sharding_tiles.log
+[ "$2" = "profile" ] && bash tools/profile_round.sh $TAG
+true

@@ -3,8 +3,8 @@
 # construction, launch issue, file formats) without a GPU: the host side of every .hip file is instrumented
 # (-Xarch_host -fsanitize=...), the device side is compiled as usual, and the library runs under tools/hipstub.
 #   sh tools/sanitize/host_sanitizers.sh [workloads...]      (default: a small, a sharded-relevant and the headline shape)
-# Round 1: both clean on dubrovnik_3_7, bal:60:6000:7, bal:300:20000:3, sphere2500, ladybug1723, w20000, with and without
-# GTG_ND_DEPTH=2, GTG_HOST_THREADS=8.
+# Round 1: both clean on edge, dubrovnik_3_7, bal:60:6000:7, bal:300:20000:3, sphere2500, ladybug1723, w20000
+# (GTG_HOST_THREADS=8; the default set below also with GTG_ND_DEPTH=2).
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 RT=$(dirname "$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)")

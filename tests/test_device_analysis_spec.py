@@ -1,0 +1,97 @@
+"""Executable specification of the device-side symbolic analysis planned for the next round.
+
+The host builds the Schur term lists with bucketed counting sorts on threads (csrc/analysis.hip).  On the device the same
+lists are to come from three data-parallel primitives: enumerate every landmark's observation pairs at the offsets of an
+exclusive scan, STABLE radix sort of the terms by their block key (row position * n + column position), run-length encode
+the sorted keys.  This test states that formulation in numpy and checks that it reproduces, bit for bit, the term lists the
+library uploads (compared through the upload hashes of tools/hipstub, with GTG_NO_REORDER=1 so that the positions are the
+caller's order): same terms, same order inside every block (landmark order -- the summation order of the device), same
+handling of a camera that observes a landmark twice."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import host_profile as HP  # noqa: E402
+
+_CHILD = r'''
+import ctypes, json, sys
+sys.path.insert(0, %(root)r)
+from tools import host_profile as HP
+from gtsam_amd import lib as L
+stub = ctypes.CDLL(HP.STUB)
+stub.hipstub_h2d_record.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_ulonglong)]
+problem, _ = HP.problem_for(%(workload)r)
+stub.hipstub_reset()
+g = L.DeviceGraph(problem)
+n = ctypes.c_longlong(); h = ctypes.c_ulonglong(); recs = []
+for i in range(stub.hipstub_h2d_count()):
+    stub.hipstub_h2d_record(i, ctypes.byref(n), ctypes.byref(h)); recs.append([n.value, str(h.value)])
+print("RESULT " + json.dumps(recs))
+'''
+
+
+def _fnv(a):
+    """The stub's record hash: FNV-1a over 8-byte little-endian words, then the remaining bytes."""
+    b = np.ascontiguousarray(a).tobytes()
+    h = 1469598103934665603; M = (1 << 64) - 1
+    nw = len(b) // 8
+    for w in np.frombuffer(b[:8 * nw], dtype="<u8").tolist():
+        h = ((h ^ w) * 1099511628211) & M
+    for c in b[8 * nw:]:
+        h = ((h ^ c) * 1099511628211) & M
+    return h
+
+
+def _sort_based_term_lists(problem):
+    """enumerate -> stable sort by block key -> run-length encode (positions = the caller's order of the cameras)."""
+    cam_of = problem.sfm_cam.astype(np.int64); lm_of = problem.sfm_point.astype(np.int64)
+    red_vars = np.where(problem.var_type != 2)[0]; lm_vars = np.where(problem.var_type == 2)[0]
+    red_index = -np.ones(problem.n_vars, np.int64); red_index[red_vars] = np.arange(red_vars.size)
+    lm_index = -np.ones(problem.n_vars, np.int64); lm_index[lm_vars] = np.arange(lm_vars.size)
+    pos = red_index[cam_of]; lm = lm_index[lm_of]
+    nrv = red_vars.size
+    order = np.argsort(lm, kind="stable")                       # landmark -> its observations in factor order (CSR)
+    cnt = np.bincount(lm, minlength=lm_vars.size); ptr = np.concatenate([[0], np.cumsum(cnt)])
+    kmax = int(cnt.max()) if cnt.size else 0
+    stride = kmax * (kmax + 1) + 1                                # emission slots per landmark: 2 per (a, b) pair
+    oa_l = []
+    for k in np.unique(cnt):                                      # all landmarks with k observations at once
+        if k == 0:
+            continue
+        ls = np.where(cnt == k)[0]
+        obs = order[ptr[ls][:, None] + np.arange(k)[None, :]]     # [n_l, k] observation ids
+        a, b = np.tril_indices(k)                                 # a >= b, row-major: the emission order (a, then b <= a)
+        xa, xb = obs[:, a], obs[:, b]; pa, pb = pos[xa], pos[xb]
+        swap = pa < pb
+        oa = np.where(swap, xb, xa); ob = np.where(swap, xa, xb); hi = np.maximum(pa, pb); lo = np.minimum(pa, pb)
+        dup = (pa == pb) & (xa != xb)                             # same camera twice: the mirrored term right behind
+        # interleave: term, then (where dup) its mirror; emission index keeps (landmark, a, b, mirror) order
+        n_l, n_t = oa.shape
+        oa2 = np.stack([oa, ob], 2).reshape(n_l, 2 * n_t); ob2 = np.stack([ob, oa], 2).reshape(n_l, 2 * n_t)
+        key2 = np.repeat(hi * nrv + lo, 2, axis=1)
+        keep = np.stack([np.ones_like(dup), dup], 2).reshape(n_l, 2 * n_t)
+        seq = ls[:, None] * stride + np.arange(2 * n_t)[None, :]  # global emission order: landmark-major
+        oa_l.append(np.stack([seq[keep], oa2[keep], ob2[keep], key2[keep]], 1))
+    allt = np.concatenate(oa_l, 0)
+    allt = allt[np.argsort(allt[:, 0], kind="stable")]            # emission order (what the scan offsets give on the device)
+    srt = np.argsort(allt[:, 3], kind="stable")                   # the stable radix sort by block key
+    keys = allt[srt, 3]
+    starts = np.flatnonzero(np.concatenate([[True], keys[1:] != keys[:-1]]))   # run-length encode
+    return allt[srt, 1].astype(np.int32), allt[srt, 2].astype(np.int32), np.concatenate([starts, [keys.size]]).astype(np.int64)
+
+
+@pytest.mark.parametrize("workload", ["bal:60:6000:7", "baldup:40:3000:3", "bal:300:20000:3"])
+def test_sort_based_formulation_reproduces_the_host_lists(workload):
+    if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
+        pytest.skip("libgtsam_amd.so not built")
+    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_NO_REORDER": "1"})
+    have = {(int(n), int(h)) for n, h in recs}
+    problem, _ = HP.problem_for(workload)
+    oa, ob, ptr = _sort_based_term_lists(problem)
+    assert (oa.nbytes, _fnv(oa)) in have, "pair_oa differs"
+    assert (ob.nbytes, _fnv(ob)) in have, "pair_ob differs"
+    assert (ptr.nbytes, _fnv(ptr)) in have, "pair_ptr differs"

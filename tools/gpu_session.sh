@@ -11,5 +11,9 @@ OUT=$REPO/gpurun_out; mkdir -p $OUT; cd $REPO; export TMPDIR=/tmp
 GTG_DEBUG_TIMING=1 timeout 120 python bench.py --steps 8 --warmup 2 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 400 $OUT/${TAG}_bench.json; grep "setup\]" $OUT/${TAG}_bench.err | tail -10 > $OUT/${TAG}_host_setup_breakdown.txt
 (GTG_EXCHANGE_TILES=1 timeout 60 python -m pytest tests/test_gpu_sharding.py -q -p no:cacheprovider 2>&1 | tail -3) > $OUT/${TAG}_sharding_tiles.log
+# stand-alone prototype of the device-side symbolic analysis against the host's lists (tools/device_analysis)
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/device_analysis/proto.hip -o /tmp/da_proto 2>/dev/null \
+  && timeout 120 python tools/device_analysis/make_input.py ladybug1723 /tmp/da_l1723.bin && timeout 60 /tmp/da_proto /tmp/da_l1723.bin) > $OUT/${TAG}_device_analysis_proto.log 2>&1
+tail -2 $OUT/${TAG}_device_analysis_proto.log
 [ "$2" = "profile" ] && bash tools/profile_round.sh $TAG
 true

@@ -15,5 +15,8 @@ tail -c 400 $OUT/${TAG}_bench.json; grep "setup\]" $OUT/${TAG}_bench.err | tail 
 (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/device_analysis/proto.hip -o /tmp/da_proto 2>/dev/null \
   && timeout 120 python tools/device_analysis/make_input.py ladybug1723 /tmp/da_l1723.bin && timeout 60 /tmp/da_proto /tmp/da_l1723.bin) > $OUT/${TAG}_device_analysis_proto.log 2>&1
 tail -2 $OUT/${TAG}_device_analysis_proto.log
+# explicit hipGraph against stream / event issue on the shape of the Cholesky schedule (tools/graph_probe.hip)
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/graph_probe.hip -o /tmp/graph_probe 2>/dev/null && timeout 60 /tmp/graph_probe 61 && timeout 60 /tmp/graph_probe 239) > $OUT/${TAG}_graph_probe.jsonl 2>&1
+tail -2 $OUT/${TAG}_graph_probe.jsonl
 [ "$2" = "profile" ] && bash tools/profile_round.sh $TAG
 true

@@ -18,5 +18,8 @@ tail -2 $OUT/${TAG}_device_analysis_proto.log
 # explicit hipGraph against stream / event issue on the shape of the Cholesky schedule (tools/graph_probe.hip)
 (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/graph_probe.hip -o /tmp/graph_probe 2>/dev/null && timeout 60 /tmp/graph_probe 61 && timeout 60 /tmp/graph_probe 239) > $OUT/${TAG}_graph_probe.jsonl 2>&1
 tail -2 $OUT/${TAG}_graph_probe.jsonl
+# chain kernel against a chip-filling bulk kernel, and the cheap remedies (tools/contention_probe.hip)
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/contention_probe.hip -o /tmp/contention_probe 2>/dev/null && timeout 60 /tmp/contention_probe) > $OUT/${TAG}_contention_probe.json 2>&1
+tail -1 $OUT/${TAG}_contention_probe.json
 [ "$2" = "profile" ] && bash tools/profile_round.sh $TAG
 true

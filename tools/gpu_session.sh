@@ -12,14 +12,14 @@ GTG_DEBUG_TIMING=1 timeout 120 python bench.py --steps 8 --warmup 2 --cpu-baseli
 tail -c 400 $OUT/${TAG}_bench.json; grep "setup\]" $OUT/${TAG}_bench.err | tail -10 > $OUT/${TAG}_host_setup_breakdown.txt
 (GTG_EXCHANGE_TILES=1 timeout 60 python -m pytest tests/test_gpu_sharding.py -q -p no:cacheprovider 2>&1 | tail -3) > $OUT/${TAG}_sharding_tiles.log
 # stand-alone prototype of the device-side symbolic analysis against the host's lists (tools/device_analysis)
-(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/device_analysis/proto.hip -o /tmp/da_proto 2>/dev/null \
-  && timeout 120 python tools/device_analysis/make_input.py ladybug1723 /tmp/da_l1723.bin && timeout 60 /tmp/da_proto /tmp/da_l1723.bin) > $OUT/${TAG}_device_analysis_proto.log 2>&1
+# (the probes are prebuilt by tools/build_probes.sh in the build container and travel with the snapshot)
+(timeout 120 python tools/device_analysis/make_input.py ladybug1723 /tmp/da_l1723.bin && timeout 60 tools/device_analysis_proto.bin /tmp/da_l1723.bin) > $OUT/${TAG}_device_analysis_proto.log 2>&1
 tail -2 $OUT/${TAG}_device_analysis_proto.log
 # explicit hipGraph against stream / event issue on the shape of the Cholesky schedule (tools/graph_probe.hip)
-(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/graph_probe.hip -o /tmp/graph_probe 2>/dev/null && timeout 60 /tmp/graph_probe 61 && timeout 60 /tmp/graph_probe 239) > $OUT/${TAG}_graph_probe.jsonl 2>&1
+(timeout 60 tools/graph_probe.bin 61 && timeout 60 tools/graph_probe.bin 239) > $OUT/${TAG}_graph_probe.jsonl 2>&1
 tail -2 $OUT/${TAG}_graph_probe.jsonl
 # chain kernel against a chip-filling bulk kernel, and the cheap remedies (tools/contention_probe.hip)
-(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/contention_probe.hip -o /tmp/contention_probe 2>/dev/null && timeout 60 /tmp/contention_probe) > $OUT/${TAG}_contention_probe.json 2>&1
+(timeout 60 tools/contention_probe.bin) > $OUT/${TAG}_contention_probe.json 2>&1
 tail -1 $OUT/${TAG}_contention_probe.json
 [ "$2" = "profile" ] && bash tools/profile_round.sh $TAG
 true

@@ -114,7 +114,7 @@ hipError_t hipLaunchKernel(const void* f, dim3s grid, dim3s block, void** args, 
 hipError_t hipFuncSetAttribute(const void* f, int attr, int v) { (void)f; (void)attr; (void)v; return 0; }
 
 /* ---- devices ---- */
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+hipError_t hipGetDeviceCount(int* n) { *n = 8; return 0; }   /* a node: one process per "device" in the multi-rank dry runs */
 hipError_t hipSetDevice(int d) { (void)d; return 0; }
 hipError_t hipGetLastError(void) { return 0; }
 const char* hipGetErrorString(hipError_t e) { (void)e; return "hipstub: no error"; }

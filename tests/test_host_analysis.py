@@ -147,7 +147,7 @@ for name, fn in [("wrong_dim", wrong_dim), ("bad_key", bad_key), ("cam_as_point"
 hh, rc, e = upload(good, shard=2, n=2); out["bad_shard"] = [rc, e]; lib.gtg_destroy(hh)
 hh, rc, e = upload(good, shard=0, n=2); lib.gtg_set_values(hh, v0.ctypes.data, v0.size)
 out["sharded_without_allreduce"] = [rc, lib.gtg_linearize(hh), err()]; lib.gtg_destroy(hh)
-hh = C.c_void_p(); out["bad_device"] = [lib.gtg_create(C.byref(hh), 5), err()]
+hh = C.c_void_p(); out["bad_device"] = [lib.gtg_create(C.byref(hh), 64), err()]   # the stub shows 8 devices
 print("RESULT " + json.dumps(out))
 '''
 

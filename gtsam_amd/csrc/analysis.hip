@@ -524,6 +524,12 @@ void analyze(gtg_context& c) {
       for (int64_t i : c.h_pad_index) T1[(size_t)(i / kTile) * nt + (size_t)(i / kTile)] = 1;
       std::vector<int32_t> ex;
       const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
+      // default schedule: the dataflow pass (chol_dataflow.hip), symbolic fill at 128-tile granularity.  GTG_CHOL=streams
+      // selects the per-column launch sequence of cholesky.hip; the elimination-tree schedule only exists there.
+      const char* sched = std::getenv("GTG_CHOL");
+      c.use_df = part_of_pos.empty() && !(sched && std::string(sched) == "streams");
+      free_df_plan(c.df);
+      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s);
       for (int a = 0; a < nt; a++)
         for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
       for (int b = 0; b < nt; b++) if (dense || rhs[(size_t)b]) { ex.push_back(nt); ex.push_back(b); }
@@ -624,7 +630,7 @@ void analyze(gtg_context& c) {
   c.layout_verified = false;
   if (c.n_shards > 1 && c.allreduce) verify_layout(c);
 
-  c.chol_flops = c.plan.flops;
+  c.chol_flops = c.use_df ? c.df.flops : c.plan.flops;
   // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements +
   // variable blocks read, Jacobian records written and read once by the assembly, blocks written
   c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + 2.0 * kSfmRec * 8) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +

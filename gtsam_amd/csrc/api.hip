@@ -142,6 +142,7 @@ int gtg_destroy(gtg_handle c) {
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
   c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
+  free_df_plan(c->df);
   destroy_chol_streams(*c);
   for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -369,7 +370,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda: call gtg_linearize first");
   if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
-  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
   if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
@@ -388,7 +389,9 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
     }
   }
-  { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data()); launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
+  { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
+    if (c->use_df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL);
+    else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
   { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
     launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p);
     launch_back_substitute(*c);
@@ -401,6 +404,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
+  if (c->h_scalars[SC_TIMEOUT] != 0.0) throw std::runtime_error("gtg_try_lambda: a dependency wait of the factorisation ran into its bound (GPU shared or preempted?); the step was not computed");
   if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq)) return GTG_INDETERMINATE;
   out[0] = c->h_scalars[SC_LIN0];
   out[1] = c->h_scalars[SC_LIN1];
@@ -418,7 +422,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda_pcg: call gtg_linearize first");
   if (!(lambda > 0.0) || !cg) throw std::invalid_argument("gtg_try_lambda_pcg: lambda must be > 0, cg = {max, min, eps_rel, eps_abs}");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
-  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, sizeof(double), c->stream), "memset");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   double g0 = 0.0, g1 = 0.0;
   int its = 0;
@@ -597,32 +601,67 @@ int gtg_debug_plan_lists(gtg_handle c, int32_t* rows, int32_t* pairs, int32_t* b
   GTG_CATCH
 }
 
+int gtg_debug_df_plan(gtg_handle c, int64_t sizes[4], int32_t* tasks, int32_t* klist) {
+  GTG_TRY
+  if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_df_plan: no problem uploaded");
+  const DfPlan& df = c->df;
+  sizes[0] = df.nt; sizes[1] = df.n_tasks; sizes[2] = (int64_t)df.h_klist.size(); sizes[3] = c->use_df ? 1 : 0;
+  if (tasks) std::copy(df.h_tasks.begin(), df.h_tasks.end(), tasks);
+  if (klist) std::copy(df.h_klist.begin(), df.h_klist.end(), klist);
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_debug_df_trace(gtg_handle c, int64_t* out, int64_t n) {
+  GTG_TRY
+  if (!c || !c->uploaded || !out || !c->df.trace.p || n != (int64_t)c->df.trace.n) throw std::invalid_argument("gtg_debug_df_trace: no trace (GTG_DF_TRACE=1 at upload) or wrong size");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemcpy(out, c->df.trace.p, sizeof(long long) * n, hipMemcpyDeviceToHost), "D2H");
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_debug_df_ctrl(gtg_handle c, int32_t out[16]) {
+  GTG_TRY
+  if (!c || !c->uploaded || !out || !c->df.ctrl.p) throw std::invalid_argument("gtg_debug_df_ctrl: no dataflow schedule");
+  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  check_hip(hipMemcpy(out, c->df.ctrl.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost), "D2H");
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   GTG_TRY
   if (!c || !A || n < 1) throw std::invalid_argument("gtg_dense_cholesky_host: bad arguments");
   check_hip(hipSetDevice(c->device), "hipSetDevice");
   const int NP = (n + kTile - 1) / kTile * kTile;
   DevBuf<double> S, Dinv, x, fail;
-  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(1);
+  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(2);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
   if (!c->chol_epoch_dev.p) { c->chol_epoch_dev.alloc(1); check_hip(hipMemset(c->chol_epoch_dev.p, 0, sizeof(long long)), "memset"); }
   check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");
-  check_hip(hipMemsetAsync(fail.p, 0, sizeof(double), c->stream), "memset");
+  check_hip(hipMemsetAsync(fail.p, 0, 2 * sizeof(double), c->stream), "memset");
   check_hip(hipMemcpy2DAsync(S.p, sizeof(double) * NP, A, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream), "H2D 2D");
   std::vector<double> ones(NP - n, 1.0);
   if (NP > n) check_hip(hipMemcpy2DAsync(S.p + (size_t)n * NP + n, sizeof(double) * (NP + 1), ones.data(), sizeof(double), sizeof(double), NP - n, hipMemcpyHostToDevice, c->stream), "pad");
   if (rhs) check_hip(hipMemcpyAsync(S.p + (size_t)NP * NP, rhs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "rhs");
   CholPlan plan;
   build_chol_plan(plan, NP / kTile, nullptr, c->stream);   // dense
-  launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p);
+  DfPlan df;
+  const char* sched = std::getenv("GTG_CHOL");
+  const bool use_df = !(sched && std::string(sched) == "streams");
+  if (use_df) { build_df_plan(df, NP / kTile, nullptr, c->stream); launch_cholesky_df(*c, S.p, NP, df, Dinv.p, fail.p); }
+  else launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p);
   if (rhs) launch_backward_solve(*c, S.p, NP, plan, Dinv.p, x.p);
-  double hf = 0;
-  check_hip(hipMemcpyAsync(&hf, fail.p, sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
+  double hf2[2] = {0, 0};
+  check_hip(hipMemcpyAsync(hf2, fail.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
-  return hf != 0.0 ? GTG_INDETERMINATE : GTG_OK;
+  free_df_plan(df);
+  if (hf2[1] != 0.0) throw std::runtime_error("gtg_dense_cholesky_host: a dependency wait of the factorisation ran into its bound");
+  return hf2[0] != 0.0 ? GTG_INDETERMINATE : GTG_OK;
   GTG_CATCH
 }
 

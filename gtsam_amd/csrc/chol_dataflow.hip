@@ -1,0 +1,614 @@
+// chol_dataflow.hip -- the tile-sparse FP64 Cholesky of the reduced camera / pose system as ONE dataflow pass.
+//
+// Same mathematics and the same tile storage as cholesky.hip (gtsam::choleskyPartial, base/cholesky.cpp:107-158, on the
+// root of the reduced system; rhs carried as an extra tile row = forward solve for free), different schedule:
+//
+//   * LEFT-LOOKING, one task per stored 128x128 tile.  Task (I, J), I > J:  R = A(I,J) - sum_k L(I,k) L(J,k)^T over the
+//     column tiles k < J where both operands are stored, accumulated in the MFMA accumulators over the whole contraction
+//     (the tile is read once and written once: no re-read / re-write of C per column pair as in the right-looking
+//     schedule), then L(I,J) = R L(J,J)^-T by block substitution in registers, streamed behind the panels of the
+//     diagonal tile.  Task PD(J): the same accumulation for the diagonal tile.
+//   * TWO PERSISTENT KERNELS per factorisation instead of ~440 launches: k_df_bulk (two workgroups per CU) takes the
+//     tile tasks from a ticket counter in a fixed topological order (column by column); k_df_chain (one workgroup on a
+//     CU the bulk stream's CU mask leaves free) factors the diagonal tiles one after the other with the streamed
+//     32-column panel of chol_device.h.  Dependencies are epoch-stamped flags in HBM (release / acquire at agent
+//     scope): a task only ever waits for tasks that precede it in the ticket order, and tickets are taken in order
+//     by running workgroups, so the earliest unfinished task always runs -- no deadlock whatever the dispatch order.
+//   * The serial chain per block column is: diagonal tile (k_df_chain) -> last substitution step of tile (J+1, J) ->
+//     its contribution to the next diagonal tile, applied by k_df_chain itself in 32-column slices as the substitution
+//     publishes them (PD(J+1) leaves that one contraction step out) -> next diagonal tile; everything else runs beside it.
+//
+// All sums run in a fixed order (the k list of a task): results are bit-reproducible and independent of which workgroup
+// ran which task.  A dependency wait that runs into its bound raises fail[1] (reported as an error by the C ABI, never
+// as "not positive definite"), after which every wait falls through and both kernels drain.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <mutex>
+#include <set>
+#include <vector>
+
+#include "chol_device.h"
+
+namespace gt {
+
+namespace {
+
+constexpr int KC = 16;            // contraction chunk staged per LDS-DMA round (columns)
+constexpr int ROWB = KC * 8;      // bytes per LDS row of a chunk
+constexpr int CH = T * KC * 8;    // bytes of one 128-row panel chunk
+constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of the substitution
+constexpr int kSpinLimit = 1 << 22;
+constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
+constexpr size_t kSmemBulk = std::max<size_t>(std::max<size_t>(4 * (size_t)CH, sizeof(double) * 64 * (T + 2)), sizeof(double) * (T * PX + 4 * kImgDoubles));
+constexpr size_t kSmemPotrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
+constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 * SB * PB;   // + one 128 x 32 slice of the tile below
+// flag values: epoch * 8 + steps; a tile (I, J) is final at 4 steps (its four 32-column blocks), a diagonal tile's word in
+// its Dinv slot counts released panels, pd_flag is epoch * 8 + 4 when the accumulated diagonal tile is in
+__device__ __forceinline__ long long final_of(long long epoch) { return epoch * 8 + 4; }
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---- cross-workgroup visibility without cache-wide fences -----------------------------------------------------------
+// The two kernels exchange tiles through HBM while they run, between XCDs whose L2s are not coherent with each other.  The
+// textbook protocol (release fence = write back the whole L2, acquire fence = invalidate it) costs microseconds per use with
+// 60 workgroups per XCD producing dirty lines (first version: 45-80 us per tile in the substitution, all of it fences).
+// Instead (GTG_DF_FENCES=0, the default):
+//   * every datum another workgroup will read is stored WRITE-THROUGH (sc1: agent-scope atomic store, relaxed), so it is
+//     in memory when the store is acknowledged; the producer waits for its own stores (s_waitcnt vmcnt(0)), a workgroup
+//     barrier collects the wavefronts, then one lane stores the flag (write-through as well);
+//   * a consumer polls the flag with L2-bypassing loads and then reads the data with plain loads: a tile is written exactly
+//     once per factorisation, by one workgroup, and nobody reads it before its flag is up -- so no L2 / L1 can hold a stale
+//     copy of it (kernel boundaries invalidate the caches, the previous factorisation's values are not cached).
+// That argument is about this schedule, not about the memory model; -DGTG_DF_FENCES=1 restores the fences for comparison.
+#ifndef GTG_DF_FENCES
+#define GTG_DF_FENCES 0
+#endif
+__device__ __forceinline__ void st_wt(double* p, double v) {
+#if GTG_DF_FENCES
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void stores_done() {   // this wavefront's stores are acknowledged (resp. released)
+#if GTG_DF_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void st_flag(long long* p, long long v) {
+#if GTG_DF_FENCES
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void acquired() {
+#if GTG_DF_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+__device__ __forceinline__ long long ld_flag(const long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool timed_out(const double* fail) {
+  return __hip_atomic_load(reinterpret_cast<const long long*>(fail + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+// Every lane of the calling wavefront polls the same words (one broadcast load); bounded: see the file comment.
+// The first wait that gives up leaves a record (what it waited for) in dbg[0..7] (gtg_debug_df_ctrl).
+__device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail,
+                                           int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
+  int spins = 0;
+  while (ld_flag(f1) < v1 || ld_flag(f2) < v2) {
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 255) == 0) {
+      if (timed_out(fail)) break;
+      if (spins > kSpinLimit) {
+        if (dbg && atomicCAS(dbg, 0, kind) == 0) {
+          dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
+        }
+        fail[1] = 1.0; break;
+      }
+    }
+  }
+  acquired();
+}
+
+// Published 32-column blocks (0..4) of the two operand tiles of a contraction step: the smaller of their two flags relative
+// to this factorisation's base (flags of earlier factorisations count as 0).  Wave-uniform.
+__device__ __forceinline__ int tile_progress(const long long* f1, const long long* f2, long long flagbase) {
+  const long long a = ld_flag(f1) - flagbase, b = ld_flag(f2) - flagbase;
+  const long long m = a < b ? a : b;
+  return __builtin_amdgcn_readfirstlane((int)(m < 0 ? 0 : m));
+}
+__device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail,
+                                             int32_t* dbg, int kind, int a, int b, int c) {
+  wait_flags(f1, flagbase + need, f2, flagbase + need, fail, dbg, kind, a, b, c);
+  return need;   // (at least; the caller asks again when it needs more)
+}
+
+// ---- one bulk task ------------------------------------------------------------------------------------------------
+// 8 wavefronts in 4 x 2, each 32 x 64 = 2 x 4 MFMA tiles (the geometry of k_syrk: two workgroups per CU give the four
+// waves per SIMD the FP64 matrix pipe needs).  Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by
+// LDS-DMA, double buffered, 16-byte slots XOR-swizzled on the source address and on the operand reads.
+__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int NP, int nt, int I, int J,
+                                         const int32_t* __restrict__ kl, int kcnt, long long* __restrict__ tile_flag,
+                                         long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
+                                         double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
+  // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
+  // the persistent task loop and kept alive (and spilled) across it
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int TI = 2, TJ = 4, NQ = 2;
+  __builtin_amdgcn_s_setprio(0);
+  double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  const double* Arow = S + ((int64_t)I * T) * NP;
+  const double* Brow = S + ((int64_t)J * T) * NP;
+  const long long* fI = tile_flag + (int64_t)I * nt;
+  const long long* fJ = tile_flag + (int64_t)J * nt;
+  const long long fin = final_of(epoch);
+  const long long flagbase = epoch * 8;
+
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto stage = [&](const double* Ap, const double* Bp, int ch, int buf) {
+    char* base = smem_raw + buf * 2 * CH;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int row = 8 * (NQ * wave + q) + drow;
+      const int logical = dslot ^ ((row >> 1) & 7);
+      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
+      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (NQ * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (NQ * wave + q) * 1024), 16, 0, 0);
+    }
+  };
+
+  // element (ti, tj, r) of this lane: uniform part (scalar registers) + one 32-bit lane offset
+  const int lane_off = lk * NP + lr;
+  auto crow = [&](int ti, int tj, int r) -> double* { return C + ((int64_t)(wr * 32 + ti * 16 + 4 * r) * NP + wc * 64 + tj * 16); };
+  v4f64 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+    for (int tj = 0; tj < TJ; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[ti][tj][r] = crow(ti, tj, r)[lane_off];
+
+  if (kcnt > 0) {
+    // A contraction step consumes its two operand tiles 16 columns at a time, and a tile is published in 32-column blocks
+    // while its substitution runs: a chunk only waits for the block it reads.  For every step but the most recent ones both
+    // tiles are long final and the test is a scalar compare; for the last step (block column J-1, whose tiles become final
+    // behind the diagonal tile that is being factored right now) the contraction streams behind the substitution.
+    int k = kl[0];
+    int cp = wait_progress(fI + k, fJ + k, flagbase, 1, fail, dbg, 1, I, J, k);   // progress known for the current step
+    const double* Ak = Arow + (int64_t)k * T;
+    const double* Bk = Brow + (int64_t)k * T;
+    stage(Ak, Bk, 0, 0);
+    __syncthreads();
+    const int a_row_off = (wr * 32 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
+    const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
+    for (int ki = 0; ki < kcnt; ki++) {
+      // The end of a task is a link of a serial chain (the next tile of this tile row, and the diagonal through it, wait for
+      // it): its last two contraction steps and its substitution win issue arbitration against the co-resident workgroup.
+      // Not the whole task: a workgroup that contracts at full speed for hundreds of microseconds starves its neighbour,
+      // which is somebody else's chain link.
+      if (ki + 2 == kcnt) __builtin_amdgcn_s_setprio(2);
+      // the flags of the next contraction step, fetched a whole step ahead of their use
+      const int kn = (ki + 1 < kcnt) ? kl[ki + 1] : k;
+      int np = tile_progress(fI + kn, fJ + kn, flagbase);
+      const double* An = Arow + (int64_t)kn * T;
+      const double* Bn = Brow + (int64_t)kn * T;
+#pragma unroll
+      for (int ch = 0; ch < T / KC; ch++) {
+        const int cur = ch & 1;
+        if (ch + 1 < T / KC) {
+          const int need = ((ch + 1) >> 1) + 1;
+          if (cp < need) { cp = tile_progress(fI + k, fJ + k, flagbase); if (cp < need) cp = wait_progress(fI + k, fJ + k, flagbase, need, fail, dbg, 2, I, J, k); }
+          stage(Ak, Bk, ch + 1, cur ^ 1);
+        } else if (ki + 1 < kcnt) {
+          if (np < 1) np = wait_progress(fI + kn, fJ + kn, flagbase, 1, fail, dbg, 2, I, J, kn);
+          stage(An, Bn, 0, cur ^ 1);
+        }
+        const char* Ac = smem_raw + cur * 2 * CH;
+        const char* Bc = Ac + CH;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+          const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
+          double a[TI], b[TJ];
+#pragma unroll
+          for (int t = 0; t < TI; t++) a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
+#pragma unroll
+          for (int t = 0; t < TJ; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
+#pragma unroll
+          for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+            for (int tj = 0; tj < TJ; tj++) acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]);
+        }
+        __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
+      }
+      k = kn; Ak = An; Bk = Bn; cp = np;
+    }
+  }
+  if (tr && tid == 0) tr[1] = wall_clock64();
+  __builtin_amdgcn_s_setprio(2);
+  // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
+  // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
+  // L(p, q-1), p >= q, are out by then as well):
+  //   R_p -= X_{q-1} L(p, q-1)^T for the blocks p >= q,  then  X_q = R_q Linv(q,q)^T  (stored, and published: flag = 8 epoch + q + 1)
+  // Layout: the tile first changes from the contraction's 32 x 64 per wavefront to 16 ROWS x all 128 columns per wavefront
+  // (two rounds through LDS).  A row of X depends on the same row of R only, so from here on the wavefronts are independent:
+  // accumulator -> A-operand conversions go through a wave-private LDS patch, every register index is a compile-time
+  // constant and every wavefront executes the same straight-line code (a block owned by half of the wavefronts, or a register
+  // chosen at run time, made the compiler park the accumulators in scratch).  Shared per step: the B operand images
+  // (<= 3 blocks L(p, q-1) + Linv(q,q)), fetched into LDS by all threads at once -- one memory latency per step.
+  const double* Xinv = Xinv_all + (size_t)J * T * T;
+  const long long* pflag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
+  long long* myflag = tile_flag + (int64_t)I * nt + J;
+  v4f64 x[8];   // column tiles 0..7 (16 columns each) of rows 32 wr + 16 wc + lk + 4 r
+  {
+    constexpr int PE = T + 2;
+    double* E = reinterpret_cast<double*>(smem_raw);   // [64][PE]
+#pragma unroll
+    for (int ct = 0; ct < 8; ct++) x[ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; tj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) E[(16 * wr + lk + 4 * r) * PE + 64 * wc + 16 * tj + lr] = acc[round][tj][r];
+      __syncthreads();
+      const bool mine = (wc == round);
+#pragma unroll
+      for (int ct = 0; ct < 8; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double v = E[(16 * wr + lk + 4 * r) * PE + 16 * ct + lr];
+          x[ct][r] = mine ? v : x[ct][r];
+        }
+      __syncthreads();
+    }
+  }
+  double* W = reinterpret_cast<double*>(smem_raw) + wave * (16 * PX);   // wave-private 16 x 32 patch
+  double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
+  double* Crow = C + (int64_t)(32 * wr + 16 * wc) * NP;                 // this wavefront's 16 rows of the tile
+  if (I == J) {
+    // PD(J): the diagonal tile with its updates in (all but block column J-1's, which k_df_chain applies itself)
+#pragma unroll
+    for (int ct = 0; ct < 8; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * ct) + lane_off, x[ct][r]);
+    stores_done();
+    __syncthreads();
+    if (tid == 0) st_flag(pd_flag + J, fin);
+    return;
+  }
+  long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
+  double2 v[4];                   // this thread's 16 bytes of each image of the step (slots 0 .. 3-q = L(q + s, q - 1), slot 3 = Linv(q,q))
+  bool have = false;              // ... already fetched (the panel was out when the previous step ended: no exposed latency)
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (pf < flagbase + q + 1) {
+      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, dbg, 3, I, J, q);
+      pf = flagbase + q + 1;
+    }
+    if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
+    if (!have) {
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) {
+        const int p = q + sl;
+        const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
+        if ((sl == 3) || (q > 0 && p < 4)) v[sl] = reinterpret_cast<const double2*>(Xinv + kOpndBase + (size_t)blk * kImgDoubles)[tid];
+      }
+    }
+    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory (its stores were issued a whole poll + load ago)
+    __syncthreads();   // the previous step's images have been consumed; X_{q-1} is out of every wavefront
+    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++)
+      if ((sl == 3) || (q > 0 && q + sl < 4)) reinterpret_cast<double2*>(img + sl * kImgDoubles)[tid] = v[sl];
+    have = false;
+    if (q < 3) {   // is the next panel out already?  then fetch its images now, behind this step's arithmetic
+      pf = ld_flag(pflag);
+      if (pf >= flagbase + q + 2) {
+        have = true;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+          const int p = q + 1 + sl;
+          const int blk = (sl == 3) ? 7 + q : p * (p - 1) / 2 + q;
+          if ((sl == 3) || (p < 4)) v[sl] = reinterpret_cast<const double2*>(Xinv + kOpndBase + (size_t)blk * kImgDoubles)[tid];
+        }
+      }
+    }
+    __syncthreads();
+    if (q > 0) {   // W holds -X_{q-1} of this wavefront's rows
+      double a[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
+#pragma unroll
+      for (int p = q; p < 4; p++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          double bl[8];
+          const double2* op = reinterpret_cast<const double2*>(img + (p - q) * kImgDoubles + (t * 64 + lane) * 8);
+#pragma unroll
+          for (int h = 0; h < 4; h++) { const double2 v = op[h]; bl[2 * h] = v.x; bl[2 * h + 1] = v.y; }
+#pragma unroll
+          for (int s = 0; s < 8; s++) x[2 * p + t] = MFMA(a[s], bl[s], x[2 * p + t]);
+        }
+    }
+    // X_q = R_q Linv(q,q)^T
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) W[(lk + 4 * r) * PX + 16 * t + lr] = x[2 * q + t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    {
+      double a[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        double bi[8];
+        const double2* op = reinterpret_cast<const double2*>(img + 3 * kImgDoubles + (t * 64 + lane) * 8);
+#pragma unroll
+        for (int h = 0; h < 4; h++) { const double2 v = op[h]; bi[2 * h] = v.x; bi[2 * h + 1] = v.y; }
+        v4f64 xn = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) xn = MFMA(a[s], bi[s], xn);
+        x[2 * q + t] = xn;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // operand reads of R_q before -X_q overwrites the patch
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double v = x[2 * q + t][r];
+        W[(lk + 4 * r) * PX + 16 * t + lr] = -v;   // negated: the A operand of the next step's updates
+        st_wt((Crow + (int64_t)(4 * r) * NP + 32 * q + 16 * t) + lane_off, v);
+      }
+  }
+  stores_done();
+  __syncthreads();
+  if (tid == 0) st_flag(myflag, flagbase + 4);
+}
+
+__global__ __launch_bounds__(512, 4) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+                                                    int ntasks, const int32_t* __restrict__ klist,
+                                                    long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                                    double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
+                                                    double* __restrict__ fail, const long long* __restrict__ epoch_p,
+                                                    long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ int s_task;
+  const long long epoch = *epoch_p;
+  for (;;) {
+    if (threadIdx.x == 0) s_task = atomicAdd(ctrl, 1);
+    __syncthreads();
+    const int t = s_task;
+    __syncthreads();
+    if (t >= ntasks) return;
+    const int32_t* d = tasks + 4 * (int64_t)t;
+    long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
+    if (tr && threadIdx.x == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
+    }
+    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], tile_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
+    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+  }
+}
+
+// one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
+__device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
+  double* Cb = A + boff(ib, cb);
+  const double* Li = X + ib * SB * PB;
+  const double* Lc = X + cb * SB * PB;
+  v4f64 acc;
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
+#pragma unroll
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
+    acc = MFMA(av, bv, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
+}
+
+// The diagonal tiles, one after the other.  Tile J: wait until PD(J) is in (every update but the one of block column J-1),
+// bring it into LDS, apply  C -= L(J,J-1) L(J,J-1)^T  in four 32-column slices as the substitution of tile (J, J-1) publishes
+// them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
+// substitution steps of the tiles below through the tile's progress word).
+__global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
+                                                     const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
+                                                     const int32_t* __restrict__ has_sub, double* __restrict__ fail,
+                                                     const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
+                                                     long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const long long epoch = *epoch_p;
+  double* A = reinterpret_cast<double*>(smem_raw);
+  double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  for (int J = 0; J < nt; J++) {
+    if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, ctrl + 8, 4, J, J, 0);
+    __syncthreads();
+    acquired();
+    if (tid == 0) { ctrl[1] = J + 1; if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started
+    const double* tile = S + ((int64_t)J * T) * NP + (int64_t)J * T;
+    diag_tile_to_lds(tile, NP, A, tid);
+    if (has_sub[J]) {
+      const double* sub = tile - T;   // tile (J, J-1)
+      const long long* sflag = tile_flag + (int64_t)J * nt + (J - 1);
+#pragma unroll 1
+      for (int q = 0; q < 4; q++) {
+        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, ctrl + 8, 5, J, J - 1, q);
+        __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
+        acquired();
+        {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
+          double2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
+            v[u] = *reinterpret_cast<const double2*>(sub + (int64_t)row * NP + SB * q + c2);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
+            double* d = X + (row >> 5) * SB * PB + (row & 31) * PB + c2;
+            d[0] = v[u].x; d[1] = v[u].y;
+          }
+        }
+        __syncthreads();
+        for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
+          const int blk = t >> 2;
+          int ib = 0, rem = blk;
+          while (rem > ib) { rem -= ib + 1; ib++; }
+          slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
+        }
+      }
+    }
+    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true);
+    __syncthreads();
+    if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
+  }
+}
+
+__global__ void k_df_begin(long long* epoch, int32_t* ctrl) { *epoch += 1; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; }
+
+}  // namespace
+
+// ---- host: task lists --------------------------------------------------------------------------------------------
+// tile_struct: (nt x nt) row-major bytes, lower triangle: tile (I, J) holds something before the factorisation
+// (nullptr = dense).  Symbolic elimination at tile granularity adds the fill; the rhs row (tile row nt) is dense.
+void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t stream) {
+  std::vector<uint8_t> B((size_t)nt * nt, 0);
+  for (int i = 0; i < nt; i++)
+    for (int j = 0; j <= i; j++) B[(size_t)i * nt + j] = tile_struct ? (*tile_struct)[(size_t)i * nt + j] : 1;
+  for (int i = 0; i < nt; i++) B[(size_t)i * nt + i] = 1;
+  for (int k = 0; k < nt; k++) {
+    std::vector<int> r;
+    for (int i = k + 1; i < nt; i++) if (B[(size_t)i * nt + k]) r.push_back(i);
+    for (size_t a = 0; a < r.size(); a++)
+      for (size_t b = 0; b <= a; b++) B[(size_t)r[a] * nt + r[b]] = 1;
+  }
+  std::vector<std::vector<int32_t>> rowcols(nt);
+  for (int i = 0; i < nt; i++)
+    for (int k = 0; k < i; k++) if (B[(size_t)i * nt + k]) rowcols[i].push_back(k);
+  df.h_tasks.clear(); df.h_klist.clear();
+  const double t3 = (double)T * T * T;
+  double flops = 0.0; int64_t stored = 0;
+  auto emit = [&](int I, int J, const std::vector<int32_t>& ks) {
+    df.h_tasks.push_back(I); df.h_tasks.push_back(J);
+    df.h_tasks.push_back((int32_t)df.h_klist.size()); df.h_tasks.push_back((int32_t)ks.size());
+    df.h_klist.insert(df.h_klist.end(), ks.begin(), ks.end());
+  };
+  std::vector<int32_t> ks;
+  std::vector<int32_t> has_sub(nt, 0);
+  for (int J = 0; J < nt; J++) {
+    // the contribution of block column J-1 to the diagonal tile is applied by k_df_chain itself (streamed): not in PD's list
+    ks = rowcols[J];
+    if (!ks.empty() && ks.back() == J - 1) { ks.pop_back(); has_sub[J] = 1; }
+    emit(J, J, ks);
+    flops += t3 / 3.0 + (double)rowcols[J].size() * t3; stored++;
+    for (int I = J + 1; I < nt; I++) {
+      if (!B[(size_t)I * nt + J]) continue;
+      ks.clear();
+      std::set_intersection(rowcols[I].begin(), rowcols[I].end(), rowcols[J].begin(), rowcols[J].end(), std::back_inserter(ks));
+      emit(I, J, ks);
+      flops += t3 + (double)ks.size() * 2.0 * t3; stored++;
+    }
+    emit(nt, J, rowcols[J]);   // rhs row: y_J (flops not counted, as in the right-looking plan)
+  }
+  df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 4;
+  df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
+  if (df.h_klist.empty()) df.h_klist.push_back(0);
+  df.tasks.upload(df.h_tasks.data(), df.h_tasks.size(), stream);
+  df.has_sub.upload(has_sub.data(), has_sub.size(), stream);
+  df.h_has_sub = has_sub;
+  df.klist.upload(df.h_klist.data(), df.h_klist.size(), stream);
+  df.tile_flag.alloc((size_t)(nt + 1) * nt); df.pd_flag.alloc(nt); df.ctrl.alloc(16);
+  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
+  check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
+  check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
+  check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 16, stream), "memset");
+  check_hip(hipStreamSynchronize(stream), "df plan upload");
+}
+
+void free_df_plan(DfPlan& df) {
+  df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
+  if (df.bulk) (void)hipStreamDestroy(df.bulk);
+  if (df.chain) (void)hipStreamDestroy(df.chain);
+  for (hipEvent_t e : {df.ev_start, df.ev_chain, df.ev_bulk}) if (e) (void)hipEventDestroy(e);
+  df.bulk = df.chain = nullptr; df.ev_start = df.ev_chain = df.ev_bulk = nullptr; df.grid = 0;
+}
+
+// fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
+void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail) {
+  const int nt = NP / T;
+  if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
+  static std::set<int> attr_set;
+  static std::mutex attr_mutex;
+  {
+    std::lock_guard<std::mutex> lock(attr_mutex);
+    if (!attr_set.count(c.device)) {
+      check_hip(hipFuncSetAttribute((const void*)k_df_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemBulk), "smem attr");
+      check_hip(hipFuncSetAttribute((const void*)k_df_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemChain), "smem attr");
+      attr_set.insert(c.device);
+    }
+  }
+  if (!df.bulk) {
+    // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
+    // of LDS, the whole register file of its SIMDs) can only be placed on exactly those -- so it is placed at once, whatever
+    // the order in which the two kernels reach the dispatcher.  (With an unmasked chain stream the dispatcher may pick a
+    // shader engine whose CUs the persistent bulk workgroups have filled, and the chain then waits for the end of the
+    // factorisation it is needed for: measured as a 2 s stall that ends in the wait bound.)
+    // Mask semantics measured on MI355X (tools/cu_mask_probe.hip): bit i = XCD i % 8, shader engine (i / 8) % 4, CU i / 32 of
+    // it; an XCD whose bits are ALL zero is not excluded but fully enabled.  A mask that really confines a kernel therefore
+    // needs a bit in every XCD: the chain's mask is the last CU of every XCD (8 CUs, 3 % of the chip), the bulk's the rest.
+    hipDeviceProp_t prop;
+    check_hip(hipGetDeviceProperties(&prop, c.device), "props");
+    const int ncu = std::max(prop.multiProcessorCount, 16);
+    const int reserve = 8;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u), inv((ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; i++) (i < ncu - reserve ? mask : inv)[i >> 5] |= 1u << (i & 31);
+    check_hip(hipExtStreamCreateWithCUMask(&df.bulk, (uint32_t)mask.size(), mask.data()), "masked stream");
+    check_hip(hipExtStreamCreateWithCUMask(&df.chain, (uint32_t)inv.size(), inv.data()), "masked stream");
+    check_hip(hipEventCreateWithFlags(&df.ev_start, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&df.ev_chain, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&df.ev_bulk, hipEventDisableTiming), "event");
+    const char* g = getenv("GTG_DF_GRID");
+    df.grid = g ? atoi(g) : 2 * (ncu - reserve);
+  }
+  hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, df.ctrl.p);
+  check_hip(hipEventRecord(df.ev_start, c.stream), "record");
+  check_hip(hipStreamWaitEvent(df.chain, df.ev_start, 0), "wait");
+  check_hip(hipStreamWaitEvent(df.bulk, df.ev_start, 0), "wait");
+  hipLaunchKernelGGL(k_df_chain, dim3(1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr);
+  const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
+  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(512), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+                     df.tile_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+  check_hip(hipEventRecord(df.ev_chain, df.chain), "record");
+  check_hip(hipEventRecord(df.ev_bulk, df.bulk), "record");
+  check_hip(hipStreamWaitEvent(c.stream, df.ev_chain, 0), "wait");
+  check_hip(hipStreamWaitEvent(c.stream, df.ev_bulk, 0), "wait");
+  check_hip(hipGetLastError(), "cholesky (dataflow)");
+}
+
+}  // namespace gt

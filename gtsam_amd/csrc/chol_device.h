@@ -1,0 +1,372 @@
+// chol_device.h -- device code shared by the two schedules of the reduced-system Cholesky (cholesky.hip: stream / event
+// schedule of per-column launches; chol_dataflow.hip: persistent dataflow kernels): MFMA helpers, the streamed 32-column
+// panel (chain wavefront + followers) and the diagonal-tile body built from it.
+#pragma once
+#include "kernels.h"
+
+namespace gt {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int T = kTile;        // 128
+constexpr int SB = 32;          // sub-block of the diagonal tile
+constexpr int P = T + 2;        // LDS pitch of a full tile: (2*P) % 64 == 4 -> MFMA operand reads conflict-free
+constexpr int PB = SB + 2;      // LDS pitch inside a 32x32 sub-block of the packed diagonal tile
+// The diagonal tile lives in LDS as its 10 lower 32x32 sub-blocks (87 KB instead of 133 KB) so that k_potrf128 can
+// share a CU with a k_syrk workgroup of the overlapped trailing update (look-ahead).
+__device__ __forceinline__ constexpr int boff(int ib, int cb) { return (ib * (ib + 1) / 2 + cb) * SB * PB; }
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+  return u.d;
+}
+
+// MFMA fragment helpers (cdna_hip_programming.md section 3, f64 16x16x4): lane l supplies
+// A[row = l&15][k = l>>4], B[k = l>>4][col = l&15]; accumulator reg r holds C[row = (l>>4) + 4r][col = l&15].
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// 128x128 tile (global, ld = NP) <-> LDS (pitch PL doubles); 16-byte accesses, 16 loads in flight per lane
+template <int PL>
+__device__ __forceinline__ void tile_to_lds(const double* __restrict__ tile, int NP, double* __restrict__ L, int tid) {
+#pragma unroll
+  for (int e0 = 0; e0 < T * (T / 2); e0 += 256 * 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 256 + tid;
+      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = e0 + u * 256 + tid;
+      double* d = L + (e / (T / 2)) * PL + 2 * (e % (T / 2));
+      d[0] = v[u].x; d[1] = v[u].y;
+    }
+  }
+}
+
+// 1/sqrt(p) to full double precision: v_rsq_f64 seed + two Newton steps (no IEEE sqrt/div sequence on
+// the 128-pivot critical path).  p <= 0 or NaN propagates inf/NaN and the caller raises the fail flag.
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double r = __builtin_amdgcn_rsq(p);
+  const double h = 0.5 * p;
+  r = r * __builtin_fma(-h, r * r, 1.5);
+  r = r * __builtin_fma(-h, r * r, 1.5);
+  return r;
+}
+
+// ---- cross-half helpers (gfx950 v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second)
+// value of the same lane (mod 32) of half H (0: lanes 0-31, 1: lanes 32-63), delivered to both halves
+template <int H>
+__device__ __forceinline__ double half_bcast(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[H], (int)a[H]);
+}
+// v(lane) + v(lane ^ 32), identical in both halves
+__device__ __forceinline__ double half_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// MFMA-operand image of a 32x32 block M as k_trsm128 consumes it (B operand of X * M^T, k split as 8 lk + s):
+// half tj, lane = 16 lk + lr keeps M[16 tj + lr][8 lk + 0..7] in 8 consecutive doubles, so a wavefront fetches its
+// operands of a block with four fully coalesced 16-byte loads per lane.
+__device__ __forceinline__ int opnd_off(int blk, int row, int col) {
+  return ((blk * 2 + (row >> 4)) * 64 + 16 * (col >> 3) + (row & 15)) * 8 + (col & 7);
+}
+constexpr int kOpndBase = 4 * SB * SB;   // doubles: the operand images follow the four plain inverses in the Xinv slot
+
+// 1/p to full double precision: v_rcp_f64 seed + two Newton steps (4 dependent FMAs: the shortest way from a pivot
+// to the multiplier of its rank-1 update)
+__device__ __forceinline__ double rcp_nr(double p) {
+  double x = __builtin_amdgcn_rcp(p);
+  double e = __builtin_fma(-p, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-p, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  return x;
+}
+
+// ---- the 32-column panel of the diagonal tile, streamed --------------------------------------------------------
+// Register layout (every wavefront of the panel): lane l keeps row i = l & 31 of its 32x32 block, the columns of
+// parity h = l >> 5 (a[cl] = A[i][2 cl + h]): a rank-1 step costs at most 16 FMAs per lane and all 64 lanes work.
+//
+// Wavefront 0 owns the diagonal block and walks the pivots (PotrfStep).  For pivot J it needs 1/piv (v_readlane +
+// rcp_nr: the serial chain, ~100 cycles) to finish column J+1, whose entries it PUBLISHES unscaled as line J+1
+// [stored in (parity, index) order pos(c) = 16 (c & 1) + c / 2 so that a half reads its 16 values as 16-byte
+// broadcasts], then it applies the rest of the rank-1 update, computes r = 1/sqrt(piv) off the chain, scales column
+// J, stores dinv[J] = r and bumps the progress counter.  All 32 lines stay in LDS.
+//
+// Every other 32-row block below (rows of L(ib,jb), i.e. the TRSM X L^T = A) and the rows of the identity (which
+// turn into L^-T, i.e. the inverse needed by k_trsm128 / k_bwd_diag) are FOLLOWERS (FollowStep): they replay the same
+// elimination on their own rows from the published (line J, r_J), a few pivots behind wavefront 0, and are done a
+// few hundred cycles after it.  They never feed back into the chain, so the chain wavefront never waits.
+// The step index is a template parameter: every register index is static.  The chain wavefront's code is branch
+// free (selects, trash address for the non-owner half) so that the scheduler can overlap the chain with the updates.
+constexpr int kLineTrash = SB * SB;   // doubles: lines[32][32], then 64 trash slots
+// explicit LDS pointers for the volatile accesses (address-space inference leaves volatile accesses as flat_*)
+typedef __attribute__((address_space(3))) volatile double* lds_vdouble_p;
+typedef __attribute__((address_space(3))) volatile int* lds_vint_p;
+
+template <int J>
+struct PotrfStep {
+  static __device__ __forceinline__ void run(double (&a)[16], const double (&cj)[16], double own, double* lines,
+                                             lds_vdouble_p rinvs, lds_vint_p prog, int progbase, int lane, int i, int h) {
+    constexpr int hJ = J & 1, cJ = J >> 1;
+    // ---- the serial chain: pivot -> 1/pivot -> column J+1 finished in its owner half -> next pivot.  The pivot and
+    // A[J+1][J] travel by v_readlane; the lane's own A[i][J] (`own`) was read back from line J one step ago, and that
+    // LDS round trip (~130 cycles) is shorter than the ~250 cycles of instruction issue of a step (measured with
+    // tools/potrf_chain_probe.hip: the bare readlane-rcp-fma chain is 90 cycles, a full step 250-300).
+    const double piv = readlane_f64(a[cJ], J + 32 * hJ);
+    const double rinv = rcp_nr(piv);
+    double cn[16], ownN = 0.0;
+    if constexpr (J + 1 < SB) {
+      constexpr int hN = (J + 1) & 1, cN = (J + 1) >> 1;
+      const double s1 = readlane_f64(a[cJ], J + 1 + 32 * hJ);   // A[J+1][J]
+      a[cN] = __builtin_fma(-((h == hN) ? own * s1 : 0.0), rinv, a[cN]);
+      // publish column J+1 (unscaled) and fetch it back for the rest of step J+1's update
+      double* line = lines + (J + 1) * SB;
+      const int pos = 16 * (i & 1) + (i >> 1);
+      *(lds_vdouble_p)((h == hN) ? line + pos : lines + kLineTrash + lane) = a[cN];
+#pragma unroll
+      for (int cl = cN; cl < 16; cl++) cn[cl] = line[16 * h + cl];
+      ownN = line[pos];               // A[i][J+1], written by the lane of row i in the owner half
+    }
+    // software-pipeline cut: nothing moves across, so a scheduling region = [rest of update J] + [chain of J+1]:
+    // the chain overlaps the updates and register pressure stays bounded
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- rest of the rank-1 update, fed by line J (read one step ago): off the chain
+    const double u = own * rinv;
+    if constexpr ((J & 1) == 1 && J + 1 < SB)   // J odd: the odd half's a[cJ+1] is column J+2
+      a[cJ + 1] = __builtin_fma(-((h == 1) ? u : 0.0), cj[cJ + 1], a[cJ + 1]);
+    constexpr int c0 = (J & 1) ? cJ + 2 : cJ + 1;
+#pragma unroll
+    for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, cj[cl], a[cl]);
+    // pin the row: keeps hipcc from deferring these updates across many steps (every step's broadcast values alive)
+#pragma unroll
+    for (int cl = cJ + 1; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    rinvs[J] = rinv;                // every lane stores the same value: no exec games on the chain wavefront
+    if constexpr ((J & 3) == 3) *prog = progbase + J + 1;   // LDS operations of one wavefront complete in order
+    PotrfStep<J + 1>::run(a, cn, ownN, lines, rinvs, prog, progbase, lane, i, h);
+  }
+};
+template <>
+struct PotrfStep<SB> {
+  static __device__ __forceinline__ void run(double (&)[16], const double (&)[16], double, double*, lds_vdouble_p, lds_vint_p,
+                                             int, int, int, int) {}
+};
+
+// The columns stay UNSCALED through the elimination (only 1/pivot is on the chain).  At the end of a panel the chain
+// wavefront computes the 32 values r_c = 1/sqrt(pivot_c) = sqrt(1/pivot_c) in parallel (lane c), publishes them in
+// (parity, index) order and raises rready; every wavefront then scales its columns.
+__device__ __forceinline__ void scale_columns(double (&a)[16], const double* rs, int h) {
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) a[cl] *= rs[16 * h + cl];
+}
+
+// factor the diagonal sub-block jb in place (upper part zeroed)
+__device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ rinvs, double* __restrict__ rs,
+                                            double* __restrict__ lines, int* prog, int jb, int lane, double* fail) {
+  const int i = lane & 31, h = lane >> 5;
+  double* row = A + boff(jb, jb) + i * PB;
+  double a[16], c0[16];
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
+  const int pos = 16 * (i & 1) + (i >> 1);
+  *(lds_vdouble_p)((h == 0) ? lines + pos : lines + kLineTrash + lane) = a[0];
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) c0[cl] = lines[16 * h + cl];
+  const double own0 = lines[pos];
+  PotrfStep<0>::run(a, c0, own0, lines, (lds_vdouble_p)(rinvs + SB * jb), (lds_vint_p)prog, SB * jb, lane, i, h);
+  const double rv = rinvs[SB * jb + i];
+  // Eigen LLT: non-positive pivot -> NumericalIssue (NaN compares false too); checked once per panel, off the chain
+  if (__builtin_amdgcn_ballot_w64(!(rv > 0.0 && rv < __builtin_inf())) != 0 && lane == 0) *fail = 1.0;
+  *(lds_vdouble_p)(rs + SB * jb + pos) = rv * rsqrt_nr(rv);
+  *(lds_vint_p)(prog + 1) = jb + 1;
+  scale_columns(a, rs + SB * jb, h);
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
+}
+
+template <int J>
+struct FollowStep {
+  static __device__ __forceinline__ void run(double (&a)[16], const double* lines, const double* rinvs,
+                                             lds_vint_p prog, int progbase, int h) {
+    if constexpr ((J & 3) == 0) {   // pivots J .. J+3 published?
+      while (*prog < progbase + J + 4) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    constexpr int hJ = J & 1, cJ = J >> 1;
+    const double own = half_bcast<hJ>(a[cJ]);
+    const double u = own * rinvs[J];
+    const double* line = lines + J * SB + 16 * h;
+    if constexpr (J + 1 < SB && ((J + 1) & 1) == 1)
+      a[cJ] = __builtin_fma(-((h == 1) ? u : 0.0), line[cJ], a[cJ]);   // column J+1 lives in the odd half's a[cJ]
+    constexpr int c0 = cJ + 1;
+#pragma unroll
+    for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, line[cl], a[cl]);
+    // pin the row: otherwise the updates are sunk below the next wait loops and every step's u / line stays alive
+#pragma unroll
+    for (int cl = cJ; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    FollowStep<J + 1>::run(a, lines, rinvs, prog, progbase, h);
+  }
+};
+template <>
+struct FollowStep<SB> {
+  static __device__ __forceinline__ void run(double (&)[16], const double*, const double*, lds_vint_p, int, int) {}
+};
+
+// follower of the diagonal sub-block jb: ib > jb -> the rows of A(ib,jb) become L(ib,jb) (in LDS);
+// ib < 0 -> the rows of the identity become L(jb,jb)^-T: lane i ends up with column i of the inverse, written
+// plain (Xout, row-major) and as the MFMA operand image (Xop)
+__device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* rinvs, const double* rs,
+                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop) {
+  const int i = lane & 31, h = lane >> 5;
+  const bool inv = ib < 0;
+  double* R = A + boff(inv ? jb : ib, jb) + i * PB;
+  double a[16];
+#pragma unroll
+  for (int cl = 0; cl < 16; cl++) a[cl] = inv ? ((2 * cl + h == i) ? 1.0 : 0.0) : R[2 * cl + h];
+  FollowStep<0>::run(a, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, h);
+  while (*(lds_vint_p)(prog + 1) < jb + 1) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  scale_columns(a, rs + SB * jb, h);
+  if (inv) {
+#pragma unroll
+    for (int cl = 0; cl < 16; cl++) {
+      Xout[(2 * cl + h) * SB + i] = a[cl];
+      Xop[opnd_off(6 + jb, 2 * cl + h, i)] = a[cl];
+    }
+  } else {
+#pragma unroll
+    for (int cl = 0; cl < 16; cl++) R[2 * cl + h] = a[cl];
+  }
+}
+
+// one 16x16 MFMA tile (ti, tj) of the update A(ib,cb) -= L(ib,jb) L(cb,jb)^T inside the diagonal tile
+__device__ __forceinline__ void tile_task(double* A, int jb, int ib, int cb, int ti, int tj, int lr, int lk) {
+  double* Cb = A + boff(ib, cb);
+  const double* Li = A + boff(ib, jb);
+  const double* Lc = A + boff(cb, jb);
+  v4f64 acc;
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
+#pragma unroll
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
+    acc = MFMA(av, bv, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
+}
+
+// write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
+// strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
+__device__ __forceinline__ void store_column(const double* A, double* tile, int NP, double* Xinv, int jb, int t, int nthreads) {
+  for (int e = t; e < (4 - jb) * 512; e += nthreads) {
+    const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
+    const double* sp = A + boff(ib, jb) + r * PB + c;
+    double2 v;
+    v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
+    v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * jb + c) = v;
+    if (ib != jb) *reinterpret_cast<double2*>(Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c)) = v;
+  }
+}
+
+// ---- diagonal tile ------------------------------------------------------------------------------------------
+// One workgroup of 8 wavefronts; per 32-column panel jb of the tile:
+//   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 5: follower
+//       producing the inverse | wave 4 idle (same SIMD as wave 0) | the remaining waves: everything of panel jb-1
+//       that nobody is waiting for (the off-chain MFMA updates and the write-back of its finished blocks)
+//   P3  the update of the NEXT panel (diagonal block + the blocks below it), all waves.
+#define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress word of the tile, after the operand images
+// the lower 32x32 sub-blocks of a diagonal tile -> the packed LDS image: 10 blocks x 512 16-byte pieces, 10 per lane, all
+// loads in flight before the writes (512 threads)
+__device__ __forceinline__ void diag_tile_to_lds(const double* __restrict__ tile, int NP, double* __restrict__ A, int tid) {
+  double2 v[10];
+#pragma unroll
+  for (int u = 0; u < 10; u++) {
+    const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
+    int ib = 0, rem = blk;
+    while (rem > ib) { rem -= ib + 1; ib++; }
+    v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15));
+  }
+#pragma unroll
+  for (int u = 0; u < 10; u++) {
+    const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
+    double* d = A + blk * SB * PB + (w >> 4) * PB + 2 * (w & 15);
+    d[0] = v[u].x; d[1] = v[u].y;
+  }
+}
+
+__device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
+                                           double* __restrict__ fail, long long* __restrict__ dbg,
+                                           const long long* __restrict__ epoch, bool preloaded = false) {
+  const long long flagbase = *epoch * 8;   // progress words are monotonic over factorisations: no reset, graph-replayable
+  double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
+  double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
+  double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
+  double* lines = rs + T;                             // [SB][SB] published columns of the current panel + 64 trash
+  int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
+  // its own followers
+  if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+  if (tid == 0) { prog[0] = 0; prog[1] = 0; }
+  STAMP(0);
+  if (!preloaded) diag_tile_to_lds(tile, NP, A, tid);   // (preloaded: the caller filled the image and synchronises below)
+  __syncthreads();
+  STAMP(1);
+#pragma unroll 1
+  for (int jb = 0; jb < 4; jb++) {
+    const int nfol = 3 - jb;   // row blocks below
+    if (wave == 0) {
+      stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail);
+    } else if (wave == 4) {
+      // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
+    } else if (wave <= nfol || wave == 5) {
+      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase);
+    } else if (jb > 0) {
+      const int pj = jb - 1;                            // deferred work of panel pj
+      const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
+      // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
+      // started): blocks (ib, cb), pj+2 <= cb <= ib
+      const int nb = 3 - pj, ntask = (nb * (nb - 1) / 2) * 4;
+      for (int t = hw; t < ntask; t += nh) {
+        const int blk = t >> 2;
+        int bi = 0, rem = blk;                           // (bi, rem): 0 <= rem <= bi < nb - 1
+        while (rem > bi) { rem -= bi + 1; bi++; }
+        tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
+      }
+      store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64);
+    }
+    __syncthreads();
+    // panel jb is complete in global memory (its inverse, and every L(jb, q<jb) operand image): release it to the
+    // TRSM workgroups of this launch, which are waiting for exactly that to run their phase jb
+    if (tid == 0)
+      __hip_atomic_store(reinterpret_cast<long long*>(Xinv + kFlagOff), flagbase + jb + 1, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    STAMP(2 + 3 * jb);
+    STAMP(3 + 3 * jb);
+    // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start
+    for (int t = wave; t < 4 * (3 - jb); t += 8) tile_task(A, jb, jb + 1 + (t >> 2), jb + 1, (t >> 1) & 1, t & 1, lr, lk);
+    __syncthreads();
+    STAMP(4 + 3 * jb);
+  }
+  store_column(A, tile, NP, Xinv, 3, tid, 512);
+  STAMP(14);
+}
+
+}  // namespace gt

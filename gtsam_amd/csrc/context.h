@@ -23,7 +23,9 @@ namespace gt {
 constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Cholesky
 
 // scalar slots reduced on the device (doubles)
-enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_COUNT = 8 };
+// SC_TIMEOUT directly follows SC_FAIL: the factorisation gets `scalars + SC_FAIL` and raises [0] for a non-positive pivot, [1] for a
+// dependency wait that ran into its bound (a scheduling problem, reported as an error -- never as "not positive definite")
+enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_TIMEOUT = 6, SC_COUNT = 8 };
 
 template <class T>
 struct DevBuf {
@@ -55,6 +57,26 @@ struct CholPlan {
   int critical_pairs = 0;                       // pairs on the longest leaf-to-root path (= all pairs without parts)
   double flops = 0.0;                           // algorithmic flops of one factorisation over the stored tiles
   double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles
+};
+
+// Dataflow schedule of the same factorisation (chol_dataflow.hip): one task per stored 128x128 tile, left-looking, executed by
+// persistent workgroups that take tasks in a fixed topological order; dependencies are epoch-stamped flags in HBM.
+struct DfPlan {
+  int nt = 0;
+  int64_t n_tasks = 0;                          // bulk tasks: per block column J the diagonal accumulation PD(J), then the tiles (I, J) below, the rhs tile last
+  DevBuf<int32_t> tasks;                        // 4 per task: I, J, offset / count into klist
+  DevBuf<int32_t> has_sub;                      // per diagonal tile J: tile (J, J-1) is stored (its update is streamed by the chain kernel)
+  std::vector<int32_t> h_has_sub;
+  DevBuf<int32_t> klist;                        // contraction lists: the column tiles k < J with both (I, k) and (J, k) stored
+  DevBuf<long long> tile_flag;                  // (nt + 1) x nt: epoch in which the tile became final
+  DevBuf<long long> pd_flag;                    // nt: epoch in which the diagonal tile received all its updates
+  DevBuf<int32_t> ctrl;                         // [0] ticket counter of the bulk queue; [8..15] record of the first wait that gave up
+  DevBuf<long long> trace;                      // GTG_DF_TRACE=1: 4 stamps per task + 2 per diagonal tile (gtg_debug_df_trace)
+  std::vector<int32_t> h_tasks, h_klist;        // host copies (debug getters, CPU tests)
+  double flops = 0.0, dense_fraction = 1.0;
+  hipStream_t bulk = nullptr, chain = nullptr;  // CU-masked streams with complementary masks: bulk kernel / chain kernel
+  hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr;
+  int grid = 0;
 };
 
 struct FactorTables {
@@ -163,6 +185,8 @@ struct gtg_context {
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
   gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words), bumped on the device
   gt::CholPlan plan;
+  gt::DfPlan df;                                // the dataflow schedule (default); `plan` keeps the lists for zeroing / exchange / backward solve
+  bool use_df = true;
   gt::DevBuf<double> xbuf;                      // multi-GPU: the exchanged part of S packed contiguously for the all-reduce
   // multi-GPU exchange at block granularity: every structurally non-zero d x d block of the reduced system (diagonal blocks +
   // the off-diagonal blocks of the WHOLE graph, identical on every shard), 81 doubles per block, then the rhs row and the

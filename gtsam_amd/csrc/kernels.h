@@ -35,6 +35,13 @@ void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unp
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x);
 void destroy_chol_streams(gtg_context& c);
 
+// chol_dataflow.hip -----------------------------------------------------------------------------------
+// The same factorisation as one dataflow pass of two persistent kernels (default schedule).  tile_struct = lower-triangular
+// boolean structure over 128x128 tiles before the factorisation ((nt x nt) row-major bytes; nullptr = dense).
+void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s);
+void free_df_plan(DfPlan& df);
+void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail_flags);
+
 // pcg.hip -----------------------------------------------------------------------------------------
 // Block-Jacobi PCG on the implicit Schur complement (needs launch_point_eliminate first): c.xred = S^-1 b.
 int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax, int max_iterations, int min_iterations,

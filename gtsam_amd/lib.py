@@ -27,7 +27,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -83,6 +83,9 @@ def load():
     lib.gtg_dense_cholesky_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.gtg_debug_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
     lib.gtg_debug_plan_lists.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+    lib.gtg_debug_df_plan.argtypes = [C.c_void_p] * 4
+    lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
+    lib.gtg_debug_df_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.gtg_io_last_error.restype = C.c_char_p
     lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
@@ -226,6 +229,27 @@ class DeviceGraph:
                                                                                   "per_pair", "pair_part", "part_parent"))), "gtg_debug_plan_lists")
         d["stored"] = d["stored"].reshape(-1, 2); d["exch"] = d["exch"].reshape(-1, 2)
         return d
+
+    def df_plan(self):
+        """Test hook: the dataflow schedule -- dict(nt, active, tasks[n][4] = I, J, koff, kcnt, klist), see gtg_debug_df_plan."""
+        sz = np.zeros(4, np.int64)
+        _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, None, None), "gtg_debug_df_plan")
+        tasks = np.zeros((int(sz[1]), 4), np.int32); klist = np.zeros(int(sz[2]), np.int32)
+        _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, tasks.ctypes.data, klist.ctypes.data), "gtg_debug_df_plan")
+        return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist)
+
+    def df_trace(self):
+        """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][2] stamps) of the last factorisation, 100 MHz ticks."""
+        pl = self.df_plan()
+        n = 8 * pl["tasks"].shape[0] + 2 * pl["nt"]
+        out = np.zeros(n, np.int64)
+        _check(self.lib.gtg_debug_df_trace(self.h, out.ctypes.data, n), "gtg_debug_df_trace")
+        return out[:8 * pl["tasks"].shape[0]].reshape(-1, 8), out[8 * pl["tasks"].shape[0]:].reshape(-1, 2)
+
+    def df_ctrl(self):
+        out = np.zeros(16, np.int32)
+        _check(self.lib.gtg_debug_df_ctrl(self.h, out.ctypes.data), "gtg_debug_df_ctrl")
+        return out
 
     def dense_cholesky(self, A, rhs=None):
         """Unit-test hook: (status, L (lower), x) of the device Cholesky + solve on a host matrix."""

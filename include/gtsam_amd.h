@@ -225,6 +225,16 @@ int gtg_dense_cholesky_host(gtg_handle h, double* A, int32_t n, double* rhs_inou
 int gtg_debug_plan_sizes(gtg_handle h, int64_t sizes[8]);
 int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* bcols, int32_t* stored, int32_t* exch,
                          int64_t* per_tile, int64_t* per_pair, int32_t* pair_part, int32_t* part_parent);
+/* The dataflow schedule of the same factorisation (csrc/chol_dataflow.hip, the default): sizes = {nt, n_tasks, |klist|, active};
+ * tasks[n_tasks][4] = I, J, offset and count into klist (I == J: accumulation of the diagonal tile, I == nt: rhs row), in the
+ * order in which the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
+int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* klist);
+/* out[0] = tickets taken in the last factorisation; out[8..15] = record of the first dependency wait that gave up (kind 1/2: tile
+ * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted) */
+int gtg_debug_df_ctrl(gtg_handle h, int32_t out[16]);
+/* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
+ * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */
+int gtg_debug_df_trace(gtg_handle h, int64_t* out, int64_t n);
 
 /* ---- wire format on the bundle-adjustment side of the path: BAL text files straight to / from the
  * SoA arrays of gtg_problem.  Host-only (no GPU needed).  Replaces SfmData::FromBalFile (gtsam/sfm/SfmData.cpp:189-246: every

@@ -35,6 +35,8 @@ g = L.DeviceGraph(problem)
 pl = g.cholesky_plan()
 out = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in pl.items()}
 out["dense_fraction_flops"] = g.cholesky_flops()
+df = g.df_plan()
+out["df"] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in df.items()}
 print("RESULT " + json.dumps(out))
 '''
 
@@ -126,6 +128,72 @@ def _execute(pl, t=8, seed=0):
     return worst, worst_y, float(np.abs(x - xd).max() / max(np.abs(xd).max(), 1e-300)), len(stored)
 
 
+def _execute_df(pl, df, t=8, seed=0):
+    """The dataflow schedule (csrc/chol_dataflow.hip) in numpy: the tasks in ticket order, exactly what a workgroup does with
+    one -- PD(J): A_JJ -= sum_k L_Jk L_Jk^T over its k list (then the chain kernel applies L_J,J-1 and factors the tile); (I, J): R = A_IJ -
+    sum_k L_Ik L_Jk^T, L_IJ = R L_JJ^-T; I == nt is the rhs row.  Every operand must be FINAL when it is read in this order
+    (that is the no-deadlock argument: a task only waits for tasks before it), every k list must be complete (dense result)."""
+    rng = np.random.default_rng(seed)
+    nt = int(pl["nt"]); n = nt * t
+    assert int(df["nt"]) == nt
+    A = np.zeros((n, n)); g = np.zeros(n)
+    for I, J in pl["exch"]:
+        if I == nt:
+            g[J * t:(J + 1) * t] = rng.normal(size=t)
+        elif I != J:
+            A[I * t:(I + 1) * t, J * t:(J + 1) * t] = rng.normal(size=(t, t)) * 0.3
+    A = A + A.T
+    A += np.diag(np.abs(A).sum(1) + 1.0 + rng.uniform(0, 1, n))
+    Ld = np.linalg.cholesky(A); yd = np.linalg.solve(Ld, g)
+    tasks = np.array(df["tasks"], np.int64).reshape(-1, 4); klist = np.array(df["klist"], np.int64)
+    owned = {(int(I), int(J)) for I, J, _, _ in tasks}
+    assert len(owned) == len(tasks), "a tile has two tasks"
+    stored_old = {(int(I), int(J)) for I, J in pl["stored"]}
+    assert owned <= stored_old, "the dataflow schedule touches a tile the zeroing / backward lists do not know"
+    for I in range(nt):
+        for J in range(I + 1):
+            if (I, J) not in owned:
+                assert not A[I * t:(I + 1) * t, J * t:(J + 1) * t].any(), "a non-zero tile of the graph has no task"
+    tile = {(I, J): (np.vstack([g[J * t:(J + 1) * t][None, :], np.zeros((t - 1, t))]) if I == nt else A[I * t:(I + 1) * t, J * t:(J + 1) * t].copy())
+            for (I, J) in owned}
+    final, diag_done = set(), set()
+
+    def L(I, k):
+        assert (I, k) in final, f"tile ({I},{k}) is read before the task that produces it in ticket order"
+        return tile[(I, k)]
+    last_col = -1
+    for I, J, off, cnt in tasks:
+        I, J, off, cnt = int(I), int(J), int(off), int(cnt)
+        assert J >= last_col, "tasks are not ordered by block column"
+        last_col = J
+        ks = [int(k) for k in klist[off:off + cnt]]
+        assert ks == sorted(ks) and all(k < J for k in ks)
+        acc = tile[(I, J)].copy()
+        for k in ks:
+            acc -= L(I, k) @ L(J, k).T
+        if I == J:
+            # k_df_chain: the update of block column J-1 is its own (streamed behind the substitution of tile (J, J-1), which
+            # must therefore precede PD(J) in ticket order -- it is the first task of column J-1's group), then the factorisation
+            if (J, J - 1) in owned:
+                assert J - 1 not in ks, "PD(J) and the chain kernel would both apply block column J-1"
+                acc -= L(J, J - 1) @ L(J, J - 1).T
+            tile[(J, J)] = np.linalg.cholesky(np.tril(acc) + np.tril(acc, -1).T); diag_done.add(J)
+        else:
+            assert J in diag_done, "a tile's substitution precedes the accumulation of its diagonal tile in ticket order"
+            tile[(I, J)] = np.linalg.solve(tile[(J, J)], acc.T).T
+            final.add((I, J))
+    worst = 0.0
+    for I in range(nt):
+        for J in range(I + 1):
+            blk = Ld[I * t:(I + 1) * t, J * t:(J + 1) * t]
+            if (I, J) in owned:
+                worst = max(worst, float(np.abs(tile[(I, J)] - blk).max()))
+            else:
+                assert np.abs(blk).max() <= 1e-13, f"fill-in at tile ({I},{J}) has no task"
+    y = np.concatenate([tile[(nt, J)][0] for J in range(nt)])
+    return worst, float(np.abs(y - yd).max()), len(owned)
+
+
 @pytest.fixture(scope="module")
 def stub():
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
@@ -147,6 +215,13 @@ def test_schedule_reproduces_a_dense_cholesky(stub, workload, nd):
         assert len(pl["part_parent"]) == 0 and not pl["per_pair"][:, 7].any()
     worst, worst_y, worst_x, n_stored = _execute(pl)
     assert worst <= 1e-10 and worst_y <= 1e-10 and worst_x <= 1e-10, (worst, worst_y, worst_x)
+    if not nd:   # the dataflow schedule (default without nested dissection): same result, never more tiles
+        assert pl["df"]["active"]
+        w, wy, n_df = _execute_df(pl, pl["df"])
+        assert w <= 1e-10 and wy <= 1e-10, (w, wy)
+        assert n_df <= n_stored
+    else:
+        assert not pl["df"]["active"]
     nt = int(pl["nt"])
     assert n_stored <= (nt + 1) * (nt + 2) // 2
     # the exchange list (structure before the factorisation) is a subset of the stored tiles
@@ -166,3 +241,5 @@ def test_forced_dense_schedule(stub):
     assert len(pl["stored"]) == nt * (nt + 1) // 2 + nt          # every lower tile + the rhs row
     worst, worst_y, worst_x, _ = _execute(pl)
     assert max(worst, worst_y, worst_x) <= 1e-10
+    w, wy, n_df = _execute_df(pl, pl["df"])
+    assert max(w, wy) <= 1e-10 and n_df == nt * (nt + 1) // 2 + nt

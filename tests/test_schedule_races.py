@@ -47,7 +47,10 @@ def stub():
 @pytest.mark.parametrize("workload,nd", [("bal:300:20000:3", 0), ("sphere2500", 0), ("ladybug1723", 0), ("sphere2500", 2), ("sphere2500", 3),
                                          ("bal:300:20000:3", 2), ("w20000", 3)])
 def test_no_unordered_tile_conflicts(stub, workload, nd):
-    env = {"GTG_ND_DEPTH": str(nd)} if nd else {}
+    # the launch-sequence schedules: the elimination-tree one (GTG_ND_DEPTH) and the look-ahead one (GTG_CHOL=streams).  The
+    # default dataflow schedule has two launches and orders its tile accesses through flags inside the kernels: its ordering
+    # argument (a task only reads tiles that are final in ticket order) is what tests/test_chol_plan.py::_execute_df checks.
+    env = {"GTG_ND_DEPTH": str(nd)} if nd else {"GTG_CHOL": "streams"}
     r = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra=env, timeout=900)
     assert r["rc"] == 0 and r["factorisation_launches"] >= r["nt"]          # at least one panel launch per block column
     assert r["streams"] >= 2 and r["ordered_conflicts_checked"] > r["factorisation_launches"]

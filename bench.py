@@ -184,10 +184,13 @@ def main():
             "time_to_converged_s": ttc, "time_to_converged_setup_s": t_setup, "converged_error": full.error(), "converged_iterations": full.iterations(),
             "converged_inner_iterations": full.getInnerIterations(), "initial_error": full.trace[0][1],
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
-            "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced camera system after RCM reordering (k_panel128 + k_syrk, one factorisation = one launch sequence; flops = stored-tile flops)",
+            "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced camera system after RCM reordering: dataflow schedule, k_df_bulk + k_df_chain, one factorisation = one launch of each (flops_per_launch = flops over the stored 128x128 tiles after symbolic fill at tile granularity; flops_block_level = the same elimination counted at the granularity of the 9x9 variable blocks)",
                          "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                         "flops_per_launch": chol_flops, "ms_per_launch": chol_ms / max(chol_calls, 1)},
+                         "flops_per_launch": chol_flops, "ms_per_launch": chol_ms / max(chol_calls, 1),
+                         "flops_block_level": opt.dev.cholesky_flops_block_level(),
+                         "achieved_block_level": opt.dev.cholesky_flops_block_level() * chol_calls / max(chol_ms * 1e-3, 1e-12) / 1e12,
+                         "flops_dense_n3_over_3": float(n_red) ** 3 / 3.0},
             "roofline_dense_kernel": None if dense is None else {
                 "bound": "mfma", "kernel": "same Cholesky with the tile schedule forced dense (n^3/3 flops): k_syrk-dominated regime",
                 "achieved": dense["flops_per_launch"] / (dense["ms_per_launch"] * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
@@ -207,8 +210,30 @@ def main():
                 from oracle import ref
                 if ref.available():
                     g = ref.RefGraph(problem)
-                    rc, ms = g.iteration_phases(values0, params.lambdaInitial, params.diagonalDamping,
-                                                1 if problem.n_sfm else 0)
+                    rc, ms, ref_res = g.iteration_phases(values0, params.lambdaInitial, params.diagonalDamping,
+                                                         1 if problem.n_sfm else 0, with_results=True)
+                    # parity of THIS run at THIS size: the device's first lambda try of the same problem against the numbers of
+                    # the reference iteration just timed (what LM's accept / reject decision is made from)
+                    pd = fresh()
+                    e0 = pd.error()
+                    pd.dev.linearize()
+                    prc, pout = pd.dev.try_lambda(params.lambdaInitial, params.diagonalDamping, params.minDiagonal, params.maxDiagonal)
+                    dn = float(np.linalg.norm(pd.dev.delta())); di = float(np.abs(pd.dev.delta()).max())
+                    pd.dev.close()
+                    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-300)   # noqa: E731
+                    rho_ref = (ref_res[0] - ref_res[3]) / (ref_res[1] - ref_res[2]) if rc == 0 and ref_res[1] != ref_res[2] else float("nan")
+                    rho_dev = (e0 - pout[2]) / (pout[0] - pout[1]) if prc == 0 and pout[0] != pout[1] else float("nan")
+                    out["parity_vs_reference"] = {
+                        "what": "first lambda try (lambda = %g, %s damping) of the same problem: this device run against the reference iteration of the cpu_baseline leg"
+                                % (params.lambdaInitial, "diagonal" if params.diagonalDamping else "identity"),
+                        "status_reference": int(rc), "status_device": int(prc),
+                        "error_rel": rel(e0, ref_res[0]), "linear_error_at_delta_rel": rel(pout[1], ref_res[2]),
+                        "trial_error_rel": rel(pout[2], ref_res[3]), "delta_norm2_rel": rel(dn, ref_res[4]), "delta_norminf_rel": rel(di, ref_res[5]),
+                        "model_fidelity_reference": rho_ref, "model_fidelity_device": rho_dev,
+                        "same_decision": bool((rho_ref > params.minModelFidelity) == (rho_dev > params.minModelFidelity)),
+                        "tolerances": {"error": 1e-9, "delta": 1e-7, "trial_error": 1e-6},
+                        "within_tolerance": bool(rc == prc == 0 and rel(e0, ref_res[0]) <= 1e-9 and rel(dn, ref_res[4]) <= 1e-7
+                                                 and rel(di, ref_res[5]) <= 1e-7 and rel(pout[2], ref_res[3]) <= 1e-6)}
                     cpu = {"value": 1e3 / ms[7], "unit": "iterations/s", "cores": 1, "kind": "reference",
                            "sample": "1 LM iteration (linearize, hessianDiagonal, damp, eliminateMultifrontal+solve with the Schur ordering, "
                                      "2x linear error, retract, nonlinear error) of the SAME problem with gtsam built from /root/reference "

@@ -490,6 +490,42 @@ void analyze(gtg_context& c) {
   }
   up(c.pad_index, c.h_pad_index, s);
 
+  // ---- block-level symbolic factorisation: the flops the elimination needs at the granularity of the variables (d x d
+  // blocks, fill included) -- sum over block columns of f^3/3 + f^2 s + f s^2 (f = the variable's dimension, s = the dimension
+  // of its below-diagonal structure), the count SURVEY section 8(d) asks for next to the stored-tile count the kernels execute.
+  {
+    const int n = c.n_red_vars;
+    std::vector<std::vector<int32_t>> below(n);          // positions > own position
+    for_each_block([&](int ra, int rb) {
+      if (ra == rb) return;
+      const int pa = c.h_red_pos[ra], pb = c.h_red_pos[rb];
+      below[std::min(pa, pb)].push_back(std::max(pa, pb));
+    });
+    std::vector<int32_t> dim_at(n);
+    for (int r = 0; r < n; r++) dim_at[c.h_red_pos[r]] = c.h_red_dim[r];
+    std::vector<std::vector<int32_t>> children(n);
+    std::vector<int32_t> merged;
+    double fl = 0.0;
+    for (int j = 0; j < n; j++) {
+      std::vector<int32_t>& sj = below[j];
+      std::sort(sj.begin(), sj.end()); sj.erase(std::unique(sj.begin(), sj.end()), sj.end());
+      for (int32_t ch : children[j]) {                   // struct(j) |= struct(child) \ {j}
+        merged.clear();
+        std::set_union(sj.begin(), sj.end(), below[ch].begin(), below[ch].end(), std::back_inserter(merged));
+        merged.erase(std::remove(merged.begin(), merged.end(), (int32_t)j), merged.end());
+        sj.swap(merged);
+        std::vector<int32_t>().swap(below[ch]);
+      }
+      double sdim = 0.0;
+      for (int32_t q : sj) sdim += dim_at[q];
+      const double f = dim_at[j];
+      fl += f * f * f / 3.0 + f * f * sdim + f * sdim * sdim;
+      if (!sj.empty()) children[sj.front()].push_back(j);
+    }
+    c.chol_flops_block = fl;
+    clk.lap("block-level symbolic factorisation");
+  }
+
   // ---- tile structure of the reduced system -> Cholesky schedule ------------------------------------------------
   {
     const int nt = c.NP / kTile, np2 = (nt + 1) / 2;

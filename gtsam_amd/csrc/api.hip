@@ -540,6 +540,7 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
   return GTG_OK;
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
+double gtg_cholesky_flops_block_level(gtg_handle c) { return c ? c->chol_flops_block : 0.0; }
 int64_t gtg_structure_hash(gtg_handle c) { return c ? (int64_t)(c->structure_hash & 0x7FFFFFFFFFFFFFFFull) : -1; }
 double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
 

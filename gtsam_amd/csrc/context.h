@@ -210,5 +210,5 @@ struct gtg_context {
   double phase_ms[GTG_PH_COUNT] = {0};
   int64_t phase_calls[GTG_PH_COUNT] = {0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double chol_flops = 0, lin_bytes = 0;
+  double chol_flops = 0, chol_flops_block = 0, lin_bytes = 0;
 };

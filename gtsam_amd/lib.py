@@ -26,7 +26,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
-           "gtg_cholesky_flops", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
+           "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
            "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
@@ -60,6 +60,8 @@ def load():
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.gtg_cholesky_flops.restype = C.c_double
     lib.gtg_cholesky_flops.argtypes = [C.c_void_p]
+    lib.gtg_cholesky_flops_block_level.restype = C.c_double
+    lib.gtg_cholesky_flops_block_level.argtypes = [C.c_void_p]
     lib.gtg_linearize_bytes.restype = C.c_double
     lib.gtg_linearize_bytes.argtypes = [C.c_void_p]
     lib.gtg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -213,6 +215,7 @@ class DeviceGraph:
         return {p: (float(ms[i]), int(calls[i])) for i, p in enumerate(PHASES)}
 
     def cholesky_flops(self): return self.lib.gtg_cholesky_flops(self.h)
+    def cholesky_flops_block_level(self): return self.lib.gtg_cholesky_flops_block_level(self.h)
     def structure_hash(self): return int(self.lib.gtg_structure_hash(self.h))
     def linearize_bytes(self): return self.lib.gtg_linearize_bytes(self.h)
 

@@ -207,6 +207,10 @@ const char* gtg_phase_name(int phase);
 /* flops of the dense Cholesky factorisation of the last try (n^3/3 + lower order) and the
  * algorithmic HBM bytes of one linearize pass (DESIGN.md section "rooflines") */
 double gtg_cholesky_flops(gtg_handle h);
+/* the same factorisation counted at the granularity of the variables: sum over the d x d block columns (symbolic fill included)
+ * of f^3/3 + f^2 s + f s^2 -- the flops a perfectly sparse elimination would need; gtg_cholesky_flops() counts what the 128x128
+ * tile kernels execute (zeros inside stored tiles included) */
+double gtg_cholesky_flops_block_level(gtg_handle h);
 /* identity (63-bit hash) of the layout of the reduced system: elimination order of the reduced variables, their offsets,
  * padding, tile structure and the list of exchanged tiles.  It is derived from the WHOLE graph, so every shard of one job
  * reports the same value; gtg_upload_problem verifies that through the all-reduce callback and fails if they differ. */

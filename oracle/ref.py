@@ -152,12 +152,14 @@ class RefGraph:
                                 C.byref(nt), C.byref(secs))
         return dict(values=out, trace=trace[:nt.value].copy(), iterations=int(it), seconds=secs.value)
 
-    def iteration_phases(self, values, lam, diagonal_damping, ordering_kind):
+    def iteration_phases(self, values, lam, diagonal_damping, ordering_kind, with_results=False):
+        """One LM iteration made of the reference's own calls, timed per phase (ms[8]); with_results: also (error, linear error
+        at 0 and at delta, trial error, |delta|_2, |delta|_inf) of that lambda try."""
         v = np.ascontiguousarray(values, np.float64)
-        ms = np.zeros(8)
-        rc = lib().ref_graph_iteration_phases(self.h, _p(v), C.c_double(lam), C.c_int(int(diagonal_damping)),
-                                              C.c_int(ordering_kind), _p(ms))
-        return rc, ms
+        ms = np.zeros(8); res = np.zeros(6)
+        rc = lib().ref_graph_iteration_phases2(self.h, _p(v), C.c_double(lam), C.c_int(int(diagonal_damping)),
+                                               C.c_int(ordering_kind), _p(ms), _p(res))
+        return (rc, ms, res) if with_results else (rc, ms)
 
 
 def load_bal(path):

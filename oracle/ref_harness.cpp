@@ -454,8 +454,11 @@ int ref_graph_lm(void* h, const double* values0, const ref_lm_params* rp, double
 // Phase timings of ONE LM iteration made of the reference's own calls in the order iterate()/
 // tryLambda() make them (LevenbergMarquardtOptimizer.cpp:121-308). ms[8]: linearize,
 // hessianDiagonal, damp, eliminate+solve, linear error x2, retract, nonlinear error, total.
-int ref_graph_iteration_phases(void* h, const double* values, double lambda, int diagonal_damping,
-                               int ordering_kind, double* ms) {
+// res (optional, 6 doubles): graph.error(values), linear error at 0 and at delta, graph.error(retract(values, delta)),
+// |delta|_2, |delta|_inf -- what LM's accept / reject decision is made from (LevenbergMarquardtOptimizer.cpp:180-235); the
+// bench line compares the device's numbers of the same lambda try with them (parity_vs_reference).
+int ref_graph_iteration_phases2(void* h, const double* values, double lambda, int diagonal_damping,
+                                int ordering_kind, double* ms, double* res) {
   RefGraph* g = static_cast<RefGraph*>(h);
   using clk = std::chrono::high_resolution_clock;
   auto msec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -477,16 +480,25 @@ int ref_graph_iteration_phases(void* h, const double* values, double lambda, int
   int status = 0;
   try { d = damped.optimize(ord, EliminatePreferCholesky); } catch (const IndeterminantLinearSystemException&) { status = 1; }
   auto t4 = clk::now();
-  double e = 0;
-  if (!status) { e += lin->error(VectorValues::Zero(d)); e += lin->error(d); }
+  double e = 0, l0 = 0, l1 = 0, e1 = 0;
+  if (!status) { l0 = lin->error(VectorValues::Zero(d)); l1 = lin->error(d); e = l0 + l1; }
   auto t5 = clk::now();
   Values nv; if (!status) nv = vals.retract(d);
   auto t6 = clk::now();
-  if (!status) e += g->graph.error(nv);
+  if (!status) { e1 = g->graph.error(nv); e += e1; }
   auto t7 = clk::now();
   ms[0] = msec(t0, t1); ms[1] = msec(t1, t2); ms[2] = msec(t2, t3); ms[3] = msec(t3, t4);
   ms[4] = msec(t4, t5); ms[5] = msec(t5, t6); ms[6] = msec(t6, t7); ms[7] = msec(t0, t7);
+  if (res) {
+    res[0] = g->graph.error(vals); res[1] = l0; res[2] = l1; res[3] = e1;
+    res[4] = status ? 0.0 : d.norm(); res[5] = 0.0;
+    if (!status) for (const auto& [key, value] : d) res[5] = std::max(res[5], value.cwiseAbs().maxCoeff());
+  }
   return status + (e != e ? 2 : 0);
+}
+int ref_graph_iteration_phases(void* h, const double* values, double lambda, int diagonal_damping,
+                               int ordering_kind, double* ms) {
+  return ref_graph_iteration_phases2(h, values, lambda, diagonal_damping, ordering_kind, ms, nullptr);
 }
 
 // ---- dataset loaders (reference's own parsers) -------------------------------------------------

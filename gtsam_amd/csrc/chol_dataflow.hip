@@ -41,7 +41,7 @@ constexpr int CH = T * KC * 8;    // bytes of one 128-row panel chunk
 constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of the substitution
 constexpr int kSpinLimit = 1 << 22;
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
-constexpr size_t kSmemBulk = std::max<size_t>(std::max<size_t>(4 * (size_t)CH, sizeof(double) * 64 * (T + 2)), sizeof(double) * (T * PX + 4 * kImgDoubles));
+constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
 constexpr size_t kSmemPotrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
 constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 * SB * PB;   // + one 128 x 32 slice of the tile below
 // flag values: epoch * 8 + steps; a tile (I, J) is final at 4 steps (its four 32-column blocks), a diagonal tile's word in
@@ -134,8 +134,11 @@ __device__ __forceinline__ int wait_progress(const long long* f1, const long lon
 }
 
 // ---- one bulk task ------------------------------------------------------------------------------------------------
-// 8 wavefronts in 4 x 2, each 32 x 64 = 2 x 4 MFMA tiles (the geometry of k_syrk: two workgroups per CU give the four
-// waves per SIMD the FP64 matrix pipe needs).  Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by
+// 8 wavefronts, each 16 ROWS x all 128 columns = 1 x 8 MFMA tiles (two workgroups per CU give the four waves per SIMD the FP64
+// matrix pipe needs).  That is the layout of the substitution that follows the contraction (a row of L(I,J) depends on the same
+// row of R only: the wavefronts are independent there), so the accumulators go straight into it; the 4 x 2 geometry of k_syrk
+// needs 6 operand reads per 8 MFMAs instead of 9, but cost a layout change through LDS and, worse, had the compiler keep both
+// copies of the tile alive and park them in scratch.  Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by
 // LDS-DMA, double buffered, 16-byte slots XOR-swizzled on the source address and on the operand reads.
 __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int NP, int nt, int I, int J,
                                          const int32_t* __restrict__ kl, int kcnt, long long* __restrict__ tile_flag,
@@ -147,9 +150,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  constexpr int TI = 2, TJ = 4, NQ = 2;
+  constexpr int NQ = 2;
   __builtin_amdgcn_s_setprio(0);
   double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
   const double* Arow = S + ((int64_t)I * T) * NP;
@@ -173,16 +175,14 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     }
   };
 
-  // element (ti, tj, r) of this lane: uniform part (scalar registers) + one 32-bit lane offset
-  const int lane_off = lk * NP + lr;
-  auto crow = [&](int ti, int tj, int r) -> double* { return C + ((int64_t)(wr * 32 + ti * 16 + 4 * r) * NP + wc * 64 + tj * 16); };
-  v4f64 acc[TI][TJ];
+  // element (ct, r) of this lane: rows 16 wave + lk + 4 r, columns 16 ct + lr -- uniform part (scalar registers) + one 32-bit lane offset
+  const unsigned lane_off = (unsigned)(lk * NP + lr);   // (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane addresses to keep)
+  double* Crow = C + (int64_t)(16 * wave) * NP;
+  v4f64 x[8];
 #pragma unroll
-  for (int ti = 0; ti < TI; ti++)
+  for (int ct = 0; ct < 8; ct++)
 #pragma unroll
-    for (int tj = 0; tj < TJ; tj++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[ti][tj][r] = crow(ti, tj, r)[lane_off];
+    for (int r = 0; r < 4; r++) x[ct][r] = (Crow + (int64_t)(4 * r) * NP + 16 * ct)[lane_off];
 
   if (kcnt > 0) {
     // A contraction step consumes its two operand tiles 16 columns at a time, and a tile is published in 32-column blocks
@@ -195,7 +195,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     const double* Bk = Brow + (int64_t)k * T;
     stage(Ak, Bk, 0, 0);
     __syncthreads();
-    const int a_row_off = (wr * 32 + lr) * ROWB, b_row_off = (wc * 64 + lr) * ROWB;
+    const int a_row_off = (16 * wave + lr) * ROWB, b_row_off = lr * ROWB;
     const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
     for (int ki = 0; ki < kcnt; ki++) {
       // The end of a task is a link of a serial chain (the next tile of this tile row, and the diagonal through it, wait for
@@ -224,15 +224,12 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
           const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-          double a[TI], b[TJ];
+          const double a = -*reinterpret_cast<const double*>(Ac + a_row_off + so);
+          double b[8];
 #pragma unroll
-          for (int t = 0; t < TI; t++) a[t] = -*reinterpret_cast<const double*>(Ac + a_row_off + t * 16 * ROWB + so);
+          for (int t = 0; t < 8; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
 #pragma unroll
-          for (int t = 0; t < TJ; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
-#pragma unroll
-          for (int ti = 0; ti < TI; ti++)
-#pragma unroll
-            for (int tj = 0; tj < TJ; tj++) acc[ti][tj] = MFMA(a[ti], b[tj], acc[ti][tj]);
+          for (int t = 0; t < 8; t++) x[t] = MFMA(a, b[t], x[t]);
         }
         __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
       }
@@ -254,33 +251,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const double* Xinv = Xinv_all + (size_t)J * T * T;
   const long long* pflag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
   long long* myflag = tile_flag + (int64_t)I * nt + J;
-  v4f64 x[8];   // column tiles 0..7 (16 columns each) of rows 32 wr + 16 wc + lk + 4 r
-  {
-    constexpr int PE = T + 2;
-    double* E = reinterpret_cast<double*>(smem_raw);   // [64][PE]
-#pragma unroll
-    for (int ct = 0; ct < 8; ct++) x[ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int round = 0; round < 2; round++) {
-#pragma unroll
-      for (int tj = 0; tj < TJ; tj++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) E[(16 * wr + lk + 4 * r) * PE + 64 * wc + 16 * tj + lr] = acc[round][tj][r];
-      __syncthreads();
-      const bool mine = (wc == round);
-#pragma unroll
-      for (int ct = 0; ct < 8; ct++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const double v = E[(16 * wr + lk + 4 * r) * PE + 16 * ct + lr];
-          x[ct][r] = mine ? v : x[ct][r];
-        }
-      __syncthreads();
-    }
-  }
   double* W = reinterpret_cast<double*>(smem_raw) + wave * (16 * PX);   // wave-private 16 x 32 patch
   double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
-  double* Crow = C + (int64_t)(32 * wr + 16 * wc) * NP;                 // this wavefront's 16 rows of the tile
   if (I == J) {
     // PD(J): the diagonal tile with its updates in (all but block column J-1's, which k_df_chain applies itself)
 #pragma unroll
@@ -293,8 +265,6 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     return;
   }
   long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
-  double2 v[4];                   // this thread's 16 bytes of each image of the step (slots 0 .. 3-q = L(q + s, q - 1), slot 3 = Linv(q,q))
-  bool have = false;              // ... already fetched (the panel was out when the previous step ended: no exposed latency)
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     if (pf < flagbase + q + 1) {
@@ -302,32 +272,18 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       pf = flagbase + q + 1;
     }
     if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
-    if (!have) {
-#pragma unroll
-      for (int sl = 0; sl < 4; sl++) {
-        const int p = q + sl;
-        const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
-        if ((sl == 3) || (q > 0 && p < 4)) v[sl] = reinterpret_cast<const double2*>(Xinv + kOpndBase + (size_t)blk * kImgDoubles)[tid];
-      }
-    }
-    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory (its stores were issued a whole poll + load ago)
+    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
     __syncthreads();   // the previous step's images have been consumed; X_{q-1} is out of every wavefront
     if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
+    // images of this step, memory -> LDS by LDS-DMA (no registers: the accumulators need them): slots 0 .. 3-q = L(q + s, q - 1)
+    // (q > 0), slot 3 = Linv(q,q); a wavefront moves 1 KiB of each (lane l: 16 bytes at 1024 wave + 16 l)
 #pragma unroll
-    for (int sl = 0; sl < 4; sl++)
-      if ((sl == 3) || (q > 0 && q + sl < 4)) reinterpret_cast<double2*>(img + sl * kImgDoubles)[tid] = v[sl];
-    have = false;
-    if (q < 3) {   // is the next panel out already?  then fetch its images now, behind this step's arithmetic
-      pf = ld_flag(pflag);
-      if (pf >= flagbase + q + 2) {
-        have = true;
-#pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-          const int p = q + 1 + sl;
-          const int blk = (sl == 3) ? 7 + q : p * (p - 1) / 2 + q;
-          if ((sl == 3) || (p < 4)) v[sl] = reinterpret_cast<const double2*>(Xinv + kOpndBase + (size_t)blk * kImgDoubles)[tid];
-        }
-      }
+    for (int sl = 0; sl < 4; sl++) {
+      const int p = q + sl;
+      const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
+      if ((sl == 3) || (q > 0 && p < 4))
+        __builtin_amdgcn_global_load_lds((gptr_t)(Xinv + kOpndBase + (size_t)blk * kImgDoubles + 2 * tid),
+                                         (lptr_t)(img + sl * kImgDoubles + 128 * wave), 16, 0, 0);
     }
     __syncthreads();
     if (q > 0) {   // W holds -X_{q-1} of this wavefront's rows
@@ -344,6 +300,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
           for (int h = 0; h < 4; h++) { const double2 v = op[h]; bl[2 * h] = v.x; bl[2 * h + 1] = v.y; }
 #pragma unroll
           for (int s = 0; s < 8; s++) x[2 * p + t] = MFMA(a[s], bl[s], x[2 * p + t]);
+          __builtin_amdgcn_sched_barrier(0);   // one operand image in registers at a time (hoisting them all spills the tile)
         }
     }
     // X_q = R_q Linv(q,q)^T
@@ -367,6 +324,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 #pragma unroll
         for (int s = 0; s < 8; s++) xn = MFMA(a[s], bi[s], xn);
         x[2 * q + t] = xn;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // operand reads of R_q before -X_q overwrites the patch
@@ -483,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
         }
       }
     }
-    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true);
+    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true, GTG_DF_FENCES == 0);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }

@@ -58,6 +58,14 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
   return r;
 }
 
+// Publication mode of the diagonal-tile body.  false: plain stores + release fence per panel (the stream / event schedule:
+// its TRSM workgroups acquire).  true: every datum another workgroup reads is stored write-through (sc1) and the panel's
+// progress word follows the workgroup barrier as a relaxed store -- no cache-wide write-back on the serial chain (the fence
+// cost 3-4 us per panel, 14 us per tile, next to 60 workgroups per XCD producing dirty lines); see chol_dataflow.hip.
+__device__ __forceinline__ void st_pub(double* p, double v, bool wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+
 // ---- cross-half helpers (gfx950 v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second)
 // value of the same lane (mod 32) of half H (0: lanes 0-31, 1: lanes 32-63), delivered to both halves
 template <int H>
@@ -227,7 +235,7 @@ struct FollowStep<SB> {
 // ib < 0 -> the rows of the identity become L(jb,jb)^-T: lane i ends up with column i of the inverse, written
 // plain (Xout, row-major) and as the MFMA operand image (Xop)
 __device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* rinvs, const double* rs,
-                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop) {
+                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop, bool wt = false) {
   const int i = lane & 31, h = lane >> 5;
   const bool inv = ib < 0;
   double* R = A + boff(inv ? jb : ib, jb) + i * PB;
@@ -241,8 +249,8 @@ __device__ __forceinline__ void stage_follow(double* A, const double* lines, con
   if (inv) {
 #pragma unroll
     for (int cl = 0; cl < 16; cl++) {
-      Xout[(2 * cl + h) * SB + i] = a[cl];
-      Xop[opnd_off(6 + jb, 2 * cl + h, i)] = a[cl];
+      Xout[(2 * cl + h) * SB + i] = a[cl];   // plain copy of the inverse: read by later kernels only (backward solve)
+      st_pub(Xop + opnd_off(6 + jb, 2 * cl + h, i), a[cl], wt);
     }
   } else {
 #pragma unroll
@@ -270,15 +278,18 @@ __device__ __forceinline__ void tile_task(double* A, int jb, int ib, int cb, int
 
 // write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
 // strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
-__device__ __forceinline__ void store_column(const double* A, double* tile, int NP, double* Xinv, int jb, int t, int nthreads) {
+__device__ __forceinline__ void store_column(const double* A, double* tile, int NP, double* Xinv, int jb, int t, int nthreads, bool wt = false) {
   for (int e = t; e < (4 - jb) * 512; e += nthreads) {
     const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
     const double* sp = A + boff(ib, jb) + r * PB + c;
     double2 v;
     v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
     v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
-    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * jb + c) = v;
-    if (ib != jb) *reinterpret_cast<double2*>(Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c)) = v;
+    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * jb + c) = v;   // (the tile itself is read by later kernels only)
+    if (ib != jb) {
+      double* o = Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c);
+      if (wt) { st_pub(o, v.x, true); st_pub(o + 1, v.y, true); } else *reinterpret_cast<double2*>(o) = v;
+    }
   }
 }
 
@@ -311,7 +322,7 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* __restrict__ tile
 
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
-                                           const long long* __restrict__ epoch, bool preloaded = false) {
+                                           const long long* __restrict__ epoch, bool preloaded = false, bool wt = false) {
   const long long flagbase = *epoch * 8;   // progress words are monotonic over factorisations: no reset, graph-replayable
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
@@ -337,7 +348,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     } else if (wave == 4) {
       // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
     } else if (wave <= nfol || wave == 5) {
-      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase);
+      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt);
     } else if (jb > 0) {
       const int pj = jb - 1;                            // deferred work of panel pj
       const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
@@ -350,13 +361,13 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
         while (rem > bi) { rem -= bi + 1; bi++; }
         tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
       }
-      store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64);
+      store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64, wt);
     }
     __syncthreads();
     // panel jb is complete in global memory (its inverse, and every L(jb, q<jb) operand image): release it to the
     // TRSM workgroups of this launch, which are waiting for exactly that to run their phase jb
     if (tid == 0)
-      __hip_atomic_store(reinterpret_cast<long long*>(Xinv + kFlagOff), flagbase + jb + 1, __ATOMIC_RELEASE,
+      __hip_atomic_store(reinterpret_cast<long long*>(Xinv + kFlagOff), flagbase + jb + 1, wt ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_AGENT);
     STAMP(2 + 3 * jb);
     STAMP(3 + 3 * jb);
@@ -365,7 +376,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     __syncthreads();
     STAMP(4 + 3 * jb);
   }
-  store_column(A, tile, NP, Xinv, 3, tid, 512);
+  store_column(A, tile, NP, Xinv, 3, tid, 512, wt);
   STAMP(14);
 }
 

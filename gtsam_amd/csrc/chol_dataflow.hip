@@ -342,13 +342,12 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   if (tid == 0) st_flag(myflag, flagbase + 4);
 }
 
-__global__ __launch_bounds__(512, 4) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
-                                                    int ntasks, const int32_t* __restrict__ klist,
-                                                    long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
-                                                    double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
-                                                    double* __restrict__ fail, const long long* __restrict__ epoch_p,
-                                                    long long* __restrict__ trace) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+                                          int ntasks, const int32_t* __restrict__ klist,
+                                          long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                          double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
+                                          double* __restrict__ fail, const long long* __restrict__ epoch_p,
+                                          long long* __restrict__ trace) {
   __shared__ int s_task;
   const long long epoch = *epoch_p;
   for (;;) {
@@ -371,6 +370,16 @@ __global__ __launch_bounds__(512, 4) void k_df_bulk(double* __restrict__ S, int 
   }
 }
 
+__global__ __launch_bounds__(512, 4) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+                                                    int ntasks, const int32_t* __restrict__ klist,
+                                                    long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                                    double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
+                                                    double* __restrict__ fail, const long long* __restrict__ epoch_p,
+                                                    long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
+}
+
 // one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
 __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
   double* Cb = A + boff(ib, cb);
@@ -389,21 +398,22 @@ __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, i
   for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
 }
 
-// The diagonal tiles, one after the other.  Tile J: wait until PD(J) is in (every update but the one of block column J-1),
+// The diagonal tiles.  Two workgroups (even / odd J) take turns, so that everything before the last slice of tile J -- waiting for
+// PD(J), bringing the tile into LDS, the first three slices -- happens while the partner factors tile J-1 (with one workgroup
+// those 13 us per tile were on the serial chain).  Tile J: wait until PD(J) is in (every update but the one of block column J-1),
 // bring it into LDS, apply  C -= L(J,J-1) L(J,J-1)^T  in four 32-column slices as the substitution of tile (J, J-1) publishes
 // them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
 // substitution steps of the tiles below through the tile's progress word).
-__global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
-                                                     const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
-                                                     const int32_t* __restrict__ has_sub, double* __restrict__ fail,
-                                                     const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
-                                                     long long* __restrict__ trace) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
+                                           const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
+                                           const int32_t* __restrict__ has_sub, double* __restrict__ fail,
+                                           const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
+                                           long long* __restrict__ trace, int first, int stride) {
   const long long epoch = *epoch_p;
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-  for (int J = 0; J < nt; J++) {
+  for (int J = first; J < nt; J += stride) {
     if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
@@ -445,6 +455,30 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
+}
+
+__global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
+                                                     const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
+                                                     const int32_t* __restrict__ has_sub, double* __restrict__ fail,
+                                                     const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
+                                                     long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both roles in ONE kernel (GTG_DF_SINGLE=1): workgroups 0 and 1 are the chain (dispatched first, so they are resident before
+// anybody waits for them), the others take the tile tasks; one workgroup per CU (the chain's LDS footprint).  Slower than the two-kernel form
+// (half the wavefronts per CU in the contraction) but a single dispatch: this is the form rocprofv3's counter collection, which
+// serialises kernels, can measure -- two kernels that wait for each other never finish under it.
+__global__ __launch_bounds__(512, 2) void k_df_single(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+                                                      int ntasks, const int32_t* __restrict__ klist,
+                                                      long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                                      const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
+                                                      int32_t* __restrict__ ctrl, double* __restrict__ fail,
+                                                      const long long* __restrict__ epoch_p, long long* __restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x < 2) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2);
+  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
 }
 
 __global__ void k_df_begin(long long* epoch, int32_t* ctrl) { *epoch += 1; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; }
@@ -527,6 +561,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     if (!attr_set.count(c.device)) {
       check_hip(hipFuncSetAttribute((const void*)k_df_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemBulk), "smem attr");
       check_hip(hipFuncSetAttribute((const void*)k_df_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemChain), "smem attr");
+      check_hip(hipFuncSetAttribute((const void*)k_df_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(kSmemChain, kSmemBulk)), "smem attr");
       attr_set.insert(c.device);
     }
   }
@@ -554,10 +589,20 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     df.grid = g ? atoi(g) : 2 * (ncu - reserve);
   }
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, df.ctrl.p);
+  static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
+  if (single) {
+    hipDeviceProp_t prop;
+    check_hip(hipGetDeviceProperties(&prop, c.device), "props");
+    const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + 2);
+    hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(512), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
+                       df.klist.p, df.tile_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+    check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
+    return;
+  }
   check_hip(hipEventRecord(df.ev_start, c.stream), "record");
   check_hip(hipStreamWaitEvent(df.chain, df.ev_start, 0), "wait");
   check_hip(hipStreamWaitEvent(df.bulk, df.ev_start, 0), "wait");
-  hipLaunchKernelGGL(k_df_chain, dim3(1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
+  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr);
   const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(512), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,

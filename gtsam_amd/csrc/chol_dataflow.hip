@@ -134,25 +134,140 @@ __device__ __forceinline__ int wait_progress(const long long* f1, const long lon
 }
 
 // ---- one bulk task ------------------------------------------------------------------------------------------------
-// 8 wavefronts, each 16 ROWS x all 128 columns = 1 x 8 MFMA tiles (two workgroups per CU give the four waves per SIMD the FP64
-// matrix pipe needs).  That is the layout of the substitution that follows the contraction (a row of L(I,J) depends on the same
-// row of R only: the wavefronts are independent there), so the accumulators go straight into it; the 4 x 2 geometry of k_syrk
-// needs 6 operand reads per 8 MFMAs instead of 9, but cost a layout change through LDS and, worse, had the compiler keep both
-// copies of the tile alive and park them in scratch.  Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by
-// LDS-DMA, double buffered, 16-byte slots XOR-swizzled on the source address and on the operand reads.
-__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int NP, int nt, int I, int J,
-                                         const int32_t* __restrict__ kl, int kcnt, long long* __restrict__ tile_flag,
-                                         long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
-                                         double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
-  // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
-  // the persistent task loop and kept alive (and spilled) across it
+// ONE workgroup of 16 wavefronts per CU (the four waves per SIMD the FP64 matrix pipe needs, all from the same task).  Two
+// 8-wave workgroups per CU gave the same contraction rate, but the END of a task -- the substitution, which is a link of a
+// serial chain -- then shared the matrix pipe with a neighbour in the middle of its contraction: 12 us from the last panel of the
+// diagonal tile to the finished tile, against 2.5 us with the CU to itself (measured with the single-kernel form).
+// Wavefront (rt, h) = (wave >> 1, wave & 1) owns rows 16 rt .. 16 rt + 15 and the column half h (64 columns = the 32-column
+// blocks 2 h and 2 h + 1): 1 x 4 MFMA tiles, 32 accumulator registers -- the substitution runs in the same layout (a row of
+// L(I,J) depends on the same row of R only), every register index is a compile-time constant, nothing spills.
+// Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by LDS-DMA, double buffered, 16-byte slots
+// XOR-swizzled on the source address and on the operand reads.
+constexpr int kBulkThreads = 1024;
+
+template <int H>
+__device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int NP, int nt, int I, int J,
+                                           long long* __restrict__ tile_flag, double* __restrict__ Xinv_all,
+                                           double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg,
+                                           long long* __restrict__ tr) {
+  // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
+  // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
+  // L(p, q-1), p >= q, are out by then as well):
+  //   R_p -= X_{q-1} L(p, q-1)^T for the blocks p >= q,  then  X_q = R_q Linv(q,q)^T  (stored, and published: flag = 8 epoch + q + 1)
+  // Block p = 2 h + l lives in x[2 l + t] of the wavefronts of column half h.  The A operand of a step is a 16 x 32 patch of LDS
+  // per row tile (W[rt]: -X_{q-1}; then R_q -> operand layout; then -X_q), shared by the two wavefronts of the row tile; the B
+  // operand images (<= 3 blocks L(p, q-1) + Linv(q,q)) come memory -> LDS by LDS-DMA, one memory latency per step.
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 1;
+  constexpr int h = H;
   const int lr = lane & 15, lk = lane >> 4;
-  constexpr int NQ = 2;
-  __builtin_amdgcn_s_setprio(0);
+  const long long flagbase = epoch * 8;
+  const unsigned lane_off = (unsigned)(lk * NP + lr);
+  double* Crow = C + (int64_t)(16 * rt) * NP + 64 * h;
+  const double* Xinv = Xinv_all + (size_t)J * T * T;
+  const long long* pflag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
+  long long* myflag = tile_flag + (int64_t)I * nt + J;
+  double* W = reinterpret_cast<double*>(smem_raw) + rt * (16 * PX);
+  double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
+  long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (pf < flagbase + q + 1) {
+      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, dbg, 3, I, J, q);
+      pf = flagbase + q + 1;
+    }
+    if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
+    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
+    __syncthreads();   // the previous step's images have been consumed; -X_{q-1} is complete in the W patches and out of every wavefront
+    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
+    {  // images of this step: slots 0 .. 3-q = L(q + s, q - 1) (q > 0), slot 3 = Linv(q,q); wavefront w moves 1 KiB pieces
+      // (w & 7) of the slots (w >> 3) and (w >> 3) + 2
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int sl = (wave >> 3) + 2 * j;           // uniform
+        const int p = q + sl;
+        const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
+        if ((sl == 3) || (q > 0 && p < 4))
+          __builtin_amdgcn_global_load_lds((gptr_t)(Xinv + kOpndBase + (size_t)blk * kImgDoubles + 128 * (wave & 7) + 2 * lane),
+                                           (lptr_t)(img + sl * kImgDoubles + 128 * (wave & 7)), 16, 0, 0);
+      }
+    }
+    __syncthreads();   // (drains the DMA)
+    if (q > 0) {
+      double a[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int p = 2 * h + l;
+        if (p < q) continue;   // (compile-time)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          double bl[8];
+          const double2* op = reinterpret_cast<const double2*>(img + (p - q) * kImgDoubles + (t * 64 + lane) * 8);
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const double2 v = op[u]; bl[2 * u] = v.x; bl[2 * u + 1] = v.y; }
+#pragma unroll
+          for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bl[s], x[2 * l + t]);
+        }
+      }
+    }
+    __syncthreads();   // both wavefronts of a row tile have read -X_{q-1}: the patch is free for R_q
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if (2 * h + l != q) continue;   // (compile-time)
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) W[(lk + 4 * r) * PX + 16 * t + lr] = x[2 * l + t][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-local: written and read by this wavefront
+      double a[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        double bi[8];
+        const double2* op = reinterpret_cast<const double2*>(img + 3 * kImgDoubles + (t * 64 + lane) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const double2 v = op[u]; bi[2 * u] = v.x; bi[2 * u + 1] = v.y; }
+        x[2 * l + t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bi[s], x[2 * l + t]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // operand reads of R_q before -X_q overwrites the patch
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double v = x[2 * l + t][r];
+          W[(lk + 4 * r) * PX + 16 * t + lr] = -v;   // negated: the A operand of the next step's updates
+          st_wt((Crow + (int64_t)(4 * r) * NP + 32 * l + 16 * t) + lane_off, v);
+        }
+    }
+  }
+  stores_done();
+  __syncthreads();
+  if (tid == 0) st_flag(myflag, flagbase + 4);
+}
+
+
+__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int NP, int nt, int I, int J,
+                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
+                                         long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
+                                         long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
+                                         double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
+  // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
+  // the persistent task loop and kept alive across it
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 1, h = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
   double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
   const double* Arow = S + ((int64_t)I * T) * NP;
   const double* Brow = S + ((int64_t)J * T) * NP;
@@ -162,27 +277,36 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const long long flagbase = epoch * 8;
 
   const int drow = lane >> 3, dslot = lane & 7;
-  auto stage = [&](const double* Ap, const double* Bp, int ch, int buf) {
+  auto stage = [&](const double* Ap, const double* Bp, int ch, int buf) {   // wavefront w moves rows 8 w .. 8 w + 7 of both panels
     char* base = smem_raw + buf * 2 * CH;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      const int row = 8 * (NQ * wave + q) + drow;
-      const int logical = dslot ^ ((row >> 1) & 7);
-      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
-      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (NQ * wave + q) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (NQ * wave + q) * 1024), 16, 0, 0);
-    }
+    const int row = 8 * wave + drow;
+    const int logical = dslot ^ ((row >> 1) & 7);
+    const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
+    const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+    __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + wave * 1024), 16, 0, 0);
   };
 
-  // element (ct, r) of this lane: rows 16 wave + lk + 4 r, columns 16 ct + lr -- uniform part (scalar registers) + one 32-bit lane offset
-  const unsigned lane_off = (unsigned)(lk * NP + lr);   // (unsigned: scalar base + 32-bit lane offset addressing, no 64-bit lane addresses to keep)
-  double* Crow = C + (int64_t)(16 * wave) * NP;
-  v4f64 x[8];
+  // element (c, r) of this lane: row 16 rt + lk + 4 r, column 64 h + 16 c + lr -- uniform part + one 32-bit lane offset
+  const unsigned lane_off = (unsigned)(lk * NP + lr);
+  double* Crow = C + (int64_t)(16 * rt) * NP + 64 * h;
+  v4f64 x[4];
+  long long* pflag_mine = part_flag + (int64_t)I * nt + J;
+  if (piece > 0) {
+    // the tile holds the earlier pieces' partial result, written (write-through) by other workgroups -- possibly while an older
+    // version of it sat in this XCD's L2 (a piece before that one may have run here): read it past the L2
+    wait_flags(pflag_mine, epoch * 64 + piece, pflag_mine, epoch * 64 + piece, fail, dbg, 7, I, J, piece);
 #pragma unroll
-  for (int ct = 0; ct < 8; ct++)
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) x[ct][r] = (Crow + (int64_t)(4 * r) * NP + 16 * ct)[lane_off];
+      for (int r = 0; r < 4; r++)
+        x[c][r] = __hip_atomic_load((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) x[c][r] = (Crow + (int64_t)(4 * r) * NP + 16 * c)[lane_off];
+  }
 
   if (kcnt > 0) {
     // A contraction step consumes its two operand tiles 16 columns at a time, and a tile is published in 32-column blocks
@@ -195,14 +319,9 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     const double* Bk = Brow + (int64_t)k * T;
     stage(Ak, Bk, 0, 0);
     __syncthreads();
-    const int a_row_off = (16 * wave + lr) * ROWB, b_row_off = lr * ROWB;
+    const int a_row_off = (16 * rt + lr) * ROWB, b_row_off = (64 * h + lr) * ROWB;
     const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
     for (int ki = 0; ki < kcnt; ki++) {
-      // The end of a task is a link of a serial chain (the next tile of this tile row, and the diagonal through it, wait for
-      // it): its last two contraction steps and its substitution win issue arbitration against the co-resident workgroup.
-      // Not the whole task: a workgroup that contracts at full speed for hundreds of microseconds starves its neighbour,
-      // which is somebody else's chain link.
-      if (ki + 2 == kcnt) __builtin_amdgcn_s_setprio(2);
       // the flags of the next contraction step, fetched a whole step ahead of their use
       const int kn = (ki + 1 < kcnt) ? kl[ki + 1] : k;
       int np = tile_progress(fI + kn, fJ + kn, flagbase);
@@ -225,11 +344,11 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         for (int kk = 0; kk < KC; kk += 4) {
           const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
           const double a = -*reinterpret_cast<const double*>(Ac + a_row_off + so);
-          double b[8];
+          double b[4];
 #pragma unroll
-          for (int t = 0; t < 8; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
+          for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
 #pragma unroll
-          for (int t = 0; t < 8; t++) x[t] = MFMA(a, b[t], x[t]);
+          for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
         }
         __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
       }
@@ -237,114 +356,39 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     }
   }
   if (tr && tid == 0) tr[1] = wall_clock64();
-  __builtin_amdgcn_s_setprio(2);
-  // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
-  // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
-  // L(p, q-1), p >= q, are out by then as well):
-  //   R_p -= X_{q-1} L(p, q-1)^T for the blocks p >= q,  then  X_q = R_q Linv(q,q)^T  (stored, and published: flag = 8 epoch + q + 1)
-  // Layout: the tile first changes from the contraction's 32 x 64 per wavefront to 16 ROWS x all 128 columns per wavefront
-  // (two rounds through LDS).  A row of X depends on the same row of R only, so from here on the wavefronts are independent:
-  // accumulator -> A-operand conversions go through a wave-private LDS patch, every register index is a compile-time
-  // constant and every wavefront executes the same straight-line code (a block owned by half of the wavefronts, or a register
-  // chosen at run time, made the compiler park the accumulators in scratch).  Shared per step: the B operand images
-  // (<= 3 blocks L(p, q-1) + Linv(q,q)), fetched into LDS by all threads at once -- one memory latency per step.
-  const double* Xinv = Xinv_all + (size_t)J * T * T;
-  const long long* pflag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
-  long long* myflag = tile_flag + (int64_t)I * nt + J;
-  double* W = reinterpret_cast<double*>(smem_raw) + wave * (16 * PX);   // wave-private 16 x 32 patch
-  double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
+
+  if (piece + 1 < pieces) {   // an early piece: the partial result goes back into the tile
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
+    stores_done();
+    __syncthreads();
+    if (tid == 0) st_flag(pflag_mine, epoch * 64 + piece + 1);
+    return;
+  }
   if (I == J) {
     // PD(J): the diagonal tile with its updates in (all but block column J-1's, which k_df_chain applies itself)
 #pragma unroll
-    for (int ct = 0; ct < 8; ct++)
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * ct) + lane_off, x[ct][r]);
+      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
     if (tid == 0) st_flag(pd_flag + J, fin);
     return;
   }
-  long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    if (pf < flagbase + q + 1) {
-      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, dbg, 3, I, J, q);
-      pf = flagbase + q + 1;
-    }
-    if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
-    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
-    __syncthreads();   // the previous step's images have been consumed; X_{q-1} is out of every wavefront
-    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
-    // images of this step, memory -> LDS by LDS-DMA (no registers: the accumulators need them): slots 0 .. 3-q = L(q + s, q - 1)
-    // (q > 0), slot 3 = Linv(q,q); a wavefront moves 1 KiB of each (lane l: 16 bytes at 1024 wave + 16 l)
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) {
-      const int p = q + sl;
-      const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
-      if ((sl == 3) || (q > 0 && p < 4))
-        __builtin_amdgcn_global_load_lds((gptr_t)(Xinv + kOpndBase + (size_t)blk * kImgDoubles + 2 * tid),
-                                         (lptr_t)(img + sl * kImgDoubles + 128 * wave), 16, 0, 0);
-    }
-    __syncthreads();
-    if (q > 0) {   // W holds -X_{q-1} of this wavefront's rows
-      double a[8];
-#pragma unroll
-      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
-#pragma unroll
-      for (int p = q; p < 4; p++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          double bl[8];
-          const double2* op = reinterpret_cast<const double2*>(img + (p - q) * kImgDoubles + (t * 64 + lane) * 8);
-#pragma unroll
-          for (int h = 0; h < 4; h++) { const double2 v = op[h]; bl[2 * h] = v.x; bl[2 * h + 1] = v.y; }
-#pragma unroll
-          for (int s = 0; s < 8; s++) x[2 * p + t] = MFMA(a[s], bl[s], x[2 * p + t]);
-          __builtin_amdgcn_sched_barrier(0);   // one operand image in registers at a time (hoisting them all spills the tile)
-        }
-    }
-    // X_q = R_q Linv(q,q)^T
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) W[(lk + 4 * r) * PX + 16 * t + lr] = x[2 * q + t][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    {
-      double a[8];
-#pragma unroll
-      for (int s = 0; s < 8; s++) a[s] = W[lr * PX + 8 * lk + s];
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        double bi[8];
-        const double2* op = reinterpret_cast<const double2*>(img + 3 * kImgDoubles + (t * 64 + lane) * 8);
-#pragma unroll
-        for (int h = 0; h < 4; h++) { const double2 v = op[h]; bi[2 * h] = v.x; bi[2 * h + 1] = v.y; }
-        v4f64 xn = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 8; s++) xn = MFMA(a[s], bi[s], xn);
-        x[2 * q + t] = xn;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // operand reads of R_q before -X_q overwrites the patch
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const double v = x[2 * q + t][r];
-        W[(lk + 4 * r) * PX + 16 * t + lr] = -v;   // negated: the A operand of the next step's updates
-        st_wt((Crow + (int64_t)(4 * r) * NP + 32 * q + 16 * t) + lane_off, v);
-      }
-  }
-  stores_done();
-  __syncthreads();
-  if (tid == 0) st_flag(myflag, flagbase + 4);
+
+  // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
+  // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
+  if (h == 0) substitute<0>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, dbg, tr);
+  else substitute<1>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, dbg, tr);
 }
 
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
                                           int ntasks, const int32_t* __restrict__ klist,
-                                          long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
+                                          long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                           double* __restrict__ fail, const long long* __restrict__ epoch_p,
                                           long long* __restrict__ trace) {
@@ -356,7 +400,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 4 * (int64_t)t;
+    const int32_t* d = tasks + 6 * (int64_t)t;
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -364,20 +408,21 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], tile_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
 }
 
-__global__ __launch_bounds__(512, 4) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+__global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
                                                     int ntasks, const int32_t* __restrict__ klist,
-                                                    long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                                    long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
+                                                    long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                                     double* __restrict__ fail, const long long* __restrict__ epoch_p,
                                                     long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
+  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
 }
 
 // one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
@@ -467,18 +512,19 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): workgroups 0 and 1 are the chain (dispatched first, so they are resident before
-// anybody waits for them), the others take the tile tasks; one workgroup per CU (the chain's LDS footprint).  Slower than the two-kernel form
-// (half the wavefronts per CU in the contraction) but a single dispatch: this is the form rocprofv3's counter collection, which
+// anybody waits for them; their upper eight wavefronts leave at once), the others take the tile tasks.  The chain's code is
+// compiled for the bulk kernel's 128 registers here (it spills: slower than the two-kernel form) but it is a single dispatch: this is the form rocprofv3's counter collection, which
 // serialises kernels, can measure -- two kernels that wait for each other never finish under it.
-__global__ __launch_bounds__(512, 2) void k_df_single(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+__global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
                                                       int ntasks, const int32_t* __restrict__ klist,
-                                                      long long* __restrict__ tile_flag, long long* __restrict__ pd_flag,
+                                                      long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
+                                                      long long* __restrict__ pd_flag,
                                                       const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long* __restrict__ epoch_p, long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < 2) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2);
-  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
+  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2); }
+  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
 }
 
 __global__ void k_df_begin(long long* epoch, int32_t* ctrl) { *epoch += 1; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; }
@@ -505,10 +551,30 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   df.h_tasks.clear(); df.h_klist.clear();
   const double t3 = (double)T * T * T;
   double flops = 0.0; int64_t stored = 0;
+  // A tile's contraction is serial on one CU (14 us per step, up to ~30 steps) and the workgroups in flight cover only ~9 block
+  // columns: a long contraction taken when its column comes up would not be done when the column's diagonal tile is factored.
+  // So a long list is cut into PIECES of at most kPiece steps; piece r accumulates in place (tile -= its steps, flag
+  // part_flag = 64 epoch + r + 1) and is queued EARLIER than the tile's own column: right behind the block column of its
+  // youngest operand, where everything it reads is final and it runs without waiting.  Only the last piece (the youngest
+  // steps + the substitution) sits in the tile's column and streams behind the columns before it.
+  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 8);
+  struct Rec { int32_t I, J, koff, kcnt, r, R; };
+  std::vector<std::vector<Rec>> finals(nt), early(nt);
   auto emit = [&](int I, int J, const std::vector<int32_t>& ks) {
-    df.h_tasks.push_back(I); df.h_tasks.push_back(J);
-    df.h_tasks.push_back((int32_t)df.h_klist.size()); df.h_tasks.push_back((int32_t)ks.size());
+    const int n = (int)ks.size();
+    const int R = std::max(1, (n + kPiece - 1) / kPiece);
+    const int32_t off = (int32_t)df.h_klist.size();
     df.h_klist.insert(df.h_klist.end(), ks.begin(), ks.end());
+    int gprev = 0;
+    for (int r = 0; r < R; r++) {
+      // the OLDEST steps form the full pieces; the last piece keeps the remainder (the youngest steps)
+      const int b = r * kPiece, e = (r == R - 1) ? n : (r + 1) * kPiece;
+      const Rec rec{I, J, off + b, e - b, r, R};
+      if (r == R - 1) { finals[J].push_back(rec); break; }
+      const int last_k = ks[e - 1];
+      const int g = std::min(J - 1, std::max(last_k + 1, gprev));   // as early as its operands exist
+      early[g].push_back(rec); gprev = g;
+    }
   };
   std::vector<int32_t> ks;
   std::vector<int32_t> has_sub(nt, 0);
@@ -527,23 +593,29 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
     }
     emit(nt, J, rowcols[J]);   // rhs row: y_J (flops not counted, as in the right-looking plan)
   }
-  df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 4;
+  // ticket order: column by column, the column's own tasks first (diagonal accumulation, the tile below it, ...), then the early
+  // pieces of later columns that were assigned to this position
+  for (int c = 0; c < nt; c++)
+    for (const auto* v : {&finals[c], &early[c]})
+      for (const Rec& t : *v) for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f);
+  df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (df.h_klist.empty()) df.h_klist.push_back(0);
   df.tasks.upload(df.h_tasks.data(), df.h_tasks.size(), stream);
   df.has_sub.upload(has_sub.data(), has_sub.size(), stream);
   df.h_has_sub = has_sub;
   df.klist.upload(df.h_klist.data(), df.h_klist.size(), stream);
-  df.tile_flag.alloc((size_t)(nt + 1) * nt); df.pd_flag.alloc(nt); df.ctrl.alloc(16);
+  df.tile_flag.alloc((size_t)(nt + 1) * nt); df.part_flag.alloc((size_t)(nt + 1) * nt); df.pd_flag.alloc(nt); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
+  check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 16, stream), "memset");
   check_hip(hipStreamSynchronize(stream), "df plan upload");
 }
 
 void free_df_plan(DfPlan& df) {
-  df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
+  df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.part_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
   if (df.bulk) (void)hipStreamDestroy(df.bulk);
   if (df.chain) (void)hipStreamDestroy(df.chain);
   for (hipEvent_t e : {df.ev_start, df.ev_chain, df.ev_bulk}) if (e) (void)hipEventDestroy(e);
@@ -586,7 +658,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     check_hip(hipEventCreateWithFlags(&df.ev_chain, hipEventDisableTiming), "event");
     check_hip(hipEventCreateWithFlags(&df.ev_bulk, hipEventDisableTiming), "event");
     const char* g = getenv("GTG_DF_GRID");
-    df.grid = g ? atoi(g) : 2 * (ncu - reserve);
+    df.grid = g ? atoi(g) : (ncu - reserve);
   }
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, df.ctrl.p);
   static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
@@ -594,8 +666,8 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + 2);
-    hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(512), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
-                       df.klist.p, df.tile_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+    hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
+                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -605,8 +677,8 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr);
   const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
-  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(512), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
   check_hip(hipEventRecord(df.ev_chain, df.chain), "record");
   check_hip(hipEventRecord(df.ev_bulk, df.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, df.ev_chain, 0), "wait");

@@ -234,10 +234,10 @@ class DeviceGraph:
         return d
 
     def df_plan(self):
-        """Test hook: the dataflow schedule -- dict(nt, active, tasks[n][4] = I, J, koff, kcnt, klist), see gtg_debug_df_plan."""
+        """Test hook: the dataflow schedule -- dict(nt, active, tasks[n][6] = I, J, koff, kcnt, piece, pieces, klist), see gtg_debug_df_plan."""
         sz = np.zeros(4, np.int64)
         _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, None, None), "gtg_debug_df_plan")
-        tasks = np.zeros((int(sz[1]), 4), np.int32); klist = np.zeros(int(sz[2]), np.int32)
+        tasks = np.zeros((int(sz[1]), 6), np.int32); klist = np.zeros(int(sz[2]), np.int32)
         _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, tasks.ctypes.data, klist.ctypes.data), "gtg_debug_df_plan")
         return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist)
 

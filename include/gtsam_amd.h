@@ -230,8 +230,9 @@ int gtg_debug_plan_sizes(gtg_handle h, int64_t sizes[8]);
 int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* bcols, int32_t* stored, int32_t* exch,
                          int64_t* per_tile, int64_t* per_pair, int32_t* pair_part, int32_t* part_parent);
 /* The dataflow schedule of the same factorisation (csrc/chol_dataflow.hip, the default): sizes = {nt, n_tasks, |klist|, active};
- * tasks[n_tasks][4] = I, J, offset and count into klist (I == J: accumulation of the diagonal tile, I == nt: rhs row), in the
- * order in which the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
+ * tasks[n_tasks][6] = I, J, offset and count into klist, piece r of R (I == J: accumulation of the diagonal tile, I == nt: rhs
+ * row; a long contraction is cut into pieces that accumulate in place, the last piece finishes the tile), in the order in which
+ * the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
 int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* klist);
 /* out[0] = tickets taken in the last factorisation; out[8..15] = record of the first dependency wait that gave up (kind 1/2: tile
  * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted) */

@@ -132,7 +132,8 @@ def _execute_df(pl, df, t=8, seed=0):
     """The dataflow schedule (csrc/chol_dataflow.hip) in numpy: the tasks in ticket order, exactly what a workgroup does with
     one -- PD(J): A_JJ -= sum_k L_Jk L_Jk^T over its k list (then the chain kernel applies L_J,J-1 and factors the tile); (I, J): R = A_IJ -
     sum_k L_Ik L_Jk^T, L_IJ = R L_JJ^-T; I == nt is the rhs row.  Every operand must be FINAL when it is read in this order
-    (that is the no-deadlock argument: a task only waits for tasks before it), every k list must be complete (dense result)."""
+    (that is the no-deadlock argument: a task only waits for tasks before it), every k list must be complete (dense result).
+    A long contraction comes in pieces (task fields r of R) that accumulate in place and are queued ahead of the tile's column."""
     rng = np.random.default_rng(seed)
     nt = int(pl["nt"]); n = nt * t
     assert int(df["nt"]) == nt
@@ -145,9 +146,9 @@ def _execute_df(pl, df, t=8, seed=0):
     A = A + A.T
     A += np.diag(np.abs(A).sum(1) + 1.0 + rng.uniform(0, 1, n))
     Ld = np.linalg.cholesky(A); yd = np.linalg.solve(Ld, g)
-    tasks = np.array(df["tasks"], np.int64).reshape(-1, 4); klist = np.array(df["klist"], np.int64)
-    owned = {(int(I), int(J)) for I, J, _, _ in tasks}
-    assert len(owned) == len(tasks), "a tile has two tasks"
+    tasks = np.array(df["tasks"], np.int64).reshape(-1, 6); klist = np.array(df["klist"], np.int64)
+    owned = {(int(I), int(J)) for I, J in tasks[:, :2]}
+    assert len(owned) == int((tasks[:, 4] == tasks[:, 5] - 1).sum()), "a tile must have exactly one finishing piece"
     stored_old = {(int(I), int(J)) for I, J in pl["stored"]}
     assert owned <= stored_old, "the dataflow schedule touches a tile the zeroing / backward lists do not know"
     for I in range(nt):
@@ -156,27 +157,32 @@ def _execute_df(pl, df, t=8, seed=0):
                 assert not A[I * t:(I + 1) * t, J * t:(J + 1) * t].any(), "a non-zero tile of the graph has no task"
     tile = {(I, J): (np.vstack([g[J * t:(J + 1) * t][None, :], np.zeros((t - 1, t))]) if I == nt else A[I * t:(I + 1) * t, J * t:(J + 1) * t].copy())
             for (I, J) in owned}
-    final, diag_done = set(), set()
+    final, diag_done, pieces_done, seen_k = set(), set(), {}, {}
 
     def L(I, k):
         assert (I, k) in final, f"tile ({I},{k}) is read before the task that produces it in ticket order"
         return tile[(I, k)]
-    last_col = -1
-    for I, J, off, cnt in tasks:
-        I, J, off, cnt = int(I), int(J), int(off), int(cnt)
-        assert J >= last_col, "tasks are not ordered by block column"
-        last_col = J
+    for I, J, off, cnt, r, R in tasks:
+        I, J, off, cnt, r, R = (int(v) for v in (I, J, off, cnt, r, R))
         ks = [int(k) for k in klist[off:off + cnt]]
         assert ks == sorted(ks) and all(k < J for k in ks)
-        acc = tile[(I, J)].copy()
+        # pieces of a tile's contraction accumulate in place, in order (piece r waits for piece r - 1), oldest steps first
+        assert pieces_done.get((I, J), 0) == r and 0 <= r < R, f"piece {r} of tile ({I},{J}) out of order"
+        assert not seen_k.get((I, J)) or (ks and ks[0] > seen_k[(I, J)][-1]) or not ks
+        seen_k.setdefault((I, J), []).extend(ks)
+        pieces_done[(I, J)] = r + 1
+        acc = tile[(I, J)]
         for k in ks:
-            acc -= L(I, k) @ L(J, k).T
+            acc = acc - L(I, k) @ L(J, k).T
+        tile[(I, J)] = acc
+        if r + 1 < R:
+            continue
         if I == J:
             # k_df_chain: the update of block column J-1 is its own (streamed behind the substitution of tile (J, J-1), which
             # must therefore precede PD(J) in ticket order -- it is the first task of column J-1's group), then the factorisation
             if (J, J - 1) in owned:
-                assert J - 1 not in ks, "PD(J) and the chain kernel would both apply block column J-1"
-                acc -= L(J, J - 1) @ L(J, J - 1).T
+                assert J - 1 not in seen_k[(J, J)], "PD(J) and the chain kernel would both apply block column J-1"
+                acc = acc - L(J, J - 1) @ L(J, J - 1).T
             tile[(J, J)] = np.linalg.cholesky(np.tril(acc) + np.tril(acc, -1).T); diag_done.add(J)
         else:
             assert J in diag_done, "a tile's substitution precedes the accumulation of its diagonal tile in ticket order"

@@ -31,8 +31,9 @@ def main():
     c_in, c_out = us(chain[:, 0]), us(chain[:, 1])
     total = max(done.max(), c_out.max())
     I, J, kcnt = T[:, 0], T[:, 1], T[:, 3]
-    pd = {int(J[i]): i for i in range(len(T)) if I[i] == J[i]}
-    sub = {int(J[i]): i for i in range(len(T)) if I[i] == J[i] + 1}
+    last = T[:, 4] == T[:, 5] - 1
+    pd = {int(J[i]): i for i in range(len(T)) if I[i] == J[i] and last[i]}
+    sub = {int(J[i]): i for i in range(len(T)) if I[i] == J[i] + 1 and last[i]}
     rows = []
     for j in range(1, nt):
         if j - 1 in sub and j in pd:

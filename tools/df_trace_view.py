@@ -6,7 +6,8 @@ d = np.load(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/df_trace_raw.npz')
 t0 = min(tasks[:, 0].min(), chain[:, 0].min()); us = lambda x: (x - t0) / 100.0
 start, acc, done = us(tasks[:, 0]), us(tasks[:, 1]), us(tasks[:, 2]); cin, cout = us(chain[:, 0]), us(chain[:, 1])
 I, J, kc = T[:, 0], T[:, 1], T[:, 3]
-idx = {(int(I[i]), int(J[i])): i for i in range(len(T))}
+last = T[:, 4] == T[:, 5] - 1
+idx = {(int(I[i]), int(J[i])): i for i in range(len(T)) if last[i]}
 cols = [int(a) for a in sys.argv[2:]] or [30, 58, 59, 60, 61, 100]
 for j in cols:
     s = idx[(j, j - 1)]; p = idx[(j, j)]
@@ -17,7 +18,7 @@ for j in cols:
     for ii in (j + 1, j + 2, j + 5):
         if (ii, j - 1) in idx:
             t = idx[(ii, j - 1)]; print('     T(%d,%d): acc_done %.1f done %.1f fin %.1f (after chain out %+.1f)' % (ii, j - 1, acc[t], done[t], done[t] - acc[t], done[t] - cout[j - 1]))
-fin = (done - acc)[I != J]
+fin = (done - acc)[(I != J) & last]
 print('finalize dur percentiles 10/50/90/99', np.percentile(fin, [10, 50, 90, 99]))
 per = np.diff(cout)
 print('chain period percentiles 10/50/90', np.percentile(per, [10, 50, 90]), 'sum', per.sum())

@@ -556,25 +556,27 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   // So a long list is cut into PIECES of at most kPiece steps; piece r accumulates in place (tile -= its steps, flag
   // part_flag = 64 epoch + r + 1) and is queued EARLIER than the tile's own column: right behind the block column of its
   // youngest operand, where everything it reads is final and it runs without waiting.  Only the last piece (the youngest
-  // steps + the substitution) sits in the tile's column and streams behind the columns before it.
-  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 8);
+  // kFinal steps + the substitution) sits in the tile's column and streams behind the columns before it.
+  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 6);
+  static const int kFinal = std::max(1, getenv("GTG_DF_FINAL") ? atoi(getenv("GTG_DF_FINAL")) : 3);
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);
   auto emit = [&](int I, int J, const std::vector<int32_t>& ks) {
     const int n = (int)ks.size();
-    const int R = std::max(1, (n + kPiece - 1) / kPiece);
+    int m = std::max(0, n - kFinal);                 // older steps, in early pieces of at most kPiece; the last piece: the youngest
+    while (m > 0 && ks[m - 1] > J - 3) m--;          // (an early piece sits two groups before its tile's column at the latest)
+    const int f = n - m;
+    const int R = (m + kPiece - 1) / kPiece + 1;
     const int32_t off = (int32_t)df.h_klist.size();
     df.h_klist.insert(df.h_klist.end(), ks.begin(), ks.end());
     int gprev = 0;
-    for (int r = 0; r < R; r++) {
-      // the OLDEST steps form the full pieces; the last piece keeps the remainder (the youngest steps)
-      const int b = r * kPiece, e = (r == R - 1) ? n : (r + 1) * kPiece;
-      const Rec rec{I, J, off + b, e - b, r, R};
-      if (r == R - 1) { finals[J].push_back(rec); break; }
+    for (int r = 0; r + 1 < R; r++) {
+      const int b = r * kPiece, e = std::min(m, (r + 1) * kPiece);
       const int last_k = ks[e - 1];
-      const int g = std::min(J - 1, std::max(last_k + 1, gprev));   // as early as its operands exist
-      early[g].push_back(rec); gprev = g;
+      const int g = std::max(last_k + 1, gprev);   // as early as its operands exist (<= J - 2)
+      early[g].push_back(Rec{I, J, off + b, e - b, r, R}); gprev = g;
     }
+    finals[J].push_back(Rec{I, J, off + m, f, R - 1, R});
   };
   std::vector<int32_t> ks;
   std::vector<int32_t> has_sub(nt, 0);
@@ -593,11 +595,13 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
     }
     emit(nt, J, rowcols[J]);   // rhs row: y_J (flops not counted, as in the right-looking plan)
   }
-  // ticket order: column by column, the column's own tasks first (diagonal accumulation, the tile below it, ...), then the early
-  // pieces of later columns that were assigned to this position
-  for (int c = 0; c < nt; c++)
-    for (const auto* v : {&finals[c], &early[c]})
-      for (const Rec& t : *v) for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f);
+  // ticket order: column c's own tasks (diagonal accumulation, the tile below it, ...), then the early pieces whose youngest
+  // operand is in column c - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
+  // pieces that merely have to be done some columns later (with the early pieces of group c - 1 in front of them, the diagonal
+  // accumulation was taken 30 us before it was needed and the chain waited 20 us for it every few columns)
+  auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
+  for (int c = 0; c < nt; c++) { put(finals[c]); if (c >= 1) put(early[c - 1]); }
+  put(early[nt - 1]);
   df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (df.h_klist.empty()) df.h_klist.push_back(0);

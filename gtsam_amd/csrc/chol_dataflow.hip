@@ -35,7 +35,7 @@ namespace gt {
 
 namespace {
 
-constexpr int KC = 16;            // contraction chunk staged per LDS-DMA round (columns)
+constexpr int KC = 32;            // contraction chunk staged per LDS-DMA round (columns): one 32-column block of the operand tiles
 constexpr int ROWB = KC * 8;      // bytes per LDS row of a chunk
 constexpr int CH = T * KC * 8;    // bytes of one 128-row panel chunk
 constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of the substitution
@@ -276,15 +276,21 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const long long fin = final_of(epoch);
   const long long flagbase = epoch * 8;
 
-  const int drow = lane >> 3, dslot = lane & 7;
+  // One DMA instruction = 1 KiB = 4 rows x 16 slots of 16 bytes (a row of a chunk is 256 bytes): lane l -> row + l / 16, stored
+  // slot l % 16, which holds the logical slot (l % 16) ^ (row & 15).  With rows 256 bytes apart every row starts at bank 0, and
+  // the 16 operand rows of an MFMA read (rows = 16 x + lr) then hit 16 different slots: conflict-free ds_read_b64.
+  const int drow = lane >> 4, dslot = lane & 15;
   auto stage = [&](const double* Ap, const double* Bp, int ch, int buf) {   // wavefront w moves rows 8 w .. 8 w + 7 of both panels
     char* base = smem_raw + buf * 2 * CH;
-    const int row = 8 * wave + drow;
-    const int logical = dslot ^ ((row >> 1) & 7);
-    const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
-    const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
-    __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int row = 8 * wave + 4 * q + drow;
+      const int logical = dslot ^ (row & 15);
+      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
+      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (2 * wave + q) * 1024), 16, 0, 0);
+    }
   };
 
   // element (c, r) of this lane: row 16 rt + lk + 4 r, column 64 h + 16 c + lr -- uniform part + one 32-bit lane offset
@@ -320,7 +326,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     stage(Ak, Bk, 0, 0);
     __syncthreads();
     const int a_row_off = (16 * rt + lr) * ROWB, b_row_off = (64 * h + lr) * ROWB;
-    const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr >> 1;
+    const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr;
     for (int ki = 0; ki < kcnt; ki++) {
       // the flags of the next contraction step, fetched a whole step ahead of their use
       const int kn = (ki + 1 < kcnt) ? kl[ki + 1] : k;
@@ -331,7 +337,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int ch = 0; ch < T / KC; ch++) {
         const int cur = ch & 1;
         if (ch + 1 < T / KC) {
-          const int need = ((ch + 1) >> 1) + 1;
+          const int need = ch + 2;   // chunk ch + 1 = the operand tiles' 32-column block ch + 1
           if (cp < need) { cp = tile_progress(fI + k, fJ + k, flagbase); if (cp < need) cp = wait_progress(fI + k, fJ + k, flagbase, need, fail, dbg, 2, I, J, k); }
           stage(Ak, Bk, ch + 1, cur ^ 1);
         } else if (ki + 1 < kcnt) {

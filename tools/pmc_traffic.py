@@ -17,7 +17,7 @@ def load(path):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
-CHOL = ("k_panel128", "k_potrf128", "k_trsm128", "k_syrk")
+CHOL = ("k_panel128", "k_potrf128", "k_trsm128", "k_syrk", "k_df_single", "k_df_bulk", "k_df_chain")
 
 
 def total(tab, pred):
@@ -28,12 +28,17 @@ def is_chol(k):
     return any(c in k for c in CHOL)
 
 
+# dataflow schedule (default): one k_df_single dispatch per factorisation in the profiled form (GTG_DF_SINGLE=1: rocprofv3's counter
+# collection serialises kernels, so the two cooperating kernels of the production form cannot run under it; same tasks, same
+# tiles read and written, one workgroup per CU instead of a separate chain kernel); stream / event schedule: one k_panel128 per
+# block column
+ndf = max((n for k, (n, s) in fetch.items() if "k_df_single" in k), default=0)
 nfac = max((n for k, (n, s) in fetch.items() if "k_panel128" in k or "k_potrf128" in k), default=0)
 nt = 122.0   # block columns of the L1723-shaped reduced system (15 507 / 128, rounded up)
-facs = nfac / nt if nfac else 0.0
+facs = float(ndf) if ndf else (nfac / nt if nfac else 0.0)
 fb, wb = total(fetch, is_chol) * 1024.0, total(write, is_chol) * 1024.0
 res = {
-    "unit": "bytes per tile-sparse Cholesky factorisation (k_panel128 + k_syrk<1|2>), RCM-ordered L1723 shape",
+    "unit": "bytes per tile-sparse Cholesky factorisation (dataflow schedule, profiled as k_df_single; or k_panel128 + k_syrk<1|2> with GTG_CHOL=streams), RCM-ordered L1723 shape",
     "FETCH_SIZE_raw_bytes": fb / facs if facs else None, "WRITE_SIZE_bytes": wb / facs if facs else None,
     "fetch_corrected_bytes": 2.0 * fb / facs if facs else None,
     "hbm_bytes_sparse": (2.0 * fb + wb) / facs if facs else None,

@@ -6,14 +6,17 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
+timeout 600 python $REPO/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 600 $OUT/${TAG}_bench.json
 rm -rf /tmp/prof_s /tmp/prof_f /tmp/prof_w
-rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $REPO/bench.py --steps 4 --warmup 1 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_trace.log 2>&1
+# (kernel tracing does not serialise dispatches: the two cooperating kernels of the dataflow Cholesky run as in production; should a
+# tool version serialise them, the factorisation reports a wait timeout instead of hanging and the single-kernel form is profiled)
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $REPO/bench.py --steps 4 --warmup 1 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_trace.log 2>&1 \
+  || { rm -rf /tmp/prof_s; GTG_DF_SINGLE=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $REPO/bench.py --steps 4 --warmup 1 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_trace.log 2>&1; }
 python $REPO/tools/rocprof_top.py $(find /tmp/prof_s -name "*.db" | head -1) $OUT/${TAG}_kernel_stats.csv | head -12
-rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python $REPO/bench.py --steps 2 --warmup 0 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_fetch.log 2>&1
+GTG_DF_SINGLE=1 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- python $REPO/bench.py --steps 2 --warmup 0 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_fetch.log 2>&1
 python $REPO/tools/rocprof_pmc.py $(find /tmp/prof_f -name "*.db" | head -1) $OUT/${TAG}_pmc_fetch_size.csv > /dev/null
-rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python $REPO/bench.py --steps 2 --warmup 0 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_write.log 2>&1
+GTG_DF_SINGLE=1 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- python $REPO/bench.py --steps 2 --warmup 0 --cpu-baseline off --skip-dense-roofline > $OUT/${TAG}_write.log 2>&1
 python $REPO/tools/rocprof_pmc.py $(find /tmp/prof_w -name "*.db" | head -1) $OUT/${TAG}_pmc_write_size.csv > /dev/null
 python $REPO/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv $OUT/${TAG}_pmc_cholesky_traffic.json
 rm -rf /tmp/prof_s /tmp/prof_f /tmp/prof_w

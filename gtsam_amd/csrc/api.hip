@@ -12,6 +12,7 @@
 #include <thread>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <new>
 #include <sys/mman.h>
@@ -47,6 +48,7 @@ template struct DevBuf<double>;
 template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<long long>;
+template struct DevBuf<unsigned char>;
 
 static void exchange(gtg_context& c, double* ptr, int64_t n) {
   if (c.n_shards > 1) {
@@ -55,6 +57,21 @@ static void exchange(gtg_context& c, double* ptr, int64_t n) {
     const int rc = c.allreduce(ptr, n, (void*)c.stream, c.allreduce_user);
     if (rc != 0) throw std::runtime_error("allreduce callback failed");
   }
+}
+
+// The dataflow factorisation is a pair of persistent kernels that wait for each other.  Two of them in flight on one device (two
+// handles driven from two host threads) can starve each other: the runtime multiplexes streams onto a few hardware queues, and
+// handle A's chain kernel may sit behind handle B's bulk kernel in one queue while B's chain kernel sits behind A's bulk kernel
+// in another -- neither pair completes until the wait bound breaks the cycle (seen with three handles: time-outs, never wrong
+// numbers).  So a process runs one dataflow factorisation per device at a time: the lock is taken before the launch and released
+// once the call has synchronised with its stream.
+static std::mutex& df_device_lock(int device) {
+  static std::mutex guard;
+  static std::map<int, std::unique_ptr<std::mutex>> locks;
+  std::lock_guard<std::mutex> g(guard);
+  auto& p = locks[device];
+  if (!p) p.reset(new std::mutex);
+  return *p;
 }
 
 static void read_scalars(gtg_context& c) {
@@ -143,6 +160,7 @@ int gtg_destroy(gtg_handle c) {
   for (auto* b : i64) b->free();
   c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   free_df_plan(c->df);
+  c->pivot_kind.free(); c->tile_exp.free();
   destroy_chol_streams(*c);
   for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -389,18 +407,25 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
     }
   }
+  std::unique_lock<std::mutex> one_at_a_time;
+  if (c->use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
   { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
-    if (c->use_df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL);
-    else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL); }
+    if (c->use_df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
+    else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
   { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
     launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p);
     launch_back_substitute(*c);
+    if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
+      check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
+      one_at_a_time.unlock();                                // done, let the other one start before waiting for it
+    }
     if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
   { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
+  if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
@@ -646,19 +671,27 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   std::vector<double> ones(NP - n, 1.0);
   if (NP > n) check_hip(hipMemcpy2DAsync(S.p + (size_t)n * NP + n, sizeof(double) * (NP + 1), ones.data(), sizeof(double), sizeof(double), NP - n, hipMemcpyHostToDevice, c->stream), "pad");
   if (rhs) check_hip(hipMemcpyAsync(S.p + (size_t)NP * NP, rhs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "rhs");
+  // rank test: the matrix is ONE frontal block, as in choleskyPartial(ABC, nFrontal = n) (base/cholesky.cpp:144-157)
+  std::vector<unsigned char> pk(NP, 0);
+  pk[n - 1] = n >= 2 ? 1 : 2;
+  DevBuf<unsigned char> dpk; dpk.upload(pk.data(), pk.size(), c->stream);
+  DevBuf<double> dexp; dexp.alloc(NP / kTile + 1);
   CholPlan plan;
   build_chol_plan(plan, NP / kTile, nullptr, c->stream);   // dense
   DfPlan df;
   const char* sched = std::getenv("GTG_CHOL");
   const bool use_df = !(sched && std::string(sched) == "streams");
-  if (use_df) { build_df_plan(df, NP / kTile, nullptr, c->stream); launch_cholesky_df(*c, S.p, NP, df, Dinv.p, fail.p); }
-  else launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p);
+  std::unique_lock<std::mutex> one_at_a_time;
+  if (use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
+  if (use_df) { build_df_plan(df, NP / kTile, nullptr, c->stream); launch_cholesky_df(*c, S.p, NP, df, Dinv.p, fail.p, dpk.p, dexp.p); }
+  else launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p, dpk.p, dexp.p);
   if (rhs) launch_backward_solve(*c, S.p, NP, plan, Dinv.p, x.p);
   double hf2[2] = {0, 0};
   check_hip(hipMemcpyAsync(hf2, fail.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
+  dpk.free(); dexp.free();
   S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
   free_df_plan(df);
   if (hf2[1] != 0.0) throw std::runtime_error("gtg_dense_cholesky_host: a dependency wait of the factorisation ran into its bound");

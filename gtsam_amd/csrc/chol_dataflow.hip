@@ -459,7 +459,8 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
                                            const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
                                            const int32_t* __restrict__ has_sub, double* __restrict__ fail,
                                            const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
-                                           long long* __restrict__ trace, int first, int stride) {
+                                           long long* __restrict__ trace, int first, int stride,
+                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   const long long epoch = *epoch_p;
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
@@ -502,7 +503,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true, GTG_DF_FENCES == 0);
+    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
@@ -512,9 +513,10 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
                                                      const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
                                                      const int32_t* __restrict__ has_sub, double* __restrict__ fail,
                                                      const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
-                                                     long long* __restrict__ trace) {
+                                                     long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
+                                                     double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace, (int)blockIdx.x, (int)gridDim.x);
+  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace, (int)blockIdx.x, (int)gridDim.x, pivot_kind, tile_exp);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): workgroups 0 and 1 are the chain (dispatched first, so they are resident before
@@ -527,9 +529,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       long long* __restrict__ pd_flag,
                                                       const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
-                                                      const long long* __restrict__ epoch_p, long long* __restrict__ trace) {
+                                                      const long long* __restrict__ epoch_p, long long* __restrict__ trace,
+                                                      const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2); }
+  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2, pivot_kind, tile_exp); }
   else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
 }
 
@@ -633,7 +636,8 @@ void free_df_plan(DfPlan& df) {
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
-void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail) {
+void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail,
+                        const unsigned char* pivot_kind, double* tile_exp) {
   const int nt = NP / T;
   if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
   static std::set<int> attr_set;
@@ -677,7 +681,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + 2);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
-                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p, pivot_kind, tile_exp);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -685,7 +689,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   check_hip(hipStreamWaitEvent(df.chain, df.ev_start, 0), "wait");
   check_hip(hipStreamWaitEvent(df.bulk, df.ev_start, 0), "wait");
   hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr);
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp);
   const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);

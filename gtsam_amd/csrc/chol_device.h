@@ -180,8 +180,13 @@ __device__ __forceinline__ void scale_columns(double (&a)[16], const double* rs,
 }
 
 // factor the diagonal sub-block jb in place (upper part zeroed)
+// pk / prev_exp: the reference's rank test (gtsam/base/cholesky.cpp:144-157, underconstrainedExponentDifference = 12) at the end of
+// every variable's block of pivots: pk[c] = 1 -- column c is the last pivot of a variable of dimension >= 2: fail when the binary
+// exponent of R(c-1,c-1) exceeds that of R(c,c) by 12 or more; pk[c] = 2 -- a one-dimensional variable: fail unless the exponent
+// of R(c,c) is > -12; 0 -- no test (inside a variable, padding).  prev_exp carries the exponent of the pivot before this panel.
 __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ rinvs, double* __restrict__ rs,
-                                            double* __restrict__ lines, int* prog, int jb, int lane, double* fail) {
+                                            double* __restrict__ lines, int* prog, int jb, int lane, double* fail,
+                                            const unsigned char* __restrict__ pk, int& prev_exp) {
   const int i = lane & 31, h = lane >> 5;
   double* row = A + boff(jb, jb) + i * PB;
   double a[16], c0[16];
@@ -201,6 +206,16 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
   scale_columns(a, rs + SB * jb, h);
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
+  if (pk) {   // off the pivot chain: the panel is out, the followers are running
+    const unsigned kind = pk[SB * jb + i];
+    const double Rii = rsqrt_nr(rv);   // sqrt(pivot) = the diagonal entry of the factor
+    const int ex = (int)((__double_as_longlong(Rii) >> 52) & 0x7ff) - 1022;   // frexp exponent
+    int before = __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, ex);
+    if (i == 0) before = prev_exp;
+    const bool bad = (kind == 1u && before - ex >= 12) || (kind == 2u && !(ex > -12));
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *fail = 1.0;
+    prev_exp = __builtin_amdgcn_readlane(ex, 31);
+  }
 }
 
 template <int J>
@@ -322,7 +337,8 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* __restrict__ tile
 
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
-                                           const long long* __restrict__ epoch, bool preloaded = false, bool wt = false) {
+                                           const long long* __restrict__ epoch, bool preloaded = false, bool wt = false,
+                                           const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr) {
   const long long flagbase = *epoch * 8;   // progress words are monotonic over factorisations: no reset, graph-replayable
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
@@ -340,11 +356,17 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   if (!preloaded) diag_tile_to_lds(tile, NP, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();
   STAMP(1);
+  // rank test at the variables' block ends (see stage_potrf): pivot kinds of this tile's columns, exponent of the pivot before it
+  const unsigned char* pk = pivot_kind ? pivot_kind + (size_t)k * T : nullptr;
+  int prev_exp = 0;
+  if (pk && tile_exp && k > 0 && wave == 0)
+    prev_exp = (int)__double_as_longlong(__hip_atomic_load(tile_exp + k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll 1
   for (int jb = 0; jb < 4; jb++) {
     const int nfol = 3 - jb;   // row blocks below
     if (wave == 0) {
-      stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail);
+      stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail, pk, prev_exp);
+      if (jb == 3 && tile_exp && lane == 0) st_pub(tile_exp + k, __longlong_as_double((long long)prev_exp), true);
     } else if (wave == 4) {
       // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
     } else if (wave <= nfol || wave == 5) {

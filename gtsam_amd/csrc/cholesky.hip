@@ -74,11 +74,12 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
   }
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    // wait until workgroup 0 has released panel p of the diagonal tile (bounded: a lost release must not hang the GPU)
+    // wait until workgroup 0 has released panel p of the diagonal tile (bounded: a lost release must not hang the GPU; the bound
+    // is seconds, and running into it raises the time-out flag, which the C ABI turns into an error)
     if (tid == 0) {
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < flagbase + p + 1) {
-        if (++spins > (1 << 20)) { *fail = 1.0; break; }
+        if (++spins > (1 << 22)) { fail[1] = 1.0; break; }   // a scheduling problem, not a matrix property: fail[1] is reported as an error (SC_TIMEOUT), never as "not positive definite"
         __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -135,9 +136,10 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
 // order), the release/acquire pair is agent scope (L2 write-back / invalidate across XCDs).
 __global__ __launch_bounds__(512, 2) void k_panel128(double* __restrict__ S, int NP, int k, const int32_t* __restrict__ rows,
                                                      double* __restrict__ Xinv, double* __restrict__ fail,
-                                                     long long* __restrict__ dbg, const long long* __restrict__ epoch) {
+                                                     long long* __restrict__ dbg, const long long* __restrict__ epoch,
+                                                     const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch);
+  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch, false, false, pivot_kind, tile_exp);
   else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, epoch);
 }
 __global__ void k_bump_epoch(long long* epoch) { *epoch += 1; }
@@ -452,7 +454,8 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 // when it is needed, so it costs one barrier packet (~3 us measured) instead of a fresh signal round trip (~13 us).
 // rest(p) starts after nar(p) so that the two never share CUs (two small MFMA launches side by side double each
 // other's latency).  panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM below.
-void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail) {
+void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail,
+                     const unsigned char* pivot_kind, double* tile_exp) {
   CholStreams& g_cs = c.cs;
   TreeStreams& g_ts = c.ts;
   const int nt = NP / T;
@@ -512,7 +515,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
     hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), sp,
-                       S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase);
+                       S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
@@ -563,7 +566,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     auto panel_on = [&](hipStream_t st, int k) {
       double* Xk = Xinv + (size_t)k * T * T;
       hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), st,
-                         S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase);
+                         S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
     };
     // Issue order: round-robin over the chains that are ready, one pair of block columns at a time.  The host needs
     // ~45 us to issue a pair (9-10 API calls) and a chain executes one in ~100 us, so a single host thread can keep two

@@ -184,6 +184,8 @@ struct gtg_context {
   gt::DevBuf<double> S;                         // (NP + kTile) x NP
   gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
+  gt::DevBuf<unsigned char> pivot_kind;         // per scalar column of S: 1 / 2 = last pivot of a variable (dim >= 2 / dim 1): the rank test of
+  gt::DevBuf<double> tile_exp;                  // base/cholesky.cpp:144-157 applies there; tile_exp: exponent of every tile's last pivot (carry)
   gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words), bumped on the device
   gt::CholPlan plan;
   gt::DfPlan df;                                // the dataflow schedule (default); `plan` keeps the lists for zeroing / exchange / backward solve

@@ -27,7 +27,8 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
 // In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
 void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan);
-void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag);
+void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag,
+                     const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
 int64_t exchange_block_doubles(const gtg_context& c);                    // size of the block-granular exchange buffer
@@ -40,7 +41,8 @@ void destroy_chol_streams(gtg_context& c);
 // boolean structure over 128x128 tiles before the factorisation ((nt x nt) row-major bytes; nullptr = dense).
 void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s);
 void free_df_plan(DfPlan& df);
-void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail_flags);
+void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
+                        const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);
 
 // pcg.hip -----------------------------------------------------------------------------------------
 // Block-Jacobi PCG on the implicit Schur complement (needs launch_point_eliminate first): c.xred = S^-1 b.

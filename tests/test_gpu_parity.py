@@ -337,6 +337,71 @@ def test_reference_cholesky_literal(gpu):
     dev.close()
 
 
+def _underconstrained_literals():
+    """gtsam/base/tests/testCholesky.cpp:101-138: A = L D L^T with D1 (last pivot 1e-12: rank test), D2 (zero pivots), D3 (negative)."""
+    L = np.array([[1, 0, 0, 0, 0, 0],
+                  [1.11177808157954, 1.06204809504665, 0.507342638873381, 1.34953401829486, 1, 0],
+                  [0.155864888199928, 1.10933048588373, 0.501255576961674, 1, 0, 0],
+                  [1.12108665967793, 1.01584408366945, 1, 0, 0, 0],
+                  [0.776164062474843, 0.117617236580373, -0.0236628691347294, 0.814118199972143, 0.694309975328922, 1],
+                  [0.1197220685104, 1, 0, 0, 0, 0]])
+    d = [0.814723686393179, 0.811780089277421, 1.82596950680844, 0.240287537694585]
+    for tail in ([1.34342584865901, 1e-12], [0.0, 0.0], [-0.5, -0.6]):
+        yield L @ np.diag(d + tail) @ L.T
+
+
+def test_underconstrained_and_negative_pivot_literals(gpu):
+    """choleskyPartial's failure semantics on the device (base/cholesky.cpp:107-158): a non-positive pivot (Eigen LLT
+    NumericalIssue) and the exponent test on the last two diagonal entries of the frontal block (difference >= 12) both give
+    `false` in the reference -> GTG_INDETERMINATE here; the matrix is one frontal block, as in the reference's test."""
+    from gtsam_amd.problem import Problem
+    from oracle import ref
+    dev = gpu.DeviceGraph(Problem(var_type=np.array([0], np.int32)))
+    for A in _underconstrained_literals():
+        if ref.available():
+            assert ref.cholesky_partial(A, 6)[0] is False          # the literal's expectation, from the reference itself
+        rc, _, _ = dev.dense_cholesky(A)
+        assert rc == 1, "under-constrained / indefinite matrix accepted"
+    # the same L with a benign diagonal passes, and so does a pivot ratio just inside the bound (2^-11 in R = 2^-22 in D)
+    L = next(_underconstrained_literals())  # noqa: F841  (shape only)
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(6, 6)); A = M @ M.T + np.eye(6)
+    assert dev.dense_cholesky(A)[0] == 0
+    D = np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 2.0 ** -20])
+    assert dev.dense_cholesky(D)[0] == 0                           # exponent difference 10 < 12
+    D = np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 2.0 ** -26])
+    assert dev.dense_cholesky(D)[0] == 1                           # exponent difference 13 >= 12
+    if ref.available():
+        assert ref.cholesky_partial(np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 2.0 ** -20]), 6)[0] is True
+        assert ref.cholesky_partial(np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 2.0 ** -26]), 6)[0] is False
+    dev.close()
+
+
+def test_rank_test_fires_at_variable_ends_of_a_graph(gpu):
+    """On a graph the test applies at the last pivot of every reduced variable (the finest partition into cliques the reference's
+    junction tree can produce).  A pose graph whose last pose is constrained in 5 of its 6 directions only
+    (a between factor with one enormous sigma) is under-constrained in exactly the reference's sense: both say indeterminate at
+    small lambda, both solve it once the damping lifts the pivot."""
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import NOISE_DIAGONAL
+    from oracle import ref
+    p, v0 = D.random_pose_graph(8, 0, seed=11)
+    # replace the noise of the last chain edge (6 -> 7) by one that leaves the last translation direction free
+    weak = p.add_noise(NOISE_DIAGONAL, 6, [0.1, 0.1, 0.1, 0.3, 0.3, 1e9])
+    last = int(np.where((p.between_v1 == 6) & (p.between_v2 == 7))[0][0])
+    p.between_noise[last] = weak
+    dev = gpu.DeviceGraph(p)
+    dev.set_values(v0); dev.linearize()
+    rc_small, _ = dev.try_lambda(1e-30, False)
+    rc_big, _ = dev.try_lambda(1.0, False)
+    assert rc_small == 1 and rc_big == 0
+    if ref.available():
+        g = ref.RefGraph(p)
+        assert g.solve(v0, 1e-30, False, ordering_kind=0)[0] == 1
+        assert g.solve(v0, 1.0, False, ordering_kind=0)[0] == 0
+    dev.close()
+
+
 def test_full_size_properties(gpu):
     """BASELINE.json's full size (Ladybug-1723 shape): size-independent properties instead of an oracle run.
     (1) error(values) is reproducible bit-for-bit run to run (no FP atomics);

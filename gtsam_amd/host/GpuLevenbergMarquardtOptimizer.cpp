@@ -7,7 +7,9 @@
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/geometry/Pose2.h>
 #include <gtsam/geometry/Pose3.h>
+#include <gtsam/linear/JacobianFactor.h>
 #include <gtsam/linear/NoiseModel.h>
+#include <gtsam/linear/linearExceptions.h>
 #include <gtsam/linear/PCGSolver.h>
 #include <gtsam/linear/Preconditioner.h>
 #include <gtsam/nonlinear/PriorFactor.h>
@@ -61,6 +63,10 @@ struct GpuLevenbergMarquardtOptimizer::Impl {
   std::vector<int32_t> var_type;
   std::vector<int64_t> val_off;
   std::vector<double> packed;            // host copy of the packed values
+  std::vector<std::pair<int32_t, int64_t>> fac_map;   // factor of graph_ -> (GTG_FAC_*, index in that type's table); (-1, 0): null
+  std::vector<int64_t> dim_off;          // variable id -> offset in the tangent vector (delta)
+  bool keep_linearization = false;       // iterate(): download the records right after gtg_linearize
+  GaussianFactorGraph::shared_ptr linearization;
   bool host_values_stale = false;
   // device-side copies of the LM state while optimize() keeps Values on the GPU
   double error = 0, lambda = 0, factor = 0;
@@ -177,6 +183,8 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
     m.keys.push_back(kv.key); m.var_type.push_back(t);
     m.val_off.push_back(m.val_off.back() + (t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3));
   }
+  m.dim_off.push_back(0);
+  for (int32_t t : m.var_type) m.dim_off.push_back(m.dim_off.back() + (t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3));
   m.packed.assign(m.val_off.back(), 0.0);
   for (size_t v = 0; v < m.keys.size(); v++) {
     double* p = m.packed.data() + m.val_off[v];
@@ -194,12 +202,14 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   std::vector<int64_t> pr_off;
   std::map<const Cal3_S2*, int32_t> calib_id;
   for (const auto& f : graph_) {
-    if (!f) continue;
+    if (!f) { m.fac_map.emplace_back(-1, 0); continue; }
     if (auto s = std::dynamic_pointer_cast<SfmFactor>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_GENERAL_SFM, (int64_t)sfm_cam.size());
       sfm_cam.push_back(idOf(s->key1())); sfm_pt.push_back(idOf(s->key2()));
       sfm_z.push_back(s->measured().x()); sfm_z.push_back(s->measured().y());
       sfm_nz.push_back(nt.add(s->noiseModel(), 2));
     } else if (auto p = std::dynamic_pointer_cast<ProjFactor>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)pj_pose.size());
       if (p->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
       pj_pose.push_back(idOf(p->key1())); pj_pt.push_back(idOf(p->key2()));
       pj_z.push_back(p->measured().x()); pj_z.push_back(p->measured().y());
@@ -214,28 +224,34 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
       if (p->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*p->body_P_sensor(), sensor.data() + sensor.size() - 12); }
       else pj_sen.push_back(-1);
     } else if (auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
       bt_1.push_back(idOf(b->key1())); bt_2.push_back(idOf(b->key2()));
       bt_z.resize(bt_z.size() + 12); packPose(b->measured(), bt_z.data() + bt_z.size() - 12);
       bt_nz.push_back(nt.add(b->noiseModel(), 6));
     } else if (auto b2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f)) {
       // same table as BetweenFactor<Pose3>: the factor's type follows from its variables', (x, y, theta) in the first 3 doubles
+      m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
       bt_1.push_back(idOf(b2->key1())); bt_2.push_back(idOf(b2->key2()));
       const Pose2& z = b2->measured();
       bt_z.insert(bt_z.end(), {z.x(), z.y(), z.theta(), 0, 0, 0, 0, 0, 0, 0, 0, 0});
       bt_nz.push_back(nt.add(b2->noiseModel(), 3));
     } else if (auto q2 = std::dynamic_pointer_cast<PriorFactor<Pose2>>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
       pr_var.push_back(idOf(q2->key())); pr_off.push_back((int64_t)pr_data.size());
       pr_data.insert(pr_data.end(), {q2->prior().x(), q2->prior().y(), q2->prior().theta()});
       pr_nz.push_back(nt.add(q2->noiseModel(), 3));
     } else if (auto pp = std::dynamic_pointer_cast<PriorFactor<Pose3>>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
       pr_var.push_back(idOf(pp->key())); pr_off.push_back((int64_t)pr_data.size());
       pr_data.resize(pr_data.size() + 12); packPose(pp->prior(), pr_data.data() + pr_data.size() - 12);
       pr_nz.push_back(nt.add(pp->noiseModel(), 6));
     } else if (auto pc = std::dynamic_pointer_cast<PriorFactor<SfmCamera>>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
       pr_var.push_back(idOf(pc->key())); pr_off.push_back((int64_t)pr_data.size());
       pr_data.resize(pr_data.size() + 17); packCamera(pc->prior(), pr_data.data() + pr_data.size() - 17);
       pr_nz.push_back(nt.add(pc->noiseModel(), 9));
     } else if (auto p3 = std::dynamic_pointer_cast<PriorFactor<Point3>>(f)) {
+      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
       pr_var.push_back(idOf(p3->key())); pr_off.push_back((int64_t)pr_data.size());
       pr_data.insert(pr_data.end(), {p3->prior().x(), p3->prior().y(), p3->prior().z()});
       pr_nz.push_back(nt.add(p3->noiseModel(), 3));
@@ -382,6 +398,7 @@ void GpuLevenbergMarquardtOptimizer::iterateDevice() {
   Impl& m = *impl_;
   if (params_.verbosityLM >= LevenbergMarquardtParams::DAMPED) std::cout << "linearizing = " << std::endl;
   check(gtg_linearize(m.h), "gtg_linearize");
+  if (m.keep_linearization) m.linearization = downloadLinearization();   // iterate()'s return value: the graph linearised here
   if (m.inner == 0) {   // write initial error
     writeLogFileDevice(m.error);
     if (params_.verbosityLM == LevenbergMarquardtParams::SUMMARY)
@@ -391,9 +408,103 @@ void GpuLevenbergMarquardtOptimizer::iterateDevice() {
 }
 
 GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::iterate() {
-  iterateDevice();
+  Impl& m = *impl_;
+  m.keep_linearization = true;   // what the reference returns: `linear`, the graph linearised at the values the iteration
+  iterateDevice();               // started from (LevenbergMarquardtOptimizer.cpp:277,307)
+  m.keep_linearization = false;
   syncValuesToHost(true);   // iterate() is a public entry point: values()/error()/lambda() must be current
-  return std::make_shared<GaussianFactorGraph>();
+  GaussianFactorGraph::shared_ptr out = m.linearization;
+  m.linearization.reset();
+  return out;
+}
+
+// The device's whitened records [A1 | A2 | b] (gtg_get_jacobians) as JacobianFactors without a noise model (the records are
+// whitened and, for Robust models, re-weighted -- what NoiseModelFactor::linearize returns for unconstrained models,
+// NonlinearFactor.cpp:150-182), one per factor of graph_, in its order.
+GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::downloadLinearization() const {
+  const Impl& m = *impl_;
+  static const int64_t width[4] = {26, 20, 78, 90};
+  std::vector<double> rec[4];
+  int64_t count[4] = {0, 0, 0, 0};
+  for (const auto& tf : m.fac_map) if (tf.first >= 0) count[tf.first]++;
+  for (int t = 0; t < 4; t++) {
+    if (!count[t]) continue;
+    rec[t].resize((size_t)(count[t] * width[t]));
+    check(gtg_get_jacobians(m.h, t, rec[t].data(), (int64_t)rec[t].size()), "gtg_get_jacobians");
+  }
+  auto out = std::make_shared<GaussianFactorGraph>();
+  out->reserve(graph_.size());
+  typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> RowMat;
+  for (size_t i = 0; i < graph_.size(); i++) {
+    const auto tf = m.fac_map[i];
+    if (tf.first < 0) { out->push_back(GaussianFactor::shared_ptr()); continue; }
+    const double* r = rec[tf.first].data() + tf.second * width[tf.first];
+    const KeyVector& keys = graph_[i]->keys();
+    if (tf.first == GTG_FAC_GENERAL_SFM) {
+      out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, 2, 9)), keys[1], Matrix(Eigen::Map<const RowMat>(r + 18, 2, 3)),
+                                          Vector(Eigen::Map<const Vector>(r + 24, 2)));
+    } else if (tf.first == GTG_FAC_PROJECTION) {
+      out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, 2, 6)), keys[1], Matrix(Eigen::Map<const RowMat>(r + 12, 2, 3)),
+                                          Vector(Eigen::Map<const Vector>(r + 18, 2)));
+    } else if (tf.first == GTG_FAC_BETWEEN_POSE3) {
+      const int d = (m.var_type[m.id.at(keys[0])] == GTG_VAR_POSE2) ? 3 : 6;   // Pose2: 3x3 blocks inside the same record
+      out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, d, d)), keys[1], Matrix(Eigen::Map<const RowMat>(r + 36, d, d)),
+                                          Vector(Eigen::Map<const Vector>(r + 72, d)));
+    } else {
+      const int32_t vt = m.var_type[m.id.at(keys[0])];
+      const int d = vt == GTG_VAR_POSE3 ? 6 : vt == GTG_VAR_SFM_CAMERA ? 9 : 3;
+      out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, d, d)), Vector(Eigen::Map<const Vector>(r + 81, d)));
+    }
+  }
+  return out;
+}
+
+GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::linearize() const {
+  const Impl& m = *impl_;
+  if (m.host_values_stale) throw std::logic_error("GpuLevenbergMarquardtOptimizer::linearize: host values out of date");   // (cannot happen through the public entry points)
+  check(gtg_linearize(m.h), "gtg_linearize");
+  return downloadLinearization();
+}
+
+VectorValues GpuLevenbergMarquardtOptimizer::solve(const GaussianFactorGraph& gfg, const NonlinearOptimizerParams& params) const {
+  const Impl& m = *impl_;
+  // Is this buildDampedSystem's output for our graph (LevenbergMarquardtState.h:125-156)?  graph_.size() linear factors, then one
+  // unary JacobianFactor per variable: A = I (or diag(sqrt hessian diagonal)), b = 0, Isotropic sigma = 1 / sqrt(lambda).
+  const size_t nf = graph_.size(), nv = m.keys.size();
+  double lambda = 0.0; bool diagonal = false, recognised = gfg.size() == nf + nv && nv > 0;
+  for (size_t v = 0; recognised && v < nv; v++) {
+    auto jf = std::dynamic_pointer_cast<JacobianFactor>(gfg[nf + v]);
+    auto iso = jf ? std::dynamic_pointer_cast<noiseModel::Isotropic>(jf->get_model()) : nullptr;
+    if (!jf || jf->size() != 1 || !iso || jf->getb().cwiseAbs().maxCoeff() != 0.0) { recognised = false; break; }
+    const double l = 1.0 / (iso->sigma() * iso->sigma());
+    if (v == 0) lambda = l; else if (std::abs(l - lambda) > 1e-12 * lambda) { recognised = false; break; }
+    const Matrix A = jf->getA(jf->begin());
+    if (!A.isDiagonal()) { recognised = false; break; }
+    if ((A.diagonal().array() != 1.0).any()) diagonal = true;
+  }
+  if (!recognised) return LevenbergMarquardtOptimizer::solve(gfg, params);
+  const auto* lm = dynamic_cast<const LevenbergMarquardtParams*>(&params);
+  const double dmin = lm ? lm->minDiagonal : params_.minDiagonal, dmax = lm ? lm->maxDiagonal : params_.maxDiagonal;
+  check(gtg_linearize(m.h), "gtg_linearize");   // the device's own linearisation at values(): what `gfg` was built from
+  double out[4];
+  int rc;
+  if (params.isIterative()) {
+    auto pcg = std::dynamic_pointer_cast<PCGSolverParameters>(params.iterativeParams);
+    if (!pcg) throw std::runtime_error("GpuLevenbergMarquardtOptimizer::solve: only PCGSolverParameters are handled by the GPU path");
+    const double cg[4] = {(double)pcg->maxIterations, (double)pcg->minIterations, pcg->epsilon_rel, pcg->epsilon_abs};
+    int32_t its = 0;
+    rc = gtg_try_lambda_pcg(m.h, lambda, diagonal, dmin, dmax, cg, out, &its);
+  } else {
+    rc = gtg_try_lambda(m.h, lambda, diagonal, dmin, dmax, out);
+  }
+  check(rc, "gtg_try_lambda");
+  if (rc == GTG_INDETERMINATE) throw IndeterminantLinearSystemException(m.keys.empty() ? Key(0) : m.keys[0]);
+  std::vector<double> delta((size_t)m.dim_off.back());
+  check(gtg_get_delta(m.h, delta.data(), (int64_t)delta.size()), "gtg_get_delta");
+  VectorValues x;
+  for (size_t v = 0; v < nv; v++)
+    x.insert(m.keys[v], Vector(Eigen::Map<const Vector>(delta.data() + m.dim_off[v], m.dim_off[v + 1] - m.dim_off[v])));
+  return x;
 }
 
 const Values& GpuLevenbergMarquardtOptimizer::optimize() {
@@ -429,6 +540,8 @@ const Values& GpuLevenbergMarquardtOptimizer::optimize() {
   syncValuesToHost(true);
   return values();
 }
+
+void GpuLevenbergMarquardtOptimizer::enablePhaseTiming(bool on) { gtg_enable_timing(impl_->h, on ? 1 : 0); }
 
 std::vector<double> GpuLevenbergMarquardtOptimizer::phaseMilliseconds() const {
   std::vector<double> ms(GTG_PH_COUNT, 0.0);

@@ -39,14 +39,29 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   ~GpuLevenbergMarquardtOptimizer() override;
 
   /// One LM iteration on the GPU; state_ (values, error, lambda, counters) is updated exactly like the
-  /// reference does.  The linearised graph is never materialised on the host: returns an empty graph.
+  /// reference does, and like the reference (LevenbergMarquardtOptimizer.cpp:273-308) it returns the graph it linearised at
+  /// the values it started from: the device's whitened records [A1 A2 b], downloaded and wrapped as JacobianFactors in the
+  /// order of the nonlinear graph.  (optimize() does not pay for that: its iterations stay on the device.)
   gtsam::GaussianFactorGraph::shared_ptr iterate() override;
+
+  /// A/B testing of the two halves of the path against the CPU (LevenbergMarquardtOptimizer.h:112-113,
+  /// NonlinearOptimizer.h:129-130; precedent tests/testNonlinearOptimizer.cpp:507-551):
+  /// linearize(): the DEVICE's linearisation of graph_ at values(), as a GaussianFactorGraph -- compare with
+  /// gtsam::LevenbergMarquardtOptimizer::linearize() / graph.linearize(values).
+  gtsam::GaussianFactorGraph::shared_ptr linearize() const override;
+  /// solve(): when `gfg` is the damped system LevenbergMarquardtState::buildDampedSystem makes of this graph's linearisation
+  /// at values() (its factors followed by one damping factor per variable), lambda and the damping mode are read off the
+  /// damping factors and the system is solved on the DEVICE (Schur complement + tile Cholesky, or PCG when params say
+  /// Iterative); any other graph goes to the reference's CPU solve.  Throws IndeterminantLinearSystemException where the
+  /// reference would.
+  gtsam::VectorValues solve(const gtsam::GaussianFactorGraph& gfg, const gtsam::NonlinearOptimizerParams& params) const override;
 
   /// defaultOptimize() (nonlinear/NonlinearOptimizer.cpp:62-117) with the Values kept on the device
   /// between iterations and synchronised to the host once at the end (and for the iteration hook).
   const gtsam::Values& optimize() override;
 
-  /// per-phase device timings (ms, accumulated) -- names via gtg_phase_name()
+  /// per-phase device timings (ms, accumulated since enablePhaseTiming(true)) -- names via gtg_phase_name()
+  void enablePhaseTiming(bool on);
   std::vector<double> phaseMilliseconds() const;
 
  private:
@@ -57,6 +72,7 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   void iterateDevice();              // LevenbergMarquardtOptimizer::iterate restated (logFile rows, SUMMARY header)
   void writeLogFileDevice(double currentError);
   void syncValuesToHost(bool force);
+  gtsam::GaussianFactorGraph::shared_ptr downloadLinearization() const;   // the device's current records as JacobianFactors
 };
 
 }  // namespace gtsam_amd

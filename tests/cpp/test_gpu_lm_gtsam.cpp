@@ -12,6 +12,7 @@
 #include <gtsam/linear/PCGSolver.h>
 #include <gtsam/linear/Preconditioner.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
+#include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
@@ -19,6 +20,7 @@
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <algorithm>
 #include <array>
 #include <random>
 #include <sstream>
@@ -50,8 +52,67 @@ static LevenbergMarquardtParams iterativeParams(LevenbergMarquardtParams params)
   return params;
 }
 
+// A/B of the two halves of the path through the subclassing boundary (LevenbergMarquardtOptimizer.h:112-113, NonlinearOptimizer.h:
+// 129-130; precedent tests/testNonlinearOptimizer.cpp:507-551): the device's linearize() against graph.linearize(), the device's
+// solve() of the reference's own damped system against the reference's solve(), both damping modes; iterate()'s return value.
+static double abTest(const char* name, const NonlinearFactorGraph& graph, const Values& initial, LevenbergMarquardtParams params) {
+  params.linearSolverType = NonlinearOptimizerParams::MULTIFRONTAL_CHOLESKY; params.iterativeParams.reset();
+  gtsam_amd::GpuLevenbergMarquardtOptimizer gpu(graph, initial, params);
+  LevenbergMarquardtOptimizer cpu(graph, initial, params);
+  const GaussianFactorGraph::shared_ptr lc = graph.linearize(initial), lg = gpu.linearize();
+  EXPECT(lc->size() == lg->size(), "%s linearize(): %zu vs %zu factors", name, lc->size(), lg->size());
+  double worstJ = 0;
+  for (size_t i = 0; i < std::min(lc->size(), lg->size()); i++) {
+    const Matrix a = lc->at(i)->augmentedJacobian(), b = lg->at(i)->augmentedJacobian();
+    if (a.rows() != b.rows() || a.cols() != b.cols() || lc->at(i)->keys() != lg->at(i)->keys()) { EXPECT(false, "%s linearize(): factor %zu shape / keys", name, i); continue; }
+    worstJ = std::max(worstJ, (a - b).cwiseAbs().maxCoeff() / std::max(1.0, a.cwiseAbs().maxCoeff()));
+  }
+  EXPECT(worstJ <= 1e-9, "%s linearize(): Jacobians differ by %.3g", name, worstJ);
+  // How well is delta determined at all?  The reference answers for itself: the same damped system solved with another
+  // (equally valid) elimination ordering differs from its first answer by `self` -- 1e-13 on the pose graphs, 1e-5 on the
+  // gauge-deficient BAL graph (priors on one camera and one point only: the damped system is ill-conditioned and the step has
+  // nearly flat directions).  The device must agree to the larger of 1e-7 and 10 x self, and reach the same quadratic cost.
+  double worstD = 0, self = 0, worstCost = 0;
+  for (int diag = 0; diag < 2; diag++) {
+    const double lambda = 1e-2;
+    internal::LevenbergMarquardtState st(initial, graph.error(initial), lambda, 10.0);
+    GaussianFactorGraph damped;
+    if (diag) {
+      VectorValues sq = lc->hessianDiagonal();
+      for (auto& kv : sq) kv.second = kv.second.cwiseMax(params.minDiagonal).cwiseMin(params.maxDiagonal).cwiseSqrt();
+      damped = st.buildDampedSystem(*lc, sq);
+    } else {
+      damped = st.buildDampedSystem(*lc);
+    }
+    LevenbergMarquardtParams pd = params; pd.diagonalDamping = diag;
+    const VectorValues xc = cpu.solve(damped, pd), xg = gpu.solve(damped, pd);
+    LevenbergMarquardtParams po = pd;
+    Ordering other = pd.ordering ? *pd.ordering : Ordering::Colamd(damped);
+    std::reverse(other.begin(), other.end());
+    po.ordering = other;
+    const VectorValues xo = cpu.solve(damped, po);
+    double scale = 0; for (const auto& kv : xc) scale = std::max(scale, kv.second.cwiseAbs().maxCoeff());
+    for (const auto& kv : xc) {
+      worstD = std::max(worstD, (kv.second - xg.at(kv.first)).cwiseAbs().maxCoeff() / std::max(scale, 1e-300));
+      self = std::max(self, (kv.second - xo.at(kv.first)).cwiseAbs().maxCoeff() / std::max(scale, 1e-300));
+    }
+    worstCost = std::max(worstCost, std::abs(damped.error(xg) - damped.error(xc)) / std::max(std::abs(damped.error(xc)), 1e-300));
+  }
+  EXPECT(worstD <= std::max(1e-7, 10.0 * self), "%s solve(): delta differs by %.3g (the reference from itself under another ordering: %.3g)", name, worstD, self);
+  EXPECT(worstCost <= 1e-8, "%s solve(): quadratic cost at the device's delta differs by %.3g", name, worstCost);
+  const GaussianFactorGraph::shared_ptr li = gpu.iterate();   // the linearisation the iteration started from
+  double worstI = 0;
+  EXPECT(li && li->size() == lc->size(), "%s iterate(): returned graph", name);
+  for (size_t i = 0; li && i < std::min(lc->size(), li->size()); i++)
+    worstI = std::max(worstI, (lc->at(i)->augmentedJacobian() - li->at(i)->augmentedJacobian()).cwiseAbs().maxCoeff() / std::max(1.0, lc->at(i)->augmentedJacobian().cwiseAbs().maxCoeff()));
+  EXPECT(worstI <= 1e-9, "%s iterate(): returned linearisation differs by %.3g", name, worstI);
+  std::printf("%-22s A/B: linearize() %.2g, solve() %.2g (reference vs itself %.2g, cost %.2g), iterate() graph %.2g\n", name, worstJ, worstD, self, worstCost, worstI);
+  return std::max(worstD, self);
+}
+
 static void compare(const char* name, const NonlinearFactorGraph& graph, const Values& initial, const LevenbergMarquardtParams& params,
                     double tol) {
+  const double sensitivity = abTest(name, graph, initial, params);   // of one damped solve on this graph (direct solvers)
   auto t0 = std::chrono::high_resolution_clock::now();
   LevenbergMarquardtOptimizer cpu(graph, initial, params);
   const Values rc = cpu.optimize();
@@ -90,15 +151,38 @@ static void compare(const char* name, const NonlinearFactorGraph& graph, const V
   lp.logFile = base + "_gpu.csv"; std::remove(lp.logFile.c_str());
   { gtsam_amd::GpuLevenbergMarquardtOptimizer o(graph, initial, lp); o.optimize(); }
   const auto rowsGpu = logRows(lp.logFile); std::remove(lp.logFile.c_str());
+  // How far apart may two CORRECT implementations be on an intermediate row?  The reference answers for itself: the same
+  // optimisation with another (equally valid) elimination ordering -- only the rounding of the solves changes.  On well-
+  // conditioned graphs its rows agree to the 6 digits the log prints; on the gauge-deficient BAL graph above (priors on one
+  // camera and one point only) the reference's own two runs drift apart by up to ~1e-3 in the intermediate errors while ending
+  // at the same minimum: rounding differences of the damped solves are amplified by the conditioning and compounded by the
+  // lambda policy.  The device must stay within the larger of 1e-6 (the log's precision), 3x the reference's own drift, and
+  // 50x the sensitivity of a single damped solve measured in the A/B test (the reference's drift is zero by construction when
+  // the solver is iterative: an ordering does not change a CG run).
+  LevenbergMarquardtParams lp2 = params;
+  Ordering other = params.ordering ? *params.ordering : Ordering::Colamd(graph);
+  std::reverse(other.begin(), other.end());
+  lp2.ordering = other;
+  lp2.logFile = base + "_cpu2.csv"; std::remove(lp2.logFile.c_str());
+  { LevenbergMarquardtOptimizer o(graph, initial, lp2); o.optimize(); }
+  const auto rowsCpu2 = logRows(lp2.logFile); std::remove(lp2.logFile.c_str());
+  double drift = 0, driftL = 0, worst = 0, worstL = 0;
+  for (size_t i = 0; i < std::min(rowsCpu.size(), rowsCpu2.size()); i++) {
+    drift = std::max(drift, std::abs(rowsCpu[i][2] - rowsCpu2[i][2]) / std::max(std::abs(rowsCpu[i][2]), 1e-300));
+    driftL = std::max(driftL, std::abs(rowsCpu[i][3] - rowsCpu2[i][3]) / std::max(std::abs(rowsCpu[i][3]), 1e-300));
+  }
+  // ... and no tighter than what ONE damped solve is determined to on this graph (A/B above), compounded over the run
+  const double tolE = std::max({1e-6, 3.0 * drift, 50.0 * sensitivity}), tolL = std::max({1e-5, 3.0 * driftL, 500.0 * sensitivity});
   EXPECT(!rowsCpu.empty() && rowsCpu.size() == rowsGpu.size(), "logFile rows %zu vs %zu", rowsCpu.size(), rowsGpu.size());
   for (size_t i = 0; i < std::min(rowsCpu.size(), rowsGpu.size()); i++) {
     EXPECT(rowsCpu[i][0] == rowsGpu[i][0] && rowsCpu[i][4] == rowsGpu[i][4], "logFile row %zu: counters", i);
-    // the intermediate iterates of the noisy, slowly converging BAL case differ at the 1e-3 level between the two
-    // implementations (measured: 4.5e-4; both end at the same minimum, checked above to `tol`), so the rows are compared
-    // at the precision that is stable along the whole trajectory; the counters must be identical
-    EXPECT(std::abs(rowsCpu[i][2] - rowsGpu[i][2]) <= 1e-2 * std::abs(rowsCpu[i][2]) + 1e-12, "logFile row %zu: error %g vs %g", i, rowsCpu[i][2], rowsGpu[i][2]);
-    EXPECT(std::abs(rowsCpu[i][3] - rowsGpu[i][3]) <= 5e-2 * std::abs(rowsCpu[i][3]), "logFile row %zu: lambda %g vs %g", i, rowsCpu[i][3], rowsGpu[i][3]);
+    worst = std::max(worst, std::abs(rowsCpu[i][2] - rowsGpu[i][2]) / std::max(std::abs(rowsCpu[i][2]), 1e-300));
+    worstL = std::max(worstL, std::abs(rowsCpu[i][3] - rowsGpu[i][3]) / std::max(std::abs(rowsCpu[i][3]), 1e-300));
+    EXPECT(std::abs(rowsCpu[i][2] - rowsGpu[i][2]) <= tolE * std::abs(rowsCpu[i][2]) + 1e-12, "logFile row %zu: error %g vs %g (tolerance %.2g)", i, rowsCpu[i][2], rowsGpu[i][2], tolE);
+    EXPECT(std::abs(rowsCpu[i][3] - rowsGpu[i][3]) <= tolL * std::abs(rowsCpu[i][3]), "logFile row %zu: lambda %g vs %g (tolerance %.2g)", i, rowsCpu[i][3], rowsGpu[i][3], tolL);
   }
+  std::printf("%-22s logFile rows: device vs reference %.2g (lambda %.2g); reference vs itself under another ordering %.2g (lambda %.2g)\n",
+              name, worst, worstL, drift, driftL);
 }
 
 int main() {

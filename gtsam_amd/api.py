@@ -366,7 +366,16 @@ class LevenbergMarquardtOptimizer:
                  device: int = 0):
         self._problem, v0, self._keys = extract(graph, initialValues)
         self._types = [initialValues.at(k) for k in self._keys]
-        self._opt = DeviceLevenbergMarquardt(self._problem, v0, params, device=device)
+        # LevenbergMarquardtParams::setOrdering: the landmarks are always eliminated first on the device (the Schur ordering);
+        # the order of the remaining variables is honoured (gtg_set_reduced_ordering), landmark keys in it are dropped
+        reduced = None
+        ordering = getattr(params, "ordering", None) if params is not None else None
+        if ordering is not None:
+            ids = {k: i for i, k in enumerate(self._keys)}
+            reduced = [ids[k] for k in ordering if k in ids and self._problem.var_type[ids[k]] != 2]
+            if len(reduced) != int((self._problem.var_type != 2).sum()):
+                raise ValueError("LevenbergMarquardtParams.ordering must contain every non-landmark key exactly once")
+        self._opt = DeviceLevenbergMarquardt(self._problem, v0, params, device=device, reduced_ordering=reduced)
 
     def optimize(self) -> Values:
         self._opt.optimize()

@@ -658,8 +658,8 @@ void analyze(gtg_context& c) {
   }
   c.xred.alloc(NP);
   c.partials.alloc(2 * 2048);
-  c.scalars.alloc(SC_COUNT);
-  check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * SC_COUNT, s), "memset");
+  c.scalars.alloc(2 * SC_COUNT);   // [SC_COUNT, 2 SC_COUNT): the copy the sharded exchange sums (read_scalars)
+  check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 2 * SC_COUNT, s), "memset");
   check_hip(hipMemsetAsync(c.hdiag_red.p, 0, sizeof(double) * NP, s), "memset");
   check_hip(hipMemsetAsync(c.xred.p, 0, sizeof(double) * NP, s), "memset");
   check_hip(hipMemsetAsync(c.delta_lm.p, 0, sizeof(double) * c.delta_lm.n, s), "memset");

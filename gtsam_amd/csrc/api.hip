@@ -74,9 +74,27 @@ static std::mutex& df_device_lock(int device) {
   return *p;
 }
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (a torch or multi-GPU host
+// keeps its own notion of "current device").
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) check_hip(hipSetDevice(dev), "hipSetDevice"); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Sharded: the scalars are partial sums and get all-reduced -- a COPY of them (second half of the buffer), so that slots a call
+// does not rewrite are not multiplied by the number of shards on every call (they would overflow to inf after a few hundred).
 static void read_scalars(gtg_context& c) {
-  exchange(c, c.scalars.p, SC_COUNT);
-  check_hip(hipMemcpyAsync(c.h_scalars, c.scalars.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, c.stream), "D2H");
+  const double* src = c.scalars.p;
+  if (c.n_shards > 1) {
+    check_hip(hipMemcpyAsync(c.scalars.p + SC_COUNT, c.scalars.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToDevice, c.stream), "D2D");
+    exchange(c, c.scalars.p + SC_COUNT, SC_COUNT);
+    src = c.scalars.p + SC_COUNT;
+  }
+  check_hip(hipMemcpyAsync(c.h_scalars, src, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, c.stream), "D2H");
   check_hip(hipStreamSynchronize(c.stream), "sync");
   c.h_scalars[SC_DELTA_SQ] /= c.n_shards;  // identical on every shard, summed by the exchange
 }
@@ -173,7 +191,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   GTG_TRY
   if (!c || !p) throw std::invalid_argument("null argument");
   if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::invalid_argument("bad shard / n_shards");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   StageClock clk;
   hipStream_t s = c->stream;
   c->shard = shard; c->n_shards = n_shards;
@@ -336,7 +354,7 @@ int64_t gtg_reduced_dim(gtg_handle c) { return c ? c->n_red : -1; }
 int gtg_set_values(gtg_handle c, const double* packed, int64_t n) {
   GTG_TRY
   if (!c || !c->uploaded || n != c->val_size) throw std::invalid_argument("gtg_set_values: wrong size or no problem uploaded");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemcpyAsync(c->values.p, packed, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "H2D");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   c->linearized = false; c->have_trial = false;
@@ -347,7 +365,7 @@ int gtg_set_values(gtg_handle c, const double* packed, int64_t n) {
 static int get_buf(gtg_handle c, const double* dev, int64_t have, double* out, int64_t n) {
   GTG_TRY
   if (!c || !c->uploaded || n != have) throw std::invalid_argument("getter: wrong size or no problem uploaded");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemcpyAsync(out, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   return GTG_OK;
@@ -360,7 +378,7 @@ int gtg_get_delta(gtg_handle c, double* d, int64_t n) { return get_buf(c, c ? c-
 int gtg_error(gtg_handle c, double* error) {
   GTG_TRY
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});
@@ -372,7 +390,7 @@ int gtg_error(gtg_handle c, double* error) {
 int gtg_linearize(gtg_handle c) {
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_linearize(*c); }
   { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c); }
   exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
@@ -387,7 +405,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   GTG_TRY
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda: call gtg_linearize first");
   if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
@@ -446,7 +464,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
   GTG_TRY
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda_pcg: call gtg_linearize first");
   if (!(lambda > 0.0) || !cg) throw std::invalid_argument("gtg_try_lambda_pcg: lambda must be > 0, cg = {max, min, eps_rel, eps_abs}");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   double g0 = 0.0, g1 = 0.0;
@@ -476,6 +494,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
 int gtg_accept(gtg_handle c) {
   GTG_TRY
   if (!c || !c->have_trial) throw std::invalid_argument("gtg_accept: no trial values (call gtg_try_lambda)");
+  DeviceGuard on_device(c->device);
   std::swap(c->values.p, c->trial.p);
   c->linearized = false; c->have_trial = false;
   return GTG_OK;
@@ -485,6 +504,7 @@ int gtg_accept(gtg_handle c) {
 int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
   GTG_TRY
   if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_gradient: linearize first / wrong size");
+  DeviceGuard on_device(c->device);
   std::vector<double> gr(9 * (size_t)std::max(c->n_red_vars, 1)), gp(3 * (size_t)std::max(c->n_lm, 1));
   check_hip(hipMemcpy(gr.data(), c->gred0.p, sizeof(double) * gr.size(), hipMemcpyDeviceToHost), "D2H");
   check_hip(hipMemcpy(gp.data(), c->gp.p, sizeof(double) * gp.size(), hipMemcpyDeviceToHost), "D2H");
@@ -500,6 +520,7 @@ int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
 int gtg_get_hessian_diagonal(gtg_handle c, double* out, int64_t n) {
   GTG_TRY
   if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_hessian_diagonal: linearize first / wrong size");
+  DeviceGuard on_device(c->device);
   std::vector<double> hd(c->NP), V(9 * (size_t)std::max(c->n_lm, 1));
   check_hip(hipMemcpy(hd.data(), c->hdiag_red.p, sizeof(double) * hd.size(), hipMemcpyDeviceToHost), "D2H");
   check_hip(hipMemcpy(V.data(), c->V.p, sizeof(double) * V.size(), hipMemcpyDeviceToHost), "D2H");
@@ -515,6 +536,7 @@ int gtg_get_hessian_diagonal(gtg_handle c, double* out, int64_t n) {
 int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
   GTG_TRY
   if (!c || !c->linearized) throw std::invalid_argument("gtg_get_jacobians: linearize first");
+  DeviceGuard on_device(c->device);
   const double* src; int64_t cnt;
   switch (type) {
     case GTG_FAC_GENERAL_SFM: src = c->f.sfm_J.p; cnt = c->f.n_sfm * kSfmRec; break;
@@ -532,6 +554,7 @@ int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
 int gtg_get_reduced_matrix(gtg_handle c, double* S, int64_t n_elems) {
   GTG_TRY
   if (!c || !c->uploaded || n_elems != c->n_red * c->n_red) throw std::invalid_argument("gtg_get_reduced_matrix: wrong size");
+  DeviceGuard on_device(c->device);
   // S carries alignment gaps (identity rows) between the nested-dissection parts: copy the square part and compact it
   const int64_t n = c->n_red, NP = c->NP;
   std::vector<double> full((size_t)NP * NP);
@@ -572,7 +595,7 @@ double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
 // debug only (not in the public header): ms per K=256 trailing update over an m x m tile grid, with ablations
 double gtg_debug_syrk_ms(gtg_handle c, int m, int abl, int reps) {
   try {
-    check_hip(hipSetDevice(c->device), "hipSetDevice");
+    DeviceGuard on_device(c->device);
     const int NP = (m + 2) * kTile;
     DevBuf<double> S; S.alloc((size_t)NP * NP);
     check_hip(hipMemset(S.p, 0, sizeof(double) * S.n), "memset");
@@ -610,7 +633,7 @@ int gtg_debug_plan_lists(gtg_handle c, int32_t* rows, int32_t* pairs, int32_t* b
                          int64_t* per_tile, int64_t* per_pair, int32_t* pair_part, int32_t* part_parent) {
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_debug_plan_lists: no problem uploaded");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   const CholPlan& pl = c->plan;
   auto down = [&](int32_t* dst, const DevBuf<int32_t>& b, size_t n) { if (dst && n) check_hip(hipMemcpy(dst, b.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost), "D2H"); };
   down(rows, pl.rows, pl.rows.n); down(pairs, pl.pairs, pl.pairs.n); down(bcols, pl.bcols, pl.bcols.n);
@@ -641,7 +664,7 @@ int gtg_debug_df_plan(gtg_handle c, int64_t sizes[4], int32_t* tasks, int32_t* k
 int gtg_debug_df_trace(gtg_handle c, int64_t* out, int64_t n) {
   GTG_TRY
   if (!c || !c->uploaded || !out || !c->df.trace.p || n != (int64_t)c->df.trace.n) throw std::invalid_argument("gtg_debug_df_trace: no trace (GTG_DF_TRACE=1 at upload) or wrong size");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemcpy(out, c->df.trace.p, sizeof(long long) * n, hipMemcpyDeviceToHost), "D2H");
   return GTG_OK;
   GTG_CATCH
@@ -650,7 +673,7 @@ int gtg_debug_df_trace(gtg_handle c, int64_t* out, int64_t n) {
 int gtg_debug_df_ctrl(gtg_handle c, int32_t out[16]) {
   GTG_TRY
   if (!c || !c->uploaded || !out || !c->df.ctrl.p) throw std::invalid_argument("gtg_debug_df_ctrl: no dataflow schedule");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   check_hip(hipMemcpy(out, c->df.ctrl.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost), "D2H");
   return GTG_OK;
   GTG_CATCH
@@ -659,7 +682,7 @@ int gtg_debug_df_ctrl(gtg_handle c, int32_t out[16]) {
 int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   GTG_TRY
   if (!c || !A || n < 1) throw std::invalid_argument("gtg_dense_cholesky_host: bad arguments");
-  check_hip(hipSetDevice(c->device), "hipSetDevice");
+  DeviceGuard on_device(c->device);
   const int NP = (n + kTile - 1) / kTile * kTile;
   DevBuf<double> S, Dinv, x, fail;
   S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(2);

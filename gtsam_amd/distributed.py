@@ -34,11 +34,18 @@ def make_allreduce(group=None):
             t = torch.from_numpy(np.frombuffer(buf, dtype=np.float64))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return
-        # the library launched its kernels on its own stream: make the collective wait for them
-        torch.cuda.synchronize()
+        # Stream-ordered, no host round trip: the library hands over the stream its kernels are on; the collective is
+        # enqueued with that stream current, so RCCL's stream waits for what is queued on it and the stream waits for the
+        # collective (c10d's stream semantics) -- the library's next kernels follow in order.  (Four exchanges per lambda
+        # try: two device-wide synchronisations around each were 8 host round trips on the critical path.)
         t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        torch.cuda.synchronize()
+        if stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            torch.cuda.synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize()
 
     return fn
 

@@ -179,8 +179,42 @@ def _gaussian3_to_noise(M, covariance):
     return NOISE_GAUSSIAN, out
 
 
-def read_2d(path):
-    """load2D (slam/dataset.cpp:179-330, defaults: maxIndex 0, smart noise, NoiseFormatAUTO, no kernel): VERTEX2 /
+NOISE_FORMAT_G2O, NOISE_FORMAT_TORO, NOISE_FORMAT_GRAPH, NOISE_FORMAT_COV, NOISE_FORMAT_AUTO = "G2O", "TORO", "GRAPH", "COV", "AUTO"
+
+
+def _noise_matrix3(v, noise_format):
+    """createNoiseModel's matrix (slam/dataset.cpp:215-262): the 6 numbers of an edge line -> (3x3 matrix, is_covariance).
+    G2O / COV: upper-triangular order [v0 v1 v2; . v3 v4; . . v5]; TORO / GRAPH: [v0 v1 v4; . v2 v5; . . v3].
+    G2O and TORO store the INFORMATION matrix, GRAPH and COV the covariance.  AUTO guesses GRAPH or COV from the zero pattern."""
+    if noise_format == NOISE_FORMAT_AUTO:
+        if v[0] != 0 and v[1] == 0 and v[2] != 0 and v[3] != 0 and v[4] == 0 and v[5] == 0:
+            noise_format = NOISE_FORMAT_GRAPH
+        elif v[0] != 0 and v[1] == 0 and v[2] == 0 and v[3] != 0 and v[4] == 0 and v[5] != 0:
+            noise_format = NOISE_FORMAT_COV
+        else:
+            raise ValueError("load2D: unrecognized covariance matrix format in dataset file. Please specify the noise format.")
+    if noise_format in (NOISE_FORMAT_G2O, NOISE_FORMAT_COV):
+        if v[0] == 0 or v[3] == 0 or v[5] == 0:
+            raise ValueError("load2D::readNoiseModel looks like this is not G2O matrix order")
+        M = np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])
+    elif noise_format in (NOISE_FORMAT_TORO, NOISE_FORMAT_GRAPH):
+        if v[0] == 0 or v[2] == 0 or v[3] == 0:
+            raise ValueError("load2D::readNoiseModel looks like this is not TORO matrix order")
+        M = np.array([[v[0], v[1], v[4]], [v[1], v[2], v[5]], [v[4], v[5], v[3]]])
+    else:
+        raise ValueError("load2D: invalid noise format")
+    return M, noise_format in (NOISE_FORMAT_GRAPH, NOISE_FORMAT_COV)
+
+
+def read_g2o(path, is_3d=False):
+    """readG2o (slam/dataset.cpp:621-633): a 3-D file goes to load3D, a 2-D file to load2D with NoiseFormatG2O -- the six
+    numbers of an EDGE_SE2 line are the upper triangle of the INFORMATION matrix (what write_g2o writes)."""
+    return read_g2o3d(path) if is_3d else read_2d(path, noise_format=NOISE_FORMAT_G2O)
+
+
+def read_2d(path, noise_format=NOISE_FORMAT_AUTO):
+    """load2D (slam/dataset.cpp:179-330, defaults: maxIndex 0, smart noise, NoiseFormatAUTO, no kernel; `noise_format` =
+    load2D's parameter of that name: "AUTO" | "G2O" | "TORO" | "GRAPH" | "COV"): VERTEX2 /
     VERTEX_SE2 / VERTEX lines -> initial Pose2 (x, y, theta); EDGE2 / EDGE / EDGE_SE2 / ODOMETRY lines ->
     BetweenFactor<Pose2> with the 6 noise numbers interpreted by their zero pattern (dataset.cpp:218-232): GRAPH order
     (covariance, [v0 v1 v4; v1 v2 v5; v4 v5 v3]) or COV order (covariance, [v0 v1 v2; v1 v3 v4; v2 v4 v5]).
@@ -191,20 +225,17 @@ def read_2d(path):
     lines = [line.split() for line in open(path)]
     for t in lines:
         if t and t[0] in ("VERTEX2", "VERTEX_SE2", "VERTEX"):
-            poses.setdefault(int(t[1]), (float(t[2]), float(t[3]), math.cos(float(t[4])), math.sin(float(t[4]))))
+            if int(t[1]) in poses:     # Values::insert throws ValuesKeyAlreadyExists (nonlinear/Values.cpp:140-145)
+                raise ValueError(f"load2D: vertex {int(t[1])} appears twice (ValuesKeyAlreadyExists in the reference)")
+            poses[int(t[1])] = (float(t[2]), float(t[3]), math.cos(float(t[4])), math.sin(float(t[4])))
     for t in lines:
         if not t:
             continue
         tag = t[0]
         if tag in ("EDGE2", "EDGE", "EDGE_SE2", "ODOMETRY"):
             v = [float(a) for a in t[6:12]]
-            if v[0] != 0 and v[1] == 0 and v[2] != 0 and v[3] != 0 and v[4] == 0 and v[5] == 0:
-                M = np.array([[v[0], v[1], v[4]], [v[1], v[2], v[5]], [v[4], v[5], v[3]]])          # NoiseFormatGRAPH
-            elif v[0] != 0 and v[1] == 0 and v[2] == 0 and v[3] != 0 and v[4] == 0 and v[5] != 0:
-                M = np.array([[v[0], v[1], v[2]], [v[1], v[3], v[4]], [v[2], v[4], v[5]]])          # NoiseFormatCOV
-            else:
-                raise ValueError("load2D: unrecognized covariance matrix format in dataset file")
-            kind, params = _gaussian3_to_noise(M, covariance=True)
+            M, is_cov = _noise_matrix3(v, noise_format)
+            kind, params = _gaussian3_to_noise(M, covariance=is_cov)
             k1, k2 = int(t[1]), int(t[2])
             zx, zy, zt = float(t[3]), float(t[4]), float(t[5])
             v1.append(k1); v2.append(k2); zs.append([zx, zy, zt])

@@ -40,7 +40,8 @@ def check_convergence(relative_error_tol, absolute_error_tol, error_tol, current
     absolute_decrease = current_error - new_error
     if verb >= _VERBOSITY["ERROR"]:
         print(f"absoluteDecrease: {absolute_decrease:.12g} {'<' if absolute_decrease <= absolute_error_tol else '>='} {absolute_error_tol:g}")
-    relative_decrease = absolute_decrease / current_error if current_error != 0 else math.inf
+    with np.errstate(divide="ignore", invalid="ignore"):   # plain IEEE division, as the reference: x/0 = +-inf, 0/0 = nan
+        relative_decrease = float(np.float64(absolute_decrease) / np.float64(current_error))
     if verb >= _VERBOSITY["ERROR"]:
         print(f"relativeDecrease: {relative_decrease:.12g} {'<' if relative_decrease <= relative_error_tol else '>='} {relative_error_tol:g}")
     converged = bool((relative_error_tol and relative_decrease <= relative_error_tol) or

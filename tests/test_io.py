@@ -267,3 +267,25 @@ def test_dataset_tests_of_the_reference_restated():
     # is already in GTSAM order
     assert np.abs(R.T @ R - info).max() <= 1e-2 * 10000
     assert np.abs(o["z"][0, 9:] - [1.001367, 0.015390, 0.004948]).max() <= 1e-5
+
+
+def test_read_g2o_2d_reads_information_matrices_and_round_trips(tmp_path):
+    """readG2o on a 2-D file is load2D with NoiseFormatG2O (slam/dataset.cpp:621-633): the six numbers are the upper triangle of the
+    INFORMATION matrix.  What write_g2o writes, read_g2o reads back to the same noise; the AUTO format of load2D treats the same
+    numbers as a covariance (the reference's behaviour for .graph files) -- hence the explicit format.  Duplicate vertices raise."""
+    from gtsam_amd import io as IO
+    p = tmp_path / "t.g2o"
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 1 1 0 0.1\nEDGE_SE2 0 1 1.0 0.0 0.1 4.0 0.0 0.0 9.0 0.0 16.0\n")
+    d = IO.read_g2o(str(p))
+    assert d["noise_kind"][0] == 2 and np.allclose(d["noise"][0, :3], [0.5, 1.0 / 3.0, 0.25])     # sigmas = 1 / sqrt(information)
+    d_auto = IO.read_2d(str(p))                                                                   # AUTO -> COV: the numbers are variances
+    assert np.allclose(d_auto["noise"][0, :3], [2.0, 3.0, 4.0])
+    out = tmp_path / "w.g2o"
+    IO.write_g2o(str(out), d, d["vertex_keys"], d["vertex_poses"])
+    d2 = IO.read_g2o(str(out))
+    assert np.allclose(d2["noise"], d["noise"]) and np.allclose(d2["z"], d["z"])
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 0 1 0 0.1\n")
+    with pytest.raises(ValueError):
+        IO.read_2d(str(p))
+    with pytest.raises(ValueError):
+        IO.read_2d(str(out), noise_format="nonsense")

@@ -60,14 +60,16 @@ __global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __
   for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
     const int64_t i = ch * 64 + lane;
     if (i < n) {
-      double c[17], p[3], zz[2], rec[kSfmRec];
+      double c[17], p[3], zz[2];
       const double* cp = values + val_off[cam[i]];
       const double* pp = values + val_off[pt[i]];
       for (int k = 0; k < 17; k++) c[k] = cp[k];
       for (int k = 0; k < 3; k++) p[k] = pp[k];
       zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
-      sfm_linearize(c, p, zz, nt.ref(nz[i]), rec);
-      for (int k = 0; k < kSfmRec; k++) my[lane * IO::PITCH + k] = rec[k];
+      // the record is built in place in the wavefront's LDS image: as a local array it lived in scratch memory (the whitening
+      // loops index it at run time) and every factor cost 208 B of scratch writes + reads on top of its 208 B record --
+      // measured 512 B written per factor (rocprofv3 WRITE_SIZE), 2.46 x the algorithmic bytes
+      sfm_linearize(c, p, zz, nt.ref(nz[i]), my + lane * IO::PITCH);
     }
     const int64_t left = n - ch * 64;
     IO::store(my, J + (int64_t)kSfmRec * ch * 64, left < 64 ? (int)left : 64, lane);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
   for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
     const int64_t i = ch * 64 + lane;
     if (i < n) {
-      double T[12], p[3], zz[2], K[5], S[12], rec[kProjRec];
+      double T[12], p[3], zz[2], K[5], S[12];
       const double* tp = values + val_off[pose[i]];
       const double* pp = values + val_off[pt[i]];
       for (int k = 0; k < 12; k++) T[k] = tp[k];
@@ -97,8 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
       const int si = sensor_idx[i];
       if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
       zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
-      proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(nz[i]), rec);
-      for (int k = 0; k < kProjRec; k++) my[lane * IO::PITCH + k] = rec[k];
+      proj_linearize(T, K, si >= 0 ? S : nullptr, p, zz, nt.ref(nz[i]), my + lane * IO::PITCH);   // in place in the LDS image (see k_lin_sfm)
     }
     const int64_t left = n - ch * 64;
     IO::store(my, J + (int64_t)kProjRec * ch * 64, left < 64 ? (int)left : 64, lane);

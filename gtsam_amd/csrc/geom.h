@@ -221,7 +221,9 @@ GT_HD bool project2(const double* T, const double* pw, double* pn, double* Dpose
 // cam = pose(12), f, k1, k2, u0, v0.  Dcam 2x9 = [Dp*Dpose | Dcal], Dpoint 2x3 (row-major).
 GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* Dcam, double* Dpoint) {
   double pn[2], Dpose[12], Dpt[6];
-  if (!project2(cam, pw, pn, Dcam ? Dpose : nullptr, Dpoint ? Dpt : nullptr)) return false;
+  // (both derivative buffers or none: a conditionally selected pointer keeps the local arrays in scratch memory on the device)
+  const bool want = Dcam || Dpoint;
+  if (!(want ? project2(cam, pw, pn, Dpose, Dpt) : project2(cam, pw, pn, nullptr, nullptr))) return false;
   const double f = cam[12], k1 = cam[13], k2 = cam[14], u0 = cam[15], v0 = cam[16];
   const double x = pn[0], y = pn[1];
   const double r = x * x + y * y;
@@ -234,7 +236,7 @@ GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* 
     const double Dp[4] = {(g + axx) * f, axy * f, axy * f, (g + ayy) * f};
     if (Dcam) {
       const double rx = r * x, ry = r * y;
-      for (int j = 0; j < 6; j++) {
+      _Pragma("unroll") for (int j = 0; j < 6; j++) {   // (unrolled: Dpose stays in registers instead of scratch memory)
         Dcam[j] = Dp[0] * Dpose[j] + Dp[1] * Dpose[6 + j];
         Dcam[9 + j] = Dp[2] * Dpose[j] + Dp[3] * Dpose[6 + j];
       }
@@ -242,7 +244,7 @@ GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* 
       Dcam[15] = v; Dcam[16] = f * ry; Dcam[17] = f * r * ry;
     }
     if (Dpoint)
-      for (int j = 0; j < 3; j++) {
+      _Pragma("unroll") for (int j = 0; j < 3; j++) {
         Dpoint[j] = Dp[0] * Dpt[j] + Dp[1] * Dpt[3 + j];
         Dpoint[3 + j] = Dp[2] * Dpt[j] + Dp[3] * Dpt[3 + j];
       }
@@ -255,17 +257,18 @@ GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* 
 GT_HD bool s2_project(const double* T, const double* K, const double* pw, double* pi, double* Dpose,
                       double* Dpoint) {
   double pn[2], Dps[12], Dpt[6];
-  if (!project2(T, pw, pn, Dpose ? Dps : nullptr, Dpoint ? Dpt : nullptr)) return false;
+  const bool want = Dpose || Dpoint;
+  if (!(want ? project2(T, pw, pn, Dps, Dpt) : project2(T, pw, pn, nullptr, nullptr))) return false;
   const double fx = K[0], fy = K[1], s = K[2], u0 = K[3], v0 = K[4];
   pi[0] = fx * pn[0] + s * pn[1] + u0;
   pi[1] = fy * pn[1] + v0;
   if (Dpose)
-    for (int j = 0; j < 6; j++) {
+    _Pragma("unroll") for (int j = 0; j < 6; j++) {
       Dpose[j] = fx * Dps[j] + s * Dps[6 + j];
       Dpose[6 + j] = 0.0 * Dps[j] + fy * Dps[6 + j];
     }
   if (Dpoint)
-    for (int j = 0; j < 3; j++) {
+    _Pragma("unroll") for (int j = 0; j < 3; j++) {
       Dpoint[j] = fx * Dpt[j] + s * Dpt[3 + j];
       Dpoint[3 + j] = 0.0 * Dpt[j] + fy * Dpt[3 + j];
     }

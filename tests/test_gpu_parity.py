@@ -184,6 +184,39 @@ def test_nested_dissection_tree_schedule_is_equivalent(gpu, monkeypatch):
     assert rel(tr[:, 1], g["trace"][:, 1]) <= 1e-6
 
 
+def test_orderings_give_the_same_step(gpu, monkeypatch):
+    """The elimination order changes the fill and the schedule, never the step: a caller's ordering
+    (gtg_set_reduced_ordering, the reference's params.ordering / Ordering argument of the optimizer's constructor,
+    NonlinearOptimizerParams.h:108) -- here the reverse and a random permutation -- and the library's minimum-degree
+    alternative (GTG_ORDERING=mindegree) against the default band ordering and the reference's golden step."""
+    g = load_golden("sphere2500")
+    p, v0 = PB.sphere2500(g)
+
+    def step(**kw):
+        dev = gpu.DeviceGraph(p, **kw)
+        dev.set_values(v0)
+        dev.linearize()
+        rc, out = dev.try_lambda(1e-5, False)
+        d, fl = dev.delta().copy(), dev.cholesky_flops_block_level()
+        dev.close()
+        assert rc == 0
+        return d, out[2], fl
+
+    d0, e0, f0 = step()
+    assert rel(d0, g["solve_delta"]) <= 1e-6
+    n = 2500
+    for order in (np.arange(n - 1, -1, -1), np.random.default_rng(5).permutation(n)):
+        d, e, f = step(reduced_ordering=order.astype(np.int32))
+        assert rel(d, d0) <= 1e-7 and abs(e - e0) <= 1e-9 * abs(e0), (rel(d, d0), e, e0)
+        assert f != f0            # the order was really used: a different fill
+    monkeypatch.setenv("GTG_ORDERING", "mindegree")
+    d, e, f = step()
+    assert rel(d, d0) <= 1e-7 and abs(e - e0) <= 1e-9 * abs(e0) and f != f0
+    monkeypatch.setenv("GTG_ORDERING", "auto")
+    d, e, f = step()
+    assert rel(d, d0) <= 1e-7 and f <= f0
+
+
 @pytest.mark.parametrize("name", ["dubrovnik_sfmex", "bal_small_iso", "posegraph_small", "projection_small", "pose2_w100"])
 def test_pcg_solver_vs_oracle_and_direct(gpu, name):
     """gtg_try_lambda_pcg (block-Jacobi PCG on the implicit Schur complement) against the oracle's restatement of the

@@ -172,7 +172,7 @@ int gtg_destroy(gtg_handle c) {
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
                             &c->pair_col, &c->pair_oa, &c->pair_ob};
   for (auto* b : i32) b->free();
-  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
+  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.bwd_col_off.free(); c->plan.bwd_col_rows.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
@@ -431,7 +431,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     if (c->use_df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
     else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
   { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
-    launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p);
+    launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
     launch_back_substitute(*c);
     if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
       check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
@@ -708,14 +708,14 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   if (use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
   if (use_df) { build_df_plan(df, NP / kTile, nullptr, c->stream); launch_cholesky_df(*c, S.p, NP, df, Dinv.p, fail.p, dpk.p, dexp.p); }
   else launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p, dpk.p, dexp.p);
-  if (rhs) launch_backward_solve(*c, S.p, NP, plan, Dinv.p, x.p);
+  if (rhs) launch_backward_solve(*c, S.p, NP, plan, Dinv.p, x.p, fail.p);
   double hf2[2] = {0, 0};
   check_hip(hipMemcpyAsync(hf2, fail.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   dpk.free(); dexp.free();
-  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free();
+  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free(); plan.bwd_col_off.free(); plan.bwd_col_rows.free();
   free_df_plan(df);
   if (hf2[1] != 0.0) throw std::runtime_error("gtg_dense_cholesky_host: a dependency wait of the factorisation ran into its bound");
   return hf2[0] != 0.0 ? GTG_INDETERMINATE : GTG_OK;

@@ -30,6 +30,7 @@
 #include <stdexcept>
 #include <mutex>
 #include <set>
+#include <string>
 #include <vector>
 
 #include "chol_device.h"
@@ -354,6 +355,16 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
     for (int p = 0; p < q; p++) if (B[(size_t)q * np + p]) tiles_of(p, bcols);
     if (kt & 1) bcols.push_back(kt - 1);
     plan.bwd_cnt[kt] = (int64_t)bcols.size() - plan.bwd_off[kt];
+  }
+  {   // the same tiles by column, rows descending: what the one-launch backward sweep walks
+    std::vector<std::vector<int32_t>> by_col(nt);
+    for (int kt = nt - 1; kt >= 0; kt--)
+      for (int64_t e = plan.bwd_off[kt]; e < plan.bwd_off[kt] + plan.bwd_cnt[kt]; e++) by_col[bcols[e]].push_back(kt);
+    std::vector<int32_t> off(nt + 1, 0), list;
+    for (int jt = 0; jt < nt; jt++) { list.insert(list.end(), by_col[jt].begin(), by_col[jt].end()); off[jt + 1] = (int32_t)list.size(); }
+    if (list.empty()) list.push_back(0);
+    plan.bwd_col_off.upload(off.data(), off.size(), stream);
+    plan.bwd_col_rows.upload(list.data(), list.size(), stream);
   }
   plan.critical_pairs = np;
   if (tree) {   // longest leaf-to-root path in pairs
@@ -715,7 +726,11 @@ __device__ __forceinline__ void blk_mul(double* __restrict__ C, const double* __
   for (int u = 0; u < 4; u++) C[i * SB + c0 + u] = (accumulate ? C[i * SB + c0 + u] : 0.0) + alpha * acc[u];
 }
 
-__global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int NP, const double* __restrict__ Xinv_all) {
+// An x entry that has not been produced yet: a signalling-NaN pattern no computation yields (arithmetic quiets NaNs).
+constexpr unsigned long long kBwdUnset = 0x7FF4A5C3D2E1F00DULL;
+
+__global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int NP, const double* __restrict__ Xinv_all,
+                                                   double* __restrict__ x) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Lb = reinterpret_cast<double*>(smem_raw);   // [6] L(p,q), p > q, at p(p-1)/2 + q
   double* Xb = Lb + 6 * SB * SB;                       // [4] Linv(p,p)
@@ -724,6 +739,7 @@ __global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int N
   const int k = blockIdx.x, tid = threadIdx.x;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
   const double* Xinv = Xinv_all + (size_t)k * T * T;
+  if (x && tid < T) reinterpret_cast<unsigned long long*>(x)[k * T + tid] = kBwdUnset;   // k_bwd_sweep waits on the entries themselves
   for (int e = tid; e < 10 * 512; e += 256) {
     const int blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
     double2 v;
@@ -817,6 +833,119 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
   if (g == 0) y[j] -= ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
 }
 
+
+// k_bwd_sweep: the whole backward solve in ONE launch.  Workgroup b owns block row j = nt - 1 - b of x (left-looking):
+//   x_j = L(j,j)^-T ( y_j - sum_{i > j, (i,j) stored} L(i,j)^T x_i ),
+// taking its tiles (i,j) in descending i, the order in which the x_i appear.  Dependencies travel through x itself: k_inv_tiles
+// fills x with kBwdUnset, a producer stores its 128 entries write-through (aligned 8-byte stores: each entry is either unset or
+// final), and a consumer's first wavefront polls the 128 entries it needs until none is unset -- one memory round trip per
+// step of the chain instead of flag-then-data.  A workgroup only ever waits for workgroups with a smaller blockIdx, which the
+// dispatcher started before it, so the sweep cannot deadlock however many workgroups are resident; a wait that runs into its
+// bound raises fail[1] (reported as an error, never as numbers).  The tile of the NEXT dependency is already in registers when
+// a wait ends (two register buffers), L(j,j)^-1 sits in LDS from the start: the serial chain x_{j+1} -> x_j costs one poll,
+// two 128x128 mat-vecs out of registers / LDS and three barriers.
+constexpr int kSweepThreads = 512;
+constexpr size_t kSweepSmem = sizeof(double) * (10 * SB * SB + 2 * T + T + 8 * T);
+
+__device__ __forceinline__ void sweep_load(double2 (&t)[16], const double* __restrict__ S, int NP, int i, int j, int g, int c2) {
+  const double* src = S + ((int64_t)i * T + 16 * g) * NP + (int64_t)j * T + c2;
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = *reinterpret_cast<const double2*>(src + (int64_t)r * NP);
+}
+
+__device__ __forceinline__ void sweep_wait(const double* x, int i, double* xs, double* fail, int tid) {
+  if (tid < 64) {
+    const unsigned long long* px = reinterpret_cast<const unsigned long long*>(x) + (int64_t)i * T + 2 * tid;
+    unsigned long long a, b;
+    for (int spins = 0;; spins++) {
+      a = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b = __hip_atomic_load(px + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(a != kBwdUnset && b != kBwdUnset)) break;
+      if (spins > (1 << 21)) { if (tid == 0) fail[1] = 1.0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    xs[2 * tid] = __longlong_as_double((long long)a);
+    xs[2 * tid + 1] = __longlong_as_double((long long)b);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void sweep_fma(const double2 (&t)[16], const double* xs, int g, double& a0, double& a1) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) { const double xv = xs[16 * g + r]; a0 += t[r].x * xv; a1 += t[r].y * xv; }
+}
+
+__global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __restrict__ S, int NP, int nt,
+                                                             const int32_t* __restrict__ col_off, const int32_t* __restrict__ col_rows,
+                                                             const double* __restrict__ Xinv_all, const double* __restrict__ y,
+                                                             double* x, double* fail) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* Lv = reinterpret_cast<double*>(smem_raw);   // L(j,j)^-1: blocks (q,q) at q, blocks (p,q), p > q, at 4 + p(p-1)/2 + q; [i][cc]
+  double* xs = Lv + 10 * SB * SB;                       // [2][T] the x_i in use / arriving
+  double* w = xs + 2 * T;                               // [T]
+  double* part = w + T;                                 // [8][T]
+  const int tid = threadIdx.x, j = nt - 1 - (int)blockIdx.x;
+  const int c2 = 2 * (tid & 63), g = tid >> 6;
+  const int32_t* rows = col_rows + col_off[j];
+  const int n = col_off[j + 1] - col_off[j];
+  double2 ta[16], tb[16];
+  if (n > 0) sweep_load(ta, S, NP, rows[0], j, g, c2);
+  if (n > 1) sweep_load(tb, S, NP, rows[1], j, g, c2);
+  {
+    const double* tile = S + ((int64_t)j * T) * NP + (int64_t)j * T;
+    const double* Xinv = Xinv_all + (size_t)j * T * T;
+    for (int e = tid; e < 10 * 512; e += kSweepThreads) {
+      const int blk = e >> 9, u = e & 511, r = u >> 4, cc = 2 * (u & 15);
+      double2 v;
+      if (blk < 4) v = *reinterpret_cast<const double2*>(Xinv + blk * SB * SB + r * SB + cc);
+      else {
+        int p = 1, q = blk - 4;
+        while (q >= p) { q -= p; p++; }
+        v = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * q + r) * NP + SB * p + cc);   // Linv(p,q) sits at upper position (q,p)
+      }
+      *reinterpret_cast<double2*>(Lv + blk * SB * SB + r * SB + cc) = v;
+    }
+  }
+  double a0 = 0.0, a1 = 0.0;
+  for (int idx = 0; idx < n; idx += 2) {   // ta holds tile idx, tb tile idx + 1
+    sweep_wait(x, rows[idx], xs, fail, tid);
+    sweep_fma(ta, xs, g, a0, a1);
+    if (idx + 2 < n) sweep_load(ta, S, NP, rows[idx + 2], j, g, c2);
+    if (idx + 1 < n) {
+      sweep_wait(x, rows[idx + 1], xs + T, fail, tid);
+      sweep_fma(tb, xs + T, g, a0, a1);
+      if (idx + 3 < n) sweep_load(tb, S, NP, rows[idx + 3], j, g, c2);
+    }
+  }
+  part[g * T + c2] = a0; part[g * T + c2 + 1] = a1;
+  __syncthreads();   // (also: Lv is staged)
+  if (tid < T) {
+    double sum = 0.0;
+#pragma unroll
+    for (int h = 0; h < 8; h++) sum += part[h * T + tid];
+    w[tid] = y[j * T + tid] - sum;
+  }
+  __syncthreads();
+  {
+    const int c = tid & (T - 1), hf = tid >> 7, q = c >> 5, cc = c & 31;
+    double b0 = 0.0, b1 = 0.0;
+    const double* Lq = Lv + q * SB * SB + cc;
+#pragma unroll
+    for (int i = 8 * hf; i < 8 * hf + 8; i += 2) { b0 += Lq[i * SB] * w[SB * q + i]; b1 += Lq[(i + 1) * SB] * w[SB * q + i + 1]; }
+    for (int p = q + 1; p < 4; p++) {
+      const double* Lp = Lv + (4 + p * (p - 1) / 2 + q) * SB * SB + cc;
+#pragma unroll
+      for (int i = 8 * hf; i < 8 * hf + 8; i += 2) { b0 += Lp[i * SB] * w[SB * p + i]; b1 += Lp[(i + 1) * SB] * w[SB * p + i + 1]; }
+    }
+    part[hf * T + c] = b0 + b1;
+  }
+  __syncthreads();
+  if (tid < T) {
+    const double v = (part[tid] + part[T + tid]) + (part[2 * T + tid] + part[3 * T + tid]);
+    __hip_atomic_store(x + j * T + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: what the waiting workgroups poll
+  }
+}
+
 // gtg_destroy: the handle's schedule streams and events
 void destroy_chol_streams(gtg_context& c) {
   CholStreams& cs = c.cs;
@@ -829,24 +958,31 @@ void destroy_chol_streams(gtg_context& c) {
   cs = CholStreams(); ts = TreeStreams();
 }
 
-void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x) {
+void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail) {
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
   const size_t smem_inv = sizeof(double) * 17 * SB * SB;
+  static const bool per_row = [] { const char* e = std::getenv("GTG_BWD"); return e && std::string(e) == "steps"; }();
   {
     static std::set<int> attr_set;
     static std::mutex attr_mutex;
     std::lock_guard<std::mutex> attr_lock(attr_mutex);
     if (!attr_set.count(c.device)) {
       check_hip(hipFuncSetAttribute((const void*)k_inv_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_inv), "smem attr");
+      check_hip(hipFuncSetAttribute((const void*)k_bwd_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepSmem), "smem attr");
       attr_set.insert(c.device);
     }
   }
-  hipLaunchKernelGGL(k_inv_tiles, dim3((unsigned)nt), dim3(256), smem_inv, c.stream, S, NP, Xinv);
-  for (int k = nt - 1; k >= 0; k--) {
-    const int ncols = (int)plan.bwd_cnt[k];
-    hipLaunchKernelGGL(k_bwd_step, dim3(ncols > 0 ? 2 * (unsigned)ncols : 1u), dim3(256), 0, c.stream, S, NP, k,
-                       plan.bcols.p + plan.bwd_off[k], ncols, Xinv + (size_t)k * T * T, y, x);
+  hipLaunchKernelGGL(k_inv_tiles, dim3((unsigned)nt), dim3(256), smem_inv, c.stream, S, NP, Xinv, per_row ? nullptr : x);
+  if (!per_row) {
+    hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)nt), dim3(kSweepThreads), kSweepSmem, c.stream, S, NP, nt, plan.bwd_col_off.p,
+                       plan.bwd_col_rows.p, Xinv, y, x, fail);
+  } else {   // GTG_BWD=steps: one launch per block row (the round-1 form, kept as the A/B of the sweep)
+    for (int k = nt - 1; k >= 0; k--) {
+      const int ncols = (int)plan.bwd_cnt[k];
+      hipLaunchKernelGGL(k_bwd_step, dim3(ncols > 0 ? 2 * (unsigned)ncols : 1u), dim3(256), 0, c.stream, S, NP, k,
+                         plan.bcols.p + plan.bwd_off[k], ncols, Xinv + (size_t)k * T * T, y, x);
+    }
   }
   check_hip(hipGetLastError(), "backward_solve");
 }

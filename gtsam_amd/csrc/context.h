@@ -43,6 +43,7 @@ constexpr int kEStride = 32;                    // doubles per E slot (one per o
 struct CholPlan {
   int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
   DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
+  DevBuf<int32_t> bwd_col_off, bwd_col_rows;    // the backward tiles by column: offsets (nt + 1), row tiles in descending order
   DevBuf<int32_t> stored;                       // every stored tile (I,J) incl. the rhs row: what a multi-GPU exchange must carry
   int64_t n_stored = 0;
   DevBuf<int32_t> exch;                         // the stored tiles that can be non-zero BEFORE the factorisation (no fill): what a multi-GPU

@@ -50,6 +50,8 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<long long>;
 template struct DevBuf<unsigned char>;
 
+static void exchange(gtg_context& c, double* ptr, int64_t n);
+void exchange_sum(gtg_context& c, double* ptr, int64_t n) { exchange(c, ptr, n); }
 static void exchange(gtg_context& c, double* ptr, int64_t n) {
   if (c.n_shards > 1) {
     if (!c.allreduce) throw std::runtime_error("n_shards > 1 but no allreduce callback was set (gtg_set_allreduce)");
@@ -474,6 +476,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
   if (iterations) *iterations = its;
   { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
     launch_back_substitute(*c);
+    if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);   // sharded: every landmark's step from the shard that owns it
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }

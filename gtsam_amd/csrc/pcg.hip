@@ -55,17 +55,18 @@ __device__ __forceinline__ void load_E(const double* __restrict__ Eo, int d, dou
 }
 
 // Per reduced variable (one workgroup of kSetupWaves wavefronts, the incident observations dealt round-robin to the
-// lanes): rhs b_r = g_r - sum_o E_o y_l(o), block D_r = H_rr + damping - sum_o E_o E_o^T, its Cholesky factor L_r and the
-// block-Jacobi preconditioner in the form it is applied in: M_r = L_r^-1 (lower, row-major, stride 9, zero padded).
+// lanes): rhs b_r = g_r - sum_o E_o y_l(o) and block D_r = H_rr + damping - sum_o E_o E_o^T (k_pcg_setup; on a sharded graph
+// both are this shard's partial sums -- damping and the unit padding only on the first shard -- and are all-reduced before the
+// next step), then its Cholesky factor L_r and the block-Jacobi preconditioner in the form it is applied in: M_r = L_r^-1
+// (lower, row-major, stride 9, zero padded) (k_pcg_factor, in place).
 constexpr int kSetupWaves = 4;
 __global__ __launch_bounds__(64 * kSetupWaves) void k_pcg_setup(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
     const double* __restrict__ E, const double* __restrict__ ylm, double invsigma, int diag, double dmin, double dmax,
-    double* __restrict__ b, double* __restrict__ Mbj, double* __restrict__ fail) {
+    int first, double* __restrict__ b, double* __restrict__ Mbj) {
   __shared__ double red[kSetupWaves][54];
-  __shared__ double D[81], Ls[81];
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
@@ -99,17 +100,25 @@ __global__ __launch_bounds__(64 * kSetupWaves) void k_pcg_setup(int32_t n_red_va
   __syncthreads();
   if (tid < 81) {
     const int i = tid / 9, j = tid % 9;
-    double v = i == j ? 1.0 : 0.0;
+    double v = (i == j && first) ? 1.0 : 0.0;
     if (i < d && j < d) {
       const int hi = i > j ? i : j, lo = i > j ? j : i;
-      v = Hd[(int64_t)81 * r + i * d + j] + (i == j ? damp(hdiag[off + i], invsigma, diag, dmin, dmax) : 0.0) - red[0][hi * (hi + 1) / 2 + lo];
+      v = Hd[(int64_t)81 * r + i * d + j] + ((i == j && first) ? damp(hdiag[off + i], invsigma, diag, dmin, dmax) : 0.0) - red[0][hi * (hi + 1) / 2 + lo];
     }
-    D[tid] = v;
-    Ls[tid] = 0.0;
+    Mbj[(int64_t)81 * r + tid] = v;
   } else if (tid >= 128 && tid < 128 + d) {
     const int i = tid - 128;
     b[off + i] = g[(int64_t)9 * r + i] - red[0][45 + i];
   }
+}
+
+__global__ __launch_bounds__(128) void k_pcg_factor(int32_t n_red_vars, const int32_t* __restrict__ red_dim, double* __restrict__ Mbj,
+                                                    double* __restrict__ fail) {
+  __shared__ double D[81], Ls[81];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  if (tid < 81) { D[tid] = Mbj[(int64_t)81 * r + tid]; Ls[tid] = 0.0; }
   __syncthreads();
   if (tid == 0) {   // d <= 9: serial LLT (Eigen semantics: a non-positive pivot is a failure)
     bool bad = false;
@@ -328,7 +337,7 @@ struct ApplyArgs {
 // camera of the L1723 shape has 394 observations on average, thousands at most)
 constexpr int kApplyWaves = 4;
 __global__ __launch_bounds__(64 * kApplyWaves) void k_pcg_apply(int32_t n_red_vars, ApplyArgs a, double invsigma, int diag, double dmin,
-    double dmax, const double* __restrict__ st, const double* __restrict__ ylm, const double* __restrict__ x,
+    double dmax, int first, const double* __restrict__ st, const double* __restrict__ ylm, const double* __restrict__ x,
     double* __restrict__ out, double* __restrict__ partials) {
   __shared__ double red[kApplyWaves][9];
   __shared__ double pq[9];
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(64 * kApplyWaves) void k_pcg_apply(int32_t n_red_va
     if (tid < d) {
       const int i = tid;
       for (int w = 0; w < kApplyWaves; w++) sacc += red[w][i];
-      sacc += damp(a.hdiag[off + i], invsigma, diag, dmin, dmax) * x[off + i];
+      if (first) sacc += damp(a.hdiag[off + i], invsigma, diag, dmin, dmax) * x[off + i];
       const double* H = a.Hd + (int64_t)81 * r;
       for (int j = 0; j < d; j++) sacc += H[i * d + j] * x[off + j];
       out[off + i] = sacc;
@@ -382,15 +391,35 @@ __global__ __launch_bounds__(64 * kApplyWaves) void k_pcg_apply(int32_t n_red_va
   __syncthreads();
   if (tid == 0) { double t = 0.0; for (int i = 0; i < 9; i++) t += pq[i]; partials[r] = t; }
 }
+
+// sharded: x . out per reduced variable once the partial products have been summed over the shards (same order as k_pcg_apply)
+__global__ __launch_bounds__(kB) void k_pcg_dot(int32_t n_red_vars, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+                                                const double* __restrict__ st, const double* __restrict__ x, const double* __restrict__ out,
+                                                double* __restrict__ partials) {
+  if (st[ST_DONE] != 0.0) return;
+  for (int64_t r = blockIdx.x * (int64_t)kB + threadIdx.x; r < n_red_vars; r += (int64_t)gridDim.x * kB) {
+    const int d = red_dim[r];
+    const int64_t off = red_off[r];
+    double t = 0.0;
+    for (int i = 0; i < d; i++) t += out[off + i] * x[off + i];
+    partials[r] = t;
+  }
+}
 }  // namespace
 
 // Solves the reduced system into c.xred.  Returns the number of CG iterations; *gamma0 / *gamma = |r|^2 of the
 // preconditioned residual at the start / end.  Seven launches per iteration, enqueued in batches of kBatch iterations with one
 // read-back of the scalars per batch (the iterations enqueued past convergence return at once): the result is exactly
 // that of checking the loop condition on the host every iteration.
+// Sharded graph (landmarks dealt to the shards, every shard holds all cameras): a shard's factors give PARTIAL sums of b, of the
+// diagonal blocks and of every product S p, so these are all-reduced (one exchange of NP doubles per product: 124 KB for the
+// L1723 / Venice shapes, next to 0.35 GB / n_shards of streaming per shard); everything else -- the preconditioner, the vector
+// updates, the scalars -- is computed redundantly and identically on every shard, so the shards stay in lock step without a
+// further exchange and leave the loop in the same iteration.
 int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax, int max_iterations, int min_iterations,
                double epsilon_rel, double epsilon_abs, double* gamma0, double* gamma_end) {
-  if (c.n_shards > 1) throw std::invalid_argument("the PCG solver does not support a sharded graph (one exchange per product)");
+  const bool sharded = c.n_shards > 1;
+  const int first = c.shard == 0 ? 1 : 0;
   constexpr int kBatch = 8;
   const int NP = c.NP, nrv = c.n_red_vars;
   const double is = std::sqrt(lambda);   // 1 / sigma with sigma = 1 / sqrt(lambda) (LMState.h:117-121)
@@ -406,7 +435,9 @@ int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax
   const int gv = grid_n(9 * (int64_t)nrv);
   hipLaunchKernelGGL(k_pcg_setup, dim3(std::max(nrv, 1)), dim3(64 * kSetupWaves), 0, s, nrv, c.red_inc_ptr.p, c.red_inc_kind.p, c.red_inc_idx.p,
                      c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p, c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag,
-                     dmin, dmax, b, c.pcg_bj.p, c.scalars.p + SC_FAIL);
+                     dmin, dmax, first, b, c.pcg_bj.p);
+  if (sharded) { exchange_sum(c, b, NP); exchange_sum(c, c.pcg_bj.p, 81 * (int64_t)nrv); }
+  hipLaunchKernelGGL(k_pcg_factor, dim3(std::max(nrv, 1)), dim3(128), 0, s, nrv, c.red_dim.p, c.pcg_bj.p, c.scalars.p + SC_FAIL);
   ApplyArgs aa{c.red_inc_ptr.p, c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.red_index.p,
                c.f.between_v1.p, c.f.between_v2.p, c.f.n_sfm, c.Hd.p, c.hdiag_red.p, c.E.p, c.f.between_J.p};
   const double dmax_it = (double)max_iterations, dmin_it = (double)min_iterations;
@@ -422,7 +453,11 @@ int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax
                          c.obs_red.p + c.f.n_sfm, c.red_off.p, st, p, c.vobs.p + 3 * c.f.n_sfm);
     if (c.n_lm)
       hipLaunchKernelGGL(k_pcg_lm, dim3(grid_n(c.n_lm)), dim3(kB), 0, s, c.n_lm, c.lm_obs_ptr.p, c.lm_obs.p, st, c.vobs.p, c.pcg_y.p);
-    hipLaunchKernelGGL(k_pcg_apply, dim3(std::max(nrv, 1)), dim3(64 * kApplyWaves), 0, s, nrv, aa, is, diag, dmin, dmax, st, c.pcg_y.p, p, q, partials);
+    hipLaunchKernelGGL(k_pcg_apply, dim3(std::max(nrv, 1)), dim3(64 * kApplyWaves), 0, s, nrv, aa, is, diag, dmin, dmax, first, st, c.pcg_y.p, p, q, partials);
+    if (sharded) {
+      exchange_sum(c, q, NP);
+      hipLaunchKernelGGL(k_pcg_dot, dim3(grid_n(nrv)), dim3(kB), 0, s, nrv, c.red_dim.p, c.red_off.p, st, p, q, partials);
+    }
     hipLaunchKernelGGL(k_pcg_scalar, dim3(1), dim3(kB), 0, s, 1, partials, nrv, st, dmax_it, dmin_it, epsilon_rel, epsilon_abs);   // alpha
     hipLaunchKernelGGL(k_pcg_update_xr, dim3(gv), dim3(kB), 0, s, nrv, c.red_dim.p, c.red_off.p, c.pcg_bj.p, st, p, q, x, r, partials);
     hipLaunchKernelGGL(k_pcg_scalar, dim3(1), dim3(kB), 0, s, 2, partials, gv, st, dmax_it, dmin_it, epsilon_rel, epsilon_abs);    // beta, gamma, k, done

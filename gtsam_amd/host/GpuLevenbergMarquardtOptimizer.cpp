@@ -275,7 +275,6 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
 
   if (shards.n_shards < 1 || shards.shard < 0 || shards.shard >= shards.n_shards) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: bad ShardSpec");
   if (shards.n_shards > 1 && !shards.allreduce) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: n_shards > 1 needs an all-reduce callback");
-  if (shards.n_shards > 1 && params_.isIterative()) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: the PCG solver is single-shard");
   check(gtg_create(&m.h, device), "gtg_create");
   if (shards.allreduce) check(gtg_set_allreduce(m.h, shards.allreduce, shards.user), "gtg_set_allreduce");   // before the upload: it verifies the layout across the shards
   check(gtg_upload_problem(m.h, &pb, shards.shard, shards.n_shards), "gtg_upload_problem");

@@ -162,6 +162,18 @@ class RefGraph:
         return (rc, ms, res) if with_results else (rc, ms)
 
 
+def _iteration_mt(self, values, lam, diagonal_damping, n_threads):
+    """ref_graph_iteration_mt: the same iteration with linearize and the landmark eliminations split over n_threads threads in the
+    harness -> (status, ms[5] = linearize, eliminate landmarks, eliminate + solve the rest, back-substitute, total, res[6])."""
+    v = np.ascontiguousarray(values, np.float64)
+    ms = np.zeros(5); res = np.zeros(6)
+    rc = lib().ref_graph_iteration_mt(self.h, _p(v), C.c_double(lam), C.c_int(int(diagonal_damping)), C.c_int(int(n_threads)), _p(ms), _p(res))
+    return rc, ms, res
+
+
+RefGraph.iteration_mt = _iteration_mt
+
+
 def load_bal(path):
     """SfmData::FromBalFile (sfm/SfmData.cpp:189-246) -> (cams17, pts3, obs_cam, obs_pt, obs_z)."""
     nc, npt, nobs = C.c_int64(), C.c_int64(), C.c_int64()

@@ -23,6 +23,7 @@
 #include <gtsam/geometry/Pose2.h>
 #include <gtsam/geometry/Pose3.h>
 #include <gtsam/inference/Ordering.h>
+#include <gtsam/linear/GaussianBayesNet.h>
 #include <gtsam/linear/GaussianFactorGraph.h>
 #include <gtsam/linear/JacobianFactor.h>
 #include <gtsam/linear/NoiseModel.h>
@@ -45,6 +46,9 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <functional>
+#include <thread>
+#include <functional>
 #include <vector>
 
 using namespace gtsam;
@@ -495,6 +499,91 @@ int ref_graph_iteration_phases2(void* h, const double* values, double lambda, in
     if (!status) for (const auto& [key, value] : d) res[5] = std::max(res[5], value.cwiseAbs().maxCoeff());
   }
   return status + (e != e ? 2 : 0);
+}
+// The same iteration with the work the reference's TBB build would spread over cores split over `n_threads` std::threads HERE,
+// in the harness (the image has no TBB headers, so the library itself is built single-threaded): a multi-thread figure next
+// to the one-thread one, made of the reference's own calls --
+//   linearize:  factor->linearize(values) over contiguous chunks of the graph (what NonlinearFactorGraph::linearize does under
+//               TBB, nonlinear/NonlinearFactorGraph.cpp:_LinearizeOneFactor);
+//   eliminate:  the landmarks of the Schur ordering in n_threads groups, each group's factors through
+//               eliminatePartialSequential on its own thread (the leaves of the elimination tree, which TBB runs in parallel),
+//               then the remaining camera / pose system on ONE thread (a chain of dense fronts: no tree parallelism to use),
+//               then the groups' back-substitution in parallel;
+//   errors and retract as in the one-thread variant (1 % of the time).
+// ms[5]: linearize, eliminate landmarks, eliminate + solve the rest, back-substitute, total.  res as in ..._phases2.
+int ref_graph_iteration_mt(void* h, const double* values, double lambda, int diagonal_damping, int n_threads, double* ms, double* res) {
+  RefGraph* g = static_cast<RefGraph*>(h);
+  using clk = std::chrono::high_resolution_clock;
+  auto msec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const Values vals = g->unpack(values);
+  const size_t nf = g->graph.size();
+  const int nth = std::max(1, n_threads);
+  auto run = [&](const std::function<void(int)>& body) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; t++) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
+  };
+  auto t0 = clk::now();
+  GaussianFactorGraph lin;
+  lin.resize(nf);
+  run([&](int t) { for (size_t i = nf * t / nth; i < nf * (t + 1) / nth; i++) lin.at(i) = g->graph[i]->linearize(vals); });
+  auto t1 = clk::now();
+  VectorValues sq;
+  if (diagonal_damping) {
+    sq = lin.hessianDiagonal();
+    for (auto& [key, value] : sq) value = value.cwiseMax(1e-6).cwiseMin(1e32).cwiseSqrt();
+  }
+  internal::LevenbergMarquardtState state(vals, 0.0, lambda, 10.0);
+  GaussianFactorGraph damped = diagonal_damping ? state.buildDampedSystem(lin, sq) : state.buildDampedSystem(lin);
+  // groups of landmarks (contiguous in the Schur ordering) and the factors that touch them
+  std::vector<int> group_of(g->n_vars, -1);
+  std::vector<Ordering> group_keys(nth);
+  Ordering rest_keys;
+  { int64_t n_pt = 0, k = 0;
+    for (int i = 0; i < g->n_vars; i++) if (g->var_type[i] == GTG_VAR_POINT3) n_pt++;
+    for (int i = 0; i < g->n_vars; i++) {
+      if (g->var_type[i] == GTG_VAR_POINT3) { const int t = (int)(k++ * nth / std::max<int64_t>(n_pt, 1)); group_of[i] = t; group_keys[t].push_back(Key(i)); }
+      else rest_keys.push_back(Key(i));
+    } }
+  std::vector<GaussianFactorGraph> sub(nth);
+  GaussianFactorGraph rest;
+  for (const auto& f : damped) {
+    int t = -1;
+    for (Key k : f->keys()) if (group_of[k] >= 0) { t = group_of[k]; break; }
+    if (t >= 0) sub[t].push_back(f); else rest.push_back(f);
+  }
+  auto t2 = clk::now();
+  std::vector<std::shared_ptr<GaussianBayesNet>> bn(nth);
+  std::vector<std::shared_ptr<GaussianFactorGraph>> rem(nth);
+  std::vector<int> bad(nth, 0);
+  run([&](int t) {
+    if (group_keys[t].empty()) return;
+    try { auto r = sub[t].eliminatePartialSequential(group_keys[t], EliminatePreferCholesky); bn[t] = r.first; rem[t] = r.second; }
+    catch (const IndeterminantLinearSystemException&) { bad[t] = 1; }
+  });
+  auto t3 = clk::now();
+  int status = 0;
+  for (int t = 0; t < nth; t++) { if (bad[t]) status = 1; else if (rem[t]) rest.push_back(*rem[t]); }
+  VectorValues d;
+  if (!status) { try { d = rest.optimize(rest_keys, EliminatePreferCholesky); } catch (const IndeterminantLinearSystemException&) { status = 1; } }
+  auto t4 = clk::now();
+  if (!status) {
+    std::vector<VectorValues> part(nth);
+    run([&](int t) { if (bn[t]) part[t] = bn[t]->optimize(d); });
+    for (int t = 0; t < nth; t++) for (Key k : group_keys[t]) d.insert(k, part[t].at(k));
+  }
+  auto t5 = clk::now();
+  double l0 = 0, l1 = 0, e1 = 0;
+  if (!status) { l0 = lin.error(VectorValues::Zero(d)); l1 = lin.error(d); e1 = g->graph.error(vals.retract(d)); }
+  auto t6 = clk::now();
+  ms[0] = msec(t0, t1); ms[1] = msec(t2, t3); ms[2] = msec(t3, t4); ms[3] = msec(t4, t5); ms[4] = msec(t0, t6);
+  if (res) {
+    res[0] = g->graph.error(vals); res[1] = l0; res[2] = l1; res[3] = e1;
+    res[4] = status ? 0.0 : d.norm(); res[5] = 0.0;
+    if (!status) for (const auto& [key, value] : d) res[5] = std::max(res[5], value.cwiseAbs().maxCoeff());
+  }
+  return status;
 }
 int ref_graph_iteration_phases(void* h, const double* values, double lambda, int diagonal_damping,
                                int ordering_kind, double* ms) {

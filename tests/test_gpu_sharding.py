@@ -102,6 +102,58 @@ def test_two_shards_equal_one(case):
     assert np.array_equal(res[0][4], res[1][4])
 
 
+@pytest.mark.parametrize("case", ["bal_60_cameras", "bal_small_unit", "posegraph_small"])
+def test_two_shards_pcg_equal_one(case):
+    """gtg_try_lambda_pcg on a sharded graph: b, the block-Jacobi blocks and every product S p are partial sums per shard and
+    all-reduced (one exchange of the reduced vector per product), the rest of the CG runs redundantly in lock step.  Same
+    iteration count and, up to the association of the sums, the same step as the single handle."""
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd import lib as L
+    if case == "bal_60_cameras":
+        from gtsam_amd import datasets as D
+        from gtsam_amd.problem import bal_problem
+        p, v0 = bal_problem(*D.synthetic_bal(60, 6000, seed=7)); diag = True
+    else:
+        p, v0 = PB.SYNTH[case](); diag = case == "bal_small_unit"
+    cg = dict(max_iterations=300, min_iterations=1, epsilon_rel=1e-10, epsilon_abs=1e-14)
+
+    def solve(dev):
+        dev.set_values(v0)
+        dev.linearize()
+        rc, out, its = dev.try_lambda_pcg(1e-3, diag, **cg)
+        return rc, out, its, dev.delta().copy()
+
+    single = L.DeviceGraph(p)
+    rc1, out1, its1, d1 = solve(single)
+    single.close()
+    assert rc1 == 0 and its1 > 1
+    sumr = TwoWaySum()
+    res = [None, None]
+
+    def run(rank):
+        try:
+            dev = L.DeviceGraph(p, shard=rank, n_shards=2, allreduce=sumr.fn(rank))
+            res[rank] = solve(dev)
+            dev.close()
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+            sumr.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for rc, out, its, d in res:
+        assert rc == 0 and abs(its - its1) <= 1
+        assert np.abs(d - d1).max() <= 1e-7 * np.abs(d1).max()
+        assert np.allclose(out[:3], out1[:3], rtol=1e-8)
+    assert np.array_equal(res[0][3], res[1][3])   # lock step: bitwise the same step on both shards
+
+
 def test_nccl_allreduce_callback_on_a_raw_device_pointer():
     """The callback bench.py registers for N > 1: a raw device pointer wrapped zero-copy and all-reduced with the
     `nccl` (= RCCL) backend.  World size 1 here (one GPU on the box): checks the wrapping + collective plumbing."""

@@ -189,6 +189,21 @@ def test_oracle_vs_live_reference(live_ref):
         assert rc == st == 0 and rel(d2, d) <= 1e-8
 
 
+def test_multi_thread_baseline_iteration_equals_the_one_thread_one(live_ref):
+    """bench.py's multi-thread cpu_baseline (ref_graph_iteration_mt: linearize and the landmark eliminations split over threads
+    in the harness) is the same iteration: same errors and the same step as the one-thread reference iteration."""
+    if live_ref is None:
+        pytest.skip("oracle/_ref not present")
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import bal_problem
+    p, v0 = bal_problem(*D.synthetic_bal(12, 400, seed=3))
+    g = live_ref.RefGraph(p)
+    rc, ms, r1 = g.iteration_phases(v0, 1e-4, True, 1, with_results=True)
+    for nth in (1, 3):
+        rc2, ms2, r2 = g.iteration_mt(v0, 1e-4, True, nth)
+        assert rc == rc2 == 0 and np.all(np.abs(r2 - r1) <= 1e-9 * np.abs(r1)), (r1, r2)
+
+
 # ---- (3) Pose2 pose graphs: BASELINE configs[0] (Pose2SLAMExample_g2o protocol with LM) --------------------------------
 @pytest.mark.parametrize("name", ["pose2_w100", "pose2_toy"])
 def test_oracle_pose2_matches_reference_golden(name):

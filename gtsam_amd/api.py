@@ -90,6 +90,13 @@ class Cal3_S2:
         self.v = np.array([fx, fy, s, u0, v0], np.float64)
 
 
+class Cal3DS2:
+    """fx, fy, s, u0, v0 + radial (k1, k2) and tangential (p1, p2) distortion (geometry/Cal3DS2_Base.h:43-66)."""
+
+    def __init__(self, fx=1.0, fy=1.0, s=0.0, u0=0.0, v0=0.0, k1=0.0, k2=0.0, p1=0.0, p2=0.0):
+        self.v = np.array([fx, fy, s, u0, v0, k1, k2, p1, p2], np.float64)
+
+
 class PinholeCameraCal3Bundler:
     """gtsam.PinholeCameraCal3Bundler = SfmCamera (sfm/SfmData.h:33)."""
 
@@ -227,6 +234,10 @@ class GenericProjectionFactorCal3_S2:
         self.z, self.model, self.keys_, self.K, self.sensor = np.asarray(measured, np.float64), model, (poseKey, pointKey), K, body_P_sensor
 
 
+class GenericProjectionFactorCal3DS2(GenericProjectionFactorCal3_S2):
+    """GenericProjectionFactor<Pose3, Point3, Cal3DS2> (wrapped name of slam/slam.i's instantiation): same factor, K a Cal3DS2."""
+
+
 class BetweenFactorPose3:
     def __init__(self, key1, key2, measured: Pose3, model):
         self.keys_, self.z, self.model = (key1, key2), measured, model
@@ -351,7 +362,10 @@ def extract(graph: NonlinearFactorGraph, values: Values):
         p.proj_pose = np.array([s[0] for s in proj], np.int32); p.proj_point = np.array([s[1] for s in proj], np.int32)
         p.proj_z = np.concatenate([s[2] for s in proj]); p.proj_noise = np.array([s[3] for s in proj], np.int32)
         p.proj_calib = np.array([s[4] for s in proj], np.int32); p.proj_sensor = np.array([s[5] for s in proj], np.int32)
-        p.calib = np.concatenate([c[1] for c in sorted(calibs.values(), key=lambda c: c[0])])
+        rows = [c[1] for c in sorted(calibs.values(), key=lambda c: c[0])]
+        p.calib = np.concatenate([r[:5] for r in rows])
+        if any(r.size == 9 for r in rows):      # Cal3DS2 entries: k1, k2, p1, p2 per calibration (zero rows for a Cal3_S2)
+            p.calib_distortion = np.concatenate([r[5:] if r.size == 9 else np.zeros(4) for r in rows])
         p.sensor = np.concatenate(sensors) if sensors else np.zeros(0)
     if btw:
         p.between_v1 = np.array([s[0] for s in btw], np.int32); p.between_v2 = np.array([s[1] for s in btw], np.int32)

@@ -297,7 +297,12 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
     f.n_proj = (int64_t)pose.size();
     up(f.proj_pose, pose, s); up(f.proj_point, pt, s); up(f.proj_noise, nz, s); up(f.proj_calib, cal, s);
     up(f.proj_sensor, sen, s); up(f.proj_z, z, s);
-    std::vector<double> calib(p->calib, p->calib + 5 * (size_t)p->n_calib), sensor(p->sensor, p->sensor + 12 * (size_t)p->n_sensor);
+    // device calibration table: 9 per entry, fx fy s u0 v0 k1 k2 p1 p2 (the distortion part zero for a Cal3_S2)
+    std::vector<double> calib(kCalibStride * (size_t)p->n_calib, 0.0), sensor(p->sensor, p->sensor + 12 * (size_t)p->n_sensor);
+    for (int32_t k = 0; k < p->n_calib; k++) {
+      for (int j = 0; j < 5; j++) calib[kCalibStride * (size_t)k + j] = p->calib[5 * (size_t)k + j];
+      if (p->calib_distortion) for (int j = 0; j < 4; j++) calib[kCalibStride * (size_t)k + 5 + j] = p->calib_distortion[4 * (size_t)k + j];
+    }
     up(f.calib, calib, s); up(f.sensor, sensor, s);
     f.proj_J.alloc(std::max<size_t>((size_t)kProjRec * f.n_proj, 1));
     hi.proj_pose = pose; hi.proj_point = pt;

@@ -90,12 +90,12 @@ __global__ __launch_bounds__(kBlock) void k_lin_proj(int64_t n, const int32_t* _
   for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
     const int64_t i = ch * 64 + lane;
     if (i < n) {
-      double T[12], p[3], zz[2], K[5], S[12];
+      double T[12], p[3], zz[2], K[kCalibStride], S[12];
       const double* tp = values + val_off[pose[i]];
       const double* pp = values + val_off[pt[i]];
       for (int k = 0; k < 12; k++) T[k] = tp[k];
       for (int k = 0; k < 3; k++) p[k] = pp[k];
-      for (int k = 0; k < 5; k++) K[k] = calib[5 * calib_idx[i] + k];
+      for (int k = 0; k < kCalibStride; k++) K[k] = calib[kCalibStride * calib_idx[i] + k];
       const int si = sensor_idx[i];
       if (si >= 0) for (int k = 0; k < 12; k++) S[k] = sensor[12 * si + k];
       zz[0] = z[2 * i]; zz[1] = z[2 * i + 1];
@@ -164,12 +164,12 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     acc += sfm_error(c, p, zz, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_proj; i += stride) {
-    double T[12], p[3], zz[2], K[5], S[12];
+    double T[12], p[3], zz[2], K[kCalibStride], S[12];
     const double* tp = values + a.val_off[a.proj_pose[i]];
     const double* pp = values + a.val_off[a.proj_pt[i]];
     for (int k = 0; k < 12; k++) T[k] = tp[k];
     for (int k = 0; k < 3; k++) p[k] = pp[k];
-    for (int k = 0; k < 5; k++) K[k] = a.calib[5 * a.proj_calib[i] + k];
+    for (int k = 0; k < kCalibStride; k++) K[k] = a.calib[kCalibStride * a.proj_calib[i] + k];
     const int si = a.proj_sensor[i];
     if (si >= 0) for (int k = 0; k < 12; k++) S[k] = a.sensor[12 * si + k];
     zz[0] = a.proj_z[2 * i]; zz[1] = a.proj_z[2 * i + 1];

@@ -252,25 +252,50 @@ GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* 
   return true;
 }
 
-// PinholeCamera<Cal3_S2>(pose, K).project (PinholePose.h:89-109) + Cal3_S2::uncalibrate
-// (geometry/Cal3_S2.cpp:44-50).  K = fx, fy, s, u0, v0.  Dpose 2x6, Dpoint 2x3.
+// PinholeCamera<Cal3_S2>(pose, K).project (PinholePose.h:89-109) + Cal3_S2::uncalibrate (geometry/Cal3_S2.cpp:44-50), or, when the
+// table entry carries distortion coefficients, + Cal3DS2_Base::uncalibrate (geometry/Cal3DS2_Base.cpp:93-132, derivative with
+// respect to the intrinsic point D2dintrinsic :71-91).  K = fx, fy, s, u0, v0, k1, k2, p1, p2 (kCalibStride).  Dpose 2x6, Dpoint 2x3.
+constexpr int kCalibStride = 9;
 GT_HD bool s2_project(const double* T, const double* K, const double* pw, double* pi, double* Dpose,
                       double* Dpoint) {
   double pn[2], Dps[12], Dpt[6];
   const bool want = Dpose || Dpoint;
   if (!(want ? project2(T, pw, pn, Dps, Dpt) : project2(T, pw, pn, nullptr, nullptr))) return false;
   const double fx = K[0], fy = K[1], s = K[2], u0 = K[3], v0 = K[4];
-  pi[0] = fx * pn[0] + s * pn[1] + u0;
-  pi[1] = fy * pn[1] + v0;
+  const double k1 = K[5], k2 = K[6], p1 = K[7], p2 = K[8];
+  // d(pixel)/d(intrinsic point): DK for a Cal3_S2, DK * DR with distortion
+  double d00 = fx, d01 = s, d10 = 0.0, d11 = fy;
+  if (k1 == 0.0 && k2 == 0.0 && p1 == 0.0 && p2 == 0.0) {
+    pi[0] = fx * pn[0] + s * pn[1] + u0;
+    pi[1] = fy * pn[1] + v0;
+  } else {
+    const double x = pn[0], y = pn[1], xy = x * y, xx = x * x, yy = y * y;
+    const double rr = xx + yy, r4 = rr * rr;
+    const double g = 1. + k1 * rr + k2 * r4;
+    const double dx = 2. * p1 * xy + p2 * (rr + 2. * xx);
+    const double dy = 2. * p2 * xy + p1 * (rr + 2. * yy);
+    const double pnx = g * x + dx, pny = g * y + dy;
+    pi[0] = fx * pnx + s * pny + u0;
+    pi[1] = fy * pny + v0;
+    if (want) {
+      const double drdx = 2. * x, drdy = 2. * y;
+      const double dgdx = k1 * drdx + k2 * 2. * rr * drdx, dgdy = k1 * drdy + k2 * 2. * rr * drdy;
+      const double dDxdx = 2. * p1 * y + p2 * (drdx + 4. * x), dDxdy = 2. * p1 * x + p2 * drdy;
+      const double dDydx = 2. * p2 * y + p1 * drdx, dDydy = 2. * p2 * x + p1 * (drdy + 4. * y);
+      const double r00 = g + x * dgdx + dDxdx, r01 = x * dgdy + dDxdy, r10 = y * dgdx + dDydx, r11 = g + y * dgdy + dDydy;
+      d00 = fx * r00 + s * r10; d01 = fx * r01 + s * r11;
+      d10 = 0.0 * r00 + fy * r10; d11 = 0.0 * r01 + fy * r11;
+    }
+  }
   if (Dpose)
     _Pragma("unroll") for (int j = 0; j < 6; j++) {
-      Dpose[j] = fx * Dps[j] + s * Dps[6 + j];
-      Dpose[6 + j] = 0.0 * Dps[j] + fy * Dps[6 + j];
+      Dpose[j] = d00 * Dps[j] + d01 * Dps[6 + j];
+      Dpose[6 + j] = d10 * Dps[j] + d11 * Dps[6 + j];
     }
   if (Dpoint)
     _Pragma("unroll") for (int j = 0; j < 3; j++) {
-      Dpoint[j] = fx * Dpt[j] + s * Dpt[3 + j];
-      Dpoint[3 + j] = 0.0 * Dpt[j] + fy * Dpt[3 + j];
+      Dpoint[j] = d00 * Dpt[j] + d01 * Dpt[3 + j];
+      Dpoint[3 + j] = d10 * Dpt[j] + d11 * Dpt[3 + j];
     }
   return true;
 }

@@ -204,8 +204,10 @@ def random_pose_graph(n, n_closures, seed=0, noise="mixed", rot_scale=1.0, init_
     return p, v0.reshape(-1)
 
 
-def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, behind=True):
-    """Small GenericProjectionFactor<Pose3,Point3,Cal3_S2> graph (+ priors).  Returns (Problem, values0)."""
+def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, behind=True, distortion=None):
+    """Small GenericProjectionFactor<Pose3,Point3,Cal3_S2> graph (+ priors).  Returns (Problem, values0).
+    distortion: optional (2, 4) array k1, k2, p1, p2 for the two calibrations -- a non-zero row makes that calibration a Cal3DS2
+    (GenericProjectionFactor<Pose3,Point3,Cal3DS2>); the measurements are generated through the same distortion."""
     from .problem import VAR_POINT3, VAR_POSE3
     rng = np.random.default_rng(seed)
     ang = np.linspace(0, 1.0, n_poses)
@@ -233,6 +235,10 @@ def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, be
             k = K[i % 2]
             if q[2] > 0:
                 u, v = q[0] / q[2], q[1] / q[2]
+                if distortion is not None:
+                    k1, k2, p1, p2 = np.asarray(distortion, float)[i % 2]
+                    rr = u * u + v * v; gg = 1 + k1 * rr + k2 * rr * rr
+                    u, v = gg * u + 2 * p1 * u * v + p2 * (rr + 2 * u * u), gg * v + 2 * p2 * u * v + p1 * (rr + 2 * v * v)
                 z = np.array([k[0] * u + k[2] * v + k[3], k[1] * v + k[4]]) + rng.normal(0, 1.0, 2)
             else:
                 z = rng.normal(0, 50, 2)
@@ -242,6 +248,8 @@ def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, be
     p.proj_z = np.array(zs).reshape(-1); p.proj_noise = np.array(nz, np.int32)
     p.proj_calib = np.array(ci, np.int32); p.proj_sensor = np.array(si, np.int32)
     p.calib = K.reshape(-1); p.sensor = sensor
+    if distortion is not None:
+        p.calib_distortion = np.ascontiguousarray(np.asarray(distortion, np.float64).reshape(-1))
     poses = np.concatenate([R.reshape(n_poses, 9), centers], 1)
     n6 = p.add_noise(NOISE_DIAGONAL, 6, [0.01] * 3 + [0.05] * 3); n3 = p.add_noise(NOISE_ISOTROPIC, 3, [0.1])
     p.add_prior(0, poses[0], n6); p.add_prior(1, poses[1], n6); p.add_prior(n_poses, pts[0], n3)

@@ -3,6 +3,7 @@
 #include "GpuLevenbergMarquardtOptimizer.h"
 
 #include <gtsam/geometry/Cal3Bundler.h>
+#include <gtsam/geometry/Cal3DS2.h>
 #include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/geometry/Pose2.h>
@@ -54,6 +55,7 @@ namespace gtsam_amd {
 typedef PinholeCamera<Cal3Bundler> SfmCamera;
 typedef GeneralSFMFactor<SfmCamera, Point3> SfmFactor;
 typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
+typedef GenericProjectionFactor<Pose3, Point3, Cal3DS2> ProjFactorDS2;
 typedef internal::LevenbergMarquardtState State;
 
 struct GpuLevenbergMarquardtOptimizer::Impl {
@@ -200,7 +202,9 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   std::vector<int32_t> sfm_cam, sfm_pt, sfm_nz, pj_pose, pj_pt, pj_nz, pj_cal, pj_sen, bt_1, bt_2, bt_nz, pr_var, pr_nz;
   std::vector<double> sfm_z, pj_z, calib, sensor, bt_z, pr_data;
   std::vector<int64_t> pr_off;
-  std::map<const Cal3_S2*, int32_t> calib_id;
+  std::map<const void*, int32_t> calib_id;   // shared calibration objects (Cal3_S2 or Cal3DS2) -> row of the calibration table
+  std::vector<double> calib_dist;            // k1 k2 p1 p2 per row (zero for a Cal3_S2)
+  bool any_distortion = false;
   for (const auto& f : graph_) {
     if (!f) { m.fac_map.emplace_back(-1, 0); continue; }
     if (auto s = std::dynamic_pointer_cast<SfmFactor>(f)) {
@@ -219,9 +223,27 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
       if (it == calib_id.end()) {
         it = calib_id.emplace(K, (int32_t)(calib.size() / 5)).first;
         calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
+        calib_dist.insert(calib_dist.end(), {0.0, 0.0, 0.0, 0.0});
       }
       pj_cal.push_back(it->second);
       if (p->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*p->body_P_sensor(), sensor.data() + sensor.size() - 12); }
+      else pj_sen.push_back(-1);
+    } else if (auto pd = std::dynamic_pointer_cast<ProjFactorDS2>(f)) {   // the same factor with a Cal3DS2 calibration (section 8(f) #3)
+      m.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)pj_pose.size());
+      if (pd->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
+      pj_pose.push_back(idOf(pd->key1())); pj_pt.push_back(idOf(pd->key2()));
+      pj_z.push_back(pd->measured().x()); pj_z.push_back(pd->measured().y());
+      pj_nz.push_back(nt.add(pd->noiseModel(), 2));
+      const Cal3DS2* K = pd->calibration().get();
+      auto it = calib_id.find(K);
+      if (it == calib_id.end()) {
+        it = calib_id.emplace(K, (int32_t)(calib.size() / 5)).first;
+        calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
+        calib_dist.insert(calib_dist.end(), {K->k1(), K->k2(), K->p1(), K->p2()});
+        any_distortion = true;
+      }
+      pj_cal.push_back(it->second);
+      if (pd->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*pd->body_P_sensor(), sensor.data() + sensor.size() - 12); }
       else pj_sen.push_back(-1);
     } else if (auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {
       m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
@@ -257,7 +279,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
       pr_nz.push_back(nt.add(p3->noiseModel(), 3));
     } else {
       throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
-                                  "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2>, "
+                                  "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2|Cal3DS2>, "
                                   "BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
     }
   }
@@ -269,7 +291,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   pb.n_sfm = (int64_t)sfm_cam.size(); pb.sfm_cam = sfm_cam.data(); pb.sfm_point = sfm_pt.data(); pb.sfm_z = sfm_z.data(); pb.sfm_noise = sfm_nz.data();
   pb.n_proj = (int64_t)pj_pose.size(); pb.proj_pose = pj_pose.data(); pb.proj_point = pj_pt.data(); pb.proj_z = pj_z.data();
   pb.proj_noise = pj_nz.data(); pb.proj_calib = pj_cal.data(); pb.proj_sensor = pj_sen.data();
-  pb.n_calib = (int32_t)(calib.size() / 5); pb.calib = calib.data(); pb.n_sensor = (int32_t)(sensor.size() / 12); pb.sensor = sensor.data();
+  pb.n_calib = (int32_t)(calib.size() / 5); pb.calib = calib.data(); pb.calib_distortion = any_distortion ? calib_dist.data() : nullptr; pb.n_sensor = (int32_t)(sensor.size() / 12); pb.sensor = sensor.data();
   pb.n_between = (int64_t)bt_1.size(); pb.between_v1 = bt_1.data(); pb.between_v2 = bt_2.data(); pb.between_z = bt_z.data(); pb.between_noise = bt_nz.data();
   pb.n_prior = (int64_t)pr_var.size(); pb.prior_var = pr_var.data(); pb.prior_off = pr_off.data(); pb.prior_data = pr_data.data(); pb.prior_noise = pr_nz.data();
 

@@ -37,6 +37,7 @@ class gtg_problem(C.Structure):
         ("between_z", _f64p), ("between_noise", _i32p),
         ("n_prior", C.c_int64), ("prior_var", _i32p), ("prior_off", _i64p), ("prior_data", _f64p),
         ("prior_noise", _i32p),
+        ("calib_distortion", _f64p),
     ]
 
 
@@ -65,6 +66,7 @@ class Problem:
     proj_calib: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     proj_sensor: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     calib: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
+    calib_distortion: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))   # [n_calib*4] k1,k2,p1,p2 (Cal3DS2) or empty
     sensor: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
     between_v1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     between_v2: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
@@ -166,6 +168,9 @@ class Problem:
         p.proj_sensor = ptr(self.proj_sensor, C.c_int32)
         p.n_calib = int(self.calib.size // 5)
         p.calib = ptr(self.calib, C.c_double)
+        if self.calib_distortion.size not in (0, 4 * p.n_calib):
+            raise ValueError("calib_distortion must be empty or hold k1, k2, p1, p2 for every calibration")
+        p.calib_distortion = ptr(self.calib_distortion, C.c_double)
         p.n_sensor = int(self.sensor.size // 12)
         p.sensor = ptr(self.sensor, C.c_double)
         p.n_between = self.n_between

@@ -93,7 +93,7 @@ typedef struct gtg_problem {
   const int32_t* proj_calib;     /* [n_proj] index into calib table */
   const int32_t* proj_sensor;    /* [n_proj] index into sensor table or -1 (body_P_sensor_ absent) */
   int32_t n_calib;
-  const double* calib;           /* [n_calib*5] Cal3_S2 fx,fy,s,u0,v0 (geometry/Cal3_S2.cpp:44-50) */
+  const double* calib;           /* [n_calib*5] Cal3_S2 fx,fy,s,u0,v0 (geometry/Cal3_S2.cpp:44-50); distortion: calib_distortion below */
   int32_t n_sensor;
   const double* sensor;          /* [n_sensor*12] body_P_sensor poses */
 
@@ -109,6 +109,11 @@ typedef struct gtg_problem {
   const int64_t* prior_off;      /* [n_prior] offset into prior_data (storage size of the var type) */
   const double* prior_data;
   const int32_t* prior_noise;    /* [n_prior] (dim = tangent dim of the variable) */
+
+  const double* calib_distortion; /* [n_calib*4] k1, k2, p1, p2 of a Cal3DS2 calibration (radial + tangential distortion,
+                                     geometry/Cal3DS2_Base.cpp:93-132: GenericProjectionFactor<Pose3, Point3, Cal3DS2>), or NULL:
+                                     every entry of the calib table is a plain Cal3_S2.  (Appended in round 2: a caller built
+                                     against the older struct must be recompiled.) */
 } gtg_problem;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

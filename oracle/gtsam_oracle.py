@@ -215,14 +215,32 @@ def sfm_project(cam17, pw):
     return pi, Dcam, Dp @ Dpoint, behind
 
 
-def s2_project(R, t, K5, pw):
-    """PinholeCamera<Cal3_S2>::project (PinholePose.h:89-109) + Cal3_S2::uncalibrate (Cal3_S2.cpp:44-50)."""
+def s2_project(R, t, K5, pw, dist=None):
+    """PinholeCamera<Cal3_S2>::project (PinholePose.h:89-109) + Cal3_S2::uncalibrate (Cal3_S2.cpp:44-50); with dist = (k1, k2,
+    p1, p2) per row: + Cal3DS2_Base::uncalibrate (geometry/Cal3DS2_Base.cpp:93-132), point derivative D2dintrinsic (:71-91)."""
     pn, Dpose, Dpoint, behind = _project2(R, t, pw)
     fx, fy, s, u0, v0 = (K5[:, i] for i in range(5))
     x, y = pn[:, 0], pn[:, 1]
     z = np.zeros_like(fx)
-    Dp = np.stack([np.stack([fx, s], -1), np.stack([z, fy], -1)], -2)
-    pi = np.stack([fx * x + s * y + u0, fy * y + v0], -1)
+    DK = np.stack([np.stack([fx, s], -1), np.stack([z, fy], -1)], -2)
+    if dist is None:
+        pi = np.stack([fx * x + s * y + u0, fy * y + v0], -1)
+        return pi, DK @ Dpose, DK @ Dpoint, behind
+    k1, k2, p1, p2 = (dist[:, i] for i in range(4))
+    xy, xx, yy = x * y, x * x, y * y
+    rr = xx + yy; r4 = rr * rr
+    g = 1. + k1 * rr + k2 * r4
+    dx = 2. * p1 * xy + p2 * (rr + 2. * xx)
+    dy = 2. * p2 * xy + p1 * (rr + 2. * yy)
+    pnx = g * x + dx; pny = g * y + dy
+    pi = np.stack([fx * pnx + s * pny + u0, fy * pny + v0], -1)
+    drdx, drdy = 2. * x, 2. * y
+    dgdx = k1 * drdx + k2 * 2. * rr * drdx; dgdy = k1 * drdy + k2 * 2. * rr * drdy
+    dDxdx = 2. * p1 * y + p2 * (drdx + 4. * x); dDxdy = 2. * p1 * x + p2 * drdy
+    dDydx = 2. * p2 * y + p1 * drdx; dDydy = 2. * p2 * x + p1 * (drdy + 4. * y)
+    DR = np.stack([np.stack([g + x * dgdx + dDxdx, x * dgdy + dDxdy], -1),
+                   np.stack([y * dgdx + dDydx, g + y * dgdy + dDydy], -1)], -2)
+    Dp = DK @ DR
     return pi, Dp @ Dpose, Dp @ Dpoint, behind
 
 
@@ -417,6 +435,8 @@ def _linearize_whitened(p: Problem, values):
     if p.n_proj:
         R, t = pose_unpack(_gather(values, off, p.proj_pose, 12)); pt = _gather(values, off, p.proj_point, 3)
         K5 = p.calib.reshape(-1, 5)[p.proj_calib]
+        cd = getattr(p, "calib_distortion", np.zeros(0))
+        dist = cd.reshape(-1, 4)[p.proj_calib] if cd.size else None     # Cal3DS2 entries (zero rows = plain Cal3_S2)
         H0 = None
         has_s = p.proj_sensor >= 0 if p.proj_sensor.size else np.zeros(p.n_proj, bool)
         if has_s.any():                                          # ProjectionFactor.h:142-148
@@ -424,7 +444,7 @@ def _linearize_whitened(p: Problem, values):
             cR, ct = pose_compose(R, t, sR, st)
             R = np.where(has_s[:, None, None], cR, R); t = np.where(has_s[:, None], ct, t)
             H0 = pose_adjoint(*pose_inverse(sR, st))             # compose H1 = g.inverse().AdjointMap() (Lie.h:56-61)
-        pi, Dpose, Dpt, behind = s2_project(R, t, K5, pt)
+        pi, Dpose, Dpt, behind = s2_project(R, t, K5, pt, dist)
         if H0 is not None:
             Dpose = np.where(has_s[:, None, None], Dpose @ H0, Dpose)
         err = pi - p.proj_z.reshape(-1, 2)

@@ -17,6 +17,7 @@
 #include "../include/gtsam_amd.h"
 
 #include <gtsam/geometry/Cal3Bundler.h>
+#include <gtsam/geometry/Cal3DS2.h>
 #include <gtsam/geometry/Cal3_S2.h>
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/geometry/Point3.h>
@@ -55,6 +56,7 @@ using namespace gtsam;
 typedef PinholeCamera<Cal3Bundler> Camera;
 typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
 typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
+typedef GenericProjectionFactor<Pose3, Point3, Cal3DS2> ProjFactorDS2;   // calibration entries with distortion (gtg_problem.calib_distortion)
 
 namespace {
 
@@ -191,13 +193,24 @@ void* ref_graph_create(const gtg_problem* p) {
     const double* c = p->calib + 5 * i;
     calibs[i] = std::make_shared<Cal3_S2>(c[0], c[1], c[2], c[3], c[4]);
   }
+  std::vector<std::shared_ptr<Cal3DS2>> calibs_ds2(p->n_calib);   // entries with a non-zero distortion are Cal3DS2 calibrations
+  if (p->calib_distortion)
+    for (int i = 0; i < p->n_calib; i++) {
+      const double* c = p->calib + 5 * i; const double* d = p->calib_distortion + 4 * i;
+      if (d[0] != 0.0 || d[1] != 0.0 || d[2] != 0.0 || d[3] != 0.0)
+        calibs_ds2[i] = std::make_shared<Cal3DS2>(c[0], c[1], c[2], c[3], c[4], d[0], d[1], d[2], d[3]);
+    }
   for (int64_t i = 0; i < p->n_proj; i++) {
     const Point2 z(p->proj_z[2 * i], p->proj_z[2 * i + 1]);
     std::optional<Pose3> sensor;
     if (p->proj_sensor && p->proj_sensor[i] >= 0) sensor = unpackPose(p->sensor + 12 * p->proj_sensor[i]);
     // throwCheirality=false, verboseCheirality=false: the defaults (ProjectionFactor.h:87-92)
-    g->graph.emplace_shared<ProjFactor>(z, noise[p->proj_noise[i]], Key(p->proj_pose[i]),
-                                         Key(p->proj_point[i]), calibs[p->proj_calib[i]], sensor);
+    if (calibs_ds2[p->proj_calib[i]])
+      g->graph.emplace_shared<ProjFactorDS2>(z, noise[p->proj_noise[i]], Key(p->proj_pose[i]),
+                                              Key(p->proj_point[i]), calibs_ds2[p->proj_calib[i]], sensor);
+    else
+      g->graph.emplace_shared<ProjFactor>(z, noise[p->proj_noise[i]], Key(p->proj_pose[i]),
+                                           Key(p->proj_point[i]), calibs[p->proj_calib[i]], sensor);
   }
   g->end[1] = g->beg[2] = g->graph.size();
   for (int64_t i = 0; i < p->n_between; i++) {

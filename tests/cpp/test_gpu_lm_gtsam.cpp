@@ -15,6 +15,9 @@
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
+#include <gtsam/geometry/Cal3DS2.h>
+#include <gtsam/geometry/Cal3_S2.h>
+#include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/slam/ProjectionFactor.h>
 
 #include <chrono>
@@ -266,6 +269,47 @@ int main() {
     graph.addPrior(X(0), truth[0], noiseModel::Diagonal::Variances(Vector3(1e-6, 1e-6, 1e-8)));
     for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract(Vector3(0.2 * N(rng), 0.2 * N(rng), 0.1 * N(rng))));
     compare("Pose2 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
+  }
+  {  // ---- visual SLAM as examples/SFMExample.cpp builds it: Pose3 + Point3, GenericProjectionFactor with a shared calibration --
+    // (a) Cal3_S2, (b) Cal3DS2 (radial + tangential distortion, geometry/Cal3DS2_Base.cpp:93-132), one camera with body_P_sensor
+    for (int variant = 0; variant < 2; variant++) {
+      NonlinearFactorGraph graph; Values initial;
+      const int nx = 8, nl = 40;
+      auto K = std::make_shared<Cal3_S2>(520.0, 515.0, 0.3, 320.0, 240.0);
+      auto Kd = std::make_shared<Cal3DS2>(520.0, 515.0, 0.3, 320.0, 240.0, -0.12, 0.03, 1.5e-3, -2e-3);
+      const Pose3 body_P_sensor(Rot3::RzRyRx(0.02, -0.03, 0.01), Point3(0.1, -0.05, 0.2));
+      std::vector<Pose3> poses; std::vector<Point3> pts;
+      for (int i = 0; i < nx; i++) {
+        const double a = 0.25 * i - 0.9;
+        poses.emplace_back(Rot3::RzRyRx(0.03 * N(rng), -a, 0.03 * N(rng)), Point3(6 * std::sin(a), 0.2 * N(rng), -7 + 1.5 * (1 - std::cos(a))));
+      }
+      for (int j = 0; j < nl; j++) pts.emplace_back(2.5 * N(rng), 1.5 * N(rng), 1.0 * N(rng));
+      auto noise = noiseModel::Isotropic::Sigma(2, 1.0);
+      for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nl; j++) {
+          if ((i + 2 * j) % 4 == 0) continue;
+          const bool sensor = i == 3;
+          const Pose3 cam = sensor ? poses[i].compose(body_P_sensor) : poses[i];
+          Point2 z;
+          try {
+            z = variant ? PinholeCamera<Cal3DS2>(cam, *Kd).project(pts[j]) : PinholeCamera<Cal3_S2>(cam, *K).project(pts[j]);
+          } catch (const CheiralityException&) { continue; }
+          z += Point2(0.5 * N(rng), 0.5 * N(rng));
+          if (variant) {
+            if (sensor) graph.emplace_shared<GenericProjectionFactor<Pose3, Point3, Cal3DS2>>(z, noise, X(i), P(j), Kd, body_P_sensor);
+            else graph.emplace_shared<GenericProjectionFactor<Pose3, Point3, Cal3DS2>>(z, noise, X(i), P(j), Kd);
+          } else {
+            if (sensor) graph.emplace_shared<GenericProjectionFactor<Pose3, Point3, Cal3_S2>>(z, noise, X(i), P(j), K, body_P_sensor);
+            else graph.emplace_shared<GenericProjectionFactor<Pose3, Point3, Cal3_S2>>(z, noise, X(i), P(j), K);
+          }
+        }
+      graph.addPrior(X(0), poses[0], noiseModel::Diagonal::Sigmas((Vector(6) << 0.01, 0.01, 0.01, 0.05, 0.05, 0.05).finished()));
+      graph.addPrior(X(1), poses[1], noiseModel::Diagonal::Sigmas((Vector(6) << 0.01, 0.01, 0.01, 0.05, 0.05, 0.05).finished()));
+      graph.addPrior(P(0), pts[0], noiseModel::Isotropic::Sigma(3, 0.1));
+      for (int i = 0; i < nx; i++) initial.insert(X(i), poses[i].retract((Vector(6) << 0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng), 0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng)).finished()));
+      for (int j = 0; j < nl; j++) initial.insert(P(j), Point3(pts[j] + Point3(0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng))));
+      compare(variant ? "Projection Cal3DS2" : "Projection Cal3_S2", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    }
   }
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;

@@ -123,6 +123,21 @@ def main():
         print(name, "init", out["error"], "final", r["trace"][-1])
 
 
+def cal3ds2():
+    """projection_ds2: GenericProjectionFactor<Pose3, Point3, Cal3DS2> through the real reference (same probes + LM trace)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems as PB
+    name = "projection_ds2"
+    p, v0 = PB.SYNTH[name]()
+    g = ref.RefGraph(p)
+    out = {"values0": v0}
+    out.update(probes(g, p, v0, ordering_kind=1))
+    r = g.lm(v0, LMP(), ordering_kind=1)
+    out["trace"] = r["trace"][:, :3]; out["final_values"] = r["values"]; out["iterations"] = r["iterations"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "init", out["error"], "final", r["trace"][-1])
+
+
 def robust():
     """m-estimator fixtures: graphs of tests/problems.py ROBUST_SYNTH through the real noiseModel::Robust."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -193,8 +208,11 @@ if __name__ == "__main__":
         pose2()
     elif "--robust-only" in sys.argv:
         robust()
+    elif "--cal3ds2-only" in sys.argv:
+        cal3ds2()
     else:
         main()
+        cal3ds2()
         robust()
         pose2()
         logfile()

@@ -46,6 +46,9 @@ SYNTH = {
     "posegraph_small": lambda: D.random_pose_graph(14, 6, seed=3),
     "posegraph_bigrot": lambda: D.random_pose_graph(10, 4, seed=5, rot_scale=1.8, init_noise=0.4),
     "projection_small": lambda: D.random_projection_graph(seed=2),
+    # GenericProjectionFactor<Pose3, Point3, Cal3DS2> (section 8(f) #3): calibration 0 with radial + tangential distortion,
+    # calibration 1 a plain Cal3_S2 -- both branches of the projection in one graph
+    "projection_ds2": lambda: D.random_projection_graph(seed=2, distortion=[[-0.12, 0.03, 1.5e-3, -2e-3], [0, 0, 0, 0]]),
     "bal_small_unit": lambda: bal_problem(*D.synthetic_bal(12, 300, seed=1, n_loops=1), (NOISE_UNIT, ())),
     "bal_small_iso": lambda: bal_problem(*D.synthetic_bal(12, 300, seed=1, n_loops=1), (NOISE_ISOTROPIC, [0.7])),
     # m-estimators (section 8(f) #2): every loss function of linear/LossFunctions.cpp on some graph
@@ -60,7 +63,7 @@ SYNTH = {
 }
 ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projection_cauchy", "projection_tukey",
                 "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy")
-SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "bal_small_unit": 1, "bal_small_iso": 1,
+SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "projection_ds2": 1, "bal_small_unit": 1, "bal_small_iso": 1,
                   "posegraph_huber": 0, "posegraph_fair": 0, "posegraph_welsch": 0, "projection_cauchy": 1,
                   "projection_tukey": 1, "projection_gm": 1, "dubrovnik_huber": 1, "dubrovnik_cauchy": 1}
 

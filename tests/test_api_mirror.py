@@ -84,6 +84,24 @@ def test_extractor_reproduces_the_soa_problem():
         api.extract(g2, vals)
 
 
+def test_cal3ds2_projection_factors_through_the_mirror():
+    """GenericProjectionFactor<Pose3, Point3, Cal3DS2> next to <..., Cal3_S2> in one graph: the extractor hands the library one
+    calibration table with the distortion coefficients beside it (zero row for the plain Cal3_S2), shared objects deduplicated."""
+    nm = api.noiseModel
+    Kd = api.Cal3DS2(520, 515, 0.3, 320, 240, -0.12, 0.03, 1.5e-3, -2e-3); K = api.Cal3_S2(400, 400, 0, 300, 200)
+    graph = api.NonlinearFactorGraph(); vals = api.Values()
+    vals.insert(X(0), api.Pose3()); vals.insert(X(1), api.Pose3()); vals.insert(P(0), np.array([0.1, 0.2, 5.0]))
+    graph.add(api.GenericProjectionFactorCal3DS2([330.0, 250.0], nm.Unit.Create(2), X(0), P(0), Kd))
+    graph.add(api.GenericProjectionFactorCal3_S2([310.0, 210.0], nm.Unit.Create(2), X(1), P(0), K))
+    graph.add(api.GenericProjectionFactorCal3DS2([331.0, 251.0], nm.Unit.Create(2), X(1), P(0), Kd, api.Pose3()))
+    p, _, _ = api.extract(graph, vals)
+    assert list(p.proj_calib) == [0, 1, 0] and list(p.proj_sensor) == [-1, -1, 0]
+    assert np.array_equal(p.calib.reshape(2, 5), [[520, 515, 0.3, 320, 240], [400, 400, 0, 300, 200]])
+    assert np.array_equal(p.calib_distortion.reshape(2, 4), [[-0.12, 0.03, 1.5e-3, -2e-3], [0, 0, 0, 0]])
+    c = p.to_ctypes()
+    assert c.n_calib == 2 and c.calib_distortion[0] == -0.12 and c.calib_distortion[7] == 0.0
+
+
 @pytest.mark.gpu
 def test_general_sfm_factor_B_written_like_the_reference():
     """tests/testGeneralSFMFactorB.cpp:44-63: default LM on dubrovnik-3-7-pre, no priors -> 0.0199833 +- 1e-5."""

@@ -180,6 +180,23 @@ def _numerical_columns(f_b, x, vtype, dim, hm, eps=1e-6):
     return np.stack(cols, 1)
 
 
+def test_cal3ds2_uncalibrate_literal(hm):
+    """geometry/tests/testCal3DS2.cpp:28-45 (TEST(Cal3DS2, Uncalibrate)): K(500, 100, 0.1, 320, 240, 1e-3, 2e-3, 3e-3, 4e-3),
+    intrinsic point (2, 3) -> K * [g x + tx, g y + ty, 1]; here through the device's projection with the camera at the origin
+    looking at (2, 3, 1), i.e. the same intrinsic point; and a zero-distortion entry is the plain Cal3_S2."""
+    K = np.array([500, 100, 0.1, 320, 240, 1e-3, 2e-3, 3e-3, 4e-3], np.float64)
+    x, y = 2.0, 3.0
+    r = x * x + y * y; g = 1 + K[5] * r + K[6] * r * r
+    tx = 2 * K[7] * x * y + K[8] * (r + 2 * x * x); ty = K[7] * (r + 2 * y * y) + 2 * K[8] * x * y
+    expect = np.array([500 * (g * x + tx) + 0.1 * (g * y + ty) + 320, 100 * (g * y + ty) + 240])
+    pose = np.ascontiguousarray(np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])[None]); pw = np.array([[x, y, 1.0]]); z = np.zeros((1, 2)); unit = np.zeros(1)
+    J = np.zeros((1, 20)); hm.hm_proj_linearize(C.c_long(1), P(pose), P(K), None, P(pw), P(z), C.c_int(0), P(unit), P(J))
+    assert np.abs(-J[0, 18:] - expect).max() <= 1e-12 * np.abs(expect).max()     # b = -(h(x) - z), z = 0
+    K2 = K.copy(); K2[5:] = 0
+    J2 = np.zeros((1, 20)); hm.hm_proj_linearize(C.c_long(1), P(pose), P(K2), None, P(pw), P(z), C.c_int(0), P(unit), P(J2))
+    assert np.allclose(-J2[0, 18:], [500 * x + 0.1 * y + 320, 100 * y + 240], rtol=1e-15)
+
+
 def test_device_jacobians_against_numerical_derivatives(hm):
     """The reference's own way of testing a factor (EXPECT_CORRECT_FACTOR_JACOBIANS, numericalDerivative: SURVEY section 4),
     applied to the device formulas: central differences of the residual through the device's retract against the analytic
@@ -204,9 +221,11 @@ def test_device_jacobians_against_numerical_derivatives(hm):
         N2 = _numerical_columns(lambda p: sfm_b(cam, p), pw, 2, 3, hm)
         assert np.abs(N1 - A1).max() <= 1e-6 * max(1.0, np.abs(A1).max()) and np.abs(N2 - A2).max() <= 1e-6 * max(1.0, np.abs(A2).max())
         # ---- GenericProjectionFactor<Pose3, Point3, Cal3_S2>, optional body_P_sensor
-        pose = np.ascontiguousarray(O.pose_pack(R, t)); K = np.array([rng.uniform(400, 900), rng.uniform(400, 900), rng.normal(0, 0.5), 320.0, 240.0])
+        # (the calibration entry is 9 doubles: fx fy s u0 v0 + k1 k2 p1 p2 -- zero for a Cal3_S2, the second pass is a Cal3DS2)
+        pose = np.ascontiguousarray(O.pose_pack(R, t)); K0 = np.array([rng.uniform(400, 900), rng.uniform(400, 900), rng.normal(0, 0.5), 320.0, 240.0, 0, 0, 0, 0])
+        Kd = K0.copy(); Kd[5:] = [rng.normal(0, 5e-2), rng.normal(0, 1e-2), rng.normal(0, 5e-3), rng.normal(0, 5e-3)]
         Rs, ts = O.pose3_expmap(rng.normal(size=(1, 6)) * 0.1); sensor = np.ascontiguousarray(O.pose_pack(Rs, ts)[0])
-        for sen in (None, sensor):
+        for K, sen in ((K0, None), (K0, sensor), (Kd, None), (Kd, sensor)):
             sp = P(sen) if sen is not None else None
             pw2 = pw if sen is None else np.ascontiguousarray((R[0] @ (Rs[0] @ pc + ts[0]) + t[0])[None])
 

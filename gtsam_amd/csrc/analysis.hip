@@ -19,6 +19,7 @@
 #include <set>
 #include <string>
 #include <stdexcept>
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <thread>
 
@@ -56,6 +57,8 @@ template <class T> struct HugeBuf {
   ~HugeBuf() { std::free(p); }
   HugeBuf(const HugeBuf&) = delete;
   HugeBuf& operator=(const HugeBuf&) = delete;
+  HugeBuf(HugeBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
+  HugeBuf& operator=(HugeBuf&& o) noexcept { if (this != &o) { std::free(p); p = o.p; o.p = nullptr; } return *this; }
   T& operator[](size_t i) { return p[i]; }
   T* get() { return p; }
   void reset() { std::free(p); p = nullptr; }
@@ -234,6 +237,24 @@ void analyze(gtg_context& c) {
         }
       }
   };
+  // The term lists come from the device (device_analysis.hip) on a single shard with a real runtime; from the host threads
+  // below for a shard (which needs the blocks of the WHOLE graph but only its own terms), under the dry-run runtime of the CPU
+  // tests (no kernels run there) and with GTG_HOST_ANALYSIS=1 (the A/B: both give bit-identical lists).
+  const bool device_terms = c.n_shards == 1 && c.n_lm > 0 && !std::getenv("GTG_HOST_ANALYSIS") && dlsym(RTLD_DEFAULT, "hipstub_kernel_name") == nullptr;
+  c.device_terms = device_terms;
+  int64_t n_terms = 0;
+  HugeBuf<int32_t> pair_oa(1), pair_ob(1);
+  std::vector<int32_t> pair_row, pair_col;
+  std::vector<int64_t> pair_ptr;
+  if (device_terms) {
+    up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s);
+    std::vector<uint64_t> keys;
+    device_schur_terms(c, obs_pos, nrv, keys, pair_ptr);
+    n_terms = c.n_pair_terms;
+    pair_row.resize(keys.size()); pair_col.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); i++) { pair_row[i] = pos_to_red[keys[i] / (uint64_t)nrv]; pair_col[i] = pos_to_red[keys[i] % (uint64_t)nrv]; }
+    clk.lap("schur terms + block list (device)");
+  } else {
   std::vector<int> lm_cut(nth + 1, c.n_lm);      // landmark ranges with equal numbers of terms
   {
     std::vector<int64_t> cum(c.n_lm + 1, 0);
@@ -251,12 +272,12 @@ void analyze(gtg_context& c) {
     for (int t = 0; t < nth; t++) { const int64_t k = cursor[t][r]; cursor[t][r] = at; at += k; }   // count -> write cursor
     row_ptr[r + 1] = at;
   }
-  const int64_t n_terms = row_ptr[nrv];
+  n_terms = row_ptr[nrv];
   HugeBuf<PT> pt((size_t)std::max<int64_t>(n_terms, 1));                 // first touched by the writers
   run_threads(nth, [&](int t) { auto& w = cursor[t]; for_terms(lm_cut[t], lm_cut[t + 1], [&](int pa, int pb, int32_t oa, int32_t ob) { pt[w[pa]++] = PT{pb, oa, ob}; }); });
   clk.lap("schur terms bucketed");
   // per row bucket: stable counting sort by column position straight into the final term lists + the row's blocks
-  HugeBuf<int32_t> pair_oa((size_t)std::max<int64_t>(n_terms, 1)), pair_ob((size_t)std::max<int64_t>(n_terms, 1));
+  pair_oa = HugeBuf<int32_t>((size_t)std::max<int64_t>(n_terms, 1)); pair_ob = HugeBuf<int32_t>((size_t)std::max<int64_t>(n_terms, 1));
   struct RowBlocks { std::vector<int32_t> col; std::vector<int64_t> start; };
   std::vector<RowBlocks> row_blocks(nrv);
   {
@@ -283,8 +304,6 @@ void analyze(gtg_context& c) {
   }
   pt.reset();
   clk.lap("schur terms sorted");
-  std::vector<int32_t> pair_row, pair_col;
-  std::vector<int64_t> pair_ptr;
   { size_t nb = 0;
     for (int r = 0; r < nrv; r++) nb += row_blocks[r].col.size();
     pair_row.reserve(nb); pair_col.reserve(nb); pair_ptr.reserve(nb + 1);
@@ -293,6 +312,7 @@ void analyze(gtg_context& c) {
         pair_row.push_back(pos_to_red[r]); pair_col.push_back(pos_to_red[row_blocks[r].col[k]]); pair_ptr.push_back(row_blocks[r].start[k]);
       }
     pair_ptr.push_back(n_terms); }
+  }
   c.n_pairs = (int64_t)pair_row.size(); c.n_pair_terms = n_terms;
   clk.lap("schur block list");
 
@@ -354,7 +374,9 @@ void analyze(gtg_context& c) {
   // because a chain is issued at ~45 us of host time per column pair and the separators cost fill. ----
   const char* nd_env = std::getenv("GTG_ND_DEPTH");
   const bool nd_forced = nd_env != nullptr;
+  struct Joiner { std::thread t; std::exception_ptr err; ~Joiner() { if (t.joinable()) t.join(); } } block_level;   // (see below)
   for (int attempt = 0; attempt < 2; attempt++) {
+  if (block_level.t.joinable()) block_level.t.join();   // a second attempt rewrites the ordering the thread reads
   const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : 0) : 0;   // opt-in (GTG_ND_DEPTH=levels), see DESIGN.md
   bool retry_rcm = false;
   std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
@@ -524,11 +546,14 @@ void analyze(gtg_context& c) {
     while (o2 % align) c.h_pad_index.push_back(o2++);
     c.NP = (int)o2;
     // re-orient the blocks: the row variable is the one placed later
+    std::vector<int64_t> flipped;
     for (size_t i = 0; i < pair_row.size(); i++)
       if (c.h_red_pos[pair_row[i]] < c.h_red_pos[pair_col[i]]) {
         std::swap(pair_row[i], pair_col[i]);
-        for (int64_t t = pair_ptr[i]; t < pair_ptr[i + 1]; t++) std::swap(pair_oa[t], pair_ob[t]);
+        if (device_terms) flipped.push_back((int64_t)i);
+        else for (int64_t t = pair_ptr[i]; t < pair_ptr[i + 1]; t++) std::swap(pair_oa[t], pair_ob[t]);
       }
+    device_flip_terms(c, flipped);
     for (size_t i = 0; i < hoff_row.size(); i++)
       if (c.h_red_pos[hoff_row[i]] < c.h_red_pos[hoff_col[i]]) {
         std::swap(hoff_row[i], hoff_col[i]);
@@ -549,7 +574,9 @@ void analyze(gtg_context& c) {
   // ---- block-level symbolic factorisation: the flops the elimination needs at the granularity of the variables (d x d
   // blocks, fill included) -- sum over block columns of f^3/3 + f^2 s + f s^2 (f = the variable's dimension, s = the dimension
   // of its below-diagonal structure), the count SURVEY section 8(d) asks for next to the stored-tile count the kernels execute.
-  {
+  // It only feeds a getter, so it runs on its own host thread beside the tile schedule and the uploads (read-only on the block
+  // lists; joined before analyze() returns, also when something below throws).
+  block_level.t = std::thread([&] { try {
     const int n = c.n_red_vars;
     std::vector<std::vector<int32_t>> below(n);          // positions > own position
     for_each_block([&](int ra, int rb) {
@@ -579,8 +606,7 @@ void analyze(gtg_context& c) {
       if (!sj.empty()) children[sj.front()].push_back(j);
     }
     c.chol_flops_block = fl;
-    clk.lap("block-level symbolic factorisation");
-  }
+  } catch (...) { block_level.err = std::current_exception(); } });
 
   // ---- tile structure of the reduced system -> Cholesky schedule ------------------------------------------------
   {
@@ -684,12 +710,16 @@ void analyze(gtg_context& c) {
   up(c.lm_index, c.h_lm_index, s); up(c.red_index, c.h_red_index, s); up(c.red_off, c.h_red_off, s);
   up(c.lm_owned, lm_owned, s);
   up(c.obs_red, obs_red, s); up(c.obs_lm, obs_lm, s);
-  up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s); up(c.lm_pri_ptr, lm_pri_ptr, s); up(c.lm_pri, lm_pri, s);
+  if (!device_terms) { up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s); }
+  up(c.lm_pri_ptr, lm_pri_ptr, s); up(c.lm_pri, lm_pri, s);
   up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
   up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
-  up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s); up(c.pair_ptr, pair_ptr, s);
-  c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);
-  if (c.n_pair_terms == 0) { c.pair_oa.alloc(1); c.pair_ob.alloc(1); }
+  up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s);
+  if (!device_terms) {   // (the device built pair_ptr / pair_oa / pair_ob in place)
+    up(c.pair_ptr, pair_ptr, s);
+    c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);
+    if (c.n_pair_terms == 0) { c.pair_oa.alloc(1); c.pair_ob.alloc(1); }
+  }
 
   // ---- numeric buffers --------------------------------------------------------------------------
   const size_t NP = c.NP;
@@ -734,6 +764,9 @@ void analyze(gtg_context& c) {
   c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + 2.0 * kSfmRec * 8) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +
                 (double)n_btw * (2 * 4 + 96 + 4 + 2.0 * kBetweenRec * 8) + (double)c.val_size * 8 +
                 (double)c.n_red_vars * 90 * 8 + (double)c.n_lm * 12 * 8 + (double)c.n_hoff * 36 * 8;
+  block_level.t.join();
+  if (block_level.err) std::rethrow_exception(block_level.err);
+  clk.lap("block-level symbolic factorisation (own thread: wait)");
 }
 
 }  // namespace gt

@@ -172,6 +172,7 @@ struct gtg_context {
   gt::DevBuf<int32_t> hoff_row, hoff_col;                            // reduced indices (row pos > col pos)
   gt::DevBuf<int64_t> hoff_ptr;  gt::DevBuf<int32_t> hoff_fac;       // block -> between factors (sign bit = transposed)
   int64_t n_pairs = 0, n_pair_terms = 0;                             // Schur block pairs
+  bool device_terms = false;                                         // their term lists were built on the device (device_analysis.hip)
   gt::DevBuf<int32_t> pair_row, pair_col;
   gt::DevBuf<int64_t> pair_ptr;  gt::DevBuf<int32_t> pair_oa, pair_ob;
 

@@ -33,6 +33,9 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
 void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
 int64_t exchange_block_doubles(const gtg_context& c);                    // size of the block-granular exchange buffer
 void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack);
+// device_analysis.hip: the Schur term lists built on the device (single shard, real runtime)
+void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
+void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
 void exchange_sum(gtg_context& c, double* ptr, int64_t n);   // api.hip: all-reduce (sum) over the shards on the handle's stream; no-op on one shard
 void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail);
 void destroy_chol_streams(gtg_context& c);

@@ -1,0 +1,47 @@
+"""GPU: the Schur term lists built on the device (csrc/device_analysis.hip: count, scan, emit, stable radix sort, run-length
+encode) against the host threads' lists (GTG_HOST_ANALYSIS=1).  The lists fix the summation order of the Schur complement, so
+equal lists mean bit-identical numbers: the step (which depends on every entry of the reduced system and of its right-hand
+side), the four scalars of the lambda try and the layout hash of the two handles must be EQUAL, not close -- on graphs that are reordered (blocks change orientation after the ordering), on one where a camera sees a landmark
+twice (mirrored diagonal terms), on projection factors and on a graph without landmarks."""
+import numpy as np
+import pytest
+
+from tests import problems as PB
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems():
+    from tools import host_profile as HP
+    yield "bal_60_cameras", HP.problem_for("bal:60:6000:7")
+    yield "camera_sees_landmark_twice", HP.problem_for("baldup:40:3000:3")
+    yield "projection_small", PB.SYNTH["projection_small"]()
+    yield "dubrovnik_3_7", PB.dubrovnik_timesfm(load_golden("dubrovnik_3_7"))
+    yield "posegraph_small (no landmarks)", PB.SYNTH["posegraph_small"]()
+
+
+@pytest.mark.parametrize("name,pv", list(_problems()), ids=[n for n, _ in _problems()])
+def test_device_lists_equal_host_lists(name, pv, monkeypatch):
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd import lib as L
+    p, v0 = pv
+
+    def run():
+        dev = L.DeviceGraph(p)
+        dev.set_values(v0)
+        dev.linearize()
+        rc, out = dev.try_lambda(1e-3, True)
+        res = (rc, out.copy(), dev.delta().copy(), dev.structure_hash(), dev.cholesky_flops())
+        dev.close()
+        return res
+
+    monkeypatch.delenv("GTG_HOST_ANALYSIS", raising=False)
+    a = run()
+    monkeypatch.setenv("GTG_HOST_ANALYSIS", "1")
+    b = run()
+    assert a[0] == b[0] == 0
+    assert a[3] == b[3] and a[4] == b[4]
+    assert np.array_equal(a[2], b[2]), np.abs(a[2] - b[2]).max()       # the step, bit for bit
+    assert np.array_equal(a[1], b[1])                                   # linear errors, trial error, |delta|

@@ -101,6 +101,13 @@ static void read_scalars(gtg_context& c) {
   c.h_scalars[SC_DELTA_SQ] /= c.n_shards;  // identical on every shard, summed by the exchange
 }
 
+static void check_smart_supported(gtg_context& c, const char* where) {
+  if (c.n_smart && c.h_scalars[SC_UNSUPPORTED] != 0.0)
+    throw std::runtime_error(std::string(where) + ": a smart factor left the supported subset (its landmark did not triangulate under "
+                             "IGNORE_DEGENERACY / HANDLE_INFINITY, where the reference switches to a point at infinity, or "
+                             "Cal3Bundler::calibrate did not converge, where the reference throws)");
+}
+
 struct PhaseTimer {
   gtg_context& c; int ph; hipEvent_t a, b;
   PhaseTimer(gtg_context& c_, int ph_, hipEvent_t* evs) : c(c_), ph(ph_), a(evs[2 * ph_]), b(evs[2 * ph_ + 1]) {
@@ -172,12 +179,13 @@ int gtg_destroy(gtg_handle c) {
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
                             &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
-                            &c->pair_col, &c->pair_oa, &c->pair_ob};
+                            &c->pair_col, &c->pair_oa, &c->pair_ob, &c->smart_status, &c->smart_cache_state, &c->sfm_smart, &c->lm_smart};
   for (auto* b : i32) b->free();
   c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.bwd_col_off.free(); c->plan.bwd_col_rows.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
-                            &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->pad_index};
+                            &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->smart_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
+  c->smart_params.free(); c->smart_cache_pose.free(); c->smart_cache_point.free();
   c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   free_df_plan(c->df);
   c->pivot_kind.free(); c->tile_exp.free();
@@ -189,14 +197,61 @@ int gtg_destroy(gtg_handle c) {
   return GTG_OK;
 }
 
-int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shards) {
+int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n_shards) {
   GTG_TRY
-  if (!c || !p) throw std::invalid_argument("null argument");
+  if (!c || !p_user) throw std::invalid_argument("null argument");
   if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::invalid_argument("bad shard / n_shards");
   DeviceGuard on_device(c->device);
   StageClock clk;
   hipStream_t s = c->stream;
   c->shard = shard; c->n_shards = n_shards;
+  // Smart factors become what the rest of the library already knows: a hidden POINT3 variable per factor behind the caller's
+  // variables and one GeneralSFM observation per measurement behind the caller's; the tables below are built from this view.
+  gtg_problem q = *p_user;
+  const gtg_problem* p = &q;
+  std::vector<int32_t> x_var_type, x_sfm_cam, x_sfm_point, x_sfm_noise;
+  std::vector<double> x_sfm_z;
+  const int64_t n_smart = p_user->n_smart > 0 ? p_user->n_smart : 0;
+  c->n_smart = n_smart; c->n_user_vars = p_user->n_vars; c->smart_obs0 = p_user->n_sfm;
+  if (n_smart) {
+    if (n_shards > 1) throw std::invalid_argument("smart factors on a sharded graph are not supported");
+    if (!p_user->smart_ptr || !p_user->smart_cam || !p_user->smart_z || !p_user->smart_noise || !p_user->smart_params)
+      throw std::invalid_argument("smart factor tables missing");
+    const int64_t n_meas = p_user->smart_ptr[n_smart];
+    x_var_type.assign(p_user->var_type, p_user->var_type + p_user->n_vars); x_var_type.resize((size_t)p_user->n_vars + n_smart, GTG_VAR_POINT3);
+    x_sfm_cam.assign(p_user->sfm_cam, p_user->sfm_cam + p_user->n_sfm); x_sfm_point.assign(p_user->sfm_point, p_user->sfm_point + p_user->n_sfm);
+    x_sfm_noise.assign(p_user->sfm_noise, p_user->sfm_noise + p_user->n_sfm); x_sfm_z.assign(p_user->sfm_z, p_user->sfm_z + 2 * p_user->n_sfm);
+    std::vector<int32_t> of_obs((size_t)p_user->n_sfm, -1);
+    for (int64_t i = 0; i < n_smart; i++) {
+      const int64_t k0 = p_user->smart_ptr[i], k1 = p_user->smart_ptr[i + 1];
+      if (k1 <= k0 || k1 > n_meas) throw std::invalid_argument("smart factor without measurements / bad smart_ptr");
+      const double* sp = p_user->smart_params + 8 * i;
+      if (!(sp[4] == 0.0 || sp[4] == 1.0 || sp[4] == 2.0)) throw std::invalid_argument("smart factor: unknown degeneracy mode");
+      for (int64_t k = k0; k < k1; k++) {
+        const int cam = p_user->smart_cam[k];
+        if (cam < 0 || cam >= p_user->n_vars || p_user->var_type[cam] != GTG_VAR_SFM_CAMERA)
+          throw std::invalid_argument("smart factor: its keys must be SFM_CAMERA variables");
+        x_sfm_cam.push_back(cam); x_sfm_point.push_back((int32_t)(p_user->n_vars + i)); x_sfm_noise.push_back(p_user->smart_noise[i]);
+        x_sfm_z.push_back(p_user->smart_z[2 * k]); x_sfm_z.push_back(p_user->smart_z[2 * k + 1]);
+        of_obs.push_back((int32_t)i);
+      }
+    }
+    q.n_vars = (int32_t)x_var_type.size(); q.var_type = x_var_type.data();
+    q.n_sfm = (int64_t)x_sfm_cam.size(); q.sfm_cam = x_sfm_cam.data(); q.sfm_point = x_sfm_point.data();
+    q.sfm_noise = x_sfm_noise.data(); q.sfm_z = x_sfm_z.data();
+    std::vector<int64_t> rel(p_user->smart_ptr, p_user->smart_ptr + n_smart + 1);
+    up(c->smart_ptr, rel, s);
+    std::vector<double> prm(p_user->smart_params, p_user->smart_params + 8 * n_smart);
+    up(c->smart_params, prm, s);
+    up(c->sfm_smart, of_obs, s);
+    std::vector<int32_t> none((size_t)n_smart, -1);
+    up(c->smart_cache_state, none, s);
+    c->smart_status.alloc((size_t)n_smart); c->smart_cache_point.alloc(3 * (size_t)n_smart); c->smart_cache_pose.alloc(12 * (size_t)n_meas);
+    check_hip(hipMemsetAsync(c->smart_status.p, 0, sizeof(int32_t) * n_smart, s), "memset");
+  } else {
+    c->smart_ptr.free(); c->smart_params.free(); c->sfm_smart.free(); c->lm_smart.free(); c->smart_status.free();
+    c->smart_cache_state.free(); c->smart_cache_pose.free(); c->smart_cache_point.free();
+  }
   c->n_vars = p->n_vars;
   c->h_var_type.assign(p->var_type, p->var_type + p->n_vars);
   c->h_val_off.assign(p->n_vars + 1, 0); c->h_dim_off.assign(p->n_vars + 1, 0);
@@ -207,6 +262,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
     c->h_dim_off[v + 1] = c->h_dim_off[v] + tangent_dim(t);
   }
   c->val_size = c->h_val_off[p->n_vars]; c->dim_size = c->h_dim_off[p->n_vars];
+  c->user_val_size = c->h_val_off[c->n_user_vars]; c->user_dim_size = c->h_dim_off[c->n_user_vars];
   up(c->var_type, c->h_var_type, s); up(c->val_off, c->h_val_off, s); up(c->dim_off, c->h_dim_off, s);
   c->values.alloc(std::max<int64_t>(c->val_size, 1)); c->trial.alloc(std::max<int64_t>(c->val_size, 1));
   c->delta.alloc(std::max<int64_t>(c->dim_size, 1));
@@ -339,6 +395,16 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p, int shard, int n_shar
   }
   clk.lap("factor tables (shard filter + upload)");
   analyze(*c);
+  if (c->n_smart) {   // landmark index of every smart factor's hidden variable
+    std::vector<int32_t> lm_smart((size_t)std::max(c->n_lm, 1), -1);
+    for (int64_t i = 0; i < c->n_smart; i++) {
+      const int l = c->h_lm_index[c->n_user_vars + i];
+      if (l < 0) throw std::runtime_error("smart factor: its hidden landmark was not classified as a landmark");
+      lm_smart[(size_t)l] = (int32_t)i;
+    }
+    up(c->lm_smart, lm_smart, s);
+    check_hip(hipStreamSynchronize(s), "sync");
+  }
   c->uploaded = true; c->linearized = false; c->have_trial = false;
   return GTG_OK;
   GTG_CATCH
@@ -354,13 +420,13 @@ int gtg_set_reduced_ordering(gtg_handle c, const int32_t* order, int32_t n) {
   GTG_CATCH
 }
 
-int64_t gtg_values_size(gtg_handle c) { return c ? c->val_size : -1; }
-int64_t gtg_tangent_size(gtg_handle c) { return c ? c->dim_size : -1; }
+int64_t gtg_values_size(gtg_handle c) { return c ? c->user_val_size : -1; }
+int64_t gtg_tangent_size(gtg_handle c) { return c ? c->user_dim_size : -1; }
 int64_t gtg_reduced_dim(gtg_handle c) { return c ? c->n_red : -1; }
 
 int gtg_set_values(gtg_handle c, const double* packed, int64_t n) {
   GTG_TRY
-  if (!c || !c->uploaded || n != c->val_size) throw std::invalid_argument("gtg_set_values: wrong size or no problem uploaded");
+  if (!c || !c->uploaded || n != c->user_val_size) throw std::invalid_argument("gtg_set_values: wrong size or no problem uploaded");
   DeviceGuard on_device(c->device);
   check_hip(hipMemcpyAsync(c->values.p, packed, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "H2D");
   check_hip(hipStreamSynchronize(c->stream), "sync");
@@ -378,17 +444,19 @@ static int get_buf(gtg_handle c, const double* dev, int64_t have, double* out, i
   return GTG_OK;
   GTG_CATCH
 }
-int gtg_get_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->values.p : nullptr, c ? c->val_size : -1, packed, n); }
-int gtg_get_trial_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->trial.p : nullptr, c ? c->val_size : -1, packed, n); }
-int gtg_get_delta(gtg_handle c, double* d, int64_t n) { return get_buf(c, c ? c->delta.p : nullptr, c ? c->dim_size : -1, d, n); }
+int gtg_get_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->values.p : nullptr, c ? c->user_val_size : -1, packed, n); }
+int gtg_get_trial_values(gtg_handle c, double* packed, int64_t n) { return get_buf(c, c ? c->trial.p : nullptr, c ? c->user_val_size : -1, packed, n); }
+int gtg_get_delta(gtg_handle c, double* d, int64_t n) { return get_buf(c, c ? c->delta.p : nullptr, c ? c->user_dim_size : -1, d, n); }
 
 int gtg_error(gtg_handle c, double* error) {
   GTG_TRY
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
   DeviceGuard on_device(c->device);
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->values.p, SC_ERROR); }
+  if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});
+  check_smart_supported(*c, "gtg_error");
   *error = c->h_scalars[SC_ERROR];
   return GTG_OK;
   GTG_CATCH
@@ -398,11 +466,18 @@ int gtg_linearize(gtg_handle c) {
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
   DeviceGuard on_device(c->device);
-  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_linearize(*c); }
-  { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c); }
+  if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
+  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false); launch_linearize(*c); }
+  { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c);
+    if (c->n_smart) {   // the cameras' Hessian diagonal is that of the Schur-complemented smart factors: needs their E blocks (undamped)
+      launch_point_eliminate(*c, 1.0, 0, 1e-6, 1e32);
+      launch_smart_hdiag(*c);
+    } }
   exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
+  if (c->n_smart) check_hip(hipMemcpyAsync(c->h_scalars + SC_UNSUPPORTED, c->scalars.p + SC_UNSUPPORTED, sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
   collect(*c, {GTG_PH_LINEARIZE, GTG_PH_ASSEMBLE});
+  check_smart_supported(*c, "gtg_linearize");
   c->linearized = true;
   return GTG_OK;
   GTG_CATCH
@@ -413,7 +488,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda: call gtg_linearize first");
   if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
   DeviceGuard on_device(c->device);
-  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
   if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
@@ -446,14 +521,15 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     }
     if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
     launch_scatter_delta(*c); }
-  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
+  check_smart_supported(*c, "gtg_try_lambda");
   if (c->h_scalars[SC_TIMEOUT] != 0.0) throw std::runtime_error("gtg_try_lambda: a dependency wait of the factorisation ran into its bound (GPU shared or preempted?); the step was not computed");
   if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq)) return GTG_INDETERMINATE;
   out[0] = c->h_scalars[SC_LIN0];
@@ -472,7 +548,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda_pcg: call gtg_linearize first");
   if (!(lambda > 0.0) || !cg) throw std::invalid_argument("gtg_try_lambda_pcg: lambda must be > 0, cg = {max, min, eps_rel, eps_abs}");
   DeviceGuard on_device(c->device);
-  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 2 * sizeof(double), c->stream), "memset");
+  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
   { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
   double g0 = 0.0, g1 = 0.0;
   int its = 0;
@@ -483,13 +559,14 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
     launch_back_substitute(*c);
     if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);   // sharded: every landmark's step from the shard that owns it
     launch_scatter_delta(*c); }
-  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
+  check_smart_supported(*c, "gtg_try_lambda_pcg");
   if (c->h_scalars[SC_FAIL] != 0.0 || !std::isfinite(dsq) || !std::isfinite(g1)) return GTG_INDETERMINATE;
   out[0] = c->h_scalars[SC_LIN0];
   out[1] = c->h_scalars[SC_LIN1];
@@ -511,12 +588,12 @@ int gtg_accept(gtg_handle c) {
 
 int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
   GTG_TRY
-  if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_gradient: linearize first / wrong size");
+  if (!c || !c->linearized || n != c->user_dim_size) throw std::invalid_argument("gtg_get_gradient: linearize first / wrong size");
   DeviceGuard on_device(c->device);
   std::vector<double> gr(9 * (size_t)std::max(c->n_red_vars, 1)), gp(3 * (size_t)std::max(c->n_lm, 1));
   check_hip(hipMemcpy(gr.data(), c->gred0.p, sizeof(double) * gr.size(), hipMemcpyDeviceToHost), "D2H");
   check_hip(hipMemcpy(gp.data(), c->gp.p, sizeof(double) * gp.size(), hipMemcpyDeviceToHost), "D2H");
-  for (int v = 0; v < c->n_vars; v++) {
+  for (int v = 0; v < c->n_user_vars; v++) {   // (the hidden landmarks of smart factors are not the caller's variables)
     double* d = g + c->h_dim_off[v];
     if (c->h_lm_index[v] >= 0) for (int k = 0; k < 3; k++) d[k] = gp[3 * c->h_lm_index[v] + k];
     else for (int k = 0; k < c->h_red_dim[c->h_red_index[v]]; k++) d[k] = gr[9 * c->h_red_index[v] + k];
@@ -527,12 +604,12 @@ int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
 
 int gtg_get_hessian_diagonal(gtg_handle c, double* out, int64_t n) {
   GTG_TRY
-  if (!c || !c->linearized || n != c->dim_size) throw std::invalid_argument("gtg_get_hessian_diagonal: linearize first / wrong size");
+  if (!c || !c->linearized || n != c->user_dim_size) throw std::invalid_argument("gtg_get_hessian_diagonal: linearize first / wrong size");
   DeviceGuard on_device(c->device);
   std::vector<double> hd(c->NP), V(9 * (size_t)std::max(c->n_lm, 1));
   check_hip(hipMemcpy(hd.data(), c->hdiag_red.p, sizeof(double) * hd.size(), hipMemcpyDeviceToHost), "D2H");
   check_hip(hipMemcpy(V.data(), c->V.p, sizeof(double) * V.size(), hipMemcpyDeviceToHost), "D2H");
-  for (int v = 0; v < c->n_vars; v++) {
+  for (int v = 0; v < c->n_user_vars; v++) {
     double* d = out + c->h_dim_off[v];
     if (c->h_lm_index[v] >= 0) for (int k = 0; k < 3; k++) d[k] = V[9 * c->h_lm_index[v] + 4 * k];
     else { const int r = c->h_red_index[v]; for (int k = 0; k < c->h_red_dim[r]; k++) d[k] = hd[c->h_red_off[r] + k]; }
@@ -547,7 +624,7 @@ int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
   DeviceGuard on_device(c->device);
   const double* src; int64_t cnt;
   switch (type) {
-    case GTG_FAC_GENERAL_SFM: src = c->f.sfm_J.p; cnt = c->f.n_sfm * kSfmRec; break;
+    case GTG_FAC_GENERAL_SFM: src = c->f.sfm_J.p; cnt = (c->n_smart ? c->smart_obs0 : c->f.n_sfm) * kSfmRec; break;   // (not the observations of smart factors)
     case GTG_FAC_PROJECTION: src = c->f.proj_J.p; cnt = c->f.n_proj * kProjRec; break;
     case GTG_FAC_BETWEEN_POSE3: src = c->f.between_J.p; cnt = c->f.n_between * kBetweenRec; break;
     case GTG_FAC_PRIOR: src = c->f.prior_J.p; cnt = c->f.n_prior * kPriorRec; break;

@@ -161,13 +161,22 @@ __device__ __forceinline__ double damp_term(double hjj, double invsigma, int dia
 // base/cholesky.cpp:144-157), L^-1 and y = L^-1 gp.
 __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int32_t* __restrict__ owned,
     const double* __restrict__ V, const double* __restrict__ gp, double invsigma, int diag, double dmin,
-    double dmax, double* __restrict__ Linv, double* __restrict__ y, double* __restrict__ fail) {
+    double dmax, double* __restrict__ Linv, double* __restrict__ y, double* __restrict__ fail,
+    const int32_t* __restrict__ lm_smart, const int32_t* __restrict__ smart_status) {
   for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
     if (!owned[l]) continue;
     const double* v = V + 9 * l;
-    const double a00 = v[0] + damp_term(v[0], invsigma, diag, dmin, dmax);
-    const double a11 = v[4] + damp_term(v[4], invsigma, diag, dmin, dmax);
-    const double a22 = v[8] + damp_term(v[8], invsigma, diag, dmin, dmax);
+    // The landmark of a smart factor is eliminated inside the factor: P = (E^T E)^-1 without damping (linearize() passes
+    // lambda = 0, SmartProjectionFactor.h:322-331, CameraSet.h:325-343); one that did not triangulate contributes nothing.
+    const int sm = lm_smart ? lm_smart[l] : -1;
+    if (sm >= 0 && smart_status[sm] != 0) {
+      for (int k = 0; k < 9; k++) Linv[9 * l + k] = 0.0;
+      y[3 * l] = 0.0; y[3 * l + 1] = 0.0; y[3 * l + 2] = 0.0;
+      continue;
+    }
+    const double a00 = v[0] + (sm >= 0 ? 0.0 : damp_term(v[0], invsigma, diag, dmin, dmax));
+    const double a11 = v[4] + (sm >= 0 ? 0.0 : damp_term(v[4], invsigma, diag, dmin, dmax));
+    const double a22 = v[8] + (sm >= 0 ? 0.0 : damp_term(v[8], invsigma, diag, dmin, dmax));
     const double a10 = v[3], a20 = v[6], a21 = v[7];
     bool bad = !(a00 > 0.0);
     const double l00 = sqrt(a00);
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
     int ex2, ex1;
     (void)frexp(l11, &ex2);
     (void)frexp(l22, &ex1);
-    bad = bad || !(ex2 - ex1 < 12);
+    bad = bad || (sm < 0 && !(ex2 - ex1 < 12));   // (choleskyPartial's rank test belongs to the eliminated cliques, not to a smart factor's inverse)
     if (bad) *fail = 1.0;
     // inverse of the lower-triangular factor
     const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
@@ -470,11 +479,60 @@ static inline double inv_sigma(double lambda) {
   return 1.0 / sigma;
 }
 
+// ---- smart factors: what differs from an explicit landmark -------------------------------------------------------------
+// (1) The Hessian factor of a smart factor is the Schur complement of its point, so hessianDiagonal() -- what diagonal damping
+// scales with (LevenbergMarquardtOptimizer.cpp:281-299) -- sees diag(F^T F - F^T E P E^T F) for its cameras, not diag(F^T F):
+// one lane per camera / pose subtracts the squared row norms of E_o = Jc^T Jp L^-T over its smart observations (in list order).
+__global__ __launch_bounds__(kBlock) void k_smart_hdiag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_kind,
+    const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
+    const int32_t* __restrict__ sfm_smart, const int32_t* __restrict__ status, const double* __restrict__ E, double* __restrict__ hdiag) {
+  for (int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x; r < n_red_vars; r += (int64_t)gridDim.x * kBlock) {
+    const int d = red_dim[r];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t k = inc_ptr[r]; k < inc_ptr[r + 1]; k++) {
+      if (inc_kind[k] != 0) continue;                      // GeneralSFM observations only
+      const int64_t o = inc_idx[k];
+      const int sm = sfm_smart[o];
+      if (sm < 0 || status[sm] != 0) continue;
+      const double* Eo = E + kEStride * o;
+      for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * Eo[3 * i] + Eo[3 * i + 1] * Eo[3 * i + 1] + Eo[3 * i + 2] * Eo[3 * i + 2];
+    }
+    for (int i = 0; i < d; i++) hdiag[red_off[r] + i] -= acc[i];
+  }
+}
+// (2) The constant of that Hessian factor is b^T b (CameraSet.h:224), not b^T b - |L^-1 E^T b|^2: linear.error(delta) of the
+// reference lies 0.5 |y_l|^2 per valid smart landmark above the error of the explicit system at the optimal point update.
+__global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32_t* __restrict__ lm_smart, const int32_t* __restrict__ status,
+                                                       const double* __restrict__ ylm, double* __restrict__ scalars) {
+  __shared__ double sm_[kBlock];
+  double acc = 0.0;
+  for (int l = threadIdx.x; l < n_lm; l += kBlock) {
+    const int s = lm_smart[l];
+    if (s >= 0 && status[s] == 0) acc += ylm[3 * l] * ylm[3 * l] + ylm[3 * l + 1] * ylm[3 * l + 1] + ylm[3 * l + 2] * ylm[3 * l + 2];
+  }
+  sm_[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm_[threadIdx.x] += sm_[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) scalars[SC_LIN1] += 0.5 * sm_[0];
+}
+
+void launch_smart_hdiag(gtg_context& c) {
+  if (!c.n_smart) return;
+  hipLaunchKernelGGL(k_smart_hdiag, dim3(grid1(c.n_red_vars)), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p, c.red_inc_kind.p,
+                     c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.sfm_smart.p, c.smart_status.p, c.E.p, c.hdiag_red.p);
+  check_hip(hipGetLastError(), "smart_hdiag");
+}
+void launch_smart_lin1(gtg_context& c) {
+  if (!c.n_smart) return;
+  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_status.p, c.ylm.p, c.scalars.p);
+  check_hip(hipGetLastError(), "smart_lin1");
+}
+
 void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin, double dmax) {
   if (!c.n_lm) return;
   const double is = inv_sigma(lambda);
   hipLaunchKernelGGL(k_point_factor, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.V.p,
-                     c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL);
+                     c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL, c.n_smart ? c.lm_smart.p : nullptr, c.smart_status.p);
   if (c.f.n_sfm)
     hipLaunchKernelGGL((k_obs_E<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
                        c.obs_lm.p, c.Linv.p, c.E.p);

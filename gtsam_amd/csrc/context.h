@@ -25,7 +25,9 @@ constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Ch
 // scalar slots reduced on the device (doubles)
 // SC_TIMEOUT directly follows SC_FAIL: the factorisation gets `scalars + SC_FAIL` and raises [0] for a non-positive pivot, [1] for a
 // dependency wait that ran into its bound (a scheduling problem, reported as an error -- never as "not positive definite")
-enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_TIMEOUT = 6, SC_COUNT = 8 };
+// SC_UNSUPPORTED: a smart factor met a case outside the supported subset (a triangulation that is not VALID under IGNORE_DEGENERACY /
+// HANDLE_INFINITY, where the reference switches to a point at infinity; Cal3Bundler::calibrate not converging, where it throws)
+enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_TIMEOUT = 6, SC_UNSUPPORTED = 7, SC_COUNT = 8 };
 
 template <class T>
 struct DevBuf {
@@ -134,6 +136,19 @@ struct gtg_context {
   std::vector<int32_t> h_var_type;
   std::vector<int64_t> h_val_off, h_dim_off;   // size n_vars+1
   int64_t val_size = 0, dim_size = 0;
+  // Smart factors (SmartProjectionFactor): every factor owns a HIDDEN landmark variable (ids n_user_vars .. n_vars-1, appended
+  // behind the caller's variables, so the caller's values / tangent vectors are prefixes of the device's) that is re-triangulated
+  // from the cameras instead of being optimised; its measurements are GeneralSFM observations smart_obs0 .. of the sfm tables.
+  int32_t n_user_vars = 0;
+  int64_t user_val_size = 0, user_dim_size = 0;
+  int64_t n_smart = 0, smart_obs0 = 0;
+  gt::DevBuf<int64_t> smart_ptr;            // [n_smart + 1] measurements of a factor, relative to smart_obs0
+  gt::DevBuf<double> smart_params;          // 8 per factor (include/gtsam_amd.h)
+  gt::DevBuf<int32_t> smart_status;         // per factor: 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT (triangulation.h:611-612)
+  gt::DevBuf<int32_t> smart_cache_state;    // per factor: -1 nothing cached, else the cached status
+  gt::DevBuf<double> smart_cache_pose;      // 12 per measurement: the camera poses of the cached triangulation
+  gt::DevBuf<double> smart_cache_point;     // 3 per factor
+  gt::DevBuf<int32_t> sfm_smart, lm_smart;  // per sfm observation / per landmark: its smart factor or -1
   gt::DevBuf<int32_t> var_type;
   gt::DevBuf<int64_t> val_off, dim_off;
   gt::DevBuf<double> values, trial, delta;

@@ -51,7 +51,7 @@ struct NoiseTab {
 __global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __restrict__ cam,
     const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz,
     const double* __restrict__ values, const int64_t* __restrict__ val_off, NoiseTab nt,
-    double* __restrict__ J) {
+    double* __restrict__ J, const int32_t* __restrict__ smart_of, const int32_t* __restrict__ smart_status) {
   typedef RecIO<kSfmRec> IO;
   __shared__ double img[kBlock / 64][IO::LDS_DOUBLES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -70,6 +70,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_sfm(int64_t n, const int32_t* __
       // loops index it at run time) and every factor cost 208 B of scratch writes + reads on top of its 208 B record --
       // measured 512 B written per factor (rocprofv3 WRITE_SIZE), 2.46 x the algorithmic bytes
       sfm_linearize(c, p, zz, nt.ref(nz[i]), my + lane * IO::PITCH);
+      // a measurement of a smart factor whose landmark did not triangulate contributes nothing (ZERO_ON_DEGENERACY,
+      // SmartProjectionFactor.h:204-211)
+      if (smart_of && smart_of[i] >= 0 && smart_status[smart_of[i]] != kTriValid)
+        for (int k = 0; k < kSfmRec; k++) my[lane * IO::PITCH + k] = 0.0;
     }
     const int64_t left = n - ch * 64;
     IO::store(my, J + (int64_t)kSfmRec * ch * 64, left < 64 ? (int)left : 64, lane);
@@ -146,6 +150,7 @@ struct ErrArgs {
   const int32_t *bt_v1, *bt_v2, *bt_nz; const double* bt_z;
   const int32_t *pr_var, *pr_nz; const int64_t* pr_off; const double* pr_data;
   const int32_t* var_type; const int64_t* val_off;
+  const int32_t *smart_of, *smart_status;   // smart factors: the factor of an sfm observation (or -1) and its triangulation status
 };
 
 // One launch covers all factor types: block b handles a fixed slice, so the summation order is fixed.
@@ -161,7 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     for (int k = 0; k < 3; k++) p[k] = pp[k];
     zz[0] = a.sfm_z[2 * i]; zz[1] = a.sfm_z[2 * i + 1];
     const int ni = a.sfm_nz[i];
-    acc += sfm_error(c, p, zz, nt.ref(ni));
+    // (a smart factor whose landmark did not triangulate has error 0, SmartProjectionFactor.h:407-427)
+    if (!(a.smart_of && a.smart_of[i] >= 0 && a.smart_status[a.smart_of[i]] != kTriValid)) acc += sfm_error(c, p, zz, nt.ref(ni));
   }
   for (int64_t i = tid; i < a.n_proj; i += stride) {
     double T[12], p[3], zz[2], K[kCalibStride], S[12];
@@ -295,12 +301,71 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(int64_t n, const double* __res
 // ---- launchers --------------------------------------------------------------------------------------
 static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p, c.noise_rkind.p, c.noise_rk.p}; }
 
+// ---- smart factors: the landmark of every factor from the cameras in `values` ------------------------------------------
+// One factor per lane.  What SmartProjectionFactor::triangulateSafe does (SmartProjectionFactor.h:127-183): re-triangulate only
+// when a camera pose moved by more than retriangulationThreshold in some entry since the cached triangulation (Pose3::equals),
+// else reuse the cached result -- the cache is per factor and shared by linearize() and error(), as in the reference, so the
+// sequence of calls is mirrored by the host (gate: the reference does not evaluate the error of a trial step whose linear
+// cost change is negative, LevenbergMarquardtOptimizer.cpp:180-191).  The point goes into the hidden variable's value slot.
+struct SmartArgs {
+  int64_t n, obs0;
+  const int64_t* ptr; const int32_t *sfm_cam, *sfm_point; const double* sfm_z; const int64_t* val_off; const double* params;
+  int32_t *status, *cache_state; double *cache_pose, *cache_point;
+};
+__global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, double* __restrict__ values, const double* __restrict__ gate,
+                                                              double* __restrict__ scalars) {
+  if (gate && !(gate[SC_LIN0] - gate[SC_LIN1] >= 0)) return;
+  for (int64_t sf = blockIdx.x * (int64_t)kBlock + threadIdx.x; sf < a.n; sf += (int64_t)gridDim.x * kBlock) {
+    const int64_t k0 = a.ptr[sf], o0 = a.obs0 + k0;
+    const int m = (int)(a.ptr[sf + 1] - k0);
+    const double* prm = a.params + 8 * sf;
+    const double thr = prm[3];
+    int st;
+    double pt[3] = {0.0, 0.0, 0.0};
+    if (m < 2) {
+      st = kTriDegenerate;
+    } else {
+      bool again = a.cache_state[sf] < 0;
+      for (int k = 0; k < m && !again; k++) {
+        const double* pose = values + a.val_off[a.sfm_cam[o0 + k]];
+        const double* old = a.cache_pose + 12 * (k0 + k);
+        for (int e = 0; e < 12; e++) again = again || fabs(pose[e] - old[e]) > thr;
+      }
+      if (again) {
+        for (int k = 0; k < m; k++) {
+          const double* pose = values + a.val_off[a.sfm_cam[o0 + k]];
+          for (int e = 0; e < 12; e++) a.cache_pose[12 * (k0 + k) + e] = pose[e];
+        }
+        st = smart_triangulate(m, a.sfm_cam + o0, a.val_off, values, a.sfm_z + 2 * o0, prm[0], prm[1], prm[2], pt);
+        a.cache_state[sf] = st;
+        for (int e = 0; e < 3; e++) a.cache_point[3 * sf + e] = pt[e];
+      } else {
+        st = a.cache_state[sf];
+        for (int e = 0; e < 3; e++) pt[e] = a.cache_point[3 * sf + e];
+      }
+    }
+    a.status[sf] = st;
+    double* slot = values + a.val_off[a.sfm_point[o0]];
+    for (int e = 0; e < 3; e++) slot[e] = st == kTriValid ? pt[e] : 0.0;
+    if (st == kTriNoConvergence || (st != kTriValid && prm[4] != 1.0)) scalars[SC_UNSUPPORTED] = 1.0;
+  }
+}
+
+void launch_smart_triangulate(gtg_context& c, double* values, bool gated) {
+  if (!c.n_smart) return;
+  SmartArgs a{c.n_smart, c.smart_obs0, c.smart_ptr.p, c.f.sfm_cam.p, c.f.sfm_point.p, c.f.sfm_z.p, c.val_off.p, c.smart_params.p,
+              c.smart_status.p, c.smart_cache_state.p, c.smart_cache_pose.p, c.smart_cache_point.p};
+  hipLaunchKernelGGL(k_smart_triangulate, dim3(grid_for(c.n_smart)), dim3(kBlock), 0, c.stream, a, values, gated ? c.scalars.p : nullptr, c.scalars.p);
+  check_hip(hipGetLastError(), "smart_triangulate");
+}
+
 void launch_linearize(gtg_context& c) {
   auto& f = c.f;
   NoiseTab nt = noise_tab(c);
   if (f.n_sfm)
     hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p,
-                       f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p);
+                       f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p,
+                       c.n_smart ? c.sfm_smart.p : nullptr, c.smart_status.p);
   if (f.n_proj)
     hipLaunchKernelGGL(k_lin_proj, dim3(grid_for(f.n_proj)), dim3(kBlock), 0, c.stream, f.n_proj, f.proj_pose.p,
                        f.proj_point.p, f.proj_z.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.calib.p,
@@ -323,7 +388,7 @@ void launch_error(gtg_context& c, const double* values, int slot) {
             f.proj_pose.p, f.proj_point.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.proj_z.p, f.calib.p, f.sensor.p,
             f.between_v1.p, f.between_v2.p, f.between_noise.p, f.between_z.p,
             f.prior_var.p, f.prior_noise.p, f.prior_off.p, f.prior_data.p,
-            c.var_type.p, c.val_off.p};
+            c.var_type.p, c.val_off.p, c.n_smart ? c.sfm_smart.p : nullptr, c.smart_status.p};
   const int64_t nmax = std::max(std::max(f.n_sfm, f.n_proj), std::max(f.n_between, f.n_prior));
   const int g = grid_for(nmax);
   hipLaunchKernelGGL(k_error, dim3(g), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p);
@@ -346,8 +411,8 @@ void launch_linear_error(gtg_context& c) {
 void launch_retract(gtg_context& c) {
   hipLaunchKernelGGL(k_retract, dim3(grid_for(c.n_vars)), dim3(kBlock), 0, c.stream, c.n_vars, c.var_type.p,
                      c.val_off.p, c.dim_off.p, c.values.p, c.delta.p, c.trial.p);
-  const int g = grid_for(c.dim_size);
-  hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(kBlock), 0, c.stream, c.dim_size, c.delta.p, c.partials.p);
+  const int g = grid_for(c.user_dim_size);   // |delta| over the caller's variables (not the hidden landmarks of smart factors)
+  hipLaunchKernelGGL(k_sumsq, dim3(g), dim3(kBlock), 0, c.stream, c.user_dim_size, c.delta.p, c.partials.p);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 1, c.scalars.p, (int)SC_DELTA_SQ);
   check_hip(hipGetLastError(), "retract");
 }

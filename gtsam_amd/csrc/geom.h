@@ -252,6 +252,129 @@ GT_HD bool sfm_project(const double* cam, const double* pw, double* pi, double* 
   return true;
 }
 
+// ---- triangulation of a smart factor's landmark (slam/SmartProjectionFactor.h:166-183 -> geometry/triangulation.h:697-752) ----
+// Cal3Bundler::calibrate (geometry/Cal3Bundler.cpp:95-128): the intrinsic point of a pixel by the reference's fixed-point
+// iteration (at most 10 rounds, stops when uncalibrate(pn) is within tol = 1e-5 pixels -- the same rounds, hence the same point).
+// false where the reference throws "fails to converge".
+GT_HD bool bundler_calibrate(double f, double k1, double k2, double u0, double v0, const double* pi, double* pn) {
+  double px = (pi[0] - u0) / f, py = (pi[1] - v0) / f;
+  const double ix = px, iy = py;
+  int iteration = 0;
+  do {
+    const double rr = (px * px) + (py * py);
+    const double g = (1 + k1 * rr + k2 * rr * rr);
+    pn[0] = ix / g; pn[1] = iy / g;
+    const double x = pn[0], y = pn[1], r = x * x + y * y, g2 = 1. + (k1 + k2 * r) * r;
+    const double du = (u0 + f * (g2 * x)) - pi[0], dv = (v0 + f * (g2 * y)) - pi[1];
+    if (sqrt(du * du + dv * dv) <= 1e-5) break;
+    px = pn[0]; py = pn[1];
+    iteration++;
+  } while (iteration < 10);
+  return iteration < 10;
+}
+
+// eigen-decomposition of a symmetric 4x4 matrix by cyclic Jacobi rotations: A -> diagonal, V = eigenvectors (columns)
+GT_HD void jacobi_eig4(double (&A)[4][4], double (&V)[4][4]) {
+  _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; sweep++) {
+    double off = 0.0, dia = 0.0;
+    _Pragma("unroll") for (int p = 0; p < 4; p++) { dia += A[p][p] * A[p][p]; _Pragma("unroll") for (int q = p + 1; q < 4; q++) off += A[p][q] * A[p][q]; }
+    if (off <= 1e-40 * dia || off == 0.0) break;
+    _Pragma("unroll") for (int p = 0; p < 3; p++)
+      _Pragma("unroll") for (int q = p + 1; q < 4; q++) {
+        const double apq = A[p][q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {      // A <- A J
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq;
+        }
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {      // A <- J^T A
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk;
+        }
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+enum { kTriValid = 0, kTriDegenerate = 1, kTriBehindCamera = 2, kTriOutlier = 3, kTriFarPoint = 4, kTriNoConvergence = 5 };
+
+// gtsam::triangulateSafe for PinholeCamera<Cal3Bundler> cameras (triangulation.h:697-752; enableEPI = false, useLOST = false):
+//   undistort every measurement (calibrate with the camera's Cal3Bundler, uncalibrate with its pinhole part, :261-268),
+//   DLT on the projection matrices K [R | t]^-1 (triangulation.cpp:27-57: rows x P_3 - P_1, y P_3 - P_2; the right singular vector
+//   of the smallest singular value, rank = singular values above rank_tol -- here from the eigen-decomposition of A^T A),
+//   rank < 3 -> DEGENERATE, a camera with the point not in front -> BEHIND_CAMERA (:536-541), then per camera the distance
+//   threshold (FAR_POINT) and the largest reprojection error against the outlier threshold (OUTLIER).
+// cams[k] -> values + val_off[cams[k]] = pose (R row-major, t), f, k1, k2, u0, v0; z = 2 per measurement.
+GT_HD int smart_triangulate(int m, const int32_t* cams, const int64_t* val_off, const double* values, const double* z,
+                            double rank_tol, double dist_thr, double outlier_thr, double* point) {
+  point[0] = point[1] = point[2] = 0.0;
+  if (m < 2) return kTriDegenerate;
+  double M[4][4], V[4][4];
+  _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) M[i][j] = 0.0;
+  for (int k = 0; k < m; k++) {
+    const double* c = values + val_off[cams[k]];
+    const double f = c[12], k1 = c[13], k2 = c[14], u0 = c[15], v0 = c[16];
+    double pn[2];
+    if (!bundler_calibrate(f, k1, k2, u0, v0, z + 2 * k, pn)) return kTriNoConvergence;
+    const double zu[2] = {f * pn[0] + u0, f * pn[1] + v0};        // Cal3_S2(f, f, 0, u0, v0).uncalibrate
+    // [R | t]^-1 = [R^T | -R^T t]; P = K [R^T | -R^T t], K = [f 0 u0; 0 f v0; 0 0 1]
+    double W[3][4];
+    _Pragma("unroll") for (int i = 0; i < 3; i++) {
+      W[i][0] = c[0 + i]; W[i][1] = c[3 + i]; W[i][2] = c[6 + i];   // R^T(i, j) = R(j, i)
+      W[i][3] = -(c[0 + i] * c[9] + c[3 + i] * c[10] + c[6 + i] * c[11]);
+    }
+    double r0[4], r1[4];
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {
+      const double P0 = f * W[0][j] + u0 * W[2][j], P1 = f * W[1][j] + v0 * W[2][j], P2 = W[2][j];
+      r0[j] = zu[0] * P2 - P0; r1[j] = zu[1] * P2 - P1;
+    }
+    _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) M[i][j] += r0[i] * r0[j] + r1[i] * r1[j];
+  }
+  jacobi_eig4(M, V);
+  int rank = 0, smallest = 0;
+  _Pragma("unroll") for (int j = 0; j < 4; j++) {
+    const double sv = sqrt(M[j][j] > 0.0 ? M[j][j] : 0.0);
+    if (sv > rank_tol) rank++;
+    if (M[j][j] < M[smallest][smallest]) smallest = j;
+  }
+  if (rank < 3) return kTriDegenerate;
+  double v[4] = {0, 0, 0, 0};
+  _Pragma("unroll") for (int j = 0; j < 4; j++) if (j == smallest) { v[0] = V[0][j]; v[1] = V[1][j]; v[2] = V[2][j]; v[3] = V[3][j]; }
+  point[0] = v[0] / v[3]; point[1] = v[1] / v[3]; point[2] = v[2] / v[3];
+  for (int k = 0; k < m; k++) {       // triangulatePoint3's cheirality check: every camera first
+    const double* c = values + val_off[cams[k]];
+    const double dx[3] = {point[0] - c[9], point[1] - c[10], point[2] - c[11]};
+    double q[3];
+    mat3_tvec(c, dx, q);
+    if (!(q[2] > 0)) return kTriBehindCamera;
+  }
+  double max_err = 0.0;
+  for (int k = 0; k < m; k++) {
+    const double* c = values + val_off[cams[k]];
+    if (dist_thr > 0) {
+      const double dx = point[0] - c[9], dy = point[1] - c[10], dz = point[2] - c[11];
+      if (sqrt(dx * dx + dy * dy + dz * dz) > dist_thr) return kTriFarPoint;
+    }
+    if (outlier_thr > 0) {
+      double cam[17], pi[2];
+      for (int j = 0; j < 17; j++) cam[j] = c[j];
+      if (sfm_project(cam, point, pi, nullptr, nullptr)) {
+        const double eu = pi[0] - z[2 * k], ev = pi[1] - z[2 * k + 1], e = sqrt(eu * eu + ev * ev);
+        max_err = e > max_err ? e : max_err;
+      }
+    }
+  }
+  if (outlier_thr > 0 && max_err > outlier_thr) return kTriOutlier;
+  return kTriValid;
+}
+
 // PinholeCamera<Cal3_S2>(pose, K).project (PinholePose.h:89-109) + Cal3_S2::uncalibrate (geometry/Cal3_S2.cpp:44-50), or, when the
 // table entry carries distortion coefficients, + Cal3DS2_Base::uncalibrate (geometry/Cal3DS2_Base.cpp:93-132, derivative with
 // respect to the intrinsic point D2dintrinsic :71-91).  K = fx, fy, s, u0, v0, k1, k2, p1, p2 (kCalibStride).  Dpose 2x6, Dpoint 2x3.

@@ -257,3 +257,33 @@ def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, be
     v0 = np.concatenate([np.concatenate([(R @ dR).reshape(n_poses, 9), centers + rng.normal(0, 0.05, centers.shape)], 1).reshape(-1),
                          (pts + rng.normal(0, 0.05, pts.shape)).reshape(-1)])
     return p, v0
+
+
+def synthetic_orbit_scene(n_cams=10, n_points=120, seed=0, see=0.7, pixel_noise=0.5, init_noise=(0.01, 0.05)):
+    """A small structure-from-motion scene with a sane field of view (cameras on an arc around a point cloud, every measurement
+    within ~0.5 of the optical axis in intrinsic coordinates, so that Cal3Bundler::calibrate converges): the input of the smart
+    factor tests.  Returns the BAL-style tuple (cams17 -- perturbed --, pts3, obs_cam, obs_pt, obs_z) with the packing of
+    bal_problem (pose R row-major + t, f, k1, k2, u0, v0); every camera sees at least two points, every point is seen twice."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(-0.9, 0.9, n_cams)
+    centers = np.stack([8 * np.sin(ang), 0.3 * rng.normal(size=n_cams), -8 * np.cos(ang)], 1)
+    R = _rodrigues(np.stack([0.02 * rng.normal(size=n_cams), -ang, 0.02 * rng.normal(size=n_cams)], 1))   # looks at the origin (+z)
+    pts = np.stack([rng.uniform(-2, 2, n_points), rng.uniform(-1.5, 1.5, n_points), rng.uniform(-2, 2, n_points)], 1)
+    f = rng.uniform(450, 800, n_cams); k1 = rng.normal(0, 2e-2, n_cams); k2 = rng.normal(0, 2e-3, n_cams)
+    oc, op, oz = [], [], []
+    seen = rng.uniform(size=(n_cams, n_points)) < see
+    seen[:2, :] = True
+    for j in range(n_points):
+        for i in range(n_cams):
+            if not seen[i, j]:
+                continue
+            q = R[i].T @ (pts[j] - centers[i])
+            u, v = q[0] / q[2], q[1] / q[2]
+            rr = u * u + v * v
+            g = 1 + (k1[i] + k2[i] * rr) * rr
+            oc.append(i); op.append(j); oz.append([f[i] * g * u + pixel_noise * rng.normal(), f[i] * g * v + pixel_noise * rng.normal()])
+    dR = _rodrigues(rng.normal(0, init_noise[0], (n_cams, 3)))
+    cams = np.zeros((n_cams, 17))
+    cams[:, :9] = (R @ dR).reshape(n_cams, 9); cams[:, 9:12] = centers + rng.normal(0, init_noise[1], centers.shape)
+    cams[:, 12] = f + rng.normal(0, 1.0, n_cams); cams[:, 13] = k1; cams[:, 14] = k2
+    return cams, pts + rng.normal(0, 0.05, pts.shape), np.array(oc, np.int32), np.array(op, np.int32), np.array(oz)

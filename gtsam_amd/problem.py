@@ -38,6 +38,8 @@ class gtg_problem(C.Structure):
         ("n_prior", C.c_int64), ("prior_var", _i32p), ("prior_off", _i64p), ("prior_data", _f64p),
         ("prior_noise", _i32p),
         ("calib_distortion", _f64p),
+        ("n_smart", C.c_int64), ("smart_ptr", _i64p), ("smart_cam", _i32p), ("smart_z", _f64p), ("smart_noise", _i32p),
+        ("smart_params", _f64p),
     ]
 
 
@@ -67,6 +69,12 @@ class Problem:
     proj_sensor: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     calib: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
     calib_distortion: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))   # [n_calib*4] k1,k2,p1,p2 (Cal3DS2) or empty
+    # SmartProjectionFactor<PinholeCamera<Cal3Bundler>>: one track per factor (include/gtsam_amd.h)
+    smart_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int64))
+    smart_cam: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    smart_z: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
+    smart_noise: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    smart_params: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
     sensor: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float64))
     between_v1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     between_v2: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
@@ -102,6 +110,8 @@ class Problem:
     def n_between(self): return int(self.between_v1.size)
     @property
     def n_prior(self): return int(self.prior_var.size)
+    @property
+    def n_smart(self): return int(self.smart_noise.size)
 
     def val_offsets(self):
         s = np.array([STORAGE[int(t)] for t in self.var_type], np.int64)
@@ -183,8 +193,33 @@ class Problem:
         p.prior_off = ptr(self.prior_off, C.c_int64)
         p.prior_data = ptr(self.prior_data, C.c_double)
         p.prior_noise = ptr(self.prior_noise, C.c_int32)
+        p.n_smart = self.n_smart
+        if self.n_smart:
+            if self.smart_ptr.size != self.n_smart + 1 or self.smart_params.size != 8 * self.n_smart or \
+               self.smart_cam.size != int(self.smart_ptr[-1]) or self.smart_z.size != 2 * self.smart_cam.size:
+                raise ValueError("inconsistent smart factor tables")
+        p.smart_ptr = ptr(np.ascontiguousarray(self.smart_ptr, np.int64), C.c_int64) if self.n_smart else C.cast(None, C.POINTER(C.c_int64))
+        p.smart_cam = ptr(self.smart_cam, C.c_int32)
+        p.smart_z = ptr(self.smart_z, C.c_double)
+        p.smart_noise = ptr(self.smart_noise, C.c_int32)
+        p.smart_params = ptr(self.smart_params, C.c_double)
         p._keep = keep
         return p
+
+    # ---- smart factors -----------------------------------------------------------------------
+    def add_smart(self, cams, zs, noise_idx: int, rank_tolerance=1.0, landmark_distance_threshold=-1.0,
+                  dynamic_outlier_rejection_threshold=-1.0, retriangulation_threshold=1e-5, degeneracy_mode=0):
+        """One SmartProjectionFactor<PinholeCamera<Cal3Bundler>>: camera variable ids + their pixel measurements; defaults =
+        SmartProjectionParams() / TriangulationParameters() (slam/SmartFactorParams.h:58-66, geometry/triangulation.h:583-600)."""
+        cams = _a(cams, np.int32); zs = _a(zs, np.float64)
+        if zs.size != 2 * cams.size or cams.size < 1:
+            raise ValueError("a smart factor needs one 2-vector per camera")
+        self.smart_cam = np.concatenate([self.smart_cam, cams]); self.smart_z = np.concatenate([self.smart_z, zs])
+        self.smart_ptr = np.concatenate([np.asarray(self.smart_ptr, np.int64), [int(self.smart_ptr[-1]) + cams.size]]).astype(np.int64)
+        self.smart_noise = np.concatenate([self.smart_noise, np.array([noise_idx], np.int32)])
+        self.smart_params = np.concatenate([self.smart_params, [rank_tolerance, landmark_distance_threshold,
+                                                                dynamic_outlier_rejection_threshold, retriangulation_threshold,
+                                                                float(degeneracy_mode), 0.0, 0.0, 0.0]])
 
     # ---- priors ------------------------------------------------------------------------------
     def add_prior(self, var: int, value, noise_idx: int):
@@ -214,6 +249,22 @@ def bal_problem(cams17, pts3, obs_cam, obs_pt, obs_z, noise=(NOISE_UNIT, ())):
     p.sfm_noise = np.full(p.sfm_cam.size, ni, np.int32)
     values = np.concatenate([cams17.reshape(-1), pts3.reshape(-1)])
     return p, values
+
+
+def smart_bal_problem(cams17, obs_cam, obs_pt, obs_z, noise=(NOISE_UNIT, ()), min_observations=1, **smart_params):
+    """The BAL graph as timing/timeSFMBALsmart.cpp:33-58 builds it: one SmartProjectionFactor<PinholeCamera<Cal3Bundler>> per track,
+    the cameras are the only variables (symbol C(i)).  Returns (Problem, packed initial values = the cameras)."""
+    cams17 = np.asarray(cams17, np.float64).reshape(-1, 17)
+    p = Problem(var_type=np.full(cams17.shape[0], VAR_SFM_CAMERA, np.int32))
+    ni = p.add_noise(noise[0], 2, noise[1])
+    obs_cam = _a(obs_cam, np.int32); obs_pt = _a(obs_pt, np.int32); obs_z = _a(obs_z, np.float64).reshape(-1, 2)
+    order = np.argsort(obs_pt, kind="stable")
+    starts = np.flatnonzero(np.r_[True, np.diff(obs_pt[order]) != 0, True])
+    for a, b in zip(starts[:-1], starts[1:]):
+        if b - a >= min_observations:
+            idx = order[a:b]
+            p.add_smart(obs_cam[idx], obs_z[idx], ni, **smart_params)
+    return p, cams17.reshape(-1).copy()
 
 
 def pose_graph_problem(n_poses, v1, v2, z12, noise_kind, noise_params):

@@ -114,6 +114,22 @@ typedef struct gtg_problem {
                                      geometry/Cal3DS2_Base.cpp:93-132: GenericProjectionFactor<Pose3, Point3, Cal3DS2>), or NULL:
                                      every entry of the calib table is a plain Cal3_S2.  (Appended in round 2: a caller built
                                      against the older struct must be recompiled.) */
+
+  /* SmartProjectionFactor<PinholeCamera<Cal3Bundler>> (slam/SmartProjectionFactor.h, the factor of timing/timeSFMBALsmart.cpp):
+   * one factor = one track; its landmark is NOT a variable but re-triangulated from the cameras at every linearisation / error
+   * evaluation (DLT, geometry/triangulation.cpp:27-57, checks of triangulateSafe triangulation.h:697-752, cached while no camera
+   * pose moves by more than retriangulationThreshold, SmartProjectionFactor.h:127-183) and eliminated without damping (HESSIAN
+   * linearisation = the Schur complement of the point, :190-233).  NULL / 0: no smart factors. */
+  int64_t n_smart;
+  const int64_t* smart_ptr;       /* [n_smart+1] offsets of a factor's measurements in smart_cam / smart_z (>= 1 measurement each) */
+  const int32_t* smart_cam;       /* variable id (SFM_CAMERA) of every measurement */
+  const double* smart_z;          /* 2 per measurement */
+  const int32_t* smart_noise;     /* [n_smart] index into the noise table (dim 2, Unit or Isotropic as the reference requires) */
+  const double* smart_params;     /* [n_smart*8] rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold,
+                                     retriangulationThreshold, degeneracyMode (0 IGNORE_DEGENERACY, 1 ZERO_ON_DEGENERACY,
+                                     2 HANDLE_INFINITY), 3 reserved.  enableEPI / useLOST / the other linearisation modes are not
+                                     supported; with IGNORE_DEGENERACY / HANDLE_INFINITY a triangulation that is not VALID (the
+                                     reference then uses a point at infinity) is reported as an error */
 } gtg_problem;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

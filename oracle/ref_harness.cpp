@@ -41,6 +41,7 @@
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
+#include <gtsam/slam/SmartProjectionFactor.h>
 #include <gtsam/slam/dataset.h>
 
 #include <chrono>
@@ -56,7 +57,8 @@ using namespace gtsam;
 typedef PinholeCamera<Cal3Bundler> Camera;
 typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
 typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
-typedef GenericProjectionFactor<Pose3, Point3, Cal3DS2> ProjFactorDS2;   // calibration entries with distortion (gtg_problem.calib_distortion)
+typedef GenericProjectionFactor<Pose3, Point3, Cal3DS2> ProjFactorDS2;
+typedef SmartProjectionFactor<Camera> SmartFactor;   // timing/timeSFMBALsmart.cpp:31   // calibration entries with distortion (gtg_problem.calib_distortion)
 
 namespace {
 
@@ -234,6 +236,18 @@ void* ref_graph_create(const gtg_problem* p) {
     else g->graph.addPrior(Key(v), Point3(d[0], d[1], d[2]), nm);
   }
   g->end[3] = g->graph.size();
+  // smart factors (after the four indexed factor types): one per track, parameters as passed
+  for (int64_t i = 0; i < p->n_smart; i++) {
+    const double* sp = p->smart_params + 8 * i;
+    SmartProjectionParams params(HESSIAN, sp[4] == 1.0 ? ZERO_ON_DEGENERACY : (sp[4] == 2.0 ? HANDLE_INFINITY : IGNORE_DEGENERACY), false, false, sp[3]);
+    params.setRankTolerance(sp[0]);
+    params.setLandmarkDistanceThreshold(sp[1]);
+    params.setDynamicOutlierRejectionThreshold(sp[2]);
+    auto f = std::make_shared<SmartFactor>(noise[p->smart_noise[i]], params);
+    for (int64_t k = p->smart_ptr[i]; k < p->smart_ptr[i + 1]; k++)
+      f->add(Point2(p->smart_z[2 * k], p->smart_z[2 * k + 1]), Key(p->smart_cam[k]));
+    g->graph.push_back(f);
+  }
   return g;
 }
 
@@ -597,6 +611,17 @@ int ref_graph_iteration_mt(void* h, const double* values, double lambda, int dia
     if (!status) for (const auto& [key, value] : d) res[5] = std::max(res[5], value.cwiseAbs().maxCoeff());
   }
   return status;
+}
+// gtsam::triangulateSafe (geometry/triangulation.h:697-752) for m PinholeCamera<Cal3Bundler> cameras (17 doubles each):
+// status 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT; point filled when valid
+int ref_triangulate_safe(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
+  CameraSet<Camera> cameras;
+  Point2Vector measured;
+  for (int k = 0; k < m; k++) { cameras.push_back(unpackCamera(cams17 + 17 * k)); measured.emplace_back(z[2 * k], z[2 * k + 1]); }
+  TriangulationParameters params(rank_tol, false, dist_thr, outlier_thr);
+  const TriangulationResult r = triangulateSafe(cameras, measured, params);
+  if (r.valid()) { point[0] = r->x(); point[1] = r->y(); point[2] = r->z(); return 0; }
+  return r.degenerate() ? 1 : r.behindCamera() ? 2 : r.outlier() ? 3 : 4;
 }
 int ref_graph_iteration_phases(void* h, const double* values, double lambda, int diagonal_damping,
                                int ordering_kind, double* ms) {

@@ -138,6 +138,27 @@ def cal3ds2():
     print(name, "init", out["error"], "final", r["trace"][-1])
 
 
+def smart():
+    """smart_orbit*.npz: SmartProjectionFactor graphs through the real reference -- error, Hessian diagonal (of the Schur-complemented
+    Hessian factors), two damped solves, LM traces with the Ceres and the legacy parameters."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems as PB
+    for name, mk in PB.SMART.items():
+        p, v0 = mk()
+        g = ref.RefGraph(p)
+        out = {"values0": v0, "error": g.error(v0), "hessian_diagonal": g.hessian_diagonal(v0)}
+        for i, (lam, dd) in enumerate(((1e-3, False), (1e-4, True))):
+            rc, delta, le = g.solve(v0, lam, dd, ordering_kind=0)
+            out[f"solve{i}_lambda"] = lam; out[f"solve{i}_diag"] = dd; out[f"solve{i}_status"] = rc
+            out[f"solve{i}_delta"] = delta; out[f"solve{i}_linerr"] = le
+            out[f"solve{i}_retract"] = g.retract(v0, delta); out[f"solve{i}_trial_error"] = g.error(out[f"solve{i}_retract"])
+        for tag, prm in (("ceres", LMP.CeresDefaults()), ("legacy", LMP())):
+            r = g.lm(v0, prm, ordering_kind=0)
+            out[tag + "_trace"] = r["trace"][:, :3]; out[tag + "_values"] = r["values"]; out[tag + "_iterations"] = r["iterations"]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "init", out["error"], "ceres", out["ceres_trace"][-1], "legacy", out["legacy_trace"][-1])
+
+
 def robust():
     """m-estimator fixtures: graphs of tests/problems.py ROBUST_SYNTH through the real noiseModel::Robust."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -210,9 +231,12 @@ if __name__ == "__main__":
         robust()
     elif "--cal3ds2-only" in sys.argv:
         cal3ds2()
+    elif "--smart-only" in sys.argv:
+        smart()
     else:
         main()
         cal3ds2()
+        smart()
         robust()
         pose2()
         logfile()

@@ -2,6 +2,7 @@
 // Compiles the per-factor device formulas (gtsam_amd/csrc/geom.h, factors.h) for the HOST with plain
 // g++ so that `-m "not gpu"` tests can pin them against the oracle without a GPU.  This library is
 // never loaded by the product (gtsam_amd/), which has no CPU path.
+#include <vector>
 #include "../../gtsam_amd/csrc/factors.h"
 static gt::NoiseRef NR(int nk, const double* nd) { return gt::NoiseRef{nk, nd, 0, 0.0}; }
 extern "C" {
@@ -43,4 +44,10 @@ double hm_robust_weight(int rk, double k, double d) { return gt::robust_weight(r
 double hm_robust_loss(int rk, double k, double d) { return gt::robust_loss(rk, k, d); }
 void hm_so3_logmap(long n, const double* R, double* w) { for (long i = 0; i < n; i++) gt::so3_logmap(R + 9 * i, w + 3 * i); }
 void hm_so3_expmap(long n, const double* w, double* R) { for (long i = 0; i < n; i++) gt::so3_expmap(w + 3 * i, R + 9 * i); }
+// smart factors: gtsam::triangulateSafe for m PinholeCamera<Cal3Bundler> cameras (17 doubles each) -> status, point
+int hm_smart_triangulate(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
+  std::vector<int32_t> ids(m); std::vector<int64_t> off(m);
+  for (int k = 0; k < m; k++) { ids[k] = k; off[k] = 17 * k; }
+  return gt::smart_triangulate(m, ids.data(), off.data(), cams17, z, rank_tol, dist_thr, outlier_thr, point);
+}
 }

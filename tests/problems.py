@@ -61,6 +61,29 @@ SYNTH = {
     "dubrovnik_huber": lambda: _dubrovnik_robust(ROBUST_HUBER, 1.345),
     "dubrovnik_cauchy": lambda: _dubrovnik_robust(ROBUST_CAUCHY, 5.0),
 }
+
+
+def smart_orbit(degenerate=False):
+    """SmartProjectionFactor<PinholeCamera<Cal3Bundler>> graphs (section 8(f) #3), built like timing/timeSFMBALsmart.cpp from
+    D.synthetic_orbit_scene: cameras are the only variables.  degenerate=True: ZERO_ON_DEGENERACY with tracks that do not
+    triangulate -- single observations (m < 2), a landmark-distance threshold that rejects the far half of the cloud, a
+    dynamic outlier threshold that rejects tracks with a bad measurement."""
+    from gtsam_amd.problem import smart_bal_problem
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(seed=3 if degenerate else 0)
+    if not degenerate:
+        return smart_bal_problem(cams, oc, op, oz)
+    oz = oz.copy()
+    first = np.flatnonzero(np.r_[True, np.diff(op) != 0])
+    oz[first[::9]] += 150.0                                              # a bad measurement in every 9th track
+    keep = np.ones(oc.size, bool)
+    for j in range(5, 120, 11):                                          # these tracks keep a single observation
+        idx = np.flatnonzero(op == j); keep[idx[1:]] = False
+    return smart_bal_problem(cams, oc[keep], op[keep], oz[keep], degeneracy_mode=1, landmark_distance_threshold=10.5,
+                             dynamic_outlier_rejection_threshold=60.0)
+
+
+SMART = {"smart_orbit": lambda: smart_orbit(False), "smart_orbit_degenerate": lambda: smart_orbit(True)}
+
 ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projection_cauchy", "projection_tukey",
                 "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy")
 SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "projection_ds2": 1, "bal_small_unit": 1, "bal_small_iso": 1,

@@ -259,3 +259,42 @@ def test_device_jacobians_against_numerical_derivatives(hm):
         N2 = _numerical_columns(lambda bb: btw2(a, bb)[72:75], b, 3, 3, hm)
         assert np.abs(N1 - J2[0:9].reshape(3, 3)).max() <= 1e-6 * max(1.0, np.abs(J2[0:9]).max())
         assert np.abs(N2 - J2[36:45].reshape(3, 3)).max() <= 1e-6
+
+
+def test_smart_triangulation_against_the_reference(hm, live_ref):
+    """geom.h::smart_triangulate (what k_smart_triangulate runs per smart factor) against gtsam::triangulateSafe of the live
+    reference: same status on well-posed, rank-deficient (two cameras at one place), behind-camera, far and outlier tracks, and
+    the same point to 1e-9 (the reference takes the smallest right singular vector of the DLT matrix by JacobiSVD, the device
+    the smallest eigenvector of A^T A by Jacobi rotations)."""
+    if live_ref is None:
+        pytest.skip("oracle/_ref not present")
+    from gtsam_amd import datasets as D
+    lib = live_ref.lib()
+    lib.ref_triangulate_safe.restype = C.c_int
+    hm.hm_smart_triangulate.restype = C.c_int
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(n_cams=8, n_points=60, seed=11)
+    rng = np.random.default_rng(2)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
+    for j in range(60):
+        idx = np.flatnonzero(op == j)
+        for variant in range(5):
+            cj = np.ascontiguousarray(cams[oc[idx]]); zj = np.ascontiguousarray(oz[idx]).copy()
+            rank_tol, dist, outl = 1.0, -1.0, -1.0
+            if variant == 1:                                   # the same camera twice and nothing else: rank < 3
+                cj = np.ascontiguousarray(np.stack([cj[0], cj[0]])); zj = np.ascontiguousarray(np.stack([zj[0], zj[0]]))
+            elif variant == 2:                                 # two cameras with exchanged, exaggerated disparities: the rays meet behind them
+                cj = np.ascontiguousarray(cj[[0, -1]]); d = zj[-1] - zj[0]
+                zj = np.ascontiguousarray(np.stack([zj[0] + 3.0 * d, zj[-1] - 3.0 * d]))
+            elif variant == 3:
+                dist = 7.5 + 0.5 * rng.uniform()
+            elif variant == 4:
+                zj[0] += 40.0; outl = 15.0
+            m = cj.shape[0]
+            pr = np.zeros(3); pd = np.zeros(3)
+            sr = lib.ref_triangulate_safe(C.c_int(m), P(cj), P(zj), C.c_double(rank_tol), C.c_double(dist), C.c_double(outl), P(pr))
+            sd = hm.hm_smart_triangulate(C.c_int(m), P(cj), P(zj), C.c_double(rank_tol), C.c_double(dist), C.c_double(outl), P(pd))
+            assert sr == sd, (j, variant, sr, sd)
+            seen[sr] += 1
+            if sr == 0:
+                assert np.abs(pr - pd).max() <= 1e-9 * max(1.0, np.abs(pr).max()), (j, variant, pr, pd)
+    assert all(v > 0 for v in seen.values()), seen              # every status occurred

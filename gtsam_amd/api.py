@@ -238,6 +238,31 @@ class GenericProjectionFactorCal3DS2(GenericProjectionFactorCal3_S2):
     """GenericProjectionFactor<Pose3, Point3, Cal3DS2> (wrapped name of slam/slam.i's instantiation): same factor, K a Cal3DS2."""
 
 
+class SmartProjectionParams:
+    """slam/SmartFactorParams.h:42-66 + geometry/triangulation.h:558-600; HESSIAN linearisation only."""
+    IGNORE_DEGENERACY, ZERO_ON_DEGENERACY, HANDLE_INFINITY = 0, 1, 2
+
+    def __init__(self, degeneracyMode=0, retriangulationThreshold=1e-5):
+        self.degeneracyMode, self.retriangulationThreshold = degeneracyMode, retriangulationThreshold
+        self.rankTolerance, self.landmarkDistanceThreshold, self.dynamicOutlierRejectionThreshold = 1.0, -1.0, -1.0
+
+    def setDegeneracyMode(self, m): self.degeneracyMode = m
+    def setRetriangulationThreshold(self, t): self.retriangulationThreshold = t
+    def setRankTolerance(self, t): self.rankTolerance = t
+    def setLandmarkDistanceThreshold(self, t): self.landmarkDistanceThreshold = t
+    def setDynamicOutlierRejectionThreshold(self, t): self.dynamicOutlierRejectionThreshold = t
+
+
+class SmartProjectionFactorPinholeCameraCal3Bundler:
+    """SmartProjectionFactor<PinholeCamera<Cal3Bundler>> (timing/timeSFMBALsmart.cpp:30-48): add(measured, cameraKey) per view."""
+
+    def __init__(self, sharedNoiseModel, params: SmartProjectionParams | None = None):
+        self.model, self.params, self.keys_, self.zs = sharedNoiseModel, params or SmartProjectionParams(), [], []
+
+    def add(self, measured, key):
+        self.zs.append(np.asarray(measured, np.float64)); self.keys_.append(key)
+
+
 class BetweenFactorPose3:
     def __init__(self, key1, key2, measured: Pose3, model):
         self.keys_, self.z, self.model = (key1, key2), measured, model
@@ -343,6 +368,10 @@ def extract(graph: NonlinearFactorGraph, values: Values):
             if f.sensor is not None:
                 si = len(sensors); sensors.append(f.sensor.packed())
             proj.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z, nid(f.model, 2), calibs[ck][0], si))
+        elif isinstance(f, SmartProjectionFactorPinholeCameraCal3Bundler):
+            sp = f.params
+            p.add_smart([vid(k) for k in f.keys_], np.concatenate(f.zs), nid(f.model, 2), sp.rankTolerance, sp.landmarkDistanceThreshold,
+                        sp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold, sp.degeneracyMode)
         elif isinstance(f, BetweenFactorPose3):
             btw.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z.packed(), nid(f.model, 6)))
         elif isinstance(f, BetweenFactorPose2):   # same table: the measurement sits in the first 3 of the 12 doubles

@@ -18,6 +18,7 @@
 #include <gtsam/slam/BetweenFactor.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
+#include <gtsam/slam/SmartProjectionFactor.h>
 
 #include <gtsam/config.h>
 
@@ -56,6 +57,14 @@ typedef PinholeCamera<Cal3Bundler> SfmCamera;
 typedef GeneralSFMFactor<SfmCamera, Point3> SfmFactor;
 typedef GenericProjectionFactor<Pose3, Point3, Cal3_S2> ProjFactor;
 typedef GenericProjectionFactor<Pose3, Point3, Cal3DS2> ProjFactorDS2;
+typedef SmartProjectionFactor<SfmCamera> SmartFactor;   // the factor of timing/timeSFMBALsmart.cpp
+// The smart factor keeps its noise model and its parameters protected and has no accessor for them; a class derived from it may
+// name them, and the pointers to member it forms are ordinary pointers to members of the factor (a maintainer binding this into
+// GTSAM would add two accessors instead).
+struct SmartAccess : SmartFactor {
+  static SharedIsotropic SmartFactorBase<SfmCamera>::* noise() { return &SmartAccess::noiseModel_; }
+  static SmartProjectionParams SmartFactor::* params() { return &SmartAccess::params_; }
+};
 typedef internal::LevenbergMarquardtState State;
 
 struct GpuLevenbergMarquardtOptimizer::Impl {
@@ -204,6 +213,9 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   std::vector<int64_t> pr_off;
   std::map<const void*, int32_t> calib_id;   // shared calibration objects (Cal3_S2 or Cal3DS2) -> row of the calibration table
   std::vector<double> calib_dist;            // k1 k2 p1 p2 per row (zero for a Cal3_S2)
+  std::vector<int64_t> sm_ptr(1, 0);          // smart factors: one track each
+  std::vector<int32_t> sm_cam, sm_nz;
+  std::vector<double> sm_z, sm_prm;
   bool any_distortion = false;
   for (const auto& f : graph_) {
     if (!f) { m.fac_map.emplace_back(-1, 0); continue; }
@@ -245,6 +257,21 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
       pj_cal.push_back(it->second);
       if (pd->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*pd->body_P_sensor(), sensor.data() + sensor.size() - 12); }
       else pj_sen.push_back(-1);
+    } else if (auto sf = std::dynamic_pointer_cast<SmartFactor>(f)) {
+      m.fac_map.emplace_back(-2, (int64_t)sm_nz.size());   // (no Jacobian record: its linearisation is a Hessian factor)
+      const SmartProjectionParams& sp = (*sf).*SmartAccess::params();
+      const TriangulationParameters& tp = sp.triangulation;
+      if (sp.linearizationMode != HESSIAN) throw std::invalid_argument("SmartProjectionFactor: only the HESSIAN linearisation is supported");
+      if (tp.enableEPI || tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: enableEPI / useLOST are not supported");
+      if (sp.throwCheirality) throw std::invalid_argument("SmartProjectionFactor with throwCheirality is not supported");
+      const SharedIsotropic& iso = (*sf).*SmartAccess::noise();
+      sm_nz.push_back(nt.add(iso, 2));
+      const auto& zs = sf->measured();
+      if (zs.size() != sf->keys().size() || zs.empty()) throw std::invalid_argument("SmartProjectionFactor: measurements and keys do not match");
+      for (size_t k = 0; k < zs.size(); k++) { sm_cam.push_back(idOf(sf->keys()[k])); sm_z.push_back(zs[k].x()); sm_z.push_back(zs[k].y()); }
+      sm_ptr.push_back((int64_t)sm_cam.size());
+      sm_prm.insert(sm_prm.end(), {tp.rankTolerance, tp.landmarkDistanceThreshold, tp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold,
+                                   sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0), 0.0, 0.0, 0.0});
     } else if (auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {
       m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
       bt_1.push_back(idOf(b->key1())); bt_2.push_back(idOf(b->key2()));
@@ -280,7 +307,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
     } else {
       throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
                                   "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2|Cal3DS2>, "
-                                  "BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
+                                  "SmartProjectionFactor<SfmCamera>, BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
     }
   }
   gtg_problem pb{};
@@ -293,6 +320,9 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   pb.proj_noise = pj_nz.data(); pb.proj_calib = pj_cal.data(); pb.proj_sensor = pj_sen.data();
   pb.n_calib = (int32_t)(calib.size() / 5); pb.calib = calib.data(); pb.calib_distortion = any_distortion ? calib_dist.data() : nullptr; pb.n_sensor = (int32_t)(sensor.size() / 12); pb.sensor = sensor.data();
   pb.n_between = (int64_t)bt_1.size(); pb.between_v1 = bt_1.data(); pb.between_v2 = bt_2.data(); pb.between_z = bt_z.data(); pb.between_noise = bt_nz.data();
+  pb.n_smart = (int64_t)sm_nz.size(); pb.smart_ptr = sm_ptr.data(); pb.smart_cam = sm_cam.data(); pb.smart_z = sm_z.data();
+  pb.smart_noise = sm_nz.data(); pb.smart_params = sm_prm.data();
+  if (pb.n_smart && shards.n_shards > 1) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: smart factors on a sharded graph are not supported");
   pb.n_prior = (int64_t)pr_var.size(); pb.prior_var = pr_var.data(); pb.prior_off = pr_off.data(); pb.prior_data = pr_data.data(); pb.prior_noise = pr_nz.data();
 
   if (shards.n_shards < 1 || shards.shard < 0 || shards.shard >= shards.n_shards) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: bad ShardSpec");
@@ -447,7 +477,8 @@ GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::downloadLineariz
   static const int64_t width[4] = {26, 20, 78, 90};
   std::vector<double> rec[4];
   int64_t count[4] = {0, 0, 0, 0};
-  for (const auto& tf : m.fac_map) if (tf.first >= 0) count[tf.first]++;
+  for (const auto& tf : m.fac_map) if (tf.first >= 0) count[tf.first]++;   // (-1: null factor, -2: smart factor -- its linearisation is a
+                                                                            // Hessian factor the device never forms: left empty here)
   for (int t = 0; t < 4; t++) {
     if (!count[t]) continue;
     rec[t].resize((size_t)(count[t] * width[t]));

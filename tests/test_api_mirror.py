@@ -102,6 +102,30 @@ def test_cal3ds2_projection_factors_through_the_mirror():
     assert c.n_calib == 2 and c.calib_distortion[0] == -0.12 and c.calib_distortion[7] == 0.0
 
 
+def test_smart_factors_through_the_mirror_give_the_soa_problem():
+    """timing/timeSFMBALsmart.cpp:33-58 written with the mirror: one smart factor per track, cameras the only variables; the
+    extractor must produce the tables of gtsam_amd.problem.smart_bal_problem (the fixture generator's input)."""
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import smart_bal_problem
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(n_cams=5, n_points=12, seed=4)
+    q, w0 = smart_bal_problem(cams, oc, op, oz, degeneracy_mode=1, landmark_distance_threshold=9.0)
+    graph = api.NonlinearFactorGraph(); vals = api.Values()
+    for i in range(5):
+        vals.insert(C(i), api.PinholeCameraCal3Bundler.from_packed(cams[i]))
+    sp = api.SmartProjectionParams(api.SmartProjectionParams.ZERO_ON_DEGENERACY); sp.setLandmarkDistanceThreshold(9.0)
+    for j in range(12):
+        f = api.SmartProjectionFactorPinholeCameraCal3Bundler(api.noiseModel.Unit.Create(2), sp)
+        for k in np.flatnonzero(op == j):
+            f.add(oz[k], C(int(oc[k])))
+        graph.add(f)
+    p, v0, keys = api.extract(graph, vals)
+    assert np.array_equal(v0, w0) and p.n_smart == q.n_smart == 12
+    for name in ("smart_ptr", "smart_cam", "smart_z", "smart_noise", "smart_params"):
+        assert np.array_equal(getattr(p, name), getattr(q, name)), name
+    c = p.to_ctypes()
+    assert c.n_smart == 12 and c.smart_ptr[12] == p.smart_cam.size
+
+
 @pytest.mark.gpu
 def test_general_sfm_factor_B_written_like_the_reference():
     """tests/testGeneralSFMFactorB.cpp:44-63: default LM on dubrovnik-3-7-pre, no priors -> 0.0199833 +- 1e-5."""

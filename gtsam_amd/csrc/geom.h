@@ -74,24 +74,22 @@ GT_HD void so3_logmap(const double* R, double* omega) {
   const double R31 = R[6], R32 = R[7], R33 = R[8];
   const double tr = R11 + R22 + R33;
   if (tr + 1.0 < 1e-3) {
-    double W, Q1, Q2, Q3, o0, o1, o2;
-    if (R33 > R22 && R33 > R11) {
-      W = R21 - R12; Q1 = 2.0 + 2.0 * R33; Q2 = R31 + R13; Q3 = R23 + R32;
-      o0 = Q2; o1 = Q3; o2 = Q1;
-    } else if (R22 > R11) {
-      W = R13 - R31; Q1 = 2.0 + 2.0 * R22; Q2 = R23 + R32; Q3 = R12 + R21;
-      o0 = Q3; o1 = Q1; o2 = Q2;
-    } else {
-      W = R32 - R23; Q1 = 2.0 + 2.0 * R11; Q2 = R12 + R21; Q3 = R31 + R13;
-      o0 = Q1; o1 = Q2; o2 = Q3;
-    }
-    const double r = sqrt(Q1);
-    const double one_over_r = 1 / r;
-    const double norm = sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W);
-    const double sgn_w = W < 0 ? -1.0 : 1.0;
-    const double mag = kPi - (2 * sgn_w * W) / norm;
-    const double scale = 0.5 * one_over_r * mag;
-    omega[0] = sgn_w * scale * o0; omega[1] = sgn_w * scale * o1; omega[2] = sgn_w * scale * o2;
+    // axis a = the largest diagonal entry (ties as in the reference: 3 over 2 over 1), (b, c) the next two cyclically;
+    // along a: 2 + 2 R_aa, along b: R_ab + R_ba, along c: R_ac + R_ca, antisymmetric part R_cb - R_bc
+    double along_a, along_b, along_c, anti;
+    int a;
+    if (R33 > R22 && R33 > R11) { a = 2; anti = R21 - R12; along_a = 2.0 + 2.0 * R33; along_b = R31 + R13; along_c = R23 + R32; }
+    else if (R22 > R11) { a = 1; anti = R13 - R31; along_a = 2.0 + 2.0 * R22; along_b = R23 + R32; along_c = R12 + R21; }
+    else { a = 0; anti = R32 - R23; along_a = 2.0 + 2.0 * R11; along_b = R12 + R21; along_c = R31 + R13; }
+    const double inv_root = 1 / sqrt(along_a);
+    const double len = sqrt(along_a * along_a + along_b * along_b + along_c * along_c + anti * anti);
+    const double sign = anti < 0 ? -1.0 : 1.0;
+    const double angle = kPi - (2 * sign * anti) / len;
+    const double k = 0.5 * inv_root * angle;
+    const double wa = sign * k * along_a, wb = sign * k * along_b, wc = sign * k * along_c;
+    if (a == 2) { omega[0] = wb; omega[1] = wc; omega[2] = wa; }
+    else if (a == 1) { omega[0] = wc; omega[1] = wa; omega[2] = wb; }
+    else { omega[0] = wa; omega[1] = wb; omega[2] = wc; }
   } else {
     double magnitude;
     const double tr_3 = tr - 3.0;

@@ -82,27 +82,20 @@ void so3_logmap(const double R[9], double w[3]) {
   const double R11 = R[0], R12 = R[1], R13 = R[2], R21 = R[3], R22 = R[4], R23 = R[5], R31 = R[6], R32 = R[7], R33 = R[8];
   const double tr = R11 + R22 + R33;
   if (tr + 1.0 < 1e-3) {   // angle close to pi
-    double q[3], scale;
-    if (R33 > R22 && R33 > R11) {
-      const double W = R21 - R12, Q1 = 2.0 + 2.0 * R33, Q2 = R31 + R13, Q3 = R23 + R32;
-      const double r = std::sqrt(Q1), one_over_r = 1 / r, norm = std::sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W);
-      const double sgn_w = W < 0 ? -1.0 : 1.0, mag = M_PI - (2 * sgn_w * W) / norm;
-      scale = 0.5 * one_over_r * mag;
-      q[0] = sgn_w * scale * Q2; q[1] = sgn_w * scale * Q3; q[2] = sgn_w * scale * Q1;
-    } else if (R22 > R11) {
-      const double W = R13 - R31, Q1 = 2.0 + 2.0 * R22, Q2 = R23 + R32, Q3 = R12 + R21;
-      const double r = std::sqrt(Q1), one_over_r = 1 / r, norm = std::sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W);
-      const double sgn_w = W < 0 ? -1.0 : 1.0, mag = M_PI - (2 * sgn_w * W) / norm;
-      scale = 0.5 * one_over_r * mag;
-      q[0] = sgn_w * scale * Q3; q[1] = sgn_w * scale * Q1; q[2] = sgn_w * scale * Q2;
-    } else {
-      const double W = R32 - R23, Q1 = 2.0 + 2.0 * R11, Q2 = R12 + R21, Q3 = R31 + R13;
-      const double r = std::sqrt(Q1), one_over_r = 1 / r, norm = std::sqrt(Q1 * Q1 + Q2 * Q2 + Q3 * Q3 + W * W);
-      const double sgn_w = W < 0 ? -1.0 : 1.0, mag = M_PI - (2 * sgn_w * W) / norm;
-      scale = 0.5 * one_over_r * mag;
-      q[0] = sgn_w * scale * Q1; q[1] = sgn_w * scale * Q2; q[2] = sgn_w * scale * Q3;
-    }
-    w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
+    // axis a = the largest diagonal entry (ties: 3 over 2 over 1), (b, c) the next two cyclically -- same arithmetic as geom.h
+    double along_a, along_b, along_c, anti;
+    int a;
+    if (R33 > R22 && R33 > R11) { a = 2; anti = R21 - R12; along_a = 2.0 + 2.0 * R33; along_b = R31 + R13; along_c = R23 + R32; }
+    else if (R22 > R11) { a = 1; anti = R13 - R31; along_a = 2.0 + 2.0 * R22; along_b = R23 + R32; along_c = R12 + R21; }
+    else { a = 0; anti = R32 - R23; along_a = 2.0 + 2.0 * R11; along_b = R12 + R21; along_c = R31 + R13; }
+    const double inv_root = 1 / std::sqrt(along_a);
+    const double len = std::sqrt(along_a * along_a + along_b * along_b + along_c * along_c + anti * anti);
+    const double sign = anti < 0 ? -1.0 : 1.0;
+    const double k = 0.5 * inv_root * (M_PI - (2 * sign * anti) / len);
+    const double wa = sign * k * along_a, wb = sign * k * along_b, wc = sign * k * along_c;
+    if (a == 2) { w[0] = wb; w[1] = wc; w[2] = wa; }
+    else if (a == 1) { w[0] = wc; w[1] = wa; w[2] = wb; }
+    else { w[0] = wa; w[1] = wb; w[2] = wc; }
     return;
   }
   double magnitude;

@@ -245,7 +245,11 @@ def test_pcg_solver_vs_oracle_and_direct(gpu, name):
             assert abs(its - info["iterations"]) <= 1, (its, info["iterations"])
             # (CG stopped at a 1e-3 relative residual on an ill-conditioned system: rounding differences between two
             #  implementations are amplified to that order; the tight case below is the strong check)
-            assert np.abs(d - d_or).max() <= (5e-3 if its == info["iterations"] else 5e-2) * scale
+            if its != info["iterations"]:   # the stopping test tipped one iteration apart: compare the iterates at the SAME count
+                rc, out, its = dev.try_lambda_pcg(lam, dd, max_iterations=info["iterations"], epsilon_rel=1e-30, epsilon_abs=1e-300)
+                assert rc == 0 and its == info["iterations"]
+                d = dev.delta()
+            assert np.abs(d - d_or).max() <= 5e-3 * scale
         else:                # tight: both are the direct solution (to the conditioning of the BAL shape: 5e-7 in the oracle)
             assert abs(its - info["iterations"]) <= 3, (its, info["iterations"])
             rc2, out2 = dev.try_lambda(lam, dd)
@@ -293,17 +297,16 @@ def test_sphere2500_solve_and_full_trajectory(gpu):
     assert rel(dev.delta(), g["solve_delta"]) <= 1e-6
     assert abs(out[1] - g["solve_linerr"][1]) <= 1e-6 * abs(g["solve_linerr"][1])
     dev.close()
-    # the whole run of BASELINE.md's golden trace: 21 outer / 45 inner iterations, 12 280 978.77 -> 1 136.95214.
-    # The first 11 outer iterations (no rejected lambda) must match step for step; from outer 12 on several lambdas
-    # are rejected per iteration and the accept/reject decisions are FP-marginal -- there the final
-    # error is the criterion (and, as measured, the whole sequence does coincide).
+    # the whole run of BASELINE.md's golden trace: 21 outer / 45 inner iterations, 12 280 978.77 -> 1 136.95214, every
+    # accept / reject decision and every lambda as the reference's (from outer 12 on several lambdas are rejected per
+    # iteration and the decisions are FP-marginal, BASELINE.md -- the sequences coincide nevertheless).
     opt = DeviceLevenbergMarquardt(p, v0, LMP())
     opt.optimize()
     tr = np.array(opt.trace)[:, :3]
     ref_trace = g["trace"]
-    assert np.array_equal(tr[:12, 0], ref_trace[:12, 0])
-    assert rel(tr[:12, 1], ref_trace[:12, 1]) <= 1e-6
-    assert abs(opt.error() - ref_trace[-1, 1]) <= 1e-5 * ref_trace[-1, 1]
+    assert tr.shape == ref_trace.shape and np.array_equal(tr[:, 0], ref_trace[:, 0])      # all 21 outer / 45 inner iterations
+    assert rel(tr[:, 1], ref_trace[:, 1]) <= 1e-6 and np.allclose(tr[:, 2], ref_trace[:, 2], rtol=1e-6)
+    assert abs(opt.error() - ref_trace[-1, 1]) <= 1e-6 * ref_trace[-1, 1]
     assert abs(opt.error() - 1136.95214) < 0.05
     print("sphere2500 outer/inner:", opt.iterations(), opt.getInnerIterations(), "reference:", int(g["iterations"]), int(ref_trace[-1, 0]))
 

@@ -693,6 +693,15 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+  // When the chain kernel has factored the last diagonal tile, the tasks of the last block columns (and the rhs row) are still
+  // being finished: six more bulk workgroups, enqueued BEHIND the chain kernel in its stream, then start on the reserved CUs and
+  // share that tail (same ticket counter).  They must not start earlier: a third persistent kernel running beside the chain on
+  // the reserved CUs (tried: its own stream with the chain's mask) starved the chain -- wait bounds hit.  Measured on L1723:
+  // 5.38 -> 5.29 ms.
+  static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
+  if (extra > 0 && df.n_tasks > grid)
+    hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, df.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
   check_hip(hipEventRecord(df.ev_chain, df.chain), "record");
   check_hip(hipEventRecord(df.ev_bulk, df.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, df.ev_chain, 0), "wait");

@@ -693,11 +693,13 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
-  // When the chain kernel has factored the last diagonal tile, the tasks of the last block columns (and the rhs row) are still
-  // being finished: six more bulk workgroups, enqueued BEHIND the chain kernel in its stream, then start on the reserved CUs and
-  // share that tail (same ticket counter).  They must not start earlier: a third persistent kernel running beside the chain on
-  // the reserved CUs (tried: its own stream with the chain's mask) starved the chain -- wait bounds hit.  Measured on L1723:
-  // 5.38 -> 5.29 ms.
+  // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
+  // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
+  // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
+  // with it (L1723, interleaved A/B on fresh boxes: 5.28-5.32 ms against 5.38-5.39 ms; GTG_DF_EXTRA=0 switches it off): the
+  // end of the chain stream is observed sooner behind a short kernel than directly behind the persistent one.  It must not
+  // start earlier: a third persistent kernel beside the chain on the reserved CUs (tried: its own stream with the chain's
+  // mask) starved the chain -- wait bounds hit.
   static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
   if (extra > 0 && df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, df.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,

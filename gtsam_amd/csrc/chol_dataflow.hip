@@ -697,7 +697,8 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
   // with it (L1723, interleaved A/B on fresh boxes: 5.28-5.32 ms against 5.38-5.39 ms; GTG_DF_EXTRA=0 switches it off): the
-  // end of the chain stream is observed sooner behind a short kernel than directly behind the persistent one.  It must not
+  // end of a stream is observed sooner behind a short kernel than directly behind a persistent one (an empty kernel behind the
+  // bulk kernel instead has the same effect: 5.28 ms).  It must not
   // start earlier: a third persistent kernel beside the chain on the reserved CUs (tried: its own stream with the chain's
   // mask) starved the chain -- wait bounds hit.
   static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;

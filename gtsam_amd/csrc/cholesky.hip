@@ -962,7 +962,8 @@ void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& pl
   const int nt = NP / T;
   double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
   const size_t smem_inv = sizeof(double) * 17 * SB * SB;
-  static const bool per_row = [] { const char* e = std::getenv("GTG_BWD"); return e && std::string(e) == "steps"; }();
+  const char* bwd_env = std::getenv("GTG_BWD");   // (read per call: the A/B test switches it inside one process)
+  const bool per_row = bwd_env && std::string(bwd_env) == "steps";
   {
     static std::set<int> attr_set;
     static std::mutex attr_mutex;

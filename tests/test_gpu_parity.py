@@ -184,6 +184,32 @@ def test_nested_dissection_tree_schedule_is_equivalent(gpu, monkeypatch):
     assert rel(tr[:, 1], g["trace"][:, 1]) <= 1e-6
 
 
+def test_backward_sweep_equals_the_per_row_launches(gpu, monkeypatch):
+    """The one-launch backward sweep (k_bwd_sweep: left-looking, dependencies polled on the entries of x) against the round-1 form
+    (GTG_BWD=steps: one launch per block row, right-looking): the same triangular solve in another association order."""
+    for name in ("sphere2500", "bal_60"):
+        if name == "sphere2500":
+            p, v0 = PB.sphere2500(load_golden("sphere2500")); lam, dd = 1e-5, False
+        else:
+            from gtsam_amd import datasets as D
+            from gtsam_amd.problem import bal_problem
+            p, v0 = bal_problem(*D.synthetic_bal(60, 6000, seed=7)); lam, dd = 1e-4, True
+        res = []
+        for mode in (None, "steps"):
+            if mode:
+                monkeypatch.setenv("GTG_BWD", mode)
+            else:
+                monkeypatch.delenv("GTG_BWD", raising=False)
+            dev = gpu.DeviceGraph(p)
+            dev.set_values(v0); dev.linearize()
+            rc, out = dev.try_lambda(lam, dd)
+            assert rc == 0
+            res.append((dev.delta().copy(), out.copy()))
+            dev.close()
+        monkeypatch.delenv("GTG_BWD", raising=False)
+        assert rel(res[0][0], res[1][0]) <= 1e-11 and np.allclose(res[0][1], res[1][1], rtol=1e-11)
+
+
 def test_orderings_give_the_same_step(gpu, monkeypatch):
     """The elimination order changes the fill and the schedule, never the step: a caller's ordering
     (gtg_set_reduced_ordering, the reference's params.ordering / Ordering argument of the optimizer's constructor,

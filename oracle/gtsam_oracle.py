@@ -529,6 +529,105 @@ def jacobians_flat(p: Problem, values, ftype):
     return np.concatenate([A1.reshape(n, -1), A2.reshape(n, -1), b], 1)
 
 
+# ------------------------------------------------------------------------------------------------
+# SmartProjectionFactor<PinholeCamera<Cal3Bundler>> (slam/SmartProjectionFactor.h, SmartFactorBase.h, geometry/triangulation.*)
+# Restated WITHOUT the factor's triangulation cache (SmartProjectionFactor.h:127-183): every call triangulates afresh, which is
+# what the reference does whenever some camera pose moved by more than retriangulationThreshold -- true for the probes the
+# fixtures hold (error, Hessian diagonal, one damped solve and its trial error from the initial values).
+# ------------------------------------------------------------------------------------------------
+TRI_VALID, TRI_DEGENERATE, TRI_BEHIND, TRI_OUTLIER, TRI_FAR = 0, 1, 2, 3, 4
+
+
+def bundler_calibrate(f, k1, k2, u0, v0, pi):
+    """Cal3Bundler::calibrate (geometry/Cal3Bundler.cpp:95-128): the reference's fixed-point iteration, tol 1e-5, <= 10 rounds."""
+    px, py = (pi[0] - u0) / f, (pi[1] - v0) / f
+    ix, iy = px, py
+    for _ in range(10):
+        rr = px * px + py * py
+        g = 1 + k1 * rr + k2 * rr * rr
+        pn = np.array([ix / g, iy / g])
+        r = pn @ pn; g2 = 1. + (k1 + k2 * r) * r
+        if np.hypot(u0 + f * g2 * pn[0] - pi[0], v0 + f * g2 * pn[1] - pi[1]) <= 1e-5:
+            return pn
+        px, py = pn
+    raise RuntimeError("Cal3Bundler::calibrate fails to converge")
+
+
+def triangulate_safe(cams17, z, rank_tol=1.0, dist_thr=-1.0, outlier_thr=-1.0):
+    """gtsam::triangulateSafe (geometry/triangulation.h:697-752) with enableEPI = useLOST = false: undistort, DLT by SVD
+    (triangulation.cpp:27-57, base/Matrix.cpp:566-584), cheirality, distance and outlier checks.  -> (status, point)."""
+    m = cams17.shape[0]
+    if m < 2:
+        return TRI_DEGENERATE, None
+    A = np.zeros((2 * m, 4))
+    for k in range(m):
+        c = cams17[k]; R = c[:9].reshape(3, 3); t = c[9:12]; f, k1, k2, u0, v0 = c[12:17]
+        pn = bundler_calibrate(f, k1, k2, u0, v0, z[k])
+        zu = np.array([f * pn[0] + u0, f * pn[1] + v0])
+        K = np.array([[f, 0, u0], [0, f, v0], [0, 0, 1.0]])
+        P = K @ np.concatenate([R.T, (-R.T @ t)[:, None]], 1)
+        A[2 * k] = zu[0] * P[2] - P[0]; A[2 * k + 1] = zu[1] * P[2] - P[1]
+    _, sv, Vt = np.linalg.svd(A)
+    if int(np.sum(sv[:min(2 * m, 4)] > rank_tol)) < 3:
+        return TRI_DEGENERATE, None
+    v = Vt[-1]; pt = v[:3] / v[3]
+    for k in range(m):
+        R = cams17[k, :9].reshape(3, 3)
+        if (R.T @ (pt - cams17[k, 9:12]))[2] <= 0:
+            return TRI_BEHIND, None
+    max_err = 0.0
+    for k in range(m):
+        if dist_thr > 0 and np.linalg.norm(pt - cams17[k, 9:12]) > dist_thr:
+            return TRI_FAR, None
+        if outlier_thr > 0:
+            pi, _, _, _ = sfm_project(cams17[k:k + 1], pt[None])
+            max_err = max(max_err, float(np.linalg.norm(pi[0] - z[k])))
+    if outlier_thr > 0 and max_err > outlier_thr:
+        return TRI_OUTLIER, None
+    return TRI_VALID, pt
+
+
+def _smart_factors(p: Problem, values):
+    """Per smart factor: (camera ids, whitened F blocks [m,2,9], E [2m,3], b [2m]) for a VALID triangulation, else None
+    (ZERO_ON_DEGENERACY: the factor contributes nothing; the other degeneracy modes are outside the restated subset)."""
+    off = p.val_offsets(); values = np.asarray(values, np.float64)
+    out = []
+    for i in range(p.n_smart):
+        k0, k1 = int(p.smart_ptr[i]), int(p.smart_ptr[i + 1])
+        cams = p.smart_cam[k0:k1]; z = p.smart_z.reshape(-1, 2)[k0:k1]
+        c17 = np.stack([values[off[c]:off[c] + 17] for c in cams])
+        prm = p.smart_params.reshape(-1, 8)[i]
+        st, pt = triangulate_safe(c17, z, prm[0], prm[1], prm[2])
+        if st != TRI_VALID:
+            if prm[4] != 1.0:
+                raise NotImplementedError("smart factor: point at infinity (IGNORE_DEGENERACY / HANDLE_INFINITY) is not restated")
+            out.append(None); continue
+        pi, Dc, Dp, behind = sfm_project(c17, np.repeat(pt[None], len(cams), 0))
+        W = noise_sqrt_info(p, int(p.smart_noise[i]))                      # 2x2 (Unit / Isotropic)
+        F = np.einsum("ij,mjk->mik", W, Dc); E = np.einsum("ij,mjk->mik", W, Dp).reshape(-1, 3)
+        b = (-(pi - z) @ W.T).reshape(-1)                                   # b = -whiten(h(x) - z), SmartFactorBase.h:296-316
+        out.append(([int(c) for c in cams], F, E, b))
+    return out
+
+
+def _smart_hessians(p: Problem, values):
+    """createHessianFactor (SmartProjectionFactor.h:190-233) = CameraSet::SchurComplement (CameraSet.h:174-226) with lambda = 0:
+    G = F^T F - F^T E P E^T F, g = F^T (b - E P E^T b), f = b^T b, P = (E^T E)^-1.  -> list of (camera ids, G, g, f)."""
+    res = []
+    for sf in _smart_factors(p, values):
+        if sf is None:
+            continue
+        cams, F, E, b = sf
+        m = len(cams)
+        P = np.linalg.inv(E.T @ E)
+        Fd = np.zeros((2 * m, 9 * m))
+        for k in range(m):
+            Fd[2 * k:2 * k + 2, 9 * k:9 * k + 9] = F[k]
+        Q = np.eye(2 * m) - E @ P @ E.T
+        res.append((cams, Fd.T @ Q @ Fd, Fd.T @ (Q @ b), float(b @ b)))
+    return res
+
+
 def error(p: Problem, values):
     """NonlinearFactorGraph::error (NonlinearFactorGraph.cpp:170-179) = sum 0.5*||whiten(r)||^2
     (NonlinearFactor.cpp:136-147), or the m-estimator loss of ||whiten(r)|| for Robust models.  b of the un-reweighted
@@ -539,6 +638,10 @@ def error(p: Problem, values):
     e = 0.0
     for ft, tup in lin.items():
         e += _loss_many(p, nz[ft], tup[2])
+    if getattr(p, "n_smart", 0):                          # totalReprojectionError (SmartProjectionFactor.h:407-427): 0.5 |b|^2 or 0
+        for sf in _smart_factors(p, values):
+            if sf is not None:
+                e += 0.5 * float(sf[3] @ sf[3])
     return e
 
 
@@ -578,6 +681,13 @@ def hessian_dense(p: Problem, values):
             g[si] += As[i].T @ b
             for j, vj in enumerate(vids):
                 H[si, slice(doff[vj], doff[vj + 1])] += As[i].T @ As[j]
+    if getattr(p, "n_smart", 0):
+        lin = dict(lin); lin["smart"] = _smart_hessians(p, values)
+        for cams, G, gg, f in lin["smart"]:
+            for a, ca in enumerate(cams):
+                g[doff[ca]:doff[ca + 1]] += gg[9 * a:9 * a + 9]
+                for bb, cb in enumerate(cams):
+                    H[doff[ca]:doff[ca + 1], doff[cb]:doff[cb + 1]] += G[9 * a:9 * a + 9, 9 * bb:9 * bb + 9]
     return H, g, lin
 
 
@@ -589,6 +699,10 @@ def hessian_diagonal(p: Problem, values):
     for vids, As, b in _factor_blocks(p, lin):
         for i, vi in enumerate(vids):
             d[doff[vi]:doff[vi + 1]] += np.sum(As[i] * As[i], 0)
+    if getattr(p, "n_smart", 0):                          # HessianFactor::hessianDiagonal: the diagonal of the Schur-complemented G
+        for cams, G, gg, f in _smart_hessians(p, values):
+            for a, ca in enumerate(cams):
+                d[doff[ca]:doff[ca + 1]] += np.diag(G)[9 * a:9 * a + 9]
     return d
 
 
@@ -743,6 +857,9 @@ def linear_error(p: Problem, lin, delta):
         for i, vi in enumerate(vids):
             r += As[i] @ delta[doff[vi]:doff[vi + 1]]
         e += 0.5 * float(r @ r)
+    for cams, G, gg, f in (lin.get("smart", ()) if isinstance(lin, dict) else ()):   # HessianFactor::error: 0.5 (f - 2 x^T g + x^T G x)
+        x = np.concatenate([delta[doff[c]:doff[c + 1]] for c in cams])
+        e += 0.5 * (f - 2.0 * float(x @ gg) + float(x @ G @ x))
     return e
 
 

@@ -155,7 +155,7 @@ int gtg_upload_problem(gtg_handle h, const gtg_problem* p, int shard, int n_shar
 int gtg_set_reduced_ordering(gtg_handle h, const int32_t* order, int32_t n);
 
 /* Values in packed storage, variable id order (see GTG_VAR_*).  Values.h:74-79. */
-int64_t gtg_values_size(gtg_handle h);   /* doubles in the packed Values */
+int64_t gtg_values_size(gtg_handle h);   /* doubles in the packed Values (the caller's variables: the landmarks of smart factors are internal) */
 int64_t gtg_tangent_size(gtg_handle h);  /* dimension of delta (VectorValues) */
 int gtg_set_values(gtg_handle h, const double* packed, int64_t n);
 int gtg_get_values(gtg_handle h, double* packed, int64_t n);        /* current (accepted) values */
@@ -180,7 +180,10 @@ int gtg_linearize(gtg_handle h);
  *   out[0] = linear.error(0)   out[1] = linear.error(delta)   out[2] = graph.error(trial values)
  *   out[3] = ||delta||_2
  * The trial values stay on the device until gtg_accept(). If linear cost change < 0 the retract /
- * error step is skipped exactly like LM.cpp:178 and out[2] = +inf. */
+ * error step is skipped exactly like LM.cpp:178 and out[2] = +inf.
+ * Errors (negative return, text in gtg_last_error): a dependency wait of the factorisation ran into its bound (GPU shared or
+ * preempted: "the step was not computed" -- never reported as GTG_INDETERMINATE); a smart factor left the supported subset
+ * (gtg_problem.smart_params; also from gtg_linearize and gtg_error). */
 int gtg_try_lambda(gtg_handle h, double lambda, int diagonal_damping, double min_diagonal,
                    double max_diagonal, double out[4]);
 

@@ -184,3 +184,45 @@ def test_degenerate_graphs_through_the_host_path(stub):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     ok = [line for line in r.stdout.splitlines() if line.startswith("ok ")]
     assert len(ok) == 10 and any("bal 17 cameras nt 2" in line for line in ok)
+
+
+def test_smart_factors_upload_hidden_landmarks_behind_the_callers_variables(stub):
+    """Host side of the smart factors under the dry-run runtime: every factor gets a hidden landmark behind the caller's
+    variables (sizes reported to the caller are those of the cameras only), its measurements become observations of the
+    reduced system's cameras, and malformed tables are rejected loudly."""
+    d = HP.run_snippet('''
+import sys, json
+import numpy as np
+from gtsam_amd import lib as L
+from tests import problems as PB
+p, v0 = PB.SMART["smart_orbit_degenerate"]()
+g = L.DeviceGraph(p)
+out = {"val_size": int(g.val_size), "dim_size": int(g.dim_size), "reduced_dim": int(g.reduced_dim), "n_vars": int(p.n_vars), "n_smart": int(p.n_smart)}
+g.set_values(v0)
+bad = 0
+try:
+    g.set_values(np.concatenate([v0, np.zeros(3)]))          # the hidden landmarks are not the caller's to set
+except L.GtsamAmdError:
+    bad += 1
+g.close()
+q, _ = PB.SMART["smart_orbit"]()
+q.smart_cam = q.smart_cam.copy(); q.smart_cam[0] = 10**6     # not a variable
+try:
+    L.DeviceGraph(q)
+except L.GtsamAmdError:
+    bad += 1
+q, _ = PB.SMART["smart_orbit"]()
+q.smart_params = q.smart_params.copy(); q.smart_params[4] = 7.0   # unknown degeneracy mode
+try:
+    L.DeviceGraph(q)
+except L.GtsamAmdError:
+    bad += 1
+try:
+    L.DeviceGraph(PB.SMART["smart_orbit"]()[0], shard=0, n_shards=2)
+except L.GtsamAmdError:
+    bad += 1
+out["rejected"] = bad
+print("RESULT " + json.dumps(out))
+''')
+    assert d["val_size"] == 17 * d["n_vars"] and d["dim_size"] == 9 * d["n_vars"] == d["reduced_dim"]
+    assert d["n_smart"] > 100 and d["rejected"] == 4

@@ -486,19 +486,28 @@ static inline double inv_sigma(double lambda) {
 __global__ __launch_bounds__(kBlock) void k_smart_hdiag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_kind,
     const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
     const int32_t* __restrict__ sfm_smart, const int32_t* __restrict__ status, const double* __restrict__ E, double* __restrict__ hdiag) {
-  for (int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x; r < n_red_vars; r += (int64_t)gridDim.x * kBlock) {
-    const int d = red_dim[r];
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t k = inc_ptr[r]; k < inc_ptr[r + 1]; k++) {
-      if (inc_kind[k] != 0) continue;                      // GeneralSFM observations only
-      const int64_t o = inc_idx[k];
-      const int sm = sfm_smart[o];
-      if (sm < 0 || status[sm] != 0) continue;
-      const double* Eo = E + kEStride * o;
-      for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * Eo[3 * i] + Eo[3 * i + 1] * Eo[3 * i + 1] + Eo[3 * i + 2] * Eo[3 * i + 2];
-    }
-    for (int i = 0; i < d; i++) hdiag[red_off[r] + i] -= acc[i];
+  // one workgroup per camera / pose: the incidence list dealt round-robin to the lanes, partial sums combined in lane order
+  // (a lane per camera took 50 ms per linearisation on a 150-camera scene with 1 500 measurements each)
+  __shared__ double part[kBlock][9];
+  const int r = blockIdx.x;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t k = inc_ptr[r] + threadIdx.x; k < inc_ptr[r + 1]; k += kBlock) {
+    if (inc_kind[k] != 0) continue;                      // GeneralSFM observations only
+    const int64_t o = inc_idx[k];
+    const int sm = sfm_smart[o];
+    if (sm < 0 || status[sm] != 0) continue;
+    const double* Eo = E + kEStride * o;
+    for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * Eo[3 * i] + Eo[3 * i + 1] * Eo[3 * i + 1] + Eo[3 * i + 2] * Eo[3 * i + 2];
   }
+  for (int i = 0; i < 9; i++) part[threadIdx.x][i] = acc[i];
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) for (int i = 0; i < 9; i++) part[threadIdx.x][i] += part[threadIdx.x + s][i];
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < d) hdiag[red_off[r] + threadIdx.x] -= part[0][threadIdx.x];
 }
 // (2) The constant of that Hessian factor is b^T b (CameraSet.h:224), not b^T b - |L^-1 E^T b|^2: linear.error(delta) of the
 // reference lies 0.5 |y_l|^2 per valid smart landmark above the error of the explicit system at the optimal point update.
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32
 
 void launch_smart_hdiag(gtg_context& c) {
   if (!c.n_smart) return;
-  hipLaunchKernelGGL(k_smart_hdiag, dim3(grid1(c.n_red_vars)), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p, c.red_inc_kind.p,
+  hipLaunchKernelGGL(k_smart_hdiag, dim3((unsigned)std::max(c.n_red_vars, 1)), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p, c.red_inc_kind.p,
                      c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.sfm_smart.p, c.smart_status.p, c.E.p, c.hdiag_red.p);
   check_hip(hipGetLastError(), "smart_hdiag");
 }

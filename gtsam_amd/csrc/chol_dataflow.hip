@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <map>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -629,10 +630,6 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
 
 void free_df_plan(DfPlan& df) {
   df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.part_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
-  if (df.bulk) (void)hipStreamDestroy(df.bulk);
-  if (df.chain) (void)hipStreamDestroy(df.chain);
-  for (hipEvent_t e : {df.ev_start, df.ev_chain, df.ev_bulk}) if (e) (void)hipEventDestroy(e);
-  df.bulk = df.chain = nullptr; df.ev_start = df.ev_chain = df.ev_bulk = nullptr; df.grid = 0;
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
@@ -651,7 +648,16 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
       attr_set.insert(c.device);
     }
   }
-  if (!df.bulk) {
+  // The two CU-masked streams and their events belong to the DEVICE, not to the handle: a process runs one dataflow
+  // factorisation per device at a time (the caller holds that device's lock, api.hip), and creating masked streams costs
+  // milliseconds -- per handle that was 5 ms on the first lambda try of every new optimizer.
+  struct DfStreams { hipStream_t bulk = nullptr, chain = nullptr; hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr; int grid = 0; };
+  static std::map<int, DfStreams> per_device;
+  static std::mutex per_device_mutex;
+  DfStreams* dsp;
+  { std::lock_guard<std::mutex> lock(per_device_mutex); dsp = &per_device[c.device]; }
+  DfStreams& ds = *dsp;
+  if (!ds.bulk) {
     // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
     // of LDS, the whole register file of its SIMDs) can only be placed on exactly those -- so it is placed at once, whatever
     // the order in which the two kernels reach the dispatcher.  (With an unmasked chain stream the dispatcher may pick a
@@ -666,13 +672,13 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     const int reserve = 8;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u), inv((ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu; i++) (i < ncu - reserve ? mask : inv)[i >> 5] |= 1u << (i & 31);
-    check_hip(hipExtStreamCreateWithCUMask(&df.bulk, (uint32_t)mask.size(), mask.data()), "masked stream");
-    check_hip(hipExtStreamCreateWithCUMask(&df.chain, (uint32_t)inv.size(), inv.data()), "masked stream");
-    check_hip(hipEventCreateWithFlags(&df.ev_start, hipEventDisableTiming), "event");
-    check_hip(hipEventCreateWithFlags(&df.ev_chain, hipEventDisableTiming), "event");
-    check_hip(hipEventCreateWithFlags(&df.ev_bulk, hipEventDisableTiming), "event");
+    check_hip(hipExtStreamCreateWithCUMask(&ds.bulk, (uint32_t)mask.size(), mask.data()), "masked stream");
+    check_hip(hipExtStreamCreateWithCUMask(&ds.chain, (uint32_t)inv.size(), inv.data()), "masked stream");
+    check_hip(hipEventCreateWithFlags(&ds.ev_start, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&ds.ev_chain, hipEventDisableTiming), "event");
+    check_hip(hipEventCreateWithFlags(&ds.ev_bulk, hipEventDisableTiming), "event");
     const char* g = getenv("GTG_DF_GRID");
-    df.grid = g ? atoi(g) : (ncu - reserve);
+    ds.grid = g ? atoi(g) : (ncu - reserve);
   }
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, df.ctrl.p);
   static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
@@ -685,13 +691,13 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
-  check_hip(hipEventRecord(df.ev_start, c.stream), "record");
-  check_hip(hipStreamWaitEvent(df.chain, df.ev_start, 0), "wait");
-  check_hip(hipStreamWaitEvent(df.bulk, df.ev_start, 0), "wait");
-  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, df.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
+  check_hip(hipEventRecord(ds.ev_start, c.stream), "record");
+  check_hip(hipStreamWaitEvent(ds.chain, ds.ev_start, 0), "wait");
+  check_hip(hipStreamWaitEvent(ds.bulk, ds.ev_start, 0), "wait");
+  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp);
-  const int grid = (int)std::min<int64_t>(df.grid, df.n_tasks);
-  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, df.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+  const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
+  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
@@ -703,12 +709,12 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   // mask) starved the chain -- wait bounds hit.
   static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
   if (extra > 0 && df.n_tasks > grid)
-    hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, df.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+    hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                        df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
-  check_hip(hipEventRecord(df.ev_chain, df.chain), "record");
-  check_hip(hipEventRecord(df.ev_bulk, df.bulk), "record");
-  check_hip(hipStreamWaitEvent(c.stream, df.ev_chain, 0), "wait");
-  check_hip(hipStreamWaitEvent(c.stream, df.ev_bulk, 0), "wait");
+  check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
+  check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
+  check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");
+  check_hip(hipStreamWaitEvent(c.stream, ds.ev_bulk, 0), "wait");
   check_hip(hipGetLastError(), "cholesky (dataflow)");
 }
 

@@ -78,9 +78,6 @@ struct DfPlan {
   DevBuf<long long> trace;                      // GTG_DF_TRACE=1: 4 stamps per task + 2 per diagonal tile (gtg_debug_df_trace)
   std::vector<int32_t> h_tasks, h_klist;        // host copies (debug getters, CPU tests)
   double flops = 0.0, dense_fraction = 1.0;
-  hipStream_t bulk = nullptr, chain = nullptr;  // CU-masked streams with complementary masks: bulk kernel / chain kernel
-  hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr;
-  int grid = 0;
 };
 
 struct FactorTables {

@@ -179,7 +179,7 @@ int gtg_destroy(gtg_handle c) {
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
                             &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
-                            &c->pair_col, &c->pair_oa, &c->pair_ob, &c->smart_status, &c->smart_cache_state, &c->sfm_smart, &c->lm_smart};
+                            &c->pair_col, &c->pair_oa, &c->pair_ob, &c->smart_status, &c->smart_lin_status, &c->smart_cache_state, &c->sfm_smart, &c->lm_smart};
   for (auto* b : i32) b->free();
   c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.bwd_col_off.free(); c->plan.bwd_col_rows.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
@@ -222,11 +222,22 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     x_sfm_cam.assign(p_user->sfm_cam, p_user->sfm_cam + p_user->n_sfm); x_sfm_point.assign(p_user->sfm_point, p_user->sfm_point + p_user->n_sfm);
     x_sfm_noise.assign(p_user->sfm_noise, p_user->sfm_noise + p_user->n_sfm); x_sfm_z.assign(p_user->sfm_z, p_user->sfm_z + 2 * p_user->n_sfm);
     std::vector<int32_t> of_obs((size_t)p_user->n_sfm, -1);
+    // the device addresses a factor's measurements as smart_obs0 + smart_ptr[i] while the expanded observations are appended one
+    // after the other: the offsets must start at 0 and be strictly increasing
+    if (p_user->smart_ptr[0] != 0) throw std::invalid_argument("smart factors: smart_ptr[0] must be 0");
     for (int64_t i = 0; i < n_smart; i++) {
       const int64_t k0 = p_user->smart_ptr[i], k1 = p_user->smart_ptr[i + 1];
       if (k1 <= k0 || k1 > n_meas) throw std::invalid_argument("smart factor without measurements / bad smart_ptr");
       const double* sp = p_user->smart_params + 8 * i;
       if (!(sp[4] == 0.0 || sp[4] == 1.0 || sp[4] == 2.0)) throw std::invalid_argument("smart factor: unknown degeneracy mode");
+      // rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold (negative = off, as in the reference),
+      // retriangulationThreshold: numbers, not NaN / inf (a NaN threshold silently disables the test it guards)
+      for (int e = 0; e < 4; e++) if (!std::isfinite(sp[e])) throw std::invalid_argument("smart factor: a threshold is not finite");
+      // the reference requires an isotropic model (SmartFactorBase.h:107-114: "SmartFactorBase: needs isotropic")
+      const int32_t nz = p_user->smart_noise[i];
+      if (nz < 0 || nz >= p_user->n_noise || p_user->noise_dim[nz] != 2 ||
+          !(p_user->noise_kind[nz] == GTG_NOISE_UNIT || p_user->noise_kind[nz] == GTG_NOISE_ISOTROPIC))
+        throw std::invalid_argument("smart factor: smart_noise must index a dim-2 Unit or Isotropic noise model");
       for (int64_t k = k0; k < k1; k++) {
         const int cam = p_user->smart_cam[k];
         if (cam < 0 || cam >= p_user->n_vars || p_user->var_type[cam] != GTG_VAR_SFM_CAMERA)
@@ -246,10 +257,11 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     up(c->sfm_smart, of_obs, s);
     std::vector<int32_t> none((size_t)n_smart, -1);
     up(c->smart_cache_state, none, s);
-    c->smart_status.alloc((size_t)n_smart); c->smart_cache_point.alloc(3 * (size_t)n_smart); c->smart_cache_pose.alloc(12 * (size_t)n_meas);
+    c->smart_status.alloc((size_t)n_smart); c->smart_lin_status.alloc((size_t)n_smart); c->smart_cache_point.alloc(3 * (size_t)n_smart); c->smart_cache_pose.alloc(12 * (size_t)n_meas);
     check_hip(hipMemsetAsync(c->smart_status.p, 0, sizeof(int32_t) * n_smart, s), "memset");
+    check_hip(hipMemsetAsync(c->smart_lin_status.p, 0, sizeof(int32_t) * n_smart, s), "memset");
   } else {
-    c->smart_ptr.free(); c->smart_params.free(); c->sfm_smart.free(); c->lm_smart.free(); c->smart_status.free();
+    c->smart_ptr.free(); c->smart_params.free(); c->sfm_smart.free(); c->lm_smart.free(); c->smart_status.free(); c->smart_lin_status.free();
     c->smart_cache_state.free(); c->smart_cache_pose.free(); c->smart_cache_point.free();
   }
   c->n_vars = p->n_vars;
@@ -453,7 +465,7 @@ int gtg_error(gtg_handle c, double* error) {
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
   DeviceGuard on_device(c->device);
   if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false); launch_error(*c, c->values.p, SC_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false, false); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});
   check_smart_supported(*c, "gtg_error");
@@ -467,7 +479,7 @@ int gtg_linearize(gtg_handle c) {
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
   DeviceGuard on_device(c->device);
   if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false); launch_linearize(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false, true); launch_linearize(*c); }
   { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c);
     if (c->n_smart) {   // the cameras' Hessian diagonal is that of the Schur-complemented smart factors: needs their E blocks (undamped)
       launch_point_eliminate(*c, 1.0, 0, 1e-6, 1e32);
@@ -523,7 +535,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
@@ -561,7 +573,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;

@@ -528,12 +528,12 @@ __global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32
 void launch_smart_hdiag(gtg_context& c) {
   if (!c.n_smart) return;
   hipLaunchKernelGGL(k_smart_hdiag, dim3((unsigned)std::max(c.n_red_vars, 1)), dim3(kBlock), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p, c.red_inc_kind.p,
-                     c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.sfm_smart.p, c.smart_status.p, c.E.p, c.hdiag_red.p);
+                     c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.sfm_smart.p, c.smart_lin_status.p, c.E.p, c.hdiag_red.p);
   check_hip(hipGetLastError(), "smart_hdiag");
 }
 void launch_smart_lin1(gtg_context& c) {
   if (!c.n_smart) return;
-  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_status.p, c.ylm.p, c.scalars.p);
+  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_lin_status.p, c.ylm.p, c.scalars.p);
   check_hip(hipGetLastError(), "smart_lin1");
 }
 
@@ -541,7 +541,7 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
   if (!c.n_lm) return;
   const double is = inv_sigma(lambda);
   hipLaunchKernelGGL(k_point_factor, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.V.p,
-                     c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL, c.n_smart ? c.lm_smart.p : nullptr, c.smart_status.p);
+                     c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL, c.n_smart ? c.lm_smart.p : nullptr, c.smart_lin_status.p);
   if (c.f.n_sfm)
     hipLaunchKernelGGL((k_obs_E<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
                        c.obs_lm.p, c.Linv.p, c.E.p);

@@ -141,7 +141,11 @@ struct gtg_context {
   int64_t n_smart = 0, smart_obs0 = 0;
   gt::DevBuf<int64_t> smart_ptr;            // [n_smart + 1] measurements of a factor, relative to smart_obs0
   gt::DevBuf<double> smart_params;          // 8 per factor (include/gtsam_amd.h)
-  gt::DevBuf<int32_t> smart_status;         // per factor: 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT (triangulation.h:611-612)
+  // per factor: 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT (triangulation.h:611-612).  TWO arrays: smart_lin_status is
+  // the outcome at the LINEARISATION point (written by gtg_linearize only; read by everything that builds the linear system, which
+  // stays fixed over the lambda retries of an iteration as the reference's linearised Hessian factor does); smart_status the
+  // outcome of the most recent ERROR evaluation (gtg_error, the trial point of a lambda try), read by k_error only
+  gt::DevBuf<int32_t> smart_status, smart_lin_status;
   gt::DevBuf<int32_t> smart_cache_state;    // per factor: -1 nothing cached, else the cached status
   gt::DevBuf<double> smart_cache_pose;      // 12 per measurement: the camera poses of the cached triangulation
   gt::DevBuf<double> smart_cache_point;     // 3 per factor

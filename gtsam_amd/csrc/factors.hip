@@ -313,7 +313,7 @@ struct SmartArgs {
   int32_t *status, *cache_state; double *cache_pose, *cache_point;
 };
 __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, double* __restrict__ values, const double* __restrict__ gate,
-                                                              double* __restrict__ scalars) {
+                                                              double* __restrict__ scalars, int for_linearize) {
   if (gate && !(gate[SC_LIN0] - gate[SC_LIN1] >= 0)) return;
   for (int64_t sf = blockIdx.x * (int64_t)kBlock + threadIdx.x; sf < a.n; sf += (int64_t)gridDim.x * kBlock) {
     const int64_t k0 = a.ptr[sf], o0 = a.obs0 + k0;
@@ -347,15 +347,19 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
     a.status[sf] = st;
     double* slot = values + a.val_off[a.sfm_point[o0]];
     for (int e = 0; e < 3; e++) slot[e] = st == kTriValid ? pt[e] : 0.0;
-    if (st == kTriNoConvergence || (st != kTriValid && prm[4] != 1.0)) scalars[SC_UNSUPPORTED] = 1.0;
+    // outside the supported subset: HANDLE_INFINITY always uses the point at infinity for a failed track; IGNORE_DEGENERACY only when it
+    // LINEARISES (computeJacobiansWithTriangulatedPoint, SmartProjectionFactor.h:356-371) -- its error is simply 0.0 (totalReprojectionError,
+    // :419-429), so a trial step that puts a track behind a camera is evaluated (and usually rejected), not an error
+    if (st == kTriNoConvergence || (st != kTriValid && (prm[4] == 2.0 || (prm[4] == 0.0 && for_linearize)))) scalars[SC_UNSUPPORTED] = 1.0;
   }
 }
 
-void launch_smart_triangulate(gtg_context& c, double* values, bool gated) {
+void launch_smart_triangulate(gtg_context& c, double* values, bool gated, bool for_linearize) {
   if (!c.n_smart) return;
   SmartArgs a{c.n_smart, c.smart_obs0, c.smart_ptr.p, c.f.sfm_cam.p, c.f.sfm_point.p, c.f.sfm_z.p, c.val_off.p, c.smart_params.p,
-              c.smart_status.p, c.smart_cache_state.p, c.smart_cache_pose.p, c.smart_cache_point.p};
-  hipLaunchKernelGGL(k_smart_triangulate, dim3(grid_for(c.n_smart)), dim3(kBlock), 0, c.stream, a, values, gated ? c.scalars.p : nullptr, c.scalars.p);
+              for_linearize ? c.smart_lin_status.p : c.smart_status.p, c.smart_cache_state.p, c.smart_cache_pose.p, c.smart_cache_point.p};
+  hipLaunchKernelGGL(k_smart_triangulate, dim3(grid_for(c.n_smart)), dim3(kBlock), 0, c.stream, a, values, gated ? c.scalars.p : nullptr, c.scalars.p,
+                     for_linearize ? 1 : 0);
   check_hip(hipGetLastError(), "smart_triangulate");
 }
 
@@ -365,7 +369,7 @@ void launch_linearize(gtg_context& c) {
   if (f.n_sfm)
     hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p,
                        f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p,
-                       c.n_smart ? c.sfm_smart.p : nullptr, c.smart_status.p);
+                       c.n_smart ? c.sfm_smart.p : nullptr, c.smart_lin_status.p);
   if (f.n_proj)
     hipLaunchKernelGGL(k_lin_proj, dim3(grid_for(f.n_proj)), dim3(kBlock), 0, c.stream, f.n_proj, f.proj_pose.p,
                        f.proj_point.p, f.proj_z.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.calib.p,

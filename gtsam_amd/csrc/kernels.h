@@ -38,7 +38,7 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
 void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
 // smart factors (SmartProjectionFactor): triangulation of the hidden landmarks from the cameras in `values` (gated: only when the
 // linear cost change of the current try is >= 0), Schur-complement correction of the Hessian diagonal, constant of linear.error
-void launch_smart_triangulate(gtg_context& c, double* values, bool gated);
+void launch_smart_triangulate(gtg_context& c, double* values, bool gated, bool for_linearize);
 void launch_smart_hdiag(gtg_context& c);
 void launch_smart_lin1(gtg_context& c);
 void exchange_sum(gtg_context& c, double* ptr, int64_t n);   // api.hip: all-reduce (sum) over the shards on the handle's stream; no-op on one shard

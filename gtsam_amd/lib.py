@@ -13,7 +13,8 @@ import numpy as np
 from .problem import Problem, gtg_problem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgtsam_amd.so")
+# GTSAM_AMD_LIB: another build of the SAME library (the fenced A/B build of the dataflow protocol, a sanitizer build); no fallback
+LIB_PATH = os.environ.get("GTSAM_AMD_LIB") or os.path.join(_HERE, "lib", "libgtsam_amd.so")
 
 GTG_OK, GTG_INDETERMINATE = 0, 1
 PHASES = ["linearize", "assemble", "point_eliminate", "schur", "cholesky", "solve", "linear_error",

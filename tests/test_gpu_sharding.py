@@ -102,6 +102,67 @@ def test_two_shards_equal_one(case):
     assert np.array_equal(res[0][4], res[1][4])
 
 
+@pytest.mark.parametrize("name", ["ladybug1723", "venice1778"])
+def test_two_shards_equal_one_at_headline_size(name):
+    """BASELINE config 5 is a SHARDED config (Venice, landmarks sharded): two shards of the L1723 and of the Venice shape on
+    one device against the single handle -- the first lambda try of the Ceres preset (lambda = 1e-4, diagonal damping: the
+    numbers LM's accept / reject decision is made from) and the first LM iterations.  The partial Schur complements of the
+    two shards are summed by the exchange, so the sums associate differently from the single handle's: the step agrees
+    to 1e-7 of its max-norm (the tolerance of one damped solve against the reference, tests/test_gpu_headline_parity.py),
+    the errors to 1e-9, and every lambda try is accepted / rejected alike."""
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd import datasets as D
+    from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+    from gtsam_amd.problem import bal_problem
+    gen = {"ladybug1723": D.ladybug_1723, "venice1778": D.venice_1778}[name]
+    p, v0 = bal_problem(*gen())
+    params = LMP.CeresDefaults(); params.setMaxIterations(3 if name == "venice1778" else 8)
+    lam = 1e-4
+
+    def one(opt):
+        e0 = opt.dev.error()
+        opt.dev.linearize()
+        rc, out = opt.dev.try_lambda(lam, True)
+        d = opt.dev.delta()
+        opt.optimize()
+        return rc, e0, np.array(out[:3]), d, np.array(opt.trace)[:, :3], opt.values_packed()
+
+    single = DeviceLevenbergMarquardt(p, v0, params)
+    rc1, e1, out1, d1, tr1, val1 = one(single)
+    h1 = single.dev.structure_hash()
+    single.dev.close()
+    assert rc1 == 0
+    sumr = TwoWaySum()
+    res = [None, None]
+
+    def run(rank):
+        try:
+            opt = DeviceLevenbergMarquardt(p, v0, params, shard=rank, n_shards=2, allreduce=sumr.fn(rank))
+            res[rank] = one(opt) + (opt.dev.structure_hash(),)
+            opt.dev.close()
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+            sumr.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for rc, e0, out, d, tr, vals, h in res:
+        assert rc == rc1 and h == h1                      # one layout of the reduced system on every shard and on the single handle
+        assert abs(e0 - e1) <= 1e-9 * e1
+        assert np.abs(d - d1).max() <= 1e-7 * np.abs(d1).max(), np.abs(d - d1).max() / np.abs(d1).max()
+        assert np.allclose(out, out1, rtol=1e-7, atol=0)
+        assert tr.shape == tr1.shape and np.array_equal(tr[:, 0], tr1[:, 0]), (tr, tr1)      # same accept / reject sequence
+        assert (np.abs(tr[:, 1] - tr1[:, 1]) <= 1e-6 * np.abs(tr1[:, 1])).all(), (tr, tr1)
+        assert np.abs(vals - val1).max() <= 1e-5 * np.abs(val1).max()
+    assert np.array_equal(res[0][5], res[1][5])           # lock step: both shards hold identical values
+
+
 @pytest.mark.parametrize("case", ["bal_60_cameras", "bal_small_unit", "posegraph_small"])
 def test_two_shards_pcg_equal_one(case):
     """gtg_try_lambda_pcg on a sharded graph: b, the block-Jacobi blocks and every product S p are partial sums per shard and

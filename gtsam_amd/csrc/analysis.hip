@@ -736,13 +736,14 @@ void analyze(gtg_context& c) {
   check_hip(hipMemsetAsync(c.Dinv.p, 0, sizeof(double) * c.Dinv.n, c.stream), "memset");
   c.chol_epoch_dev.alloc(1);
   check_hip(hipMemsetAsync(c.chol_epoch_dev.p, 0, sizeof(long long), c.stream), "memset");
+  c.chol_epoch = 0;   // (Dinv and the flag arrays of the dataflow plan are freshly zeroed as well)
   {  // where the reference's rank test applies in the reduced system: the last pivot of every variable
     std::vector<unsigned char> pk(std::max<size_t>(NP, 1), 0);
     for (int r = 0; r < c.n_red_vars; r++) pk[c.h_red_off[r] + c.h_red_dim[r] - 1] = c.h_red_dim[r] >= 2 ? 1 : 2;
     c.pivot_kind.upload(pk.data(), pk.size(), c.stream);
     c.tile_exp.alloc(NP / kTile + 1);
   }
-  c.xred.alloc(NP);
+  c.xred.alloc(2 * NP);   // + the shadow copies the backward sweep polls when an entry seems stuck (cholesky.hip::sweep_wait)
   c.partials.alloc(2 * 2048);
   c.scalars.alloc(2 * SC_COUNT);   // [SC_COUNT, 2 SC_COUNT): the copy the sharded exchange sums (read_scalars)
   check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 2 * SC_COUNT, s), "memset");

@@ -500,44 +500,84 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   if (!c || !c->uploaded || !c->linearized) throw std::invalid_argument("gtg_try_lambda: call gtg_linearize first");
   if (!(lambda > 0.0)) throw std::invalid_argument("gtg_try_lambda: lambda must be > 0");
   DeviceGuard on_device(c->device);
-  check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
-  { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
-  if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
-    static const bool by_tiles = std::getenv("GTG_EXCHANGE_TILES") != nullptr;   // whole 128x128 tiles (the first version) instead of blocks
-    if (by_tiles || c->n_xb == 0) {
-      const int64_t nb = c->plan.n_exch * kTile * kTile;
-      if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
-      launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
-      exchange(*c, c->xbuf.p, nb);
-      launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
-    } else {                // only the structurally non-zero d x d blocks (the same list on every shard) + rhs row + padding
-      const int64_t nb = exchange_block_doubles(*c);
-      if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
-      launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, false);
-      exchange(*c, c->xbuf.p, nb);
-      launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
+  // The factorisation's kernels wait for each other inside a launch (dataflow schedule: two persistent kernels; stream schedule: the
+  // TRSM workgroups of a panel launch).  A dependency wait that runs into its bound raises SC_TIMEOUT and the kernels drain: a chain
+  // kernel that was not placed, a device shared with another process, or -- seen with several handles on one device -- a flag that an
+  // XCD's L2 kept serving with its old value although the flags are published twice (chol_dataflow.hip::st_flag).  The try is then
+  // repeated, first with the other schedule (stream / event launches of cholesky.hip: kernels that never wait for a kernel launched
+  // after them; its plan is always built), then once more with the dataflow schedule.  The reduced system is assembled again each
+  // time, because the factorisation works in place; the schedules are bit-identical, so a repeated try returns the same numbers.
+  // Sharded: the scalars are summed over the shards by read_scalars, so every shard sees the time-out of any shard and all repeat.
+  for (int attempt = 0; attempt < 3; attempt++) {
+    const bool df = c->use_df && attempt != 1;
+    check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
+    { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+    { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
+    if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
+      static const bool by_tiles = std::getenv("GTG_EXCHANGE_TILES") != nullptr;   // whole 128x128 tiles (the first version) instead of blocks
+      if (by_tiles || c->n_xb == 0) {
+        const int64_t nb = c->plan.n_exch * kTile * kTile;
+        if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
+        launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
+        exchange(*c, c->xbuf.p, nb);
+        launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
+      } else {                // only the structurally non-zero d x d blocks (the same list on every shard) + rhs row + padding
+        const int64_t nb = exchange_block_doubles(*c);
+        if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
+        launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, false);
+        exchange(*c, c->xbuf.p, nb);
+        launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
+      }
     }
+    std::unique_lock<std::mutex> one_at_a_time;
+    if (df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
+    { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
+      if (df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
+      else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
+    { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
+      launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
+      launch_back_substitute(*c);
+      if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
+        check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
+        one_at_a_time.unlock();                                // done, let the other one start before waiting for it
+      }
+      if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
+      launch_scatter_delta(*c); }
+    { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
+    { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
+    { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+    read_scalars(*c);
+    if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
+    if (attempt < 2 && c->h_scalars[SC_TIMEOUT] != 0.0) {
+      static const bool quiet = std::getenv("GTG_QUIET") != nullptr;
+      if (!quiet) {
+        // post-mortem: which wait gave up (chol_dataflow.hip::wait_flags records the first one of a dataflow pass), what it saw, and
+        // what the same words hold in memory NOW, read from the host after the kernels have drained
+        int32_t ctl[16] = {0};
+        long long now1 = -1, now2 = -1;
+        const int nt = c->NP / kTile;
+        if (df && c->df.ctrl.p) {
+          (void)hipMemcpy(ctl, c->df.ctrl.p, sizeof(ctl), hipMemcpyDeviceToHost);
+          const int kind = ctl[8], I = ctl[9], J = ctl[10], k = ctl[11];
+          const long long *w1 = nullptr, *w2 = nullptr;
+          if (kind == 1 || kind == 2) { w1 = c->df.tile_flag.p + (int64_t)I * nt + k; w2 = c->df.tile_flag.p + (int64_t)J * nt + k; }
+          else if (kind == 3) w1 = w2 = c->df.tile_flag.p + (int64_t)J * nt + J;
+          else if (kind == 4) w1 = w2 = c->df.pd_flag.p + I;
+          else if (kind == 5) w1 = w2 = c->df.tile_flag.p + (int64_t)I * nt + J;
+          else if (kind == 7) w1 = w2 = c->df.part_flag.p + (int64_t)I * nt + J;
+          if (w1) { (void)hipMemcpy(&now1, w1, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&now2, w2, 8, hipMemcpyDeviceToHost); }
+        }
+        std::fprintf(stderr, "[gtsam_amd] %s factorisation (epoch %lld): a dependency wait ran into its bound; repeating the lambda try with the %s "
+                     "schedule.  wait kind %d at (%d, %d, %d): saw %d / %d, wanted %d / %d; memory now holds %lld / %lld; waiter on XCD %d (hw id 0x%x); "
+                     "tickets taken %d, diagonal tiles started %d of %d, waits that ended on the shadow words %d\n",
+                     df ? "dataflow" : "stream-schedule", c->chol_epoch, df ? "stream" : "dataflow", ctl[8], ctl[9], ctl[10], ctl[11], ctl[12], ctl[13], ctl[14],
+                     ctl[15], now1, now2, ctl[2], (unsigned)ctl[3], ctl[0], ctl[1], nt, ctl[6]);
+      }
+      c->df_fallbacks++;
+      continue;
+    }
+    break;
   }
-  std::unique_lock<std::mutex> one_at_a_time;
-  if (c->use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
-  { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
-    if (c->use_df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
-    else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
-  { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
-    launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
-    launch_back_substitute(*c);
-    if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
-      check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
-      one_at_a_time.unlock();                                // done, let the other one start before waiting for it
-    }
-    if (c->n_lm) exchange(*c, c->delta_lm.p, 3 * (int64_t)c->n_lm);
-    launch_scatter_delta(*c); }
-  { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
-  { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
-  read_scalars(*c);
-  if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_SCHUR, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;
   const double dsq = c->h_scalars[SC_DELTA_SQ];
@@ -772,6 +812,7 @@ int gtg_debug_df_ctrl(gtg_handle c, int32_t out[16]) {
   if (!c || !c->uploaded || !out || !c->df.ctrl.p) throw std::invalid_argument("gtg_debug_df_ctrl: no dataflow schedule");
   DeviceGuard on_device(c->device);
   check_hip(hipMemcpy(out, c->df.ctrl.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost), "D2H");
+  out[15] = (int32_t)c->df_fallbacks;   // (host counter) lambda tries repeated with the stream schedule after a time-out
   return GTG_OK;
   GTG_CATCH
 }
@@ -782,7 +823,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   DeviceGuard on_device(c->device);
   const int NP = (n + kTile - 1) / kTile * kTile;
   DevBuf<double> S, Dinv, x, fail;
-  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(NP); fail.alloc(2);
+  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
   if (!c->chol_epoch_dev.p) { c->chol_epoch_dev.alloc(1); check_hip(hipMemset(c->chol_epoch_dev.p, 0, sizeof(long long)), "memset"); }
   check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");

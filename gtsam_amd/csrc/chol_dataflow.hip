@@ -22,6 +22,7 @@
 // ran which task.  A dependency wait that runs into its bound raises fail[1] (reported as an error by the C ABI, never
 // as "not positive definite"), after which every wait falls through and both kernels drain.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -81,38 +82,68 @@ __device__ __forceinline__ void stores_done() {   // this wavefront's stores are
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-__device__ __forceinline__ void st_flag(long long* p, long long v) {
+// Every flag is published TWICE: at its word and at a shadow word `sh` words further on (another line, another page).  A poller reads
+// the first; when a wait drags on (1024 polls) it also looks at the shadow.  Reason: in a process with several handles on one device
+// a polled line is occasionally left STUCK in the poller's XCD L2 with the value it had when the polling began -- sc1 loads (served
+// by that L2) return the old flag for seconds while memory holds the new one and every other XCD sees it (about one wait in 1e8;
+// tools/df_contention_diag.py, profiles/r03_df_contention.txt).  The shadow is not polled while it changes, so it is fetched fresh.
+__device__ __forceinline__ void st_flag(long long* p, long long v, long long sh) {
 #if GTG_DF_FENCES
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+  __hip_atomic_store(p + sh, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// GTG_DF_SAFE (experiment): the guide's hand-off recipe on the consumer side -- ONE agent-scope acquire (buffer_inv sc1) after a
+// flag matched, and the flag itself read by a returning read-modify-write atomic (executed at the device's point of coherence,
+// never served from a cache) instead of an sc1 load (served by the XCD's L2)
+#ifndef GTG_DF_SAFE
+#define GTG_DF_SAFE 0
+#endif
 __device__ __forceinline__ void acquired() {
-#if GTG_DF_FENCES
+#if GTG_DF_FENCES || (GTG_DF_SAFE & 1)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
   asm volatile("" ::: "memory");
 #endif
 }
 __device__ __forceinline__ long long ld_flag(const long long* p) {
+#if (GTG_DF_SAFE & 2)
+  // wave-uniform address: one lane asks, the value is broadcast
+  long long v = 0;
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+    v = __hip_atomic_fetch_or(const_cast<long long*>(p), 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned)lo;
+#else
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 __device__ __forceinline__ bool timed_out(const double* fail) {
   return __hip_atomic_load(reinterpret_cast<const long long*>(fail + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 // Every lane of the calling wavefront polls the same words (one broadcast load); bounded: see the file comment.
 // The first wait that gives up leaves a record (what it waited for) in dbg[0..7] (gtg_debug_df_ctrl).
-__device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail,
+__device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail, long long sh,
                                            int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
   int spins = 0;
   while (ld_flag(f1) < v1 || ld_flag(f2) < v2) {
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 255) == 0) {
       if (timed_out(fail)) break;
+      if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
+        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
+        break;
+      }
       if (spins > kSpinLimit) {
         if (dbg && atomicCAS(dbg, 0, kind) == 0) {
           dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
+          // post-mortem (ctrl[2..3]): where the waiter runs
+          unsigned xcc, hw;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+          dbg[-6] = (int)(xcc & 0xf); dbg[-5] = (int)hw;
         }
         fail[1] = 1.0; break;
       }
@@ -126,11 +157,14 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
 __device__ __forceinline__ int tile_progress(const long long* f1, const long long* f2, long long flagbase) {
   const long long a = ld_flag(f1) - flagbase, b = ld_flag(f2) - flagbase;
   const long long m = a < b ? a : b;
+#if (GTG_DF_SAFE & 1)
+  acquired();
+#endif
   return __builtin_amdgcn_readfirstlane((int)(m < 0 ? 0 : m));
 }
-__device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail,
+__device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail, long long sh,
                                              int32_t* dbg, int kind, int a, int b, int c) {
-  wait_flags(f1, flagbase + need, f2, flagbase + need, fail, dbg, kind, a, b, c);
+  wait_flags(f1, flagbase + need, f2, flagbase + need, fail, sh, dbg, kind, a, b, c);
   return need;   // (at least; the caller asks again when it needs more)
 }
 
@@ -149,7 +183,7 @@ constexpr int kBulkThreads = 1024;
 template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int NP, int nt, int I, int J,
                                            long long* __restrict__ tile_flag, double* __restrict__ Xinv_all,
-                                           double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg,
+                                           double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg,
                                            long long* __restrict__ tr) {
   // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
   // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
@@ -169,21 +203,24 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   const unsigned lane_off = (unsigned)(lk * NP + lr);
   double* Crow = C + (int64_t)(16 * rt) * NP + 64 * h;
   const double* Xinv = Xinv_all + (size_t)J * T * T;
-  const long long* pflag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
+  const long long* pflag = tile_flag + (int64_t)J * nt + J;   // the diagonal tile's progress word (released panels): the diagonal of the flag array
   long long* myflag = tile_flag + (int64_t)I * nt + J;
   double* W = reinterpret_cast<double*>(smem_raw) + rt * (16 * PX);
   double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
   long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
+#if (GTG_DF_SAFE & 1)
+  acquired();
+#endif
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     if (pf < flagbase + q + 1) {
-      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, dbg, 3, I, J, q);
+      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, sh, dbg, 3, I, J, q);
       pf = flagbase + q + 1;
     }
     if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
     if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
     __syncthreads();   // the previous step's images have been consumed; -X_{q-1} is complete in the W patches and out of every wavefront
-    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
+    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q, sh);
     {  // images of this step: slots 0 .. 3-q = L(q + s, q - 1) (q > 0), slot 3 = Linv(q,q); wavefront w moves 1 KiB pieces
       // (w & 7) of the slots (w >> 3) and (w >> 3) + 2
 #pragma unroll
@@ -252,7 +289,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   }
   stores_done();
   __syncthreads();
-  if (tid == 0) st_flag(myflag, flagbase + 4);
+  if (tid == 0) st_flag(myflag, flagbase + 4, sh);
 }
 
 
@@ -260,7 +297,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
-                                         double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
+                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
   // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
   // the persistent task loop and kept alive across it
   int tid_ = threadIdx.x;
@@ -302,7 +339,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   if (piece > 0) {
     // the tile holds the earlier pieces' partial result, written (write-through) by other workgroups -- possibly while an older
     // version of it sat in this XCD's L2 (a piece before that one may have run here): read it past the L2
-    wait_flags(pflag_mine, epoch * 64 + piece, pflag_mine, epoch * 64 + piece, fail, dbg, 7, I, J, piece);
+    wait_flags(pflag_mine, epoch * 64 + piece, pflag_mine, epoch * 64 + piece, fail, sh, dbg, 7, I, J, piece);
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -321,7 +358,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     // tiles are long final and the test is a scalar compare; for the last step (block column J-1, whose tiles become final
     // behind the diagonal tile that is being factored right now) the contraction streams behind the substitution.
     int k = kl[0];
-    int cp = wait_progress(fI + k, fJ + k, flagbase, 1, fail, dbg, 1, I, J, k);   // progress known for the current step
+    int cp = wait_progress(fI + k, fJ + k, flagbase, 1, fail, sh, dbg, 1, I, J, k);   // progress known for the current step
     const double* Ak = Arow + (int64_t)k * T;
     const double* Bk = Brow + (int64_t)k * T;
     stage(Ak, Bk, 0, 0);
@@ -339,10 +376,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         const int cur = ch & 1;
         if (ch + 1 < T / KC) {
           const int need = ch + 2;   // chunk ch + 1 = the operand tiles' 32-column block ch + 1
-          if (cp < need) { cp = tile_progress(fI + k, fJ + k, flagbase); if (cp < need) cp = wait_progress(fI + k, fJ + k, flagbase, need, fail, dbg, 2, I, J, k); }
+          if (cp < need) { cp = tile_progress(fI + k, fJ + k, flagbase); if (cp < need) cp = wait_progress(fI + k, fJ + k, flagbase, need, fail, sh, dbg, 2, I, J, k); }
           stage(Ak, Bk, ch + 1, cur ^ 1);
         } else if (ki + 1 < kcnt) {
-          if (np < 1) np = wait_progress(fI + kn, fJ + kn, flagbase, 1, fail, dbg, 2, I, J, kn);
+          if (np < 1) np = wait_progress(fI + kn, fJ + kn, flagbase, 1, fail, sh, dbg, 2, I, J, kn);
           stage(An, Bn, 0, cur ^ 1);
         }
         const char* Ac = smem_raw + cur * 2 * CH;
@@ -371,7 +408,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pflag_mine, epoch * 64 + piece + 1);
+    if (tid == 0) st_flag(pflag_mine, epoch * 64 + piece + 1, sh);
     return;
   }
   if (I == J) {
@@ -382,14 +419,14 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pd_flag + J, fin);
+    if (tid == 0) st_flag(pd_flag + J, fin, sh);
     return;
   }
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (h == 0) substitute<0>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, dbg, tr);
-  else substitute<1>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, dbg, tr);
+  if (h == 0) substitute<0>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, sh, dbg, tr);
+  else substitute<1>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, sh, dbg, tr);
 }
 
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
@@ -397,10 +434,9 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
                                           long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                           long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
-                                          double* __restrict__ fail, const long long* __restrict__ epoch_p,
+                                          double* __restrict__ fail, const long long epoch, const long long sh,
                                           long long* __restrict__ trace) {
   __shared__ int s_task;
-  const long long epoch = *epoch_p;
   for (;;) {
     if (threadIdx.x == 0) s_task = atomicAdd(ctrl, 1);
     __syncthreads();
@@ -415,7 +451,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -426,10 +462,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                                     long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
-                                                    double* __restrict__ fail, const long long* __restrict__ epoch_p,
+                                                    double* __restrict__ fail, const long long epoch, const long long sh,
                                                     long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
+  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
 // one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
@@ -457,17 +493,16 @@ __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, i
 // them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
 // substitution steps of the tiles below through the tile's progress word).
 __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
-                                           const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
+                                           const long long* __restrict__ pd_flag, long long* tile_flag,
                                            const int32_t* __restrict__ has_sub, double* __restrict__ fail,
-                                           const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
+                                           const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, int first, int stride,
                                            const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
-  const long long epoch = *epoch_p;
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   for (int J = first; J < nt; J += stride) {
-    if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, ctrl + 8, 4, J, J, 0);
+    if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, sh, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
     if (tid == 0) { ctrl[1] = J + 1; if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started
@@ -478,7 +513,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
       const long long* sflag = tile_flag + (int64_t)J * nt + (J - 1);
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, ctrl + 8, 5, J, J - 1, q);
+        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
@@ -504,20 +539,20 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch_p, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
+    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + (int64_t)J * nt + J, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
 }
 
 __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
-                                                     const long long* __restrict__ pd_flag, const long long* __restrict__ tile_flag,
+                                                     const long long* __restrict__ pd_flag, long long* tile_flag,
                                                      const int32_t* __restrict__ has_sub, double* __restrict__ fail,
-                                                     const long long* __restrict__ epoch_p, int32_t* __restrict__ ctrl,
+                                                     const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace, (int)blockIdx.x, (int)gridDim.x, pivot_kind, tile_exp);
+  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace, (int)blockIdx.x, (int)gridDim.x, pivot_kind, tile_exp);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): workgroups 0 and 1 are the chain (dispatched first, so they are resident before
@@ -530,14 +565,14 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       long long* __restrict__ pd_flag,
                                                       const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
-                                                      const long long* __restrict__ epoch_p, long long* __restrict__ trace,
+                                                      const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch_p, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2, pivot_kind, tile_exp); }
-  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch_p, trace);
+  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2, pivot_kind, tile_exp); }
+  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
-__global__ void k_df_begin(long long* epoch, int32_t* ctrl) { *epoch += 1; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; }
+__global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; ctrl[6] = 0; }
 
 }  // namespace
 
@@ -619,7 +654,9 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   df.has_sub.upload(has_sub.data(), has_sub.size(), stream);
   df.h_has_sub = has_sub;
   df.klist.upload(df.h_klist.data(), df.h_klist.size(), stream);
-  df.tile_flag.alloc((size_t)(nt + 1) * nt); df.part_flag.alloc((size_t)(nt + 1) * nt); df.pd_flag.alloc(nt); df.ctrl.alloc(16);
+  // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
+  df.shadow = ((int64_t)(nt + 1) * nt + 511) / 512 * 512;
+  df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
@@ -680,25 +717,35 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     const char* g = getenv("GTG_DF_GRID");
     ds.grid = g ? atoi(g) : (ncu - reserve);
   }
-  hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, df.ctrl.p);
+  // the factorisation's epoch: counted on the host and handed to both kernels BY VALUE -- the ticket counter is only ever touched by
+  // atomics, the flags by write-through stores and sc1 loads, and nothing the two kernels synchronise through is a word that a
+  // kernel of the previous factorisation wrote with a plain store
+  const long long epoch = ++c.chol_epoch;
+  hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, epoch, df.ctrl.p);
   static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
   if (single) {
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + 2);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
-                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p, pivot_kind, tile_exp);
+                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
   check_hip(hipEventRecord(ds.ev_start, c.stream), "record");
   check_hip(hipStreamWaitEvent(ds.chain, ds.ev_start, 0), "wait");
   check_hip(hipStreamWaitEvent(ds.bulk, ds.ev_start, 0), "wait");
-  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, c.chol_epoch_dev.p, df.ctrl.p,
+  // test hook (tests/test_gpu_dataflow_protocol.py): GTG_DF_TEST_TIMEOUT=n leaves the chain kernel out of the process's n-th dataflow
+  // factorisation -- the bulk kernel's waits then run into their bound, exactly what a chain kernel that was never placed looks like
+  static const int drop_at = getenv("GTG_DF_TEST_TIMEOUT") ? atoi(getenv("GTG_DF_TEST_TIMEOUT")) : 0;
+  static std::atomic<int> launches{0};
+  const bool drop_chain = drop_at > 0 && ++launches == drop_at;
+  if (!drop_chain)
+  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
@@ -710,7 +757,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
   if (extra > 0 && df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, c.chol_epoch_dev.p, df.trace.p);
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");

@@ -337,9 +337,11 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* __restrict__ tile
 
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
-                                           const long long* __restrict__ epoch, bool preloaded = false, bool wt = false,
+                                           long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
                                            const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr) {
-  const long long flagbase = *epoch * 8;   // progress words are monotonic over factorisations: no reset, graph-replayable
+  const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
+  // (host-counted): a word in device memory that every factorisation rewrites was read one factorisation stale by one of two
+  // co-operating kernels under multi-handle contention (rate ~1e-3; tools/df_contention_diag.py, profiles/r03_df_contention.txt)
   double* A = reinterpret_cast<double*>(smem_raw);   // 10 packed lower sub-blocks [SB][PB]
   double* rinvs = A + 10 * SB * PB;                   // [T]  1 / pivot
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
@@ -389,8 +391,11 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     // panel jb is complete in global memory (its inverse, and every L(jb, q<jb) operand image): release it to the
     // TRSM workgroups of this launch, which are waiting for exactly that to run their phase jb
     if (tid == 0)
-      __hip_atomic_store(reinterpret_cast<long long*>(Xinv + kFlagOff), flagbase + jb + 1, wt ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
+    {
+      __hip_atomic_store(pflag, flagbase + jb + 1, wt ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_AGENT);
+      if (pflag_shadow) __hip_atomic_store(pflag + pflag_shadow, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // chol_dataflow.hip::st_flag
+    }
     STAMP(2 + 3 * jb);
     STAMP(3 + 3 * jb);
     // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start

@@ -49,8 +49,8 @@ namespace gt {
 constexpr int TR = 64;   // rows per TRSM workgroup
 __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S, int NP, int k, int wg,
                                           const int32_t* __restrict__ rows, double* __restrict__ Xinv,
-                                          double* __restrict__ fail, const long long* __restrict__ epoch) {
-  const long long flagbase = *epoch * 8;
+                                          double* __restrict__ fail, long long epoch) {
+  const long long flagbase = epoch * 8;
   double* Xs = reinterpret_cast<double*>(smem_raw);   // [TR][P]
   const int I = rows[wg >> 1], half_rows = (wg & 1) * TR;
   __builtin_amdgcn_s_setprio(2);
@@ -81,6 +81,8 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < flagbase + p + 1) {
         if (++spins > (1 << 22)) { fail[1] = 1.0; break; }   // a scheduling problem, not a matrix property: fail[1] is reported as an error (SC_TIMEOUT), never as "not positive definite"
+        // the word stuck in this XCD's L2 with its old value (chol_dataflow.hip::st_flag): the shadow word, published behind it
+        if ((spins & 1023) == 0 && __hip_atomic_load(flag + 64, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= flagbase + p + 1) break;
         __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -137,13 +139,13 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
 // order), the release/acquire pair is agent scope (L2 write-back / invalidate across XCDs).
 __global__ __launch_bounds__(512, 2) void k_panel128(double* __restrict__ S, int NP, int k, const int32_t* __restrict__ rows,
                                                      double* __restrict__ Xinv, double* __restrict__ fail,
-                                                     long long* __restrict__ dbg, const long long* __restrict__ epoch,
+                                                     long long* __restrict__ dbg, long long epoch,
                                                      const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch, false, false, pivot_kind, tile_exp);
+  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch, reinterpret_cast<long long*>(Xinv + kFlagOff), 64, false, false, pivot_kind, tile_exp);
   else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, epoch);
 }
-__global__ void k_bump_epoch(long long* epoch) { *epoch += 1; }
+__global__ void k_set_epoch(long long* epoch, long long value) { *epoch = value; }
 
 // ---- trailing update: C(I,J) -= sum_{kt} L(I,kt) L(J,kt)^T ---------------------------------------------------
 // 128x128 output tile per workgroup, 4 wavefronts in 2x2, each 64x64 = 4x4 MFMA tiles.  The contraction
@@ -488,8 +490,8 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   }
   attr_lock.unlock();
   const int npairs = (nt + 1) / 2;
-  const long long* flagbase = c.chol_epoch_dev.p;
-  hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p);
+  const long long flagbase = ++c.chol_epoch;   // host-counted, passed to every kernel by value (chol_device.h::potrf_body)
+  hipLaunchKernelGGL(k_set_epoch, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, flagbase);
   if (!g_cs.panel) {
     int lo = 0, hi = 0;
     check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
@@ -739,7 +741,10 @@ __global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int N
   const int k = blockIdx.x, tid = threadIdx.x;
   double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
   const double* Xinv = Xinv_all + (size_t)k * T * T;
-  if (x && tid < T) reinterpret_cast<unsigned long long*>(x)[k * T + tid] = kBwdUnset;   // k_bwd_sweep waits on the entries themselves
+  if (x && tid < T) {   // k_bwd_sweep waits on the entries themselves (and, when a wait drags on, on their shadow copies NP entries further on)
+    reinterpret_cast<unsigned long long*>(x)[k * T + tid] = kBwdUnset;
+    reinterpret_cast<unsigned long long*>(x)[NP + k * T + tid] = kBwdUnset;
+  }
   for (int e = tid; e < 10 * 512; e += 256) {
     const int blk = e >> 9, w = e & 511, r = w >> 4, c2 = 2 * (w & 15);
     double2 v;
@@ -853,7 +858,7 @@ __device__ __forceinline__ void sweep_load(double2 (&t)[16], const double* __res
   for (int r = 0; r < 16; r++) t[r] = *reinterpret_cast<const double2*>(src + (int64_t)r * NP);
 }
 
-__device__ __forceinline__ void sweep_wait(const double* x, int i, double* xs, double* fail, int tid) {
+__device__ __forceinline__ void sweep_wait(const double* x, int NP, int i, double* xs, double* fail, int tid) {
   if (tid < 64) {
     const unsigned long long* px = reinterpret_cast<const unsigned long long*>(x) + (int64_t)i * T + 2 * tid;
     unsigned long long a, b;
@@ -862,6 +867,11 @@ __device__ __forceinline__ void sweep_wait(const double* x, int i, double* xs, d
       b = __hip_atomic_load(px + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all(a != kBwdUnset && b != kBwdUnset)) break;
       if (spins > (1 << 21)) { if (tid == 0) fail[1] = 1.0; break; }
+      if ((spins & 1023) == 1023) {   // the entries stuck in this XCD's L2 as unset (chol_dataflow.hip::st_flag): their shadow copies
+        a = __hip_atomic_load(px + NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(px + NP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(a != kBwdUnset && b != kBwdUnset)) break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     xs[2 * tid] = __longlong_as_double((long long)a);
@@ -908,11 +918,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __res
   }
   double a0 = 0.0, a1 = 0.0;
   for (int idx = 0; idx < n; idx += 2) {   // ta holds tile idx, tb tile idx + 1
-    sweep_wait(x, rows[idx], xs, fail, tid);
+    sweep_wait(x, NP, rows[idx], xs, fail, tid);
     sweep_fma(ta, xs, g, a0, a1);
     if (idx + 2 < n) sweep_load(ta, S, NP, rows[idx + 2], j, g, c2);
     if (idx + 1 < n) {
-      sweep_wait(x, rows[idx + 1], xs + T, fail, tid);
+      sweep_wait(x, NP, rows[idx + 1], xs + T, fail, tid);
       sweep_fma(tb, xs + T, g, a0, a1);
       if (idx + 3 < n) sweep_load(tb, S, NP, rows[idx + 3], j, g, c2);
     }
@@ -943,6 +953,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __res
   if (tid < T) {
     const double v = (part[tid] + part[T + tid]) + (part[2 * T + tid] + part[3 * T + tid]);
     __hip_atomic_store(x + j * T + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: what the waiting workgroups poll
+    __hip_atomic_store(x + NP + j * T + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // and its shadow copy
   }
 }
 

@@ -74,6 +74,7 @@ struct DfPlan {
   DevBuf<int32_t> klist;                        // contraction lists: the column tiles k < J with both (I, k) and (J, k) stored
   DevBuf<long long> tile_flag;                  // (nt + 1) x nt: epoch in which the tile became final
   DevBuf<long long> pd_flag;                    // nt: epoch in which the diagonal tile received all its updates
+  int64_t shadow = 0;                           // every flag is also stored `shadow` words behind its word (chol_dataflow.hip::st_flag)
   DevBuf<int32_t> ctrl;                         // [0] ticket counter of the bulk queue; [8..15] record of the first wait that gave up
   DevBuf<long long> trace;                      // GTG_DF_TRACE=1: 4 stamps per task + 2 per diagonal tile (gtg_debug_df_trace)
   std::vector<int32_t> h_tasks, h_klist;        // host copies (debug getters, CPU tests)
@@ -204,10 +205,12 @@ struct gtg_context {
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
   gt::DevBuf<unsigned char> pivot_kind;         // per scalar column of S: 1 / 2 = last pivot of a variable (dim >= 2 / dim 1): the rank test of
   gt::DevBuf<double> tile_exp;                  // base/cholesky.cpp:144-157 applies there; tile_exp: exponent of every tile's last pivot (carry)
-  gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words), bumped on the device
+  gt::DevBuf<long long> chol_epoch_dev;         // factorisations launched so far (base of the progress words): a device copy of chol_epoch (debug)
+  long long chol_epoch = 0;                     // counted on the host, passed to the kernels by value
   gt::CholPlan plan;
   gt::DfPlan df;                                // the dataflow schedule (default); `plan` keeps the lists for zeroing / exchange / backward solve
   bool use_df = true;
+  int64_t df_fallbacks = 0;                    // lambda tries repeated with the stream schedule after a time-out of the dataflow pass
   gt::DevBuf<double> xbuf;                      // multi-GPU: the exchanged part of S packed contiguously for the all-reduce
   // multi-GPU exchange at block granularity: every structurally non-zero d x d block of the reduced system (diagonal blocks +
   // the off-diagonal blocks of the WHOLE graph, identical on every shard), 81 doubles per block, then the rhs row and the

@@ -259,7 +259,9 @@ int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* b
  * the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
 int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* klist);
 /* out[0] = tickets taken in the last factorisation; out[8..15] = record of the first dependency wait that gave up (kind 1/2: tile
- * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted) */
+ * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted --
+ * out[15], the second wanted value, is replaced by a host counter: the lambda tries of this handle that were repeated with the
+ * stream schedule after a time-out of the dataflow pass) */
 int gtg_debug_df_ctrl(gtg_handle h, int32_t out[16]);
 /* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
  * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */

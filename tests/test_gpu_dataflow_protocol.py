@@ -120,3 +120,39 @@ def test_fenced_protocol_gives_identical_numbers():
         assert a[name]["rc"] == b[name]["rc"] == 0
         for k in ("scalars", "delta", "trace", "values"):
             assert a[name][k] == b[name][k], (name, k, a[name]["final"], b[name]["final"])
+
+
+_CHILD_FALLBACK = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+from tests.test_gpu_dataflow_protocol import _sphere
+p, v0, prm = _sphere()
+opt = DeviceLevenbergMarquardt(p, v0, prm)
+opt.optimize()
+tr = np.array(opt.trace)[:, :3]
+print("RESULT " + json.dumps(dict(trace=tr.tobytes().hex(), rows=int(tr.shape[0]), final=float(tr[-1, 1]),
+                                  fallbacks=int(opt.dev.df_ctrl()[15]))))
+'''
+
+
+def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule():
+    """A dependency wait of the dataflow factorisation that runs into its bound (here: the chain kernel is left out of the third
+    factorisation, GTG_DF_TEST_TIMEOUT=3 -- what a chain kernel that the dispatcher never placed looks like) must not abort
+    optimize(): the lambda try is computed once more with the stream / event schedule (same sums in the same order: the two
+    schedules are bit-identical), so the LM trajectory is exactly the undisturbed one and the handle counts one fallback."""
+    import torch
+    assert torch.cuda.is_available()
+
+    def child(extra_env):
+        env = dict(os.environ); env.pop("GTSAM_AMD_LIB", None); env.update(extra_env)
+        r = subprocess.run([sys.executable, "-c", _CHILD_FALLBACK % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        return json.loads(line[len("RESULT "):]), r.stderr
+    a, _ = child({})
+    b, err = child({"GTG_DF_TEST_TIMEOUT": "3"})
+    assert a["fallbacks"] == 0 and b["fallbacks"] == 1, (a["fallbacks"], b["fallbacks"])
+    assert "repeating the lambda try with the stream schedule" in err
+    assert a["trace"] == b["trace"], (a["final"], b["final"], a["rows"], b["rows"])

@@ -134,6 +134,7 @@ hipError_t hipMalloc(void** p, size_t n) {
   __atomic_add_fetch(&g_alloc, (long long)n, __ATOMIC_RELAXED);
   return *p ? 0 : 2;
 }
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned flags) { (void)flags; return hipMalloc(p, n); }
 hipError_t hipFree(void* p) { free(p); return 0; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, int kind) {
   memcpy(d, s, n);

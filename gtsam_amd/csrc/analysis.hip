@@ -368,16 +368,25 @@ void analyze(gtg_context& c) {
   // The reference gets its elimination order from COLAMD (inference/Ordering.cpp:42-124) unless the user passes
   // one; here the order only decides where each camera/pose block sits in S.  A banded / loop-closing block
   // pattern then leaves most 128x128 tiles of the factor empty, and the tile schedule skips them.
-  // ---- ordering of the reduced variables + Cholesky schedule.  Default: RCM (one serial chain).  GTG_ND_DEPTH=n asks for
-  // n levels of nested dissection (independent chains, tree schedule in cholesky.hip): correct, but measured slower or
-  // equal on every workload of this round (sphere2500 5.3 -> 5.3..8.9 ms, w20000 21.8 -> 20.4..31.6 ms, L1723 +60 % flops),
-  // because a chain is issued at ~45 us of host time per column pair and the separators cost fill. ----
+  // ---- ordering of the reduced variables + Cholesky schedule.  RCM gives ONE serial chain of diagonal tiles; nested dissection
+  // (GTG_ND_DEPTH=n levels; default: 2 levels where the criterion below holds, 0 switches it off) gives the elimination tree independent
+  // subtrees, which the dataflow kernels run as several chains side by side (chol_dataflow.hip::build_df_plan) -- the reference's
+  // parallel elimination of independent cliques (inference/ClusterTree-inst.h:218-317).  It pays in the latency-bound regime only:
+  // the separators cost fill (L1723 shape: +60 % flops for a 30 % shorter chain), so it is TRIED where the block structure is very
+  // sparse (pose graphs: < 1 % of the reduced system's entries) and KEPT where the longest chain gets >= 30 % shorter. ----
   const char* nd_env = std::getenv("GTG_ND_DEPTH");
   const bool nd_forced = nd_env != nullptr;
+  int nd_auto = 0;
+  const char* ord_req = std::getenv("GTG_ORDERING");   // an explicitly requested ordering method (minimum degree) is one chain
+  if (!nd_forced && hi.user_order.empty() && c.n_red >= 24 * (int64_t)kTile && !(ord_req && std::string(ord_req) != "rcm")) {
+    double nnz = 0.0;
+    for_each_block([&](int ra, int rb) { if (ra != rb) nnz += 2.0 * c.h_red_dim[ra] * c.h_red_dim[rb]; });
+    if (nnz <= 0.01 * (double)c.n_red * (double)c.n_red) nd_auto = 3;   // 8 leaves on 4 chain slots: sphere2500 1.39 ms (2 levels: 1.78, one chain: 4.6)
+  }
   struct Joiner { std::thread t; std::exception_ptr err; ~Joiner() { if (t.joinable()) t.join(); } } block_level;   // (see below)
   for (int attempt = 0; attempt < 2; attempt++) {
   if (block_level.t.joinable()) block_level.t.join();   // a second attempt rewrites the ordering the thread reads
-  const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : 0) : 0;   // opt-in (GTG_ND_DEPTH=levels), see DESIGN.md
+  const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : nd_auto) : 0;
   bool retry_rcm = false;
   std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
   std::vector<int32_t> part_parent;          // parent part (-1: root) of every part, parts numbered in elimination order
@@ -440,12 +449,16 @@ void analyze(gtg_context& c) {
         int best = -1; int64_t below = 0;
         std::vector<int64_t> pre(L + 2, 0);
         for (int l = 0; l <= L; l++) pre[l + 1] = pre[l] + cnt[l];
-        for (int l = 1; l < L; l++) {
-          below = pre[l];
-          const int64_t above = n - pre[l + 1];   // nodes not reached by the BFS count as "above"
-          if (std::min(below, above) * 4 < n) continue;
-          if (best < 0 || cnt[l] < cnt[best]) best = l;
-        }
+        // balance first (the parts become chains of diagonal tiles that run side by side: the longest one is the critical path), then
+        // the smallest separator among the balanced cuts; a cut that leaves a quarter on each side is the fallback
+        for (int64_t share : {10, 8, 5})
+          if (best < 0)
+            for (int l = 1; l < L; l++) {
+              below = pre[l];
+              const int64_t above = n - pre[l + 1];   // nodes not reached by the BFS count as "above"
+              if (std::min(below, above) * 20 < n * share) continue;
+              if (best < 0 || cnt[l] < cnt[best]) best = l;
+            }
         for (int32_t v : nodes) active[v] = 0;
         if (best > 0 && cnt[best] * 3 < n) {
           std::vector<int32_t> A, Bn, Sn;
@@ -645,9 +658,11 @@ void analyze(gtg_context& c) {
       // default schedule: the dataflow pass (chol_dataflow.hip), symbolic fill at 128-tile granularity.  GTG_CHOL=streams
       // selects the per-column launch sequence of cholesky.hip; the elimination-tree schedule only exists there.
       const char* sched = std::getenv("GTG_CHOL");
-      c.use_df = part_of_pos.empty() && !(sched && std::string(sched) == "streams");
+      c.use_df = !(sched && std::string(sched) == "streams");
       free_df_plan(c.df);
-      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s);
+      std::vector<int32_t> tile_part;                      // nested dissection: the part of every block column (parts are aligned to column pairs)
+      if (!pair_part.empty()) { tile_part.resize(nt); for (int t = 0; t < nt; t++) tile_part[t] = pair_part[t / 2]; }
+      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s, &tile_part, &part_parent);
       for (int a = 0; a < nt; a++)
         for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
       for (int b = 0; b < nt; b++) if (dense || rhs[(size_t)b]) { ex.push_back(nt); ex.push_back(b); }
@@ -698,8 +713,10 @@ void analyze(gtg_context& c) {
                              (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9, c.plan.critical_pairs, np2);
     // keep the nested-dissection ordering only where it pays: the chains must get clearly shorter and the problem must be
     // in the latency-bound regime (separators cost fill: on the L1723 shape +60 % flops for a 30 % shorter path)
-    if (!part_of_pos.empty() && !nd_forced &&
-        !(c.plan.critical_pairs * 10 <= np2 * 8 && c.plan.flops <= 6e10)) { retry_rcm = true; }
+    if (!part_of_pos.empty() && !nd_forced) {
+      const bool shorter = c.use_df ? c.df.critical_tiles * 10 <= nt * 7 : c.plan.critical_pairs * 10 <= np2 * 7;
+      if (!(shorter && (c.use_df ? c.df.flops : c.plan.flops) <= 6e10)) retry_rcm = true;
+    }
   }
 
   if (!retry_rcm) break;

@@ -798,6 +798,18 @@ int gtg_debug_df_plan(gtg_handle c, int64_t sizes[4], int32_t* tasks, int32_t* k
   GTG_CATCH
 }
 
+int gtg_debug_df_chains(gtg_handle c, int64_t sizes[3], int32_t* chain_off, int32_t* chain_tiles, int32_t* seq) {
+  GTG_TRY
+  if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_df_chains: no problem uploaded");
+  const DfPlan& df = c->df;
+  sizes[0] = df.n_chain; sizes[1] = (int64_t)df.h_chain_tiles.size(); sizes[2] = (int64_t)df.h_seq.size();
+  if (chain_off) std::copy(df.h_chain_off.begin(), df.h_chain_off.end(), chain_off);
+  if (chain_tiles) std::copy(df.h_chain_tiles.begin(), df.h_chain_tiles.end(), chain_tiles);
+  if (seq) std::copy(df.h_seq.begin(), df.h_seq.end(), seq);
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_debug_df_trace(gtg_handle c, int64_t* out, int64_t n) {
   GTG_TRY
   if (!c || !c->uploaded || !out || !c->df.trace.p || n != (int64_t)c->df.trace.n) throw std::invalid_argument("gtg_debug_df_trace: no trace (GTG_DF_TRACE=1 at upload) or wrong size");

@@ -42,6 +42,7 @@ constexpr int ROWB = KC * 8;      // bytes per LDS row of a chunk
 constexpr int CH = T * KC * 8;    // bytes of one 128-row panel chunk
 constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of the substitution
 constexpr int kSpinLimit = 1 << 22;
+constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finished pieces of the tile's contraction (< kPieceBase pieces per tile)
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
 constexpr size_t kSmemPotrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
@@ -339,7 +340,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   if (piece > 0) {
     // the tile holds the earlier pieces' partial result, written (write-through) by other workgroups -- possibly while an older
     // version of it sat in this XCD's L2 (a piece before that one may have run here): read it past the L2
-    wait_flags(pflag_mine, epoch * 64 + piece, pflag_mine, epoch * 64 + piece, fail, sh, dbg, 7, I, J, piece);
+    wait_flags(pflag_mine, epoch * kPieceBase + piece, pflag_mine, epoch * kPieceBase + piece, fail, sh, dbg, 7, I, J, piece);
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -408,7 +409,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pflag_mine, epoch * 64 + piece + 1, sh);
+    if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + piece + 1, sh);
     return;
   }
   if (I == J) {
@@ -496,16 +497,17 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
                                            const long long* __restrict__ pd_flag, long long* tile_flag,
                                            const int32_t* __restrict__ has_sub, double* __restrict__ fail,
                                            const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
-                                           long long* __restrict__ trace, int first, int stride,
+                                           long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
                                            const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-  for (int J = first; J < nt; J += stride) {
+  for (int it = 0; it < n_mine; it++) {
+    const int J = my_tiles[it];
     if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, sh, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
-    if (tid == 0) { ctrl[1] = J + 1; if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started
+    if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const double* tile = S + ((int64_t)J * T) * NP + (int64_t)J * T;
     diag_tile_to_lds(tile, NP, A, tid);
     if (has_sub[J]) {
@@ -550,12 +552,14 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
                                                      const int32_t* __restrict__ has_sub, double* __restrict__ fail,
                                                      const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
-                                                     double* __restrict__ tile_exp) {
+                                                     double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
+                                                     const int32_t* __restrict__ chain_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace, (int)blockIdx.x, (int)gridDim.x, pivot_kind, tile_exp);
+  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
+             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
 }
 
-// Both roles in ONE kernel (GTG_DF_SINGLE=1): workgroups 0 and 1 are the chain (dispatched first, so they are resident before
+// Both roles in ONE kernel (GTG_DF_SINGLE=1): the first n_chain workgroups are the chain (dispatched first, so they are resident before
 // anybody waits for them; their upper eight wavefronts leave at once), the others take the tile tasks.  The chain's code is
 // compiled for the bulk kernel's 128 registers here (it spills: slower than the two-kernel form) but it is a single dispatch: this is the form rocprofv3's counter collection, which
 // serialises kernels, can measure -- two kernels that wait for each other never finish under it.
@@ -566,9 +570,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
-                                                      const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
+                                                      const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
+                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < 2) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, (int)blockIdx.x, 2, pivot_kind, tile_exp); }
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
   else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
@@ -579,7 +584,8 @@ __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *
 // ---- host: task lists --------------------------------------------------------------------------------------------
 // tile_struct: (nt x nt) row-major bytes, lower triangle: tile (I, J) holds something before the factorisation
 // (nullptr = dense).  Symbolic elimination at tile granularity adds the fill; the rhs row (tile row nt) is dense.
-void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t stream) {
+void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t stream,
+                   const std::vector<int32_t>* tile_part, const std::vector<int32_t>* part_parent) {
   std::vector<uint8_t> B((size_t)nt * nt, 0);
   for (int i = 0; i < nt; i++)
     for (int j = 0; j <= i; j++) B[(size_t)i * nt + j] = tile_struct ? (*tile_struct)[(size_t)i * nt + j] : 1;
@@ -593,35 +599,103 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   std::vector<std::vector<int32_t>> rowcols(nt);
   for (int i = 0; i < nt; i++)
     for (int k = 0; k < i; k++) if (B[(size_t)i * nt + k]) rowcols[i].push_back(k);
+
+  // ---- elimination-tree parallelism: several diagonal chains --------------------------------------------------------
+  // With a nested-dissection ordering (analysis.hip) the block columns fall into PARTS: leaves that do not touch each other and the
+  // separators above them (part_parent; children are numbered before their parent, a part is a contiguous range of tiles).  The
+  // reference eliminates independent subtrees of its junction tree concurrently (inference/ClusterTree-inst.h:218-317,
+  // base/treeTraversal/parallelTraversalTasks.h:35-156); here every leaf gets its own chain of diagonal tiles:
+  //   * the block columns are taken in an order `seq` that interleaves the parts that are ready (all children done) column by
+  //     column, pos[c] = place of column c in it.  Ticket order, contraction lists and the placement of early pieces below are all
+  //     stated in terms of pos (without parts pos[c] = c and everything is what it was);
+  //   * the chain kernel runs 2 workgroups per SLOT (<= 4 slots on the 8 reserved CUs); a leaf takes the next slot round robin,
+  //     a separator the slot of its first child; a slot's tiles are taken in pos order, alternating between its two workgroups.
+  // Deadlock freedom is unchanged: a task only waits for tasks with smaller tickets and for diagonal tiles whose own inputs have
+  // smaller tickets; a chain workgroup walks its tiles in pos order, so the tile it waits for is always the one whose inputs come first.
+  const bool tree = tile_part && part_parent && part_parent->size() > 1 && (int)tile_part->size() == nt;
+  const int nparts = tree ? (int)part_parent->size() : 1;
+  std::vector<int32_t> part_of(nt, 0), seq, pos(nt, 0);
+  if (tree) for (int c = 0; c < nt; c++) part_of[c] = (*tile_part)[c];
+  {
+    std::vector<std::vector<int32_t>> cols(nparts);
+    for (int c = 0; c < nt; c++) cols[part_of[c]].push_back(c);
+    std::vector<int> pending(nparts, 0), next(nparts, 0);
+    if (tree) for (int x = 0; x < nparts; x++) if ((*part_parent)[x] >= 0) pending[(*part_parent)[x]]++;
+    std::vector<int> active;
+    for (int x = 0; x < nparts; x++) if (pending[x] == 0) active.push_back(x);
+    while (!active.empty()) {
+      std::vector<int> still;
+      for (int x : active) {
+        if (next[x] < (int)cols[x].size()) seq.push_back(cols[x][next[x]++]);
+        if (next[x] < (int)cols[x].size()) { still.push_back(x); continue; }
+        const int par = tree ? (*part_parent)[x] : -1;
+        if (par >= 0 && --pending[par] == 0) still.push_back(par);
+      }
+      active.swap(still);
+    }
+    if ((int)seq.size() != nt) throw std::runtime_error("dataflow plan: the parts do not cover the block columns");
+    for (int q = 0; q < nt; q++) pos[seq[q]] = q;
+    // slots and chain lists
+    std::vector<int> slot(nparts, 0);
+    int nslots = 1;
+    if (tree) {
+      static const int max_slots = std::max(1, std::min(8, getenv("GTG_DF_SLOTS") ? atoi(getenv("GTG_DF_SLOTS")) : 4));   // > 4: 16 reserved CUs
+      std::vector<int> first_child(nparts, -1);
+      for (int x = nparts - 1; x >= 0; x--) if ((*part_parent)[x] >= 0) first_child[(*part_parent)[x]] = x;
+      int leaves = 0;
+      for (int x = 0; x < nparts; x++) if (first_child[x] < 0) slot[x] = leaves++ % max_slots;
+      for (int x = 0; x < nparts; x++) if (first_child[x] >= 0) slot[x] = slot[first_child[x]];   // (children precede their parent)
+      nslots = std::min(leaves, max_slots);
+    }
+    std::vector<std::vector<int32_t>> per_slot(nslots);
+    for (int q = 0; q < nt; q++) per_slot[slot[part_of[seq[q]]]].push_back(seq[q]);      // pos order
+    df.h_chain_off.assign(1, 0); df.h_chain_tiles.clear();
+    const int per = nt > 1 ? 2 : 1;
+    int longest = 0;
+    for (int sl = 0; sl < nslots; sl++) {
+      longest = std::max(longest, (int)per_slot[sl].size());
+      for (int w = 0; w < per; w++) {
+        for (size_t i = w; i < per_slot[sl].size(); i += per) df.h_chain_tiles.push_back(per_slot[sl][i]);
+        df.h_chain_off.push_back((int32_t)df.h_chain_tiles.size());
+      }
+    }
+    df.n_chain = (int)df.h_chain_off.size() - 1;
+    df.h_seq = seq;
+    df.critical_tiles = longest;
+  }
+  auto by_pos = [&](std::vector<int32_t>& v) { if (tree) std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) { return pos[a] < pos[b]; }); };
+
   df.h_tasks.clear(); df.h_klist.clear();
   const double t3 = (double)T * T * T;
   double flops = 0.0; int64_t stored = 0;
   // A tile's contraction is serial on one CU (14 us per step, up to ~30 steps) and the workgroups in flight cover only ~9 block
   // columns: a long contraction taken when its column comes up would not be done when the column's diagonal tile is factored.
   // So a long list is cut into PIECES of at most kPiece steps; piece r accumulates in place (tile -= its steps, flag
-  // part_flag = 64 epoch + r + 1) and is queued EARLIER than the tile's own column: right behind the block column of its
+  // part_flag = kPieceBase epoch + r + 1) and is queued EARLIER than the tile's own column: right behind the block column of its
   // youngest operand, where everything it reads is final and it runs without waiting.  Only the last piece (the youngest
   // kFinal steps + the substitution) sits in the tile's column and streams behind the columns before it.
   static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 6);
   static const int kFinal = std::max(1, getenv("GTG_DF_FINAL") ? atoi(getenv("GTG_DF_FINAL")) : 3);
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
-  std::vector<std::vector<Rec>> finals(nt), early(nt);
-  auto emit = [&](int I, int J, const std::vector<int32_t>& ks) {
-    const int n = (int)ks.size();
+  std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
+  auto emit = [&](int I, int J, std::vector<int32_t>& ks) {
+    by_pos(ks);                                        // the steps in the order in which their operands come into being
+    const int n = (int)ks.size(), G = pos[J];
     int m = std::max(0, n - kFinal);                 // older steps, in early pieces of at most kPiece; the last piece: the youngest
-    while (m > 0 && ks[m - 1] > J - 3) m--;          // (an early piece sits two groups before its tile's column at the latest)
+    while (m > 0 && pos[ks[m - 1]] > G - 3) m--;     // (an early piece sits two groups before its tile's column at the latest)
     const int f = n - m;
     const int R = (m + kPiece - 1) / kPiece + 1;
+    if (R >= (int)kPieceBase) throw std::runtime_error("dataflow plan: a contraction list needs more pieces than the part flags can count");
     const int32_t off = (int32_t)df.h_klist.size();
     df.h_klist.insert(df.h_klist.end(), ks.begin(), ks.end());
     int gprev = 0;
     for (int r = 0; r + 1 < R; r++) {
       const int b = r * kPiece, e = std::min(m, (r + 1) * kPiece);
       const int last_k = ks[e - 1];
-      const int g = std::max(last_k + 1, gprev);   // as early as its operands exist (<= J - 2)
+      const int g = std::max(pos[last_k] + 1, gprev);   // as early as its operands exist (<= G - 2)
       early[g].push_back(Rec{I, J, off + b, e - b, r, R}); gprev = g;
     }
-    finals[J].push_back(Rec{I, J, off + m, f, R - 1, R});
+    finals[G].push_back(Rec{I, J, off + m, f, R - 1, R});
   };
   std::vector<int32_t> ks;
   std::vector<int32_t> has_sub(nt, 0);
@@ -638,14 +712,15 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
       emit(I, J, ks);
       flops += t3 + (double)ks.size() * 2.0 * t3; stored++;
     }
-    emit(nt, J, rowcols[J]);   // rhs row: y_J (flops not counted, as in the right-looking plan)
+    ks = rowcols[J];
+    emit(nt, J, ks);   // rhs row: y_J (flops not counted, as in the right-looking plan)
   }
-  // ticket order: column c's own tasks (diagonal accumulation, the tile below it, ...), then the early pieces whose youngest
-  // operand is in column c - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
-  // pieces that merely have to be done some columns later (with the early pieces of group c - 1 in front of them, the diagonal
+  // ticket order: the own tasks of the column in place q (diagonal accumulation, the tile below it, ...), then the early pieces whose
+  // youngest operand is in place q - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
+  // pieces that merely have to be done some columns later (with the early pieces of group q - 1 in front of them, the diagonal
   // accumulation was taken 30 us before it was needed and the chain waited 20 us for it every few columns)
   auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
-  for (int c = 0; c < nt; c++) { put(finals[c]); if (c >= 1) put(early[c - 1]); }
+  for (int q = 0; q < nt; q++) { put(finals[q]); if (q >= 1) put(early[q - 1]); }
   put(early[nt - 1]);
   df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
@@ -654,6 +729,8 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   df.has_sub.upload(has_sub.data(), has_sub.size(), stream);
   df.h_has_sub = has_sub;
   df.klist.upload(df.h_klist.data(), df.h_klist.size(), stream);
+  df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
+  df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
   df.shadow = ((int64_t)(nt + 1) * nt + 511) / 512 * 512;
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
@@ -667,6 +744,7 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
 
 void free_df_plan(DfPlan& df) {
   df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.part_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
+  df.chain_off.free(); df.chain_tiles.free();
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
@@ -689,10 +767,11 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   // factorisation per device at a time (the caller holds that device's lock, api.hip), and creating masked streams costs
   // milliseconds -- per handle that was 5 ms on the first lambda try of every new optimizer.
   struct DfStreams { hipStream_t bulk = nullptr, chain = nullptr; hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr; int grid = 0; };
-  static std::map<int, DfStreams> per_device;
+  static std::map<std::pair<int, int>, DfStreams> per_device;   // (device, reserved CUs)
   static std::mutex per_device_mutex;
   DfStreams* dsp;
-  { std::lock_guard<std::mutex> lock(per_device_mutex); dsp = &per_device[c.device]; }
+  const int reserve = df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see below)
+  { std::lock_guard<std::mutex> lock(per_device_mutex); dsp = &per_device[{c.device, reserve}]; }
   DfStreams& ds = *dsp;
   if (!ds.bulk) {
     // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
@@ -706,7 +785,6 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int ncu = std::max(prop.multiProcessorCount, 16);
-    const int reserve = 8;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u), inv((ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu; i++) (i < ncu - reserve ? mask : inv)[i >> 5] |= 1u << (i & 31);
     check_hip(hipExtStreamCreateWithCUMask(&ds.bulk, (uint32_t)mask.size(), mask.data()), "masked stream");
@@ -726,9 +804,10 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   if (single) {
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
-    const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + 2);
+    const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
-                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp);
+                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
+                       df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -741,8 +820,8 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   static std::atomic<int> launches{0};
   const bool drop_chain = drop_at > 0 && ++launches == drop_at;
   if (!drop_chain)
-  hipLaunchKernelGGL(k_df_chain, dim3(nt > 1 ? 2 : 1), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp);
+  hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);

@@ -68,7 +68,7 @@ struct DfPlan {
   int nt = 0;
   int64_t n_tasks = 0;                          // bulk tasks: per block column J the diagonal accumulation PD(J), then the tiles (I, J) below, the rhs tile last
   DevBuf<int32_t> tasks;                        // 6 per task: I, J, offset / count into klist, piece r of R (the last piece finishes the tile)
-  DevBuf<long long> part_flag;                  // (nt + 1) x nt: 64 epoch + pieces of the tile's contraction that are in
+  DevBuf<long long> part_flag;                  // (nt + 1) x nt: kPieceBase epoch + pieces of the tile's contraction that are in
   DevBuf<int32_t> has_sub;                      // per diagonal tile J: tile (J, J-1) is stored (its update is streamed by the chain kernel)
   std::vector<int32_t> h_has_sub;
   DevBuf<int32_t> klist;                        // contraction lists: the column tiles k < J with both (I, k) and (J, k) stored
@@ -78,6 +78,12 @@ struct DfPlan {
   DevBuf<int32_t> ctrl;                         // [0] ticket counter of the bulk queue; [8..15] record of the first wait that gave up
   DevBuf<long long> trace;                      // GTG_DF_TRACE=1: 4 stamps per task + 2 per diagonal tile (gtg_debug_df_trace)
   std::vector<int32_t> h_tasks, h_klist;        // host copies (debug getters, CPU tests)
+  // the diagonal tiles by chain workgroup: workgroup w of k_df_chain factors chain_tiles[chain_off[w] .. chain_off[w + 1]) in that order.
+  // One slot = two workgroups that alternate; several slots when a nested-dissection ordering gave the factorisation independent parts
+  int n_chain = 0;
+  DevBuf<int32_t> chain_off, chain_tiles;
+  std::vector<int32_t> h_chain_off, h_chain_tiles, h_seq;   // h_seq: the order in which the block columns are taken (ticket groups)
+  int critical_tiles = 0;                       // diagonal tiles of the longest slot
   double flops = 0.0, dense_fraction = 1.0;
 };
 

@@ -48,7 +48,8 @@ void destroy_chol_streams(gtg_context& c);
 // chol_dataflow.hip -----------------------------------------------------------------------------------
 // The same factorisation as one dataflow pass of two persistent kernels (default schedule).  tile_struct = lower-triangular
 // boolean structure over 128x128 tiles before the factorisation ((nt x nt) row-major bytes; nullptr = dense).
-void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s);
+void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s,
+                   const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 void free_df_plan(DfPlan& df);
 void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
                         const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);

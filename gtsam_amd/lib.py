@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -87,6 +87,7 @@ def load():
     lib.gtg_debug_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
     lib.gtg_debug_plan_lists.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.gtg_debug_df_plan.argtypes = [C.c_void_p] * 4
+    lib.gtg_debug_df_chains.argtypes = [C.c_void_p] * 5
     lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
     lib.gtg_debug_df_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.gtg_io_last_error.restype = C.c_char_p
@@ -240,7 +241,11 @@ class DeviceGraph:
         _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, None, None), "gtg_debug_df_plan")
         tasks = np.zeros((int(sz[1]), 6), np.int32); klist = np.zeros(int(sz[2]), np.int32)
         _check(self.lib.gtg_debug_df_plan(self.h, sz.ctypes.data, tasks.ctypes.data, klist.ctypes.data), "gtg_debug_df_plan")
-        return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist)
+        cs = np.zeros(3, np.int64)
+        _check(self.lib.gtg_debug_df_chains(self.h, cs.ctypes.data, None, None, None), "gtg_debug_df_chains")
+        coff = np.zeros(int(cs[0]) + 1, np.int32); ctiles = np.zeros(int(cs[1]), np.int32); seq = np.zeros(int(cs[2]), np.int32)
+        _check(self.lib.gtg_debug_df_chains(self.h, cs.ctypes.data, coff.ctypes.data, ctiles.ctypes.data, seq.ctypes.data), "gtg_debug_df_chains")
+        return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist, chain_off=coff, chain_tiles=ctiles, seq=seq)
 
     def df_trace(self):
         """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][2] stamps) of the last factorisation, 100 MHz ticks."""

@@ -258,6 +258,11 @@ int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* b
  * row; a long contraction is cut into pieces that accumulate in place, the last piece finishes the tile), in the order in which
  * the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
 int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* klist);
+/* The diagonal chains of the same schedule: sizes = {chain workgroups W, diagonal tiles, block columns}; workgroup w of the chain
+ * kernel factors chain_tiles[chain_off[w] .. chain_off[w + 1]) in that order (one chain = two workgroups that alternate; several
+ * chains when a nested-dissection ordering gave the elimination tree independent subtrees -- the reference's parallel elimination of
+ * independent cliques, inference/ClusterTree-inst.h:218-317); seq = the order in which the block columns' tasks are queued. */
+int gtg_debug_df_chains(gtg_handle h, int64_t sizes[3], int32_t* chain_off, int32_t* chain_tiles, int32_t* seq);
 /* out[0] = tickets taken in the last factorisation; out[8..15] = record of the first dependency wait that gave up (kind 1/2: tile
  * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted --
  * out[15], the second wanted value, is replaced by a host counter: the lambda tries of this handle that were repeated with the

@@ -42,7 +42,7 @@ print("RESULT " + json.dumps(out))
 
 
 def _plan(workload, nd_depth=0):
-    env = {"GTG_ND_DEPTH": str(nd_depth)} if nd_depth else {}
+    env = {} if nd_depth is None else {"GTG_ND_DEPTH": str(nd_depth)}      # None: the library's own choice; 0: nested dissection off
     d = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra=env)
     for k in ("rows", "pairs", "bcols", "pair_part", "part_parent"):
         d[k] = np.array(d[k], np.int64)
@@ -147,6 +147,16 @@ def _execute_df(pl, df, t=8, seed=0):
     A += np.diag(np.abs(A).sum(1) + 1.0 + rng.uniform(0, 1, n))
     Ld = np.linalg.cholesky(A); yd = np.linalg.solve(Ld, g)
     tasks = np.array(df["tasks"], np.int64).reshape(-1, 6); klist = np.array(df["klist"], np.int64)
+    # the order in which the block columns are queued (interleaves the independent parts of a nested-dissection ordering) and the
+    # diagonal chains: every diagonal tile in exactly one chain workgroup's list, every list in queueing order -- a chain workgroup
+    # that waits for its next tile then waits for the tile whose inputs are queued first (the no-deadlock argument of build_df_plan)
+    seq = np.array(df["seq"], np.int64); coff = np.array(df["chain_off"], np.int64); ctiles = np.array(df["chain_tiles"], np.int64)
+    assert sorted(seq.tolist()) == list(range(nt)) and sorted(ctiles.tolist()) == list(range(nt))
+    pos = np.empty(nt, np.int64); pos[seq] = np.arange(nt)
+    assert len(coff) >= 2 and coff[0] == 0 and coff[-1] == nt
+    for w in range(len(coff) - 1):
+        mine = ctiles[coff[w]:coff[w + 1]]
+        assert (np.diff(pos[mine]) > 0).all(), f"chain workgroup {w} does not take its tiles in queueing order"
     owned = {(int(I), int(J)) for I, J in tasks[:, :2]}
     assert len(owned) == int((tasks[:, 4] == tasks[:, 5] - 1).sum()), "a tile must have exactly one finishing piece"
     stored_old = {(int(I), int(J)) for I, J in pl["stored"]}
@@ -165,10 +175,10 @@ def _execute_df(pl, df, t=8, seed=0):
     for I, J, off, cnt, r, R in tasks:
         I, J, off, cnt, r, R = (int(v) for v in (I, J, off, cnt, r, R))
         ks = [int(k) for k in klist[off:off + cnt]]
-        assert ks == sorted(ks) and all(k < J for k in ks)
+        assert [pos[k] for k in ks] == sorted(pos[k] for k in ks) and all(k < J for k in ks)     # steps in the order their operands appear
         # pieces of a tile's contraction accumulate in place, in order (piece r waits for piece r - 1), oldest steps first
         assert pieces_done.get((I, J), 0) == r and 0 <= r < R, f"piece {r} of tile ({I},{J}) out of order"
-        assert not seen_k.get((I, J)) or (ks and ks[0] > seen_k[(I, J)][-1]) or not ks
+        assert not seen_k.get((I, J)) or (ks and pos[ks[0]] > pos[seen_k[(I, J)][-1]]) or not ks
         seen_k.setdefault((I, J), []).extend(ks)
         pieces_done[(I, J)] = r + 1
         acc = tile[(I, J)]
@@ -209,9 +219,12 @@ def stub():
 
 @pytest.mark.parametrize("workload,nd", [("bal:60:6000:7", 0), ("dubrovnik16", 0), ("sphere2500", 0), ("sphere2500", 2),
                                          ("sphere2500", 3), ("bal:300:20000:3", 0), ("bal:300:20000:3", 2),
-                                         ("ladybug1723", 0), ("ladybug1723", 2), ("w20000", 0), ("w20000", 3)])
+                                         ("ladybug1723", 0), ("ladybug1723", 2), ("w20000", 0), ("w20000", 3),
+                                         ("sphere2500", None), ("w20000", None), ("ladybug1723", None), ("dubrovnik16", None)])
 def test_schedule_reproduces_a_dense_cholesky(stub, workload, nd):
     pl = _plan(workload, nd)
+    if nd is None:     # the library's own choice: several chains for the sparse pose graphs, one band for the camera systems
+        nd = 3 if workload in ("sphere2500", "w20000") else 0
     if nd:
         assert len(pl["part_parent"]) > 1, "nested dissection was requested but the plan has a single part"
         # children precede their parent, a pair of columns belongs to exactly one part
@@ -221,13 +234,19 @@ def test_schedule_reproduces_a_dense_cholesky(stub, workload, nd):
         assert len(pl["part_parent"]) == 0 and not pl["per_pair"][:, 7].any()
     worst, worst_y, worst_x, n_stored = _execute(pl)
     assert worst <= 1e-10 and worst_y <= 1e-10 and worst_x <= 1e-10, (worst, worst_y, worst_x)
-    if not nd:   # the dataflow schedule (default without nested dissection): same result, never more tiles
-        assert pl["df"]["active"]
-        w, wy, n_df = _execute_df(pl, pl["df"])
-        assert w <= 1e-10 and wy <= 1e-10, (w, wy)
-        assert n_df <= n_stored
+    # the dataflow schedule (the default, with or without nested dissection): same result, never more tiles
+    assert pl["df"]["active"]
+    w, wy, n_df = _execute_df(pl, pl["df"])
+    assert w <= 1e-10 and wy <= 1e-10, (w, wy)
+    assert n_df <= n_stored
+    n_chain_wg = len(pl["df"]["chain_off"]) - 1
+    nt = int(pl["nt"])
+    if nd:    # independent subtrees run as several diagonal chains (<= 4 slots of two workgroups)
+        assert 2 < n_chain_wg <= 8 and n_chain_wg % 2 == 0, n_chain_wg
+        longest = max(np.diff(np.array(pl["df"]["chain_off"])[::2]))        # diagonal tiles of the longest slot
+        assert longest < nt, (longest, nt)
     else:
-        assert not pl["df"]["active"]
+        assert n_chain_wg == (2 if nt > 1 else 1)
     nt = int(pl["nt"])
     assert n_stored <= (nt + 1) * (nt + 2) // 2
     # the exchange list (structure before the factorisation) is a subset of the stored tiles

@@ -162,20 +162,31 @@ def test_pose2_w20000_full_trajectory(gpu):
     assert rel(opt.values_packed(), g["final_values"]) <= 1e-4
 
 
-def test_nested_dissection_tree_schedule_is_equivalent(gpu, monkeypatch):
-    """GTG_ND_DEPTH=2: nested-dissection ordering (parts aligned to 256-column pairs, identity padding between them) and
-    the elimination-tree schedule of the tile Cholesky (independent chains on their own streams, cross-part updates on
-    one in-order stream).  Same damped solve and same LM trajectory as the reference, on a graph large enough to split
-    (sphere2500: 7 parts)."""
+@pytest.mark.parametrize("sched,depth", [("dataflow", 2), ("dataflow", 3), ("dataflow", 0), ("streams", 2)])
+def test_nested_dissection_schedules_are_equivalent(gpu, monkeypatch, sched, depth):
+    """Elimination-tree parallelism (the reference eliminates independent cliques concurrently, inference/ClusterTree-inst.h:218-317):
+    a nested-dissection ordering (parts aligned to 256-column pairs, identity padding between them) gives the tile Cholesky
+    independent parts.  dataflow: the parts are several diagonal chains inside the two persistent kernels (the default for
+    sparse pose graphs, 2 levels; chol_dataflow.hip::build_df_plan); streams: the round-1 tree schedule (chains on their own
+    streams, cross-part updates on one in-order stream); depth 0: one chain (RCM).  Every variant: the reference's damped solve
+    and the reference's full LM trajectory on sphere2500."""
     from gtsam_amd.optimizer import DeviceLevenbergMarquardt
-    monkeypatch.setenv("GTG_ND_DEPTH", "2")
+    monkeypatch.setenv("GTG_ND_DEPTH", str(depth))
+    if sched == "streams":
+        monkeypatch.setenv("GTG_CHOL", "streams")
     g = load_golden("sphere2500")
     p, v0 = PB.sphere2500(g)
     dev = gpu.DeviceGraph(p)
+    pl = dev.df_plan()
+    assert pl["active"] == (sched == "dataflow")
+    if sched == "dataflow":
+        n_wg = len(pl["chain_off"]) - 1
+        assert (n_wg == 2) if depth == 0 else (2 < n_wg <= 8), n_wg
     dev.set_values(v0)
     dev.linearize()
     rc, out = dev.try_lambda(1e-5, False)
     assert rc == 0 and rel(dev.delta(), g["solve_delta"]) <= 1e-6
+    assert dev.df_ctrl()[15] == 0 if sched == "dataflow" else True        # no lambda try had to be repeated
     dev.close()
     opt = DeviceLevenbergMarquardt(p, v0, LMP())
     opt.optimize()

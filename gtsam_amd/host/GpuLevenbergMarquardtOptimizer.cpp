@@ -40,14 +40,19 @@
 #error "gtsam_amd: a point behind the camera zeroes the factor, as the reference does when it throws CheiralityException (flag on)"
 #endif
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <algorithm>
 #include <map>
 #include <stdexcept>
+#include <thread>
 
 using namespace gtsam;
 
@@ -69,8 +74,12 @@ typedef internal::LevenbergMarquardtState State;
 
 struct GpuLevenbergMarquardtOptimizer::Impl {
   gtg_handle h = nullptr;
-  std::vector<Key> keys;                 // variable id -> Key (Values order)
-  std::map<Key, int32_t> id;             // Key -> variable id
+  std::vector<Key> keys;                 // variable id -> Key (Values order: sorted)
+  int32_t idOf(Key k) const {            // Key -> variable id: binary search over the sorted, contiguous keys
+    auto it = std::lower_bound(keys.begin(), keys.end(), k);
+    if (it == keys.end() || *it != k) throw ValuesKeyDoesNotExist("GpuLevenbergMarquardtOptimizer", k);
+    return (int32_t)(it - keys.begin());
+  }
   std::vector<int32_t> var_type;
   std::vector<int64_t> val_off;
   std::vector<double> packed;            // host copy of the packed values
@@ -161,52 +170,199 @@ struct NoiseTable {
 };
 }  // namespace
 
+// Construction.  The reference's constructor (LevenbergMarquardtOptimizer.cpp:47-66, NonlinearOptimizer.cpp:41-43) copies the graph
+// and the Values and evaluates graph.error(initialValues) on the host -- 0.11 s for the L1723 shape, one thread (NonlinearFactorGraph.cpp
+// :170-179 is serial even with TBB).  Here the base classes are constructed on an EMPTY graph (so that neither that pass nor COLAMD
+// runs: the ordering handed over is the caller's, or a trivial one -- the device path has its own elimination structure), then
+// graph_ and state_ (both protected, NonlinearOptimizer.h:78-80) are set: the graph by shared_ptr copies, the state from the
+// caller's Values and the error the DEVICE computed for them (k_error, <= 1e-9 of the reference's, tests/test_gpu_parity.py).
+static LevenbergMarquardtParams withOrdering(const LevenbergMarquardtParams& params, const Values& initial, const Ordering* ordering) {
+  LevenbergMarquardtParams p = params;
+  if (ordering) p.ordering = *ordering;
+  else if (!p.ordering) p.ordering = Ordering(initial.keys());
+  return p;
+}
+
 GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
                                                                const LevenbergMarquardtParams& params, int device,
                                                                const ShardSpec& shards)
-    : LevenbergMarquardtOptimizer(graph, initial, [&] {
-        // the reference's constructor runs COLAMD when no ordering is given (LevenbergMarquardtParams.h:112-117);
-        // the device path has its own elimination structure, so hand it a trivial ordering to skip that work
-        if (params.ordering) return params;
-        LevenbergMarquardtParams p = params; p.ordering = Ordering(initial.keys()); return p; }()),
-      impl_(new Impl) { init(initial, device, shards); }
+    : LevenbergMarquardtOptimizer(NonlinearFactorGraph(), Values(), withOrdering(params, initial, nullptr)), impl_(new Impl) {
+  graph_ = graph;
+  init(initial, device, shards);
+}
 
 GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
                                                                const Ordering& ordering,
                                                                const LevenbergMarquardtParams& params, int device,
                                                                const ShardSpec& shards)
-    : LevenbergMarquardtOptimizer(graph, initial, ordering, params), impl_(new Impl) { init(initial, device, shards); }
+    : LevenbergMarquardtOptimizer(NonlinearFactorGraph(), Values(), withOrdering(params, initial, &ordering)), impl_(new Impl) {
+  graph_ = graph;
+  init(initial, device, shards);
+}
 
 GpuLevenbergMarquardtOptimizer::~GpuLevenbergMarquardtOptimizer() = default;
 
+namespace {
+// What one host thread extracts from its range of the graph: the rows of every factor table in graph order, the noise models and
+// calibrations as (run length, object) -- rows of the shared tables are handed out afterwards, sequentially, in first-occurrence
+// order, so that the tables are those of a single-threaded pass whatever the thread count.
+struct Extract {
+  std::vector<int32_t> sfm_cam, sfm_pt, pj_pose, pj_pt, pj_sen, bt_1, bt_2, pr_var, sm_cam;
+  std::vector<double> sfm_z, pj_z, sensor, bt_z, pr_data, sm_z, sm_prm;
+  std::vector<int64_t> pr_off, sm_ptr;
+  std::vector<std::pair<int32_t, int64_t>> fac_map;                       // (type, index in THIS chunk's table of that type)
+  typedef std::vector<std::pair<int64_t, SharedNoiseModel>> Runs;
+  Runs sfm_nz, pj_nz, bt_nz, pr_nz, sm_nz;
+  std::vector<int32_t> bt_dim, pr_dim;                                      // expected noise dimension per between / prior factor
+  std::vector<std::pair<const void*, int>> pj_cal;                          // calibration object per projection factor, 1 = Cal3DS2
+  std::exception_ptr err; size_t err_at = 0;
+  static void run(Runs& r, const SharedNoiseModel& nm) { if (!r.empty() && r.back().second.get() == nm.get()) r.back().first++; else r.emplace_back(1, nm); }
+};
+}  // namespace
+
 void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, const ShardSpec& shards) {
   Impl& m = *impl_;
-  // ---- variables: Values order (sorted by Key, Values.h:74-79) ---------------------------------------------
-  m.val_off.push_back(0);
+  const bool timing = std::getenv("GTG_DEBUG_TIMING") != nullptr;   // host-side breakdown of the construction on stderr
+  auto tprev = std::chrono::high_resolution_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::high_resolution_clock::now();
+    std::fprintf(stderr, "[gtsam_amd shim ] %-46s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
+  // the state's deep copy of the caller's Values (one heap object per variable) runs beside the extraction
+  Values stateValues;
+  std::exception_ptr copyErr;
+  std::thread copier([&] { try { stateValues = initial; } catch (...) { copyErr = std::current_exception(); } });
+  struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } joinCopier{copier};
+
+  // ---- variables: Values order (sorted by Key, Values.h:74-79); one pass, packed as they are classified ---------------
+  const size_t nvars = initial.size();
+  m.keys.reserve(nvars); m.var_type.reserve(nvars); m.val_off.reserve(nvars + 1); m.dim_off.reserve(nvars + 1);
+  m.val_off.push_back(0); m.dim_off.push_back(0);
+  m.packed.reserve(17 * nvars / 4 + 64);
   for (const auto& kv : initial) {
     int32_t t;
-    if (dynamic_cast<const GenericValue<Pose3>*>(&kv.value)) t = GTG_VAR_POSE3;
-    else if (dynamic_cast<const GenericValue<SfmCamera>*>(&kv.value)) t = GTG_VAR_SFM_CAMERA;
-    else if (dynamic_cast<const GenericValue<Point3>*>(&kv.value)) t = GTG_VAR_POINT3;
-    else if (dynamic_cast<const GenericValue<Pose2>*>(&kv.value)) t = GTG_VAR_POSE2;
+    const size_t at = m.packed.size();
+    if (auto* v = dynamic_cast<const GenericValue<Point3>*>(&kv.value)) { t = GTG_VAR_POINT3; const Point3& q = v->value(); m.packed.insert(m.packed.end(), {q.x(), q.y(), q.z()}); }
+    else if (auto* v = dynamic_cast<const GenericValue<SfmCamera>*>(&kv.value)) { t = GTG_VAR_SFM_CAMERA; m.packed.resize(at + 17); packCamera(v->value(), m.packed.data() + at); }
+    else if (auto* v = dynamic_cast<const GenericValue<Pose3>*>(&kv.value)) { t = GTG_VAR_POSE3; m.packed.resize(at + 12); packPose(v->value(), m.packed.data() + at); }
+    else if (auto* v = dynamic_cast<const GenericValue<Pose2>*>(&kv.value)) { t = GTG_VAR_POSE2; const Pose2& q = v->value(); m.packed.insert(m.packed.end(), {q.x(), q.y(), q.theta()}); }
     else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported value type for key " + DefaultKeyFormatter(kv.key));
-    m.id[kv.key] = (int32_t)m.keys.size();
     m.keys.push_back(kv.key); m.var_type.push_back(t);
-    m.val_off.push_back(m.val_off.back() + (t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3));
+    m.val_off.push_back((int64_t)m.packed.size());
+    m.dim_off.push_back(m.dim_off.back() + (t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3));
   }
-  m.dim_off.push_back(0);
-  for (int32_t t : m.var_type) m.dim_off.push_back(m.dim_off.back() + (t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3));
-  m.packed.assign(m.val_off.back(), 0.0);
-  for (size_t v = 0; v < m.keys.size(); v++) {
-    double* p = m.packed.data() + m.val_off[v];
-    if (m.var_type[v] == GTG_VAR_POSE3) packPose(initial.at<Pose3>(m.keys[v]), p);
-    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) packCamera(initial.at<SfmCamera>(m.keys[v]), p);
-    else if (m.var_type[v] == GTG_VAR_POSE2) { const Pose2 q = initial.at<Pose2>(m.keys[v]); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
-    else { const Point3 q = initial.at<Point3>(m.keys[v]); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
-  }
-  auto idOf = [&](Key k) { auto it = m.id.find(k); if (it == m.id.end()) throw ValuesKeyDoesNotExist("GpuLevenbergMarquardtOptimizer", k); return it->second; };
+  // Key -> variable id: the keys are sorted, so a binary search over the contiguous array (a std::map of 158 000 keys cost 0.2 s of
+  // pointer chasing for the 1.35 M lookups of the L1723 shape)
+  auto idOf = [&](Key k) { return m.idOf(k); };
+  lap("variables: classify + pack");
 
-  // ---- factors: one pass, dynamic_cast to the supported types (anything else is a hard error) ------------------
+  // ---- factors: dynamic_cast to the supported types (anything else is a hard error), on host threads ------------------
+  const size_t nfac = graph_.size();
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const char* thr_env = std::getenv("GTG_HOST_THREADS");
+  const size_t grain = std::getenv("GTG_EXTRACT_GRAIN") ? std::max(1, std::atoi(std::getenv("GTG_EXTRACT_GRAIN"))) : 4096;   // factors per thread at least (tests: 1)
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(hw, 32u)), nfac / grain + 1}));
+  std::vector<Extract> part(nthreads);
+  auto work = [&](size_t ti) {
+    Extract& x = part[ti];
+    const size_t b = nfac * ti / nthreads, e = nfac * (ti + 1) / nthreads;
+    x.fac_map.reserve(e - b);
+    x.sm_ptr.push_back(0);
+    size_t i = b;
+    try {
+      for (; i < e; i++) {
+        const auto& f = graph_[i];
+        if (!f) { x.fac_map.emplace_back(-1, 0); continue; }
+        if (auto s = dynamic_cast<const SfmFactor*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_GENERAL_SFM, (int64_t)x.sfm_cam.size());
+          x.sfm_cam.push_back(idOf(s->key1())); x.sfm_pt.push_back(idOf(s->key2()));
+          x.sfm_z.push_back(s->measured().x()); x.sfm_z.push_back(s->measured().y());
+          Extract::run(x.sfm_nz, s->noiseModel());
+        } else if (auto p = dynamic_cast<const ProjFactor*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)x.pj_pose.size());
+          if (p->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
+          x.pj_pose.push_back(idOf(p->key1())); x.pj_pt.push_back(idOf(p->key2()));
+          x.pj_z.push_back(p->measured().x()); x.pj_z.push_back(p->measured().y());
+          Extract::run(x.pj_nz, p->noiseModel());
+          x.pj_cal.emplace_back(p->calibration().get(), 0);
+          if (p->body_P_sensor()) { x.pj_sen.push_back((int32_t)(x.sensor.size() / 12)); x.sensor.resize(x.sensor.size() + 12); packPose(*p->body_P_sensor(), x.sensor.data() + x.sensor.size() - 12); }
+          else x.pj_sen.push_back(-1);
+        } else if (auto pd = dynamic_cast<const ProjFactorDS2*>(f.get())) {   // the same factor with a Cal3DS2 calibration (section 8(f) #3)
+          x.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)x.pj_pose.size());
+          if (pd->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
+          x.pj_pose.push_back(idOf(pd->key1())); x.pj_pt.push_back(idOf(pd->key2()));
+          x.pj_z.push_back(pd->measured().x()); x.pj_z.push_back(pd->measured().y());
+          Extract::run(x.pj_nz, pd->noiseModel());
+          x.pj_cal.emplace_back(pd->calibration().get(), 1);
+          if (pd->body_P_sensor()) { x.pj_sen.push_back((int32_t)(x.sensor.size() / 12)); x.sensor.resize(x.sensor.size() + 12); packPose(*pd->body_P_sensor(), x.sensor.data() + x.sensor.size() - 12); }
+          else x.pj_sen.push_back(-1);
+        } else if (auto sf = dynamic_cast<const SmartFactor*>(f.get())) {
+          x.fac_map.emplace_back(-2, (int64_t)x.sm_prm.size() / 8);   // (no Jacobian record: its linearisation is a Hessian factor)
+          const SmartProjectionParams& sp = (*sf).*SmartAccess::params();
+          const TriangulationParameters& tp = sp.triangulation;
+          if (sp.linearizationMode != HESSIAN) throw std::invalid_argument("SmartProjectionFactor: only the HESSIAN linearisation is supported");
+          if (tp.enableEPI || tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: enableEPI / useLOST are not supported");
+          if (sp.throwCheirality) throw std::invalid_argument("SmartProjectionFactor with throwCheirality is not supported");
+          const SharedIsotropic& iso = (*sf).*SmartAccess::noise();
+          Extract::run(x.sm_nz, iso);
+          const auto& zs = sf->measured();
+          if (zs.size() != sf->keys().size() || zs.empty()) throw std::invalid_argument("SmartProjectionFactor: measurements and keys do not match");
+          for (size_t k = 0; k < zs.size(); k++) { x.sm_cam.push_back(idOf(sf->keys()[k])); x.sm_z.push_back(zs[k].x()); x.sm_z.push_back(zs[k].y()); }
+          x.sm_ptr.push_back((int64_t)x.sm_cam.size());
+          x.sm_prm.insert(x.sm_prm.end(), {tp.rankTolerance, tp.landmarkDistanceThreshold, tp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold,
+                                           sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0), 0.0, 0.0, 0.0});
+        } else if (auto bb = dynamic_cast<const BetweenFactor<Pose3>*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)x.bt_1.size());
+          x.bt_1.push_back(idOf(bb->key1())); x.bt_2.push_back(idOf(bb->key2()));
+          x.bt_z.resize(x.bt_z.size() + 12); packPose(bb->measured(), x.bt_z.data() + x.bt_z.size() - 12);
+          Extract::run(x.bt_nz, bb->noiseModel()); x.bt_dim.push_back(6);
+        } else if (auto b2 = dynamic_cast<const BetweenFactor<Pose2>*>(f.get())) {
+          // same table as BetweenFactor<Pose3>: the factor's type follows from its variables', (x, y, theta) in the first 3 doubles
+          x.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)x.bt_1.size());
+          x.bt_1.push_back(idOf(b2->key1())); x.bt_2.push_back(idOf(b2->key2()));
+          const Pose2& z = b2->measured();
+          x.bt_z.insert(x.bt_z.end(), {z.x(), z.y(), z.theta(), 0, 0, 0, 0, 0, 0, 0, 0, 0});
+          Extract::run(x.bt_nz, b2->noiseModel()); x.bt_dim.push_back(3);
+        } else if (auto q2 = dynamic_cast<const PriorFactor<Pose2>*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)x.pr_var.size());
+          x.pr_var.push_back(idOf(q2->key())); x.pr_off.push_back((int64_t)x.pr_data.size());
+          x.pr_data.insert(x.pr_data.end(), {q2->prior().x(), q2->prior().y(), q2->prior().theta()});
+          Extract::run(x.pr_nz, q2->noiseModel()); x.pr_dim.push_back(3);
+        } else if (auto pp = dynamic_cast<const PriorFactor<Pose3>*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)x.pr_var.size());
+          x.pr_var.push_back(idOf(pp->key())); x.pr_off.push_back((int64_t)x.pr_data.size());
+          x.pr_data.resize(x.pr_data.size() + 12); packPose(pp->prior(), x.pr_data.data() + x.pr_data.size() - 12);
+          Extract::run(x.pr_nz, pp->noiseModel()); x.pr_dim.push_back(6);
+        } else if (auto pc = dynamic_cast<const PriorFactor<SfmCamera>*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)x.pr_var.size());
+          x.pr_var.push_back(idOf(pc->key())); x.pr_off.push_back((int64_t)x.pr_data.size());
+          x.pr_data.resize(x.pr_data.size() + 17); packCamera(pc->prior(), x.pr_data.data() + x.pr_data.size() - 17);
+          Extract::run(x.pr_nz, pc->noiseModel()); x.pr_dim.push_back(9);
+        } else if (auto p3 = dynamic_cast<const PriorFactor<Point3>*>(f.get())) {
+          x.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)x.pr_var.size());
+          x.pr_var.push_back(idOf(p3->key())); x.pr_off.push_back((int64_t)x.pr_data.size());
+          x.pr_data.insert(x.pr_data.end(), {p3->prior().x(), p3->prior().y(), p3->prior().z()});
+          Extract::run(x.pr_nz, p3->noiseModel()); x.pr_dim.push_back(3);
+        } else {
+          throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
+                                      "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2|Cal3DS2>, "
+                                      "SmartProjectionFactor<SfmCamera>, BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
+        }
+      }
+    } catch (...) { x.err = std::current_exception(); x.err_at = i; }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (size_t ti = 1; ti < nthreads; ti++) pool.emplace_back(work, ti);
+    work(0);
+    for (auto& t : pool) t.join();
+  }
+  for (const Extract& x : part) if (x.err) std::rethrow_exception(x.err);   // the first offending factor in graph order
+  lap("factors: extraction (host threads)");
+
+  // ---- merge in graph order: concatenate the tables, hand out the rows of the noise / calibration tables -----------------
   NoiseTable nt;
   std::vector<int32_t> sfm_cam, sfm_pt, sfm_nz, pj_pose, pj_pt, pj_nz, pj_cal, pj_sen, bt_1, bt_2, bt_nz, pr_var, pr_nz;
   std::vector<double> sfm_z, pj_z, calib, sensor, bt_z, pr_data;
@@ -217,99 +373,54 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   std::vector<int32_t> sm_cam, sm_nz;
   std::vector<double> sm_z, sm_prm;
   bool any_distortion = false;
-  for (const auto& f : graph_) {
-    if (!f) { m.fac_map.emplace_back(-1, 0); continue; }
-    if (auto s = std::dynamic_pointer_cast<SfmFactor>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_GENERAL_SFM, (int64_t)sfm_cam.size());
-      sfm_cam.push_back(idOf(s->key1())); sfm_pt.push_back(idOf(s->key2()));
-      sfm_z.push_back(s->measured().x()); sfm_z.push_back(s->measured().y());
-      sfm_nz.push_back(nt.add(s->noiseModel(), 2));
-    } else if (auto p = std::dynamic_pointer_cast<ProjFactor>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)pj_pose.size());
-      if (p->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
-      pj_pose.push_back(idOf(p->key1())); pj_pt.push_back(idOf(p->key2()));
-      pj_z.push_back(p->measured().x()); pj_z.push_back(p->measured().y());
-      pj_nz.push_back(nt.add(p->noiseModel(), 2));
-      const Cal3_S2* K = p->calibration().get();
-      auto it = calib_id.find(K);
-      if (it == calib_id.end()) {
-        it = calib_id.emplace(K, (int32_t)(calib.size() / 5)).first;
-        calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
-        calib_dist.insert(calib_dist.end(), {0.0, 0.0, 0.0, 0.0});
-      }
-      pj_cal.push_back(it->second);
-      if (p->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*p->body_P_sensor(), sensor.data() + sensor.size() - 12); }
-      else pj_sen.push_back(-1);
-    } else if (auto pd = std::dynamic_pointer_cast<ProjFactorDS2>(f)) {   // the same factor with a Cal3DS2 calibration (section 8(f) #3)
-      m.fac_map.emplace_back(GTG_FAC_PROJECTION, (int64_t)pj_pose.size());
-      if (pd->throwCheirality()) throw std::invalid_argument("GenericProjectionFactor with throwCheirality is not supported");
-      pj_pose.push_back(idOf(pd->key1())); pj_pt.push_back(idOf(pd->key2()));
-      pj_z.push_back(pd->measured().x()); pj_z.push_back(pd->measured().y());
-      pj_nz.push_back(nt.add(pd->noiseModel(), 2));
-      const Cal3DS2* K = pd->calibration().get();
-      auto it = calib_id.find(K);
-      if (it == calib_id.end()) {
-        it = calib_id.emplace(K, (int32_t)(calib.size() / 5)).first;
-        calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
-        calib_dist.insert(calib_dist.end(), {K->k1(), K->k2(), K->p1(), K->p2()});
-        any_distortion = true;
-      }
-      pj_cal.push_back(it->second);
-      if (pd->body_P_sensor()) { pj_sen.push_back((int32_t)(sensor.size() / 12)); sensor.resize(sensor.size() + 12); packPose(*pd->body_P_sensor(), sensor.data() + sensor.size() - 12); }
-      else pj_sen.push_back(-1);
-    } else if (auto sf = std::dynamic_pointer_cast<SmartFactor>(f)) {
-      m.fac_map.emplace_back(-2, (int64_t)sm_nz.size());   // (no Jacobian record: its linearisation is a Hessian factor)
-      const SmartProjectionParams& sp = (*sf).*SmartAccess::params();
-      const TriangulationParameters& tp = sp.triangulation;
-      if (sp.linearizationMode != HESSIAN) throw std::invalid_argument("SmartProjectionFactor: only the HESSIAN linearisation is supported");
-      if (tp.enableEPI || tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: enableEPI / useLOST are not supported");
-      if (sp.throwCheirality) throw std::invalid_argument("SmartProjectionFactor with throwCheirality is not supported");
-      const SharedIsotropic& iso = (*sf).*SmartAccess::noise();
-      sm_nz.push_back(nt.add(iso, 2));
-      const auto& zs = sf->measured();
-      if (zs.size() != sf->keys().size() || zs.empty()) throw std::invalid_argument("SmartProjectionFactor: measurements and keys do not match");
-      for (size_t k = 0; k < zs.size(); k++) { sm_cam.push_back(idOf(sf->keys()[k])); sm_z.push_back(zs[k].x()); sm_z.push_back(zs[k].y()); }
-      sm_ptr.push_back((int64_t)sm_cam.size());
-      sm_prm.insert(sm_prm.end(), {tp.rankTolerance, tp.landmarkDistanceThreshold, tp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold,
-                                   sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0), 0.0, 0.0, 0.0});
-    } else if (auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
-      bt_1.push_back(idOf(b->key1())); bt_2.push_back(idOf(b->key2()));
-      bt_z.resize(bt_z.size() + 12); packPose(b->measured(), bt_z.data() + bt_z.size() - 12);
-      bt_nz.push_back(nt.add(b->noiseModel(), 6));
-    } else if (auto b2 = std::dynamic_pointer_cast<BetweenFactor<Pose2>>(f)) {
-      // same table as BetweenFactor<Pose3>: the factor's type follows from its variables', (x, y, theta) in the first 3 doubles
-      m.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)bt_1.size());
-      bt_1.push_back(idOf(b2->key1())); bt_2.push_back(idOf(b2->key2()));
-      const Pose2& z = b2->measured();
-      bt_z.insert(bt_z.end(), {z.x(), z.y(), z.theta(), 0, 0, 0, 0, 0, 0, 0, 0, 0});
-      bt_nz.push_back(nt.add(b2->noiseModel(), 3));
-    } else if (auto q2 = std::dynamic_pointer_cast<PriorFactor<Pose2>>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
-      pr_var.push_back(idOf(q2->key())); pr_off.push_back((int64_t)pr_data.size());
-      pr_data.insert(pr_data.end(), {q2->prior().x(), q2->prior().y(), q2->prior().theta()});
-      pr_nz.push_back(nt.add(q2->noiseModel(), 3));
-    } else if (auto pp = std::dynamic_pointer_cast<PriorFactor<Pose3>>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
-      pr_var.push_back(idOf(pp->key())); pr_off.push_back((int64_t)pr_data.size());
-      pr_data.resize(pr_data.size() + 12); packPose(pp->prior(), pr_data.data() + pr_data.size() - 12);
-      pr_nz.push_back(nt.add(pp->noiseModel(), 6));
-    } else if (auto pc = std::dynamic_pointer_cast<PriorFactor<SfmCamera>>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
-      pr_var.push_back(idOf(pc->key())); pr_off.push_back((int64_t)pr_data.size());
-      pr_data.resize(pr_data.size() + 17); packCamera(pc->prior(), pr_data.data() + pr_data.size() - 17);
-      pr_nz.push_back(nt.add(pc->noiseModel(), 9));
-    } else if (auto p3 = std::dynamic_pointer_cast<PriorFactor<Point3>>(f)) {
-      m.fac_map.emplace_back(GTG_FAC_PRIOR, (int64_t)pr_var.size());
-      pr_var.push_back(idOf(p3->key())); pr_off.push_back((int64_t)pr_data.size());
-      pr_data.insert(pr_data.end(), {p3->prior().x(), p3->prior().y(), p3->prior().z()});
-      pr_nz.push_back(nt.add(p3->noiseModel(), 3));
-    } else {
-      throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: factor type outside the GPU hot path "
-                                  "(supported: GeneralSFMFactor<SfmCamera,Point3>, GenericProjectionFactor<Pose3,Point3,Cal3_S2|Cal3DS2>, "
-                                  "SmartProjectionFactor<SfmCamera>, BetweenFactor<Pose3|Pose2>, PriorFactor<Pose3|Pose2|SfmCamera|Point3>)");
-    }
+  {
+    size_t n_sfm = 0, n_pj = 0, n_bt = 0, n_pr = 0, n_smc = 0, n_sm = 0;
+    for (const Extract& x : part) { n_sfm += x.sfm_cam.size(); n_pj += x.pj_pose.size(); n_bt += x.bt_1.size(); n_pr += x.pr_var.size(); n_smc += x.sm_cam.size(); n_sm += x.sm_prm.size() / 8; }
+    sfm_cam.reserve(n_sfm); sfm_pt.reserve(n_sfm); sfm_nz.reserve(n_sfm); sfm_z.reserve(2 * n_sfm);
+    pj_pose.reserve(n_pj); pj_pt.reserve(n_pj); pj_nz.reserve(n_pj); pj_cal.reserve(n_pj); pj_sen.reserve(n_pj); pj_z.reserve(2 * n_pj);
+    bt_1.reserve(n_bt); bt_2.reserve(n_bt); bt_nz.reserve(n_bt); bt_z.reserve(12 * n_bt);
+    m.fac_map.reserve(nfac);
   }
+  auto cat = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+  for (const Extract& x : part) {
+    const int64_t o_sfm = (int64_t)sfm_cam.size(), o_pj = (int64_t)pj_pose.size(), o_bt = (int64_t)bt_1.size(), o_pr = (int64_t)pr_var.size(),
+                  o_sm = (int64_t)sm_nz.size(), o_sen = (int64_t)(sensor.size() / 12), o_prd = (int64_t)pr_data.size(), o_smc = (int64_t)sm_cam.size();
+    for (const auto& fm : x.fac_map)
+      m.fac_map.emplace_back(fm.first, fm.second + (fm.first == GTG_FAC_GENERAL_SFM ? o_sfm : fm.first == GTG_FAC_PROJECTION ? o_pj :
+                                                      fm.first == GTG_FAC_BETWEEN_POSE3 ? o_bt : fm.first == GTG_FAC_PRIOR ? o_pr : fm.first == -2 ? o_sm : 0));
+    cat(sfm_cam, x.sfm_cam); cat(sfm_pt, x.sfm_pt); cat(sfm_z, x.sfm_z);
+    for (const auto& r : x.sfm_nz) sfm_nz.insert(sfm_nz.end(), (size_t)r.first, nt.add(r.second, 2));
+    cat(pj_pose, x.pj_pose); cat(pj_pt, x.pj_pt); cat(pj_z, x.pj_z);
+    for (const auto& r : x.pj_nz) pj_nz.insert(pj_nz.end(), (size_t)r.first, nt.add(r.second, 2));
+    for (int32_t sidx : x.pj_sen) pj_sen.push_back(sidx < 0 ? -1 : (int32_t)(sidx + o_sen));
+    cat(sensor, x.sensor);
+    for (const auto& kc : x.pj_cal) {
+      auto it = calib_id.find(kc.first);
+      if (it == calib_id.end()) {
+        it = calib_id.emplace(kc.first, (int32_t)(calib.size() / 5)).first;
+        if (kc.second) {
+          const Cal3DS2* K = static_cast<const Cal3DS2*>(kc.first);
+          calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
+          calib_dist.insert(calib_dist.end(), {K->k1(), K->k2(), K->p1(), K->p2()});
+          any_distortion = true;
+        } else {
+          const Cal3_S2* K = static_cast<const Cal3_S2*>(kc.first);
+          calib.insert(calib.end(), {K->fx(), K->fy(), K->skew(), K->px(), K->py()});
+          calib_dist.insert(calib_dist.end(), {0.0, 0.0, 0.0, 0.0});
+        }
+      }
+      pj_cal.push_back(it->second);
+    }
+    cat(bt_1, x.bt_1); cat(bt_2, x.bt_2); cat(bt_z, x.bt_z);
+    { size_t at = 0; for (const auto& r : x.bt_nz) { bt_nz.insert(bt_nz.end(), (size_t)r.first, nt.add(r.second, (size_t)x.bt_dim[at])); at += (size_t)r.first; } }
+    cat(pr_var, x.pr_var); cat(pr_data, x.pr_data);
+    for (int64_t o : x.pr_off) pr_off.push_back(o + o_prd);
+    { size_t at = 0; for (const auto& r : x.pr_nz) { pr_nz.insert(pr_nz.end(), (size_t)r.first, nt.add(r.second, (size_t)x.pr_dim[at])); at += (size_t)r.first; } }
+    cat(sm_cam, x.sm_cam); cat(sm_z, x.sm_z); cat(sm_prm, x.sm_prm);
+    for (size_t k = 1; k < x.sm_ptr.size(); k++) sm_ptr.push_back(x.sm_ptr[k] + o_smc);
+    for (const auto& r : x.sm_nz) sm_nz.insert(sm_nz.end(), (size_t)r.first, nt.add(r.second, 2));
+  }
+  lap("factors: merge, noise / calibration tables");
   gtg_problem pb{};
   pb.n_vars = (int32_t)m.keys.size(); pb.var_type = m.var_type.data();
   pb.n_noise = (int32_t)nt.kind.size(); pb.noise_kind = nt.kind.data(); pb.noise_dim = nt.dim.data();
@@ -331,6 +442,16 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   if (shards.allreduce) check(gtg_set_allreduce(m.h, shards.allreduce, shards.user), "gtg_set_allreduce");   // before the upload: it verifies the layout across the shards
   check(gtg_upload_problem(m.h, &pb, shards.shard, shards.n_shards), "gtg_upload_problem");
   check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
+  lap("library: create + upload + set_values");
+  // State(initialValues, graph.error(initialValues), lambdaInitial, lambdaFactor) -- LevenbergMarquardtOptimizer.cpp:47-53 -- with
+  // the error evaluated on the device
+  double e0 = 0.0;
+  check(gtg_error(m.h, &e0), "gtg_error");
+  lap("device: initial error");
+  copier.join();
+  lap("wait for the copy of the Values");
+  if (copyErr) std::rethrow_exception(copyErr);
+  state_.reset(new State(std::move(stateValues), e0, params_.lambdaInitial, params_.lambdaFactor));
   const State* s = static_cast<const State*>(state_.get());
   m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;
 }
@@ -499,11 +620,11 @@ GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::downloadLineariz
       out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, 2, 6)), keys[1], Matrix(Eigen::Map<const RowMat>(r + 12, 2, 3)),
                                           Vector(Eigen::Map<const Vector>(r + 18, 2)));
     } else if (tf.first == GTG_FAC_BETWEEN_POSE3) {
-      const int d = (m.var_type[m.id.at(keys[0])] == GTG_VAR_POSE2) ? 3 : 6;   // Pose2: 3x3 blocks inside the same record
+      const int d = (m.var_type[m.idOf(keys[0])] == GTG_VAR_POSE2) ? 3 : 6;   // Pose2: 3x3 blocks inside the same record
       out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, d, d)), keys[1], Matrix(Eigen::Map<const RowMat>(r + 36, d, d)),
                                           Vector(Eigen::Map<const Vector>(r + 72, d)));
     } else {
-      const int32_t vt = m.var_type[m.id.at(keys[0])];
+      const int32_t vt = m.var_type[m.idOf(keys[0])];
       const int d = vt == GTG_VAR_POSE3 ? 6 : vt == GTG_VAR_SFM_CAMERA ? 9 : 3;
       out->emplace_shared<JacobianFactor>(keys[0], Matrix(Eigen::Map<const RowMat>(r, d, d)), Vector(Eigen::Map<const Vector>(r + 81, d)));
     }
@@ -537,7 +658,25 @@ VectorValues GpuLevenbergMarquardtOptimizer::solve(const GaussianFactorGraph& gf
   if (!recognised) return LevenbergMarquardtOptimizer::solve(gfg, params);
   const auto* lm = dynamic_cast<const LevenbergMarquardtParams*>(&params);
   const double dmin = lm ? lm->minDiagonal : params_.minDiagonal, dmax = lm ? lm->maxDiagonal : params_.maxDiagonal;
-  check(gtg_linearize(m.h), "gtg_linearize");   // the device's own linearisation at values(): what `gfg` was built from
+  check(gtg_linearize(m.h), "gtg_linearize");   // the device's own linearisation at values(): what `gfg` should have been built from
+  // ... which is VERIFIED, not assumed: a sample of gfg's factors (64 evenly spaced + the last) is compared with the device's
+  // records of the same factors -- same keys, same [A | b] to 1e-9.  A graph linearised at other values, or with factors edited by
+  // the caller, has the right SHAPE but not these numbers; it goes to the reference's CPU solve like any other graph.  (Entries of
+  // smart factors -- Hessian factors the device never forms -- are null in the device's graph and are skipped.)
+  {
+    const GaussianFactorGraph::shared_ptr dev = downloadLinearization();
+    const size_t step = std::max<size_t>(1, nf / 64);
+    for (size_t i = 0; recognised && i < nf; i = (i + step < nf || i == nf - 1) ? i + step : nf - 1) {
+      const auto mine = std::dynamic_pointer_cast<JacobianFactor>((*dev)[i]);
+      if (!mine) continue;
+      const auto theirs = std::dynamic_pointer_cast<JacobianFactor>(gfg[i]);
+      if (!theirs || theirs->keys() != mine->keys()) { recognised = false; break; }
+      const Matrix Ab1 = mine->augmentedJacobian(), Ab2 = theirs->augmentedJacobian();   // (whitened: the device's records carry no model)
+      if (Ab1.rows() != Ab2.rows() || Ab1.cols() != Ab2.cols() ||
+          !((Ab1 - Ab2).cwiseAbs().maxCoeff() <= 1e-9 * std::max(1.0, Ab2.cwiseAbs().maxCoeff()))) recognised = false;
+    }
+    if (!recognised) return LevenbergMarquardtOptimizer::solve(gfg, params);
+  }
   double out[4];
   int rc;
   if (params.isIterative()) {

@@ -102,6 +102,22 @@ static double abTest(const char* name, const NonlinearFactorGraph& graph, const 
     }
     worstCost = std::max(worstCost, std::abs(damped.error(xg) - damped.error(xc)) / std::max(std::abs(damped.error(xc)), 1e-300));
   }
+  {
+    // a damped system of the right SHAPE but linearised somewhere else (the values moved by a retract): solve() must notice -- it
+    // compares a sample of the factors with the device's own linearisation -- and hand it to the reference's CPU solve, so the
+    // answer is the reference's for THAT system (to rounding: the same code), not the device's step at values()
+    VectorValues nudge = lc->hessianDiagonal();
+    for (auto& kv : nudge) kv.second.setConstant(1e-3);
+    const Values elsewhere = initial.retract(nudge);
+    const GaussianFactorGraph::shared_ptr le = graph.linearize(elsewhere);
+    internal::LevenbergMarquardtState st(elsewhere, graph.error(elsewhere), 1e-2, 10.0);
+    const GaussianFactorGraph dampedElsewhere = st.buildDampedSystem(*le);
+    LevenbergMarquardtParams pd = params; pd.diagonalDamping = false;
+    const VectorValues xc = cpu.solve(dampedElsewhere, pd), xg = gpu.solve(dampedElsewhere, pd);
+    double worst = 0, scale = 0;
+    for (const auto& kv : xc) { scale = std::max(scale, kv.second.cwiseAbs().maxCoeff()); worst = std::max(worst, (kv.second - xg.at(kv.first)).cwiseAbs().maxCoeff()); }
+    EXPECT(worst <= 1e-12 * std::max(scale, 1e-300), "%s solve(): a system linearised at other values was not handed to the CPU solve (differs by %.3g of %.3g)", name, worst, scale);
+  }
   EXPECT(worstD <= std::max(1e-7, 10.0 * self), "%s solve(): delta differs by %.3g (the reference from itself under another ordering: %.3g)", name, worstD, self);
   EXPECT(worstCost <= 1e-8, "%s solve(): quadratic cost at the device's delta differs by %.3g", name, worstCost);
   const GaussianFactorGraph::shared_ptr li = gpu.iterate();   // the linearisation the iteration started from

@@ -65,7 +65,10 @@ int main(int argc, char** argv) {
     hipstub_reset();
     gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial);
     report("sfmexample_bal_dubrovnik_3_7");
-    if (std::abs(lm.error() - graph.error(initial)) > 1e-9 * lm.error()) { failures++; std::printf("FAIL initial error\n"); }
+    // (this program runs under tools/hipstub, where kernels do not run: the initial error, which the optimizer takes from the device
+    // since round 3, is checked against graph.error(initial) by the GPU test tests/cpp/test_gpu_lm_gtsam.cpp; here: the state exists,
+    // holds the caller's values, and the copy of the graph is complete)
+    if (lm.values().size() != initial.size() || !lm.values().equals(initial, 1e-12)) { failures++; std::printf("FAIL initial values\n"); }
     // the same graph as shard s of 2 (ShardSpec): set-up incl. the layout verification through the callback
     int world = 2;
     for (int sh = 0; sh < world; sh++) {

@@ -33,6 +33,8 @@ def build_workload(name):
     from gtsam_amd.problem import bal_problem
     if name == "ladybug1723":
         return bal_problem(*D.ladybug_1723()), "BAL Ladybug problem-1723-156502 shape (synthetic, seed 42)"
+    if name == "streets1723":
+        return bal_problem(*D.streets_1723()), "BAL shape of the L1723 size on a street-network drive with random long-range loop closures (synthetic, seed 42; generator sensitivity, SURVEY section 7 hard part 8)"
     if name == "venice1778":
         return bal_problem(*D.venice_1778()), "BAL Venice problem-1778-993923 shape (synthetic, seed 42)"
     if name == "dubrovnik16":
@@ -276,6 +278,38 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
         out["cpu_baseline"] = cpu
+        # The C++ host north_star asks for, measured in this run: the reference's own benchmark program of the path
+        # (timing/timeSFMBAL.cpp with the optimizer's type name changed, tools/cpp/time_sfm_bal_gpu.cpp) on the same problem
+        # written as a BAL file -- GTSAM's loader, GTSAM's graph, GpuLevenbergMarquardtOptimizer (extraction + upload +
+        # optimize() through the C ABI).  Second construction / optimisation of the process (the first also pays the first
+        # use of the device); time_to_converged = construction -> checkConvergence, the metric's definition.
+        out["cpp_host"] = None
+        exe = os.path.join(ROOT, "tests", "_build", "time_sfm_bal_gpu")
+        if world == 1 and args.workload in ("ladybug1723", "dubrovnik16", "venice1778", "streets1723") and os.path.exists(exe) and args.cpu_baseline != "off":
+            try:
+                import subprocess
+                import tempfile
+                from gtsam_amd import datasets as D
+                from gtsam_amd import io as IO
+                gen = {"ladybug1723": D.ladybug_1723, "dubrovnik16": D.dubrovnik_16, "venice1778": D.venice_1778, "streets1723": D.streets_1723}[args.workload]
+                path = os.path.join(tempfile.gettempdir(), f"gtsam_amd_bench_{args.workload}.txt")
+                IO.write_bal(path, *gen())
+                r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+                os.unlink(path)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                j = json.loads(line)
+                out["cpp_host"] = {
+                    "program": "tools/cpp/time_sfm_bal_gpu.cpp (= timing/timeSFMBAL.cpp, optimizer type changed), GTSAM built from /root/reference",
+                    "construct_ms": j["second_run_construct_ms"], "optimize_ms": j["second_run_optimize_ms"],
+                    "time_to_converged_s": (j["second_run_construct_ms"] + j["second_run_optimize_ms"]) * 1e-3,
+                    "iterations": j["iterations"], "inner_iterations": j["inner_iterations"],
+                    "iterations_per_s_optimize_only": j["second_run_iterations_per_s_optimize_only"],
+                    "device_phase_ms": j["second_run_device_phase_ms"],
+                    "first_run_construct_ms": j["construct_ms"], "first_run_optimize_ms": j["optimize_ms"],
+                    "final_error": j["final_error"], "final_error_recomputed_by_gtsam_on_host": j["final_error_recomputed_on_host"],
+                    "exit_code": r.returncode}
+            except Exception as e:  # noqa: BLE001
+                out["cpp_host"] = {"failed": str(e)[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

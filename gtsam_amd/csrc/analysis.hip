@@ -541,10 +541,48 @@ void analyze(gtg_context& c) {
         }
         return ord;
       };
+      // What the kernels execute is decided at TILE granularity: whole 128 x 128 tiles, fill included.  "auto" therefore scores the two
+      // orderings by the flops over the tiles they would store (the count of chol_dataflow.hip::build_df_plan), not by the block-level
+      // count: on the street-network shape (datasets.py::synthetic_bal_streets, random long-range loop closures) minimum degree needs
+      // FEWER flops at block level (42 against 57 GFLOP) and 12 x MORE at tile level (1 170 against 101: its fill is scattered, 96 % of
+      // the tiles are touched) -- the first version of "auto" compared block-level counts and picked it.
+      auto tile_flops = [&](const std::vector<int32_t>& ord) {
+        std::vector<int64_t> off(nrv2 + 1, 0);
+        std::vector<int32_t> pos(nrv2);
+        for (int i = 0; i < nrv2; i++) { pos[ord[i]] = i; off[i + 1] = off[i] + c.h_red_dim[ord[i]]; }
+        const int ntl = (int)((off[nrv2] + kTile - 1) / kTile);
+        std::vector<uint8_t> Bt((size_t)ntl * ntl, 0);
+        auto mark = [&](int pa, int pb) {
+          for (int64_t a = off[pa] / kTile; a <= (off[pa + 1] - 1) / kTile; a++)
+            for (int64_t b = off[pb] / kTile; b <= (off[pb + 1] - 1) / kTile; b++) Bt[(size_t)std::max(a, b) * ntl + std::min(a, b)] = 1;
+        };
+        for (int v = 0; v < nrv2; v++) { mark(pos[v], pos[v]); for (int32_t w : adj[v]) if (pos[w] < pos[v]) mark(pos[v], pos[w]); }
+        for (int k = 0; k < ntl; k++) {
+          std::vector<int> r;
+          for (int i = k + 1; i < ntl; i++) if (Bt[(size_t)i * ntl + k]) r.push_back(i);
+          for (size_t a = 0; a < r.size(); a++) for (size_t b = 0; b <= a; b++) Bt[(size_t)r[a] * ntl + r[b]] = 1;
+        }
+        const double t3 = (double)kTile * kTile * kTile;
+        double fl = 0.0;
+        std::vector<int> cnt(ntl, 0);
+        for (int i = 0; i < ntl; i++) for (int k = 0; k < i; k++) cnt[i] += Bt[(size_t)i * ntl + k];
+        for (int J = 0; J < ntl; J++) {
+          fl += t3 / 3.0 + cnt[J] * t3;
+          for (int I = J + 1; I < ntl; I++) {
+            if (!Bt[(size_t)I * ntl + J]) continue;
+            int both = 0;
+            for (int k = 0; k < J; k++) both += Bt[(size_t)I * ntl + k] & Bt[(size_t)J * ntl + k];
+            fl += t3 + 2.0 * both * t3;
+          }
+        }
+        return fl;
+      };
       const std::vector<int32_t> md = min_degree();
       const double f_rcm = block_flops(order), f_md = block_flops(md);
-      if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] ordering: block-level GFLOP rcm %.1f, minimum degree %.1f (%s)\n", f_rcm / 1e9, f_md / 1e9, ord_mode.c_str());
-      if (ord_mode == "mindegree" || f_md < f_rcm) order = md;
+      const double t_rcm = tile_flops(order), t_md = tile_flops(md);
+      if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] ordering: GFLOP at block level rcm %.1f, minimum degree %.1f; over 128 x 128 tiles rcm %.1f, minimum degree %.1f (%s)\n",
+                               f_rcm / 1e9, f_md / 1e9, t_rcm / 1e9, t_md / 1e9, ord_mode.c_str());
+      if (ord_mode == "mindegree" || t_md < t_rcm) order = md;
     }
     for (int i = 0; i < nrv2; i++) { c.h_red_pos[order[i]] = i; pos_to_red[i] = order[i]; }
     // offsets: every part starts on a 256-column pair boundary, so that a pair of block columns belongs to one part
@@ -711,6 +749,8 @@ void analyze(gtg_context& c) {
     clk.lap("cholesky tile schedule");
     if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation, critical path %d of %d column pairs\n",
                              (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9, c.plan.critical_pairs, np2);
+    if (clk.on && c.use_df) std::fprintf(stderr, "[gtsam_amd setup] dataflow plan: %lld tasks, %.3f GFLOP over the stored tiles (fraction %.3f), %d chain workgroups, longest chain slot %d of %d diagonal tiles\n",
+                                         (long long)c.df.n_tasks, c.df.flops * 1e-9, c.df.dense_fraction, c.df.n_chain, c.df.critical_tiles, nt);
     // keep the nested-dissection ordering only where it pays: the chains must get clearly shorter and the problem must be
     // in the latency-bound regime (separators cost fill: on the L1723 shape +60 % flops for a 30 % shorter path)
     if (!part_of_pos.empty() && !nd_forced) {

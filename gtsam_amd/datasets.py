@@ -122,6 +122,94 @@ def synthetic_bal(n_cams, n_points, mean_track=4.34, seed=42, long_frac=0.012, p
     return cams, pts0, obs_cam.astype(np.int32), obs_pt.astype(np.int32), z
 
 
+def synthetic_bal_streets(n_cams, n_points, mean_track=4.34, seed=42, grid=5, block=45.0, pixel_noise=0.5, long_frac=0.012):
+    """A second BAL shape for the sensitivity of the ordering / tile design to the co-visibility structure (hard
+    part 8): the cameras drive a RANDOM WALK through a grid x grid street network (no U-turns), so streets are revisited at random
+    times and in both directions -- long-range loop closures all over the reduced camera system instead of the cyclic band of
+    synthetic_bal's laps around one block.  Landmarks sit on the facades (6-25 m off a street's centre line); a landmark is seen
+    by cameras within 35 m that have it in front and in their field of view, 2 + Exp(mean) of them (long tail as in
+    synthetic_bal).  Same camera model, noise, perturbation and return convention as synthetic_bal."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    # ---- the drive: node to node on the grid, one camera every `step` metres
+    n_edges_needed = 4 * grid * grid
+    step = n_edges_needed * block / n_cams
+    node = np.array([rng.integers(0, grid + 1), rng.integers(0, grid + 1)])
+    prev_dir = None
+    centers, headings = [], []
+    carry = 0.0
+    dirs = np.array([[1, 0], [-1, 0], [0, 1], [0, -1]])
+    while len(centers) < n_cams:
+        ok = [d for d in dirs if 0 <= node[0] + d[0] <= grid and 0 <= node[1] + d[1] <= grid and (prev_dir is None or not np.array_equal(d, -prev_dir))]
+        d = ok[rng.integers(0, len(ok))]
+        a, b = node * block, (node + d) * block
+        t = carry
+        while t < block and len(centers) < n_cams:
+            c = a + (b - a) * (t / block)
+            centers.append([c[0] + rng.normal(0, 0.3), c[1] + rng.normal(0, 0.3), 1.5 + 0.2 * rng.normal()])
+            headings.append(np.arctan2(d[1], d[0]))
+            t += step
+        carry = t - block
+        node = node + d; prev_dir = d
+    centers = np.array(centers); heading = np.array(headings) + rng.normal(0, 0.05, n_cams)
+    yaw = heading + rng.uniform(-np.pi, np.pi, n_cams)                   # omnidirectional rig: a random viewing direction per camera
+    fwd = np.stack([np.cos(yaw), np.sin(yaw), np.zeros(n_cams)], 1)
+    down = np.tile(np.array([0, 0, -1.0]), (n_cams, 1))
+    right = np.cross(down, fwd)
+    Rwc = np.stack([right, down, fwd], 2) @ _rodrigues(rng.normal(0, 0.03, (n_cams, 3)))
+    f = rng.uniform(400, 900, n_cams); k1 = rng.normal(0, 1e-2, n_cams); k2 = rng.normal(0, 1e-4, n_cams)
+    # ---- landmarks on the facades of the streets that were driven
+    anchor = centers[rng.integers(0, n_cams, n_points)]
+    side = rng.uniform(0, 2 * np.pi, n_points)
+    off = rng.uniform(6, 25, n_points)
+    pts = np.stack([anchor[:, 0] + off * np.cos(side), anchor[:, 1] + off * np.sin(side), rng.uniform(0, 12, n_points)], 1)
+    k = 2 + np.floor(rng.exponential(mean_track - 1.72 - 50 * long_frac, n_points)).astype(np.int64)
+    long_idx = rng.choice(n_points, max(1, int(long_frac * n_points)), replace=False)
+    k[long_idx] = rng.integers(50, 120, long_idx.size)
+    tree = cKDTree(centers[:, :2])
+    cand_all = tree.query_ball_point(pts[:, :2], r=35.0)
+    obs_cam, obs_pt = [], []
+    for j in range(n_points):
+        cand = np.asarray(cand_all[j], np.int64)
+        if cand.size < 2:
+            continue
+        d = pts[j] - centers[cand]
+        zc = np.einsum("ni,ni->n", d, Rwc[cand][:, :, 2]); xc = np.einsum("ni,ni->n", d, Rwc[cand][:, :, 0])
+        good = cand[(zc > 1.0) & (np.abs(xc) < 1.2 * zc)]
+        if good.size < 2:
+            continue
+        take = rng.choice(good, min(k[j], good.size), replace=False); take.sort()
+        obs_cam.append(take); obs_pt.append(np.full(take.size, j))
+    obs_cam = np.concatenate(obs_cam); obs_pt_raw = np.concatenate(obs_pt)
+    used = np.unique(obs_pt_raw)
+    remap = -np.ones(n_points, np.int64); remap[used] = np.arange(used.size)
+    obs_pt = remap[obs_pt_raw]; pts = pts[used]
+    usedc = np.unique(obs_cam)
+    if usedc.size != n_cams:
+        remapc = -np.ones(n_cams, np.int64); remapc[usedc] = np.arange(usedc.size)
+        obs_cam = remapc[obs_cam]
+        centers, Rwc, f, k1, k2 = centers[usedc], Rwc[usedc], f[usedc], k1[usedc], k2[usedc]
+        n_cams = usedc.size
+    Rcw = np.swapaxes(Rwc, 1, 2)
+    q = np.einsum("nij,nj->ni", Rcw[obs_cam], pts[obs_pt] - centers[obs_cam])
+    x, y = q[:, 0] / q[:, 2], q[:, 1] / q[:, 2]
+    r2 = x * x + y * y
+    g = 1 + (k1[obs_cam] + k2[obs_cam] * r2) * r2
+    z = np.stack([f[obs_cam] * g * x, f[obs_cam] * g * y], 1) + rng.normal(0, pixel_noise, (obs_cam.size, 2))
+    dR = _rodrigues(rng.normal(0, 2e-3, (n_cams, 3)))
+    cams = np.zeros((n_cams, 17))
+    cams[:, :9] = (Rwc @ dR).reshape(-1, 9)
+    cams[:, 9:12] = centers + rng.normal(0, 2e-2, (n_cams, 3))
+    cams[:, 12] = f + rng.normal(0, 1.0, n_cams); cams[:, 13] = k1; cams[:, 14] = k2
+    pts0 = pts + rng.normal(0, 5e-2, pts.shape)
+    return cams, pts0, obs_cam.astype(np.int32), obs_pt.astype(np.int32), z
+
+
+def streets_1723(seed=42):
+    """The L1723 size (1 723 cameras, ~156 000 points, ~4.3 observations per point) on the street-network drive."""
+    return synthetic_bal_streets(1723, 156502, mean_track=4.34, seed=seed)
+
+
 def ladybug_1723(seed=42):
     """BAL Ladybug problem-1723-156502 shape (1723 cameras, 156 502 points, ~678 718 obs)."""
     return synthetic_bal(1723, 156502, mean_track=4.34, seed=seed)

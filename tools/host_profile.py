@@ -37,6 +37,7 @@ def problem_for(name):
     from tests import problems as PB
     gold = os.path.join(ROOT, "tests", "golden")
     if name == "ladybug1723": return bal_problem(*D.ladybug_1723())
+    if name == "streets1723": return bal_problem(*D.streets_1723())
     if name == "venice1778": return bal_problem(*D.venice_1778())
     if name == "dubrovnik16": return bal_problem(*D.dubrovnik_16())
     if name == "sphere2500": return PB.sphere2500(dict(np.load(os.path.join(gold, "sphere2500.npz"))))

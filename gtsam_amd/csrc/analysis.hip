@@ -19,7 +19,7 @@
 #include <set>
 #include <string>
 #include <stdexcept>
-#include <dlfcn.h>
+#include <cstring>
 #include <sys/mman.h>
 #include <thread>
 
@@ -240,7 +240,11 @@ void analyze(gtg_context& c) {
   // The term lists come from the device (device_analysis.hip) on a single shard with a real runtime; from the host threads
   // below for a shard (which needs the blocks of the WHOLE graph but only its own terms), under the dry-run runtime of the CPU
   // tests (no kernels run there) and with GTG_HOST_ANALYSIS=1 (the A/B: both give bit-identical lists).
-  const bool device_terms = c.n_shards == 1 && c.n_lm > 0 && !std::getenv("GTG_HOST_ANALYSIS") && dlsym(RTLD_DEFAULT, "hipstub_kernel_name") == nullptr;
+  // (kernels_can_run: the library's code objects are gfx950 only; a runtime that reports another architecture -- the dry-run
+  // runtime of the CPU tests reports none -- cannot run the device pass)
+  bool kernels_can_run = false;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) kernels_can_run = std::strncmp(prop.gcnArchName, "gfx", 3) == 0; }
+  const bool device_terms = c.n_shards == 1 && c.n_lm > 0 && !std::getenv("GTG_HOST_ANALYSIS") && kernels_can_run;
   c.device_terms = device_terms;
   int64_t n_terms = 0;
   HugeBuf<int32_t> pair_oa(1), pair_ob(1);

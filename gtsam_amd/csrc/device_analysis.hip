@@ -15,7 +15,10 @@
 // tile schedule.  After the ordering the terms of the blocks whose orientation flips are swapped in place (k_da_flip).
 // The host version stays: it serves the sharded upload (a shard needs the blocks of the WHOLE graph but only its own terms)
 // and the dry-run runtime of the CPU tests, which cannot run kernels.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <stdexcept>
 
@@ -92,8 +95,8 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
   size_t tmp_bytes = 0, need = 0; void* tmp = nullptr;
   auto ensure = [&](size_t n) { if (n > tmp_bytes) { if (tmp) (void)hipFree(tmp); hc(hipMalloc(&tmp, n), "hipMalloc"); tmp_bytes = n; } };
   hipLaunchKernelGGL(k_da_count, dim3((unsigned)((n_lm + 1 + 255) / 256)), dim3(256), 0, s, n_lm, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_cnt.p);
-  hc(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_cnt.p, d_off.p, n_lm + 1, s), "scan"); ensure(need);
-  hc(hipcub::DeviceScan::ExclusiveSum(tmp, need, d_cnt.p, d_off.p, n_lm + 1, s), "scan");
+  hc(rocprim::exclusive_scan(nullptr, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan"); ensure(need);
+  hc(rocprim::exclusive_scan(tmp, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan");
   int64_t total = 0;
   hc(hipMemcpyAsync(&total, d_off.p + n_lm, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
@@ -109,9 +112,11 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
   int bits = 1;
   while (((uint64_t)1 << bits) < (uint64_t)nrv * (uint64_t)nrv) bits++;
   size_t need_sort = 0, need_rle = 0, need_scan = 0;
-  hc(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)total, 0, bits, s), "sort");
-  hc(hipcub::DeviceRunLengthEncode::Encode(nullptr, need_rle, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)total, s), "rle");
-  hc(hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, (int32_t*)nullptr, (int64_t*)nullptr, (int)total + 1, s), "scan");
+  // (rocPRIM: a stable LSD radix sort over the `bits` significant key bits -- stability is what keeps the landmark order inside a
+  // block, i.e. the summation order of the Schur complement --, run-length encode, exclusive scan)
+  hc(rocprim::radix_sort_pairs(nullptr, need_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)total, 0u, (unsigned)bits, s), "sort");
+  hc(rocprim::run_length_encode(nullptr, need_rle, (uint64_t*)nullptr, (unsigned)total, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, s), "rle");
+  hc(rocprim::exclusive_scan(nullptr, need_scan, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)total + 1, rocprim::plus<int64_t>(), s), "scan");
   const size_t need_tmp = std::max(need_sort, std::max(need_rle, need_scan));
   const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(4 * (N + 1)) + al(8 * (N + 1)) + al(16) + al(need_tmp);
   char* pool = nullptr;
@@ -127,14 +132,14 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
   void* cub_tmp = take(need_tmp);
   hipLaunchKernelGGL(k_da_emit, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
                      key, idx, t_oa, t_ob);
-  need = need_sort; hc(hipcub::DeviceRadixSort::SortPairs(cub_tmp, need, key, key2, idx, idx2, (int)total, 0, bits, s), "sort");
+  need = need_sort; hc(rocprim::radix_sort_pairs(cub_tmp, need, key, key2, idx, idx2, (size_t)total, 0u, (unsigned)bits, s), "sort");
   hipLaunchKernelGGL(k_da_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, idx2, t_oa, t_ob, c.pair_oa.p, c.pair_ob.p);
-  need = need_rle; hc(hipcub::DeviceRunLengthEncode::Encode(cub_tmp, need, key2, uniq, runs, d_nruns, (int)total, s), "rle");
+  need = need_rle; hc(rocprim::run_length_encode(cub_tmp, need, key2, (unsigned)total, uniq, runs, d_nruns, s), "rle");
   int nruns = 0;
   hc(hipMemcpyAsync(&nruns, d_nruns, sizeof(int), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
   hc(hipMemsetAsync(runs + nruns, 0, sizeof(int32_t), s), "memset");
-  need = need_scan; hc(hipcub::DeviceScan::ExclusiveSum(cub_tmp, need, runs, pp, nruns + 1, s), "scan");   // int32 counts -> int64 offsets
+  need = need_scan; hc(rocprim::exclusive_scan(cub_tmp, need, runs, pp, (int64_t)0, (size_t)nruns + 1, rocprim::plus<int64_t>(), s), "scan");   // int32 counts -> int64 offsets
   block_keys.resize((size_t)nruns); block_ptr.resize((size_t)nruns + 1);
   hc(hipMemcpyAsync(block_keys.data(), uniq, sizeof(uint64_t) * (size_t)nruns, hipMemcpyDeviceToHost, s), "D2H");
   hc(hipMemcpyAsync(block_ptr.data(), pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToHost, s), "D2H");

@@ -11,6 +11,7 @@
 #include <gtsam/inference/Symbol.h>
 #include <gtsam/linear/PCGSolver.h>
 #include <gtsam/linear/Preconditioner.h>
+#include <gtsam/linear/linearExceptions.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/slam/BetweenFactor.h>
@@ -110,12 +111,19 @@ static double abTest(const char* name, const NonlinearFactorGraph& graph, const 
     for (auto& kv : nudge) kv.second.setConstant(1e-3);
     const Values elsewhere = initial.retract(nudge);
     const GaussianFactorGraph::shared_ptr le = graph.linearize(elsewhere);
-    internal::LevenbergMarquardtState st(elsewhere, graph.error(elsewhere), 1e-2, 10.0);
+    internal::LevenbergMarquardtState st(elsewhere, graph.error(elsewhere), 1.0, 10.0);
     const GaussianFactorGraph dampedElsewhere = st.buildDampedSystem(*le);
     LevenbergMarquardtParams pd = params; pd.diagonalDamping = false;
-    const VectorValues xc = cpu.solve(dampedElsewhere, pd), xg = gpu.solve(dampedElsewhere, pd);
+    // (the reference may find THIS system indeterminate -- its rank test on the last two pivots of a landmark's clique is touchy on
+    // weakly observed depth directions; then the device path, having declined, must end in the same exception)
+    bool cpuThrew = false, gpuThrew = false;
+    VectorValues xc, xg;
+    try { xc = cpu.solve(dampedElsewhere, pd); } catch (const IndeterminantLinearSystemException&) { cpuThrew = true; }
+    try { xg = gpu.solve(dampedElsewhere, pd); } catch (const IndeterminantLinearSystemException&) { gpuThrew = true; }
+    EXPECT(cpuThrew == gpuThrew, "%s solve(): a system linearised at other values: reference %s, device path %s", name, cpuThrew ? "threw" : "solved", gpuThrew ? "threw" : "solved");
     double worst = 0, scale = 0;
-    for (const auto& kv : xc) { scale = std::max(scale, kv.second.cwiseAbs().maxCoeff()); worst = std::max(worst, (kv.second - xg.at(kv.first)).cwiseAbs().maxCoeff()); }
+    if (!cpuThrew && !gpuThrew)
+      for (const auto& kv : xc) { scale = std::max(scale, kv.second.cwiseAbs().maxCoeff()); worst = std::max(worst, (kv.second - xg.at(kv.first)).cwiseAbs().maxCoeff()); }
     EXPECT(worst <= 1e-12 * std::max(scale, 1e-300), "%s solve(): a system linearised at other values was not handed to the CPU solve (differs by %.3g of %.3g)", name, worst, scale);
   }
   EXPECT(worstD <= std::max(1e-7, 10.0 * self), "%s solve(): delta differs by %.3g (the reference from itself under another ordering: %.3g)", name, worstD, self);

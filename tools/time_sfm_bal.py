@@ -28,6 +28,8 @@ def main():
         extra = ["--cpu-iterations", sys.argv[sys.argv.index("--cpu-iterations") + 1]]
     out = subprocess.run([exe, path] + extra, capture_output=True, text=True, timeout=3000)
     sys.stdout.write(out.stdout)
+    if os.environ.get("GTG_DEBUG_TIMING"):
+        sys.stderr.write(out.stderr)
     if out.returncode:
         sys.stderr.write(out.stderr)
         raise SystemExit(out.returncode)

@@ -506,7 +506,8 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   // XCD's L2 kept serving with its old value although the flags are published twice (chol_dataflow.hip::st_flag).  The try is then
   // repeated, first with the other schedule (stream / event launches of cholesky.hip: kernels that never wait for a kernel launched
   // after them; its plan is always built), then once more with the dataflow schedule.  The reduced system is assembled again each
-  // time, because the factorisation works in place; the schedules are bit-identical, so a repeated try returns the same numbers.
+  // time, because the factorisation works in place; with one chain the schedules run the same sums in the same order (a repeated try
+  // returns the same bits), with several chains they differ in the order of the cross-part updates (the same numbers to rounding).
   // Sharded: the scalars are summed over the shards by read_scalars, so every shard sees the time-out of any shard and all repeat.
   for (int attempt = 0; attempt < 3; attempt++) {
     const bool df = c->use_df && attempt != 1;

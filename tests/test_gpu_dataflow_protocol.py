@@ -137,16 +137,22 @@ print("RESULT " + json.dumps(dict(trace=tr.tobytes().hex(), rows=int(tr.shape[0]
 '''
 
 
-def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule():
+@pytest.mark.parametrize("nd", ["0", None], ids=["one_chain", "default_ordering"])
+def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule(nd):
     """A dependency wait of the dataflow factorisation that runs into its bound (here: the chain kernel is left out of the third
     factorisation, GTG_DF_TEST_TIMEOUT=3 -- what a chain kernel that the dispatcher never placed looks like) must not abort
-    optimize(): the lambda try is computed once more with the stream / event schedule (same sums in the same order: the two
-    schedules are bit-identical), so the LM trajectory is exactly the undisturbed one and the handle counts one fallback."""
+    optimize(): the lambda try is computed once more with the stream / event schedule, and the handle counts one fallback.
+    With one chain (GTG_ND_DEPTH=0) the two schedules run the same sums in the same order, so the LM trajectory is bit for bit the
+    undisturbed one; with the default ordering of this graph (nested dissection, several chains) the cross-part updates are
+    summed in a different order by the stream schedule: same rows, same accept / reject decisions, errors equal to 1e-6 (the
+    tolerance of the LM-trace comparisons with the reference)."""
     import torch
     assert torch.cuda.is_available()
 
     def child(extra_env):
-        env = dict(os.environ); env.pop("GTSAM_AMD_LIB", None); env.update(extra_env)
+        env = dict(os.environ); env.pop("GTSAM_AMD_LIB", None); env.pop("GTG_ND_DEPTH", None); env.update(extra_env)
+        if nd is not None:
+            env["GTG_ND_DEPTH"] = nd
         r = subprocess.run([sys.executable, "-c", _CHILD_FALLBACK % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
@@ -155,4 +161,11 @@ def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule():
     b, err = child({"GTG_DF_TEST_TIMEOUT": "3"})
     assert a["fallbacks"] == 0 and b["fallbacks"] == 1, (a["fallbacks"], b["fallbacks"])
     assert "repeating the lambda try with the stream schedule" in err
-    assert a["trace"] == b["trace"], (a["final"], b["final"], a["rows"], b["rows"])
+    ta = np.frombuffer(bytes.fromhex(a["trace"]), np.float64).reshape(-1, 3)
+    tb = np.frombuffer(bytes.fromhex(b["trace"]), np.float64).reshape(-1, 3)
+    assert ta.shape == tb.shape and np.array_equal(ta[:, 0], tb[:, 0]), (ta, tb)
+    if nd == "0":
+        assert a["trace"] == b["trace"], (a["final"], b["final"], a["rows"], b["rows"])
+    else:
+        # (the tolerance of every LM-trace comparison with the reference: rounding differences of one solve are amplified along the run)
+        assert (np.abs(ta[:, 1] - tb[:, 1]) <= 1e-6 * np.abs(ta[:, 1])).all() and np.allclose(ta[:, 2], tb[:, 2], rtol=1e-6), (ta, tb)

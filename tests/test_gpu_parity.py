@@ -234,7 +234,7 @@ def test_orderings_give_the_same_step(gpu, monkeypatch):
         dev.set_values(v0)
         dev.linearize()
         rc, out = dev.try_lambda(1e-5, False)
-        d, fl = dev.delta().copy(), dev.cholesky_flops_block_level()
+        d, fl = dev.delta().copy(), (dev.cholesky_flops_block_level(), dev.cholesky_flops())   # (block level, over the stored tiles)
         dev.close()
         assert rc == 0
         return d, out[2], fl
@@ -249,9 +249,15 @@ def test_orderings_give_the_same_step(gpu, monkeypatch):
     monkeypatch.setenv("GTG_ORDERING", "mindegree")
     d, e, f = step()
     assert rel(d, d0) <= 1e-7 and abs(e - e0) <= 1e-9 * abs(e0) and f != f0
+    f_md = f
+    monkeypatch.setenv("GTG_ORDERING", "rcm")            # (explicitly one band: the default for this graph is nested dissection)
+    d, e, f_rcm = step()
+    assert rel(d, d0) <= 1e-7 and abs(e - e0) <= 1e-9 * abs(e0)
+    # "auto" keeps whichever of the two needs fewer flops over the 128 x 128 tiles it stores -- what the kernels execute; the
+    # block-level count misleads (street-network BAL shape: minimum degree 42 against 57 GFLOP at block level, 1 086 against 85 over tiles)
     monkeypatch.setenv("GTG_ORDERING", "auto")
     d, e, f = step()
-    assert rel(d, d0) <= 1e-7 and f <= f0
+    assert rel(d, d0) <= 1e-7 and f[1] == min(f_rcm[1], f_md[1]), (f, f_rcm, f_md)
 
 
 @pytest.mark.parametrize("name", ["dubrovnik_sfmex", "bal_small_iso", "posegraph_small", "projection_small", "pose2_w100"])

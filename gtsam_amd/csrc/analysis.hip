@@ -381,8 +381,8 @@ void analyze(gtg_context& c) {
   const char* nd_env = std::getenv("GTG_ND_DEPTH");
   const bool nd_forced = nd_env != nullptr;
   int nd_auto = 0;
-  const char* ord_req = std::getenv("GTG_ORDERING");   // an explicitly requested ordering method (minimum degree) is one chain
-  if (!nd_forced && hi.user_order.empty() && c.n_red >= 24 * (int64_t)kTile && !(ord_req && std::string(ord_req) != "rcm")) {
+  const char* ord_req = std::getenv("GTG_ORDERING");   // an explicitly requested ordering method (rcm, mindegree, auto) is one chain
+  if (!nd_forced && hi.user_order.empty() && c.n_red >= 24 * (int64_t)kTile && !ord_req) {
     double nnz = 0.0;
     for_each_block([&](int ra, int rb) { if (ra != rb) nnz += 2.0 * c.h_red_dim[ra] * c.h_red_dim[rb]; });
     if (nnz <= 0.01 * (double)c.n_red * (double)c.n_red) nd_auto = 3;   // 8 leaves on 4 chain slots: sphere2500 1.39 ms (2 levels: 1.78, one chain: 4.6)

@@ -262,10 +262,16 @@ __device__ __forceinline__ void stage_follow(double* A, const double* lines, con
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   scale_columns(a, rs + SB * jb, h);
   if (inv) {
+    // two base addresses + compile-time offsets (row 2 cl + h of the inverse: opnd_off(6 + jb, 2 cl + h, i) = its value at cl = 0 plus
+    // 512 (cl >> 3) + 16 (cl & 7) doubles).  With the offsets left to the compiler it kept 16 address registers, spilled six of them
+    // and reloaded each one behind an s_waitcnt vmcnt(0) -- which also waits for the write-through store before it: six store round
+    // trips in a row on the wavefront that every panel's release waits for.
+    double* xo = Xout + h * SB + i;
+    double* xp = Xop + opnd_off(6 + jb, h, i);
 #pragma unroll
     for (int cl = 0; cl < 16; cl++) {
-      Xout[(2 * cl + h) * SB + i] = a[cl];   // plain copy of the inverse: read by later kernels only (backward solve)
-      st_pub(Xop + opnd_off(6 + jb, 2 * cl + h, i), a[cl], wt);
+      xo[cl * 2 * SB] = a[cl];   // plain copy of the inverse: read by later kernels only (backward solve)
+      st_pub(xp + (cl >> 3) * 512 + (cl & 7) * 16, a[cl], wt);
     }
   } else {
 #pragma unroll

@@ -189,6 +189,11 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
                                             const unsigned char* __restrict__ pk, int& prev_exp) {
   const int i = lane & 31, h = lane >> 5;
   double* row = A + boff(jb, jb) + i * PB;
+  // the pivot kinds of this panel's columns (rank test below): requested NOW, so that the global load's latency lies under the 32 pivots
+  // (left where it is used -- after them, in front of the barrier that releases the panel -- it cost a memory round trip per panel
+  // on the wavefront everybody waits for; the scheduling barriers inside the steps keep the load up here)
+  unsigned kind = 0;
+  if (pk) kind = pk[SB * jb + i];
   double a[16], c0[16];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
@@ -207,7 +212,6 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
   if (pk) {   // off the pivot chain: the panel is out, the followers are running
-    const unsigned kind = pk[SB * jb + i];
     const double Rii = rsqrt_nr(rv);   // sqrt(pivot) = the diagonal entry of the factor
     const int ex = (int)((__double_as_longlong(Rii) >> 52) & 0x7ff) - 1022;   // frexp exponent
     int before = __builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, ex);

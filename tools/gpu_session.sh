@@ -1,9 +1,12 @@
 out=gpurun_out/$1; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
-REPO=$GRAFT_REPO_ROOT
-rm -rf /tmp/prof_s
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python $REPO/bench.py --steps 4 --warmup 1 --cpu-baseline off --skip-dense-roofline > $REPO/$out/trace.log 2>&1
-python $REPO/tools/rocprof_top.py $(find /tmp/prof_s -name "*.db" | head -1) $REPO/gpurun_out/r03_kernel_stats.csv | head -8
-cd $REPO
-( timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -12 ) > gpurun_out/r03_gpu_tests.log 2>&1
-tail -4 gpurun_out/r03_gpu_tests.log
+run() { echo "== $*" ; timeout 900 "${@}" 2>&1 | grep -v amdgpu.ids; }
+{
+echo "== gpu tests"; timeout 1400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline_parity.py tests/test_gpu_device_analysis.py tests/test_gpu_sharding.py -q -x 2>&1 | grep -v amdgpu.ids | tail -5
+for w in ladybug1723 venice1778 streets1723; do
+  run python bench.py --cpu-baseline off --skip-dense-roofline --workload $w
+  GTG_SCHUR_XCD=0 run python bench.py --cpu-baseline off --skip-dense-roofline --workload $w
+done
+GTG_SCHUR_WG=4 run python bench.py --cpu-baseline off --skip-dense-roofline --workload ladybug1723
+GTG_SCHUR_WG=16 run python bench.py --cpu-baseline off --skip-dense-roofline --workload ladybug1723
+} > $out/log.txt 2>&1
+grep -E "passed|failed|Error" $out/log.txt | head

@@ -210,6 +210,62 @@ def _execute_df(pl, df, t=8, seed=0):
     return worst, float(np.abs(y - yd).max()), len(owned)
 
 
+def _simulate_df(pl, df, n_bulk):
+    """Deadlock freedom of the dataflow schedule, simulated with BLOCKING workers: n_bulk bulk workgroups take tickets in order and
+    then hold their task until everything it reads exists (a piece waits for the piece before it, a contraction for its operand tiles,
+    a substitution for the diagonal tile of its column); the chain workgroups walk their tile lists in order and hold a tile until its
+    accumulated updates (PD) and the tile to its left are in.  Nobody ever lets go of a task.  The claim of build_df_plan: this
+    finishes for ANY number of resident bulk workgroups, also one -- a task only waits for smaller tickets and for diagonal tiles
+    whose own inputs have smaller tickets, and a chain workgroup waits for its tiles in queueing order."""
+    nt = int(df["nt"])
+    tasks = np.array(df["tasks"], np.int64).reshape(-1, 6); klist = np.array(df["klist"], np.int64)
+    coff = np.array(df["chain_off"], np.int64); ctiles = np.array(df["chain_tiles"], np.int64)
+    owned = {(int(I), int(J)) for I, J in tasks[:, :2]}
+    final, pd_done, diag_done, pieces = set(), set(), set(), {}
+    chain_at = [int(coff[w]) for w in range(len(coff) - 1)]
+    holding = [None] * n_bulk           # ticket a bulk workgroup holds
+    next_ticket = 0
+    done_tasks = 0
+
+    def ready(t):
+        I, J, off, cnt, r, R = (int(v) for v in tasks[t])
+        if pieces.get((I, J), 0) != r:
+            return False
+        for k in klist[off:off + cnt]:
+            k = int(k)
+            if (I, k) not in final and not (I == J and False):
+                return False
+            if (J, k) not in final:
+                return False
+        if r + 1 == R and I != J and J not in diag_done:
+            return False
+        return True
+
+    def finish(t):
+        I, J, off, cnt, r, R = (int(v) for v in tasks[t])
+        pieces[(I, J)] = r + 1
+        if r + 1 == R:
+            if I == J:
+                pd_done.add(J)
+            else:
+                final.add((I, J))
+    progress = True
+    while progress:
+        progress = False
+        for w in range(n_bulk):
+            if holding[w] is None and next_ticket < len(tasks):
+                holding[w] = next_ticket; next_ticket += 1; progress = True
+            if holding[w] is not None and ready(holding[w]):
+                finish(holding[w]); holding[w] = None; done_tasks += 1; progress = True
+        for w in range(len(chain_at)):
+            if chain_at[w] < coff[w + 1]:
+                J = int(ctiles[chain_at[w]])
+                if J in pd_done and ((J, J - 1) not in owned or (J, J - 1) in final):
+                    diag_done.add(J); chain_at[w] += 1; progress = True
+    assert done_tasks == len(tasks) and len(diag_done) == nt, \
+        f"deadlock with {n_bulk} bulk workgroups: {done_tasks} of {len(tasks)} tasks, {len(diag_done)} of {nt} diagonal tiles"
+
+
 @pytest.fixture(scope="module")
 def stub():
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
@@ -268,3 +324,11 @@ def test_forced_dense_schedule(stub):
     assert max(worst, worst_y, worst_x) <= 1e-10
     w, wy, n_df = _execute_df(pl, pl["df"])
     assert max(w, wy) <= 1e-10 and n_df == nt * (nt + 1) // 2 + nt
+
+
+@pytest.mark.parametrize("workload,nd", [("sphere2500", None), ("sphere2500", 2), ("w20000", None), ("ladybug1723", None), ("bal:300:20000:3", 2)])
+def test_dataflow_schedule_cannot_deadlock(stub, workload, nd):
+    """One, three and 248 resident bulk workgroups, blocking semantics (see _simulate_df): single-chain and multi-chain plans."""
+    pl = _plan(workload, nd)
+    for n_bulk in (1, 3, 248):
+        _simulate_df(pl, pl["df"], n_bulk)

@@ -1,12 +1,9 @@
 out=gpurun_out/$1; mkdir -p $out
-run() { echo "== $*" ; timeout 900 "${@}" 2>&1 | grep -v amdgpu.ids; }
 {
-echo "== gpu tests"; timeout 1400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline_parity.py tests/test_gpu_device_analysis.py tests/test_gpu_sharding.py -q -x 2>&1 | grep -v amdgpu.ids | tail -5
-for w in ladybug1723 venice1778 streets1723; do
-  run python bench.py --cpu-baseline off --skip-dense-roofline --workload $w
-  GTG_SCHUR_XCD=0 run python bench.py --cpu-baseline off --skip-dense-roofline --workload $w
+for pf in "6 3" "4 3" "8 3" "6 2" "6 4" "4 2" "8 4" "12 3" "3 2"; do
+  set -- $pf
+  echo "== PIECE $1 FINAL $2"
+  GTG_DF_PIECE=$1 GTG_DF_FINAL=$2 timeout 300 python bench.py --cpu-baseline off --skip-dense-roofline --steps 12 2>/dev/null | grep '^{'
 done
-GTG_SCHUR_WG=4 run python bench.py --cpu-baseline off --skip-dense-roofline --workload ladybug1723
-GTG_SCHUR_WG=16 run python bench.py --cpu-baseline off --skip-dense-roofline --workload ladybug1723
+for g in 240 232 216; do echo "== GRID $g"; GTG_DF_GRID=$g timeout 300 python bench.py --cpu-baseline off --skip-dense-roofline --steps 12 2>/dev/null | grep '^{'; done
 } > $out/log.txt 2>&1
-grep -E "passed|failed|Error" $out/log.txt | head

@@ -50,7 +50,7 @@ def test_no_unordered_tile_conflicts(stub, workload, nd):
     # the launch-sequence schedules: the elimination-tree one (GTG_ND_DEPTH) and the look-ahead one (GTG_CHOL=streams).  The
     # default dataflow schedule has two launches and orders its tile accesses through flags inside the kernels: its ordering
     # argument (a task only reads tiles that are final in ticket order) is what tests/test_chol_plan.py::_execute_df checks.
-    env = {"GTG_ND_DEPTH": str(nd)} if nd else {"GTG_CHOL": "streams"}
+    env = {"GTG_CHOL": "streams", "GTG_ND_DEPTH": str(nd)}    # (since round 3 a nested-dissection plan runs on the dataflow kernels by default)
     r = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra=env, timeout=900)
     assert r["rc"] == 0 and r["factorisation_launches"] >= r["nt"]          # at least one panel launch per block column
     assert r["streams"] >= 2 and r["ordered_conflicts_checked"] > r["factorisation_launches"]

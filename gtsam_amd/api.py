@@ -239,13 +239,16 @@ class GenericProjectionFactorCal3DS2(GenericProjectionFactorCal3_S2):
 
 
 class SmartProjectionParams:
-    """slam/SmartFactorParams.h:42-66 + geometry/triangulation.h:558-600; HESSIAN linearisation only."""
+    """slam/SmartFactorParams.h:42-66 + geometry/triangulation.h:558-600 (IMPLICIT_SCHUR is refused at upload)."""
     IGNORE_DEGENERACY, ZERO_ON_DEGENERACY, HANDLE_INFINITY = 0, 1, 2
+    HESSIAN, IMPLICIT_SCHUR, JACOBIAN_Q, JACOBIAN_SVD = 0, 1, 2, 3
 
-    def __init__(self, degeneracyMode=0, retriangulationThreshold=1e-5):
+    def __init__(self, linearizationMode=0, degeneracyMode=0, retriangulationThreshold=1e-5):
+        self.linearizationMode = linearizationMode
         self.degeneracyMode, self.retriangulationThreshold = degeneracyMode, retriangulationThreshold
         self.rankTolerance, self.landmarkDistanceThreshold, self.dynamicOutlierRejectionThreshold = 1.0, -1.0, -1.0
 
+    def setLinearizationMode(self, m): self.linearizationMode = m
     def setDegeneracyMode(self, m): self.degeneracyMode = m
     def setRetriangulationThreshold(self, t): self.retriangulationThreshold = t
     def setRankTolerance(self, t): self.rankTolerance = t
@@ -371,7 +374,7 @@ def extract(graph: NonlinearFactorGraph, values: Values):
         elif isinstance(f, SmartProjectionFactorPinholeCameraCal3Bundler):
             sp = f.params
             p.add_smart([vid(k) for k in f.keys_], np.concatenate(f.zs), nid(f.model, 2), sp.rankTolerance, sp.landmarkDistanceThreshold,
-                        sp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold, sp.degeneracyMode)
+                        sp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold, sp.degeneracyMode, sp.linearizationMode)
         elif isinstance(f, BetweenFactorPose3):
             btw.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z.packed(), nid(f.model, 6)))
         elif isinstance(f, BetweenFactorPose2):   # same table: the measurement sits in the first 3 of the 12 doubles

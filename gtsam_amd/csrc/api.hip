@@ -102,10 +102,12 @@ static void read_scalars(gtg_context& c) {
 }
 
 static void check_smart_supported(gtg_context& c, const char* where) {
-  if (c.n_smart && c.h_scalars[SC_UNSUPPORTED] != 0.0)
-    throw std::runtime_error(std::string(where) + ": a smart factor left the supported subset (its landmark did not triangulate under "
-                             "IGNORE_DEGENERACY / HANDLE_INFINITY, where the reference switches to a point at infinity, or "
-                             "Cal3Bundler::calibrate did not converge, where the reference throws)");
+  if (!c.n_smart || c.h_scalars[SC_UNSUPPORTED] == 0.0) return;
+  // the two places where the reference's smart factor throws out of linearize() / error() instead of returning a number
+  if (c.h_scalars[SC_UNSUPPORTED] == 2.0)
+    throw std::runtime_error(std::string(where) + ": CheiralityException -- a smart factor's point at infinity (IGNORE_DEGENERACY / HANDLE_INFINITY "
+                             "with a landmark that did not triangulate) lies behind one of the factor's cameras; the reference throws here");
+  throw std::runtime_error(std::string(where) + ": Cal3Bundler::calibrate did not converge for a measurement of a smart factor; the reference throws here");
 }
 
 struct PhaseTimer {
@@ -230,6 +232,10 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
       if (k1 <= k0 || k1 > n_meas) throw std::invalid_argument("smart factor without measurements / bad smart_ptr");
       const double* sp = p_user->smart_params + 8 * i;
       if (!(sp[4] == 0.0 || sp[4] == 1.0 || sp[4] == 2.0)) throw std::invalid_argument("smart factor: unknown degeneracy mode");
+      // LinearizationMode (SmartFactorParams.h:31-33): HESSIAN, JACOBIAN_Q, JACOBIAN_SVD give the same normal equations (they differ in
+      // what a failed track contributes and in the constant of the linear error); IMPLICIT_SCHUR factors cannot be eliminated by
+      // the reference's direct solvers at all (RegularImplicitSchurFactor has no augmentedJacobian / augmentedInformation)
+      if (!(sp[5] == 0.0 || sp[5] == 2.0 || sp[5] == 3.0)) throw std::invalid_argument("smart factor: linearization mode must be 0 HESSIAN, 2 JACOBIAN_Q or 3 JACOBIAN_SVD");
       // rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold (negative = off, as in the reference),
       // retriangulationThreshold: numbers, not NaN / inf (a NaN threshold silently disables the test it guards)
       for (int e = 0; e < 4; e++) if (!std::isfinite(sp[e])) throw std::invalid_argument("smart factor: a threshold is not finite");
@@ -546,7 +552,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       launch_scatter_delta(*c); }
     { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
     { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-    { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+    { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, true); }
     read_scalars(*c);
     if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
     if (attempt < 2 && c->h_scalars[SC_TIMEOUT] != 0.0) {
@@ -614,7 +620,7 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, true); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;

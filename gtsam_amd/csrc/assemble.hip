@@ -168,15 +168,19 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
     const double* v = V + 9 * l;
     // The landmark of a smart factor is eliminated inside the factor: P = (E^T E)^-1 without damping (linearize() passes
     // lambda = 0, SmartProjectionFactor.h:322-331, CameraSet.h:325-343); one that did not triangulate contributes nothing.
+    // A failed track under IGNORE_DEGENERACY / HANDLE_INFINITY is a point at infinity with TWO degrees of freedom (kTriAtInfinity,
+    // factors.hip k_lin_smart_at_infinity): its E blocks have a zero third column, so row / column 3 of V is exactly zero; a 1 on
+    // that diagonal entry leaves P = (E^T E)^-1 of the 2 x 2 block and an uncoupled third coordinate (y_3 = 0).
     const int sm = lm_smart ? lm_smart[l] : -1;
-    if (sm >= 0 && smart_status[sm] != 0) {
+    const int st = sm >= 0 ? smart_status[sm] : 0;
+    if (st != 0 && !(st & kTriAtInfinity)) {
       for (int k = 0; k < 9; k++) Linv[9 * l + k] = 0.0;
       y[3 * l] = 0.0; y[3 * l + 1] = 0.0; y[3 * l + 2] = 0.0;
       continue;
     }
     const double a00 = v[0] + (sm >= 0 ? 0.0 : damp_term(v[0], invsigma, diag, dmin, dmax));
     const double a11 = v[4] + (sm >= 0 ? 0.0 : damp_term(v[4], invsigma, diag, dmin, dmax));
-    const double a22 = v[8] + (sm >= 0 ? 0.0 : damp_term(v[8], invsigma, diag, dmin, dmax));
+    const double a22 = (st & kTriAtInfinity) ? 1.0 : v[8] + (sm >= 0 ? 0.0 : damp_term(v[8], invsigma, diag, dmin, dmax));
     const double a10 = v[3], a20 = v[6], a21 = v[7];
     bool bad = !(a00 > 0.0);
     const double l00 = sqrt(a00);
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_smart_hdiag(int32_t n_red_vars, cons
     if (inc_kind[k] != 0) continue;                      // GeneralSFM observations only
     const int64_t o = inc_idx[k];
     const int sm = sfm_smart[o];
-    if (sm < 0 || status[sm] != 0) continue;
+    if (sm < 0 || (status[sm] != 0 && !(status[sm] & kTriAtInfinity))) continue;
     const double* Eo = E + kEStride * o;
     for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * Eo[3 * i] + Eo[3 * i + 1] * Eo[3 * i + 1] + Eo[3 * i + 2] * Eo[3 * i + 2];
   }
@@ -510,19 +514,26 @@ __global__ __launch_bounds__(kBlock) void k_smart_hdiag(int32_t n_red_vars, cons
   if ((int)threadIdx.x < d) hdiag[red_off[r] + threadIdx.x] -= part[0][threadIdx.x];
 }
 // (2) The constant of that Hessian factor is b^T b (CameraSet.h:224), not b^T b - |L^-1 E^T b|^2: linear.error(delta) of the
-// reference lies 0.5 |y_l|^2 per valid smart landmark above the error of the explicit system at the optimal point update.
+// reference lies 0.5 |y_l|^2 per contributing smart landmark above the error of the explicit system at the optimal point update.
+// A JacobianFactorQ / JacobianFactorSVD (JACOBIAN_Q, JACOBIAN_SVD) is Q [F | b] with the projector Q = I - E P E^T instead: its
+// constant IS b^T Q b, so there linear.error(0) lies 0.5 |y_l|^2 BELOW 0.5 |b|^2 and linear.error(delta) needs no correction.
 __global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32_t* __restrict__ lm_smart, const int32_t* __restrict__ status,
-                                                       const double* __restrict__ ylm, double* __restrict__ scalars) {
-  __shared__ double sm_[kBlock];
-  double acc = 0.0;
+                                                       const double* __restrict__ params, const double* __restrict__ ylm, double* __restrict__ scalars) {
+  __shared__ double sm_[2][kBlock];
+  double acc_h = 0.0, acc_j = 0.0;
   for (int l = threadIdx.x; l < n_lm; l += kBlock) {
     const int s = lm_smart[l];
-    if (s >= 0 && status[s] == 0) acc += ylm[3 * l] * ylm[3 * l] + ylm[3 * l + 1] * ylm[3 * l + 1] + ylm[3 * l + 2] * ylm[3 * l + 2];
+    if (s < 0 || (status[s] != 0 && !(status[s] & kTriAtInfinity))) continue;
+    const double yy = ylm[3 * l] * ylm[3 * l] + ylm[3 * l + 1] * ylm[3 * l + 1] + ylm[3 * l + 2] * ylm[3 * l + 2];
+    if (params[8 * s + 5] == 0.0) acc_h += yy; else acc_j += yy;
   }
-  sm_[threadIdx.x] = acc;
+  sm_[0][threadIdx.x] = acc_h; sm_[1][threadIdx.x] = acc_j;
   __syncthreads();
-  for (int s = kBlock / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm_[threadIdx.x] += sm_[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) scalars[SC_LIN1] += 0.5 * sm_[0];
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sm_[0][threadIdx.x] += sm_[0][threadIdx.x + s]; sm_[1][threadIdx.x] += sm_[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { scalars[SC_LIN1] += 0.5 * sm_[0][0]; scalars[SC_LIN0] -= 0.5 * sm_[1][0]; }
 }
 
 void launch_smart_hdiag(gtg_context& c) {
@@ -533,7 +544,7 @@ void launch_smart_hdiag(gtg_context& c) {
 }
 void launch_smart_lin1(gtg_context& c) {
   if (!c.n_smart) return;
-  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_lin_status.p, c.ylm.p, c.scalars.p);
+  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_lin_status.p, c.smart_params.p, c.ylm.p, c.scalars.p);
   check_hip(hipGetLastError(), "smart_lin1");
 }
 

@@ -25,8 +25,8 @@ constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Ch
 // scalar slots reduced on the device (doubles)
 // SC_TIMEOUT directly follows SC_FAIL: the factorisation gets `scalars + SC_FAIL` and raises [0] for a non-positive pivot, [1] for a
 // dependency wait that ran into its bound (a scheduling problem, reported as an error -- never as "not positive definite")
-// SC_UNSUPPORTED: a smart factor met a case outside the supported subset (a triangulation that is not VALID under IGNORE_DEGENERACY /
-// HANDLE_INFINITY, where the reference switches to a point at infinity; Cal3Bundler::calibrate not converging, where it throws)
+// SC_UNSUPPORTED: a smart factor met a case in which the reference throws out of linearize() / error(): 1 = Cal3Bundler::calibrate did
+// not converge, 2 = CheiralityException (a failed track's point at infinity behind one of its cameras)
 enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_TIMEOUT = 6, SC_UNSUPPORTED = 7, SC_COUNT = 8 };
 
 template <class T>
@@ -148,7 +148,8 @@ struct gtg_context {
   int64_t n_smart = 0, smart_obs0 = 0;
   gt::DevBuf<int64_t> smart_ptr;            // [n_smart + 1] measurements of a factor, relative to smart_obs0
   gt::DevBuf<double> smart_params;          // 8 per factor (include/gtsam_amd.h)
-  // per factor: 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT (triangulation.h:611-612).  TWO arrays: smart_lin_status is
+  // per factor: 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT (triangulation.h:611-612), + 16 (kTriAtInfinity) when this
+  // use of a failed track replaces the landmark by a point at infinity.  TWO arrays: smart_lin_status is
   // the outcome at the LINEARISATION point (written by gtg_linearize only; read by everything that builds the linear system, which
   // stays fixed over the lambda retries of an iteration as the reference's linearised Hessian factor does); smart_status the
   // outcome of the most recent ERROR evaluation (gtg_error, the trial point of a lambda try), read by k_error only

@@ -86,6 +86,33 @@ GT_HD double sfm_error(const double* cam, const double* pt, const double* z, con
   return factor_loss(n, r[0] * r[0] + r[1] * r[1]);
 }
 
+// One measurement of a smart factor whose landmark is a point at infinity (SmartFactorBase::computeJacobians<Unit3>,
+// slam/SmartFactorBase.h:316-324, whitened as :356-363): the same record, the landmark block 2 x 2 padded with a zero column.
+// false where the reference throws a CheiralityException (not caught by the smart factor).
+GT_HD bool sfm_linearize_at_infinity(const double* cam, const double* dir, const double* z, const NoiseRef& n, double* J) {
+  double pi[2];
+  if (!sfm_project_at_infinity(cam, dir, pi, J, J + 18)) {
+    for (int i = 0; i < kSfmRec; i++) J[i] = 0.0;
+    return false;
+  }
+  J[24] = z[0] - pi[0];
+  J[25] = z[1] - pi[1];
+  whiten_cols<2>(n.kind, n.data, J, 9);
+  whiten_cols<2>(n.kind, n.data, J + 18, 3);
+  whiten_cols<2>(n.kind, n.data, J + 24, 1);
+  return true;
+}
+// its share of SmartFactorBase::totalReprojectionError<Unit3> (SmartFactorBase.h:296-303): 0.5 |whitened (h - z)|^2
+GT_HD bool sfm_error_at_infinity(const double* cam, const double* dir, const double* z, const NoiseRef& n, double* e) {
+  double pi[2];
+  *e = 0.0;
+  if (!sfm_project_at_infinity(cam, dir, pi, nullptr, nullptr)) return false;
+  double r[2] = {pi[0] - z[0], pi[1] - z[1]};
+  whiten_cols<2>(n.kind, n.data, r, 1);
+  *e = 0.5 * (r[0] * r[0] + r[1] * r[1]);
+  return true;
+}
+
 // ---- GenericProjectionFactor<Pose3,Point3,Cal3_S2> ---------------------------------------------
 GT_HD void proj_linearize(const double* pose, const double* K, const double* sensor, const double* pt,
                           const double* z, const NoiseRef& n, double* J) {

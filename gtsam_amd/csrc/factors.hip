@@ -344,14 +344,64 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
         for (int e = 0; e < 3; e++) pt[e] = a.cache_point[3 * sf + e];
       }
     }
-    a.status[sf] = st;
+    // A failed track (TriangulationResult without a point: every status but VALID) is, depending on the factor's parameters,
+    //   linearize: HESSIAN mode -- nothing under ZERO_ON_DEGENERACY (SmartProjectionFactor.h:212-219), else a POINT AT INFINITY, the
+    //              direction of the first measurement from the first camera (computeJacobiansWithTriangulatedPoint, :356-371);
+    //              JACOBIAN_Q / JACOBIAN_SVD -- an empty factor whatever the degeneracy mode (:245-272);
+    //   error():   the point at infinity under HANDLE_INFINITY, 0.0 otherwise (totalReprojectionError, :419-429).
+    // The direction is taken from the cameras of THIS call (it is not part of the cached triangulation).
+    const int mode = (int)prm[4], lin_mode = (int)prm[5];
+    bool at_infinity = st != kTriValid && st != kTriNoConvergence && (for_linearize ? (mode != 1 && lin_mode == 0) : mode == 2);
+    if (at_infinity && !sfm_backproject_at_infinity(values + a.val_off[a.sfm_cam[o0]], a.sfm_z + 2 * o0, pt)) { st = kTriNoConvergence; at_infinity = false; }
+    a.status[sf] = st | (at_infinity ? kTriAtInfinity : 0);
     double* slot = values + a.val_off[a.sfm_point[o0]];
-    for (int e = 0; e < 3; e++) slot[e] = st == kTriValid ? pt[e] : 0.0;
-    // outside the supported subset: HANDLE_INFINITY always uses the point at infinity for a failed track; IGNORE_DEGENERACY only when it
-    // LINEARISES (computeJacobiansWithTriangulatedPoint, SmartProjectionFactor.h:356-371) -- its error is simply 0.0 (totalReprojectionError,
-    // :419-429), so a trial step that puts a track behind a camera is evaluated (and usually rejected), not an error
-    if (st == kTriNoConvergence || (st != kTriValid && (prm[4] == 2.0 || (prm[4] == 0.0 && for_linearize)))) scalars[SC_UNSUPPORTED] = 1.0;
+    for (int e = 0; e < 3; e++) slot[e] = (st == kTriValid || at_infinity) ? pt[e] : 0.0;
+    if (st == kTriNoConvergence) scalars[SC_UNSUPPORTED] = 1.0;      // Cal3Bundler::calibrate throws in the reference
   }
+}
+
+// The measurements of the tracks flagged kTriAtInfinity, one per lane: k_lin_sfm has zeroed their records, this kernel writes the
+// rotation-only records of SmartFactorBase::computeJacobians<Unit3> in their place (landmark block 2 x 2 + a zero column: the hidden
+// landmark keeps its 3-wide slot, k_point_factor puts a 1 on the uncoupled third diagonal entry).  A direction behind one of the
+// cameras is a CheiralityException that nothing in the reference catches: reported (SC_UNSUPPORTED = 2).
+__global__ __launch_bounds__(kBlock) void k_lin_smart_at_infinity(int64_t n_meas, int64_t obs0, const int32_t* __restrict__ cam,
+    const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz, const double* __restrict__ values,
+    const int64_t* __restrict__ val_off, NoiseTab nt, double* __restrict__ J, const int32_t* __restrict__ smart_of,
+    const int32_t* __restrict__ status, double* __restrict__ scalars) {
+  for (int64_t k = blockIdx.x * (int64_t)kBlock + threadIdx.x; k < n_meas; k += (int64_t)gridDim.x * kBlock) {
+    const int64_t o = obs0 + k;
+    if (!(status[smart_of[o]] & kTriAtInfinity)) continue;
+    double c[17], d[3], zz[2], rec[kSfmRec];
+    const double* cp = values + val_off[cam[o]];
+    const double* dp = values + val_off[pt[o]];
+    for (int e = 0; e < 17; e++) c[e] = cp[e];
+    for (int e = 0; e < 3; e++) d[e] = dp[e];
+    zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
+    if (!sfm_linearize_at_infinity(c, d, zz, nt.ref(nz[o]), rec)) scalars[SC_UNSUPPORTED] = 2.0;
+    for (int e = 0; e < kSfmRec; e++) J[(int64_t)kSfmRec * o + e] = rec[e];
+  }
+}
+// ... and their share of the error (HANDLE_INFINITY): one workgroup, fixed lane assignment, added to the sum k_error left in `slot`.
+__global__ __launch_bounds__(kBlock) void k_error_smart_at_infinity(int64_t n_meas, int64_t obs0, const int32_t* __restrict__ cam,
+    const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz, const double* __restrict__ values,
+    const int64_t* __restrict__ val_off, NoiseTab nt, const int32_t* __restrict__ smart_of, const int32_t* __restrict__ status,
+    const double* __restrict__ gate, double* __restrict__ scalars, int slot) {
+  if (gate && !(gate[SC_LIN0] - gate[SC_LIN1] >= 0)) return;      // (the triangulation of this trial point was skipped: see k_smart_triangulate)
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < n_meas; k += kBlock) {
+    const int64_t o = obs0 + k;
+    if (!(status[smart_of[o]] & kTriAtInfinity)) continue;
+    double c[17], d[3], zz[2], e;
+    const double* cp = values + val_off[cam[o]];
+    const double* dp = values + val_off[pt[o]];
+    for (int i = 0; i < 17; i++) c[i] = cp[i];
+    for (int i = 0; i < 3; i++) d[i] = dp[i];
+    zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
+    if (!sfm_error_at_infinity(c, d, zz, nt.ref(nz[o]), &e)) scalars[SC_UNSUPPORTED] = 2.0;
+    acc += e;
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) scalars[slot] += s;
 }
 
 void launch_smart_triangulate(gtg_context& c, double* values, bool gated, bool for_linearize) {
@@ -370,6 +420,10 @@ void launch_linearize(gtg_context& c) {
     hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p,
                        f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p,
                        c.n_smart ? c.sfm_smart.p : nullptr, c.smart_lin_status.p);
+  if (c.n_smart)
+    hipLaunchKernelGGL(k_lin_smart_at_infinity, dim3(grid_for(f.n_sfm - c.smart_obs0)), dim3(kBlock), 0, c.stream, f.n_sfm - c.smart_obs0, c.smart_obs0,
+                       f.sfm_cam.p, f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p, c.sfm_smart.p,
+                       c.smart_lin_status.p, c.scalars.p);
   if (f.n_proj)
     hipLaunchKernelGGL(k_lin_proj, dim3(grid_for(f.n_proj)), dim3(kBlock), 0, c.stream, f.n_proj, f.proj_pose.p,
                        f.proj_point.p, f.proj_z.p, f.proj_noise.p, f.proj_calib.p, f.proj_sensor.p, f.calib.p,
@@ -385,7 +439,7 @@ void launch_linearize(gtg_context& c) {
   check_hip(hipGetLastError(), "linearize");
 }
 
-void launch_error(gtg_context& c, const double* values, int slot) {
+void launch_error(gtg_context& c, const double* values, int slot, bool gated) {
   auto& f = c.f;
   ErrArgs a{f.n_sfm, f.n_proj, f.n_between, f.n_prior,
             f.sfm_cam.p, f.sfm_point.p, f.sfm_noise.p, f.sfm_z.p,
@@ -397,6 +451,10 @@ void launch_error(gtg_context& c, const double* values, int slot) {
   const int g = grid_for(nmax);
   hipLaunchKernelGGL(k_error, dim3(g), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 1, c.scalars.p, slot);
+  if (c.n_smart)
+    hipLaunchKernelGGL(k_error_smart_at_infinity, dim3(1), dim3(kBlock), 0, c.stream, f.n_sfm - c.smart_obs0, c.smart_obs0, f.sfm_cam.p, f.sfm_point.p,
+                       f.sfm_z.p, f.sfm_noise.p, values, c.val_off.p, noise_tab(c), c.sfm_smart.p, c.smart_status.p,
+                       gated ? c.scalars.p : nullptr, c.scalars.p, slot);
   check_hip(hipGetLastError(), "error");
 }
 

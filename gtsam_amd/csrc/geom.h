@@ -271,6 +271,86 @@ GT_HD bool bundler_calibrate(double f, double k1, double k2, double u0, double v
   return iteration < 10;
 }
 
+// ---- a smart factor's landmark at infinity (slam/SmartProjectionFactor.h:356-371, :419-427) ------------------------------------------
+// When the triangulation is not VALID the reference replaces the landmark by the direction of the FIRST measurement seen from the
+// FIRST camera, a Unit3 (two degrees of freedom), and projects that into every camera: rotation-only factors.
+// Unit3::basis (geometry/Unit3.cpp:73-135): b1 = normalize(n x axis), axis = the coordinate axis of the smallest |n_i| (ties: x, then
+// y), b2 = n x b1.
+GT_HD void unit3_basis(const double* n, double* b1, double* b2) {
+  const double mx = fabs(n[0]), my = fabs(n[1]), mz = fabs(n[2]);
+  double a[3] = {0.0, 0.0, 0.0};
+  if (mx <= my && mx <= mz) a[0] = 1.0; else if (my <= mx && my <= mz) a[1] = 1.0; else a[2] = 1.0;
+  const double c[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
+  const double l = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  b1[0] = c[0] / l; b1[1] = c[1] / l; b1[2] = c[2] / l;
+  b2[0] = n[1] * b1[2] - n[2] * b1[1]; b2[1] = n[2] * b1[0] - n[0] * b1[2]; b2[2] = n[0] * b1[1] - n[1] * b1[0];
+}
+// PinholeBaseK::backprojectPointAtInfinity (geometry/PinholePose.h:164-168): Rot3::rotate(Unit3(calibrate(z), 1)); both Unit3
+// constructors normalise (Unit3.cpp:36-38, Rot3.cpp:109-116).  false where Cal3Bundler::calibrate throws.
+GT_HD bool sfm_backproject_at_infinity(const double* cam, const double* z, double* dir) {
+  double pn[2];
+  if (!bundler_calibrate(cam[12], cam[13], cam[14], cam[15], cam[16], z, pn)) return false;
+  const double l = sqrt(pn[0] * pn[0] + pn[1] * pn[1] + 1.0);
+  const double pc[3] = {pn[0] / l, pn[1] / l, 1.0 / l};
+  double w[3];
+  mat3_vec(cam, pc, w);
+  const double lw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  dir[0] = w[0] / lw; dir[1] = w[1] / lw; dir[2] = w[2] / lw;
+  return true;
+}
+// PinholeCamera<Cal3Bundler>::project2(Unit3) (geometry/PinholeCamera.h:251-254 -> PinholePose.h:89-109 ->
+// CalibratedCamera.cpp:138-165): q = Unit3(R^T d) (Rot3.cpp:119-126), pn = (q_x, q_y) / q_z, then Cal3Bundler::uncalibrate.
+//   Dpose = Duv B_q B_q^T [q]x on the rotation, ZERO on the translation;   Dpoint (2x2) = Duv B_q B_q^T R^T B_d
+// with Duv = [1/q_z 0 -u/q_z; 0 1/q_z -v/q_z] and B the tangent bases.  Duv q = 0 and B_q B_q^T = I - q q^T, so the basis of q drops
+// out: Dpose = Duv [q]x, Dpoint = Duv R^T B_d.  Dcam 2x9 = [Dp Dpose | Dcal]; Ddir 2x3 = [Dp Dpoint | 0]: the landmark keeps its
+// 3-wide slot in the elimination, the third coordinate is not coupled to anything.
+// false on a CheiralityException (q_z <= 0, CalibratedCamera.cpp:146-149) -- which the smart factor does NOT catch.
+GT_HD bool sfm_project_at_infinity(const double* cam, const double* dir, double* pi, double* Dcam, double* Ddir) {
+  double q[3];
+  mat3_tvec(cam, dir, q);
+  const double lq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  q[0] /= lq; q[1] /= lq; q[2] /= lq;
+  if (q[2] <= 0) return false;
+  const double d = 1.0 / q[2];
+  const double x = q[0] * d, y = q[1] * d;
+  const double f = cam[12], k1 = cam[13], k2 = cam[14], u0 = cam[15], v0 = cam[16];
+  const double r = x * x + y * y;
+  const double g = 1. + (k1 + k2 * r) * r;
+  const double u = g * x, v = g * y;
+  pi[0] = u0 + f * u; pi[1] = v0 + f * v;
+  if (Dcam || Ddir) {
+    const double a = 2. * (k1 + 2. * k2 * r);
+    const double axx = a * x * x, axy = a * x * y, ayy = a * y * y;
+    const double Dp[4] = {(g + axx) * f, axy * f, axy * f, (g + ayy) * f};
+    const double Duv[6] = {d, 0.0, -x * d, 0.0, d, -y * d};
+    if (Dcam) {
+      double S[9];
+      skew3(q[0], q[1], q[2], S);
+      for (int j = 0; j < 3; j++) {
+        const double r0 = Duv[0] * S[j] + Duv[1] * S[3 + j] + Duv[2] * S[6 + j];
+        const double r1 = Duv[3] * S[j] + Duv[4] * S[3 + j] + Duv[5] * S[6 + j];
+        Dcam[j] = Dp[0] * r0 + Dp[1] * r1; Dcam[9 + j] = Dp[2] * r0 + Dp[3] * r1;
+        Dcam[3 + j] = 0.0; Dcam[12 + j] = 0.0;
+      }
+      const double rx = r * x, ry = r * y;
+      Dcam[6] = u; Dcam[7] = f * rx; Dcam[8] = f * r * rx;
+      Dcam[15] = v; Dcam[16] = f * ry; Dcam[17] = f * r * ry;
+    }
+    if (Ddir) {
+      double B[2][3];
+      unit3_basis(dir, B[0], B[1]);
+      for (int j = 0; j < 2; j++) {
+        double t[3];
+        mat3_tvec(cam, B[j], t);                                       // R^T b_j
+        const double r0 = Duv[0] * t[0] + Duv[2] * t[2], r1 = Duv[4] * t[1] + Duv[5] * t[2];
+        Ddir[j] = Dp[0] * r0 + Dp[1] * r1; Ddir[3 + j] = Dp[2] * r0 + Dp[3] * r1;
+      }
+      Ddir[2] = 0.0; Ddir[5] = 0.0;
+    }
+  }
+  return true;
+}
+
 // eigen-decomposition of a symmetric 4x4 matrix by cyclic Jacobi rotations: A -> diagonal, V = eigenvectors (columns)
 GT_HD void jacobi_eig4(double (&A)[4][4], double (&V)[4][4]) {
   _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
@@ -301,7 +381,8 @@ GT_HD void jacobi_eig4(double (&A)[4][4], double (&V)[4][4]) {
   }
 }
 
-enum { kTriValid = 0, kTriDegenerate = 1, kTriBehindCamera = 2, kTriOutlier = 3, kTriFarPoint = 4, kTriNoConvergence = 5 };
+enum { kTriValid = 0, kTriDegenerate = 1, kTriBehindCamera = 2, kTriOutlier = 3, kTriFarPoint = 4, kTriNoConvergence = 5,
+       kTriAtInfinity = 16 };   // flag on a failed status: this use of the factor replaces the landmark by a point at infinity
 
 // gtsam::triangulateSafe for PinholeCamera<Cal3Bundler> cameras (triangulation.h:697-752; enableEPI = false, useLOST = false):
 //   undistort every measurement (calibrate with the camera's Cal3Bundler, uncalibrate with its pinhole part, :261-268),

@@ -8,7 +8,7 @@ namespace gt {
 
 // factors.hip -------------------------------------------------------------------------------------
 void launch_linearize(gtg_context& c);                                  // fills *_J from c.values
-void launch_error(gtg_context& c, const double* values, int scalar_slot);  // nonlinear error -> scalars[slot]
+void launch_error(gtg_context& c, const double* values, int scalar_slot, bool gated = false);  // nonlinear error -> scalars[slot] (gated: as launch_smart_triangulate)
 void launch_linear_error(gtg_context& c);                               // scalars[SC_LIN0], [SC_LIN1] from J, delta
 void launch_retract(gtg_context& c);                                    // trial = values (+) delta ; scalars[SC_DELTA_SQ]
 

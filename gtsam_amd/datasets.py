@@ -347,16 +347,25 @@ def random_projection_graph(n_poses=6, n_points=40, seed=0, with_sensor=True, be
     return p, v0
 
 
-def synthetic_orbit_scene(n_cams=10, n_points=120, seed=0, see=0.7, pixel_noise=0.5, init_noise=(0.01, 0.05)):
+def synthetic_orbit_scene(n_cams=10, n_points=120, seed=0, see=0.7, pixel_noise=0.5, init_noise=(0.01, 0.05), arc=0.9, far_points=0,
+                          far_distance=(1500.0, 4000.0), spread=1.0):
     """A small structure-from-motion scene with a sane field of view (cameras on an arc around a point cloud, every measurement
     within ~0.5 of the optical axis in intrinsic coordinates, so that Cal3Bundler::calibrate converges): the input of the smart
-    factor tests.  Returns the BAL-style tuple (cams17 -- perturbed --, pts3, obs_cam, obs_pt, obs_z) with the packing of
+    factor tests.  `arc`: half the opening of the arc in radians (below ~0.55 every camera sees every other camera's viewing
+    directions in front of it: what a smart factor's point at infinity needs).  `far_points`: that many of the points lie
+    `far_distance` away behind the cloud (parallax of a few pixels: a landmark-distance threshold rejects them and the point at
+    infinity is a good model of them).  `spread` widens the cloud across the optical axes (the distortion coefficients are
+    barely observable from measurements near the image centre).  Returns the BAL-style tuple (cams17 -- perturbed --, pts3, obs_cam, obs_pt, obs_z) with the packing of
     bal_problem (pose R row-major + t, f, k1, k2, u0, v0); every camera sees at least two points, every point is seen twice."""
     rng = np.random.default_rng(seed)
-    ang = np.linspace(-0.9, 0.9, n_cams)
+    ang = np.linspace(-arc, arc, n_cams)
     centers = np.stack([8 * np.sin(ang), 0.3 * rng.normal(size=n_cams), -8 * np.cos(ang)], 1)
     R = _rodrigues(np.stack([0.02 * rng.normal(size=n_cams), -ang, 0.02 * rng.normal(size=n_cams)], 1))   # looks at the origin (+z)
-    pts = np.stack([rng.uniform(-2, 2, n_points), rng.uniform(-1.5, 1.5, n_points), rng.uniform(-2, 2, n_points)], 1)
+    pts = np.stack([rng.uniform(-2, 2, n_points) * spread, rng.uniform(-1.5, 1.5, n_points) * spread, rng.uniform(-2, 2, n_points)], 1)
+    if far_points:                                     # (own generator: the stream of the near scene does not depend on this option)
+        r2 = np.random.default_rng(seed + 1000)
+        dist = r2.uniform(far_distance[0], far_distance[1], far_points)
+        pts[-far_points:] = np.stack([dist * r2.uniform(-0.15, 0.15, far_points), dist * r2.uniform(-0.12, 0.12, far_points), dist], 1)
     f = rng.uniform(450, 800, n_cams); k1 = rng.normal(0, 2e-2, n_cams); k2 = rng.normal(0, 2e-3, n_cams)
     oc, op, oz = [], [], []
     seen = rng.uniform(size=(n_cams, n_points)) < see

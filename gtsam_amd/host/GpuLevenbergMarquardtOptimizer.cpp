@@ -302,9 +302,11 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
           x.fac_map.emplace_back(-2, (int64_t)x.sm_prm.size() / 8);   // (no Jacobian record: its linearisation is a Hessian factor)
           const SmartProjectionParams& sp = (*sf).*SmartAccess::params();
           const TriangulationParameters& tp = sp.triangulation;
-          if (sp.linearizationMode != HESSIAN) throw std::invalid_argument("SmartProjectionFactor: only the HESSIAN linearisation is supported");
+          // HESSIAN, JACOBIAN_Q and JACOBIAN_SVD are the same normal equations (the device never forms the factor itself); an
+          // IMPLICIT_SCHUR factor cannot be eliminated by the reference's direct solvers either.  (throwCheirality / verboseCheirality
+          // are read by the pose-only smart factors, not by SmartProjectionFactor<CAMERA>.)
+          if (sp.linearizationMode == IMPLICIT_SCHUR) throw std::invalid_argument("SmartProjectionFactor: the IMPLICIT_SCHUR linearisation is not supported");
           if (tp.enableEPI || tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: enableEPI / useLOST are not supported");
-          if (sp.throwCheirality) throw std::invalid_argument("SmartProjectionFactor with throwCheirality is not supported");
           const SharedIsotropic& iso = (*sf).*SmartAccess::noise();
           Extract::run(x.sm_nz, iso);
           const auto& zs = sf->measured();
@@ -312,7 +314,8 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
           for (size_t k = 0; k < zs.size(); k++) { x.sm_cam.push_back(idOf(sf->keys()[k])); x.sm_z.push_back(zs[k].x()); x.sm_z.push_back(zs[k].y()); }
           x.sm_ptr.push_back((int64_t)x.sm_cam.size());
           x.sm_prm.insert(x.sm_prm.end(), {tp.rankTolerance, tp.landmarkDistanceThreshold, tp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold,
-                                           sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0), 0.0, 0.0, 0.0});
+                                           sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0),
+                                           sp.linearizationMode == JACOBIAN_Q ? 2.0 : (sp.linearizationMode == JACOBIAN_SVD ? 3.0 : 0.0), 0.0, 0.0});
         } else if (auto bb = dynamic_cast<const BetweenFactor<Pose3>*>(f.get())) {
           x.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)x.bt_1.size());
           x.bt_1.push_back(idOf(bb->key1())); x.bt_2.push_back(idOf(bb->key2()));

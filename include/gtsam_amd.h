@@ -118,8 +118,8 @@ typedef struct gtg_problem {
   /* SmartProjectionFactor<PinholeCamera<Cal3Bundler>> (slam/SmartProjectionFactor.h, the factor of timing/timeSFMBALsmart.cpp):
    * one factor = one track; its landmark is NOT a variable but re-triangulated from the cameras at every linearisation / error
    * evaluation (DLT, geometry/triangulation.cpp:27-57, checks of triangulateSafe triangulation.h:697-752, cached while no camera
-   * pose moves by more than retriangulationThreshold, SmartProjectionFactor.h:127-183) and eliminated without damping (HESSIAN
-   * linearisation = the Schur complement of the point, :190-233).  NULL / 0: no smart factors. */
+   * pose moves by more than retriangulationThreshold, SmartProjectionFactor.h:127-183) and eliminated without damping (the Schur
+   * complement of the point, :190-233; JacobianFactorQ / JacobianFactorSVD are the same normal equations).  NULL / 0: no smart factors. */
   int64_t n_smart;
   const int64_t* smart_ptr;       /* [n_smart+1] offsets of a factor's measurements in smart_cam / smart_z (>= 1 measurement each) */
   const int32_t* smart_cam;       /* variable id (SFM_CAMERA) of every measurement */
@@ -127,9 +127,14 @@ typedef struct gtg_problem {
   const int32_t* smart_noise;     /* [n_smart] index into the noise table (dim 2, Unit or Isotropic as the reference requires) */
   const double* smart_params;     /* [n_smart*8] rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold,
                                      retriangulationThreshold, degeneracyMode (0 IGNORE_DEGENERACY, 1 ZERO_ON_DEGENERACY,
-                                     2 HANDLE_INFINITY), 3 reserved.  enableEPI / useLOST / the other linearisation modes are not
-                                     supported; with IGNORE_DEGENERACY / HANDLE_INFINITY a triangulation that is not VALID (the
-                                     reference then uses a point at infinity) is reported as an error */
+                                     2 HANDLE_INFINITY), linearizationMode (0 HESSIAN, 2 JACOBIAN_Q, 3 JACOBIAN_SVD; 1 =
+                                     IMPLICIT_SCHUR is refused: the reference's direct solvers cannot eliminate it either),
+                                     2 reserved.  A track that does not triangulate is what SmartProjectionFactor.h makes of it:
+                                     nothing (ZERO_ON_DEGENERACY; the Jacobian modes when linearising), a point at infinity
+                                     (:356-371 when linearising in HESSIAN mode, :419-427 in the error under HANDLE_INFINITY), error
+                                     0.0 otherwise.  enableEPI / useLOST are not supported.  Where the reference THROWS out of
+                                     linearize() / error() -- the point at infinity behind one of the track's cameras
+                                     (CheiralityException), Cal3Bundler::calibrate not converging -- the call returns an error */
 } gtg_problem;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -182,8 +187,8 @@ int gtg_linearize(gtg_handle h);
  * The trial values stay on the device until gtg_accept(). If linear cost change < 0 the retract /
  * error step is skipped exactly like LM.cpp:178 and out[2] = +inf.
  * Errors (negative return, text in gtg_last_error): a dependency wait of the factorisation ran into its bound (GPU shared or
- * preempted: "the step was not computed" -- never reported as GTG_INDETERMINATE); a smart factor left the supported subset
- * (gtg_problem.smart_params; also from gtg_linearize and gtg_error). */
+ * preempted: "the step was not computed" -- never reported as GTG_INDETERMINATE); a smart factor met one of the two cases in
+ * which the reference throws (gtg_problem.smart_params; also from gtg_linearize and gtg_error). */
 int gtg_try_lambda(gtg_handle h, double lambda, int diagonal_damping, double min_diagonal,
                    double max_diagonal, double out[4]);
 

@@ -587,9 +587,56 @@ def triangulate_safe(cams17, z, rank_tol=1.0, dist_thr=-1.0, outlier_thr=-1.0):
     return TRI_VALID, pt
 
 
-def _smart_factors(p: Problem, values):
-    """Per smart factor: (camera ids, whitened F blocks [m,2,9], E [2m,3], b [2m]) for a VALID triangulation, else None
-    (ZERO_ON_DEGENERACY: the factor contributes nothing; the other degeneracy modes are outside the restated subset)."""
+def unit3_basis(n):
+    """Unit3::basis (geometry/Unit3.cpp:73-135): b1 = normalize(n x axis) with the coordinate axis of the smallest |n_i| (ties: x
+    first, then y), b2 = n x b1.  -> 3x2."""
+    mx, my, mz = np.abs(n)
+    axis = np.array([1.0, 0, 0]) if (mx <= my and mx <= mz) else (np.array([0, 1.0, 0]) if (my <= mx and my <= mz) else np.array([0, 0, 1.0]))
+    b1 = np.cross(n, axis); b1 = b1 / np.linalg.norm(b1)
+    return np.stack([b1, np.cross(n, b1)], 1)
+
+
+def backproject_point_at_infinity(cam17, z):
+    """PinholeBaseK::backprojectPointAtInfinity (geometry/PinholePose.h:164-168): rotate Unit3(calibrate(z), 1) into the world."""
+    pn = bundler_calibrate(*cam17[12:17], z)
+    pc = np.array([pn[0], pn[1], 1.0]); pc /= np.linalg.norm(pc)
+    w = cam17[:9].reshape(3, 3) @ pc
+    return w / np.linalg.norm(w)                                             # Rot3::rotate(Unit3) normalises again (Rot3.cpp:109-116)
+
+
+def sfm_project_at_infinity(cam17, d):
+    """PinholeCamera<Cal3Bundler>::project2(Unit3) (geometry/PinholeCamera.h:251-254 -> PinholePose.h:89-109 ->
+    CalibratedCamera.cpp:138-165, Rot3::unrotate(Unit3) Rot3.cpp:119-126, PinholeBase::Project(Unit3) CalibratedCamera.cpp:97-106),
+    the chain of Jacobians as the reference multiplies it.  -> pi, Dcam 2x9, Dpoint 2x2; raises on the CheiralityException."""
+    R = cam17[:9].reshape(3, 3); f, k1, k2, u0, v0 = cam17[12:17]
+    q = R.T @ d; q = q / np.linalg.norm(q)
+    if q[2] <= 0:
+        raise RuntimeError("CheiralityException")
+    Bq, Bd = unit3_basis(q), unit3_basis(d)
+    Dpc_rot = Bq.T @ skew(q[None])[0]                                               # 2x3
+    Dpc_point = Bq.T @ R.T @ Bd                                              # 2x2
+    dz = 1.0 / q[2]; u, v = q[0] * dz, q[1] * dz
+    Dpn_pc = np.array([[dz, 0, -u * dz], [0, dz, -v * dz]]) @ Bq             # 2x2
+    Dpose = np.zeros((2, 6)); Dpose[:, :3] = Dpn_pc @ Dpc_rot
+    Dpoint = Dpn_pc @ Dpc_point
+    r = u * u + v * v; g = 1. + (k1 + k2 * r) * r                            # Cal3Bundler::uncalibrate (Cal3Bundler.cpp:66-92)
+    pi = np.array([u0 + f * g * u, v0 + f * g * v])
+    a = 2. * (k1 + 2. * k2 * r)
+    Dp = f * np.array([[g + a * u * u, a * u * v], [a * u * v, g + a * v * v]])
+    Dcal = np.array([[g * u, f * r * u, f * r * r * u], [g * v, f * r * v, f * r * r * v]])
+    return pi, np.concatenate([Dp @ Dpose, Dcal], 1), Dp @ Dpoint
+
+
+SMART_HESSIAN, SMART_IMPLICIT_SCHUR, SMART_JACOBIAN_Q, SMART_JACOBIAN_SVD = 0, 1, 2, 3      # LinearizationMode (SmartFactorParams.h:31-33)
+
+
+def _smart_factors(p: Problem, values, for_error=False):
+    """Per smart factor: (camera ids, whitened F blocks [m,2,9], E [2m,N], b [2m]) or None where the factor contributes nothing.
+    N = 3 for a VALID triangulation.  Otherwise (the optional<Point3> of TriangulationResult is empty for every other status):
+      linearising, HESSIAN mode: ZERO_ON_DEGENERACY -> nothing (SmartProjectionFactor.h:212-219); IGNORE_DEGENERACY and
+        HANDLE_INFINITY -> the point at infinity of the first measurement, N = 2 (computeJacobiansWithTriangulatedPoint, :356-371);
+      linearising, JACOBIAN_Q / JACOBIAN_SVD: an empty factor whatever the degeneracy mode (:245-272);
+      error(): HANDLE_INFINITY -> the point at infinity, every other mode 0.0 (totalReprojectionError, :407-427)."""
     off = p.val_offsets(); values = np.asarray(values, np.float64)
     out = []
     for i in range(p.n_smart):
@@ -598,13 +645,17 @@ def _smart_factors(p: Problem, values):
         c17 = np.stack([values[off[c]:off[c] + 17] for c in cams])
         prm = p.smart_params.reshape(-1, 8)[i]
         st, pt = triangulate_safe(c17, z, prm[0], prm[1], prm[2])
-        if st != TRI_VALID:
-            if prm[4] != 1.0:
-                raise NotImplementedError("smart factor: point at infinity (IGNORE_DEGENERACY / HANDLE_INFINITY) is not restated")
-            out.append(None); continue
-        pi, Dc, Dp, behind = sfm_project(c17, np.repeat(pt[None], len(cams), 0))
         W = noise_sqrt_info(p, int(p.smart_noise[i]))                      # 2x2 (Unit / Isotropic)
-        F = np.einsum("ij,mjk->mik", W, Dc); E = np.einsum("ij,mjk->mik", W, Dp).reshape(-1, 3)
+        if st != TRI_VALID:
+            at_infinity = (prm[4] == 2.0) if for_error else (prm[4] != 1.0 and prm[5] == SMART_HESSIAN)
+            if not at_infinity:
+                out.append(None); continue
+            d = backproject_point_at_infinity(c17[0], z[0])
+            pr = [sfm_project_at_infinity(c17[k], d) for k in range(len(cams))]
+            pi = np.stack([q[0] for q in pr]); Dc = np.stack([q[1] for q in pr]); Dp = np.stack([q[2] for q in pr])
+        else:
+            pi, Dc, Dp, behind = sfm_project(c17, np.repeat(pt[None], len(cams), 0))
+        F = np.einsum("ij,mjk->mik", W, Dc); E = np.einsum("ij,mjk->mik", W, Dp).reshape(-1, Dp.shape[2])
         b = (-(pi - z) @ W.T).reshape(-1)                                   # b = -whiten(h(x) - z), SmartFactorBase.h:296-316
         out.append(([int(c) for c in cams], F, E, b))
     return out
@@ -612,9 +663,12 @@ def _smart_factors(p: Problem, values):
 
 def _smart_hessians(p: Problem, values):
     """createHessianFactor (SmartProjectionFactor.h:190-233) = CameraSet::SchurComplement (CameraSet.h:174-226) with lambda = 0:
-    G = F^T F - F^T E P E^T F, g = F^T (b - E P E^T b), f = b^T b, P = (E^T E)^-1.  -> list of (camera ids, G, g, f)."""
+    G = F^T F - F^T E P E^T F, g = F^T (b - E P E^T b), f = b^T b, P = (E^T E)^-1 (3x3, or 2x2 at infinity).
+    JACOBIAN_Q (JacobianFactorQ.h:53-79: Q F, Q b with the projector Q = I - E P E^T) and JACOBIAN_SVD (JacobianFactorSVD.h:
+    Enull^T F, Enull^T b, Enull Enull^T = Q) have the same G and g, and the constant b^T Q b.  -> list of (camera ids, G, g, f)."""
     res = []
-    for sf in _smart_factors(p, values):
+    modes = p.smart_params.reshape(-1, 8)[:, 5]
+    for i, sf in enumerate(_smart_factors(p, values)):
         if sf is None:
             continue
         cams, F, E, b = sf
@@ -624,7 +678,7 @@ def _smart_hessians(p: Problem, values):
         for k in range(m):
             Fd[2 * k:2 * k + 2, 9 * k:9 * k + 9] = F[k]
         Q = np.eye(2 * m) - E @ P @ E.T
-        res.append((cams, Fd.T @ Q @ Fd, Fd.T @ (Q @ b), float(b @ b)))
+        res.append((cams, Fd.T @ Q @ Fd, Fd.T @ (Q @ b), float(b @ b) if modes[i] == SMART_HESSIAN else float(b @ Q @ b)))
     return res
 
 
@@ -639,7 +693,7 @@ def error(p: Problem, values):
     for ft, tup in lin.items():
         e += _loss_many(p, nz[ft], tup[2])
     if getattr(p, "n_smart", 0):                          # totalReprojectionError (SmartProjectionFactor.h:407-427): 0.5 |b|^2 or 0
-        for sf in _smart_factors(p, values):
+        for sf in _smart_factors(p, values, for_error=True):
             if sf is not None:
                 e += 0.5 * float(sf[3] @ sf[3])
     return e

@@ -99,7 +99,9 @@ class RefGraph:
     def hessian_diagonal(self, values):
         v = np.ascontiguousarray(values, np.float64)
         d = np.zeros(self.dim_size)
-        lib().ref_graph_hessian_diagonal(self.h, _p(v), _p(d))
+        rc = lib().ref_graph_hessian_diagonal(self.h, _p(v), _p(d))
+        if rc == 3:
+            raise RuntimeError("CheiralityException")
         return d
 
     def solve(self, values, lam, diagonal_damping=False, min_diag=1e-6, max_diag=1e32, ordering_kind=0):

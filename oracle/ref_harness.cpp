@@ -42,6 +42,7 @@
 #include <gtsam/slam/GeneralSFMFactor.h>
 #include <gtsam/slam/ProjectionFactor.h>
 #include <gtsam/slam/SmartProjectionFactor.h>
+#include <limits>
 #include <gtsam/slam/dataset.h>
 
 #include <chrono>
@@ -239,7 +240,8 @@ void* ref_graph_create(const gtg_problem* p) {
   // smart factors (after the four indexed factor types): one per track, parameters as passed
   for (int64_t i = 0; i < p->n_smart; i++) {
     const double* sp = p->smart_params + 8 * i;
-    SmartProjectionParams params(HESSIAN, sp[4] == 1.0 ? ZERO_ON_DEGENERACY : (sp[4] == 2.0 ? HANDLE_INFINITY : IGNORE_DEGENERACY), false, false, sp[3]);
+    const LinearizationMode lm = sp[5] == 1.0 ? IMPLICIT_SCHUR : (sp[5] == 2.0 ? JACOBIAN_Q : (sp[5] == 3.0 ? JACOBIAN_SVD : HESSIAN));
+    SmartProjectionParams params(lm, sp[4] == 1.0 ? ZERO_ON_DEGENERACY : (sp[4] == 2.0 ? HANDLE_INFINITY : IGNORE_DEGENERACY), false, false, sp[3]);
     params.setRankTolerance(sp[0]);
     params.setLandmarkDistanceThreshold(sp[1]);
     params.setDynamicOutlierRejectionThreshold(sp[2]);
@@ -255,9 +257,11 @@ void ref_graph_destroy(void* h) { delete static_cast<RefGraph*>(h); }
 int64_t ref_graph_values_size(void* h) { return static_cast<RefGraph*>(h)->val_size; }
 int64_t ref_graph_tangent_size(void* h) { return static_cast<RefGraph*>(h)->dim_size; }
 
+// NaN where the reference throws a CheiralityException (a smart factor's point at infinity behind one of its cameras:
+// CalibratedCamera.cpp:146-149, not caught by SmartProjectionFactor)
 double ref_graph_error(void* h, const double* values) {
   RefGraph* g = static_cast<RefGraph*>(h);
-  return g->graph.error(g->unpack(values));
+  try { return g->graph.error(g->unpack(values)); } catch (const CheiralityException&) { return std::numeric_limits<double>::quiet_NaN(); }
 }
 
 // Same layout as gtg_get_jacobians(): row-major per factor [A1 | A2 | b]; PRIOR padded to 9.
@@ -319,8 +323,10 @@ int ref_graph_hessian(void* h, const double* values, double* H, double* grad) {
 
 int ref_graph_hessian_diagonal(void* h, const double* values, double* d) {
   RefGraph* g = static_cast<RefGraph*>(h);
-  auto lin = g->graph.linearize(g->unpack(values));
-  g->packDelta(lin->hessianDiagonal(), d);
+  try {
+    auto lin = g->graph.linearize(g->unpack(values));
+    g->packDelta(lin->hessianDiagonal(), d);
+  } catch (const CheiralityException&) { return 3; }      // (see ref_graph_error)
   return 0;
 }
 

@@ -22,6 +22,8 @@
 #include <gtsam/slam/ProjectionFactor.h>
 #include <gtsam/slam/SmartProjectionFactor.h>
 
+#include "smart_far_scene.h"
+
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -160,7 +162,10 @@ static void compare(const char* name, const NonlinearFactorGraph& graph, const V
   EXPECT(cpu.getInnerIterations() == gpu.getInnerIterations(), "inner iterations");
   EXPECT(std::abs(cpu.error() - gpu.error()) <= tol * std::abs(cpu.error()) + 1e-12, "final error %.15g vs %.15g", cpu.error(), gpu.error());
   EXPECT(std::abs(cpu.lambda() - gpu.lambda()) <= 1e-3 * cpu.lambda(), "lambda %.12g vs %.12g", cpu.lambda(), gpu.lambda());  // Ceres policy: lambda is the PRODUCT over all iterations of a cubic in the model fidelity, so 1e-8 differences in the errors of a noisy, slowly converging problem show up at 1e-4 here
-  EXPECT(std::abs(graph.error(rg) - gpu.error()) <= 1e-9 * std::abs(gpu.error()) + 1e-12, "values()/error() out of sync");
+  // (a smart factor keeps the triangulated POINT of its last re-triangulation while no camera moves by more than
+  // retriangulationThreshold, SmartProjectionFactor.h:127-183: graph.error() of a graph whose factors the CPU run has just used
+  // depends on that run's last trial point, so the cross-check of values() against error() is made on the other graphs only)
+  if (!g_skip_ab) EXPECT(std::abs(graph.error(rg) - gpu.error()) <= 1e-9 * std::abs(gpu.error()) + 1e-12, "values()/error() out of sync");
   EXPECT(valuesDiff(rc, rg) <= 1e-5, "optimised values differ by %.3g", valuesDiff(rc, rg));
   // iterate() one step at a time keeps the host state current
   gtsam_amd::GpuLevenbergMarquardtOptimizer step(graph, initial, params);
@@ -374,6 +379,22 @@ int main() {
       LevenbergMarquardtParams ceres; LevenbergMarquardtParams::SetCeresDefaults(&ceres);
       compare(variant ? "Smart ZERO_ON_DEGENERACY" : "Smart BAL ceres", graph, initial, ceres, 1e-6);
       compare(variant ? "Smart ZERO legacy" : "Smart BAL legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
+      g_skip_ab = false;
+    }
+  }
+  {  // ---- smart factors whose failed tracks become POINTS AT INFINITY (HANDLE_INFINITY: in the linearisation and in the error;
+    //      IGNORE_DEGENERACY, the reference's default: in the linearisation only), and the Jacobian linearisation modes (a failed
+    //      track is an empty factor, the constant of the linear error is b^T Q b): tests/cpp/smart_far_scene.h ------------------
+    const LinearizationMode lins[] = {HESSIAN, HESSIAN, JACOBIAN_SVD, JACOBIAN_Q};
+    const DegeneracyMode degs[] = {HANDLE_INFINITY, IGNORE_DEGENERACY, HANDLE_INFINITY, IGNORE_DEGENERACY};
+    const char* names[] = {"Smart HANDLE_INFINITY", "Smart IGNORE_DEGEN.", "Smart JACOBIAN_SVD", "Smart JACOBIAN_Q"};
+    for (int v = 0; v < 4; v++) {
+      NonlinearFactorGraph graph; Values initial;
+      smartFarScene(lins[v], degs[v], &graph, &initial);
+      g_skip_ab = true;
+      LevenbergMarquardtParams ceres; LevenbergMarquardtParams::SetCeresDefaults(&ceres);
+      compare((std::string(names[v]) + " c").c_str(), graph, initial, ceres, 1e-6);
+      compare((std::string(names[v]) + " l").c_str(), graph, initial, LevenbergMarquardtParams(), 1e-6);
       g_skip_ab = false;
     }
   }

@@ -44,6 +44,16 @@ double hm_robust_weight(int rk, double k, double d) { return gt::robust_weight(r
 double hm_robust_loss(int rk, double k, double d) { return gt::robust_loss(rk, k, d); }
 void hm_so3_logmap(long n, const double* R, double* w) { for (long i = 0; i < n; i++) gt::so3_logmap(R + 9 * i, w + 3 * i); }
 void hm_so3_expmap(long n, const double* w, double* R) { for (long i = 0; i < n; i++) gt::so3_expmap(w + 3 * i, R + 9 * i); }
+// a smart factor's point at infinity: direction of measurement z seen from cam0, then one record / error per camera
+int hm_sfm_backproject_at_infinity(const double* cam, const double* z, double* dir) { return gt::sfm_backproject_at_infinity(cam, z, dir) ? 1 : 0; }
+int hm_sfm_linearize_at_infinity(long n, const double* cam, const double* dir, const double* z, int nk, const double* nd, double* J, double* e) {
+  int bad = 0;
+  for (long i = 0; i < n; i++) {
+    if (!gt::sfm_linearize_at_infinity(cam + 17 * i, dir + 3 * i, z + 2 * i, NR(nk, nd), J + gt::kSfmRec * i)) bad++;
+    gt::sfm_error_at_infinity(cam + 17 * i, dir + 3 * i, z + 2 * i, NR(nk, nd), e + i);
+  }
+  return bad;
+}
 // smart factors: gtsam::triangulateSafe for m PinholeCamera<Cal3Bundler> cameras (17 doubles each) -> status, point
 int hm_smart_triangulate(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
   std::vector<int32_t> ids(m); std::vector<int64_t> off(m);

@@ -82,7 +82,36 @@ def smart_orbit(degenerate=False):
                              dynamic_outlier_rejection_threshold=60.0)
 
 
-SMART = {"smart_orbit": lambda: smart_orbit(False), "smart_orbit_degenerate": lambda: smart_orbit(True)}
+def smart_far(degeneracy_mode, linearization_mode=0, arc=0.5, init_noise=(0.01, 0.05), spread=1.0):
+    """The degeneracy modes that replace a failed track by a POINT AT INFINITY (SmartProjectionFactor.h:356-371, :419-427), on a
+    scene where that is a sensible model: a quarter of the landmarks lie thousands of units behind the cloud and fail the
+    landmark-distance threshold (FAR_POINT), some tracks keep a single observation (DEGENERATE).  (A NEAR track seen from infinity
+    has residuals of hundreds of pixels and sends the reference's LM into steps where Cal3Bundler::calibrate throws; outlier
+    tracks are in smart_orbit_degenerate.)  HANDLE_INFINITY (2): the point at infinity in the linearisation and in the error; IGNORE_DEGENERACY
+    (0, the reference's default): in the linearisation only, error 0.0; with a Jacobian linearisation mode (2 JACOBIAN_Q,
+    3 JACOBIAN_SVD) a failed track is an empty factor whatever the degeneracy mode.  The arc is narrow: the direction of a
+    track's first measurement must lie in front of every camera of the track, or the reference throws a CheiralityException out of
+    linearize() / error() (CalibratedCamera.cpp:146-149) -- arc = 0.9 is that case."""
+    from gtsam_amd.problem import smart_bal_problem
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(seed=7, arc=arc, far_points=30, init_noise=init_noise, spread=spread)
+    keep = np.ones(oc.size, bool)
+    for j in range(5, 120, 17):                                          # these tracks keep a single observation
+        idx = np.flatnonzero(op == j); keep[idx[1:]] = False
+    p, v0 = smart_bal_problem(cams, oc[keep], op[keep], oz[keep], degeneracy_mode=degeneracy_mode, linearization_mode=linearization_mode,
+                              landmark_distance_threshold=100.0)
+    # priors on the two end cameras fix the gauge: without them the end game of the legacy parameters (identity damping down to
+    # lambda = 1e-8 on a system with seven flat directions) is decided by the rounding of the solve, in the reference as well
+    ni = p.add_noise(NOISE_ISOTROPIC, 9, [0.05])
+    p.add_prior(0, v0[:17], ni); p.add_prior(p.n_vars - 1, v0[-17:], ni)
+    return p, v0
+
+
+SMART = {"smart_orbit": lambda: smart_orbit(False), "smart_orbit_degenerate": lambda: smart_orbit(True),
+         "smart_far_infinity": lambda: smart_far(2), "smart_far_ignore": lambda: smart_far(0),
+         # (closer initial values: without the far tracks in the linear system the first steps from the noisier start leave the region
+         # where Cal3Bundler::calibrate converges, and the reference throws)
+         "smart_far_jacobian_q": lambda: smart_far(0, linearization_mode=2, init_noise=(0.002, 0.01), spread=1.8),
+         "smart_far_jacobian_svd": lambda: smart_far(2, linearization_mode=3, init_noise=(0.002, 0.01), spread=1.8)}
 
 ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projection_cauchy", "projection_tukey",
                 "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy")

@@ -112,7 +112,7 @@ def test_smart_factors_through_the_mirror_give_the_soa_problem():
     graph = api.NonlinearFactorGraph(); vals = api.Values()
     for i in range(5):
         vals.insert(C(i), api.PinholeCameraCal3Bundler.from_packed(cams[i]))
-    sp = api.SmartProjectionParams(api.SmartProjectionParams.ZERO_ON_DEGENERACY); sp.setLandmarkDistanceThreshold(9.0)
+    sp = api.SmartProjectionParams(api.SmartProjectionParams.HESSIAN, api.SmartProjectionParams.ZERO_ON_DEGENERACY); sp.setLandmarkDistanceThreshold(9.0)
     for j in range(12):
         f = api.SmartProjectionFactorPinholeCameraCal3Bundler(api.noiseModel.Unit.Create(2), sp)
         for k in np.flatnonzero(op == j):

@@ -298,3 +298,54 @@ def test_smart_triangulation_against_the_reference(hm, live_ref):
             if sr == 0:
                 assert np.abs(pr - pd).max() <= 1e-9 * max(1.0, np.abs(pr).max()), (j, variant, pr, pd)
     assert all(v > 0 for v in seen.values()), seen              # every status occurred
+
+
+def test_smart_point_at_infinity(hm):
+    """The records of a smart factor whose landmark is a point at infinity (geom.h sfm_backproject_at_infinity /
+    sfm_project_at_infinity, factors.h sfm_linearize_at_infinity) against the oracle's restatement, which multiplies the chain of
+    Jacobians the way the reference does (with both tangent bases) and is itself pinned on the reference's fixtures
+    (tests/golden/smart_far_*.npz).  The device drops the basis of the camera-frame direction (it cancels) and keeps the world
+    basis: the landmark block must agree entry by entry, the third (padding) column must be zero, and the derivative with
+    respect to the translation must be zero."""
+    rng = np.random.default_rng(11); n = 400
+    cam, _ = _cams(rng, n)
+    z = rng.normal(0, 120, (n, 2))
+    dirs = np.zeros((n, 3))
+    for i in range(n):
+        assert hm.hm_sfm_backproject_at_infinity(P(cam[i]), P(z[i]), P(dirs[i])) == 1
+        assert rel(dirs[i], O.backproject_point_at_infinity(cam[i], z[i])) <= 1e-14
+    # look at each direction from OTHER cameras as well: a rotation of up to ~60 degrees keeps most of them in front
+    cam2 = cam.copy()
+    dR, _ = O.pose3_expmap(np.concatenate([rng.normal(0, 0.35, (n, 3)), np.zeros((n, 3))], 1))
+    cam2[:, :9] = np.einsum("nij,njk->nik", cam[:, :9].reshape(n, 3, 3), dR).reshape(n, 9)
+    z2 = z + rng.normal(0, 40, (n, 2))
+    nd = np.array([1.0 / 0.7])
+    J = np.zeros((n, 26)); e = np.zeros(n)
+    bad = hm.hm_sfm_linearize_at_infinity(C.c_long(n), P(cam2), P(dirs), P(z2), C.c_int(1), P(nd), P(J), P(e))
+    n_behind = 0
+    for i in range(n):
+        try:
+            pi, Dc, Dp = O.sfm_project_at_infinity(cam2[i], dirs[i])
+        except RuntimeError:
+            n_behind += 1
+            assert not J[i].any() and e[i] == 0.0
+            continue
+        ref = np.concatenate([(Dc / 0.7).reshape(-1), np.concatenate([Dp, np.zeros((2, 1))], 1).reshape(-1) / 0.7, (z2[i] - pi) / 0.7])
+        assert np.abs(J[i] - ref).max() <= 1e-11 * np.abs(ref).max(), i
+        assert not J[i, 3:6].any() and not J[i, 12:15].any() and J[i, 20] == 0.0 and J[i, 23] == 0.0
+        assert abs(e[i] - 0.5 * (ref[24:] ** 2).sum()) <= 1e-12 * max(e[i], 1.0)
+    assert bad == n_behind and n_behind < n // 4
+    # and the Jacobian IS the derivative: central differences on the rotation and on the direction's tangent plane
+    i = int(np.flatnonzero(J.any(1))[0]); h = 1e-6
+    B = O.unit3_basis(dirs[i])
+    for k in range(2):
+        dp = dirs[i] + h * B[:, k]; dm = dirs[i] - h * B[:, k]
+        num = (O.sfm_project_at_infinity(cam2[i], dp / np.linalg.norm(dp))[0] - O.sfm_project_at_infinity(cam2[i], dm / np.linalg.norm(dm))[0]) / (2 * h)
+        assert np.abs(num / 0.7 - J[i, [18 + k, 21 + k]]).max() <= 1e-5 * np.abs(J[i, 18:24]).max()
+    for k in range(3):
+        w = np.zeros((1, 6)); w[0, k] = h
+        Rp, _ = O.pose3_expmap(w); Rm, _ = O.pose3_expmap(-w)
+        cp = cam2[i].copy(); cp[:9] = (cam2[i, :9].reshape(3, 3) @ Rp[0]).reshape(-1)
+        cm = cam2[i].copy(); cm[:9] = (cam2[i, :9].reshape(3, 3) @ Rm[0]).reshape(-1)
+        num = (O.sfm_project_at_infinity(cp, dirs[i])[0] - O.sfm_project_at_infinity(cm, dirs[i])[0]) / (2 * h)
+        assert np.abs(num / 0.7 - J[i, [k, 9 + k]]).max() <= 1e-5 * np.abs(J[i, :18]).max()

@@ -222,6 +222,34 @@ def test_oracle_smart_factors_match_reference_golden(name):
         assert abs(O.error(p, O.retract(p, v0, d)) - g[f"solve{i}_trial_error"]) <= 1e-6 * g[f"solve{i}_trial_error"]
 
 
+def test_smart_point_at_infinity_cheirality(live_ref):
+    """Where the reference THROWS instead of returning a number: a failed track's point at infinity (the direction of its first
+    measurement from its first camera) behind another camera of the track is a CheiralityException out of linearize() under
+    IGNORE_DEGENERACY and HANDLE_INFINITY, and out of error() under HANDLE_INFINITY (CalibratedCamera.cpp:146-149; nothing in
+    SmartProjectionFactor catches it).  The real reference and the restatement agree on that, and on the error under
+    IGNORE_DEGENERACY (failed tracks count 0.0)."""
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import smart_bal_problem
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(seed=5)
+    for mode in (0, 2):
+        p, v0 = smart_bal_problem(cams, oc, op, oz, landmark_distance_threshold=8.0, degeneracy_mode=mode)
+        with pytest.raises(RuntimeError, match="CheiralityException"):
+            O.hessian_diagonal(p, v0)
+        if mode == 2:
+            with pytest.raises(RuntimeError, match="CheiralityException"):
+                O.error(p, v0)
+        if live_ref is None:
+            continue
+        g = live_ref.RefGraph(p)
+        with pytest.raises(RuntimeError, match="CheiralityException"):
+            g.hessian_diagonal(v0)
+        e = g.error(v0)
+        if mode == 0:
+            assert abs(O.error(p, v0) - e) <= 1e-12 * e
+        else:
+            assert np.isnan(e)                                  # the harness turns the exception into NaN
+
+
 # ---- (3) Pose2 pose graphs: BASELINE configs[0] (Pose2SLAMExample_g2o protocol with LM) --------------------------------
 @pytest.mark.parametrize("name", ["pose2_w100", "pose2_toy"])
 def test_oracle_pose2_matches_reference_golden(name):

@@ -1,6 +1,5 @@
 out=gpurun_out/$1; mkdir -p $out
 {
-for w in ladybug1723 venice1778; do
-  echo "== $w sorted"; BENCH_SORT_LANDMARKS=1 timeout 600 python bench.py --cpu-baseline off --skip-dense-roofline --workload $w 2>&1 | grep -v amdgpu | tail -5
-done
+echo "== smart + shim"; timeout 900 python -m pytest tests/test_gpu_smart_factors.py tests/test_gpu_gtsam_shim.py -q -x 2>&1 | tail -40
+echo "== shim log"; timeout 600 tests/_build/test_gpu_lm_gtsam 2>&1 | grep -i "smart\|FAIL\|PASSED" | head -60
 } > $out/log.txt 2>&1

@@ -806,7 +806,8 @@ void analyze(gtg_context& c) {
   }
   c.xred.alloc(2 * NP);   // + the shadow copies the backward sweep polls when an entry seems stuck (cholesky.hip::sweep_wait)
   c.partials.alloc(2 * 2048);
-  c.scalars.alloc(2 * SC_COUNT);   // [SC_COUNT, 2 SC_COUNT): the copy the sharded exchange sums (read_scalars)
+  c.scalars.alloc(3 * SC_COUNT);   // [SC_COUNT, 2 SC_COUNT): the copy the sharded exchange sums (read_scalars); [2 SC_COUNT, 3 SC_COUNT): the
+                                   // summed linear errors in front of the gated kernels of a sharded smart graph (smart_gate)
   check_hip(hipMemsetAsync(c.scalars.p, 0, sizeof(double) * 2 * SC_COUNT, s), "memset");
   check_hip(hipMemsetAsync(c.hdiag_red.p, 0, sizeof(double) * NP, s), "memset");
   check_hip(hipMemsetAsync(c.xred.p, 0, sizeof(double) * NP, s), "memset");

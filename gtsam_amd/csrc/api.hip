@@ -101,10 +101,20 @@ static void read_scalars(gtg_context& c) {
   c.h_scalars[SC_DELTA_SQ] /= c.n_shards;  // identical on every shard, summed by the exchange
 }
 
+// The kernels that follow LM's "is the linear cost change >= 0" (LevenbergMarquardtOptimizer.cpp:180-191: no error evaluation, hence no
+// re-triangulation, of a trial step the model does not like) read the two linear errors on the device.  On a sharded graph every shard
+// holds only its share of them: the sums are exchanged first, into a copy (read_scalars sums the originals once more, later).
+static bool smart_gate(gtg_context& c) {
+  if (!c.n_smart || c.n_shards == 1) return false;
+  check_hip(hipMemcpyAsync(c.scalars.p + 2 * SC_COUNT, c.scalars.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToDevice, c.stream), "D2D");
+  exchange(c, c.scalars.p + 2 * SC_COUNT, SC_COUNT);
+  return true;
+}
+
 static void check_smart_supported(gtg_context& c, const char* where) {
   if (!c.n_smart || c.h_scalars[SC_UNSUPPORTED] == 0.0) return;
   // the two places where the reference's smart factor throws out of linearize() / error() instead of returning a number
-  if (c.h_scalars[SC_UNSUPPORTED] == 2.0)
+  if (c.h_scalars[SC_UNSUPPORTED] >= kUnsupportedCheirality)      // (summed over the shards: calibrate counts 1 per shard)
     throw std::runtime_error(std::string(where) + ": CheiralityException -- a smart factor's point at infinity (IGNORE_DEGENERACY / HANDLE_INFINITY "
                              "with a landmark that did not triangulate) lies behind one of the factor's cameras; the reference throws here");
   throw std::runtime_error(std::string(where) + ": Cal3Bundler::calibrate did not converge for a measurement of a smart factor; the reference throws here");
@@ -211,12 +221,11 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
   // variables and one GeneralSFM observation per measurement behind the caller's; the tables below are built from this view.
   gtg_problem q = *p_user;
   const gtg_problem* p = &q;
-  std::vector<int32_t> x_var_type, x_sfm_cam, x_sfm_point, x_sfm_noise;
+  std::vector<int32_t> x_var_type, x_sfm_cam, x_sfm_point, x_sfm_noise, x_of_obs;
   std::vector<double> x_sfm_z;
   const int64_t n_smart = p_user->n_smart > 0 ? p_user->n_smart : 0;
   c->n_smart = n_smart; c->n_user_vars = p_user->n_vars; c->smart_obs0 = p_user->n_sfm;
   if (n_smart) {
-    if (n_shards > 1) throw std::invalid_argument("smart factors on a sharded graph are not supported");
     if (!p_user->smart_ptr || !p_user->smart_cam || !p_user->smart_z || !p_user->smart_noise || !p_user->smart_params)
       throw std::invalid_argument("smart factor tables missing");
     const int64_t n_meas = p_user->smart_ptr[n_smart];
@@ -256,11 +265,9 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     q.n_vars = (int32_t)x_var_type.size(); q.var_type = x_var_type.data();
     q.n_sfm = (int64_t)x_sfm_cam.size(); q.sfm_cam = x_sfm_cam.data(); q.sfm_point = x_sfm_point.data();
     q.sfm_noise = x_sfm_noise.data(); q.sfm_z = x_sfm_z.data();
-    std::vector<int64_t> rel(p_user->smart_ptr, p_user->smart_ptr + n_smart + 1);
-    up(c->smart_ptr, rel, s);
     std::vector<double> prm(p_user->smart_params, p_user->smart_params + 8 * n_smart);
     up(c->smart_params, prm, s);
-    up(c->sfm_smart, of_obs, s);
+    x_of_obs = std::move(of_obs);           // (smart_ptr and sfm_smart follow the shard filter of the observation table below)
     std::vector<int32_t> none((size_t)n_smart, -1);
     up(c->smart_cache_state, none, s);
     c->smart_status.alloc((size_t)n_smart); c->smart_lin_status.alloc((size_t)n_smart); c->smart_cache_point.alloc(3 * (size_t)n_smart); c->smart_cache_pose.alloc(12 * (size_t)n_meas);
@@ -350,6 +357,24 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
         cam.push_back(p->sfm_cam[i]); pt.push_back(p->sfm_point[i]); nz.push_back(p->sfm_noise[i]);
         z.push_back(p->sfm_z[2 * i]); z.push_back(p->sfm_z[2 * i + 1]);
       }
+    }
+    if (n_smart) {
+      // Sharded, a smart factor follows its hidden landmark like any landmark factor: this shard holds the measurements of the
+      // tracks it owns, in the order of the whole table.  The per-factor arrays keep the GLOBAL factor index (parameters, status,
+      // cache); a factor of another shard has no measurements here (smart_ptr[i + 1] == smart_ptr[i]) and is skipped.
+      std::vector<int64_t> rel((size_t)n_smart + 1, 0);
+      std::vector<int32_t> of_local;
+      int64_t obs0 = 0;
+      for (int64_t i = 0; i < p->n_sfm; i++) {
+        if (n_shards > 1 && !own_lm(p->sfm_point[i])) continue;
+        const int32_t sf = x_of_obs[(size_t)i];
+        of_local.push_back(sf);
+        if (sf < 0) obs0++; else rel[(size_t)sf + 1]++;
+      }
+      for (int64_t i = 0; i < n_smart; i++) rel[(size_t)i + 1] += rel[(size_t)i];
+      c->smart_obs0 = obs0;
+      up(c->smart_ptr, rel, s);
+      up(c->sfm_smart, of_local, s);
     }
     f.n_sfm = (int64_t)cam.size();
     up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
@@ -471,7 +496,7 @@ int gtg_error(gtg_handle c, double* error) {
   if (!c || !c->uploaded || !error) throw std::invalid_argument("gtg_error: no problem uploaded");
   DeviceGuard on_device(c->device);
   if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false, false); launch_error(*c, c->values.p, SC_ERROR); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, nullptr, false); launch_error(*c, c->values.p, SC_ERROR); }
   read_scalars(*c);
   collect(*c, {GTG_PH_ERROR});
   check_smart_supported(*c, "gtg_error");
@@ -485,14 +510,17 @@ int gtg_linearize(gtg_handle c) {
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
   DeviceGuard on_device(c->device);
   if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
-  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, false, true); launch_linearize(*c); }
+  { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, nullptr, true); launch_linearize(*c); }
   { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c);
     if (c->n_smart) {   // the cameras' Hessian diagonal is that of the Schur-complemented smart factors: needs their E blocks (undamped)
       launch_point_eliminate(*c, 1.0, 0, 1e-6, 1e32);
       launch_smart_hdiag(*c);
     } }
   exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
-  if (c->n_smart) check_hip(hipMemcpyAsync(c->h_scalars + SC_UNSUPPORTED, c->scalars.p + SC_UNSUPPORTED, sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
+  if (c->n_smart) {   // (sharded: every shard must see what any shard met)
+    if (c->n_shards > 1) exchange(*c, c->scalars.p + SC_UNSUPPORTED, 1);
+    check_hip(hipMemcpyAsync(c->h_scalars + SC_UNSUPPORTED, c->scalars.p + SC_UNSUPPORTED, sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
+  }
   check_hip(hipStreamSynchronize(c->stream), "sync");
   collect(*c, {GTG_PH_LINEARIZE, GTG_PH_ASSEMBLE});
   check_smart_supported(*c, "gtg_linearize");
@@ -552,7 +580,8 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       launch_scatter_delta(*c); }
     { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
     { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-    { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, true); }
+    { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); const double* gate = c->scalars.p + (smart_gate(*c) ? 2 * SC_COUNT : 0);
+      launch_smart_triangulate(*c, c->trial.p, gate, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, gate); }
     read_scalars(*c);
     if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
     if (attempt < 2 && c->h_scalars[SC_TIMEOUT] != 0.0) {
@@ -620,7 +649,8 @@ int gtg_try_lambda_pcg(gtg_handle c, double lambda, int diag, double dmin, doubl
     launch_scatter_delta(*c); }
   { PhaseTimer t(*c, GTG_PH_LINEAR_ERROR, c->phase_events.data()); launch_linear_error(*c); launch_smart_lin1(*c); }
   { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
-  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); launch_smart_triangulate(*c, c->trial.p, true, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, true); }
+  { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); const double* gate = c->scalars.p + (smart_gate(*c) ? 2 * SC_COUNT : 0);
+      launch_smart_triangulate(*c, c->trial.p, gate, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, gate); }
   read_scalars(*c);
   collect(*c, {GTG_PH_POINT_ELIM, GTG_PH_CHOLESKY, GTG_PH_SOLVE, GTG_PH_LINEAR_ERROR, GTG_PH_RETRACT, GTG_PH_ERROR});
   c->have_trial = true;

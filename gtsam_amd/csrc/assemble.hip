@@ -517,13 +517,13 @@ __global__ __launch_bounds__(kBlock) void k_smart_hdiag(int32_t n_red_vars, cons
 // reference lies 0.5 |y_l|^2 per contributing smart landmark above the error of the explicit system at the optimal point update.
 // A JacobianFactorQ / JacobianFactorSVD (JACOBIAN_Q, JACOBIAN_SVD) is Q [F | b] with the projector Q = I - E P E^T instead: its
 // constant IS b^T Q b, so there linear.error(0) lies 0.5 |y_l|^2 BELOW 0.5 |b|^2 and linear.error(delta) needs no correction.
-__global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32_t* __restrict__ lm_smart, const int32_t* __restrict__ status,
-                                                       const double* __restrict__ params, const double* __restrict__ ylm, double* __restrict__ scalars) {
+__global__ __launch_bounds__(kBlock) void k_smart_lin1(int32_t n_lm, const int32_t* __restrict__ owned, const int32_t* __restrict__ lm_smart,
+                                                       const int32_t* __restrict__ status, const double* __restrict__ params, const double* __restrict__ ylm, double* __restrict__ scalars) {
   __shared__ double sm_[2][kBlock];
   double acc_h = 0.0, acc_j = 0.0;
   for (int l = threadIdx.x; l < n_lm; l += kBlock) {
     const int s = lm_smart[l];
-    if (s < 0 || (status[s] != 0 && !(status[s] & kTriAtInfinity))) continue;
+    if (s < 0 || !owned[l] || (status[s] != 0 && !(status[s] & kTriAtInfinity))) continue;
     const double yy = ylm[3 * l] * ylm[3 * l] + ylm[3 * l + 1] * ylm[3 * l + 1] + ylm[3 * l + 2] * ylm[3 * l + 2];
     if (params[8 * s + 5] == 0.0) acc_h += yy; else acc_j += yy;
   }
@@ -544,7 +544,7 @@ void launch_smart_hdiag(gtg_context& c) {
 }
 void launch_smart_lin1(gtg_context& c) {
   if (!c.n_smart) return;
-  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_smart.p, c.smart_lin_status.p, c.smart_params.p, c.ylm.p, c.scalars.p);
+  hipLaunchKernelGGL(k_smart_lin1, dim3(1), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.lm_smart.p, c.smart_lin_status.p, c.smart_params.p, c.ylm.p, c.scalars.p);
   check_hip(hipGetLastError(), "smart_lin1");
 }
 

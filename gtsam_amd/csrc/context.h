@@ -26,7 +26,9 @@ constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Ch
 // SC_TIMEOUT directly follows SC_FAIL: the factorisation gets `scalars + SC_FAIL` and raises [0] for a non-positive pivot, [1] for a
 // dependency wait that ran into its bound (a scheduling problem, reported as an error -- never as "not positive definite")
 // SC_UNSUPPORTED: a smart factor met a case in which the reference throws out of linearize() / error(): 1 = Cal3Bundler::calibrate did
-// not converge, 2 = CheiralityException (a failed track's point at infinity behind one of its cameras)
+// not converge, kUnsupportedCheirality = CheiralityException (a failed track's point at infinity behind one of its cameras); summed over
+// the shards, so the second code lies above any count of the first
+constexpr double kUnsupportedCheirality = 1024.0;
 enum { SC_ERROR = 0, SC_LIN0 = 1, SC_LIN1 = 2, SC_TRIAL_ERROR = 3, SC_DELTA_SQ = 4, SC_FAIL = 5, SC_TIMEOUT = 6, SC_UNSUPPORTED = 7, SC_COUNT = 8 };
 
 template <class T>

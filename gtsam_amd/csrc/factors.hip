@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
   for (int64_t sf = blockIdx.x * (int64_t)kBlock + threadIdx.x; sf < a.n; sf += (int64_t)gridDim.x * kBlock) {
     const int64_t k0 = a.ptr[sf], o0 = a.obs0 + k0;
     const int m = (int)(a.ptr[sf + 1] - k0);
+    if (m == 0) continue;                                // a factor of another shard (every factor has a measurement: gtg_upload_problem)
     const double* prm = a.params + 8 * sf;
     const double thr = prm[3];
     int st;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
 // The measurements of the tracks flagged kTriAtInfinity, one per lane: k_lin_sfm has zeroed their records, this kernel writes the
 // rotation-only records of SmartFactorBase::computeJacobians<Unit3> in their place (landmark block 2 x 2 + a zero column: the hidden
 // landmark keeps its 3-wide slot, k_point_factor puts a 1 on the uncoupled third diagonal entry).  A direction behind one of the
-// cameras is a CheiralityException that nothing in the reference catches: reported (SC_UNSUPPORTED = 2).
+// cameras is a CheiralityException that nothing in the reference catches: reported (SC_UNSUPPORTED = kUnsupportedCheirality).
 __global__ __launch_bounds__(kBlock) void k_lin_smart_at_infinity(int64_t n_meas, int64_t obs0, const int32_t* __restrict__ cam,
     const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz, const double* __restrict__ values,
     const int64_t* __restrict__ val_off, NoiseTab nt, double* __restrict__ J, const int32_t* __restrict__ smart_of,
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_smart_at_infinity(int64_t n_meas
     for (int e = 0; e < 17; e++) c[e] = cp[e];
     for (int e = 0; e < 3; e++) d[e] = dp[e];
     zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
-    if (!sfm_linearize_at_infinity(c, d, zz, nt.ref(nz[o]), rec)) scalars[SC_UNSUPPORTED] = 2.0;
+    if (!sfm_linearize_at_infinity(c, d, zz, nt.ref(nz[o]), rec)) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;
     for (int e = 0; e < kSfmRec; e++) J[(int64_t)kSfmRec * o + e] = rec[e];
   }
 }
@@ -397,18 +398,18 @@ __global__ __launch_bounds__(kBlock) void k_error_smart_at_infinity(int64_t n_me
     for (int i = 0; i < 17; i++) c[i] = cp[i];
     for (int i = 0; i < 3; i++) d[i] = dp[i];
     zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
-    if (!sfm_error_at_infinity(c, d, zz, nt.ref(nz[o]), &e)) scalars[SC_UNSUPPORTED] = 2.0;
+    if (!sfm_error_at_infinity(c, d, zz, nt.ref(nz[o]), &e)) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;
     acc += e;
   }
   const double s = block_sum(acc);
   if (threadIdx.x == 0) scalars[slot] += s;
 }
 
-void launch_smart_triangulate(gtg_context& c, double* values, bool gated, bool for_linearize) {
+void launch_smart_triangulate(gtg_context& c, double* values, const double* gate, bool for_linearize) {
   if (!c.n_smart) return;
   SmartArgs a{c.n_smart, c.smart_obs0, c.smart_ptr.p, c.f.sfm_cam.p, c.f.sfm_point.p, c.f.sfm_z.p, c.val_off.p, c.smart_params.p,
               for_linearize ? c.smart_lin_status.p : c.smart_status.p, c.smart_cache_state.p, c.smart_cache_pose.p, c.smart_cache_point.p};
-  hipLaunchKernelGGL(k_smart_triangulate, dim3(grid_for(c.n_smart)), dim3(kBlock), 0, c.stream, a, values, gated ? c.scalars.p : nullptr, c.scalars.p,
+  hipLaunchKernelGGL(k_smart_triangulate, dim3(grid_for(c.n_smart)), dim3(kBlock), 0, c.stream, a, values, gate, c.scalars.p,
                      for_linearize ? 1 : 0);
   check_hip(hipGetLastError(), "smart_triangulate");
 }
@@ -439,7 +440,7 @@ void launch_linearize(gtg_context& c) {
   check_hip(hipGetLastError(), "linearize");
 }
 
-void launch_error(gtg_context& c, const double* values, int slot, bool gated) {
+void launch_error(gtg_context& c, const double* values, int slot, const double* gate) {
   auto& f = c.f;
   ErrArgs a{f.n_sfm, f.n_proj, f.n_between, f.n_prior,
             f.sfm_cam.p, f.sfm_point.p, f.sfm_noise.p, f.sfm_z.p,
@@ -454,7 +455,7 @@ void launch_error(gtg_context& c, const double* values, int slot, bool gated) {
   if (c.n_smart)
     hipLaunchKernelGGL(k_error_smart_at_infinity, dim3(1), dim3(kBlock), 0, c.stream, f.n_sfm - c.smart_obs0, c.smart_obs0, f.sfm_cam.p, f.sfm_point.p,
                        f.sfm_z.p, f.sfm_noise.p, values, c.val_off.p, noise_tab(c), c.sfm_smart.p, c.smart_status.p,
-                       gated ? c.scalars.p : nullptr, c.scalars.p, slot);
+                       gate, c.scalars.p, slot);
   check_hip(hipGetLastError(), "error");
 }
 

@@ -8,7 +8,7 @@ namespace gt {
 
 // factors.hip -------------------------------------------------------------------------------------
 void launch_linearize(gtg_context& c);                                  // fills *_J from c.values
-void launch_error(gtg_context& c, const double* values, int scalar_slot, bool gated = false);  // nonlinear error -> scalars[slot] (gated: as launch_smart_triangulate)
+void launch_error(gtg_context& c, const double* values, int scalar_slot, const double* gate = nullptr);  // nonlinear error -> scalars[slot] (gate: as launch_smart_triangulate)
 void launch_linear_error(gtg_context& c);                               // scalars[SC_LIN0], [SC_LIN1] from J, delta
 void launch_retract(gtg_context& c);                                    // trial = values (+) delta ; scalars[SC_DELTA_SQ]
 
@@ -38,7 +38,7 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
 void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
 // smart factors (SmartProjectionFactor): triangulation of the hidden landmarks from the cameras in `values` (gated: only when the
 // linear cost change of the current try is >= 0), Schur-complement correction of the Hessian diagonal, constant of linear.error
-void launch_smart_triangulate(gtg_context& c, double* values, bool gated, bool for_linearize);
+void launch_smart_triangulate(gtg_context& c, double* values, const double* gate, bool for_linearize);   // gate: scalars with the linear errors (trial point) or null
 void launch_smart_hdiag(gtg_context& c);
 void launch_smart_lin1(gtg_context& c);
 void exchange_sum(gtg_context& c, double* ptr, int64_t n);   // api.hip: all-reduce (sum) over the shards on the handle's stream; no-op on one shard

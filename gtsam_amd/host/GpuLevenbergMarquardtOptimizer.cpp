@@ -436,7 +436,6 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   pb.n_between = (int64_t)bt_1.size(); pb.between_v1 = bt_1.data(); pb.between_v2 = bt_2.data(); pb.between_z = bt_z.data(); pb.between_noise = bt_nz.data();
   pb.n_smart = (int64_t)sm_nz.size(); pb.smart_ptr = sm_ptr.data(); pb.smart_cam = sm_cam.data(); pb.smart_z = sm_z.data();
   pb.smart_noise = sm_nz.data(); pb.smart_params = sm_prm.data();
-  if (pb.n_smart && shards.n_shards > 1) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: smart factors on a sharded graph are not supported");
   pb.n_prior = (int64_t)pr_var.size(); pb.prior_var = pr_var.data(); pb.prior_off = pr_off.data(); pb.prior_data = pr_data.data(); pb.prior_noise = pr_nz.data();
 
   if (shards.n_shards < 1 || shards.shard < 0 || shards.shard >= shards.n_shards) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: bad ShardSpec");

@@ -38,7 +38,8 @@ class TwoWaySum:
         return allreduce
 
 
-@pytest.mark.parametrize("case", ["dubrovnik_sfmex", "bal_small_unit", "posegraph_small", "bal_60_cameras", "posegraph_200"])
+@pytest.mark.parametrize("case", ["dubrovnik_sfmex", "bal_small_unit", "posegraph_small", "bal_60_cameras", "posegraph_200",
+                                  "smart_orbit_degenerate", "smart_far_infinity", "smart_far_jacobian_svd"])
 def test_two_shards_equal_one(case):
     import torch
     assert torch.cuda.is_available()
@@ -47,6 +48,10 @@ def test_two_shards_equal_one(case):
         p, v0 = PB.dubrovnik_sfmexample(load_golden("dubrovnik_3_7")); params = LMP()
     elif case == "bal_small_unit":
         p, v0 = PB.SYNTH[case](); params = LMP.CeresDefaults()
+    elif case.startswith("smart_"):
+        # smart factors follow their hidden landmark: each shard triangulates and eliminates the tracks it owns (failed tracks as
+        # nothing / as points at infinity, Hessian- and Jacobian-mode constants of the linear error), the sums meet in the exchange
+        p, v0 = PB.SMART[case](); params = LMP.CeresDefaults()
     elif case == "bal_60_cameras":
         # 540 reduced dimensions = 5 tiles, RCM-reordered: the shards' layouts only agree because they are derived from
         # the whole graph (each shard has the Schur blocks of half of the landmarks)

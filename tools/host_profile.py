@@ -43,6 +43,7 @@ def problem_for(name):
     if name == "sphere2500": return PB.sphere2500(dict(np.load(os.path.join(gold, "sphere2500.npz"))))
     if name == "w20000": return PB.pose2_graph(dict(np.load(os.path.join(gold, "pose2_w20000.npz"))))
     if name == "dubrovnik_3_7": return PB.dubrovnik_timesfm(dict(np.load(os.path.join(gold, "dubrovnik_3_7.npz"))))
+    if name.startswith("smart:"): return PB.SMART[name.split(":", 1)[1]]()      # smart:<fixture name of tests/problems.py>
     if name.startswith("bal:"):   # bal:<cams>:<points>:<seed>
         _, nc, npt, seed = name.split(":")
         return bal_problem(*D.synthetic_bal(int(nc), int(npt), seed=int(seed)))

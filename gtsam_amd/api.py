@@ -247,11 +247,13 @@ class SmartProjectionParams:
         self.linearizationMode = linearizationMode
         self.degeneracyMode, self.retriangulationThreshold = degeneracyMode, retriangulationThreshold
         self.rankTolerance, self.landmarkDistanceThreshold, self.dynamicOutlierRejectionThreshold = 1.0, -1.0, -1.0
+        self.enableEPI = False
 
     def setLinearizationMode(self, m): self.linearizationMode = m
     def setDegeneracyMode(self, m): self.degeneracyMode = m
     def setRetriangulationThreshold(self, t): self.retriangulationThreshold = t
     def setRankTolerance(self, t): self.rankTolerance = t
+    def setEnableEPI(self, b): self.enableEPI = bool(b)
     def setLandmarkDistanceThreshold(self, t): self.landmarkDistanceThreshold = t
     def setDynamicOutlierRejectionThreshold(self, t): self.dynamicOutlierRejectionThreshold = t
 
@@ -374,7 +376,7 @@ def extract(graph: NonlinearFactorGraph, values: Values):
         elif isinstance(f, SmartProjectionFactorPinholeCameraCal3Bundler):
             sp = f.params
             p.add_smart([vid(k) for k in f.keys_], np.concatenate(f.zs), nid(f.model, 2), sp.rankTolerance, sp.landmarkDistanceThreshold,
-                        sp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold, sp.degeneracyMode, sp.linearizationMode)
+                        sp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold, sp.degeneracyMode, sp.linearizationMode, sp.enableEPI)
         elif isinstance(f, BetweenFactorPose3):
             btw.append((vid(f.keys_[0]), vid(f.keys_[1]), f.z.packed(), nid(f.model, 6)))
         elif isinstance(f, BetweenFactorPose2):   # same table: the measurement sits in the first 3 of the 12 doubles

@@ -116,7 +116,8 @@ static void check_smart_supported(gtg_context& c, const char* where) {
   // the two places where the reference's smart factor throws out of linearize() / error() instead of returning a number
   if (c.h_scalars[SC_UNSUPPORTED] >= kUnsupportedCheirality)      // (summed over the shards: calibrate counts 1 per shard)
     throw std::runtime_error(std::string(where) + ": CheiralityException -- a smart factor's point at infinity (IGNORE_DEGENERACY / HANDLE_INFINITY "
-                             "with a landmark that did not triangulate) lies behind one of the factor's cameras; the reference throws here");
+                             "with a landmark that did not triangulate) lies behind one of the factor's cameras, or the refinement of a "
+                             "triangulation (enableEPI) linearised at a point behind a camera; the reference throws here");
   throw std::runtime_error(std::string(where) + ": Cal3Bundler::calibrate did not converge for a measurement of a smart factor; the reference throws here");
 }
 
@@ -244,6 +245,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
       // LinearizationMode (SmartFactorParams.h:31-33): HESSIAN, JACOBIAN_Q, JACOBIAN_SVD give the same normal equations (they differ in
       // what a failed track contributes and in the constant of the linear error); IMPLICIT_SCHUR factors cannot be eliminated by
       // the reference's direct solvers at all (RegularImplicitSchurFactor has no augmentedJacobian / augmentedInformation)
+      if (!(sp[6] == 0.0 || sp[6] == 1.0)) throw std::invalid_argument("smart factor: enableEPI must be 0 or 1");
       if (!(sp[5] == 0.0 || sp[5] == 2.0 || sp[5] == 3.0)) throw std::invalid_argument("smart factor: linearization mode must be 0 HESSIAN, 2 JACOBIAN_Q or 3 JACOBIAN_SVD");
       // rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold (negative = off, as in the reference),
       // retriangulationThreshold: numbers, not NaN / inf (a NaN threshold silently disables the test it guards)

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
           const double* pose = values + a.val_off[a.sfm_cam[o0 + k]];
           for (int e = 0; e < 12; e++) a.cache_pose[12 * (k0 + k) + e] = pose[e];
         }
-        st = smart_triangulate(m, a.sfm_cam + o0, a.val_off, values, a.sfm_z + 2 * o0, prm[0], prm[1], prm[2], pt);
+        st = smart_triangulate(m, a.sfm_cam + o0, a.val_off, values, a.sfm_z + 2 * o0, prm[0], prm[1], prm[2], pt, prm[6] != 0.0);
         a.cache_state[sf] = st;
         for (int e = 0; e < 3; e++) a.cache_point[3 * sf + e] = pt[e];
       } else {
@@ -352,12 +352,13 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
     //   error():   the point at infinity under HANDLE_INFINITY, 0.0 otherwise (totalReprojectionError, :419-429).
     // The direction is taken from the cameras of THIS call (it is not part of the cached triangulation).
     const int mode = (int)prm[4], lin_mode = (int)prm[5];
-    bool at_infinity = st != kTriValid && st != kTriNoConvergence && (for_linearize ? (mode != 1 && lin_mode == 0) : mode == 2);
+    bool at_infinity = st != kTriValid && st != kTriNoConvergence && st != kTriCheiralityThrown && (for_linearize ? (mode != 1 && lin_mode == 0) : mode == 2);
     if (at_infinity && !sfm_backproject_at_infinity(values + a.val_off[a.sfm_cam[o0]], a.sfm_z + 2 * o0, pt)) { st = kTriNoConvergence; at_infinity = false; }
     a.status[sf] = st | (at_infinity ? kTriAtInfinity : 0);
     double* slot = values + a.val_off[a.sfm_point[o0]];
     for (int e = 0; e < 3; e++) slot[e] = (st == kTriValid || at_infinity) ? pt[e] : 0.0;
     if (st == kTriNoConvergence) scalars[SC_UNSUPPORTED] = 1.0;      // Cal3Bundler::calibrate throws in the reference
+    if (st == kTriCheiralityThrown) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;   // enableEPI: geom.h::triangulate_refine
   }
 }
 

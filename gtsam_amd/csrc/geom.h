@@ -382,9 +382,110 @@ GT_HD void jacobi_eig4(double (&A)[4][4], double (&V)[4][4]) {
 }
 
 enum { kTriValid = 0, kTriDegenerate = 1, kTriBehindCamera = 2, kTriOutlier = 3, kTriFarPoint = 4, kTriNoConvergence = 5,
+       kTriCheiralityThrown = 6,   // enableEPI: the refinement linearised at a point behind a camera -- the reference throws (see triangulate_refine)
        kTriAtInfinity = 16 };   // flag on a failed status: this use of the factor replaces the landmark by a point at infinity
 
-// gtsam::triangulateSafe for PinholeCamera<Cal3Bundler> cameras (triangulation.h:697-752; enableEPI = false, useLOST = false):
+// ---- TriangulationParameters::enableEPI: gtsam::triangulateNonlinear (geometry/triangulation.h:211-221) ------------------------------
+// The DLT point refined by the reference's own LevenbergMarquardtOptimizer on one TriangulationFactor per camera
+// (slam/TriangulationFactor.h:121-136: h(x) - z through the camera's full projection, unit noise) with the parameters of
+// triangulation.cpp:177-195 -- lambdaInitial 1, lambdaFactor 10 (fixed), at most 100 iterations, absoluteErrorTol 1.0, the rest
+// defaults (relativeErrorTol 1e-5, lambdaUpperBound 1e5, minModelFidelity 1e-3, identity damping).  The state machine is that of
+// LM.cpp:121-308 / NonlinearOptimizer.cpp:62-117 on one 3-dimensional variable; it stops after a step or two (absoluteErrorTol 1.0),
+// so the RESULT depends on every accept / reject decision and is reproduced decision by decision.
+//   tri_cost: sum over the cameras of |h - z|^2; with `H`: also A^T A (upper triangle: 00 01 02 11 12 22), A^T b with b = z - h.
+//   A point behind a camera evaluates to the constant error (2 fx, 2 fx) (PinholeCamera.h:323-325) -- but LINEARISING there is a
+//   CheiralityException nothing catches (TriangulationFactor::linearize projects without evaluateError's try / catch, :148-170):
+//   returns false.
+GT_HD bool tri_cost(int m, const int32_t* cams, const int64_t* val_off, const double* values, const double* z, const double* pt,
+                    double* H, double* g, double* sumsq) {
+  double f = 0.0;
+  if (H) { for (int i = 0; i < 6; i++) H[i] = 0.0; g[0] = g[1] = g[2] = 0.0; }
+  for (int k = 0; k < m; k++) {
+    const double* c = values + val_off[cams[k]];
+    double cam[17], pi[2], Dp[6];
+    for (int j = 0; j < 17; j++) cam[j] = c[j];
+    const bool front = H ? sfm_project(cam, pt, pi, nullptr, Dp) : sfm_project(cam, pt, pi, nullptr, nullptr);
+    if (!front) {
+      if (H) return false;
+      f += 2.0 * (2.0 * cam[12]) * (2.0 * cam[12]);
+      continue;
+    }
+    const double b0 = z[2 * k] - pi[0], b1 = z[2 * k + 1] - pi[1];
+    f += b0 * b0 + b1 * b1;
+    if (H) {
+      H[0] += Dp[0] * Dp[0] + Dp[3] * Dp[3]; H[1] += Dp[0] * Dp[1] + Dp[3] * Dp[4]; H[2] += Dp[0] * Dp[2] + Dp[3] * Dp[5];
+      H[3] += Dp[1] * Dp[1] + Dp[4] * Dp[4]; H[4] += Dp[1] * Dp[2] + Dp[4] * Dp[5]; H[5] += Dp[2] * Dp[2] + Dp[5] * Dp[5];
+      g[0] += Dp[0] * b0 + Dp[3] * b1; g[1] += Dp[1] * b0 + Dp[4] * b1; g[2] += Dp[2] * b0 + Dp[5] * b1;
+    }
+  }
+  *sumsq = f;
+  return true;
+}
+// false: the reference throws (see above); the point is refined in place otherwise.
+GT_HD bool triangulate_refine(int m, const int32_t* cams, const int64_t* val_off, const double* values, const double* z, double* pt) {
+  double H[6], g[3], bb, f;
+  tri_cost(m, cams, val_off, values, z, pt, nullptr, nullptr, &f);
+  double err = 0.5 * f, lam = 1.0;
+  int iterations = 0;
+  if (err <= 0.0) return true;                                      // errorTol = 0 (NonlinearOptimizer.cpp:68-74)
+  double new_error = err;
+  for (;;) {
+    const double current_error = new_error;
+    if (!tri_cost(m, cams, val_off, values, z, pt, H, g, &bb)) return false;
+    for (;;) {                                                      // tryLambda until a step is accepted or the search is given up
+      // the one clique of the damped system: Eigen LLT of H + lambda I (choleskyPartial, base/cholesky.cpp:107-158) and its rank test
+      // on the exponents of the last two pivots
+      const double a00 = H[0] + lam, a11 = H[3] + lam, a22 = H[5] + lam;
+      bool ok = a00 > 0.0;
+      const double r00 = sqrt(a00), r01 = H[1] / r00, r02 = H[2] / r00;
+      const double x11 = a11 - r01 * r01;
+      ok = ok && x11 > 0.0;
+      const double r11 = sqrt(x11), r12 = (H[4] - r01 * r02) / r11;
+      const double x22 = a22 - r02 * r02 - r12 * r12;
+      ok = ok && x22 > 0.0;
+      const double r22 = sqrt(x22);
+      if (ok) { int e2, e1; (void)frexp(r11, &e2); (void)frexp(r22, &e1); ok = e2 - e1 < 12; }
+      bool step_ok = false, stop = false;
+      double trial[3] = {0.0, 0.0, 0.0}, trial_err = 0.0;
+      if (ok) {
+        const double y0 = g[0] / r00, y1 = (g[1] - r01 * y0) / r11, y2 = (g[2] - r02 * y0 - r12 * y1) / r22;   // R^T y = g
+        const double d2 = y2 / r22, d1 = (y1 - r12 * d2) / r11, d0 = (y0 - r01 * d1 - r02 * d2) / r00;      // R delta = y
+        // linear.error(0) = 0.5 |b|^2; linear.error(delta) = 0.5 |A delta - b|^2 = 0.5 (|b|^2 - 2 g.delta + delta^T H delta), undamped
+        const double Hd0 = H[0] * d0 + H[1] * d1 + H[2] * d2, Hd1 = H[1] * d0 + H[3] * d1 + H[4] * d2, Hd2 = H[2] * d0 + H[4] * d1 + H[5] * d2;
+        const double old_lin = 0.5 * bb, new_lin = 0.5 * (bb - 2.0 * (g[0] * d0 + g[1] * d1 + g[2] * d2) + (d0 * Hd0 + d1 * Hd1 + d2 * Hd2));
+        const double lin_change = old_lin - new_lin;
+        if (lin_change >= 0) {
+          trial[0] = pt[0] + d0; trial[1] = pt[1] + d1; trial[2] = pt[2] + d2;
+          double ft;
+          tri_cost(m, cams, val_off, values, z, trial, nullptr, nullptr, &ft);
+          trial_err = 0.5 * ft;
+          const double cost_change = err - trial_err;
+          if (lin_change > kEps * old_lin) step_ok = cost_change / lin_change > 1e-3;
+          if (fabs(cost_change) < 1e-5 * err) stop = true;
+        }
+      }
+      if (step_ok) {
+        lam = lam / 10.0;                                           // decreaseLambda, fixed factor; lambdaLowerBound 0
+        pt[0] = trial[0]; pt[1] = trial[1]; pt[2] = trial[2]; err = trial_err;
+        iterations++;
+        break;
+      } else if (!stop) {
+        lam *= 10.0;                                                // increaseLambda
+        if (lam >= 1e5) break;
+      } else {
+        break;
+      }
+    }
+    new_error = err;
+    // checkConvergence(relativeErrorTol 1e-5, absoluteErrorTol 1.0, errorTol 0) (NonlinearOptimizer.cpp:182-231)
+    const double absolute_decrease = current_error - new_error, relative_decrease = absolute_decrease / current_error;
+    const bool converged = new_error <= 0.0 || relative_decrease <= 1e-5 || absolute_decrease <= 1.0;
+    if (!(iterations < 100 && !converged && current_error - current_error == 0.0)) break;     // (x - x == 0: finite)
+  }
+  return true;
+}
+
+// gtsam::triangulateSafe for PinholeCamera<Cal3Bundler> cameras (triangulation.h:697-752; useLOST = false):
 //   undistort every measurement (calibrate with the camera's Cal3Bundler, uncalibrate with its pinhole part, :261-268),
 //   DLT on the projection matrices K [R | t]^-1 (triangulation.cpp:27-57: rows x P_3 - P_1, y P_3 - P_2; the right singular vector
 //   of the smallest singular value, rank = singular values above rank_tol -- here from the eigen-decomposition of A^T A),
@@ -392,7 +493,7 @@ enum { kTriValid = 0, kTriDegenerate = 1, kTriBehindCamera = 2, kTriOutlier = 3,
 //   threshold (FAR_POINT) and the largest reprojection error against the outlier threshold (OUTLIER).
 // cams[k] -> values + val_off[cams[k]] = pose (R row-major, t), f, k1, k2, u0, v0; z = 2 per measurement.
 GT_HD int smart_triangulate(int m, const int32_t* cams, const int64_t* val_off, const double* values, const double* z,
-                            double rank_tol, double dist_thr, double outlier_thr, double* point) {
+                            double rank_tol, double dist_thr, double outlier_thr, double* point, bool enable_epi = false) {
   point[0] = point[1] = point[2] = 0.0;
   if (m < 2) return kTriDegenerate;
   double M[4][4], V[4][4];
@@ -427,6 +528,7 @@ GT_HD int smart_triangulate(int m, const int32_t* cams, const int64_t* val_off, 
   double v[4] = {0, 0, 0, 0};
   _Pragma("unroll") for (int j = 0; j < 4; j++) if (j == smallest) { v[0] = V[0][j]; v[1] = V[1][j]; v[2] = V[2][j]; v[3] = V[3][j]; }
   point[0] = v[0] / v[3]; point[1] = v[1] / v[3]; point[2] = v[2] / v[3];
+  if (enable_epi && !triangulate_refine(m, cams, val_off, values, z, point)) return kTriCheiralityThrown;   // (triangulation.h:531-534)
   for (int k = 0; k < m; k++) {       // triangulatePoint3's cheirality check: every camera first
     const double* c = values + val_off[cams[k]];
     const double dx[3] = {point[0] - c[9], point[1] - c[10], point[2] - c[11]};

@@ -306,7 +306,8 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
           // IMPLICIT_SCHUR factor cannot be eliminated by the reference's direct solvers either.  (throwCheirality / verboseCheirality
           // are read by the pose-only smart factors, not by SmartProjectionFactor<CAMERA>.)
           if (sp.linearizationMode == IMPLICIT_SCHUR) throw std::invalid_argument("SmartProjectionFactor: the IMPLICIT_SCHUR linearisation is not supported");
-          if (tp.enableEPI || tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: enableEPI / useLOST are not supported");
+          if (tp.useLOST) throw std::invalid_argument("SmartProjectionFactor: useLOST is not supported");
+          if (tp.enableEPI && tp.noiseModel) throw std::invalid_argument("SmartProjectionFactor: enableEPI with a noise model in the triangulation parameters is not supported");
           const SharedIsotropic& iso = (*sf).*SmartAccess::noise();
           Extract::run(x.sm_nz, iso);
           const auto& zs = sf->measured();
@@ -315,7 +316,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
           x.sm_ptr.push_back((int64_t)x.sm_cam.size());
           x.sm_prm.insert(x.sm_prm.end(), {tp.rankTolerance, tp.landmarkDistanceThreshold, tp.dynamicOutlierRejectionThreshold, sp.retriangulationThreshold,
                                            sp.degeneracyMode == ZERO_ON_DEGENERACY ? 1.0 : (sp.degeneracyMode == HANDLE_INFINITY ? 2.0 : 0.0),
-                                           sp.linearizationMode == JACOBIAN_Q ? 2.0 : (sp.linearizationMode == JACOBIAN_SVD ? 3.0 : 0.0), 0.0, 0.0});
+                                           sp.linearizationMode == JACOBIAN_Q ? 2.0 : (sp.linearizationMode == JACOBIAN_SVD ? 3.0 : 0.0), tp.enableEPI ? 1.0 : 0.0, 0.0});
         } else if (auto bb = dynamic_cast<const BetweenFactor<Pose3>*>(f.get())) {
           x.fac_map.emplace_back(GTG_FAC_BETWEEN_POSE3, (int64_t)x.bt_1.size());
           x.bt_1.push_back(idOf(bb->key1())); x.bt_2.push_back(idOf(bb->key2()));

@@ -209,11 +209,12 @@ class Problem:
     # ---- smart factors -----------------------------------------------------------------------
     def add_smart(self, cams, zs, noise_idx: int, rank_tolerance=1.0, landmark_distance_threshold=-1.0,
                   dynamic_outlier_rejection_threshold=-1.0, retriangulation_threshold=1e-5, degeneracy_mode=0,
-                  linearization_mode=0):
+                  linearization_mode=0, enable_epi=False):
         """One SmartProjectionFactor<PinholeCamera<Cal3Bundler>>: camera variable ids + their pixel measurements; defaults =
         SmartProjectionParams() / TriangulationParameters() (slam/SmartFactorParams.h:58-66, geometry/triangulation.h:583-600).
         degeneracy_mode 0 IGNORE_DEGENERACY, 1 ZERO_ON_DEGENERACY, 2 HANDLE_INFINITY; linearization_mode 0 HESSIAN, 2 JACOBIAN_Q,
-        3 JACOBIAN_SVD (1 = IMPLICIT_SCHUR cannot be eliminated by the reference's direct solvers and is refused)."""
+        3 JACOBIAN_SVD (1 = IMPLICIT_SCHUR cannot be eliminated by the reference's direct solvers and is refused); enable_epi =
+        TriangulationParameters::enableEPI (the DLT point refined by the reference's LM on TriangulationFactors)."""
         cams = _a(cams, np.int32); zs = _a(zs, np.float64)
         if zs.size != 2 * cams.size or cams.size < 1:
             raise ValueError("a smart factor needs one 2-vector per camera")
@@ -222,7 +223,7 @@ class Problem:
         self.smart_noise = np.concatenate([self.smart_noise, np.array([noise_idx], np.int32)])
         self.smart_params = np.concatenate([self.smart_params, [rank_tolerance, landmark_distance_threshold,
                                                                 dynamic_outlier_rejection_threshold, retriangulation_threshold,
-                                                                float(degeneracy_mode), float(linearization_mode), 0.0, 0.0]])
+                                                                float(degeneracy_mode), float(linearization_mode), 1.0 if enable_epi else 0.0, 0.0]])
 
     # ---- priors ------------------------------------------------------------------------------
     def add_prior(self, var: int, value, noise_idx: int):

@@ -129,12 +129,14 @@ typedef struct gtg_problem {
                                      retriangulationThreshold, degeneracyMode (0 IGNORE_DEGENERACY, 1 ZERO_ON_DEGENERACY,
                                      2 HANDLE_INFINITY), linearizationMode (0 HESSIAN, 2 JACOBIAN_Q, 3 JACOBIAN_SVD; 1 =
                                      IMPLICIT_SCHUR is refused: the reference's direct solvers cannot eliminate it either),
-                                     2 reserved.  A track that does not triangulate is what SmartProjectionFactor.h makes of it:
+                                     enableEPI (0 / 1: the DLT point refined by the reference's LM on TriangulationFactors,
+                                     triangulation.h:211-221, 531-534), 1 reserved.  A track that does not triangulate is what SmartProjectionFactor.h makes of it:
                                      nothing (ZERO_ON_DEGENERACY; the Jacobian modes when linearising), a point at infinity
                                      (:356-371 when linearising in HESSIAN mode, :419-427 in the error under HANDLE_INFINITY), error
-                                     0.0 otherwise.  enableEPI / useLOST are not supported.  Where the reference THROWS out of
+                                     0.0 otherwise.  useLOST is not supported.  Where the reference THROWS out of
                                      linearize() / error() -- the point at infinity behind one of the track's cameras
-                                     (CheiralityException), Cal3Bundler::calibrate not converging -- the call returns an error */
+                                     or the enableEPI refinement linearising behind a camera (CheiralityException),
+                                     Cal3Bundler::calibrate not converging -- the call returns an error */
 } gtg_problem;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

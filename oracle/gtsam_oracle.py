@@ -553,9 +553,78 @@ def bundler_calibrate(f, k1, k2, u0, v0, pi):
     raise RuntimeError("Cal3Bundler::calibrate fails to converge")
 
 
-def triangulate_safe(cams17, z, rank_tol=1.0, dist_thr=-1.0, outlier_thr=-1.0):
-    """gtsam::triangulateSafe (geometry/triangulation.h:697-752) with enableEPI = useLOST = false: undistort, DLT by SVD
-    (triangulation.cpp:27-57, base/Matrix.cpp:566-584), cheirality, distance and outlier checks.  -> (status, point)."""
+def triangulate_nonlinear(cams17, z, point0):
+    """gtsam::triangulateNonlinear (geometry/triangulation.h:211-221): the DLT point refined by LevenbergMarquardtOptimizer on one
+    TriangulationFactor per camera (slam/TriangulationFactor.h:121-136: h(x) - z with the camera's full projection, unit noise; a
+    point behind the camera is the constant error (2 fx, 2 fx), PinholeCamera.h:323-325; LINEARISING there throws) with the parameters of
+    triangulation.cpp:177-195: lambdaInitial 1, lambdaFactor 10, at most 100 iterations, absoluteErrorTol 1.0, the other defaults
+    (relativeErrorTol 1e-5, lambdaUpperBound 1e5, minModelFidelity 1e-3, identity damping, fixed factor).  The state machine is
+    lm_optimize's (LM.cpp:121-308, NonlinearOptimizer.cpp:62-117), on a single 3-dimensional variable."""
+    m = cams17.shape[0]
+
+    def residuals(pt, jac):
+        pi, Dc, Dp, behind = sfm_project(cams17, np.repeat(pt[None], m, 0))
+        r = pi - z
+        r[behind] = 2.0 * cams17[behind, 12:13]
+        if jac:           # TriangulationFactor::linearize projects without evaluateError's try / catch (TriangulationFactor.h:148-170)
+            if behind.any():
+                raise RuntimeError("CheiralityException")
+            return r.reshape(-1), Dp.reshape(-1, 3)
+        return r.reshape(-1), None
+
+    def err_of(pt):
+        r, _ = residuals(pt, False)
+        return 0.5 * float(r @ r)
+    pt = np.asarray(point0, np.float64).copy()
+    err = err_of(pt)
+    lam, factor = 1.0, 10.0
+    iterations = 0
+    if err <= 0.0:
+        return pt
+    new_error = err
+    while True:
+        current_error = new_error
+        r, A = residuals(pt, True)
+        b = -r
+        H = A.T @ A; g = A.T @ b
+        while True:
+            ABC = np.zeros((4, 4)); ABC[:3, :3] = H + lam * np.eye(3); ABC[:3, 3] = g; ABC[3, :3] = g; ABC[3, 3] = b @ b
+            ok = cholesky_partial(ABC, 3)[0]                    # the one clique of the damped system (Eigen LLT + the rank test)
+            step_ok = False; stop = False
+            trial_err = math.inf; trial = None
+            if ok:
+                delta = np.linalg.solve(H + lam * np.eye(3), g)
+                old_lin = 0.5 * float(b @ b); new_lin = 0.5 * float((A @ delta - b) @ (A @ delta - b))
+                lin_change = old_lin - new_lin
+                if lin_change >= 0:
+                    trial = pt + delta
+                    trial_err = err_of(trial)
+                    cost_change = err - trial_err
+                    if lin_change > EPS * old_lin:
+                        step_ok = cost_change / lin_change > 1e-3
+                    if abs(cost_change) < 1e-5 * err:
+                        stop = True
+            if step_ok:
+                lam = max(0.0, lam / factor)
+                pt, err = trial, trial_err
+                iterations += 1
+                break
+            elif not stop:
+                lam *= factor
+                if lam >= 1e5:
+                    break
+            else:
+                break
+        new_error = err
+        if not (iterations < 100 and not check_convergence(1e-5, 1.0, 0.0, current_error, new_error) and math.isfinite(current_error)):
+            break
+    return pt
+
+
+def triangulate_safe(cams17, z, rank_tol=1.0, dist_thr=-1.0, outlier_thr=-1.0, enable_epi=False):
+    """gtsam::triangulateSafe (geometry/triangulation.h:697-752) with useLOST = false: undistort, DLT by SVD
+    (triangulation.cpp:27-57, base/Matrix.cpp:566-584), the nonlinear refinement when enableEPI is set (triangulation.h:531-534),
+    cheirality, distance and outlier checks.  -> (status, point)."""
     m = cams17.shape[0]
     if m < 2:
         return TRI_DEGENERATE, None
@@ -571,6 +640,8 @@ def triangulate_safe(cams17, z, rank_tol=1.0, dist_thr=-1.0, outlier_thr=-1.0):
     if int(np.sum(sv[:min(2 * m, 4)] > rank_tol)) < 3:
         return TRI_DEGENERATE, None
     v = Vt[-1]; pt = v[:3] / v[3]
+    if enable_epi:
+        pt = triangulate_nonlinear(cams17, z, pt)
     for k in range(m):
         R = cams17[k, :9].reshape(3, 3)
         if (R.T @ (pt - cams17[k, 9:12]))[2] <= 0:
@@ -644,7 +715,7 @@ def _smart_factors(p: Problem, values, for_error=False):
         cams = p.smart_cam[k0:k1]; z = p.smart_z.reshape(-1, 2)[k0:k1]
         c17 = np.stack([values[off[c]:off[c] + 17] for c in cams])
         prm = p.smart_params.reshape(-1, 8)[i]
-        st, pt = triangulate_safe(c17, z, prm[0], prm[1], prm[2])
+        st, pt = triangulate_safe(c17, z, prm[0], prm[1], prm[2], enable_epi=bool(prm[6]))
         W = noise_sqrt_info(p, int(p.smart_noise[i]))                      # 2x2 (Unit / Isotropic)
         if st != TRI_VALID:
             at_infinity = (prm[4] == 2.0) if for_error else (prm[4] != 1.0 and prm[5] == SMART_HESSIAN)

@@ -243,6 +243,7 @@ void* ref_graph_create(const gtg_problem* p) {
     const LinearizationMode lm = sp[5] == 1.0 ? IMPLICIT_SCHUR : (sp[5] == 2.0 ? JACOBIAN_Q : (sp[5] == 3.0 ? JACOBIAN_SVD : HESSIAN));
     SmartProjectionParams params(lm, sp[4] == 1.0 ? ZERO_ON_DEGENERACY : (sp[4] == 2.0 ? HANDLE_INFINITY : IGNORE_DEGENERACY), false, false, sp[3]);
     params.setRankTolerance(sp[0]);
+    params.setEnableEPI(sp[6] != 0.0);
     params.setLandmarkDistanceThreshold(sp[1]);
     params.setDynamicOutlierRejectionThreshold(sp[2]);
     auto f = std::make_shared<SmartFactor>(noise[p->smart_noise[i]], params);
@@ -620,12 +621,21 @@ int ref_graph_iteration_mt(void* h, const double* values, double lambda, int dia
 }
 // gtsam::triangulateSafe (geometry/triangulation.h:697-752) for m PinholeCamera<Cal3Bundler> cameras (17 doubles each):
 // status 0 VALID, 1 DEGENERATE, 2 BEHIND_CAMERA, 3 OUTLIER, 4 FAR_POINT; point filled when valid
+// enable_epi: TriangulationParameters::enableEPI -- the DLT point refined by triangulateNonlinear (triangulation.h:211-221: LM on
+// TriangulationFactors, triangulation.cpp:177-195) before the checks
+int ref_triangulate_safe_epi(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, int enable_epi, double* point);
 int ref_triangulate_safe(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
+  return ref_triangulate_safe_epi(m, cams17, z, rank_tol, dist_thr, outlier_thr, 0, point);
+}
+int ref_triangulate_safe_epi(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, int enable_epi, double* point) {
   CameraSet<Camera> cameras;
   Point2Vector measured;
   for (int k = 0; k < m; k++) { cameras.push_back(unpackCamera(cams17 + 17 * k)); measured.emplace_back(z[2 * k], z[2 * k + 1]); }
-  TriangulationParameters params(rank_tol, false, dist_thr, outlier_thr);
-  const TriangulationResult r = triangulateSafe(cameras, measured, params);
+  TriangulationParameters params(rank_tol, enable_epi != 0, dist_thr, outlier_thr);
+  // (TriangulationFactor::linearize projects without the try / catch of its evaluateError, slam/TriangulationFactor.h:148-170: a
+  // refinement that linearises at a point behind one of the cameras throws a CheiralityException through triangulateSafe -> 6)
+  TriangulationResult r = TriangulationResult::Degenerate();
+  try { r = triangulateSafe(cameras, measured, params); } catch (const CheiralityException&) { return 6; }
   if (r.valid()) { point[0] = r->x(); point[1] = r->y(); point[2] = r->z(); return 0; }
   return r.degenerate() ? 1 : r.behindCamera() ? 2 : r.outlier() ? 3 : 4;
 }

@@ -50,3 +50,36 @@ inline void smartFarScene(gtsam::LinearizationMode lin, gtsam::DegeneracyMode de
   for (int i : {0, nc - 1})
     graph->addPrior(Symbol('c', i), initial->at<Camera>(Symbol('c', i)), noiseModel::Isotropic::Sigma(9, 0.05));
 }
+
+// An orbit scene without failed tracks (cameras on a wide arc around a compact cloud, 2 pixels of measurement noise) for
+// TriangulationParameters::enableEPI: every triangulation refined by the reference's LM on TriangulationFactors.
+inline void smartEpiScene(gtsam::NonlinearFactorGraph* graph, gtsam::Values* initial) {
+  using namespace gtsam;
+  typedef PinholeCamera<Cal3Bundler> Camera;
+  std::mt19937 rng(4321);
+  std::normal_distribution<double> N(0.0, 1.0);
+  const int nc = 9, np = 80;
+  std::vector<Camera> cams; std::vector<Point3> pts;
+  for (int i = 0; i < nc; i++) {
+    const double a = 0.22 * i - 0.9;
+    cams.emplace_back(Pose3(Rot3::RzRyRx(0.02 * N(rng), -a, 0.02 * N(rng)), Point3(8 * std::sin(a), 0.3 * N(rng), -8 * std::cos(a))),
+                      Cal3Bundler(500 + 30 * i, 2e-2 * N(rng), 2e-3 * N(rng), 0, 0));
+  }
+  for (int j = 0; j < np; j++) pts.emplace_back(1.2 * N(rng), 0.9 * N(rng), 1.2 * N(rng));
+  SmartProjectionParams sp;
+  sp.setEnableEPI(true);
+  auto noise = noiseModel::Isotropic::Sigma(2, 2.0);
+  for (int j = 0; j < np; j++) {
+    auto f = std::make_shared<SmartProjectionFactor<Camera>>(noise, sp);
+    int used = 0;
+    for (int i = 0; i < nc; i++) {
+      if ((i + 3 * j) % 4 == 0 && used >= 2) continue;
+      const auto zs = cams[i].projectSafe(pts[j]);
+      if (!zs.second) continue;
+      f->add(zs.first + Point2(2.0 * N(rng), 2.0 * N(rng)), Symbol('c', i)); used++;
+    }
+    graph->push_back(f);
+  }
+  for (int i = 0; i < nc; i++)
+    initial->insert(Symbol('c', i), cams[i].retract((Vector(9) << 0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng), 0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng), N(rng), 0, 0).finished()));
+}

@@ -398,6 +398,15 @@ int main() {
       g_skip_ab = false;
     }
   }
+  {  // ---- TriangulationParameters::enableEPI: every triangulation refined by the reference's own LM (tests/cpp/smart_far_scene.h) ----
+    NonlinearFactorGraph graph; Values initial;
+    smartEpiScene(&graph, &initial);
+    g_skip_ab = true;
+    LevenbergMarquardtParams ceres; LevenbergMarquardtParams::SetCeresDefaults(&ceres);
+    compare("Smart enableEPI c", graph, initial, ceres, 1e-6);
+    compare("Smart enableEPI l", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    g_skip_ab = false;
+  }
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;
     initial.insert(X(0), Pose3()); initial.insert(X(1), Pose3());

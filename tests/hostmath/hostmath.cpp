@@ -55,9 +55,12 @@ int hm_sfm_linearize_at_infinity(long n, const double* cam, const double* dir, c
   return bad;
 }
 // smart factors: gtsam::triangulateSafe for m PinholeCamera<Cal3Bundler> cameras (17 doubles each) -> status, point
-int hm_smart_triangulate(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
+int hm_smart_triangulate_epi(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, int enable_epi, double* point) {
   std::vector<int32_t> ids(m); std::vector<int64_t> off(m);
   for (int k = 0; k < m; k++) { ids[k] = k; off[k] = 17 * k; }
-  return gt::smart_triangulate(m, ids.data(), off.data(), cams17, z, rank_tol, dist_thr, outlier_thr, point);
+  return gt::smart_triangulate(m, ids.data(), off.data(), cams17, z, rank_tol, dist_thr, outlier_thr, point, enable_epi != 0);
+}
+int hm_smart_triangulate(int m, const double* cams17, const double* z, double rank_tol, double dist_thr, double outlier_thr, double* point) {
+  return hm_smart_triangulate_epi(m, cams17, z, rank_tol, dist_thr, outlier_thr, 0, point);
 }
 }

@@ -63,15 +63,17 @@ SYNTH = {
 }
 
 
-def smart_orbit(degenerate=False):
+def smart_orbit(degenerate=False, enable_epi=False):
     """SmartProjectionFactor<PinholeCamera<Cal3Bundler>> graphs (section 8(f) #3), built like timing/timeSFMBALsmart.cpp from
     D.synthetic_orbit_scene: cameras are the only variables.  degenerate=True: ZERO_ON_DEGENERACY with tracks that do not
     triangulate -- single observations (m < 2), a landmark-distance threshold that rejects the far half of the cloud, a
     dynamic outlier threshold that rejects tracks with a bad measurement."""
     from gtsam_amd.problem import smart_bal_problem
-    cams, pts, oc, op, oz = D.synthetic_orbit_scene(seed=3 if degenerate else 0)
+    # (enable_epi: TriangulationParameters::enableEPI, every triangulation refined by the reference's LM on TriangulationFactors; four
+    # times the pixel noise, so that the refinement moves the points)
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(seed=3 if degenerate else 0, pixel_noise=2.0 if enable_epi else 0.5)
     if not degenerate:
-        return smart_bal_problem(cams, oc, op, oz)
+        return smart_bal_problem(cams, oc, op, oz, enable_epi=enable_epi)
     oz = oz.copy()
     first = np.flatnonzero(np.r_[True, np.diff(op) != 0])
     oz[first[::9]] += 150.0                                              # a bad measurement in every 9th track
@@ -79,10 +81,10 @@ def smart_orbit(degenerate=False):
     for j in range(5, 120, 11):                                          # these tracks keep a single observation
         idx = np.flatnonzero(op == j); keep[idx[1:]] = False
     return smart_bal_problem(cams, oc[keep], op[keep], oz[keep], degeneracy_mode=1, landmark_distance_threshold=10.5,
-                             dynamic_outlier_rejection_threshold=60.0)
+                             dynamic_outlier_rejection_threshold=60.0, enable_epi=enable_epi)
 
 
-def smart_far(degeneracy_mode, linearization_mode=0, arc=0.5, init_noise=(0.01, 0.05), spread=1.0):
+def smart_far(degeneracy_mode, linearization_mode=0, arc=0.5, init_noise=(0.01, 0.05), spread=1.0, enable_epi=False):
     """The degeneracy modes that replace a failed track by a POINT AT INFINITY (SmartProjectionFactor.h:356-371, :419-427), on a
     scene where that is a sensible model: a quarter of the landmarks lie thousands of units behind the cloud and fail the
     landmark-distance threshold (FAR_POINT), some tracks keep a single observation (DEGENERATE).  (A NEAR track seen from infinity
@@ -98,7 +100,7 @@ def smart_far(degeneracy_mode, linearization_mode=0, arc=0.5, init_noise=(0.01, 
     for j in range(5, 120, 17):                                          # these tracks keep a single observation
         idx = np.flatnonzero(op == j); keep[idx[1:]] = False
     p, v0 = smart_bal_problem(cams, oc[keep], op[keep], oz[keep], degeneracy_mode=degeneracy_mode, linearization_mode=linearization_mode,
-                              landmark_distance_threshold=100.0)
+                              landmark_distance_threshold=100.0, enable_epi=enable_epi)
     # priors on the two end cameras fix the gauge: without them the end game of the legacy parameters (identity damping down to
     # lambda = 1e-8 on a system with seven flat directions) is decided by the rounding of the solve, in the reference as well
     ni = p.add_noise(NOISE_ISOTROPIC, 9, [0.05])
@@ -107,6 +109,7 @@ def smart_far(degeneracy_mode, linearization_mode=0, arc=0.5, init_noise=(0.01, 
 
 
 SMART = {"smart_orbit": lambda: smart_orbit(False), "smart_orbit_degenerate": lambda: smart_orbit(True),
+         "smart_orbit_epi": lambda: smart_orbit(False, enable_epi=True),
          "smart_far_infinity": lambda: smart_far(2), "smart_far_ignore": lambda: smart_far(0),
          # (closer initial values: without the far tracks in the linear system the first steps from the noisier start leave the region
          # where Cal3Bundler::calibrate converges, and the reference throws)

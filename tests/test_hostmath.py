@@ -300,6 +300,60 @@ def test_smart_triangulation_against_the_reference(hm, live_ref):
     assert all(v > 0 for v in seen.values()), seen              # every status occurred
 
 
+def test_smart_triangulation_with_epi(hm, live_ref):
+    """TriangulationParameters::enableEPI: geom.h::triangulate_refine -- the reference's LM on one TriangulationFactor per camera,
+    restated decision by decision -- against the oracle's restatement (always) and the live reference's triangulateSafe (when
+    present), on clean, rank-deficient, behind-camera, far, outlier and NOISY tracks (there the refinement moves the point by up
+    to tens of units): the same status, the same point to 1e-9, and the same CheiralityException where the refinement linearises
+    at a point behind a camera (status 6 on all three sides)."""
+    from gtsam_amd import datasets as D
+    hm.hm_smart_triangulate_epi.restype = C.c_int
+    lib = None
+    if live_ref is not None:
+        lib = live_ref.lib(); lib.ref_triangulate_safe_epi.restype = C.c_int
+    cams, pts, oc, op, oz = D.synthetic_orbit_scene(n_cams=8, n_points=60, seed=11)
+    rng = np.random.default_rng(2)
+    seen = {}; moved = 0.0
+    for j in range(60):
+        idx = np.flatnonzero(op == j)
+        for variant in range(6):
+            cj = np.ascontiguousarray(cams[oc[idx]]); zj = np.ascontiguousarray(oz[idx]).copy()
+            rank_tol, dist, outl = 1.0, -1.0, -1.0
+            if variant == 1:
+                cj = np.ascontiguousarray(np.stack([cj[0], cj[0]])); zj = np.ascontiguousarray(np.stack([zj[0], zj[0]]))
+            elif variant == 2:
+                cj = np.ascontiguousarray(cj[[0, -1]]); d = zj[-1] - zj[0]
+                zj = np.ascontiguousarray(np.stack([zj[0] + 3.0 * d, zj[-1] - 3.0 * d]))
+            elif variant == 3:
+                dist = 7.5 + 0.5 * rng.uniform()
+            elif variant == 4:
+                zj[0] += 40.0; outl = 15.0
+            elif variant == 5:
+                zj += rng.normal(0, 6.0, zj.shape)
+            m = cj.shape[0]
+            pd = np.zeros(3); p0 = np.zeros(3)
+            sd = hm.hm_smart_triangulate_epi(C.c_int(m), P(cj), P(zj), C.c_double(rank_tol), C.c_double(dist), C.c_double(outl), C.c_int(1), P(pd))
+            s0 = hm.hm_smart_triangulate_epi(C.c_int(m), P(cj), P(zj), C.c_double(rank_tol), C.c_double(dist), C.c_double(outl), C.c_int(0), P(p0))
+            try:
+                so, po = O.triangulate_safe(cj, zj, rank_tol, dist, outl, enable_epi=True)
+            except RuntimeError as e:
+                assert "Cheirality" in str(e); so, po = 6, None
+            assert sd == so, (j, variant, sd, so)
+            seen[sd] = seen.get(sd, 0) + 1
+            if sd == 0:
+                assert np.abs(pd - po).max() <= 1e-9 * max(1.0, np.abs(po).max()), (j, variant, pd, po)
+                if s0 == 0:
+                    moved = max(moved, float(np.abs(pd - p0).max()))
+            if lib is not None:
+                pr = np.zeros(3)
+                sr = lib.ref_triangulate_safe_epi(C.c_int(m), P(cj), P(zj), C.c_double(rank_tol), C.c_double(dist), C.c_double(outl), C.c_int(1), P(pr))
+                assert sr == sd, (j, variant, sr, sd)
+                if sr == 0:
+                    assert np.abs(pr - pd).max() <= 1e-9 * max(1.0, np.abs(pr).max()), (j, variant, pr, pd)
+    assert seen.get(0, 0) > 100 and seen.get(1, 0) and seen.get(3, 0) and seen.get(4, 0) and seen.get(6, 0), seen
+    assert moved > 1.0                                          # the refinement is not a no-op on these inputs
+
+
 def test_smart_point_at_infinity(hm):
     """The records of a smart factor whose landmark is a point at infinity (geom.h sfm_backproject_at_infinity /
     sfm_project_at_infinity, factors.h sfm_linearize_at_infinity) against the oracle's restatement, which multiplies the chain of

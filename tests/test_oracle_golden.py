@@ -250,6 +250,23 @@ def test_smart_point_at_infinity_cheirality(live_ref):
             assert np.isnan(e)                                  # the harness turns the exception into NaN
 
 
+def test_smart_epi_refinement_behind_a_camera_throws(live_ref):
+    """enableEPI: the refinement of a triangulation (LM on TriangulationFactors) LINEARISES without the try / catch its error
+    evaluation has (slam/TriangulationFactor.h:148-170 vs :121-136), so a DLT point behind a camera -- the tracks with a bad
+    measurement of the degenerate scene -- is a CheiralityException out of error() and linearize(); the restatement agrees."""
+    p, v0 = PB.smart_orbit(True, enable_epi=True)
+    with pytest.raises(RuntimeError, match="CheiralityException"):
+        O.error(p, v0)
+    with pytest.raises(RuntimeError, match="CheiralityException"):
+        O.hessian_diagonal(p, v0)
+    if live_ref is not None:
+        assert np.isnan(live_ref.RefGraph(p).error(v0))
+        # (a fresh graph: the factor records the camera poses as triangulated BEFORE it triangulates, SmartProjectionFactor.h:127-164,
+        # so after an exception the next call with the same cameras silently reuses the previous result)
+        with pytest.raises(RuntimeError, match="CheiralityException"):
+            live_ref.RefGraph(p).hessian_diagonal(v0)
+
+
 # ---- (3) Pose2 pose graphs: BASELINE configs[0] (Pose2SLAMExample_g2o protocol with LM) --------------------------------
 @pytest.mark.parametrize("name", ["pose2_w100", "pose2_toy"])
 def test_oracle_pose2_matches_reference_golden(name):

@@ -1,8 +1,5 @@
 out=gpurun_out/$1; mkdir -p $out
 {
-echo "== full gpu suite"; timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -15
-} > $out/gpu_tests.log 2>&1
-timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
-timeout 300 python bench.py --skip-dense-roofline --cpu-baseline off --workload streets1723 > $out/bench_streets1723.json 2> $out/bench_streets.err
-timeout 600 tests/_build/test_gpu_lm_gtsam > $out/shim_test.log 2>&1
-tail -3 $out/gpu_tests.log; tail -c 400 $out/bench.json; tail -2 $out/shim_test.log
+echo "== smart"; timeout 900 python -m pytest tests/test_gpu_smart_factors.py tests/test_gpu_sharding.py -q -k "smart or epi" 2>&1 | tail -30
+echo "== shim"; timeout 600 tests/_build/test_gpu_lm_gtsam 2>&1 | grep -i "EPI\|FAIL\|PASSED" | head -20
+} > $out/log.txt 2>&1

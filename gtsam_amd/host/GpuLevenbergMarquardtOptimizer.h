@@ -75,4 +75,13 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   gtsam::GaussianFactorGraph::shared_ptr downloadLinearization() const;   // the device's current records as JacobianFactors
 };
 
+/// LevenbergMarquardtParams that name the GPU optimizer as their optimizer type (LevenbergMarquardtParams.h:45 does so for the
+/// reference's own), for the callers that are templated on it: gtsam::GncOptimizer<gtsam::GncParams<GpuLevenbergMarquardtParams>>
+/// (nonlinear/GncOptimizer.h:47, 185-187, 236-238) then runs every inner weighted least-squares problem on the device.
+struct GpuLevenbergMarquardtParams : gtsam::LevenbergMarquardtParams {
+  using OptimizerType = GpuLevenbergMarquardtOptimizer;
+  GpuLevenbergMarquardtParams() = default;
+  GpuLevenbergMarquardtParams(const gtsam::LevenbergMarquardtParams& p) : gtsam::LevenbergMarquardtParams(p) {}   // NOLINT: a drop-in for the base
+};
+
 }  // namespace gtsam_amd

@@ -12,6 +12,7 @@
 #include <gtsam/linear/PCGSolver.h>
 #include <gtsam/linear/Preconditioner.h>
 #include <gtsam/linear/linearExceptions.h>
+#include <gtsam/nonlinear/GncOptimizer.h>
 #include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/nonlinear/internal/LevenbergMarquardtState.h>
 #include <gtsam/slam/BetweenFactor.h>
@@ -406,6 +407,38 @@ int main() {
     compare("Smart enableEPI c", graph, initial, ceres, 1e-6);
     compare("Smart enableEPI l", graph, initial, LevenbergMarquardtParams(), 1e-6);
     g_skip_ab = false;
+  }
+  {  // ---- a caller templated on the optimizer type ("Callers"): graduated non-convexity around the GPU
+    //      optimizer -- GncOptimizer builds a re-weighted graph (Gaussian::Information models) and a fresh base optimizer in every
+    //      outer iteration (nonlinear/GncOptimizer.h:185-187, 236-238, 395-412) -----------------------------------------------------
+    NonlinearFactorGraph graph; Values initial;
+    const int n = 40;
+    std::vector<Pose3> truth;
+    for (int i = 0; i < n; i++) truth.emplace_back(Rot3::RzRyRx(0.05 * std::sin(0.3 * i), 0.04 * i, 0.1 * std::cos(0.2 * i)), Point3(1.5 * i, 0.4 * std::sin(0.5 * i), 0.1 * i));
+    auto odo = noiseModel::Isotropic::Sigma(6, 0.05);
+    auto add = [&](int a, int b, bool outlier) {
+      Pose3 z = truth[a].between(truth[b]).retract((Vector(6) << 0.01 * N(rng), 0.01 * N(rng), 0.01 * N(rng), 0.03 * N(rng), 0.03 * N(rng), 0.03 * N(rng)).finished());
+      if (outlier) z = z * Pose3(Rot3::RzRyRx(0.6, -0.4, 0.5), Point3(3.0, -2.0, 1.5));
+      graph.emplace_shared<BetweenFactor<Pose3>>(X(a), X(b), z, odo);
+    };
+    for (int i = 0; i + 1 < n; i++) add(i, i + 1, false);
+    for (int i = 0; i + 5 < n; i += 3) add(i, i + 5, i % 9 == 3);      // loop closures, some of them wrong
+    graph.addPrior(X(0), truth[0], noiseModel::Isotropic::Sigma(6, 0.01));
+    for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract((Vector(6) << 0.02 * N(rng), 0.02 * N(rng), 0.02 * N(rng), 0.1 * N(rng), 0.1 * N(rng), 0.1 * N(rng)).finished()));
+    LevenbergMarquardtParams lm;
+    GncParams<LevenbergMarquardtParams> pc(lm);
+    GncParams<gtsam_amd::GpuLevenbergMarquardtParams> pg{gtsam_amd::GpuLevenbergMarquardtParams(lm)};
+    GncOptimizer<GncParams<LevenbergMarquardtParams>> gc(graph, initial, pc);
+    GncOptimizer<GncParams<gtsam_amd::GpuLevenbergMarquardtParams>> gg(graph, initial, pg);
+    const Values rc = gc.optimize(), rg = gg.optimize();
+    const Vector wc = gc.getWeights(), wg = gg.getWeights();
+    int rejected = 0;
+    for (int i = 0; i < wc.size(); i++) rejected += wc[i] < 0.5;
+    std::printf("GNC (TLS) around LM    %d factors, %d rejected as outliers; weights differ by %.3g, values by %.3g\n", (int)wc.size(), rejected,
+                (wc - wg).cwiseAbs().maxCoeff(), valuesDiff(rc, rg));
+    EXPECT(rejected >= 1 && rejected < (int)wc.size() / 4, "GNC: %d of %d factors rejected", rejected, (int)wc.size());
+    EXPECT((wc - wg).cwiseAbs().maxCoeff() <= 1e-6, "GNC weights: CPU vs GPU base optimizer differ by %.3g", (wc - wg).cwiseAbs().maxCoeff());
+    EXPECT(valuesDiff(rc, rg) <= 1e-6, "GNC values: CPU vs GPU base optimizer differ by %.3g", valuesDiff(rc, rg));
   }
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;

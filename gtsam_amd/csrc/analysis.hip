@@ -116,13 +116,24 @@ void analyze(gtg_context& c) {
     else { c.h_red_index[v] = (int)c.h_red_var.size(); c.h_red_var.push_back(v); }
   }
   c.n_lm = (int)c.h_lm_var.size(); c.n_red_vars = (int)c.h_red_var.size();
-  // validate factor roles
-  for (int64_t i = 0; i < n_sfm; i++)
-    if (c.h_var_type[hi.sfm_cam[i]] != GTG_VAR_SFM_CAMERA || c.h_var_type[hi.sfm_point[i]] != GTG_VAR_POINT3)
-      throw std::invalid_argument("GeneralSFMFactor keys must be (SFM_CAMERA, POINT3)");
-  for (int64_t i = 0; i < n_proj; i++)
-    if (c.h_var_type[hi.proj_pose[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.proj_point[i]] != GTG_VAR_POINT3)
-      throw std::invalid_argument("GenericProjectionFactor keys must be (POSE3, POINT3)");
+  // The incidence and term lists come from the device (device_analysis.hip) on a single shard with a real runtime; from the host threads
+  // below for a shard (which needs the blocks of the WHOLE graph but only its own terms), under the dry-run runtime of the CPU
+  // tests (no kernels run there) and with GTG_HOST_ANALYSIS=1 (the A/B: both give bit-identical lists).
+  // (kernels_can_run: the library's code objects are gfx950 only; a runtime that reports another architecture -- the dry-run
+  // runtime of the CPU tests reports none -- cannot run the device pass)
+  bool kernels_can_run = false;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) kernels_can_run = std::strncmp(prop.gcnArchName, "gfx", 3) == 0; }
+  const bool device_terms = c.n_shards == 1 && c.n_lm > 0 && !std::getenv("GTG_HOST_ANALYSIS") && kernels_can_run;
+  c.device_terms = device_terms;
+  // validate factor roles (the observation factors' in the device pass when it runs: device_incidence_lists)
+  if (!device_terms) {
+    for (int64_t i = 0; i < n_sfm; i++)
+      if (c.h_var_type[hi.sfm_cam[i]] != GTG_VAR_SFM_CAMERA || c.h_var_type[hi.sfm_point[i]] != GTG_VAR_POINT3)
+        throw std::invalid_argument("GeneralSFMFactor keys must be (SFM_CAMERA, POINT3)");
+    for (int64_t i = 0; i < n_proj; i++)
+      if (c.h_var_type[hi.proj_pose[i]] != GTG_VAR_POSE3 || c.h_var_type[hi.proj_point[i]] != GTG_VAR_POINT3)
+        throw std::invalid_argument("GenericProjectionFactor keys must be (POSE3, POINT3)");
+  }
   for (int64_t i = 0; i < n_btw; i++)
     if (c.h_var_type[hi.between_v1[i]] != c.h_var_type[hi.between_v2[i]] || hi.between_v1[i] == hi.between_v2[i] ||
         (c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE3 && c.h_var_type[hi.between_v1[i]] != GTG_VAR_POSE2))
@@ -155,38 +166,49 @@ void analyze(gtg_context& c) {
 
   // observations
   c.n_obs = n_sfm + n_proj;
-  std::vector<int32_t> obs_red(c.n_obs), obs_lm(c.n_obs);
+  std::vector<int32_t> obs_red, obs_lm, lm_obs, inc_kind, inc_idx;
+  std::vector<int64_t> lm_obs_ptr, inc_ptr;
+  DevBuf<int32_t> d_obs_pos;                    // (device pass: observation -> position of its camera, consumed by device_schur_terms)
+  if (device_terms) {
+    device_incidence_lists(c, c.h_red_pos, d_obs_pos);
+  } else {
+  obs_red.resize(c.n_obs); obs_lm.resize(c.n_obs);
   for (int64_t i = 0; i < n_sfm; i++) { obs_red[i] = c.h_red_index[hi.sfm_cam[i]]; obs_lm[i] = c.h_lm_index[hi.sfm_point[i]]; }
   for (int64_t i = 0; i < n_proj; i++) { obs_red[n_sfm + i] = c.h_red_index[hi.proj_pose[i]]; obs_lm[n_sfm + i] = c.h_lm_index[hi.proj_point[i]]; }
 
-  // landmark -> observations / priors (CSR, factor order)
-  std::vector<int64_t> lm_obs_ptr(c.n_lm + 1, 0), lm_pri_ptr(c.n_lm + 1, 0);
+  // landmark -> observations (CSR, factor order)
+  lm_obs_ptr.assign(c.n_lm + 1, 0);
   for (int64_t o = 0; o < c.n_obs; o++) lm_obs_ptr[obs_lm[o] + 1]++;
-  for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri_ptr[l + 1]++; }
-  for (int l = 0; l < c.n_lm; l++) { lm_obs_ptr[l + 1] += lm_obs_ptr[l]; lm_pri_ptr[l + 1] += lm_pri_ptr[l]; }
-  std::vector<int32_t> lm_obs(c.n_obs), lm_pri(lm_pri_ptr[c.n_lm]);
+  for (int l = 0; l < c.n_lm; l++) lm_obs_ptr[l + 1] += lm_obs_ptr[l];
+  lm_obs.resize(c.n_obs);
   { std::vector<int64_t> w(lm_obs_ptr.begin(), lm_obs_ptr.end() - 1);
     for (int64_t o = 0; o < c.n_obs; o++) lm_obs[w[obs_lm[o]]++] = (int32_t)o; }
-  { std::vector<int64_t> w(lm_pri_ptr.begin(), lm_pri_ptr.end() - 1);
-    for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri[w[l]++] = (int32_t)i; } }
-  std::vector<int32_t> lm_owned(std::max(c.n_lm, 1), 0);
-  for (int l = 0; l < c.n_lm; l++) lm_owned[l] = (l % c.n_shards) == c.shard;
 
   // reduced variable -> contributions
-  std::vector<int64_t> inc_ptr(c.n_red_vars + 1, 0);
+  inc_ptr.assign(c.n_red_vars + 1, 0);
   auto count = [&](int v) { const int r = c.h_red_index[v]; if (r >= 0) inc_ptr[r + 1]++; };
   for (int64_t i = 0; i < n_sfm; i++) count(hi.sfm_cam[i]);
   for (int64_t i = 0; i < n_proj; i++) count(hi.proj_pose[i]);
   for (int64_t i = 0; i < n_btw; i++) { count(hi.between_v1[i]); count(hi.between_v2[i]); }
   for (int64_t i = 0; i < n_pri; i++) count(hi.prior_var[i]);
   for (int r = 0; r < c.n_red_vars; r++) inc_ptr[r + 1] += inc_ptr[r];
-  std::vector<int32_t> inc_kind(inc_ptr[c.n_red_vars]), inc_idx(inc_ptr[c.n_red_vars]);
+  inc_kind.resize(inc_ptr[c.n_red_vars]); inc_idx.resize(inc_ptr[c.n_red_vars]);
   { std::vector<int64_t> w(inc_ptr.begin(), inc_ptr.end() - 1);
     auto put = [&](int v, int kind, int64_t idx) { const int r = c.h_red_index[v]; if (r >= 0) { inc_kind[w[r]] = kind; inc_idx[w[r]++] = (int32_t)idx; } };
     for (int64_t i = 0; i < n_sfm; i++) put(hi.sfm_cam[i], 0, i);
     for (int64_t i = 0; i < n_proj; i++) put(hi.proj_pose[i], 1, i);
     for (int64_t i = 0; i < n_btw; i++) { put(hi.between_v1[i], 2, i); put(hi.between_v2[i], 3, i); }
     for (int64_t i = 0; i < n_pri; i++) put(hi.prior_var[i], 4, i); }
+  }
+  // landmark -> priors (CSR, factor order; a handful)
+  std::vector<int64_t> lm_pri_ptr(c.n_lm + 1, 0);
+  for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri_ptr[l + 1]++; }
+  for (int l = 0; l < c.n_lm; l++) lm_pri_ptr[l + 1] += lm_pri_ptr[l];
+  std::vector<int32_t> lm_pri(lm_pri_ptr[c.n_lm]);
+  { std::vector<int64_t> w(lm_pri_ptr.begin(), lm_pri_ptr.end() - 1);
+    for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri[w[l]++] = (int32_t)i; } }
+  std::vector<int32_t> lm_owned(std::max(c.n_lm, 1), 0);
+  for (int l = 0; l < c.n_lm; l++) lm_owned[l] = (l % c.n_shards) == c.shard;
 
   // off-diagonal pose-pose blocks from BetweenFactors
   struct HB { int64_t key; int32_t code; };
@@ -212,7 +234,7 @@ void analyze(gtg_context& c) {
   hoff_ptr.push_back(n_btw);
   c.n_hoff = (int64_t)hoff_row.size();
 
-  clk.lap("incidence lists");
+  clk.lap(device_terms ? "variable classification, between / prior lists" : "incidence lists");
   // Schur block pairs: for every landmark, every pair of its observations is one term E_a E_b^T of the block
   // (row = the later position, column = the earlier one).  Terms are bucketed by the row position of their block
   // (counting sort), then every row bucket is sorted by column position (stable: the generation order = landmark
@@ -222,8 +244,8 @@ void analyze(gtg_context& c) {
   struct PT { int32_t pb, oa, ob; };
   const int nrv = c.n_red_vars;
   const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), c.n_obs / 16384));
-  std::vector<int32_t> obs_pos(c.n_obs);
-  for (int64_t o = 0; o < c.n_obs; o++) obs_pos[o] = c.h_red_pos[obs_red[o]];
+  std::vector<int32_t> obs_pos;
+  if (!device_terms) { obs_pos.resize(c.n_obs); for (int64_t o = 0; o < c.n_obs; o++) obs_pos[o] = c.h_red_pos[obs_red[o]]; }
   auto for_terms = [&](int l0, int l1, auto&& emit) {
     for (int l = l0; l < l1; l++)
       for (int64_t a = lm_obs_ptr[l]; a < lm_obs_ptr[l + 1]; a++) {
@@ -237,27 +259,17 @@ void analyze(gtg_context& c) {
         }
       }
   };
-  // The term lists come from the device (device_analysis.hip) on a single shard with a real runtime; from the host threads
-  // below for a shard (which needs the blocks of the WHOLE graph but only its own terms), under the dry-run runtime of the CPU
-  // tests (no kernels run there) and with GTG_HOST_ANALYSIS=1 (the A/B: both give bit-identical lists).
-  // (kernels_can_run: the library's code objects are gfx950 only; a runtime that reports another architecture -- the dry-run
-  // runtime of the CPU tests reports none -- cannot run the device pass)
-  bool kernels_can_run = false;
-  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) kernels_can_run = std::strncmp(prop.gcnArchName, "gfx", 3) == 0; }
-  const bool device_terms = c.n_shards == 1 && c.n_lm > 0 && !std::getenv("GTG_HOST_ANALYSIS") && kernels_can_run;
-  c.device_terms = device_terms;
   int64_t n_terms = 0;
   HugeBuf<int32_t> pair_oa(1), pair_ob(1);
   std::vector<int32_t> pair_row, pair_col;
   std::vector<int64_t> pair_ptr;
   if (device_terms) {
-    up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s);
     std::vector<uint64_t> keys;
-    device_schur_terms(c, obs_pos, nrv, keys, pair_ptr);
+    device_schur_terms(c, d_obs_pos, nrv, keys, pair_ptr);
     n_terms = c.n_pair_terms;
     pair_row.resize(keys.size()); pair_col.resize(keys.size());
     for (size_t i = 0; i < keys.size(); i++) { pair_row[i] = pos_to_red[keys[i] / (uint64_t)nrv]; pair_col[i] = pos_to_red[keys[i] % (uint64_t)nrv]; }
-    clk.lap("schur terms + block list (device)");
+    clk.lap("incidence lists, schur terms + block list (device)");
   } else {
   std::vector<int> lm_cut(nth + 1, c.n_lm);      // landmark ranges with equal numbers of terms
   {
@@ -770,10 +782,12 @@ void analyze(gtg_context& c) {
   up(c.lm_var, c.h_lm_var, s); up(c.red_var, c.h_red_var, s); up(c.red_dim, c.h_red_dim, s);
   up(c.lm_index, c.h_lm_index, s); up(c.red_index, c.h_red_index, s); up(c.red_off, c.h_red_off, s);
   up(c.lm_owned, lm_owned, s);
-  up(c.obs_red, obs_red, s); up(c.obs_lm, obs_lm, s);
-  if (!device_terms) { up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s); }
+  if (!device_terms) {   // (else built in place by device_incidence_lists)
+    up(c.obs_red, obs_red, s); up(c.obs_lm, obs_lm, s);
+    up(c.lm_obs_ptr, lm_obs_ptr, s); up(c.lm_obs, lm_obs, s);
+    up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
+  }
   up(c.lm_pri_ptr, lm_pri_ptr, s); up(c.lm_pri, lm_pri, s);
-  up(c.red_inc_ptr, inc_ptr, s); up(c.red_inc_kind, inc_kind, s); up(c.red_inc_idx, inc_idx, s);
   up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
   up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s);
   if (!device_terms) {   // (the device built pair_ptr / pair_oa / pair_ob in place)

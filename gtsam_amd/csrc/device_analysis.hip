@@ -13,6 +13,11 @@
 // The 6 M terms of the L1723 shape take 2.8 ms (profiles/r02_device_analysis_proto.log) against 12 ms on 32 host threads, and
 // 49 MB of term lists never cross PCIe; the host gets back the 0.2 M block keys and offsets it needs for the ordering and the
 // tile schedule.  After the ordering the terms of the blocks whose orientation flips are swapped in place (k_da_flip).
+// The incidence lists in front of that pass -- observation -> (reduced variable, landmark, position), landmark -> observations,
+// reduced variable -> its factors -- are built here as well (device_incidence_lists: one kernel per observation with the role
+// check of the factor keys, two stable radix sorts, CSR offsets by binary search in the sorted keys; 4.6 ms of host passes over the
+// 0.68 M observations of the L1723 shape before).  Stable sorts keep the factor order inside every list, which is the order the
+// host's counting sorts produce: the lists -- and with them every sum the device forms -- are the same whichever side built them.
 // The host version stays: it serves the sharded upload (a shard needs the blocks of the WHOLE graph but only its own terms)
 // and the dry-run runtime of the CPU tests, which cannot run kernels.
 #include <cstring>
@@ -79,6 +84,63 @@ __global__ __launch_bounds__(256) void k_da_flip(int64_t n_flip, const int64_t* 
   for (int64_t t = pptr[p] + (threadIdx.x & 63); t < pptr[p + 1]; t += 64) { const int32_t x = oa[t]; oa[t] = ob[t]; ob[t] = x; }
 }
 
+// one observation per lane: its reduced variable, landmark and position; the keys' roles (GeneralSFMFactor: SFM_CAMERA + POINT3,
+// GenericProjectionFactor: POSE3 + POINT3) checked on the way -> bad[0] = 1 / 2
+__global__ __launch_bounds__(256) void k_da_obs(int64_t n_sfm, int64_t n_proj, const int32_t* __restrict__ sfm_cam, const int32_t* __restrict__ sfm_point,
+    const int32_t* __restrict__ proj_pose, const int32_t* __restrict__ proj_point, const int32_t* __restrict__ var_type,
+    const int32_t* __restrict__ red_index, const int32_t* __restrict__ lm_index, const int32_t* __restrict__ red_pos,
+    int32_t* __restrict__ obs_red, int32_t* __restrict__ obs_lm, int32_t* __restrict__ obs_pos, uint32_t* __restrict__ key,
+    uint32_t* __restrict__ val, int32_t* __restrict__ bad) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_sfm + n_proj) return;
+  const bool sfm = o < n_sfm;
+  const int cam = sfm ? sfm_cam[o] : proj_pose[o - n_sfm], pt = sfm ? sfm_point[o] : proj_point[o - n_sfm];
+  if (var_type[cam] != (sfm ? GTG_VAR_SFM_CAMERA : GTG_VAR_POSE3) || var_type[pt] != GTG_VAR_POINT3) { bad[0] = sfm ? 1 : 2; key[o] = 0; val[o] = (uint32_t)o; return; }
+  const int r = red_index[cam], l = lm_index[pt];
+  obs_red[o] = r; obs_lm[o] = l; obs_pos[o] = red_pos[r];
+  key[o] = (uint32_t)l; val[o] = (uint32_t)o;
+}
+// the factors of every reduced variable, in the order the host lists them: all GeneralSFM observations, all projection observations,
+// the between factors (factor i: its first key, then its second), the priors.  One entry per (factor, key); key = reduced index,
+// or `none` for a key that is not a reduced variable (a prior on a landmark) -- those sort behind everything and are dropped.
+__global__ __launch_bounds__(256) void k_da_inc_keys(int64_t n_sfm, int64_t n_proj, int64_t n_btw, int64_t n_pri, const int32_t* __restrict__ sfm_cam,
+    const int32_t* __restrict__ proj_pose, const int32_t* __restrict__ bt1, const int32_t* __restrict__ bt2, const int32_t* __restrict__ pri_var,
+    const int32_t* __restrict__ red_index, uint32_t none, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b0 = n_sfm + n_proj, b1 = b0 + 2 * n_btw;
+  if (e >= b1 + n_pri) return;
+  int v;
+  if (e < n_sfm) v = sfm_cam[e];
+  else if (e < b0) v = proj_pose[e - n_sfm];
+  else if (e < b1) { const int64_t j = e - b0; v = (j & 1) ? bt2[j >> 1] : bt1[j >> 1]; }
+  else v = pri_var[e - b1];
+  const int r = red_index[v];
+  key[e] = r >= 0 ? (uint32_t)r : none;
+  val[e] = (uint32_t)e;
+}
+__global__ __launch_bounds__(256) void k_da_inc_decode(int64_t n, int64_t n_sfm, int64_t n_proj, int64_t n_btw, const uint32_t* __restrict__ seq,
+                                                       int32_t* __restrict__ kind, int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t e = seq[i], b0 = n_sfm + n_proj, b1 = b0 + 2 * n_btw;
+  if (e < n_sfm) { kind[i] = 0; idx[i] = (int32_t)e; }
+  else if (e < b0) { kind[i] = 1; idx[i] = (int32_t)(e - n_sfm); }
+  else if (e < b1) { const int64_t j = e - b0; kind[i] = 2 + (int)(j & 1); idx[i] = (int32_t)(j >> 1); }
+  else { kind[i] = 4; idx[i] = (int32_t)(e - b1); }
+}
+// CSR offsets of a sorted key array: ptr[g] = first position whose key is >= g, g = 0 .. n_groups
+__global__ __launch_bounds__(256) void k_da_offsets(int64_t n, const uint32_t* __restrict__ sorted, int n_groups, int64_t* __restrict__ ptr) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n_groups) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted[mid] < (uint32_t)g) lo = mid + 1; else hi = mid; }
+  ptr[g] = lo;
+}
+__global__ __launch_bounds__(256) void k_da_u32_to_i32(int64_t n, const uint32_t* __restrict__ a, int32_t* __restrict__ b) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = (int32_t)a[i];
+}
+
 inline void hc(hipError_t e, const char* what) { check_hip(e, what); }
 
 }  // namespace
@@ -86,11 +148,10 @@ inline void hc(hipError_t e, const char* what) { check_hip(e, what); }
 // Fills c.pair_oa / c.pair_ob / c.pair_ptr (device, final buffers) from the landmark -> observation lists (already uploaded to
 // c.lm_obs_ptr / c.lm_obs) and the positions of the observations' cameras; returns the unique block keys (row position * nrv +
 // column position, ascending) and the term offsets of the blocks to the host.
-void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int nrv, std::vector<uint64_t>& block_keys,
+void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys,
                         std::vector<int64_t>& block_ptr) {
   hipStream_t s = c.stream;
   const int n_lm = c.n_lm;
-  DevBuf<int32_t> d_pos; d_pos.upload(obs_pos.data(), obs_pos.size(), s);
   DevBuf<int64_t> d_cnt, d_off; d_cnt.alloc((size_t)n_lm + 1); d_off.alloc((size_t)n_lm + 1);
   size_t tmp_bytes = 0, need = 0; void* tmp = nullptr;
   auto ensure = [&](size_t n) { if (n > tmp_bytes) { if (tmp) (void)hipFree(tmp); hc(hipMalloc(&tmp, n), "hipMalloc"); tmp_bytes = n; } };
@@ -149,6 +210,69 @@ void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int
   d_pos.free(); d_cnt.free(); d_off.free();
   if (tmp) (void)hipFree(tmp);
   (void)hipFree(pool);
+}
+
+// The incidence lists of the analysis, on the device (see the file header).  In: the factor tables (c.f.*), c.var_type; up: the
+// variable -> landmark / reduced index maps and the positions of the reduced variables.  Out: c.obs_red, c.obs_lm, c.lm_obs_ptr,
+// c.lm_obs, c.red_inc_ptr / kind / idx, and d_pos (observation -> position of its camera) for device_schur_terms.
+// Throws std::invalid_argument for factor keys of the wrong variable type, with the host pass's messages.
+void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos, DevBuf<int32_t>& d_pos) {
+  hipStream_t s = c.stream;
+  auto& f = c.f;
+  const int64_t n_sfm = f.n_sfm, n_proj = f.n_proj, n_btw = f.n_between, n_pri = f.n_prior, n_obs = n_sfm + n_proj;
+  const int n_lm = c.n_lm, nrv = c.n_red_vars;
+  const int64_t M = n_obs + 2 * n_btw + n_pri;
+  if (n_obs >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 31)) throw std::runtime_error("device analysis: too many factors");
+  c.lm_index.upload(c.h_lm_index.data(), c.h_lm_index.size(), s); c.red_index.upload(c.h_red_index.data(), c.h_red_index.size(), s);
+  DevBuf<int32_t> d_red_pos; d_red_pos.upload(red_pos.data(), red_pos.size(), s);
+  c.obs_red.alloc((size_t)std::max<int64_t>(n_obs, 1)); c.obs_lm.alloc((size_t)std::max<int64_t>(n_obs, 1)); d_pos.alloc((size_t)std::max<int64_t>(n_obs, 1));
+  c.lm_obs_ptr.alloc((size_t)n_lm + 1); c.lm_obs.alloc((size_t)std::max<int64_t>(n_obs, 1));
+  c.red_inc_ptr.alloc((size_t)nrv + 1);
+  auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+  const size_t N = (size_t)std::max<int64_t>(M, 1);
+  int bits_lm = 1, bits_red = 1;
+  while (((uint64_t)1 << bits_lm) < (uint64_t)n_lm + 1) bits_lm++;
+  while (((uint64_t)1 << bits_red) < (uint64_t)nrv + 2) bits_red++;
+  size_t need_a = 0, need_b = 0;
+  hc(rocprim::radix_sort_pairs(nullptr, need_a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)std::max<int64_t>(n_obs, 1), 0u, (unsigned)bits_lm, s), "sort");
+  hc(rocprim::radix_sort_pairs(nullptr, need_b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, N, 0u, (unsigned)bits_red, s), "sort");
+  const size_t need_tmp = std::max(need_a, need_b);
+  char* pool = nullptr;
+  hc(hipMalloc(reinterpret_cast<void**>(&pool), 4 * al(4 * N) + al(16) + al(need_tmp)), "hipMalloc");
+  size_t at = 0;
+  auto take = [&](size_t nbytes) { char* q = pool + at; at += al(nbytes); return q; };
+  uint32_t* key = reinterpret_cast<uint32_t*>(take(4 * N)); uint32_t* key2 = reinterpret_cast<uint32_t*>(take(4 * N));
+  uint32_t* val = reinterpret_cast<uint32_t*>(take(4 * N)); uint32_t* val2 = reinterpret_cast<uint32_t*>(take(4 * N));
+  int32_t* bad = reinterpret_cast<int32_t*>(take(16));
+  void* tmp = take(need_tmp);
+  hc(hipMemsetAsync(bad, 0, 16, s), "memset");
+  auto grid = [](int64_t n) { return dim3((unsigned)((std::max<int64_t>(n, 1) + 255) / 256)); };
+  size_t need;
+  if (n_obs) {
+    hipLaunchKernelGGL(k_da_obs, grid(n_obs), dim3(256), 0, s, n_sfm, n_proj, f.sfm_cam.p, f.sfm_point.p, f.proj_pose.p, f.proj_point.p, c.var_type.p,
+                       c.red_index.p, c.lm_index.p, d_red_pos.p, c.obs_red.p, c.obs_lm.p, d_pos.p, key, val, bad);
+    need = need_tmp; hc(rocprim::radix_sort_pairs(tmp, need, key, key2, val, val2, (size_t)n_obs, 0u, (unsigned)bits_lm, s), "sort");
+    hipLaunchKernelGGL(k_da_u32_to_i32, grid(n_obs), dim3(256), 0, s, n_obs, val2, c.lm_obs.p);
+  }
+  hipLaunchKernelGGL(k_da_offsets, grid(n_lm + 1), dim3(256), 0, s, n_obs, key2, n_lm, c.lm_obs_ptr.p);
+  int32_t h_bad = 0;
+  hc(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
+  hipLaunchKernelGGL(k_da_inc_keys, grid(M), dim3(256), 0, s, n_sfm, n_proj, n_btw, n_pri, f.sfm_cam.p, f.proj_pose.p, f.between_v1.p, f.between_v2.p,
+                     f.prior_var.p, c.red_index.p, (uint32_t)nrv, key, val);
+  need = need_tmp; hc(rocprim::radix_sort_pairs(tmp, need, key, key2, val, val2, (size_t)M, 0u, (unsigned)bits_red, s), "sort");
+  hipLaunchKernelGGL(k_da_offsets, grid(nrv + 1), dim3(256), 0, s, M, key2, nrv, c.red_inc_ptr.p);
+  int64_t n_inc = 0;
+  hc(hipMemcpyAsync(&n_inc, c.red_inc_ptr.p + nrv, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
+  hc(hipStreamSynchronize(s), "sync");
+  if (h_bad) {
+    (void)hipFree(pool); d_red_pos.free();
+    throw std::invalid_argument(h_bad == 1 ? "GeneralSFMFactor keys must be (SFM_CAMERA, POINT3)" : "GenericProjectionFactor keys must be (POSE3, POINT3)");
+  }
+  c.red_inc_kind.alloc((size_t)std::max<int64_t>(n_inc, 1)); c.red_inc_idx.alloc((size_t)std::max<int64_t>(n_inc, 1));
+  hipLaunchKernelGGL(k_da_inc_decode, grid(n_inc), dim3(256), 0, s, n_inc, n_sfm, n_proj, n_btw, val2, c.red_inc_kind.p, c.red_inc_idx.p);
+  hc(hipStreamSynchronize(s), "sync");
+  (void)hipFree(pool);
+  d_red_pos.free();
 }
 
 // After the ordering: blocks whose row variable is now placed EARLIER than their column variable change orientation.

@@ -34,7 +34,8 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 int64_t exchange_block_doubles(const gtg_context& c);                    // size of the block-granular exchange buffer
 void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack);
 // device_analysis.hip: the Schur term lists built on the device (single shard, real runtime)
-void device_schur_terms(gtg_context& c, const std::vector<int32_t>& obs_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
+void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos, gt::DevBuf<int32_t>& d_pos);
+void device_schur_terms(gtg_context& c, gt::DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
 void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
 // smart factors (SmartProjectionFactor): triangulation of the hidden landmarks from the cameras in `values` (gated: only when the
 // linear cost change of the current try is >= 0), Schur-complement correction of the Hessian diagonal, constant of linear.error

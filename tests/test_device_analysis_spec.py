@@ -95,3 +95,53 @@ def test_sort_based_formulation_reproduces_the_host_lists(workload):
     assert (oa.nbytes, _fnv(oa)) in have, "pair_oa differs"
     assert (ob.nbytes, _fnv(ob)) in have, "pair_ob differs"
     assert (ptr.nbytes, _fnv(ptr)) in have, "pair_ptr differs"
+
+
+def _sort_based_incidence_lists(problem):
+    """device_analysis.hip::device_incidence_lists in numpy: per observation (reduced index, landmark), the landmark -> observation
+    lists by a STABLE sort of the observations by landmark + offsets by binary search in the sorted keys, and the reduced
+    variable -> factor lists by a stable sort of one entry per (factor, key) -- numbered GeneralSFM observations, projection
+    observations, between factors (factor i: first key, then second key), priors -- by reduced index (keys that are not reduced
+    variables sort behind everything and are dropped)."""
+    VAR_POINT3 = 2
+    red_vars = np.where(problem.var_type != VAR_POINT3)[0]; lm_vars = np.where(problem.var_type == VAR_POINT3)[0]
+    red_index = -np.ones(problem.n_vars, np.int64); red_index[red_vars] = np.arange(red_vars.size)
+    lm_index = -np.ones(problem.n_vars, np.int64); lm_index[lm_vars] = np.arange(lm_vars.size)
+    cam = np.concatenate([problem.sfm_cam, problem.proj_pose]).astype(np.int64)
+    pt = np.concatenate([problem.sfm_point, problem.proj_point]).astype(np.int64)
+    obs_red = red_index[cam].astype(np.int32); obs_lm = lm_index[pt].astype(np.int32)
+    order = np.argsort(obs_lm, kind="stable")
+    lm_obs = order.astype(np.int32)
+    lm_obs_ptr = np.searchsorted(obs_lm[order], np.arange(lm_vars.size + 1), side="left").astype(np.int64)
+    n_sfm, n_proj, n_btw, n_pri = problem.n_sfm, problem.n_proj, problem.n_between, problem.n_prior
+    bt = np.stack([problem.between_v1, problem.between_v2], 1).reshape(-1).astype(np.int64)       # factor i: v1, v2
+    v = np.concatenate([problem.sfm_cam.astype(np.int64), problem.proj_pose.astype(np.int64), bt, problem.prior_var.astype(np.int64)])
+    key = red_index[v]; key = np.where(key >= 0, key, red_vars.size)
+    srt = np.argsort(key, kind="stable")
+    inc_ptr = np.searchsorted(key[srt], np.arange(red_vars.size + 1), side="left").astype(np.int64)
+    seq = srt[:inc_ptr[-1]]
+    b0, b1 = n_sfm + n_proj, n_sfm + n_proj + 2 * n_btw
+    kind = np.where(seq < n_sfm, 0, np.where(seq < b0, 1, np.where(seq < b1, 2 + ((seq - b0) & 1), 4))).astype(np.int32)
+    idx = np.where(seq < n_sfm, seq, np.where(seq < b0, seq - n_sfm, np.where(seq < b1, (seq - b0) >> 1, seq - b1))).astype(np.int32)
+    return obs_red, obs_lm, lm_obs_ptr, lm_obs, inc_ptr, kind, idx
+
+
+@pytest.mark.parametrize("workload", ["bal:60:6000:7", "baldup:40:3000:3", "dubrovnik_3_7", "smart:smart_far_infinity"])
+def test_sort_based_incidence_lists_reproduce_the_host_lists(workload):
+    """The same for the incidence lists the device pass builds in front of the term lists (landmark -> observations, reduced
+    variable -> factors): the sort-based formulation against the lists the host's counting sorts upload."""
+    if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
+        pytest.skip("libgtsam_amd.so not built")
+    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_NO_REORDER": "1"})
+    have = {(int(n), int(h)) for n, h in recs}
+    problem, _ = HP.problem_for(workload)
+    if workload.startswith("smart:"):          # the library's own view of a smart graph: hidden landmarks, measurements as observations
+        from gtsam_amd.problem import Problem
+        q = Problem(var_type=np.concatenate([problem.var_type, np.full(problem.n_smart, 2, np.int32)]))
+        q.sfm_cam = problem.smart_cam.copy()
+        q.sfm_point = (problem.n_vars + np.repeat(np.arange(problem.n_smart), np.diff(problem.smart_ptr))).astype(np.int32)
+        q.prior_var = problem.prior_var.copy()
+        problem = q
+    names = ("obs_red", "obs_lm", "lm_obs_ptr", "lm_obs", "red_inc_ptr", "red_inc_kind", "red_inc_idx")
+    for name, a in zip(names, _sort_based_incidence_lists(problem)):
+        assert (a.nbytes, _fnv(a)) in have, name + " differs"

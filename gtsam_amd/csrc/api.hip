@@ -31,18 +31,67 @@ void check_hip(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// The big buffers of a handle (the reduced system: 1.9 GB on the L1723 shape, 31 GB on w20000; the E slots; the Jacobian records;
+// the term lists) are kept for the next handle of the process when one is released instead of going back to the driver: on boxes
+// where the driver clears device memory as it hands it out a fresh hipMalloc costs ~30 ms per GB (the L1723 set-up 17 -> 91 ms,
+// w20000 15 -> 860 ms, measured), and programs construct optimizers one after the other (GncOptimizer: one per outer iteration).
+// Only blocks of >= 32 MB are kept, at most GTG_ALLOC_CACHE_MB (default 8192, 0 = off) in total per process; a kept block serves a
+// request of 80 - 100 % of its size on the same device.  Every such buffer is fully written by the kernels before it is read (the
+// reduced system: its stored tiles are zeroed at the start of every lambda try), so recycled contents are never observed.
+namespace {
+struct KeptBlock { void* p; size_t bytes; int device; };
+std::mutex g_kept_mu;
+std::vector<KeptBlock> g_kept;
+size_t g_kept_bytes = 0;
+constexpr size_t kKeepMin = (size_t)32 << 20;
+size_t keep_limit() {
+  static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 8192L) << 20; }();
+  return lim;
+}
+void* take_kept(size_t bytes, size_t* got) {
+  if (bytes < kKeepMin || keep_limit() == 0) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_kept_mu);
+  int best = -1;
+  for (int i = 0; i < (int)g_kept.size(); i++)
+    if (g_kept[i].device == dev && g_kept[i].bytes >= bytes && g_kept[i].bytes - bytes <= g_kept[i].bytes / 5 &&
+        (best < 0 || g_kept[i].bytes < g_kept[best].bytes)) best = i;
+  if (best < 0) return nullptr;
+  void* q = g_kept[best].p;
+  *got = g_kept[best].bytes;
+  g_kept_bytes -= g_kept[best].bytes;
+  g_kept.erase(g_kept.begin() + best);
+  return q;
+}
+bool keep_block(void* q, size_t bytes) {        // (hipFree synchronises the device; a kept block must be idle as well)
+  if (bytes < kKeepMin || keep_limit() == 0) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(g_kept_mu);
+  if (g_kept_bytes + bytes > keep_limit()) return false;
+  if (hipDeviceSynchronize() != hipSuccess) return false;
+  g_kept.push_back(KeptBlock{q, bytes, dev});
+  g_kept_bytes += bytes;
+  return true;
+}
+}  // namespace
+
 template <class T> void DevBuf<T>::alloc(size_t count) {
   free();
   n = count;
-  if (count) check_hip(hipMalloc(&p, sizeof(T) * count), "hipMalloc");
+  if (!count) return;
+  if (void* q = take_kept(sizeof(T) * count, &cap)) { p = static_cast<T*>(q); return; }
+  check_hip(hipMalloc(&p, sizeof(T) * count), "hipMalloc");
+  cap = sizeof(T) * count;
 }
 template <class T> void DevBuf<T>::upload(const T* host, size_t count, hipStream_t s) {
   if (count != n || (count && !p)) alloc(count);
   if (count) check_hip(hipMemcpyAsync(p, host, sizeof(T) * count, hipMemcpyHostToDevice, s), "H2D");
 }
 template <class T> void DevBuf<T>::free() {
-  if (p) (void)hipFree(p);
-  p = nullptr; n = 0;
+  if (p && !keep_block(p, cap ? cap : sizeof(T) * n)) (void)hipFree(p);
+  p = nullptr; n = 0; cap = 0;
 }
 template struct DevBuf<double>;
 template struct DevBuf<int32_t>;

@@ -35,6 +35,7 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap = 0;                               // bytes of the allocation behind p (>= n elements: api.hip keeps and re-issues big blocks)
   void alloc(size_t count);
   void upload(const T* host, size_t count, hipStream_t s);
   void free();

@@ -83,6 +83,7 @@ struct GpuLevenbergMarquardtOptimizer::Impl {
   std::vector<int32_t> var_type;
   std::vector<int64_t> val_off;
   std::vector<double> packed;            // host copy of the packed values
+  Values scratch;                        // this object's own Values (same keys as the state's): payloads overwritten in place by syncValuesToHost
   std::vector<std::pair<int32_t, int64_t>> fac_map;   // factor of graph_ -> (GTG_FAC_*, index in that type's table); (-1, 0): null
   std::vector<int64_t> dim_off;          // variable id -> offset in the tangent vector (delta)
   bool keep_linearization = false;       // iterate(): download the records right after gtg_linearize
@@ -187,8 +188,7 @@ GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFa
                                                                const LevenbergMarquardtParams& params, int device,
                                                                const ShardSpec& shards)
     : LevenbergMarquardtOptimizer(NonlinearFactorGraph(), Values(), withOrdering(params, initial, nullptr)), impl_(new Impl) {
-  graph_ = graph;
-  init(initial, device, shards);
+  init(graph, initial, device, shards);
 }
 
 GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFactorGraph& graph, const Values& initial,
@@ -196,8 +196,7 @@ GpuLevenbergMarquardtOptimizer::GpuLevenbergMarquardtOptimizer(const NonlinearFa
                                                                const LevenbergMarquardtParams& params, int device,
                                                                const ShardSpec& shards)
     : LevenbergMarquardtOptimizer(NonlinearFactorGraph(), Values(), withOrdering(params, initial, &ordering)), impl_(new Impl) {
-  graph_ = graph;
-  init(initial, device, shards);
+  init(graph, initial, device, shards);
 }
 
 GpuLevenbergMarquardtOptimizer::~GpuLevenbergMarquardtOptimizer() = default;
@@ -220,7 +219,7 @@ struct Extract {
 };
 }  // namespace
 
-void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, const ShardSpec& shards) {
+void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, const Values& initial, int device, const ShardSpec& shards) {
   Impl& m = *impl_;
   const bool timing = std::getenv("GTG_DEBUG_TIMING") != nullptr;   // host-side breakdown of the construction on stderr
   auto tprev = std::chrono::high_resolution_clock::now();
@@ -230,10 +229,14 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
     std::fprintf(stderr, "[gtsam_amd shim ] %-46s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
     tprev = now;
   };
-  // the state's deep copy of the caller's Values (one heap object per variable) runs beside the extraction
-  Values stateValues;
+  // Two copies the optimizer owes its base class run beside the extraction, which reads the CALLER's graph meanwhile:
+  //  - graph_ (NonlinearOptimizer.h:78): one shared-pointer copy per factor -- 18 ms for the 0.68 M factors of the L1723 shape;
+  //  - a deep copy of the caller's Values (one heap object per variable).  It stays in the Impl: values() needs a Values object
+  //    inside a State, and BOTH constructors of LevenbergMarquardtState deep-copy what they are given (the Values&& one passes
+  //    its argument on as an lvalue, LevenbergMarquardtState.h:61-63), so the cheapest way to a current State is to overwrite the
+  //    payloads of this copy in place (syncValuesToHost) and let the constructor copy it.
   std::exception_ptr copyErr;
-  std::thread copier([&] { try { stateValues = initial; } catch (...) { copyErr = std::current_exception(); } });
+  std::thread copier([&] { try { graph_ = graph; m.scratch = initial; } catch (...) { copyErr = std::current_exception(); } });
   struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } joinCopier{copier};
 
   // ---- variables: Values order (sorted by Key, Values.h:74-79); one pass, packed as they are classified ---------------
@@ -259,7 +262,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   lap("variables: classify + pack");
 
   // ---- factors: dynamic_cast to the supported types (anything else is a hard error), on host threads ------------------
-  const size_t nfac = graph_.size();
+  const size_t nfac = graph.size();
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const char* thr_env = std::getenv("GTG_HOST_THREADS");
   const size_t grain = std::getenv("GTG_EXTRACT_GRAIN") ? std::max(1, std::atoi(std::getenv("GTG_EXTRACT_GRAIN"))) : 4096;   // factors per thread at least (tests: 1)
@@ -273,7 +276,7 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
     size_t i = b;
     try {
       for (; i < e; i++) {
-        const auto& f = graph_[i];
+        const auto& f = graph[i];
         if (!f) { x.fac_map.emplace_back(-1, 0); continue; }
         if (auto s = dynamic_cast<const SfmFactor*>(f.get())) {
           x.fac_map.emplace_back(GTG_FAC_GENERAL_SFM, (int64_t)x.sfm_cam.size());
@@ -452,26 +455,31 @@ void GpuLevenbergMarquardtOptimizer::init(const Values& initial, int device, con
   check(gtg_error(m.h, &e0), "gtg_error");
   lap("device: initial error");
   copier.join();
-  lap("wait for the copy of the Values");
+  lap("wait for the copies of the graph and the Values");
   if (copyErr) std::rethrow_exception(copyErr);
-  state_.reset(new State(std::move(stateValues), e0, params_.lambdaInitial, params_.lambdaFactor));
+  state_.reset(new State(m.scratch, e0, params_.lambdaInitial, params_.lambdaFactor));
   const State* s = static_cast<const State*>(state_.get());
   m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;
+  lap("state");
 }
 
 void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
   Impl& m = *impl_;
   if (!m.host_values_stale && !force) return;
   check(gtg_get_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_get_values");
-  Values vals;
-  for (size_t v = 0; v < m.keys.size(); v++) {
+  // overwrite the payloads of the Impl's own copy in place (same keys, same order: both sorted by Key; the GenericValue objects
+  // are this object's, reached through Values' const iteration), then let the State's constructor copy it (see init)
+  size_t v = 0;
+  for (const auto& kv : m.scratch) {
     const double* p = m.packed.data() + m.val_off[v];
-    if (m.var_type[v] == GTG_VAR_POSE3) vals.insert(m.keys[v], unpackPose(p));
-    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) vals.insert(m.keys[v], SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16])));
-    else if (m.var_type[v] == GTG_VAR_POSE2) vals.insert(m.keys[v], Pose2(p[0], p[1], p[2]));
-    else vals.insert(m.keys[v], Point3(p[0], p[1], p[2]));
+    Value& val = const_cast<Value&>(kv.value);
+    if (m.var_type[v] == GTG_VAR_POINT3) static_cast<GenericValue<Point3>&>(val).value() = Point3(p[0], p[1], p[2]);
+    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) static_cast<GenericValue<SfmCamera>&>(val).value() = SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16]));
+    else if (m.var_type[v] == GTG_VAR_POSE3) static_cast<GenericValue<Pose3>&>(val).value() = unpackPose(p);
+    else static_cast<GenericValue<Pose2>&>(val).value() = Pose2(p[0], p[1], p[2]);
+    v++;
   }
-  state_.reset(new State(std::move(vals), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
+  state_.reset(new State(m.scratch, m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
   m.host_values_stale = false;
 }
 

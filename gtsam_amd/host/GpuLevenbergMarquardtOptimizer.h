@@ -67,7 +67,7 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
-  void init(const gtsam::Values& initial, int device, const ShardSpec& shards);
+  void init(const gtsam::NonlinearFactorGraph& graph, const gtsam::Values& initial, int device, const ShardSpec& shards);
   bool tryLambdaDevice();            // LevenbergMarquardtOptimizer::tryLambda restated
   void iterateDevice();              // LevenbergMarquardtOptimizer::iterate restated (logFile rows, SUMMARY header)
   void writeLogFileDevice(double currentError);

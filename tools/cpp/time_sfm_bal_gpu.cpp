@@ -52,14 +52,22 @@ int main(int argc, char* argv[]) {
   for (size_t ii = 0; ii < db.numberCameras(); ii++) ordering.push_back(C(ii));
   params.setOrdering(ordering);
   const auto t2 = std::chrono::high_resolution_clock::now();
-  gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial, params);   // initial error (host, as the reference), extraction, analysis, upload
-  const auto t3 = std::chrono::high_resolution_clock::now();
-  const double e0 = lm.error();
-  const Values result = lm.optimize();
-  const auto t4 = std::chrono::high_resolution_clock::now();
-  const double hostError = graph.error(result);
+  // (the first optimizer lives in its own scope, as in a program that optimises one problem after the other: its device buffers are
+  // released before the second one is constructed)
+  std::chrono::high_resolution_clock::time_point t3, t4;
+  double e0, lmError, hostError; size_t lmIterations; int lmInner;
+  {
+    gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial, params);   // extraction, analysis, upload, initial error (device)
+    t3 = std::chrono::high_resolution_clock::now();
+    e0 = lm.error();
+    const Values result = lm.optimize();
+    t4 = std::chrono::high_resolution_clock::now();
+    hostError = graph.error(result);
+    lmError = lm.error(); lmIterations = lm.iterations(); lmInner = lm.getInnerIterations();
+  }
   // the same once more in this process: the first run above also paid for the first use of the device (code object load, stream
-  // and event creation, first-touch of the host scratch) -- a program that optimises more than once pays the second figure
+  // and event creation, first-touch of the host scratch, device memory from the driver) -- a program that optimises more than once
+  // pays the second figure
   const auto w0 = std::chrono::high_resolution_clock::now();
   gtsam_amd::GpuLevenbergMarquardtOptimizer lm2(graph, initial, params);
   const auto w1 = std::chrono::high_resolution_clock::now();
@@ -82,9 +90,9 @@ int main(int argc, char* argv[]) {
               "\"iterations_per_s_with_construction\": %.2f, \"initial_error\": %.9g, \"final_error\": %.12g, \"final_error_recomputed_on_host\": %.12g, "
               "\"second_run_construct_ms\": %.1f, \"second_run_optimize_ms\": %.1f, \"second_run_iterations_per_s_optimize_only\": %.2f, "
               "\"second_run_iterations_per_s_with_construction\": %.2f, \"second_run_device_phase_ms\": %.1f, \"cpu_reference_ms_per_iteration\": %.1f, \"cpu_reference_iterations\": %d, \"cpu_reference_error_after\": %.9g}\n",
-              db.numberCameras(), db.numberTracks(), graph.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), lm.iterations(),
-              lm.getInnerIterations(), ms(t3, t4) / std::max<size_t>(lm.iterations(), 1), 1e3 * lm.iterations() / ms(t3, t4),
-              1e3 * lm.iterations() / ms(t2, t4), e0, lm.error(), hostError, ms(w0, w1), ms(w1, w2), 1e3 * lm2.iterations() / ms(w1, w2),
+              db.numberCameras(), db.numberTracks(), graph.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), lmIterations,
+              lmInner, ms(t3, t4) / std::max<size_t>(lmIterations, 1), 1e3 * lmIterations / ms(t3, t4),
+              1e3 * lmIterations / ms(t2, t4), e0, lmError, hostError, ms(w0, w1), ms(w1, w2), 1e3 * lm2.iterations() / ms(w1, w2),
               1e3 * lm2.iterations() / ms(w0, w2), deviceMs, cpuMsPerIteration, cpuIterations, cpuError);
-  return std::abs(hostError - lm.error()) <= 1e-9 * std::abs(hostError) ? 0 : 1;
+  return std::abs(hostError - lmError) <= 1e-9 * std::abs(hostError) ? 0 : 1;
 }

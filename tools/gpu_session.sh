@@ -1,5 +1,6 @@
 out=gpurun_out/$1; mkdir -p $out
 {
-echo "== device analysis A/B + parity"; timeout 900 python -m pytest tests/test_gpu_device_analysis.py tests/test_gpu_parity.py tests/test_gpu_smart_factors.py -q -x 2>&1 | tail -12
-echo "== bench"; GTG_DEBUG_TIMING=1 timeout 600 python bench.py --cpu-baseline off --skip-dense-roofline 2>&1 | grep -v "amdgpu" | grep "setup\]\|metric" | cut -c1-900 | tail -40
-} > $out/log.txt 2>&1
+echo "== full gpu suite"; timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -15
+} > $out/gpu_tests.log 2>&1
+timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+tail -3 $out/gpu_tests.log; tail -c 600 $out/bench.json

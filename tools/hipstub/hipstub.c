@@ -166,5 +166,6 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { trace(OP_RECORD, s, e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double*)b - *(double*)a); return 0; }
 hipError_t hipEventSynchronize(hipEvent_t e) { (void)e; return 0; }
 hipError_t hipDeviceSynchronize(void) { return 0; }
+hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 int hipstub_kernel_count(void) { return g_nfn; }
 const char* hipstub_kernel_at(int i, const void** host) { *host = g_fn[i].host; return g_fn[i].name; }

@@ -35,7 +35,7 @@ void check_hip(hipError_t e, const char* what) {
 // the term lists) are kept for the next handle of the process when one is released instead of going back to the driver: on boxes
 // where the driver clears device memory as it hands it out a fresh hipMalloc costs ~30 ms per GB (the L1723 set-up 17 -> 91 ms,
 // w20000 15 -> 860 ms, measured), and programs construct optimizers one after the other (GncOptimizer: one per outer iteration).
-// Only blocks of >= 32 MB are kept, at most GTG_ALLOC_CACHE_MB (default 8192, 0 = off) in total per process; a kept block serves a
+// Only blocks of >= 16 MB are kept, at most GTG_ALLOC_CACHE_MB (default 8192, 0 = off) in total per process; a kept block serves a
 // request of 80 - 100 % of its size on the same device.  Every such buffer is fully written by the kernels before it is read (the
 // reduced system: its stored tiles are zeroed at the start of every lambda try), so recycled contents are never observed.
 namespace {
@@ -43,7 +43,7 @@ struct KeptBlock { void* p; size_t bytes; int device; };
 std::mutex g_kept_mu;
 std::vector<KeptBlock> g_kept;
 size_t g_kept_bytes = 0;
-constexpr size_t kKeepMin = (size_t)32 << 20;
+constexpr size_t kKeepMin = (size_t)16 << 20;
 size_t keep_limit() {
   static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 8192L) << 20; }();
   return lim;

@@ -180,8 +180,8 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   hc(rocprim::exclusive_scan(nullptr, need_scan, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)total + 1, rocprim::plus<int64_t>(), s), "scan");
   const size_t need_tmp = std::max(need_sort, std::max(need_rle, need_scan));
   const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(4 * (N + 1)) + al(8 * (N + 1)) + al(16) + al(need_tmp);
-  char* pool = nullptr;
-  hc(hipMalloc(reinterpret_cast<void**>(&pool), bytes), "hipMalloc");
+  DevBuf<unsigned char> pool_buf; pool_buf.alloc(bytes);     // (through DevBuf: a block of this size is kept for the next handle, api.hip)
+  char* pool = reinterpret_cast<char*>(pool_buf.p);
   size_t at = 0;
   auto take = [&](size_t nbytes) { char* q = pool + at; at += al(nbytes); return q; };
   uint64_t* key = reinterpret_cast<uint64_t*>(take(8 * N)); uint64_t* key2 = reinterpret_cast<uint64_t*>(take(8 * N));
@@ -209,7 +209,7 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   hc(hipStreamSynchronize(s), "sync");
   d_pos.free(); d_cnt.free(); d_off.free();
   if (tmp) (void)hipFree(tmp);
-  (void)hipFree(pool);
+  pool_buf.free();
 }
 
 // The incidence lists of the analysis, on the device (see the file header).  In: the factor tables (c.f.*), c.var_type; up: the
@@ -237,8 +237,8 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   hc(rocprim::radix_sort_pairs(nullptr, need_a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)std::max<int64_t>(n_obs, 1), 0u, (unsigned)bits_lm, s), "sort");
   hc(rocprim::radix_sort_pairs(nullptr, need_b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, N, 0u, (unsigned)bits_red, s), "sort");
   const size_t need_tmp = std::max(need_a, need_b);
-  char* pool = nullptr;
-  hc(hipMalloc(reinterpret_cast<void**>(&pool), 4 * al(4 * N) + al(16) + al(need_tmp)), "hipMalloc");
+  DevBuf<unsigned char> pool_buf; pool_buf.alloc(4 * al(4 * N) + al(16) + al(need_tmp));
+  char* pool = reinterpret_cast<char*>(pool_buf.p);
   size_t at = 0;
   auto take = [&](size_t nbytes) { char* q = pool + at; at += al(nbytes); return q; };
   uint32_t* key = reinterpret_cast<uint32_t*>(take(4 * N)); uint32_t* key2 = reinterpret_cast<uint32_t*>(take(4 * N));
@@ -265,13 +265,13 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   hc(hipMemcpyAsync(&n_inc, c.red_inc_ptr.p + nrv, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
   if (h_bad) {
-    (void)hipFree(pool); d_red_pos.free();
+    pool_buf.free(); d_red_pos.free();
     throw std::invalid_argument(h_bad == 1 ? "GeneralSFMFactor keys must be (SFM_CAMERA, POINT3)" : "GenericProjectionFactor keys must be (POSE3, POINT3)");
   }
   c.red_inc_kind.alloc((size_t)std::max<int64_t>(n_inc, 1)); c.red_inc_idx.alloc((size_t)std::max<int64_t>(n_inc, 1));
   hipLaunchKernelGGL(k_da_inc_decode, grid(n_inc), dim3(256), 0, s, n_inc, n_sfm, n_proj, n_btw, val2, c.red_inc_kind.p, c.red_inc_idx.p);
   hc(hipStreamSynchronize(s), "sync");
-  (void)hipFree(pool);
+  pool_buf.free();
   d_red_pos.free();
 }
 

@@ -246,7 +246,7 @@ print("RESULT " + json.dumps(out))
 
 
 def test_big_device_blocks_are_kept_for_the_next_handle(stub):
-    """api.hip keeps released device blocks of >= 32 MB for the next handle of the process (bounded by GTG_ALLOC_CACHE_MB): the
+    """api.hip keeps released device blocks of >= 16 MB for the next handle of the process (bounded by GTG_ALLOC_CACHE_MB): the
     second construction of the same problem asks the runtime for less memory by at least the reduced system's size, unless the
     cache is switched off; a block is only re-issued for a request of 80 - 100 % of its size."""
     code = '''

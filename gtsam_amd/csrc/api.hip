@@ -291,10 +291,10 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
       if (k1 <= k0 || k1 > n_meas) throw std::invalid_argument("smart factor without measurements / bad smart_ptr");
       const double* sp = p_user->smart_params + 8 * i;
       if (!(sp[4] == 0.0 || sp[4] == 1.0 || sp[4] == 2.0)) throw std::invalid_argument("smart factor: unknown degeneracy mode");
+      if (!(sp[6] == 0.0 || sp[6] == 1.0)) throw std::invalid_argument("smart factor: enableEPI must be 0 or 1");
       // LinearizationMode (SmartFactorParams.h:31-33): HESSIAN, JACOBIAN_Q, JACOBIAN_SVD give the same normal equations (they differ in
       // what a failed track contributes and in the constant of the linear error); IMPLICIT_SCHUR factors cannot be eliminated by
       // the reference's direct solvers at all (RegularImplicitSchurFactor has no augmentedJacobian / augmentedInformation)
-      if (!(sp[6] == 0.0 || sp[6] == 1.0)) throw std::invalid_argument("smart factor: enableEPI must be 0 or 1");
       if (!(sp[5] == 0.0 || sp[5] == 2.0 || sp[5] == 3.0)) throw std::invalid_argument("smart factor: linearization mode must be 0 HESSIAN, 2 JACOBIAN_Q or 3 JACOBIAN_SVD");
       // rankTolerance, landmarkDistanceThreshold, dynamicOutlierRejectionThreshold (negative = off, as in the reference),
       // retriangulationThreshold: numbers, not NaN / inf (a NaN threshold silently disables the test it guards)

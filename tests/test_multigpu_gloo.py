@@ -126,3 +126,42 @@ def test_shard_filter_partitions_every_factor_exactly_once():
     assert sum(q.n_sfm for q in parts) == p.n_sfm and sum(q.n_prior for q in parts) == p.n_prior
     # a landmark's observations never straddle shards
     assert set(np.unique(parts[0].sfm_point)).isdisjoint(set(np.unique(parts[1].sfm_point)))
+
+
+def shard_smart_problem(p: Problem, shard: int, n: int) -> Problem:
+    """gtg_upload_problem's rule for smart factors: factor i follows its hidden landmark, the (user landmarks + i)-th POINT3
+    variable, to shard (rank % n); the other factors as in shard_problem."""
+    q = shard_problem(p, shard, n)
+    n_user_lm = int((p.var_type == VAR_POINT3).sum())
+    for i in range(p.n_smart):
+        if (n_user_lm + i) % n != shard:
+            continue
+        k0, k1 = int(p.smart_ptr[i]), int(p.smart_ptr[i + 1])
+        prm = p.smart_params.reshape(-1, 8)[i]
+        q.add_smart(p.smart_cam[k0:k1], p.smart_z.reshape(-1, 2)[k0:k1], int(p.smart_noise[i]), prm[0], prm[1], prm[2], prm[3], int(prm[4]),
+                    int(prm[5]), bool(prm[6]))
+    return q
+
+
+@pytest.mark.parametrize("name", ["smart_orbit_degenerate", "smart_far_infinity", "smart_far_jacobian_svd"])
+def test_sharded_smart_graph_sums_to_the_whole(name):
+    """The algebra the sharded smart path relies on (tests/test_gpu_sharding.py runs it on the device): every smart factor lives on
+    exactly one shard, and error, Hessian diagonal (of the Schur-complemented factors), the reduced system of the cameras and both
+    linear errors of a step are the SUMS over the shards of what each shard's factors give -- the exchanges that exist for
+    explicit landmarks carry them.  Oracle only."""
+    from oracle import gtsam_oracle as O
+    p, v0 = PB.SMART[name]()
+    for n in (2, 3):
+        parts = [shard_smart_problem(p, r, n) for r in range(n)]
+        assert sum(q.n_smart for q in parts) == p.n_smart and sum(q.n_prior for q in parts) == p.n_prior
+        assert abs(sum(O.error(q, v0) for q in parts) - O.error(p, v0)) <= 1e-12 * O.error(p, v0)
+        hd = sum(O.hessian_diagonal(q, v0) for q in parts)
+        assert np.abs(hd - O.hessian_diagonal(p, v0)).max() <= 1e-12 * np.abs(hd).max()
+        H = sum(O.hessian_dense(q, v0)[0] for q in parts); g = sum(O.hessian_dense(q, v0)[1] for q in parts)
+        Hw, gw, _ = O.hessian_dense(p, v0)
+        assert np.abs(H - Hw).max() <= 1e-12 * np.abs(Hw).max() and np.abs(g - gw).max() <= 1e-12 * np.abs(gw).max()
+        st, d, _, _, lin = O.solve_damped(p, v0, 1e-3, True)
+        lins = [O.solve_damped(q, v0, 1e-3, True)[4] for q in parts]          # (each shard's linearisation; the step is the whole graph's)
+        for x in (np.zeros_like(d), d):
+            whole = O.linear_error(p, lin, x)
+            assert abs(sum(O.linear_error(q, lq, x) for q, lq in zip(parts, lins)) - whole) <= 1e-11 * abs(whole)

@@ -898,6 +898,14 @@ int gtg_debug_df_chains(gtg_handle c, int64_t sizes[3], int32_t* chain_off, int3
   GTG_CATCH
 }
 
+int gtg_debug_reduced_order(gtg_handle c, int32_t* var_of_position, int32_t n) {
+  GTG_TRY
+  if (!c || !c->uploaded || !var_of_position || n != c->n_red_vars) throw std::invalid_argument("gtg_debug_reduced_order: no problem uploaded or wrong size");
+  for (int r = 0; r < c->n_red_vars; r++) var_of_position[c->h_red_pos[r]] = c->h_red_var[r];
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_debug_df_trace(gtg_handle c, int64_t* out, int64_t n) {
   GTG_TRY
   if (!c || !c->uploaded || !out || !c->df.trace.p || n != (int64_t)c->df.trace.n) throw std::invalid_argument("gtg_debug_df_trace: no trace (GTG_DF_TRACE=1 at upload) or wrong size");

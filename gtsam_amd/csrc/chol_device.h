@@ -328,14 +328,24 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, int 
 constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress word of the tile, after the operand images
 // the lower 32x32 sub-blocks of a diagonal tile -> the packed LDS image: 10 blocks x 512 16-byte pieces, 10 per lane, all
 // loads in flight before the writes (512 threads)
-__device__ __forceinline__ void diag_tile_to_lds(const double* __restrict__ tile, int NP, double* __restrict__ A, int tid) {
+// SC1: the tile was handed over by another workgroup of a running kernel (write-through stores + flag, chol_dataflow.hip): read it
+// with agent-scope (sc1) loads, which are served past this CU's L1 -- the consumer half of the hand-off (8-byte accesses: the widest
+// a relaxed agent-scope load lowers to)
+template <bool SC1 = false>
+__device__ __forceinline__ void diag_tile_to_lds(const double* tile, int NP, double* __restrict__ A, int tid) {
   double2 v[10];
 #pragma unroll
   for (int u = 0; u < 10; u++) {
     const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
     int ib = 0, rem = blk;
     while (rem > ib) { rem -= ib + 1; ib++; }
-    v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15));
+    const double* src = tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15);
+    if constexpr (SC1) {
+      v[u].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[u].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      v[u] = *reinterpret_cast<const double2*>(src);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 10; u++) {
@@ -397,10 +407,21 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       }
       store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64, wt);
     }
+    // Panel jb is released to the workgroups waiting for it (the TRSM workgroups of this launch / the substitutions of the dataflow
+    // schedule) once its inverse and every L(jb, q<jb) operand image are in memory.
+    //   plain stores (wt = false): workgroup barrier, then ONE lane's agent-scope release store (L2 write-back) of the progress word;
+    //   write-through stores (wt = true): EVERY storing wavefront waits for its own stores to be acknowledged (s_waitcnt vmcnt(0)),
+    //   then the workgroup barrier, then one lane's relaxed store of the word.  The barrier alone is NOT enough: a workgroup-scope
+    //   release does not wait for vmcnt on this target, and the word -- stored by wavefront 0 -- overtook the images of wavefront 5
+    //   and of the deferred wavefronts under uneven memory load: a substitution then read the previous factorisation's inverse
+    //   (rounds 1-3: rare last-digit differences with several handles on one device; cdna_hip_programming.md G16 pitfall 14).
+    //   For the panels 0..2 the wait is taken AFTER the updates of the next panel (P3: LDS only), so the acknowledgements arrive
+    //   under them and the pivot chain does not stall; the substitution step q only has to be done before panel q+1 is.  The last
+    //   panel's word follows its drain directly (it is the one on the serial chain of the factorisation).
+    const bool late = wt && jb < 3;
+    if (wt && !late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // panel jb is complete in global memory (its inverse, and every L(jb, q<jb) operand image): release it to the
-    // TRSM workgroups of this launch, which are waiting for exactly that to run their phase jb
-    if (tid == 0)
+    if (tid == 0 && !late)
     {
       __hip_atomic_store(pflag, flagbase + jb + 1, wt ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -410,7 +431,13 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     STAMP(3 + 3 * jb);
     // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start
     for (int t = wave; t < 4 * (3 - jb); t += 8) tile_task(A, jb, jb + 1 + (t >> 2), jb + 1, (t >> 1) & 1, t & 1, lr, lk);
+    if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tid == 0 && late)
+    {
+      __hip_atomic_store(pflag, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pflag_shadow) __hip_atomic_store(pflag + pflag_shadow, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     STAMP(4 + 3 * jb);
   }
   store_column(A, tile, NP, Xinv, 3, tid, 512, wt);

@@ -47,6 +47,9 @@ namespace gt {
 // instead of 320.  The L(p,q) / Xinv operands of a wavefront (80 doubles per lane) are fetched into registers up
 // front, in flight together with the tile load.
 constexpr int TR = 64;   // rows per TRSM workgroup
+// a dependency wait inside a launch (TRSM workgroups behind workgroup 0; the backward sweep) gives up after 100 ms of the 100 MHz constant
+// clock and raises fail[1] (SC_TIMEOUT: an error, never numbers) -- the bound used to be millions of polls, seconds per stuck wait
+constexpr long long kEventWaitTicks = 10000000;
 __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S, int NP, int k, int wg,
                                           const int32_t* __restrict__ rows, double* __restrict__ Xinv,
                                           double* __restrict__ fail, long long epoch) {
@@ -79,8 +82,10 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
     // is seconds, and running into it raises the time-out flag, which the C ABI turns into an error)
     if (tid == 0) {
       int spins = 0;
+      const long long t0 = wall_clock64();
       while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < flagbase + p + 1) {
-        if (++spins > (1 << 22)) { fail[1] = 1.0; break; }   // a scheduling problem, not a matrix property: fail[1] is reported as an error (SC_TIMEOUT), never as "not positive definite"
+        // a scheduling problem, not a matrix property: fail[1] is reported as an error (SC_TIMEOUT), never as "not positive definite"
+        if ((++spins & 255) == 0 && wall_clock64() - t0 > kEventWaitTicks) { __hip_atomic_store(fail + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         // the word stuck in this XCD's L2 with its old value (chol_dataflow.hip::st_flag): the shadow word, published behind it
         if ((spins & 1023) == 0 && __hip_atomic_load(flag + 64, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= flagbase + p + 1) break;
         __builtin_amdgcn_s_sleep(4);
@@ -862,11 +867,12 @@ __device__ __forceinline__ void sweep_wait(const double* x, int NP, int i, doubl
   if (tid < 64) {
     const unsigned long long* px = reinterpret_cast<const unsigned long long*>(x) + (int64_t)i * T + 2 * tid;
     unsigned long long a, b;
+    const long long t0 = wall_clock64();
     for (int spins = 0;; spins++) {
       a = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       b = __hip_atomic_load(px + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__all(a != kBwdUnset && b != kBwdUnset)) break;
-      if (spins > (1 << 21)) { if (tid == 0) fail[1] = 1.0; break; }
+      if ((spins & 255) == 255 && wall_clock64() - t0 > kEventWaitTicks) { if (tid == 0) __hip_atomic_store(fail + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if ((spins & 1023) == 1023) {   // the entries stuck in this XCD's L2 as unset (chol_dataflow.hip::st_flag): their shadow copies
         a = __hip_atomic_load(px + NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         b = __hip_atomic_load(px + NP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -83,7 +83,9 @@ struct GpuLevenbergMarquardtOptimizer::Impl {
   std::vector<int32_t> var_type;
   std::vector<int64_t> val_off;
   std::vector<double> packed;            // host copy of the packed values
-  Values scratch;                        // this object's own Values (same keys as the state's): payloads overwritten in place by syncValuesToHost
+  Values scratch;                        // the deep copy of the caller's Values (made beside the extraction); swapped into the State at the end of init
+  std::vector<Value*> slots;             // variable id -> the GenericValue object of that variable inside the State's Values (heap objects
+                                         // owned by the map's nodes: they stay where they are when the map is swapped into the next State)
   std::vector<std::pair<int32_t, int64_t>> fac_map;   // factor of graph_ -> (GTG_FAC_*, index in that type's table); (-1, 0): null
   std::vector<int64_t> dim_off;          // variable id -> offset in the tangent vector (delta)
   bool keep_linearization = false;       // iterate(): download the records right after gtg_linearize
@@ -457,7 +459,16 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   copier.join();
   lap("wait for the copies of the graph and the Values");
   if (copyErr) std::rethrow_exception(copyErr);
-  state_.reset(new State(m.scratch, e0, params_.lambdaInitial, params_.lambdaFactor));
+  // Both constructors of LevenbergMarquardtState deep-copy the Values they are given (the Values&& one passes its argument on as an
+  // lvalue, LevenbergMarquardtState.h:61-63): 16 ms for the 158 000 variables of the L1723 shape, per State.  So a State is built on
+  // an EMPTY Values and this object's copy is swapped in (Values::swap, Values.h:344: the maps trade their nodes, O(1)).
+  {
+    std::unique_ptr<State> fresh(new State(Values(), e0, params_.lambdaInitial, params_.lambdaFactor));
+    const_cast<Values&>(fresh->values).swap(m.scratch);
+    m.slots.clear(); m.slots.reserve(nvars);
+    for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));
+    state_ = std::move(fresh);
+  }
   const State* s = static_cast<const State*>(state_.get());
   m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;
   lap("state");
@@ -466,20 +477,31 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
 void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
   Impl& m = *impl_;
   if (!m.host_values_stale && !force) return;
-  check(gtg_get_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_get_values");
-  // overwrite the payloads of the Impl's own copy in place (same keys, same order: both sorted by Key; the GenericValue objects
-  // are this object's, reached through Values' const iteration), then let the State's constructor copy it (see init)
-  size_t v = 0;
-  for (const auto& kv : m.scratch) {
-    const double* p = m.packed.data() + m.val_off[v];
-    Value& val = const_cast<Value&>(kv.value);
-    if (m.var_type[v] == GTG_VAR_POINT3) static_cast<GenericValue<Point3>&>(val).value() = Point3(p[0], p[1], p[2]);
-    else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) static_cast<GenericValue<SfmCamera>&>(val).value() = SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16]));
-    else if (m.var_type[v] == GTG_VAR_POSE3) static_cast<GenericValue<Pose3>&>(val).value() = unpackPose(p);
-    else static_cast<GenericValue<Pose2>&>(val).value() = Pose2(p[0], p[1], p[2]);
-    v++;
+  if (m.host_values_stale) {
+    check(gtg_get_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_get_values");
+    // overwrite the payloads of the State's Values in place (m.slots: the GenericValue objects by variable id), host threads
+    const size_t nv = m.slots.size();
+    auto work = [&](size_t b, size_t e) {
+      for (size_t v = b; v < e; v++) {
+        const double* p = m.packed.data() + m.val_off[v];
+        Value& val = *m.slots[v];
+        if (m.var_type[v] == GTG_VAR_POINT3) static_cast<GenericValue<Point3>&>(val).value() = Point3(p[0], p[1], p[2]);
+        else if (m.var_type[v] == GTG_VAR_SFM_CAMERA) static_cast<GenericValue<SfmCamera>&>(val).value() = SfmCamera(unpackPose(p), Cal3Bundler(p[12], p[13], p[14], p[15], p[16]));
+        else if (m.var_type[v] == GTG_VAR_POSE3) static_cast<GenericValue<Pose3>&>(val).value() = unpackPose(p);
+        else static_cast<GenericValue<Pose2>&>(val).value() = Pose2(p[0], p[1], p[2]);
+      }
+    };
+    const char* thr_env = std::getenv("GTG_HOST_THREADS");
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(std::max(1u, std::thread::hardware_concurrency()), 8u)), nv / 8192 + 1}));
+    std::vector<std::thread> pool;
+    for (size_t ti = 1; ti < nthreads; ti++) pool.emplace_back(work, nv * ti / nthreads, nv * (ti + 1) / nthreads);
+    work(0, nv / nthreads);
+    for (auto& t : pool) t.join();
   }
-  state_.reset(new State(m.scratch, m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
+  // the next State takes the SAME Values object over (swap: O(1); see init) with the device's error / lambda / counters
+  std::unique_ptr<State> fresh(new State(Values(), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
+  const_cast<Values&>(fresh->values).swap(const_cast<Values&>(state_->values));
+  state_ = std::move(fresh);
   m.host_values_stale = false;
 }
 

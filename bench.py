@@ -52,6 +52,99 @@ def build_workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+_PMC_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import bench
+from gtsam_amd.optimizer import DeviceLevenbergMarquardt
+from gtsam_amd.params import LevenbergMarquardtParams
+(problem, values0), _ = bench.build_workload(%(workload)r)
+prm = LevenbergMarquardtParams.CeresDefaults()
+opt = DeviceLevenbergMarquardt(problem, values0, prm)
+opt.dev.linearize()
+for _ in range(2):
+    opt.dev.try_lambda(prm.lambdaInitial, prm.diagonalDamping, prm.minDiagonal, prm.maxDiagonal)
+opt.dev.close()
+print("PMC_CHILD_DONE")
+"""
+
+
+def measure_traffic(workload):
+    """HBM bytes per factorisation of the dominant kernel, measured in THIS run: two rocprofv3 --pmc sub-runs (FETCH_SIZE, WRITE_SIZE:
+    separate passes, as MI355X_MICROARCH.md prescribes) of a child that performs two lambda tries of the bench workload with the
+    dataflow factorisation in its single-kernel form (GTG_DF_SINGLE=1: counter collection serialises kernels, under which the two
+    cooperating kernels of the production form cannot run; same tasks, same tiles read and written).  Counters are KB; FETCH_SIZE is
+    doubled on gfx950 (the guide's correction).  Returns (bytes or None, source string, per-kernel dict)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found", {}
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gtg_pmc_", dir="/tmp")
+        env = dict(os.environ, GTG_DF_SINGLE="1", TMPDIR="/tmp", GTG_QUIET="1")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, "-c", _PMC_CHILD % {"root": ROOT, "workload": workload}],
+                               env=env, cwd="/tmp", capture_output=True, text=True, timeout=420)
+            if "PMC_CHILD_DONE" not in r.stdout:       # (rocprofv3 may crash in its own finalisation after the database is written: not the criterion)
+                return None, "pmc child failed: " + (r.stderr or r.stdout)[-200:], {}
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, "rocprofv3 wrote no database", {}
+            con = sqlite3.connect(dbs[0])
+            # (the view tools/rocprof_pmc.py reads: one row per dispatch and counter)
+            rows = con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+            con.close()
+            sums[counter] = {name: (int(n), float(v)) for name, n, v in rows}
+        except Exception as e:  # noqa: BLE001
+            return None, f"pmc pass {counter} failed: {e}"[:300], {}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    per = {}
+    for name, (n, v) in sums["FETCH_SIZE"].items():
+        w = sums["WRITE_SIZE"].get(name, (n, 0.0))
+        per[name.replace("(anonymous namespace)::", "").split("(")[0]] = {"launches": n, "read": 2.0 * v * 1024.0 / max(n, 1), "written": w[1] * 1024.0 / max(w[0], 1)}
+    chol = [v for k, v in per.items() if "k_df_single" in k]
+    if not chol:
+        return None, "no k_df_single dispatch in the pmc passes", per
+    return chol[0]["read"] + chol[0]["written"], ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs (separate passes) of two lambda tries, "
+                                                  "dataflow factorisation in its single-kernel form (GTG_DF_SINGLE=1), FETCH_SIZE x 2 (gfx950), KB units"), per
+
+
+def cpp_host_leg(workload, steps, warmup):
+    """The headline as north_star defines the host: tools/cpp/bench_lm_gtsam.cpp -- GTSAM's loader, GTSAM's NonlinearFactorGraph / Values /
+    LevenbergMarquardtParams, gtsam_amd::GpuLevenbergMarquardtOptimizer::optimize() through the C ABI; exactly `steps` LM iterations timed."""
+    import subprocess
+    import tempfile
+    from gtsam_amd import datasets as D
+    from gtsam_amd import io as IO
+    exe = os.path.join(ROOT, "tests", "_build", "bench_lm_gtsam")
+    gens = {"ladybug1723": D.ladybug_1723, "dubrovnik16": D.dubrovnik_16, "venice1778": D.venice_1778, "streets1723": D.streets_1723}
+    if workload not in gens:
+        return {"failed": "not a BAL workload (the C++ bench program is timing/timeSFMBAL.cpp's protocol)"}
+    if not os.path.exists(exe):
+        return {"failed": "tests/_build/bench_lm_gtsam not built (make -C gtsam_amd/host; needs GTSAM's headers = /root/reference)"}
+    path = os.path.join(tempfile.gettempdir(), f"gtsam_amd_bench_{workload}_{os.getpid()}.txt")
+    try:
+        IO.write_bal(path, *gens[workload]())
+        r = subprocess.run([exe, path, "--steps", str(steps), "--warmup", str(warmup)], capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not line:
+            return {"failed": ("no output; stderr: " + r.stderr[-300:])}
+        j = json.loads(line[-1]); j["exit_code"] = r.returncode
+        if r.returncode != 0 or j.get("steps") != steps:
+            j["failed"] = "exit code %d, %s steps" % (r.returncode, j.get("steps"))
+        return j
+    except Exception as e:  # noqa: BLE001
+        return {"failed": str(e)[:300]}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +153,8 @@ def main():
     ap.add_argument("--workload", default="ladybug1723")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--skip-dense-roofline", action="store_true", help="do not run the extra dense-schedule factorisations (used for clean profiles)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="auto: measure roofline.traffic in this run (two rocprofv3 --pmc sub-runs)")
+    ap.add_argument("--host", default="auto", choices=["auto", "python"], help="auto: the headline is timed in the C++ host (tools/cpp/bench_lm_gtsam.cpp) at N = 1")
     args = ap.parse_args()
 
     import torch
@@ -171,20 +266,35 @@ def main():
         # (whole 128x128 tiles, structural zeros inside them included): `achieved_stored_tiles` / `frac_stored_tiles`
         achieved = flops_block * chol_calls / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
         achieved_tiles = chol_flops * chol_calls / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
-        # HBM bytes per factorisation: NOT measured in this run (PMC collection serialises kernels and needs its own rocprofv3
-        # passes); the figure is read from the committed PMC passes of this same command and labelled as such
-        traffic, traffic_source = None, None
-        try:
-            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_cholesky_traffic.json") and "dense" not in f)
-            if pmc and args.workload == "ladybug1723" and world == 1:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("hbm_bytes_sparse")
-                traffic_source = "from_profiles: profiles/%s (separate rocprofv3 --pmc passes, tools/profile_round.sh), not measured in this run" % pmc[-1]
-        except Exception:  # noqa: BLE001
-            traffic = None
+        # HBM bytes per factorisation: measured in this run by two rocprofv3 --pmc sub-runs (measure_traffic); when that is not possible
+        # (no rocprofv3, --traffic off, N > 1) the figure of the committed PMC passes of the same command is quoted and labelled as such
+        traffic, traffic_source, traffic_kernels = None, None, {}
+        full.dev.close()
+        if args.traffic == "auto" and world == 1:
+            traffic, traffic_source, traffic_kernels = measure_traffic(args.workload)
+        if traffic is None:
+            why = traffic_source
+            try:
+                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_cholesky_traffic.json") and "dense" not in f)
+                if pmc and args.workload == "ladybug1723" and world == 1:
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))).get("hbm_bytes_sparse")
+                    traffic_source = "from_profiles: profiles/%s (separate rocprofv3 --pmc passes, tools/profile_round.sh), not measured in this run%s" % (pmc[-1], (" (" + why + ")") if why else "")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        # the headline: timed in the C++ host (north_star: "host stays C++ with GTSAM's ... API surface intact"); the Python mirror's
+        # loop above stays in the line as `python_mirror` (it is also where the per-phase device times and the roofline come from)
+        cpp = cpp_host_leg(args.workload, args.steps, args.warmup) if (world == 1 and args.host == "auto") else {"failed": "N > 1 or --host python: the sharded run is driven by torch.distributed from the Python mirror"}
+        cpp_ok = "failed" not in cpp
         out = {
-            "metric": "LM iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s",
+            "metric": "LM iterations/sec", "value": cpp["iterations_per_s"] if cpp_ok else args.steps / elapsed, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "ms_per_step": cpp["ms_per_step"] if cpp_ok else 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "value_source": ("C++ host: tools/cpp/bench_lm_gtsam.cpp (GTSAM graph, Values and params; gtsam_amd::GpuLevenbergMarquardtOptimizer::optimize() through the C ABI; "
+                             "exactly `steps` LM iterations over optimize() calls of optimizers constructed before the timed region)") if cpp_ok
+                            else "Python mirror of the host (gtsam_amd/optimizer.py over the same C ABI): " + str(cpp.get("failed")),
+            "python_mirror": {"value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "lambda_tries_per_s": tries / elapsed,
+                              "note": "same C ABI driven from gtsam_amd/optimizer.py; a run that converges inside the timed loop restarts from the initial values (set_values + error), inside the timed region"},
+            "cpp_host": cpp,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "protocol": ("timeSFMBAL: GeneralSFMFactor Unit(2) noise, no priors, Ceres LM params, Schur ordering" if problem.n_sfm
                                     else "Pose2SLAMExample_g2o with LevenbergMarquardt (legacy params), BetweenFactor<Pose2> + prior" if (problem.var_type == 3).any()
@@ -193,13 +303,18 @@ def main():
                        "poses": int(((problem.var_type == 0) | (problem.var_type == 3)).sum()), "between_factors": int(problem.n_between),
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
                        "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU"},
-            "lambda_tries_per_s": tries / elapsed,
-            "time_to_converged_s": ttc, "time_to_converged_setup_s": t_setup, "converged_error": full.error(), "converged_iterations": full.iterations(),
+            "lambda_tries_per_s": cpp["lambda_tries_per_s"] if cpp_ok else tries / elapsed,
+            # construction -> checkConvergence.  `time_to_converged_s` is the COLD figure when the C++ leg ran (first optimizer of a fresh
+            # process: code-object load, first device allocations); warm = a later optimizer of the same process
+            "time_to_converged_s": cpp["cold_time_to_converged_s"] if cpp_ok else ttc,
+            "time_to_converged_warm_s": cpp["warm_time_to_converged_s"] if cpp_ok else ttc,
+            "time_to_converged_python_mirror_warm_s": ttc, "time_to_converged_setup_s": t_setup, "converged_error": full.error(), "converged_iterations": full.iterations(),
             "converged_inner_iterations": full.getInnerIterations(), "initial_error": full.trace[0][1],
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
             "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced camera system after RCM reordering: dataflow schedule, k_df_bulk + k_df_chain, one factorisation = one launch of each (flops_per_launch = the elimination counted at the granularity of the variable blocks, fill included = the algorithmic count `frac` is quoted on; flops_stored_tiles = what the kernels execute over the stored 128x128 tiles)",
                          "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_other_kernels_bytes_per_launch": {k: v for k, v in traffic_kernels.items() if "k_df_single" not in k} or None,
                          "flops_per_launch": flops_block, "ms_per_launch": chol_ms / max(chol_calls, 1),
                          "flops_block_level": flops_block, "flops_stored_tiles": chol_flops,
                          "achieved_stored_tiles": achieved_tiles, "frac_stored_tiles": achieved_tiles / FP64_MATRIX_PEAK_TFLOPS,
@@ -253,7 +368,7 @@ def main():
                                      "(-O3 -mavx2 -mfma, no TBB)",
                            "phase_ms": dict(zip(["linearize", "hessianDiagonal", "damp", "eliminate_solve", "linear_error_x2", "retract", "error", "total"],
                                                 [float(x) for x in ms])),
-                           "host_cpus": os.cpu_count()}
+                           "cores_used": 1, "host_cpus": os.cpu_count()}
                     # multi-thread variant (the library is built without TBB -- no headers in the image -- so the split is made in
                     # the harness, oracle/ref_harness.cpp ref_graph_iteration_mt: linearize and the landmark eliminations of the
                     # Schur ordering on `threads` std::threads, the camera system on one); reported next to the 1-thread figure,
@@ -269,7 +384,7 @@ def main():
                                                  [float(x) for x in ms_mt])),
                             "delta_norm2_rel_vs_1_thread": rel(res_mt[4], ref_res[4])}
                         if rc_mt == 0 and cpu["multi_thread"]["value"] > cpu["value"]:
-                            cpu["value_1_thread"] = cpu["value"]; cpu["value"] = cpu["multi_thread"]["value"]; cpu["cores"] = nth
+                            cpu["value_1_thread"] = cpu["value"]; cpu["value"] = cpu["multi_thread"]["value"]; cpu["cores"] = nth; cpu["cores_used"] = nth
                     except Exception as e:  # noqa: BLE001
                         cpu["multi_thread"] = {"value": None, "failed": str(e)}
                 else:
@@ -283,38 +398,6 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
         out["cpu_baseline"] = cpu
-        # The C++ host north_star asks for, measured in this run: the reference's own benchmark program of the path
-        # (timing/timeSFMBAL.cpp with the optimizer's type name changed, tools/cpp/time_sfm_bal_gpu.cpp) on the same problem
-        # written as a BAL file -- GTSAM's loader, GTSAM's graph, GpuLevenbergMarquardtOptimizer (extraction + upload +
-        # optimize() through the C ABI).  Second construction / optimisation of the process (the first also pays the first
-        # use of the device); time_to_converged = construction -> checkConvergence, the metric's definition.
-        out["cpp_host"] = None
-        exe = os.path.join(ROOT, "tests", "_build", "time_sfm_bal_gpu")
-        if world == 1 and args.workload in ("ladybug1723", "dubrovnik16", "venice1778", "streets1723") and os.path.exists(exe) and args.cpu_baseline != "off":
-            try:
-                import subprocess
-                import tempfile
-                from gtsam_amd import datasets as D
-                from gtsam_amd import io as IO
-                gen = {"ladybug1723": D.ladybug_1723, "dubrovnik16": D.dubrovnik_16, "venice1778": D.venice_1778, "streets1723": D.streets_1723}[args.workload]
-                path = os.path.join(tempfile.gettempdir(), f"gtsam_amd_bench_{args.workload}.txt")
-                IO.write_bal(path, *gen())
-                r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
-                os.unlink(path)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-                j = json.loads(line)
-                out["cpp_host"] = {
-                    "program": "tools/cpp/time_sfm_bal_gpu.cpp (= timing/timeSFMBAL.cpp, optimizer type changed), GTSAM built from /root/reference",
-                    "construct_ms": j["second_run_construct_ms"], "optimize_ms": j["second_run_optimize_ms"],
-                    "time_to_converged_s": (j["second_run_construct_ms"] + j["second_run_optimize_ms"]) * 1e-3,
-                    "iterations": j["iterations"], "inner_iterations": j["inner_iterations"],
-                    "iterations_per_s_optimize_only": j["second_run_iterations_per_s_optimize_only"],
-                    "device_phase_ms": j["second_run_device_phase_ms"],
-                    "first_run_construct_ms": j["construct_ms"], "first_run_optimize_ms": j["optimize_ms"],
-                    "final_error": j["final_error"], "final_error_recomputed_by_gtsam_on_host": j["final_error_recomputed_on_host"],
-                    "exit_code": r.returncode}
-            except Exception as e:  # noqa: BLE001
-                out["cpp_host"] = {"failed": str(e)[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

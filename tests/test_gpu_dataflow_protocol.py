@@ -141,14 +141,16 @@ print("RESULT " + json.dumps(dict(trace=tr.tobytes().hex(), rows=int(tr.shape[0]
 
 
 @pytest.mark.parametrize("nd", ["0", None], ids=["one_chain", "default_ordering"])
-def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule(nd):
+def test_a_timed_out_dataflow_pass_is_repeated(nd):
     """A dependency wait of the dataflow factorisation that runs into its bound (here: the chain kernel is left out of the third
     factorisation, GTG_DF_TEST_TIMEOUT=3 -- what a chain kernel that the dispatcher never placed looks like) must not abort
-    optimize(): the lambda try is computed once more with the stream / event schedule, and the handle counts one fallback.
-    With one chain (GTG_ND_DEPTH=0) the two schedules run the same sums in the same order, so the LM trajectory is bit for bit the
-    undisturbed one; with the default ordering of this graph (nested dissection, several chains) the cross-part updates are
-    summed in a different order by the stream schedule: same rows, same accept / reject decisions, errors equal to 1e-6 (the
-    tolerance of the LM-trace comparisons with the reference)."""
+    optimize(): the lambda try is computed once more, first with the SAME schedule (the repeat returns the bits of an undisturbed
+    try, whatever the ordering: the LM trajectory does not depend on whether a wait timed out), and the handle counts one repeat.
+    When the repeat times out as well (GTG_DF_TEST_TIMEOUT=3:2 leaves the chain kernel out of two factorisations in a row) the try
+    goes to the stream / event schedule.  With one chain (GTG_ND_DEPTH=0) that schedule runs the same sums in the same order, so
+    the trajectory is still bit for bit the undisturbed one; with the default ordering of this graph (nested dissection, several
+    chains) it sums the cross-part updates in a different order: same rows, same accept / reject decisions, errors equal to 1e-6
+    (the tolerance of the LM-trace comparisons with the reference)."""
     import torch
     assert torch.cuda.is_available()
 
@@ -163,12 +165,16 @@ def test_a_timed_out_dataflow_pass_is_repeated_with_the_stream_schedule(nd):
     a, _ = child({})
     b, err = child({"GTG_DF_TEST_TIMEOUT": "3"})
     assert a["fallbacks"] == 0 and b["fallbacks"] == 1, (a["fallbacks"], b["fallbacks"])
+    assert "repeating the lambda try with the dataflow schedule" in err
+    assert a["trace"] == b["trace"], (a["final"], b["final"], a["rows"], b["rows"])
+    c, err = child({"GTG_DF_TEST_TIMEOUT": "3:2"})
+    assert c["fallbacks"] == 2, c["fallbacks"]
     assert "repeating the lambda try with the stream schedule" in err
     ta = np.frombuffer(bytes.fromhex(a["trace"]), np.float64).reshape(-1, 3)
-    tb = np.frombuffer(bytes.fromhex(b["trace"]), np.float64).reshape(-1, 3)
-    assert ta.shape == tb.shape and np.array_equal(ta[:, 0], tb[:, 0]), (ta, tb)
+    tc = np.frombuffer(bytes.fromhex(c["trace"]), np.float64).reshape(-1, 3)
+    assert ta.shape == tc.shape and np.array_equal(ta[:, 0], tc[:, 0]), (ta, tc)
     if nd == "0":
-        assert a["trace"] == b["trace"], (a["final"], b["final"], a["rows"], b["rows"])
+        assert a["trace"] == c["trace"], (a["final"], c["final"], a["rows"], c["rows"])
     else:
         # (the tolerance of every LM-trace comparison with the reference: rounding differences of one solve are amplified along the run)
-        assert (np.abs(ta[:, 1] - tb[:, 1]) <= 1e-6 * np.abs(ta[:, 1])).all() and np.allclose(ta[:, 2], tb[:, 2], rtol=1e-6), (ta, tb)
+        assert (np.abs(ta[:, 1] - tc[:, 1]) <= 1e-6 * np.abs(ta[:, 1])).all() and np.allclose(ta[:, 2], tc[:, 2], rtol=1e-6), (ta, tc)

@@ -43,14 +43,15 @@ def main():
         try:
             opt = DeviceLevenbergMarquardt(p, v0, prm)
             opt.optimize()
-            out[i] = (np.array(opt.trace)[:, :3], opt.values_packed(), int(opt.dev.df_ctrl()[15]))
+            ctl = opt.dev.df_ctrl()
+            out[i] = (np.array(opt.trace)[:, :3], opt.values_packed(), int(ctl[15]), int(ctl[6]), int(ctl[7]))
             opt.dev.close()
         except Exception as e:  # noqa: BLE001
             out[i] = str(e)
 
     ref = [None]; run(ref, 0)
     assert not isinstance(ref[0], str), ref[0]
-    n = diff = err = fb = rnd = 0
+    n = diff = err = fb = rnd = shadow = rmw = 0
     t0 = time.time()
     while time.time() - t0 < seconds:
         res = [None] * nthreads
@@ -61,7 +62,7 @@ def main():
             n += 1
             if isinstance(r, str):
                 err += 1; print(json.dumps({"round": rnd, "error": r[:200]}), flush=True); continue
-            fb += r[2]
+            fb += r[2]; shadow += r[3]; rmw += r[4]
             if r[0].shape != ref[0][0].shape or not np.array_equal(r[0], ref[0][0]) or not np.array_equal(r[1], ref[0][1]):
                 diff += 1
                 msg = f"shape {r[0].shape} vs {ref[0][0].shape}"
@@ -69,10 +70,10 @@ def main():
                     d = np.abs(r[0] - ref[0][0]); k = np.unravel_index(np.argmax(d), d.shape)
                     first = int(np.argmax((r[0] != ref[0][0]).any(axis=1)))
                     msg = f"first differing row {first}; max abs {d.max():.3e} at row {k[0]} col {k[1]}; final {r[0][-1, 1]!r} vs {ref[0][0][-1, 1]!r}"
-                print(json.dumps({"round": rnd, "differs": msg}), flush=True)
+                print(json.dumps({"round": rnd, "differs": msg, "repeated_tries_of_this_run": r[2]}), flush=True)
         rnd += 1
     print(json.dumps({"problem": problem, "lib": os.path.basename(L.LIB_PATH), "threads": nthreads, "seconds": round(time.time() - t0, 1),
-                      "optimisations": n, "different": diff, "errors": err, "fallbacks": fb,
+                      "optimisations": n, "different": diff, "errors": err, "fallbacks": fb, "waits_ended_on_shadow_words": shadow, "waits_ended_on_rmw_poll": rmw,
                       "factorisations_per_optimisation": int(ref[0][0].shape[0])}), flush=True)
     return 0 if diff == 0 and err == 0 else 1
 

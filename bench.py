@@ -191,7 +191,11 @@ def main():
         return DeviceLevenbergMarquardt(problem, values0, params, device=local_rank, shard=rank, n_shards=world,
                                         allreduce=allreduce)
 
+    torch.cuda.synchronize()
+    mem_free0 = torch.cuda.mem_get_info()[0]
     opt = fresh()
+    torch.cuda.synchronize()
+    handle_bytes = mem_free0 - torch.cuda.mem_get_info()[0]      # device memory one handle takes from the driver (the library keeps nothing aside by default)
     n_red = opt.dev.reduced_dim
 
     def run_iterations(o, k):
@@ -308,7 +312,7 @@ def main():
             # process: code-object load, first device allocations); warm = a later optimizer of the same process
             "time_to_converged_s": cpp["cold_time_to_converged_s"] if cpp_ok else ttc,
             "time_to_converged_warm_s": cpp["warm_time_to_converged_s"] if cpp_ok else ttc,
-            "time_to_converged_python_mirror_warm_s": ttc, "time_to_converged_setup_s": t_setup, "converged_error": full.error(), "converged_iterations": full.iterations(),
+            "time_to_converged_python_mirror_warm_s": ttc, "time_to_converged_setup_s": t_setup, "device_memory_per_handle_bytes": int(handle_bytes), "converged_error": full.error(), "converged_iterations": full.iterations(),
             "converged_inner_iterations": full.getInnerIterations(), "initial_error": full.trace[0][1],
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
             "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced camera system after RCM reordering: dataflow schedule, k_df_bulk + k_df_chain, one factorisation = one launch of each (flops_per_launch = the elimination counted at the granularity of the variable blocks, fill included = the algorithmic count `frac` is quoted on; flops_stored_tiles = what the kernels execute over the stored 128x128 tiles)",

@@ -716,7 +716,7 @@ void analyze(gtg_context& c) {
       free_df_plan(c.df);
       std::vector<int32_t> tile_part;                      // nested dissection: the part of every block column (parts are aligned to column pairs)
       if (!pair_part.empty()) { tile_part.resize(nt); for (int t = 0; t < nt; t++) tile_part[t] = pair_part[t / 2]; }
-      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s, &tile_part, &part_parent);
+      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s, c.plan.h_slot, c.plan.n_stored, &tile_part, &part_parent);
       for (int a = 0; a < nt; a++)
         for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
       for (int b = 0; b < nt; b++) if (dense || rhs[(size_t)b]) { ex.push_back(nt); ex.push_back(b); }
@@ -806,7 +806,7 @@ void analyze(gtg_context& c) {
   c.E.alloc(std::max<size_t>(kEStride * (size_t)c.n_obs, 1));
   c.vobs.alloc(std::max<size_t>(3 * (size_t)c.n_obs, 1));
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
-  c.S.alloc((NP + kTile) * NP);
+  c.S.alloc((size_t)c.plan.n_stored * kTileDoubles);   // the stored tiles only (context.h::SMat)
   c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
   check_hip(hipMemsetAsync(c.Dinv.p, 0, sizeof(double) * c.Dinv.n, c.stream), "memset");
   c.chol_epoch_dev.alloc(1);

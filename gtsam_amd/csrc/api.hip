@@ -31,23 +31,27 @@ void check_hip(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// The big buffers of a handle (the reduced system: 1.9 GB on the L1723 shape, 31 GB on w20000; the E slots; the Jacobian records;
-// the term lists) are kept for the next handle of the process when one is released instead of going back to the driver: on boxes
-// where the driver clears device memory as it hands it out a fresh hipMalloc costs ~30 ms per GB (the L1723 set-up 17 -> 91 ms,
-// w20000 15 -> 860 ms, measured), and programs construct optimizers one after the other (GncOptimizer: one per outer iteration).
-// Only blocks of >= 16 MB are kept, at most GTG_ALLOC_CACHE_MB (default 8192, 0 = off) in total per process; a kept block serves a
-// request of 80 - 100 % of its size on the same device.  Every such buffer is fully written by the kernels before it is read (the
-// reduced system: its stored tiles are zeroed at the start of every lambda try), so recycled contents are never observed.
+// Optional (GTG_ALLOC_CACHE_MB=n, default 0 = off): the big buffers of a handle (>= 16 MB: the E slots, the Jacobian records, the
+// term lists, the stored tiles of the reduced system) are kept for the next handle of the process when one is released instead of
+// going back to the driver, at most n MB per DEVICE; a kept block serves a request of 80 - 100 % of its size on the same device.  On
+// boxes where the driver clears device memory as it hands it out a fresh hipMalloc costs ~30 ms per GB, and programs construct
+// optimizers one after the other (GncOptimizer: one per outer iteration).  It was on by default (8 GB) in round 3, when the reduced
+// system was a dense (NP + 128) x NP array (1.9 GB on the L1723 shape, 31 GB on w20000); with the tile-indexed storage of round 4
+// (0.45 GB / < 1 GB) the cache is no longer needed for the set-up times and holds no memory that the process's other users (torch,
+// RCCL) cannot see unless it is asked to.  When an allocation fails, every kept block of that device is released and the
+// allocation is tried once more; gtg_release_cached_memory() releases them at any time.  Every such buffer is fully written by the
+// kernels before it is read, so recycled contents are never observed (GTG_ALLOC_POISON=1 fills a recycled block with NaNs first:
+// a debug mode the parity suite can be run under).
 namespace {
 struct KeptBlock { void* p; size_t bytes; int device; };
 std::mutex g_kept_mu;
 std::vector<KeptBlock> g_kept;
-size_t g_kept_bytes = 0;
 constexpr size_t kKeepMin = (size_t)16 << 20;
 size_t keep_limit() {
-  static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 8192L) << 20; }();
+  static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 0L) << 20; }();
   return lim;
 }
+size_t kept_bytes_on(int dev) { size_t b = 0; for (const auto& k : g_kept) if (k.device == dev) b += k.bytes; return b; }   // (g_kept_mu held)
 void* take_kept(size_t bytes, size_t* got) {
   if (bytes < kKeepMin || keep_limit() == 0) return nullptr;
   int dev = 0;
@@ -60,8 +64,9 @@ void* take_kept(size_t bytes, size_t* got) {
   if (best < 0) return nullptr;
   void* q = g_kept[best].p;
   *got = g_kept[best].bytes;
-  g_kept_bytes -= g_kept[best].bytes;
   g_kept.erase(g_kept.begin() + best);
+  static const bool poison = std::getenv("GTG_ALLOC_POISON") != nullptr;
+  if (poison) (void)hipMemset(q, 0xFF, *got);   // all-ones bytes = a NaN in every double, -1 in every index
   return q;
 }
 bool keep_block(void* q, size_t bytes) {        // (hipFree synchronises the device; a kept block must be idle as well)
@@ -69,11 +74,25 @@ bool keep_block(void* q, size_t bytes) {        // (hipFree synchronises the dev
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lk(g_kept_mu);
-  if (g_kept_bytes + bytes > keep_limit()) return false;
+  if (kept_bytes_on(dev) + bytes > keep_limit()) return false;
   if (hipDeviceSynchronize() != hipSuccess) return false;
   g_kept.push_back(KeptBlock{q, bytes, dev});
-  g_kept_bytes += bytes;
   return true;
+}
+size_t release_kept(int dev) {                  // dev < 0: every device
+  std::lock_guard<std::mutex> lk(g_kept_mu);
+  size_t freed = 0;
+  for (size_t i = 0; i < g_kept.size();) {
+    if (dev < 0 || g_kept[i].device == dev) {
+      int cur = 0;
+      const bool sw = hipGetDevice(&cur) == hipSuccess && cur != g_kept[i].device && hipSetDevice(g_kept[i].device) == hipSuccess;
+      (void)hipFree(g_kept[i].p);
+      if (sw) (void)hipSetDevice(cur);
+      freed += g_kept[i].bytes;
+      g_kept.erase(g_kept.begin() + (long)i);
+    } else i++;
+  }
+  return freed;
 }
 }  // namespace
 
@@ -82,7 +101,14 @@ template <class T> void DevBuf<T>::alloc(size_t count) {
   n = count;
   if (!count) return;
   if (void* q = take_kept(sizeof(T) * count, &cap)) { p = static_cast<T*>(q); return; }
-  check_hip(hipMalloc(&p, sizeof(T) * count), "hipMalloc");
+  hipError_t e = hipMalloc(&p, sizeof(T) * count);
+  if (e != hipSuccess) {   // out of memory with blocks kept aside: give them back to the driver and try once more
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && release_kept(dev) > 0) e = hipMalloc(&p, sizeof(T) * count);
+  }
+  if (e != hipSuccess) { p = nullptr; n = 0; }
+  check_hip(e, "hipMalloc");
   cap = sizeof(T) * count;
 }
 template <class T> void DevBuf<T>::upload(const T* host, size_t count, hipStream_t s) {
@@ -192,7 +218,7 @@ static void collect(gtg_context& c, std::initializer_list<int> phases) {
 
 }  // namespace gt
 
-namespace gt { long long* g_potrf_dbg_set(long long*); float debug_time_syrk(gtg_context&, double*, int, int, int, int); }
+namespace gt { long long* g_potrf_dbg_set(long long*); float debug_time_syrk(gtg_context&, SMat, int, int, int); }
 using namespace gt;
 
 #define GTG_TRY try {
@@ -243,7 +269,7 @@ int gtg_destroy(gtg_handle c) {
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
                             &c->pair_col, &c->pair_oa, &c->pair_ob, &c->smart_status, &c->smart_lin_status, &c->smart_cache_state, &c->sfm_smart, &c->lm_smart};
   for (auto* b : i32) b->free();
-  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.bwd_col_off.free(); c->plan.bwd_col_rows.free(); c->plan.stored.free(); c->plan.exch.free(); c->xbuf.free();
+  c->plan.rows.free(); c->plan.pairs.free(); c->plan.bcols.free(); c->plan.bwd_col_off.free(); c->plan.bwd_col_rows.free(); c->plan.stored.free(); c->plan.slot.free(); c->yred.free(); c->plan.exch.free(); c->xbuf.free();
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->smart_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
@@ -589,13 +615,15 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   // TRSM workgroups of a panel launch).  A dependency wait that runs into its bound raises SC_TIMEOUT and the kernels drain: a chain
   // kernel that was not placed, a device shared with another process, or -- seen with several handles on one device -- a flag that an
   // XCD's L2 kept serving with its old value although the flags are published twice (chol_dataflow.hip::st_flag).  The try is then
-  // repeated, first with the other schedule (stream / event launches of cholesky.hip: kernels that never wait for a kernel launched
-  // after them; its plan is always built), then once more with the dataflow schedule.  The reduced system is assembled again each
-  // time, because the factorisation works in place; with one chain the schedules run the same sums in the same order (a repeated try
-  // returns the same bits), with several chains they differ in the order of the cross-part updates (the same numbers to rounding).
+  // repeated: first with the SAME schedule (a stuck wait is a property of one pass, not of the problem, and the repeat returns the
+  // same bits as an undisturbed try: the trajectory does not depend on whether a wait timed out), then, should that time out as
+  // well, with the other schedule (stream / event launches of cholesky.hip: kernels that never wait for a kernel launched after
+  // them; its plan is always built; with one chain it runs the same sums in the same order, with several chains the cross-part
+  // updates are summed in another order: the same numbers to rounding).  The reduced system is assembled again each time, because
+  // the factorisation works in place.
   // Sharded: the scalars are summed over the shards by read_scalars, so every shard sees the time-out of any shard and all repeat.
   for (int attempt = 0; attempt < 3; attempt++) {
-    const bool df = c->use_df && attempt != 1;
+    const bool df = c->use_df && attempt != 2;
     check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
     { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
     { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
@@ -604,24 +632,24 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       if (by_tiles || c->n_xb == 0) {
         const int64_t nb = c->plan.n_exch * kTile * kTile;
         if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
-        launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, false);
+        launch_pack_tiles(*c, smat(*c), c->plan, c->xbuf.p, false);
         exchange(*c, c->xbuf.p, nb);
-        launch_pack_tiles(*c, c->S.p, c->NP, c->plan, c->xbuf.p, true);
+        launch_pack_tiles(*c, smat(*c), c->plan, c->xbuf.p, true);
       } else {                // only the structurally non-zero d x d blocks (the same list on every shard) + rhs row + padding
         const int64_t nb = exchange_block_doubles(*c);
         if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
-        launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, false);
+        launch_pack_blocks(*c, smat(*c), c->NP, c->xbuf.p, false);
         exchange(*c, c->xbuf.p, nb);
-        launch_pack_blocks(*c, c->S.p, c->NP, c->xbuf.p, true);
+        launch_pack_blocks(*c, smat(*c), c->NP, c->xbuf.p, true);
       }
     }
     std::unique_lock<std::mutex> one_at_a_time;
     if (df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
     { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
-      if (df) launch_cholesky_df(*c, c->S.p, c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
-      else launch_cholesky(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
+      if (df) launch_cholesky_df(*c, smat(*c), c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
+      else launch_cholesky(*c, smat(*c), c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
     { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
-      launch_backward_solve(*c, c->S.p, c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
+      launch_backward_solve(*c, smat(*c), c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
       launch_back_substitute(*c);
       if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
         check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
@@ -647,18 +675,20 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
           (void)hipMemcpy(ctl, c->df.ctrl.p, sizeof(ctl), hipMemcpyDeviceToHost);
           const int kind = ctl[8], I = ctl[9], J = ctl[10], k = ctl[11];
           const long long *w1 = nullptr, *w2 = nullptr;
-          if (kind == 1 || kind == 2) { w1 = c->df.tile_flag.p + (int64_t)I * nt + k; w2 = c->df.tile_flag.p + (int64_t)J * nt + k; }
-          else if (kind == 3) w1 = w2 = c->df.tile_flag.p + (int64_t)J * nt + J;
+          // (flag words are indexed by tile slot; kinds 1 / 2 record the SLOT of the first operand tile in k)
+          auto slot_of = [&](int a, int b) { return (a >= 0 && a <= nt && b >= 0 && b < nt) ? (int64_t)c->plan.h_slot[(size_t)a * nt + b] : (int64_t)-1; };
+          if (kind == 1 || kind == 2) { if (k >= 0 && k < c->plan.n_stored) w1 = w2 = c->df.tile_flag.p + k; }
+          else if (kind == 3 && slot_of(J, J) >= 0) w1 = w2 = c->df.tile_flag.p + slot_of(J, J);
           else if (kind == 4) w1 = w2 = c->df.pd_flag.p + I;
-          else if (kind == 5) w1 = w2 = c->df.tile_flag.p + (int64_t)I * nt + J;
-          else if (kind == 7) w1 = w2 = c->df.part_flag.p + (int64_t)I * nt + J;
+          else if (kind == 5 && slot_of(I, J) >= 0) w1 = w2 = c->df.tile_flag.p + slot_of(I, J);
+          else if (kind == 7 && slot_of(I, J) >= 0) w1 = w2 = c->df.part_flag.p + slot_of(I, J);
           if (w1) { (void)hipMemcpy(&now1, w1, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&now2, w2, 8, hipMemcpyDeviceToHost); }
         }
         std::fprintf(stderr, "[gtsam_amd] %s factorisation (epoch %lld): a dependency wait ran into its bound; repeating the lambda try with the %s "
                      "schedule.  wait kind %d at (%d, %d, %d): saw %d / %d, wanted %d / %d; memory now holds %lld / %lld; waiter on XCD %d (hw id 0x%x); "
-                     "tickets taken %d, diagonal tiles started %d of %d, waits that ended on the shadow words %d\n",
-                     df ? "dataflow" : "stream-schedule", c->chol_epoch, df ? "stream" : "dataflow", ctl[8], ctl[9], ctl[10], ctl[11], ctl[12], ctl[13], ctl[14],
-                     ctl[15], now1, now2, ctl[2], (unsigned)ctl[3], ctl[0], ctl[1], nt, ctl[6]);
+                     "tickets taken %d, diagonal tiles started %d of %d; over this handle's life: waits that ended on the shadow words %d, on the read-modify-write poll %d\n",
+                     df ? "dataflow" : "stream-schedule", c->chol_epoch, (c->use_df && attempt + 1 != 2) ? "dataflow" : "stream", ctl[8], ctl[9], ctl[10], ctl[11], ctl[12], ctl[13], ctl[14],
+                     ctl[15], now1, now2, ctl[2], (unsigned)ctl[3], ctl[0], ctl[1], nt, ctl[6], ctl[7]);
       }
       c->df_fallbacks++;
       continue;
@@ -782,8 +812,20 @@ int gtg_get_reduced_matrix(gtg_handle c, double* S, int64_t n_elems) {
   DeviceGuard on_device(c->device);
   // S carries alignment gaps (identity rows) between the nested-dissection parts: copy the square part and compact it
   const int64_t n = c->n_red, NP = c->NP;
-  std::vector<double> full((size_t)NP * NP);
-  check_hip(hipMemcpy(full.data(), c->S.p, sizeof(double) * full.size(), hipMemcpyDeviceToHost), "D2H");
+  // (the stored tiles are brought over and scattered into a dense array on the host; tiles without a slot are zero)
+  std::vector<double> full((size_t)NP * NP, 0.0);
+  {
+    std::vector<double> tiles(c->S.n);
+    check_hip(hipMemcpy(tiles.data(), c->S.p, sizeof(double) * tiles.size(), hipMemcpyDeviceToHost), "D2H");
+    const int nt = (int)(NP / kTile);
+    for (int I = 0; I < nt; I++)
+      for (int J = 0; J < nt; J++) {
+        const int32_t q = c->plan.h_slot[(size_t)I * nt + J];
+        if (q < 0) continue;
+        for (int r = 0; r < kTile; r++)
+          std::memcpy(&full[((size_t)I * kTile + r) * NP + (size_t)J * kTile], &tiles[(size_t)q * kTileDoubles + (size_t)r * kTile], sizeof(double) * kTile);
+      }
+  }
   std::vector<char> is_pad((size_t)NP, 0);
   for (int64_t i : c->h_pad_index) is_pad[(size_t)i] = 1;
   std::vector<int64_t> keep; keep.reserve((size_t)n);
@@ -821,11 +863,14 @@ double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
 double gtg_debug_syrk_ms(gtg_handle c, int m, int abl, int reps) {
   try {
     DeviceGuard on_device(c->device);
-    const int NP = (m + 2) * kTile;
-    DevBuf<double> S; S.alloc((size_t)NP * NP);
+    const int nt = m + 2;      // every tile of an nt x nt grid gets a slot
+    DevBuf<double> S; S.alloc((size_t)nt * nt * kTileDoubles);
+    std::vector<int32_t> hs((size_t)(nt + 1) * nt, -1);
+    for (int q = 0; q < nt * nt; q++) hs[(size_t)q] = q;
+    DevBuf<int32_t> slot; slot.upload(hs.data(), hs.size(), c->stream);
     check_hip(hipMemset(S.p, 0, sizeof(double) * S.n), "memset");
-    const double ms = debug_time_syrk(*c, S.p, NP, m, abl, reps);
-    S.free();
+    const double ms = debug_time_syrk(*c, SMat{S.p, slot.p, nt}, m, abl, reps);
+    S.free(); slot.free();
     return ms;
   } catch (const std::exception& e) { g_last_error = e.what(); return -1.0; }
 }
@@ -930,42 +975,51 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   if (!c || !A || n < 1) throw std::invalid_argument("gtg_dense_cholesky_host: bad arguments");
   DeviceGuard on_device(c->device);
   const int NP = (n + kTile - 1) / kTile * kTile;
+  const int nt = NP / kTile;
+  CholPlan plan;
+  build_chol_plan(plan, nt, nullptr, c->stream);   // dense: every lower tile + the rhs row has a slot
   DevBuf<double> S, Dinv, x, fail;
-  S.alloc((size_t)(NP + kTile) * NP); Dinv.alloc((size_t)(NP / kTile) * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
+  S.alloc((size_t)plan.n_stored * kTileDoubles); Dinv.alloc((size_t)nt * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
   if (!c->chol_epoch_dev.p) { c->chol_epoch_dev.alloc(1); check_hip(hipMemset(c->chol_epoch_dev.p, 0, sizeof(long long)), "memset"); }
-  check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * S.n, c->stream), "memset");
   check_hip(hipMemsetAsync(fail.p, 0, 2 * sizeof(double), c->stream), "memset");
-  check_hip(hipMemcpy2DAsync(S.p, sizeof(double) * NP, A, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, c->stream), "H2D 2D");
-  std::vector<double> ones(NP - n, 1.0);
-  if (NP > n) check_hip(hipMemcpy2DAsync(S.p + (size_t)n * NP + n, sizeof(double) * (NP + 1), ones.data(), sizeof(double), sizeof(double), NP - n, hipMemcpyHostToDevice, c->stream), "pad");
-  if (rhs) check_hip(hipMemcpyAsync(S.p + (size_t)NP * NP, rhs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream), "rhs");
+  // the matrix by tiles (host side): lower triangle of A, identity on the padding, rhs in row 0 of the rhs tiles
+  std::vector<double> tiles((size_t)plan.n_stored * kTileDoubles, 0.0);
+  const SMat hs{tiles.data(), plan.h_slot.data(), nt};
+  for (int64_t i = 0; i < n; i++) for (int64_t j = 0; j <= i; j++) *hs.at(i, j) = A[i * n + j];
+  for (int64_t i = 0; i < n; i++) for (int64_t j = i + 1; j < std::min<int64_t>(n, (i / kTile + 1) * kTile); j++) *hs.at(i, j) = A[i * n + j];   // (upper part of the diagonal tiles, as the dense copy had it)
+  for (int64_t i = n; i < NP; i++) *hs.at(i, i) = 1.0;
+  if (rhs) for (int64_t j = 0; j < n; j++) *hs.at(NP, j) = rhs[j];
+  check_hip(hipMemcpyAsync(S.p, tiles.data(), sizeof(double) * tiles.size(), hipMemcpyHostToDevice, c->stream), "H2D");
+  const SMat Sm{S.p, plan.slot.p, nt};
   // rank test: the matrix is ONE frontal block, as in choleskyPartial(ABC, nFrontal = n) (base/cholesky.cpp:144-157)
   std::vector<unsigned char> pk(NP, 0);
   pk[n - 1] = n >= 2 ? 1 : 2;
   DevBuf<unsigned char> dpk; dpk.upload(pk.data(), pk.size(), c->stream);
   DevBuf<double> dexp; dexp.alloc(NP / kTile + 1);
-  CholPlan plan;
-  build_chol_plan(plan, NP / kTile, nullptr, c->stream);   // dense
   DfPlan df;
   const char* sched = std::getenv("GTG_CHOL");
   const bool use_df = !(sched && std::string(sched) == "streams");
   std::unique_lock<std::mutex> one_at_a_time;
   if (use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
-  if (use_df) { build_df_plan(df, NP / kTile, nullptr, c->stream); launch_cholesky_df(*c, S.p, NP, df, Dinv.p, fail.p, dpk.p, dexp.p); }
-  else launch_cholesky(*c, S.p, NP, plan, Dinv.p, fail.p, dpk.p, dexp.p);
-  if (rhs) launch_backward_solve(*c, S.p, NP, plan, Dinv.p, x.p, fail.p);
+  if (use_df) { build_df_plan(df, nt, nullptr, c->stream, plan.h_slot, plan.n_stored); launch_cholesky_df(*c, Sm, NP, df, Dinv.p, fail.p, dpk.p, dexp.p); }
+  else launch_cholesky(*c, Sm, NP, plan, Dinv.p, fail.p, dpk.p, dexp.p);
+  if (rhs) launch_backward_solve(*c, Sm, NP, plan, Dinv.p, x.p, fail.p);
   double hf2[2] = {0, 0};
   check_hip(hipMemcpyAsync(hf2, fail.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H");
-  check_hip(hipMemcpy2DAsync(A, sizeof(double) * n, S.p, sizeof(double) * NP, sizeof(double) * n, n, hipMemcpyDeviceToHost, c->stream), "D2H 2D");
+  check_hip(hipMemcpyAsync(tiles.data(), S.p, sizeof(double) * tiles.size(), hipMemcpyDeviceToHost, c->stream), "D2H");
   if (rhs) check_hip(hipMemcpyAsync(rhs, x.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream), "D2H");
   check_hip(hipStreamSynchronize(c->stream), "sync");
+  for (int64_t i = 0; i < n; i++)       // the factor: lower triangle (and what the diagonal tiles hold above it, as before)
+    for (int64_t j = 0; j < std::min<int64_t>(n, (i / kTile + 1) * kTile); j++) A[i * n + j] = *hs.at(i, j);
   dpk.free(); dexp.free();
-  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free(); plan.bwd_col_off.free(); plan.bwd_col_rows.free();
+  S.free(); Dinv.free(); x.free(); fail.free(); plan.rows.free(); plan.pairs.free(); plan.bcols.free(); plan.stored.free(); plan.slot.free(); plan.bwd_col_off.free(); plan.bwd_col_rows.free();
   free_df_plan(df);
   if (hf2[1] != 0.0) throw std::runtime_error("gtg_dense_cholesky_host: a dependency wait of the factorisation ran into its bound");
   return hf2[0] != 0.0 ? GTG_INDETERMINATE : GTG_OK;
   GTG_CATCH
 }
+
+int64_t gtg_release_cached_memory(void) { return (int64_t)release_kept(-1); }
 
 }  // extern "C"

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
     const double* __restrict__ E, const double* __restrict__ ylm, double invsigma,
-    int diag, double dmin, double dmax, int add_damping, double* __restrict__ S, int NP) {
+    int diag, double dmin, double dmax, int add_damping, SMat S) {
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int i = e / d, j = e % d;
     double v = Hd[(int64_t)81 * r + e];
     if (i == j && add_damping) v += damp_term(hdiag[off + i], invsigma, diag, dmin, dmax);
-    S[(off + i) * (int64_t)NP + off + j] = v;
+    if (double* q = S.at_stored(off + i, off + j)) *q = v;
   }
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t k = inc_ptr[r] + lane; k < inc_ptr[r + 1]; k += 64) {
@@ -312,18 +312,18 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
   for (int i = 0; i < 9; i++)
     for (int s = 32; s > 0; s >>= 1) acc[i] += __shfl_down(acc[i], s, 64);
   if (lane == 0)
-    for (int i = 0; i < d; i++) S[(int64_t)NP * NP + off + i] = g[(int64_t)9 * r + i] - acc[i];
+    for (int i = 0; i < d; i++) *S.at((int64_t)kTile * S.nt, off + i) = g[(int64_t)9 * r + i] - acc[i];   // rhs row
 }
 
 __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int32_t* __restrict__ row,
     const int32_t* __restrict__ col, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
-    const double* __restrict__ Hoff, double* __restrict__ S, int NP) {
+    const double* __restrict__ Hoff, SMat S) {
   const int64_t blk = blockIdx.x;
   if (blk >= n_blocks) return;
   const int d = red_dim[row[blk]];
   if ((int)threadIdx.x >= d * d) return;
   const int i = threadIdx.x / d, j = threadIdx.x % d;
-  S[(red_off[row[blk]] + i) * (int64_t)NP + red_off[col[blk]] + j] = Hoff[(int64_t)81 * blk + threadIdx.x];
+  if (double* q = S.at_stored(red_off[row[blk]] + i, red_off[col[blk]] + j)) *q = Hoff[(int64_t)81 * blk + threadIdx.x];
 }
 
 // One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the landmarks seen
@@ -337,7 +337,7 @@ typedef double v4f64s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
-    const double* __restrict__ E, double* __restrict__ S, int NP) {
+    const double* __restrict__ E, SMat S) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = blockIdx.x * (int64_t)4 + wv;
   if (p >= n_pairs) return;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int3
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = lk + 4 * r;
-    if (row < da && lr < db) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= acc[r];
+    if (row < da && lr < db) if (double* q = S.at_stored(oa_ + row, ob_ + lr)) *q -= acc[r];
   }
 }
 
@@ -381,7 +381,7 @@ constexpr int kPairWaves = 16;
 __global__ __launch_bounds__(64 * kPairWaves) void k_schur_pairs_heavy(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
-    const double* __restrict__ E, double* __restrict__ S, int NP) {
+    const double* __restrict__ E, SMat S) {
   __shared__ double part[kPairWaves][256];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = blockIdx.x;
@@ -412,15 +412,15 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_schur_pairs_heavy(int64_t n
       double sum = 0.0;
 #pragma unroll
       for (int w = 0; w < kPairWaves; w++) sum += part[w][r * 64 + lane];
-      if (row < da && lr < db) S[(oa_ + row) * (int64_t)NP + ob_ + lr] -= sum;
+      if (row < da && lr < db) if (double* q = S.at_stored(oa_ + row, ob_ + lr)) *q -= sum;
     }
   }
 }
 
 // identity on the padded rows / columns of S (tail padding to the tile size, alignment gaps between the parts)
-__global__ void k_pad_diag(double* __restrict__ S, const int64_t* __restrict__ pad, int64_t npad, int NP) {
+__global__ void k_pad_diag(SMat S, const int64_t* __restrict__ pad, int64_t npad) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t < npad) { const int64_t i = pad[t]; S[i * NP + i] = 1.0; }
+  if (t < npad) { const int64_t i = pad[t]; *S.at(i, i) = 1.0; }
 }
 
 // ---- back-substitution ---------------------------------------------------------------------------------
@@ -564,24 +564,24 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
 
 void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax) {
   const double is = inv_sigma(lambda);
-  const int NP = c.NP;
-  launch_zero_tiles(c, c.S.p, NP, c.plan);
+  const SMat S = smat(c);
+  launch_zero_tiles(c, S, c.plan);
   if (c.n_red_vars)
     hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
-                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, c.S.p, NP);
+                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, S);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
-                       c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, c.S.p, NP);
+                       c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, S);
   if (c.n_pairs && c.n_pair_terms > 512 * c.n_pairs)   // few pairs, thousands of terms each
     hipLaunchKernelGGL(k_schur_pairs_heavy, dim3((unsigned)c.n_pairs), dim3(64 * kPairWaves), 0, c.stream, c.n_pairs, c.pair_row.p,
-                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
+                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, S);
   else if (c.n_pairs)
     hipLaunchKernelGGL(k_schur_pairs, dim3((unsigned)((c.n_pairs + 3) / 4)), dim3(256), 0, c.stream, c.n_pairs, c.pair_row.p,
-                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, c.S.p, NP);
+                       c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, S);
   const int64_t npad = (int64_t)c.h_pad_index.size();
   if (npad > 0 && c.shard == 0)
-    hipLaunchKernelGGL(k_pad_diag, dim3((unsigned)((npad + 63) / 64)), dim3(64), 0, c.stream, c.S.p, c.pad_index.p, npad, NP);
+    hipLaunchKernelGGL(k_pad_diag, dim3((unsigned)((npad + 63) / 64)), dim3(64), 0, c.stream, S, c.pad_index.p, npad);
   check_hip(hipGetLastError(), "build_reduced");
 }
 

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <map>
 #include <mutex>
@@ -96,13 +97,27 @@ __device__ __forceinline__ void stores_done() {   // this wavefront's stores are
 // a polled line is occasionally left STUCK in the poller's XCD L2 with the value it had when the polling began -- sc1 loads (served
 // by that L2) return the old flag for seconds while memory holds the new one and every other XCD sees it (about one wait in 1e8;
 // tools/df_contention_diag.py, profiles/r03_df_contention.txt).  The shadow is not polled while it changes, so it is fetched fresh.
+// Round 4: the word itself is published by a READ-MODIFY-WRITE atomic (an exchange whose result is not used), and a wait that drags
+// on also looks at the word with one (wait_flags: fetch_max with 0).  Agent-scope RMW atomics are executed at the device's point of
+// coherence -- the ticket counter of the bulk kernel relies on exactly that across the 8 XCDs -- so neither a store lingering on
+// the producer's side nor a line lingering on the poller's side can come between the two (the post-mortems of the stuck waits,
+// profiles/r04_df_handoff.txt, do not tell the two apart: all that is known is that the poller's sc1 loads kept returning an
+// older value of a word that memory held the new value of once the kernels had drained).
 __device__ __forceinline__ void st_flag(long long* p, long long v, long long sh) {
 #if GTG_DF_FENCES
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   __hip_atomic_store(p + sh, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the word as the point of coherence holds it (flags only grow: max with 0 leaves them alone); wave-uniform address: one lane asks
+__device__ __forceinline__ long long ld_flag_rmw(const long long* p) {
+  long long v = 0;
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+    v = __hip_atomic_fetch_max(const_cast<long long*>(p), 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned)lo;
 }
 // GTG_DF_SAFE (A/B builds, `make safe`): bit 0 -- additionally ONE agent-scope acquire (buffer_inv sc1) after a flag matched (the
 // guide's other valid consumer form); bit 1 -- the flag itself read by a returning read-modify-write atomic instead of an sc1 load;
@@ -151,6 +166,10 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
         if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
         break;
       }
+      if ((spins & 1023) == 512 && ld_flag_rmw(f1) >= v1 && ld_flag_rmw(f2) >= v2) {    // ... or ask the point of coherence
+        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 1, 1);   // ctrl[7]: waits that ended on the read-modify-write poll
+        break;
+      }
       if (wall_clock64() - t0 > kWaitTicks) {
         if (dbg && atomicCAS(dbg, 0, kind) == 0) {
           dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
@@ -197,8 +216,8 @@ __device__ __forceinline__ int wait_progress(const long long* f1, const long lon
 constexpr int kBulkThreads = 1024;
 
 template <int H>
-__device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int NP, int nt, int I, int J,
-                                           long long* __restrict__ tile_flag, double* __restrict__ Xinv_all,
+__device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
+                                           long long* __restrict__ myflag, const long long* __restrict__ pflag, double* __restrict__ Xinv_all,
                                            double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg,
                                            long long* __restrict__ tr) {
   // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
@@ -216,11 +235,10 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   constexpr int h = H;
   const int lr = lane & 15, lk = lane >> 4;
   const long long flagbase = epoch * 8;
-  const unsigned lane_off = (unsigned)(lk * NP + lr);
-  double* Crow = C + (int64_t)(16 * rt) * NP + 64 * h;
+  const unsigned lane_off = (unsigned)(lk * T + lr);
+  double* Crow = C + (16 * rt) * T + 64 * h;
   const double* Xinv = Xinv_all + (size_t)J * T * T;
-  const long long* pflag = tile_flag + (int64_t)J * nt + J;   // the diagonal tile's progress word (released panels): the diagonal of the flag array
-  long long* myflag = tile_flag + (int64_t)I * nt + J;
+  // pflag: the diagonal tile's progress word (released panels) = the flag word of tile (J, J); myflag: the word of this tile
   double* W = reinterpret_cast<double*>(smem_raw) + rt * (16 * PX);
   double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
   long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
@@ -299,7 +317,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
         for (int r = 0; r < 4; r++) {
           const double v = x[2 * l + t][r];
           W[(lk + 4 * r) * PX + 16 * t + lr] = -v;   // negated: the A operand of the next step's updates
-          st_wt((Crow + (int64_t)(4 * r) * NP + 32 * l + 16 * t) + lane_off, v);
+          st_wt((Crow + (4 * r) * T + 32 * l + 16 * t) + lane_off, v);
         }
     }
   }
@@ -309,7 +327,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 }
 
 
-__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int NP, int nt, int I, int J,
+__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
@@ -322,11 +340,9 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 1, h = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  double* C = S + ((int64_t)I * T) * NP + (int64_t)J * T;
-  const double* Arow = S + ((int64_t)I * T) * NP;
-  const double* Brow = S + ((int64_t)J * T) * NP;
-  const long long* fI = tile_flag + (int64_t)I * nt;
-  const long long* fJ = tile_flag + (int64_t)J * nt;
+  // slotC: the slot of tile (I, J), slotD: of the diagonal tile (J, J); a contraction step is the pair of slots of its two operand
+  // tiles (I, k), (J, k) -- tiles and their flag words are both indexed by slot
+  double* C = S + (int64_t)slotC * TT;
   const long long fin = final_of(epoch);
   const long long flagbase = epoch * 8;
 
@@ -340,18 +356,18 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     for (int q = 0; q < 2; q++) {
       const int row = 8 * wave + 4 * q + drow;
       const int logical = dslot ^ (row & 15);
-      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
-      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+      const double* ga = Ap + row * T + ch * KC + 2 * logical;
+      const double* gb = Bp + row * T + ch * KC + 2 * logical;
       __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (2 * wave + q) * 1024), 16, 0, kHandoffAux);
       __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (2 * wave + q) * 1024), 16, 0, kHandoffAux);
     }
   };
 
   // element (c, r) of this lane: row 16 rt + lk + 4 r, column 64 h + 16 c + lr -- uniform part + one 32-bit lane offset
-  const unsigned lane_off = (unsigned)(lk * NP + lr);
-  double* Crow = C + (int64_t)(16 * rt) * NP + 64 * h;
+  const unsigned lane_off = (unsigned)(lk * T + lr);
+  double* Crow = C + (16 * rt) * T + 64 * h;
   v4f64 x[4];
-  long long* pflag_mine = part_flag + (int64_t)I * nt + J;
+  long long* pflag_mine = part_flag + slotC;
   if (piece > 0) {
     // the tile holds the earlier pieces' partial result, written (write-through) by other workgroups -- possibly while an older
     // version of it sat in this XCD's L2 (a piece before that one may have run here): read it past the L2
@@ -360,12 +376,12 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     for (int c = 0; c < 4; c++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        x[c][r] = __hip_atomic_load((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x[c][r] = __hip_atomic_load((Crow + (4 * r) * T + 16 * c) + lane_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) x[c][r] = (Crow + (int64_t)(4 * r) * NP + 16 * c)[lane_off];
+      for (int r = 0; r < 4; r++) x[c][r] = (Crow + (4 * r) * T + 16 * c)[lane_off];
   }
 
   if (kcnt > 0) {
@@ -373,29 +389,29 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     // while its substitution runs: a chunk only waits for the block it reads.  For every step but the most recent ones both
     // tiles are long final and the test is a scalar compare; for the last step (block column J-1, whose tiles become final
     // behind the diagonal tile that is being factored right now) the contraction streams behind the substitution.
-    int k = kl[0];
-    int cp = wait_progress(fI + k, fJ + k, flagbase, 1, fail, sh, dbg, 1, I, J, k);   // progress known for the current step
-    const double* Ak = Arow + (int64_t)k * T;
-    const double* Bk = Brow + (int64_t)k * T;
+    int ka = kl[0], kb = kl[1];
+    int cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, 1, fail, sh, dbg, 1, I, J, ka);   // progress known for the current step
+    const double* Ak = S + (int64_t)ka * TT;
+    const double* Bk = S + (int64_t)kb * TT;
     stage(Ak, Bk, 0, 0);
     __syncthreads();
     const int a_row_off = (16 * rt + lr) * ROWB, b_row_off = (64 * h + lr) * ROWB;
     const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr;
     for (int ki = 0; ki < kcnt; ki++) {
       // the flags of the next contraction step, fetched a whole step ahead of their use
-      const int kn = (ki + 1 < kcnt) ? kl[ki + 1] : k;
-      int np = tile_progress(fI + kn, fJ + kn, flagbase);
-      const double* An = Arow + (int64_t)kn * T;
-      const double* Bn = Brow + (int64_t)kn * T;
+      const int kna = (ki + 1 < kcnt) ? kl[2 * ki + 2] : ka, knb = (ki + 1 < kcnt) ? kl[2 * ki + 3] : kb;
+      int np = tile_progress(tile_flag + kna, tile_flag + knb, flagbase);
+      const double* An = S + (int64_t)kna * TT;
+      const double* Bn = S + (int64_t)knb * TT;
 #pragma unroll
       for (int ch = 0; ch < T / KC; ch++) {
         const int cur = ch & 1;
         if (ch + 1 < T / KC) {
           const int need = ch + 2;   // chunk ch + 1 = the operand tiles' 32-column block ch + 1
-          if (cp < need) { cp = tile_progress(fI + k, fJ + k, flagbase); if (cp < need) cp = wait_progress(fI + k, fJ + k, flagbase, need, fail, sh, dbg, 2, I, J, k); }
+          if (cp < need) { cp = tile_progress(tile_flag + ka, tile_flag + kb, flagbase); if (cp < need) cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, need, fail, sh, dbg, 2, I, J, ka); }
           stage(Ak, Bk, ch + 1, cur ^ 1);
         } else if (ki + 1 < kcnt) {
-          if (np < 1) np = wait_progress(fI + kn, fJ + kn, flagbase, 1, fail, sh, dbg, 2, I, J, kn);
+          if (np < 1) np = wait_progress(tile_flag + kna, tile_flag + knb, flagbase, 1, fail, sh, dbg, 2, I, J, kna);
           stage(An, Bn, 0, cur ^ 1);
         }
         const char* Ac = smem_raw + cur * 2 * CH;
@@ -412,7 +428,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         }
         __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
       }
-      k = kn; Ak = An; Bk = Bn; cp = np;
+      ka = kna; kb = knb; Ak = An; Bk = Bn; cp = np;
     }
   }
   if (tr && tid == 0) tr[1] = wall_clock64();
@@ -421,7 +437,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
+      for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
     if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + piece + 1, sh);
@@ -432,7 +448,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) st_wt((Crow + (int64_t)(4 * r) * NP + 16 * c) + lane_off, x[c][r]);
+      for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
     if (tid == 0) st_flag(pd_flag + J, fin, sh);
@@ -441,11 +457,11 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (h == 0) substitute<0>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, sh, dbg, tr);
-  else substitute<1>(smem_raw, x, C, NP, nt, I, J, tile_flag, Xinv_all, fail, epoch, sh, dbg, tr);
+  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
+  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
 }
 
-__device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+__device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, const int32_t* __restrict__ tasks,
                                           int ntasks, const int32_t* __restrict__ klist,
                                           long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                           long long* __restrict__ pd_flag,
@@ -459,7 +475,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 6 * (int64_t)t;
+    const int32_t* d = tasks + 8 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J)
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -470,13 +486,13 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
 #if (GTG_DF_SAFE & 4)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and at the start of every task
 #endif
-    run_task(smem_raw, S, NP, nt, d[0], d[1], klist + d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
 }
 
-__global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+__global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S, const int32_t* __restrict__ tasks,
                                                     int ntasks, const int32_t* __restrict__ klist,
                                                     long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                                     long long* __restrict__ pd_flag,
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     double* __restrict__ fail, const long long epoch, const long long sh,
                                                     long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
 // one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
@@ -511,9 +527,9 @@ __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, i
 // bring it into LDS, apply  C -= L(J,J-1) L(J,J-1)^T  in four 32-column slices as the substitution of tile (J, J-1) publishes
 // them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
 // substitution steps of the tiles below through the tile's progress word).
-__device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
+__device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, double* __restrict__ Xinv_all,
                                            const long long* __restrict__ pd_flag, long long* tile_flag,
-                                           const int32_t* __restrict__ has_sub, double* __restrict__ fail,
+                                           const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                            const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
                                            const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
@@ -526,11 +542,12 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     __syncthreads();
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
-    const double* tile = S + ((int64_t)J * T) * NP + (int64_t)J * T;
-    diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, NP, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
-    if (has_sub[J]) {
-      const double* sub = tile - T;   // tile (J, J-1)
-      const long long* sflag = tile_flag + (int64_t)J * nt + (J - 1);
+    const int dslot = chain_slots[2 * J], sslot = chain_slots[2 * J + 1];   // slots of (J, J) and of (J, J-1) (-1: not stored)
+    double* tile = S + (int64_t)dslot * TT;
+    diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
+    if (sslot >= 0) {
+      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
+      const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
         if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
@@ -541,7 +558,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
-            const double* src = sub + (int64_t)row * NP + SB * q + c2;   // X_q of the substitution: handed over (sc1 loads)
+            const double* src = sub + row * T + SB * q + c2;   // X_q of the substitution: handed over (sc1 loads)
 #if GTG_DF_FENCES
             v[u] = *reinterpret_cast<const double2*>(src);
 #else
@@ -565,21 +582,21 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, S, NP, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + (int64_t)J * nt + J, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
+    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
 }
 
-__global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int NP, int nt, double* __restrict__ Xinv_all,
+__global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, double* __restrict__ Xinv_all,
                                                      const long long* __restrict__ pd_flag, long long* tile_flag,
-                                                     const int32_t* __restrict__ has_sub, double* __restrict__ fail,
+                                                     const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                                      const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
                                                      const int32_t* __restrict__ chain_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
+  chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
              chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
 }
 
@@ -587,21 +604,21 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, int
 // anybody waits for them; their upper eight wavefronts leave at once), the others take the tile tasks.  The chain's code is
 // compiled for the bulk kernel's 128 registers here (it spills: slower than the two-kernel form) but it is a single dispatch: this is the form rocprofv3's counter collection, which
 // serialises kernels, can measure -- two kernels that wait for each other never finish under it.
-__global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__ S, int NP, int nt, const int32_t* __restrict__ tasks,
+__global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__ S, const int32_t* __restrict__ tasks,
                                                       int ntasks, const int32_t* __restrict__ klist,
                                                       long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                                       long long* __restrict__ pd_flag,
-                                                      const int32_t* __restrict__ has_sub, double* __restrict__ Xinv_all,
+                                                      const int32_t* __restrict__ chain_slots, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
                                                       const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, NP, nt, Xinv_all, pd_flag, tile_flag, has_sub, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
-  else bulk_loop(smem_raw, S, NP, nt, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
+  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
-__global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; ctrl[6] = 0; }
+__global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
 
 }  // namespace
 
@@ -609,6 +626,7 @@ __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *
 // tile_struct: (nt x nt) row-major bytes, lower triangle: tile (I, J) holds something before the factorisation
 // (nullptr = dense).  Symbolic elimination at tile granularity adds the fill; the rhs row (tile row nt) is dense.
 void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t stream,
+                   const std::vector<int32_t>& slot, int64_t n_slots,
                    const std::vector<int32_t>* tile_part, const std::vector<int32_t>* part_parent) {
   std::vector<uint8_t> B((size_t)nt * nt, 0);
   for (int i = 0; i < nt; i++)
@@ -749,14 +767,42 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (df.h_klist.empty()) df.h_klist.push_back(0);
-  df.tasks.upload(df.h_tasks.data(), df.h_tasks.size(), stream);
-  df.has_sub.upload(has_sub.data(), has_sub.size(), stream);
+  // Device form: tiles AND their flag words are addressed by SLOT (context.h::SMat; the slots come from the stream schedule's plan,
+  // whose stored set -- fill at the granularity of column pairs -- contains this one).  A task carries the slots of its tile and of
+  // its diagonal tile, a contraction step the slots of its two operand tiles; h_tasks / h_klist keep the tile coordinates (debug
+  // getters, tests/test_chol_plan.py).
+  auto slot_of = [&](int I, int J) {
+    const int32_t q = slot[(size_t)I * nt + J];
+    if (q < 0) throw std::runtime_error("dataflow plan: a tile of the task list has no slot in the stored-tile list");
+    return q;
+  };
+  {
+    std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 8);
+    std::vector<int32_t> dk(2 * df.h_klist.size(), 0);
+    std::vector<uint8_t> seen(df.h_klist.size(), 0);
+    for (int64_t t = 0; t < df.n_tasks; t++) {
+      const int32_t* d = df.h_tasks.data() + 6 * t;
+      const int I = d[0], J = d[1];
+      for (int x = 0; x < 6; x++) dt.push_back(d[x]);
+      dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
+      for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
+        const int k = df.h_klist[e];
+        dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);
+        seen[e] = 1;
+      }
+    }
+    df.tasks.upload(dt.data(), dt.size(), stream);
+    df.klist.upload(dk.data(), dk.size(), stream);
+    std::vector<int32_t> cs(2 * (size_t)nt, -1);
+    for (int J = 0; J < nt; J++) { cs[2 * J] = slot_of(J, J); if (has_sub[J]) cs[2 * J + 1] = slot_of(J, J - 1); }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1)
+    check_hip(hipStreamSynchronize(stream), "df plan upload");
+  }
   df.h_has_sub = has_sub;
-  df.klist.upload(df.h_klist.data(), df.h_klist.size(), stream);
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
-  df.shadow = ((int64_t)(nt + 1) * nt + 511) / 512 * 512;
+  df.shadow = (n_slots + 511) / 512 * 512;   // (flag words by slot)
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
@@ -772,9 +818,10 @@ void free_df_plan(DfPlan& df) {
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
-void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail,
+void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xinv, double* fail,
                         const unsigned char* pivot_kind, double* tile_exp) {
   const int nt = NP / T;
+  double* S = Sm.p;
   if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
   static std::set<int> attr_set;
   static std::mutex attr_mutex;
@@ -829,7 +876,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
-    hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, NP, nt, df.tasks.p, (int)df.n_tasks,
+    hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
                        df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
                        df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
@@ -840,14 +887,17 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   check_hip(hipStreamWaitEvent(ds.bulk, ds.ev_start, 0), "wait");
   // test hook (tests/test_gpu_dataflow_protocol.py): GTG_DF_TEST_TIMEOUT=n leaves the chain kernel out of the process's n-th dataflow
   // factorisation -- the bulk kernel's waits then run into their bound, exactly what a chain kernel that was never placed looks like
+  // ("n:m": out of m consecutive ones from the n-th on -- two in a row make the repeated try time out as well)
   static const int drop_at = getenv("GTG_DF_TEST_TIMEOUT") ? atoi(getenv("GTG_DF_TEST_TIMEOUT")) : 0;
+  static const int drop_n = (getenv("GTG_DF_TEST_TIMEOUT") && strchr(getenv("GTG_DF_TEST_TIMEOUT"), ':')) ? atoi(strchr(getenv("GTG_DF_TEST_TIMEOUT"), ':') + 1) : 1;
   static std::atomic<int> launches{0};
-  const bool drop_chain = drop_at > 0 && ++launches == drop_at;
+  const int launch_no = ++launches;
+  const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
-  hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, NP, nt, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
+  hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
-  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+  hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
@@ -859,7 +909,7 @@ void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* X
   // mask) starved the chain -- wait bounds hit.
   static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
   if (extra > 0 && df.n_tasks > grid)
-    hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, NP, nt, df.tasks.p, (int)df.n_tasks, df.klist.p,
+    hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
                        df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");

@@ -9,6 +9,7 @@ namespace gt {
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int T = kTile;        // 128
+constexpr int TT = kTileDoubles;  // doubles of one tile slot (context.h::SMat)
 constexpr int SB = 32;          // sub-block of the diagonal tile
 constexpr int P = T + 2;        // LDS pitch of a full tile: (2*P) % 64 == 4 -> MFMA operand reads conflict-free
 constexpr int PB = SB + 2;      // LDS pitch inside a 32x32 sub-block of the packed diagonal tile
@@ -30,14 +31,14 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // 128x128 tile (global, ld = NP) <-> LDS (pitch PL doubles); 16-byte accesses, 16 loads in flight per lane
 template <int PL>
-__device__ __forceinline__ void tile_to_lds(const double* __restrict__ tile, int NP, double* __restrict__ L, int tid) {
+__device__ __forceinline__ void tile_to_lds(const double* __restrict__ tile, double* __restrict__ L, int tid) {
 #pragma unroll
   for (int e0 = 0; e0 < T * (T / 2); e0 += 256 * 16) {
     double2 v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int e = e0 + u * 256 + tid;
-      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
+      v[u] = *reinterpret_cast<const double2*>(tile + (e / (T / 2)) * T + 2 * (e % (T / 2)));
     }
 #pragma unroll
     for (int u = 0; u < 16; u++) {
@@ -303,14 +304,14 @@ __device__ __forceinline__ void tile_task(double* A, int jb, int ib, int cb, int
 
 // write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
 // strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
-__device__ __forceinline__ void store_column(const double* A, double* tile, int NP, double* Xinv, int jb, int t, int nthreads, bool wt = false) {
+__device__ __forceinline__ void store_column(const double* A, double* tile, double* Xinv, int jb, int t, int nthreads, bool wt = false) {
   for (int e = t; e < (4 - jb) * 512; e += nthreads) {
     const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
     const double* sp = A + boff(ib, jb) + r * PB + c;
     double2 v;
     v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
     v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
-    *reinterpret_cast<double2*>(tile + (int64_t)(SB * ib + r) * NP + SB * jb + c) = v;   // (the tile itself is read by later kernels only)
+    *reinterpret_cast<double2*>(tile + (SB * ib + r) * T + SB * jb + c) = v;   // (the tile itself is read by later kernels only)
     if (ib != jb) {
       double* o = Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c);
       if (wt) { st_pub(o, v.x, true); st_pub(o + 1, v.y, true); } else *reinterpret_cast<double2*>(o) = v;
@@ -332,14 +333,14 @@ constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress wor
 // with agent-scope (sc1) loads, which are served past this CU's L1 -- the consumer half of the hand-off (8-byte accesses: the widest
 // a relaxed agent-scope load lowers to)
 template <bool SC1 = false>
-__device__ __forceinline__ void diag_tile_to_lds(const double* tile, int NP, double* __restrict__ A, int tid) {
+__device__ __forceinline__ void diag_tile_to_lds(const double* tile, double* __restrict__ A, int tid) {
   double2 v[10];
 #pragma unroll
   for (int u = 0; u < 10; u++) {
     const int e = u * 512 + tid, blk = e >> 9, w = e & 511;
     int ib = 0, rem = blk;
     while (rem > ib) { rem -= ib + 1; ib++; }
-    const double* src = tile + (int64_t)(SB * ib + (w >> 4)) * NP + SB * rem + 2 * (w & 15);
+    const double* src = tile + (SB * ib + (w >> 4)) * T + SB * rem + 2 * (w & 15);
     if constexpr (SC1) {
       v[u].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       v[u].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -355,7 +356,7 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* tile, int NP, dou
   }
 }
 
-__device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ S, int NP, int k, double* __restrict__ Xinv,
+__device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ tile, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
                                            const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr) {
@@ -369,13 +370,12 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
   if (tid == 0) { prog[0] = 0; prog[1] = 0; }
   STAMP(0);
-  if (!preloaded) diag_tile_to_lds(tile, NP, A, tid);   // (preloaded: the caller filled the image and synchronises below)
+  if (!preloaded) diag_tile_to_lds(tile, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();
   STAMP(1);
   // rank test at the variables' block ends (see stage_potrf): pivot kinds of this tile's columns, exponent of the pivot before it
@@ -405,7 +405,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
         while (rem > bi) { rem -= bi + 1; bi++; }
         tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
       }
-      store_column(A, tile, NP, Xinv, pj, hw * 64 + lane, nh * 64, wt);
+      store_column(A, tile, Xinv, pj, hw * 64 + lane, nh * 64, wt);
     }
     // Panel jb is released to the workgroups waiting for it (the TRSM workgroups of this launch / the substitutions of the dataflow
     // schedule) once its inverse and every L(jb, q<jb) operand image are in memory.
@@ -423,8 +423,8 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     __syncthreads();
     if (tid == 0 && !late)
     {
-      __hip_atomic_store(pflag, flagbase + jb + 1, wt ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      if (wt) (void)__hip_atomic_exchange(pflag, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (chol_dataflow.hip::st_flag)
+      else __hip_atomic_store(pflag, flagbase + jb + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (pflag_shadow) __hip_atomic_store(pflag + pflag_shadow, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // chol_dataflow.hip::st_flag
     }
     STAMP(2 + 3 * jb);
@@ -435,12 +435,12 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     __syncthreads();
     if (tid == 0 && late)
     {
-      __hip_atomic_store(pflag, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_exchange(pflag, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (chol_dataflow.hip::st_flag)
       if (pflag_shadow) __hip_atomic_store(pflag + pflag_shadow, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     STAMP(4 + 3 * jb);
   }
-  store_column(A, tile, NP, Xinv, 3, tid, 512, wt);
+  store_column(A, tile, Xinv, 3, tid, 512, wt);
   STAMP(14);
 }
 

@@ -4,8 +4,8 @@
 // Eigen LLT + TRSM + SYRK) does on the root clique(s) of the reduced camera system, and
 // GaussianBayesTree::optimize (linear/linearAlgorithms-inst.h:49-155) does for the back-substitution.
 //
-// Layout: S row-major, lower triangle, ld = NP (multiple of 128), followed by one extra 128-row tile
-// whose row 0 holds the right-hand side: carrying it through TRSM + trailing updates performs the
+// Layout: S BY TILES (chol_device.h::SMat): one contiguous 128 x 128 slot per stored tile of the lower triangle, plus the
+// tiles of one extra tile row whose row 0 holds the right-hand side: carrying it through TRSM + trailing updates performs the
 // forward solve L y = g for free (the reference does the same with its augmented [H g; g^T f] matrix,
 // HessianFactor.cpp:239-252).
 //
@@ -50,7 +50,7 @@ constexpr int TR = 64;   // rows per TRSM workgroup
 // a dependency wait inside a launch (TRSM workgroups behind workgroup 0; the backward sweep) gives up after 100 ms of the 100 MHz constant
 // clock and raises fail[1] (SC_TIMEOUT: an error, never numbers) -- the bound used to be millions of polls, seconds per stuck wait
 constexpr long long kEventWaitTicks = 10000000;
-__device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S, int NP, int k, int wg,
+__device__ __forceinline__ void trsm_body(char* smem_raw, SMat S, int k, int wg,
                                           const int32_t* __restrict__ rows, double* __restrict__ Xinv,
                                           double* __restrict__ fail, long long epoch) {
   const long long flagbase = epoch * 8;
@@ -60,14 +60,14 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int r0 = 16 * (wave >> 1), tj = wave & 1;
-  double* tile = S + ((int64_t)I * T + half_rows) * NP + (int64_t)k * T;
+  double* tile = S.tile(I, k) + half_rows * T;
   const long long* flag = reinterpret_cast<const long long*>(Xinv + kFlagOff);
   {
     double2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int e = u * 512 + tid;
-      v[u] = *reinterpret_cast<const double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2)));
+      v[u] = *reinterpret_cast<const double2*>(tile + (e / (T / 2)) * T + 2 * (e % (T / 2)));
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -133,7 +133,7 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
     const int row = e / (T / 2), pc = e % (T / 2);
     double2 v;
     v.x = Xs[row * P + 2 * pc]; v.y = Xs[row * P + 2 * pc + 1];
-    *reinterpret_cast<double2*>(tile + (int64_t)row * NP + 2 * pc) = v;
+    *reinterpret_cast<double2*>(tile + row * T + 2 * pc) = v;
   }
 }
 
@@ -142,13 +142,13 @@ __device__ __forceinline__ void trsm_body(char* smem_raw, double* __restrict__ S
 // p of the diagonal tile, so that when the diagonal tile is done only the last phase of the TRSM is left: the TRSM's
 // latency leaves the serial panel chain.  Workgroup 0 never waits for the others (no deadlock, whatever the dispatch
 // order), the release/acquire pair is agent scope (L2 write-back / invalidate across XCDs).
-__global__ __launch_bounds__(512, 2) void k_panel128(double* __restrict__ S, int NP, int k, const int32_t* __restrict__ rows,
+__global__ __launch_bounds__(512, 2) void k_panel128(SMat S, int k, const int32_t* __restrict__ rows,
                                                      double* __restrict__ Xinv, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, long long epoch,
                                                      const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x == 0) potrf_body(smem_raw, S, NP, k, Xinv, fail, dbg, epoch, reinterpret_cast<long long*>(Xinv + kFlagOff), 64, false, false, pivot_kind, tile_exp);
-  else trsm_body(smem_raw, S, NP, k, (int)blockIdx.x - 1, rows, Xinv, fail, epoch);
+  if (blockIdx.x == 0) potrf_body(smem_raw, S.tile(k, k), k, Xinv, fail, dbg, epoch, reinterpret_cast<long long*>(Xinv + kFlagOff), 64, false, false, pivot_kind, tile_exp);
+  else trsm_body(smem_raw, S, k, (int)blockIdx.x - 1, rows, Xinv, fail, epoch);
 }
 __global__ void k_set_epoch(long long* epoch, long long value) { *epoch = value; }
 
@@ -182,7 +182,7 @@ constexpr int STI = 8, STJ = 4;
 // Q = 2 is the latency variant for the small launches on the serial panel chain (thin update, look-ahead columns):
 // a workgroup owns a 64x64 quadrant (wavefront = 16x32), four times as many workgroups each a quarter as long.
 template <int KT, int ABL = 0, int Q = 1>   // ABL: ablation bits for tools/ (1 no DMA, 2 no C load, 4 no C store, 8 no MFMA)
-__global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP, int ktile0,
+__global__ __launch_bounds__(512, 4) void k_syrk(SMat S, int ktile0,
                                                  const int32_t* __restrict__ pairs, int npairs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];   // [2 buffers][A chunk | B chunk]
   // the quadrant variant only runs on the serial chain: its waves win issue arbitration (MFMA pipe, LDS) against the
@@ -199,9 +199,11 @@ __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP,
   const int idx = item / (Q * Q), qi = (item % (Q * Q)) / Q, qj = item % Q;
   const int I = pairs[2 * idx], J = pairs[2 * idx + 1];
   if (Q > 1 && I == J && qj > qi) return;   // strictly-upper quadrant of a diagonal tile: never read
-  const double* Ap = S + ((int64_t)I * T + qi * RW) * NP + (int64_t)ktile0 * T;
-  const double* Bp = S + ((int64_t)J * T + qj * RW) * NP + (int64_t)ktile0 * T;
-  double* C = S + ((int64_t)I * T + qi * RW) * NP + (int64_t)J * T + qj * RW;
+  // the KT operand tiles of the two row panels (contraction over the block columns ktile0 .. ktile0 + KT - 1) and the target
+  const double* Ap[KT]; const double* Bp[KT];
+#pragma unroll
+  for (int t = 0; t < KT; t++) { Ap[t] = S.tile(I, ktile0 + t) + qi * RW * T; Bp[t] = S.tile(J, ktile0 + t) + qj * RW * T; }
+  double* C = S.tile(I, J) + qi * RW * T + qj * RW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves: rows 16 TI wr .., cols 16 TJ wc ..
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP,
     for (int q = 0; q < NQ; q++) {
       const int row = 8 * (NQ * wave + q) + drow;
       const int logical = dslot ^ ((row >> 1) & 7);
-      const double* ga = Ap + (int64_t)row * NP + ch * KC + 2 * logical;
-      const double* gb = Bp + (int64_t)row * NP + ch * KC + 2 * logical;
+      const double* ga = Ap[(ch * KC) / T] + row * T + (ch * KC) % T + 2 * logical;
+      const double* gb = Bp[(ch * KC) / T] + row * T + (ch * KC) % T + 2 * logical;
       __builtin_amdgcn_global_load_lds((gptr_t)ga, (lptr_t)(base + (NQ * wave + q) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)(base + CH + (NQ * wave + q) * 1024), 16, 0, 0);
     }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP,
     for (int tj = 0; tj < TJ; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        acc[ti][tj][r] = (ABL & 2) ? 0.0 : C[(int64_t)(wr * 16 * TI + ti * 16 + lk + 4 * r) * NP + wc * 16 * TJ + tj * 16 + lr];
+        acc[ti][tj][r] = (ABL & 2) ? 0.0 : C[(wr * 16 * TI + ti * 16 + lk + 4 * r) * T + wc * 16 * TJ + tj * 16 + lr];
   __syncthreads();
   // operand byte offsets inside a chunk: row R = 16 TI wr (or 16 TJ wc) + 16 t + lr ((R >> 1) & 7 == lr >> 1), column kk + lk;
   // half-wave = 16 rows x 2 halves of one slot: bank = 32 (lr & 1) + 4 (slot ^ (lr >> 1)) + 2 (lk & 1): all distinct
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk(double* __restrict__ S, int NP,
     for (int tj = 0; tj < TJ; tj++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (!(ABL & 4) || acc[ti][tj][r] == 123.456) C[(int64_t)(wr * 16 * TI + ti * 16 + lk + 4 * r) * NP + wc * 16 * TJ + tj * 16 + lr] = acc[ti][tj][r];
+        if (!(ABL & 4) || acc[ti][tj][r] == 123.456) C[(wr * 16 * TI + ti * 16 + lk + 4 * r) * T + wc * 16 * TJ + tj * 16 + lr] = acc[ti][tj][r];
 }
 
 long long* g_potrf_dbg = nullptr;   // debug: cycle stamps of the last k_potrf128 (see gtg_debug_potrf_stamps)
@@ -396,27 +398,35 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
   plan.bcols.upload(bcols.data(), bcols.size(), stream);
   plan.n_stored = (int64_t)stored_list.size() / 2;
   plan.stored.upload(stored_list.data(), stored_list.size(), stream);
+  // tile -> slot (chol_device.h::SMat): the stored tiles in list order
+  plan.h_slot.assign((size_t)(nt + 1) * nt, -1);
+  for (int64_t q = 0; q < plan.n_stored; q++) {
+    int32_t& sl = plan.h_slot[(size_t)stored_list[2 * q] * nt + stored_list[2 * q + 1]];
+    if (sl >= 0) throw std::runtime_error("cholesky plan: a tile is listed twice");
+    sl = (int32_t)q;
+  }
+  plan.slot.upload(plan.h_slot.data(), plan.h_slot.size(), stream);
   check_hip(hipStreamSynchronize(stream), "plan upload");
 }
 
 // Multi-GPU exchange helper: copy the stored tiles of S into / out of a contiguous buffer, so that the all-reduce of
 // the partial reduced systems carries only the stored lower tiles (not the dense (NP+128) x NP array).
-__global__ __launch_bounds__(256) void k_pack_tiles(double* __restrict__ S, int NP, const int32_t* __restrict__ tiles,
+__global__ __launch_bounds__(256) void k_pack_tiles(SMat S, const int32_t* __restrict__ tiles,
                                                     double* __restrict__ buf, int unpack) {
   const int I = tiles[2 * blockIdx.x], J = tiles[2 * blockIdx.x + 1];
-  double* tile = S + ((int64_t)I * T) * NP + (int64_t)J * T;
+  double* tile = S.tile(I, J);
   double* b = buf + (int64_t)blockIdx.x * T * T;
 #pragma unroll 8
   for (int e = threadIdx.x; e < T * (T / 2); e += 256) {
     const int r = e / (T / 2), c2 = 2 * (e % (T / 2));
-    double2* g = reinterpret_cast<double2*>(tile + (int64_t)r * NP + c2);
+    double2* g = reinterpret_cast<double2*>(tile + r * T + c2);
     double2* p = reinterpret_cast<double2*>(b + r * T + c2);
     if (unpack) *g = *p; else *p = *g;
   }
 }
 // The same exchange at block granularity: the structurally non-zero d x d blocks of the reduced system (81-double slots),
 // then the rhs row (NP doubles), then the padding diagonal.  HBM-bound gather / scatter of 72-byte row segments.
-__global__ __launch_bounds__(256) void k_pack_blocks(double* __restrict__ S, int NP, int64_t n_xb, const int64_t* __restrict__ row_off,
+__global__ __launch_bounds__(256) void k_pack_blocks(SMat S, int NP, int64_t n_xb, const int64_t* __restrict__ row_off,
                                                      const int64_t* __restrict__ col_off, const int32_t* __restrict__ dims,
                                                      const int64_t* __restrict__ pad, int64_t npad, double* __restrict__ buf, int unpack) {
   const int64_t nblk = 81 * n_xb, total = nblk + NP + npad;
@@ -426,18 +436,19 @@ __global__ __launch_bounds__(256) void k_pack_blocks(double* __restrict__ S, int
       const int64_t b = idx / 81;
       const int e = (int)(idx - 81 * b), i = e / 9, j = e - 9 * i, d = dims[b];
       if (i >= (d & 255) || j >= (d >> 8)) { if (!unpack) buf[idx] = 0.0; continue; }
-      s = S + (row_off[b] + i) * (int64_t)NP + col_off[b] + j;
+      s = S.at_stored(row_off[b] + i, col_off[b] + j);
+      if (!s) { if (!unpack) buf[idx] = 0.0; continue; }   // (an entry of a straddling block in the upper triangle: no slot, never read)
     } else if (idx < nblk + NP) {
-      s = S + (int64_t)NP * NP + (idx - nblk);
+      s = S.at(NP, idx - nblk);
     } else {
       const int64_t q = pad[idx - nblk - NP];
-      s = S + q * (int64_t)NP + q;
+      s = S.at(q, q);
     }
     if (unpack) *s = buf[idx]; else buf[idx] = *s;
   }
 }
 int64_t exchange_block_doubles(const gtg_context& c) { return 81 * c.n_xb + c.NP + (int64_t)c.h_pad_index.size(); }
-void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack) {
+void launch_pack_blocks(gtg_context& c, SMat S, int NP, double* buf, bool unpack) {
   const int64_t total = exchange_block_doubles(c);
   const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
   hipLaunchKernelGGL(k_pack_blocks, dim3(grid), dim3(256), 0, c.stream, S, NP, c.n_xb, c.xb_row_off.p, c.xb_col_off.p, c.xb_dim.p,
@@ -445,21 +456,12 @@ void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unp
   check_hip(hipGetLastError(), "pack_blocks");
 }
 // zero the stored tiles of S (the others are never read): what the per-try rebuild of the reduced system needs
-// instead of a memset of the whole (NP + 128) x NP array (29 GB for a 20 000-pose 2-D graph, 99 % of it unused)
-__global__ __launch_bounds__(256) void k_zero_tiles(double* __restrict__ S, int NP, const int32_t* __restrict__ tiles) {
-  const int I = tiles[2 * blockIdx.x], J = tiles[2 * blockIdx.x + 1];
-  double* tile = S + ((int64_t)I * T) * NP + (int64_t)J * T;
-  const double2 z = {0.0, 0.0};
-#pragma unroll 8
-  for (int e = threadIdx.x; e < T * (T / 2); e += 256)
-    *reinterpret_cast<double2*>(tile + (int64_t)(e / (T / 2)) * NP + 2 * (e % (T / 2))) = z;
+// (the slots ARE the stored tiles: one memset of the slot array)
+void launch_zero_tiles(gtg_context& c, SMat S, const CholPlan& plan) {
+  check_hip(hipMemsetAsync(S.p, 0, sizeof(double) * (size_t)plan.n_stored * TT, c.stream), "zero tiles");
 }
-void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan) {
-  hipLaunchKernelGGL(k_zero_tiles, dim3((unsigned)plan.n_stored), dim3(256), 0, c.stream, S, NP, plan.stored.p);
-  check_hip(hipGetLastError(), "zero_tiles");
-}
-void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack) {
-  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_exch), dim3(256), 0, c.stream, S, NP, plan.exch.p, buf, unpack ? 1 : 0);
+void launch_pack_tiles(gtg_context& c, SMat S, const CholPlan& plan, double* buf, bool unpack) {
+  hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)plan.n_exch), dim3(256), 0, c.stream, S, plan.exch.p, buf, unpack ? 1 : 0);
   check_hip(hipGetLastError(), "pack_tiles");
 }
 
@@ -472,7 +474,7 @@ void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, 
 // when it is needed, so it costs one barrier packet (~3 us measured) instead of a fresh signal round trip (~13 us).
 // rest(p) starts after nar(p) so that the two never share CUs (two small MFMA launches side by side double each
 // other's latency).  panel(k) is ONE launch (k_panel128): the diagonal tile and, streamed behind it, the TRSM below.
-void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail,
+void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, double* Xinv, double* fail,
                      const unsigned char* pivot_kind, double* tile_exp) {
   CholStreams& g_cs = c.cs;
   TreeStreams& g_ts = c.ts;
@@ -533,7 +535,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
     double* Xk = Xinv + (size_t)k * T * T;
     hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), sp,
-                       S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
+                       S, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
@@ -544,10 +546,10 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
   auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi, bool latency) {
     if (cnt[pi] <= 0) return;
     if (latency && cnt[pi] <= kLatencyTiles)
-      hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * cnt[pi])), dim3(512), smem_syrk / 2, st, S, NP, k,
+      hipLaunchKernelGGL((k_syrk<2, 0, 2>), dim3(syrk_grid(4 * cnt[pi])), dim3(512), smem_syrk / 2, st, S, k,
                          pairs + 2 * off[pi], (int)cnt[pi]);
     else
-      hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, NP, k, pairs + 2 * off[pi], (int)cnt[pi]);
+      hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, k, pairs + 2 * off[pi], (int)cnt[pi]);
   };
   if (!plan.pair_part.empty()) {
     // ---- elimination-tree schedule: the parts of a nested-dissection ordering are independent serial chains.  Every
@@ -584,7 +586,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     auto panel_on = [&](hipStream_t st, int k) {
       double* Xk = Xinv + (size_t)k * T * T;
       hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), st,
-                         S, NP, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
+                         S, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
     };
     // Issue order: round-robin over the chains that are ready, one pair of block columns at a time.  The host needs
     // ~45 us to issue a pair (9-10 API calls) and a chain executes one in ~100 us, so a single host thread can keep two
@@ -616,10 +618,10 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
         panel_on(xp, k);
         if (k + 1 < nt) {
           if (plan.s1_cnt[pi] <= kLatencyTiles)
-            hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, xp, S, NP, k,
+            hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, xp, S, k,
                                pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
           else
-            hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, xp, S, NP, k,
+            hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, xp, S, k,
                                pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
           panel_on(xp, k + 1);
           if (pi > first[x]) check_hip(hipStreamWaitEvent(xp, g_cs.P[pi - 1], 0), "wait");
@@ -656,10 +658,10 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
     panel(k);
     if (k + 1 < nt) {
       if (plan.s1_cnt[pi] <= kLatencyTiles)
-        hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, sp, S, NP, k,
+        hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, sp, S, k,
                            pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
       else
-        hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, NP, k,
+        hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, sp, S, k,
                            pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
       panel(k + 1);
       // the next pair's columns: everything older pairs owe them (rest(<= p-1), update stream) must be in; that event
@@ -680,7 +682,7 @@ void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, do
 }
 
 // debug (tools/syrk_ablation.py): time `reps` launches of the K=256 update over a dense m x m tile grid with ablations
-float debug_time_syrk(gtg_context& c, double* S, int NP, int m, int abl, int reps) {
+float debug_time_syrk(gtg_context& c, SMat S, int m, int abl, int reps) {
   const size_t smem_syrk = 4 * (size_t)CHB;
   auto set = [&](const void* f) { check_hip(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_syrk), "smem attr"); };
   set((const void*)k_syrk<2, 0>); set((const void*)k_syrk<2, 1>); set((const void*)k_syrk<2, 3>); set((const void*)k_syrk<2, 7>); set((const void*)k_syrk<2, 6>); set((const void*)k_syrk<2, 15>);
@@ -694,12 +696,12 @@ float debug_time_syrk(gtg_context& c, double* S, int NP, int m, int abl, int rep
   check_hip(hipEventRecord(e0, c.stream), "record");
   for (int r = 0; r < reps; r++) {
     switch (abl) {
-      case 0: hipLaunchKernelGGL((k_syrk<2, 0>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
-      case 1: hipLaunchKernelGGL((k_syrk<2, 1>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
-      case 3: hipLaunchKernelGGL((k_syrk<2, 3>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
-      case 6: hipLaunchKernelGGL((k_syrk<2, 6>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
-      case 7: hipLaunchKernelGGL((k_syrk<2, 7>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
-      default: hipLaunchKernelGGL((k_syrk<2, 15>), grid, blk, smem_syrk, c.stream, S, NP, 0, dl.p, np); break;
+      case 0: hipLaunchKernelGGL((k_syrk<2, 0>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
+      case 1: hipLaunchKernelGGL((k_syrk<2, 1>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
+      case 3: hipLaunchKernelGGL((k_syrk<2, 3>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
+      case 6: hipLaunchKernelGGL((k_syrk<2, 6>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
+      case 7: hipLaunchKernelGGL((k_syrk<2, 7>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
+      default: hipLaunchKernelGGL((k_syrk<2, 15>), grid, blk, smem_syrk, c.stream, S, 0, dl.p, np); break;
     }
   }
   check_hip(hipEventRecord(e1, c.stream), "record"); check_hip(hipStreamSynchronize(c.stream), "sync");
@@ -736,7 +738,7 @@ __device__ __forceinline__ void blk_mul(double* __restrict__ C, const double* __
 // An x entry that has not been produced yet: a signalling-NaN pattern no computation yields (arithmetic quiets NaNs).
 constexpr unsigned long long kBwdUnset = 0x7FF4A5C3D2E1F00DULL;
 
-__global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int NP, const double* __restrict__ Xinv_all,
+__global__ __launch_bounds__(256) void k_inv_tiles(SMat S, int NP, const double* __restrict__ Xinv_all,
                                                    double* __restrict__ x) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* Lb = reinterpret_cast<double*>(smem_raw);   // [6] L(p,q), p > q, at p(p-1)/2 + q
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int N
   double* Wb = Xb + 4 * SB * SB;                       // [6] Linv(p,q), p > q
   double* Tm = Wb + 6 * SB * SB;                       // scratch
   const int k = blockIdx.x, tid = threadIdx.x;
-  double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  double* tile = S.tile(k, k);
   const double* Xinv = Xinv_all + (size_t)k * T * T;
   if (x && tid < T) {   // k_bwd_sweep waits on the entries themselves (and, when a wait drags on, on their shadow copies NP entries further on)
     reinterpret_cast<unsigned long long*>(x)[k * T + tid] = kBwdUnset;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int N
     if (blk < 6) {
       int p = 1, q = blk;
       while (q >= p) { q -= p; p++; }
-      v = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * p + r) * NP + SB * q + c2);
+      v = *reinterpret_cast<const double2*>(tile + (SB * p + r) * T + SB * q + c2);
       Lb[blk * SB * SB + r * SB + c2] = v.x; Lb[blk * SB * SB + r * SB + c2 + 1] = v.y;
     } else {
       v = *reinterpret_cast<const double2*>(Xinv + (blk - 6) * SB * SB + r * SB + c2);
@@ -783,11 +785,11 @@ __global__ __launch_bounds__(256) void k_inv_tiles(double* __restrict__ S, int N
     while (q >= p) { q -= p; p++; }
     double2 v;
     v.x = Wb[blk * SB * SB + r * SB + c2]; v.y = Wb[blk * SB * SB + r * SB + c2 + 1];
-    *reinterpret_cast<double2*>(tile + (int64_t)(SB * q + r) * NP + SB * p + c2) = v;   // upper position (q,p)
+    *reinterpret_cast<double2*>(tile + (SB * q + r) * T + SB * p + c2) = v;   // upper position (q,p)
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, int NP, int k, const int32_t* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_bwd_step(SMat S, int k, const int32_t* __restrict__ cols,
                                                   int ncols, const double* __restrict__ Xinv, double* __restrict__ y,
                                                   double* __restrict__ x) {
   __shared__ double ys[T];
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
   __shared__ double xs[T];
   __shared__ double part[4][64];
   const int tid = threadIdx.x;
-  const double* tile = S + ((int64_t)k * T) * NP + (int64_t)k * T;
+  const double* tile = S.tile(k, k);
   if (tid < T) ys[tid] = y[k * T + tid];
   __syncthreads();
   {  // x_q[cc] = sum_i Linv(q,q)[i][cc] y_q[i] + sum_{p>q} sum_i Linv(p,q)[i][cc] y_p[i]; two threads per entry (i halves)
@@ -808,11 +810,11 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
       a1 += Xq[(i + 1) * SB] * ys[SB * q + i + 1];
     }
     for (int p = q + 1; p < 4; p++) {
-      const double* Wp = tile + (int64_t)(SB * q) * NP + SB * p + cc;   // Linv(p,q) sits at upper position (q,p)
+      const double* Wp = tile + (SB * q) * T + SB * p + cc;   // Linv(p,q) sits at upper position (q,p)
 #pragma unroll 8
       for (int i = 16 * hf; i < 16 * hf + 16; i += 2) {
-        a0 += Wp[(int64_t)i * NP] * ys[SB * p + i];
-        a1 += Wp[(int64_t)(i + 1) * NP] * ys[SB * p + i + 1];
+        a0 += Wp[i * T] * ys[SB * p + i];
+        a1 += Wp[(i + 1) * T] * ys[SB * p + i + 1];
       }
     }
     xh[hf][c] = a0 + a1;
@@ -826,16 +828,17 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
   __syncthreads();
   if (ncols == 0) return;
   const int c = tid & 63, g = tid >> 6;
-  const int j = cols[blockIdx.x >> 1] * T + (blockIdx.x & 1) * 64 + c;   // stored column tiles only
+  const int jt = cols[blockIdx.x >> 1], jc = (blockIdx.x & 1) * 64 + c;   // stored column tiles only
+  const int j = jt * T + jc;
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   {
-    const double* Lr = S + ((int64_t)k * T + 32 * g) * NP + j;
+    const double* Lr = S.tile(k, jt) + (32 * g) * T + jc;
 #pragma unroll
     for (int r = 0; r < 32; r += 4) {
-      acc0 += Lr[(int64_t)r * NP] * xs[32 * g + r];
-      acc1 += Lr[(int64_t)(r + 1) * NP] * xs[32 * g + r + 1];
-      acc2 += Lr[(int64_t)(r + 2) * NP] * xs[32 * g + r + 2];
-      acc3 += Lr[(int64_t)(r + 3) * NP] * xs[32 * g + r + 3];
+      acc0 += Lr[r * T] * xs[32 * g + r];
+      acc1 += Lr[(r + 1) * T] * xs[32 * g + r + 1];
+      acc2 += Lr[(r + 2) * T] * xs[32 * g + r + 2];
+      acc3 += Lr[(r + 3) * T] * xs[32 * g + r + 3];
     }
   }
   part[g][c] = (acc0 + acc1) + (acc2 + acc3);
@@ -857,10 +860,10 @@ __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, 
 constexpr int kSweepThreads = 512;
 constexpr size_t kSweepSmem = sizeof(double) * (10 * SB * SB + 2 * T + T + 8 * T);
 
-__device__ __forceinline__ void sweep_load(double2 (&t)[16], const double* __restrict__ S, int NP, int i, int j, int g, int c2) {
-  const double* src = S + ((int64_t)i * T + 16 * g) * NP + (int64_t)j * T + c2;
+__device__ __forceinline__ void sweep_load(double2 (&t)[16], const SMat& S, int i, int j, int g, int c2) {
+  const double* src = S.tile(i, j) + (16 * g) * T + c2;
 #pragma unroll
-  for (int r = 0; r < 16; r++) t[r] = *reinterpret_cast<const double2*>(src + (int64_t)r * NP);
+  for (int r = 0; r < 16; r++) t[r] = *reinterpret_cast<const double2*>(src + r * T);
 }
 
 __device__ __forceinline__ void sweep_wait(const double* x, int NP, int i, double* xs, double* fail, int tid) {
@@ -891,7 +894,7 @@ __device__ __forceinline__ void sweep_fma(const double2 (&t)[16], const double* 
   for (int r = 0; r < 16; r++) { const double xv = xs[16 * g + r]; a0 += t[r].x * xv; a1 += t[r].y * xv; }
 }
 
-__global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __restrict__ S, int NP, int nt,
+__global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(SMat S, int NP, int nt,
                                                              const int32_t* __restrict__ col_off, const int32_t* __restrict__ col_rows,
                                                              const double* __restrict__ Xinv_all, const double* __restrict__ y,
                                                              double* x, double* fail) {
@@ -905,10 +908,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __res
   const int32_t* rows = col_rows + col_off[j];
   const int n = col_off[j + 1] - col_off[j];
   double2 ta[16], tb[16];
-  if (n > 0) sweep_load(ta, S, NP, rows[0], j, g, c2);
-  if (n > 1) sweep_load(tb, S, NP, rows[1], j, g, c2);
+  if (n > 0) sweep_load(ta, S, rows[0], j, g, c2);
+  if (n > 1) sweep_load(tb, S, rows[1], j, g, c2);
   {
-    const double* tile = S + ((int64_t)j * T) * NP + (int64_t)j * T;
+    const double* tile = S.tile(j, j);
     const double* Xinv = Xinv_all + (size_t)j * T * T;
     for (int e = tid; e < 10 * 512; e += kSweepThreads) {
       const int blk = e >> 9, u = e & 511, r = u >> 4, cc = 2 * (u & 15);
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __res
       else {
         int p = 1, q = blk - 4;
         while (q >= p) { q -= p; p++; }
-        v = *reinterpret_cast<const double2*>(tile + (int64_t)(SB * q + r) * NP + SB * p + cc);   // Linv(p,q) sits at upper position (q,p)
+        v = *reinterpret_cast<const double2*>(tile + (SB * q + r) * T + SB * p + cc);   // Linv(p,q) sits at upper position (q,p)
       }
       *reinterpret_cast<double2*>(Lv + blk * SB * SB + r * SB + cc) = v;
     }
@@ -926,11 +929,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(const double* __res
   for (int idx = 0; idx < n; idx += 2) {   // ta holds tile idx, tb tile idx + 1
     sweep_wait(x, NP, rows[idx], xs, fail, tid);
     sweep_fma(ta, xs, g, a0, a1);
-    if (idx + 2 < n) sweep_load(ta, S, NP, rows[idx + 2], j, g, c2);
+    if (idx + 2 < n) sweep_load(ta, S, rows[idx + 2], j, g, c2);
     if (idx + 1 < n) {
       sweep_wait(x, NP, rows[idx + 1], xs + T, fail, tid);
       sweep_fma(tb, xs + T, g, a0, a1);
-      if (idx + 3 < n) sweep_load(tb, S, NP, rows[idx + 3], j, g, c2);
+      if (idx + 3 < n) sweep_load(tb, S, rows[idx + 3], j, g, c2);
     }
   }
   part[g * T + c2] = a0; part[g * T + c2 + 1] = a1;
@@ -975,9 +978,14 @@ void destroy_chol_streams(gtg_context& c) {
   cs = CholStreams(); ts = TreeStreams();
 }
 
-void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail) {
+// y = L^-1 g sits in row 0 of the rhs tiles after the factorisation: gathered into a contiguous vector for the backward solve
+__global__ __launch_bounds__(T) void k_gather_rhs(SMat S, double* __restrict__ y) { y[blockIdx.x * T + threadIdx.x] = S.tile(S.nt, blockIdx.x)[threadIdx.x]; }
+
+void launch_backward_solve(gtg_context& c, SMat S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail) {
   const int nt = NP / T;
-  double* y = S + (int64_t)NP * NP;  // rhs row (extra tile, row 0) now holds y = L^-1 g
+  if ((int64_t)c.yred.n != NP) c.yred.alloc(NP);
+  double* y = c.yred.p;
+  hipLaunchKernelGGL(k_gather_rhs, dim3((unsigned)nt), dim3(T), 0, c.stream, S, y);
   const size_t smem_inv = sizeof(double) * 17 * SB * SB;
   const char* bwd_env = std::getenv("GTG_BWD");   // (read per call: the A/B test switches it inside one process)
   const bool per_row = bwd_env && std::string(bwd_env) == "steps";
@@ -998,7 +1006,7 @@ void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& pl
   } else {   // GTG_BWD=steps: one launch per block row (the round-1 form, kept as the A/B of the sweep)
     for (int k = nt - 1; k >= 0; k--) {
       const int ncols = (int)plan.bwd_cnt[k];
-      hipLaunchKernelGGL(k_bwd_step, dim3(ncols > 0 ? 2 * (unsigned)ncols : 1u), dim3(256), 0, c.stream, S, NP, k,
+      hipLaunchKernelGGL(k_bwd_step, dim3(ncols > 0 ? 2 * (unsigned)ncols : 1u), dim3(256), 0, c.stream, S, k,
                          plan.bcols.p + plan.bwd_off[k], ncols, Xinv + (size_t)k * T * T, y, x);
     }
   }

@@ -7,8 +7,8 @@
 //   V, gp                   landmarks: 3x3 blocks (stride 9) and gradient (stride 3)
 //   Hoff                    off-diagonal reduced blocks from BetweenFactors (stride 81)
 //   E                       per landmark-observation  E = Jc^T Jp L^-T  (stride 27), rebuilt per lambda
-//   S                       dense reduced system, row-major lower triangle, ld = NP (multiple of 128),
-//                           plus one extra 128-row tile whose first row carries the rhs (g^T -> y^T)
+//   S                       reduced system BY TILES: one contiguous 128 x 128 slot per stored tile of the lower triangle
+//                           (plan.slot: tile -> slot) plus the tiles of one extra tile row whose first row carries the rhs (g^T -> y^T)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,6 +21,28 @@
 namespace gt {
 
 constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Cholesky
+constexpr int kTileDoubles = kTile * kTile;
+
+// ---- storage of the reduced system: BY TILES -----------------------------------------------------------------------------
+// Every 128 x 128 tile of the lower triangle that the symbolic factorisation says can become non-zero (fill included), and every
+// tile of the rhs row (tile row nt: row 0 of those tiles carries the right-hand side through the factorisation), owns one
+// contiguous slot of 128 x 128 doubles, row-major with pitch 128; slot[I * nt + J] is its index, -1 for a tile that is never
+// touched (what the reference keeps per clique as SymmetricBlockMatrix blocks, base/SymmetricBlockMatrix.h:195-237).  Rounds 1-3
+// kept the whole (NP + 128) x NP array: 1.9 GB for the 15 507 columns of the L1723 shape with 45 % of the tiles ever touched,
+// 31 GB for a 20 000-pose graph with a few per cent.
+struct SMat {
+  double* p; const int32_t* slot; int nt;
+  __host__ __device__ __forceinline__ double* tile(int I, int J) const { return p + (int64_t)slot[(int64_t)I * nt + J] * kTileDoubles; }
+  // entry (r, c) of the matrix in scalar coordinates (r = 128 nt: the rhs row)
+  __host__ __device__ __forceinline__ double* at(int64_t r, int64_t c) const { return tile((int)(r >> 7), (int)(c >> 7)) + ((r & 127) << 7) + (c & 127); }
+  // the same for writers of whole variable blocks: a d x d block that straddles a tile boundary next to the diagonal has entries in a
+  // tile of the UPPER triangle, which has no slot (and which nobody reads): nullptr there
+  __host__ __device__ __forceinline__ double* at_stored(int64_t r, int64_t c) const {
+    const int32_t q = slot[(r >> 7) * nt + (c >> 7)];
+    return q < 0 ? nullptr : p + (int64_t)q * kTileDoubles + ((r & 127) << 7) + (c & 127);
+  }
+};
+
 
 // scalar slots reduced on the device (doubles)
 // SC_TIMEOUT directly follows SC_FAIL: the factorisation gets `scalars + SC_FAIL` and raises [0] for a non-positive pivot, [1] for a
@@ -49,8 +71,10 @@ struct CholPlan {
   int nt = 0;                                   // 128-tiles of the square part (the rhs tile is index nt)
   DevBuf<int32_t> rows, pairs, bcols;           // concatenated lists: TRSM row tiles, SYRK (I,J) pairs, backward column tiles
   DevBuf<int32_t> bwd_col_off, bwd_col_rows;    // the backward tiles by column: offsets (nt + 1), row tiles in descending order
-  DevBuf<int32_t> stored;                       // every stored tile (I,J) incl. the rhs row: what a multi-GPU exchange must carry
+  DevBuf<int32_t> stored;                       // every stored tile (I,J) incl. the rhs row, in SLOT order: tile q of this list lives in slot q of S
   int64_t n_stored = 0;
+  DevBuf<int32_t> slot;                         // (nt + 1) x nt: tile (I, J) -> its slot in S, -1 = never touched (chol_device.h::SMat)
+  std::vector<int32_t> h_slot;
   DevBuf<int32_t> exch;                         // the stored tiles that can be non-zero BEFORE the factorisation (no fill): what a multi-GPU
   int64_t n_exch = 0;                           // exchange of the partial reduced systems has to carry (L1723: 19 % fewer than `stored`)
   std::vector<int64_t> trsm_off, trsm_cnt;      // per column tile
@@ -210,7 +234,8 @@ struct gtg_context {
   gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (32/obs), delta (3)
   gt::DevBuf<double> pcg_vec, pcg_bj, pcg_y;    // PCG solver: r, p, q1, q2, b (5 x NP); block-Jacobi factors (81 / reduced variable); y_l (3 / landmark)
   gt::DevBuf<double> vobs;                      // per try: Jp^T (Jc x_cam) of every observation (3), for the back-substitution
-  gt::DevBuf<double> S;                         // (NP + kTile) x NP
+  gt::DevBuf<double> S;                         // plan.n_stored slots of 128 x 128 doubles: the stored tiles of the reduced system + the rhs row's tiles
+  gt::DevBuf<double> yred;                      // NP: y = L^-1 g gathered from the rhs tiles for the backward solve
   gt::DevBuf<double> Dinv;                      // per diagonal tile (128x128 doubles): the four 32x32 diagonal inverses, the MFMA operand
                                                 // images of the tile's sub-blocks for the TRSM, and the tile's progress word (zeroed at allocation)
   gt::DevBuf<unsigned char> pivot_kind;         // per scalar column of S: 1 / 2 = last pivot of a variable (dim >= 2 / dim 1): the rank test of
@@ -246,3 +271,7 @@ struct gtg_context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double chol_flops = 0, chol_flops_block = 0, lin_bytes = 0;
 };
+
+namespace gt {
+inline SMat smat(const gtg_context& c) { return SMat{c.S.p, c.plan.slot.p, c.plan.nt}; }   // the handle's reduced system (context.h::SMat)
+}  // namespace gt

@@ -307,6 +307,10 @@ static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.no
 // else reuse the cached result -- the cache is per factor and shared by linearize() and error(), as in the reference, so the
 // sequence of calls is mirrored by the host (gate: the reference does not evaluate the error of a trial step whose linear
 // cost change is negative, LevenbergMarquardtOptimizer.cpp:180-191).  The point goes into the hidden variable's value slot.
+// the code of the case the reference throws in: the LARGER one wins when lanes meet both (positive doubles order like their bit patterns)
+__device__ __forceinline__ void raise_unsupported(double* scalars, double code) {
+  atomicMax(reinterpret_cast<unsigned long long*>(scalars + SC_UNSUPPORTED), (unsigned long long)__double_as_longlong(code));
+}
 struct SmartArgs {
   int64_t n, obs0;
   const int64_t* ptr; const int32_t *sfm_cam, *sfm_point; const double* sfm_z; const int64_t* val_off; const double* params;
@@ -314,7 +318,8 @@ struct SmartArgs {
 };
 __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, double* __restrict__ values, const double* __restrict__ gate,
                                                               double* __restrict__ scalars, int for_linearize) {
-  if (gate && !(gate[SC_LIN0] - gate[SC_LIN1] >= 0)) return;
+  // (a try whose factorisation timed out is repeated, api.hip: its garbage trial point must not touch the triangulation cache)
+  if (gate && (gate[SC_TIMEOUT] != 0.0 || !(gate[SC_LIN0] - gate[SC_LIN1] >= 0))) return;
   for (int64_t sf = blockIdx.x * (int64_t)kBlock + threadIdx.x; sf < a.n; sf += (int64_t)gridDim.x * kBlock) {
     const int64_t k0 = a.ptr[sf], o0 = a.obs0 + k0;
     const int m = (int)(a.ptr[sf + 1] - k0);
@@ -357,8 +362,8 @@ __global__ __launch_bounds__(kBlock) void k_smart_triangulate(SmartArgs a, doubl
     a.status[sf] = st | (at_infinity ? kTriAtInfinity : 0);
     double* slot = values + a.val_off[a.sfm_point[o0]];
     for (int e = 0; e < 3; e++) slot[e] = (st == kTriValid || at_infinity) ? pt[e] : 0.0;
-    if (st == kTriNoConvergence) scalars[SC_UNSUPPORTED] = 1.0;      // Cal3Bundler::calibrate throws in the reference
-    if (st == kTriCheiralityThrown) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;   // enableEPI: geom.h::triangulate_refine
+    if (st == kTriNoConvergence) raise_unsupported(scalars, 1.0);      // Cal3Bundler::calibrate throws in the reference
+    if (st == kTriCheiralityThrown) raise_unsupported(scalars, kUnsupportedCheirality);   // enableEPI: geom.h::triangulate_refine
   }
 }
 
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_smart_at_infinity(int64_t n_meas
     for (int e = 0; e < 17; e++) c[e] = cp[e];
     for (int e = 0; e < 3; e++) d[e] = dp[e];
     zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
-    if (!sfm_linearize_at_infinity(c, d, zz, nt.ref(nz[o]), rec)) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;
+    if (!sfm_linearize_at_infinity(c, d, zz, nt.ref(nz[o]), rec)) raise_unsupported(scalars, kUnsupportedCheirality);
     for (int e = 0; e < kSfmRec; e++) J[(int64_t)kSfmRec * o + e] = rec[e];
   }
 }
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_error_smart_at_infinity(int64_t n_me
     const int32_t* __restrict__ pt, const double* __restrict__ z, const int32_t* __restrict__ nz, const double* __restrict__ values,
     const int64_t* __restrict__ val_off, NoiseTab nt, const int32_t* __restrict__ smart_of, const int32_t* __restrict__ status,
     const double* __restrict__ gate, double* __restrict__ scalars, int slot) {
-  if (gate && !(gate[SC_LIN0] - gate[SC_LIN1] >= 0)) return;      // (the triangulation of this trial point was skipped: see k_smart_triangulate)
+  if (gate && (gate[SC_TIMEOUT] != 0.0 || !(gate[SC_LIN0] - gate[SC_LIN1] >= 0))) return;      // (the triangulation of this trial point was skipped: see k_smart_triangulate)
   double acc = 0.0;
   for (int64_t k = threadIdx.x; k < n_meas; k += kBlock) {
     const int64_t o = obs0 + k;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_error_smart_at_infinity(int64_t n_me
     for (int i = 0; i < 17; i++) c[i] = cp[i];
     for (int i = 0; i < 3; i++) d[i] = dp[i];
     zz[0] = z[2 * o]; zz[1] = z[2 * o + 1];
-    if (!sfm_error_at_infinity(c, d, zz, nt.ref(nz[o]), &e)) scalars[SC_UNSUPPORTED] = kUnsupportedCheirality;
+    if (!sfm_error_at_infinity(c, d, zz, nt.ref(nz[o]), &e)) raise_unsupported(scalars, kUnsupportedCheirality);
     acc += e;
   }
   const double s = block_sum(acc);

@@ -26,13 +26,13 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
                      const std::vector<int32_t>* pair_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 // In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
-void launch_zero_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan);
-void launch_cholesky(gtg_context& c, double* S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag,
+void launch_zero_tiles(gtg_context& c, SMat S, const CholPlan& plan);
+void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, double* Xinv, double* fail_flag,
                      const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);
 // x = L^-T y  with L the factor in S, y = row NP of S. Result in x[0..NP).
-void launch_pack_tiles(gtg_context& c, double* S, int NP, const CholPlan& plan, double* buf, bool unpack);
+void launch_pack_tiles(gtg_context& c, SMat S, const CholPlan& plan, double* buf, bool unpack);
 int64_t exchange_block_doubles(const gtg_context& c);                    // size of the block-granular exchange buffer
-void launch_pack_blocks(gtg_context& c, double* S, int NP, double* buf, bool unpack);
+void launch_pack_blocks(gtg_context& c, SMat S, int NP, double* buf, bool unpack);
 // device_analysis.hip: the Schur term lists built on the device (single shard, real runtime)
 void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos, gt::DevBuf<int32_t>& d_pos);
 void device_schur_terms(gtg_context& c, gt::DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
@@ -43,16 +43,17 @@ void launch_smart_triangulate(gtg_context& c, double* values, const double* gate
 void launch_smart_hdiag(gtg_context& c);
 void launch_smart_lin1(gtg_context& c);
 void exchange_sum(gtg_context& c, double* ptr, int64_t n);   // api.hip: all-reduce (sum) over the shards on the handle's stream; no-op on one shard
-void launch_backward_solve(gtg_context& c, double* S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail);
+void launch_backward_solve(gtg_context& c, SMat S, int NP, const CholPlan& plan, const double* Xinv, double* x, double* fail);
 void destroy_chol_streams(gtg_context& c);
 
 // chol_dataflow.hip -----------------------------------------------------------------------------------
 // The same factorisation as one dataflow pass of two persistent kernels (default schedule).  tile_struct = lower-triangular
 // boolean structure over 128x128 tiles before the factorisation ((nt x nt) row-major bytes; nullptr = dense).
 void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s,
+                   const std::vector<int32_t>& slot, int64_t n_slots,     // tile -> slot table of the stored tiles (CholPlan::h_slot)
                    const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 void free_df_plan(DfPlan& df);
-void launch_cholesky_df(gtg_context& c, double* S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
+void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
                         const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);
 
 // pcg.hip -----------------------------------------------------------------------------------------

@@ -103,11 +103,12 @@ hipError_t hipLaunchKernel(const void* f, dim3s grid, dim3s block, void** args, 
   hipstub_op* op = trace(OP_LAUNCH, s, f);
   if (op) {
     op->grid = grid.x;
-    /* the kernels of the Cholesky schedule take (S, NP, k, list, count | ...): keep those five words (other kernels have
-     * other, possibly shorter, argument lists and are only traced by name) */
+    /* the kernels of the Cholesky schedule take (SMat S, int k, list, count | ...): keep the first four arguments (of S its base
+     * pointer; other kernels have other, possibly shorter, argument lists and are only traced by name) */
     const char* name = hipstub_kernel_name(f);
-    if (strstr(name, "k_panel128") || strstr(name, "k_syrk"))
-      for (int i = 0; i < 5; i++) { unsigned long long w = 0; memcpy(&w, args[i], i == 1 || i == 2 || i == 4 ? 4 : 8); op->args[i] = w; }
+    const int syrk = strstr(name, "k_syrk") != 0;
+    if (strstr(name, "k_panel128") || syrk)
+      for (int i = 0; i < 4; i++) { unsigned long long w = 0; memcpy(&w, args[i], (i == 1 || (i == 3 && syrk)) ? 4 : 8); op->args[i] = w; }
   }
   return 0;
 }

@@ -8,8 +8,8 @@ that this module builds the happens-before relation HIP guarantees (FIFO order i
 hipStreamWaitEvent(s, e) follows everything that preceded the captured hipEventRecord(e)) as vector clocks, derives the set
 of 128x128 tiles every launch reads and writes
 
-    k_panel128(k, rows)            read+write (k,k) and (I,k) for the listed row tiles I
-    k_syrk<KT>(k, pairs (I,J))     read+write (I,J); read (I,k..k+KT-1), (J,k..k+KT-1)
+    k_panel128(S, k, rows)            read+write (k,k) and (I,k) for the listed row tiles I
+    k_syrk<KT>(S, k, pairs (I,J), n)  read+write (I,J); read (I,k..k+KT-1), (J,k..k+KT-1)
 
 and checks that every two launches touching a common tile, at least one of them writing, are ordered (two updates of the
 same tile are read-modify-write: they must be ordered too, and the order is what makes the sums reproducible).  Every other
@@ -44,7 +44,7 @@ def trace(stub):
         d = {"type": o.type, "stream": o.stream or 0, "obj": o.obj or 0, "grid": o.grid}
         if o.type == OP_LAUNCH:
             d["name"] = stub.hipstub_kernel_name(o.obj).decode()
-            d["args"] = [int(a) for a in o.args[:5]]
+            d["args"] = [int(a) for a in o.args[:4]]
         out.append(d)
     return out
 
@@ -57,14 +57,14 @@ def accesses(op):
     """(reads, writes) tile sets of a launch of the factorisation, or None for any other operation."""
     name = op.get("name", "")
     if "k_panel128" in name:
-        k = op["args"][2] & 0xFFFFFFFF
-        rows = _i32_list(op["args"][3], (op["grid"] - 1) // 2)
+        k = op["args"][1] & 0xFFFFFFFF
+        rows = _i32_list(op["args"][2], (op["grid"] - 1) // 2)
         t = {(k, k)} | {(int(i), k) for i in rows}
         return t, t
     m = re.search(r"k_syrkILi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
-        kt = int(m.group(1)); k0 = op["args"][2] & 0xFFFFFFFF; npairs = op["args"][4] & 0xFFFFFFFF
-        flat = _i32_list(op["args"][3], 2 * npairs)
+        kt = int(m.group(1)); k0 = op["args"][1] & 0xFFFFFFFF; npairs = op["args"][3] & 0xFFFFFFFF
+        flat = _i32_list(op["args"][2], 2 * npairs)
         reads, writes = set(), set()
         for q in range(npairs):
             i, j = int(flat[2 * q]), int(flat[2 * q + 1])

@@ -693,7 +693,6 @@ void analyze(gtg_context& c) {
       for (int pp = 0; pp < c.n_red_vars; pp++) pair_part[c.h_red_off[pos_to_red[pp]] / (2 * kTile)] = part_of_pos[pp];
       for (int q = 0; q < np2; q++) if (pair_part[q] < 0) throw std::runtime_error("nested dissection: a column pair without variables");
     }
-    build_chol_plan(c.plan, nt, std::getenv("GTG_DENSE_PLAN") ? nullptr : &B2, s, &pair_part, &part_parent);
     {  // tiles that hold something before the factorisation: diagonal blocks, pose-pose blocks, Schur pairs, rhs row
       std::vector<uint8_t> T1((size_t)nt * nt, 0);
       std::vector<uint8_t> rhs((size_t)nt, 0);
@@ -716,7 +715,18 @@ void analyze(gtg_context& c) {
       free_df_plan(c.df);
       std::vector<int32_t> tile_part;                      // nested dissection: the part of every block column (parts are aligned to column pairs)
       if (!pair_part.empty()) { tile_part.resize(nt); for (int t = 0; t < nt; t++) tile_part[t] = pair_part[t / 2]; }
-      if (c.use_df) build_df_plan(c.df, nt, dense ? nullptr : &T1, s, c.plan.h_slot, c.plan.n_stored, &tile_part, &part_parent);
+      // The two tile schedules are built side by side: the task lists of the dataflow pass on a thread of their own (pure host code),
+      // the stream schedule's lists -- which also number the stored tiles (slots) -- here; the dataflow plan is resolved to slots
+      // and uploaded when both are done.
+      {
+        std::thread dfh; std::exception_ptr dferr;
+        if (c.use_df) dfh = std::thread([&] { try { build_df_plan_host(c.df, nt, dense ? nullptr : &T1, &tile_part, &part_parent); } catch (...) { dferr = std::current_exception(); } });
+        try { build_chol_plan(c.plan, nt, dense ? nullptr : &B2, s, &pair_part, &part_parent); }
+        catch (...) { if (dfh.joinable()) dfh.join(); throw; }
+        if (dfh.joinable()) dfh.join();
+        if (dferr) std::rethrow_exception(dferr);
+        if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored);
+      }
       for (int a = 0; a < nt; a++)
         for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
       for (int b = 0; b < nt; b++) if (dense || rhs[(size_t)b]) { ex.push_back(nt); ex.push_back(b); }

@@ -625,9 +625,17 @@ __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *
 // ---- host: task lists --------------------------------------------------------------------------------------------
 // tile_struct: (nt x nt) row-major bytes, lower triangle: tile (I, J) holds something before the factorisation
 // (nullptr = dense).  Symbolic elimination at tile granularity adds the fill; the rhs row (tile row nt) is dense.
+// Two halves: build_df_plan_host is pure host code (no runtime call: analysis.hip runs it on its own thread beside build_chol_plan),
+// upload_df_plan resolves the tiles to slots -- which come from the stream schedule's plan -- and makes the device copies.
 void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t stream,
                    const std::vector<int32_t>& slot, int64_t n_slots,
                    const std::vector<int32_t>* tile_part, const std::vector<int32_t>* part_parent) {
+  build_df_plan_host(df, nt, tile_struct, tile_part, part_parent);
+  upload_df_plan(df, stream, slot, n_slots);
+}
+
+void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct,
+                        const std::vector<int32_t>* tile_part, const std::vector<int32_t>* part_parent) {
   std::vector<uint8_t> B((size_t)nt * nt, 0);
   for (int i = 0; i < nt; i++)
     for (int j = 0; j <= i; j++) B[(size_t)i * nt + j] = tile_struct ? (*tile_struct)[(size_t)i * nt + j] : 1;
@@ -767,6 +775,12 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
   df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (df.h_klist.empty()) df.h_klist.push_back(0);
+  df.h_has_sub = has_sub;
+}
+
+void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots) {
+  const int nt = df.nt;
+  const std::vector<int32_t>& has_sub = df.h_has_sub;
   // Device form: tiles AND their flag words are addressed by SLOT (context.h::SMat; the slots come from the stream schedule's plan,
   // whose stored set -- fill at the granularity of column pairs -- contains this one).  A task carries the slots of its tile and of
   // its diagonal tile, a contraction step the slots of its two operand tiles; h_tasks / h_klist keep the tile coordinates (debug
@@ -798,7 +812,6 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
     df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1)
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
-  df.h_has_sub = has_sub;
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays

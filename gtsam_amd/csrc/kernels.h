@@ -52,6 +52,9 @@ void destroy_chol_streams(gtg_context& c);
 void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, hipStream_t s,
                    const std::vector<int32_t>& slot, int64_t n_slots,     // tile -> slot table of the stored tiles (CholPlan::h_slot)
                    const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
+void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct,             // the host half (no runtime call)
+                        const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
+void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots);   // the device half
 void free_df_plan(DfPlan& df);
 void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
                         const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);

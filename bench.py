@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--skip-dense-roofline", action="store_true", help="do not run the extra dense-schedule factorisations (used for clean profiles)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="auto: measure roofline.traffic in this run (two rocprofv3 --pmc sub-runs)")
+    ap.add_argument("--parallelism", default="speculative", choices=["speculative", "shard"],
+                    help="N > 1: speculative = replicated handles, replica r tries the r-th lambda of the rejection sequence (gtsam_amd/speculative.py); "
+                         "shard = landmarks sharded, one all-reduce of the reduced camera system per try (SURVEY 8(e))")
     ap.add_argument("--host", default="auto", choices=["auto", "python"], help="auto: the headline is timed in the C++ host (tools/cpp/bench_lm_gtsam.cpp) at N = 1")
     args = ap.parse_args()
 
@@ -168,12 +171,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the GPU"
     torch.cuda.set_device(local_rank)
     allreduce = None
+    comm = None
+    speculative = world > 1 and args.parallelism == "speculative"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from gtsam_amd.distributed import make_allreduce
-        allreduce = make_allreduce()
+        if speculative:
+            from gtsam_amd.speculative import TorchComm
+            comm = TorchComm()
+        else:
+            from gtsam_amd.distributed import make_allreduce
+            allreduce = make_allreduce()
 
     def barrier():
         torch.cuda.synchronize()
@@ -188,6 +197,9 @@ def main():
         params = LevenbergMarquardtParams()                  # Pose3SLAMExample_g2o protocol with legacy LM
 
     def fresh():
+        if speculative:     # every rank holds the whole graph
+            from gtsam_amd.speculative import SpeculativeLevenbergMarquardt
+            return SpeculativeLevenbergMarquardt(problem, values0, params, device=local_rank, comm=comm)
         return DeviceLevenbergMarquardt(problem, values0, params, device=local_rank, shard=rank, n_shards=world,
                                         allreduce=allreduce)
 
@@ -306,7 +318,8 @@ def main():
                        "cameras": int((problem.var_type == 1).sum()), "points": int((problem.var_type == 2).sum()),
                        "poses": int(((problem.var_type == 0) | (problem.var_type == 3)).sum()), "between_factors": int(problem.n_between),
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
-                       "parallelism": f"landmark-shard x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"speculative-lambda x{world} (replicas; replica r tries the r-th lambda of the rejection sequence, decisions replayed in order: the sequential trajectory)"
+                                       if speculative else f"landmark-shard x{world}") if world > 1 else "single GPU"},
             "lambda_tries_per_s": cpp["lambda_tries_per_s"] if cpp_ok else tries / elapsed,
             # construction -> checkConvergence.  `time_to_converged_s` is the COLD figure when the C++ leg ran (first optimizer of a fresh
             # process: code-object load, first device allocations); warm = a later optimizer of the same process

@@ -756,6 +756,28 @@ int gtg_accept(gtg_handle c) {
   GTG_CATCH
 }
 
+// Replicated handles (one per GPU, each holding the whole graph -- the speculative lambda search of gtsam_amd/speculative.py): the
+// device addresses of the packed values for a device-to-device exchange run by the caller on the handle's stream.
+int gtg_values_device_ptr(gtg_handle c, int which, void** ptr, int64_t* n_doubles, void** stream) {
+  GTG_TRY
+  if (!c || !c->uploaded || !ptr || (which != 0 && which != 1)) throw std::invalid_argument("gtg_values_device_ptr: no problem uploaded / bad arguments");
+  if (which == 1 && !c->have_trial) throw std::invalid_argument("gtg_values_device_ptr: no trial values (call gtg_try_lambda)");
+  *ptr = which == 0 ? (void*)c->values.p : (void*)c->trial.p;
+  if (n_doubles) *n_doubles = c->user_val_size;
+  if (stream) *stream = (void*)c->stream;
+  return GTG_OK;
+  GTG_CATCH
+}
+int gtg_values_changed(gtg_handle c) {
+  GTG_TRY
+  if (!c || !c->uploaded) throw std::invalid_argument("gtg_values_changed: no problem uploaded");
+  DeviceGuard on_device(c->device);
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  c->linearized = false; c->have_trial = false;
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_get_gradient(gtg_handle c, double* g, int64_t n) {
   GTG_TRY
   if (!c || !c->linearized || n != c->user_dim_size) throw std::invalid_argument("gtg_get_gradient: linearize first / wrong size");

@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_trace", "gtg_release_cached_memory",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -79,6 +79,8 @@ def load():
     lib.gtg_try_lambda_pcg.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_int32)]
     lib.gtg_accept.argtypes = [C.c_void_p]
+    lib.gtg_values_device_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gtg_values_changed.argtypes = [C.c_void_p]
     lib.gtg_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     lib.gtg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.gtg_reset_timing.argtypes = [C.c_void_p]
@@ -208,6 +210,15 @@ class DeviceGraph:
 
     def accept(self):
         _check(self.lib.gtg_accept(self.h), "gtg_accept")
+
+    def values_device_ptr(self, which=0):
+        """-> (device address, doubles, stream) of the current (0) / trial (1) values: gtg_values_device_ptr."""
+        p = C.c_void_p(); n = C.c_int64(); st = C.c_void_p()
+        _check(self.lib.gtg_values_device_ptr(self.h, int(which), C.byref(p), C.byref(n), C.byref(st)), "gtg_values_device_ptr")
+        return int(p.value or 0), int(n.value), int(st.value or 0)
+
+    def values_changed(self):
+        _check(self.lib.gtg_values_changed(self.h), "gtg_values_changed")
 
     # measurement ---------------------------------------------------------------------------------------
     def enable_timing(self, on=True): self.lib.gtg_enable_timing(self.h, int(on))

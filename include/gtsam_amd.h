@@ -206,6 +206,18 @@ int gtg_try_lambda_pcg(gtg_handle h, double lambda, int diagonal_damping, double
 /* state_ = decreaseLambda(... newValues ...) (LevenbergMarquardtState.h:81-94): trial -> current. */
 int gtg_accept(gtg_handle h);
 
+/* Replicated handles -- one per GPU, each holding the WHOLE graph (n_shards = 1), driven in lock step by one process per GPU: the
+ * device address of the packed values (which = 0: the current values, 1: the trial values of the last gtg_try_lambda), their
+ * length in doubles and the stream the handle's kernels run on, for a device-to-device exchange run by the caller on that stream
+ * (e.g. ncclBroadcast of the accepted trial values from the replica whose lambda was taken into every other replica's current
+ * values).  After writing a handle's current values in place, gtg_values_changed() tells it so (what gtg_set_values does after
+ * its copy): the linearisation and the trial values are no longer valid.  Used by the speculative lambda search of
+ * gtsam_amd/speculative.py: replica r tries the r-th lambda of the sequence LevenbergMarquardtOptimizer::tryLambda would walk
+ * through on consecutive rejections (LevenbergMarquardtOptimizer.cpp:121-270, LevenbergMarquardtState.h:70-76), the decisions are
+ * replayed in order from the gathered results: the trajectory is the sequential one, an iteration costs one try. */
+int gtg_values_device_ptr(gtg_handle h, int which, void** ptr, int64_t* n_doubles, void** stream);
+int gtg_values_changed(gtg_handle h);
+
 /* ---- parity / debug getters (host copies) --------------------------------------------------- */
 int gtg_get_delta(gtg_handle h, double* delta, int64_t n);            /* VectorValues of last solve, variable id order */
 int gtg_get_gradient(gtg_handle h, double* g, int64_t n);             /* J^T b, variable id order */

@@ -15,15 +15,16 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "data", "config", "roofline", "cpu_baseline", "time_to_converged_s", "time_to_converged_setup_s"}
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_bench_contract_and_multi_rank_flow(world):
+@pytest.mark.parametrize("world,mode", [(1, "speculative"), (2, "speculative"), (2, "shard")])
+def test_bench_contract_and_multi_rank_flow(world, mode):
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
         pytest.skip("libgtsam_amd.so not built")
     stub = HP.build_stub()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, LD_PRELOAD=stub, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, LD_PRELOAD=stub, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_PARALLELISM=mode)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py")], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -38,4 +39,4 @@ def test_bench_contract_and_multi_rank_flow(world):
     assert rec["scaling"] == "strong" and rec["dtype"] == "f64" and rec["data"] == "synthetic" and rec["vs_baseline"] is None
     assert "workload" in rec["config"] and "model" not in rec["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rec["roofline"])
-    assert rec["config"]["parallelism"] == ("single GPU" if world == 1 else "landmark-shard x2")
+    assert rec["config"]["parallelism"].startswith("single GPU" if world == 1 else ("speculative-lambda x2" if mode == "speculative" else "landmark-shard x2"))

@@ -409,9 +409,14 @@ void analyze(gtg_context& c) {
   if (hi.user_order.empty() && c.n_red_vars >= 16 && !std::getenv("GTG_NO_REORDER")) {
     const int nrv2 = c.n_red_vars;
     std::vector<std::vector<int32_t>> adj(nrv2);
-    auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
-    for_each_block(edge);
-    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    bool have_adj = false;
+    auto ensure_adj = [&] {   // the host's adjacency lists (sorted, unique): not built when the ordering runs on the device
+      if (have_adj) return;
+      auto edge = [&](int a, int b) { if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } };
+      for_each_block(edge);
+      for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+      have_adj = true;
+    };
     std::vector<int32_t> level(nrv2, -1);
     std::vector<char> active(nrv2, 0);     // node belongs to the subgraph being processed and is not ordered yet
     auto bfs_levels = [&](int start, std::vector<int32_t>& q) {   // BFS over active nodes, fills level[], returns order
@@ -501,7 +506,21 @@ void analyze(gtg_context& c) {
     const int nd_depth = nd_depth_try;
     std::vector<int32_t> all(nrv2);
     for (int i = 0; i < nrv2; i++) all[i] = i;
-    dissect(all, nd_depth);
+    // One part (no nested dissection) on a single shard with a real runtime: reverse Cuthill-McKee runs on the DEVICE
+    // (device_ordering.hip: the same ordering position for position; GTG_HOST_ORDERING=1 keeps the host queue as the A/B).
+    bool ordered_on_device = false;
+    {
+      const char* oe = std::getenv("GTG_ORDERING");
+      const bool plain_rcm = !oe || std::string(oe) == "rcm";
+      if (nd_depth == 0 && plain_rcm && kernels_can_run && c.n_shards == 1 && !std::getenv("GTG_HOST_ORDERING")) {
+        std::vector<int32_t> ea, eb;
+        for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } });
+        PartRec leaf; leaf.parent = -1;
+        if (device_rcm(c, nrv2, ea, eb, leaf.nodes)) { parts.push_back(std::move(leaf)); ordered_on_device = true; }
+      }
+    }
+    if (!ordered_on_device) { ensure_adj(); dissect(all, nd_depth); }
+    if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] ordering computed on the %s\n", ordered_on_device ? "device" : "host");
     std::vector<int32_t> order; order.reserve(nrv2);
     for (size_t pi = 0; pi < parts.size(); pi++) {
       for (int32_t v : parts[pi].nodes) { order.push_back(v); part_of_pos.push_back((int32_t)pi); }
@@ -516,6 +535,7 @@ void analyze(gtg_context& c) {
     const char* ord_env = std::getenv("GTG_ORDERING");
     const std::string ord_mode = ord_env ? ord_env : "rcm";
     if (parts.size() == 1 && (ord_mode == "mindegree" || ord_mode == "auto")) {
+      ensure_adj();
       auto block_flops = [&](const std::vector<int32_t>& ord) {
         std::vector<int32_t> pos(nrv2);
         for (int i = 0; i < nrv2; i++) pos[ord[i]] = i;

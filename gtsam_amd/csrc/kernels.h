@@ -37,6 +37,8 @@ void launch_pack_blocks(gtg_context& c, SMat S, int NP, double* buf, bool unpack
 void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos, gt::DevBuf<int32_t>& d_pos);
 void device_schur_terms(gtg_context& c, gt::DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
 void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
+// device_ordering.hip: reverse Cuthill-McKee of the reduced variables' block graph on the device (false: outside what the kernel handles)
+bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& edge_a, const std::vector<int32_t>& edge_b, std::vector<int32_t>& order);
 // smart factors (SmartProjectionFactor): triangulation of the hidden landmarks from the cameras in `values` (gated: only when the
 // linear cost change of the current try is >= 0), Schur-complement correction of the Hessian diagonal, constant of linear.error
 void launch_smart_triangulate(gtg_context& c, double* values, const double* gate, bool for_linearize);   // gate: scalars with the linear errors (trial point) or null

@@ -45,3 +45,40 @@ def test_device_lists_equal_host_lists(name, pv, monkeypatch):
     assert a[3] == b[3] and a[4] == b[4]
     assert np.array_equal(a[2], b[2]), np.abs(a[2] - b[2]).max()       # the step, bit for bit
     assert np.array_equal(a[1], b[1])                                   # linear errors, trial error, |delta|
+
+
+def _ordering_problems():
+    from tools import host_profile as HP
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import bal_problem
+    yield "bal_60_cameras", HP.problem_for("bal:60:6000:7")[0]
+    yield "bal_300_cameras", HP.problem_for("bal:300:20000:3")[0]
+    yield "camera_sees_landmark_twice", HP.problem_for("baldup:40:3000:3")[0]
+    yield "streets1723 (long-range loop closures)", HP.problem_for("streets1723")[0]
+    yield "ladybug1723 (the bench shape)", bal_problem(*D.ladybug_1723())[0]
+    yield "sphere2500 as one part", PB.sphere2500(load_golden("sphere2500"))[0]
+    yield "dubrovnik16 (16 cameras: complete graph)", bal_problem(*D.dubrovnik_16())[0]
+
+
+@pytest.mark.parametrize("name,p", list(_ordering_problems()), ids=[n for n, _ in _ordering_problems()])
+def test_device_ordering_equals_host_ordering(name, p, monkeypatch):
+    """Reverse Cuthill-McKee of the reduced variables on the device (csrc/device_ordering.hip: adjacency by radix sort, one workgroup
+    walking the BFS levels) against the host's serial queue (GTG_HOST_ORDERING=1): the same elimination order position for position,
+    hence the same layout hash and the same tile schedule (inference/Ordering.cpp:42-124 is the reference's place for this step)."""
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd import lib as L
+    monkeypatch.setenv("GTG_ND_DEPTH", "0")          # one part: the case the device kernel covers (nested dissection stays on the host)
+
+    def run():
+        dev = L.DeviceGraph(p)
+        res = (dev.reduced_order().copy(), dev.structure_hash(), dev.cholesky_flops())
+        dev.close()
+        return res
+
+    monkeypatch.delenv("GTG_HOST_ORDERING", raising=False)
+    a = run()
+    monkeypatch.setenv("GTG_HOST_ORDERING", "1")
+    b = run()
+    assert np.array_equal(a[0], b[0]), (np.flatnonzero(a[0] != b[0])[:10], a[0][:10], b[0][:10])
+    assert a[1] == b[1] and a[2] == b[2]

@@ -41,6 +41,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -692,23 +693,53 @@ VectorValues GpuLevenbergMarquardtOptimizer::solve(const GaussianFactorGraph& gf
   const auto* lm = dynamic_cast<const LevenbergMarquardtParams*>(&params);
   const double dmin = lm ? lm->minDiagonal : params_.minDiagonal, dmax = lm ? lm->maxDiagonal : params_.maxDiagonal;
   check(gtg_linearize(m.h), "gtg_linearize");   // the device's own linearisation at values(): what `gfg` should have been built from
-  // ... which is VERIFIED, not assumed: a sample of gfg's factors (64 evenly spaced + the last) is compared with the device's
-  // records of the same factors -- same keys, same [A | b] to 1e-9.  A graph linearised at other values, or with factors edited by
-  // the caller, has the right SHAPE but not these numbers; it goes to the reference's CPU solve like any other graph.  (Entries of
-  // smart factors -- Hessian factors the device never forms -- are null in the device's graph and are skipped.)
+  // ... which is VERIFIED, not assumed, for EVERY factor: gfg's [A | b] blocks are compared with the device's raw records of the same
+  // factors (same keys, same numbers to 1e-9) on host threads, without constructing a single factor object.  A graph linearised at
+  // other values, or with any factor edited by the caller, has the right SHAPE but not these numbers; it goes to the reference's CPU
+  // solve like any other graph.  (Entries of smart factors -- Hessian factors the device never forms -- are skipped.)
   {
-    const GaussianFactorGraph::shared_ptr dev = downloadLinearization();
-    const size_t step = std::max<size_t>(1, nf / 64);
-    for (size_t i = 0; recognised && i < nf; i = (i + step < nf || i == nf - 1) ? i + step : nf - 1) {
-      const auto mine = std::dynamic_pointer_cast<JacobianFactor>((*dev)[i]);
-      if (!mine) continue;
-      const auto theirs = std::dynamic_pointer_cast<JacobianFactor>(gfg[i]);
-      if (!theirs || theirs->keys() != mine->keys()) { recognised = false; break; }
-      const Matrix Ab1 = mine->augmentedJacobian(), Ab2 = theirs->augmentedJacobian();   // (whitened: the device's records carry no model)
-      if (Ab1.rows() != Ab2.rows() || Ab1.cols() != Ab2.cols() ||
-          !((Ab1 - Ab2).cwiseAbs().maxCoeff() <= 1e-9 * std::max(1.0, Ab2.cwiseAbs().maxCoeff()))) recognised = false;
+    static const int64_t width[4] = {26, 20, 78, 90};
+    std::vector<double> rec[4];
+    int64_t count[4] = {0, 0, 0, 0};
+    for (const auto& tf : m.fac_map) if (tf.first >= 0) count[tf.first]++;
+    for (int t = 0; t < 4; t++) {
+      if (!count[t]) continue;
+      rec[t].resize((size_t)(count[t] * width[t]));
+      check(gtg_get_jacobians(m.h, t, rec[t].data(), (int64_t)rec[t].size()), "gtg_get_jacobians");
     }
-    if (!recognised) return LevenbergMarquardtOptimizer::solve(gfg, params);
+    std::atomic<bool> same{true};
+    auto work = [&](size_t b0, size_t e0) {
+      for (size_t i = b0; i < e0 && same.load(std::memory_order_relaxed); i++) {
+        const auto tf = m.fac_map[i];
+        if (tf.first < 0) continue;
+        const auto* theirs = dynamic_cast<const JacobianFactor*>(gfg[i].get());
+        if (!theirs || theirs->get_model() || theirs->keys() != graph_[i]->keys()) { same = false; return; }
+        const double* r = rec[tf.first].data() + tf.second * width[tf.first];
+        // the record's layout (what downloadLinearization wraps): row-major blocks, then b
+        int rows, nblk, boff[2], bcols[2], rhs;
+        if (tf.first == GTG_FAC_GENERAL_SFM) { rows = 2; nblk = 2; boff[0] = 0; bcols[0] = 9; boff[1] = 18; bcols[1] = 3; rhs = 24; }
+        else if (tf.first == GTG_FAC_PROJECTION) { rows = 2; nblk = 2; boff[0] = 0; bcols[0] = 6; boff[1] = 12; bcols[1] = 3; rhs = 18; }
+        else if (tf.first == GTG_FAC_BETWEEN_POSE3) { const int d = (m.var_type[m.idOf(theirs->keys()[0])] == GTG_VAR_POSE2) ? 3 : 6; rows = d; nblk = 2; boff[0] = 0; bcols[0] = d; boff[1] = 36; bcols[1] = d; rhs = 72; }
+        else { const int32_t vt = m.var_type[m.idOf(theirs->keys()[0])]; const int d = vt == GTG_VAR_POSE3 ? 6 : vt == GTG_VAR_SFM_CAMERA ? 9 : 3; rows = d; nblk = 1; boff[0] = 0; bcols[0] = d; boff[1] = 0; bcols[1] = 0; rhs = 81; }
+        if ((int)theirs->size() != nblk || (int)theirs->rows() != rows) { same = false; return; }
+        double scale = 1.0, worst = 0.0;
+        for (int k = 0; k < nblk; k++) {
+          const auto A = theirs->getA(theirs->begin() + k);
+          if ((int)A.cols() != bcols[k]) { same = false; return; }
+          for (int a = 0; a < rows; a++)
+            for (int cc = 0; cc < bcols[k]; cc++) { const double x = A(a, cc); scale = std::max(scale, std::abs(x)); worst = std::max(worst, std::abs(x - r[boff[k] + a * bcols[k] + cc])); }
+        }
+        const auto bb = theirs->getb();
+        for (int a = 0; a < rows; a++) { scale = std::max(scale, std::abs(bb(a))); worst = std::max(worst, std::abs(bb(a) - r[rhs + a])); }
+        if (!(worst <= 1e-9 * scale)) { same = false; return; }
+      }
+    };
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)std::min(std::max(1u, std::thread::hardware_concurrency()), 16u), nf / 16384 + 1}));
+    std::vector<std::thread> pool;
+    for (size_t ti = 1; ti < nthreads; ti++) pool.emplace_back(work, nf * ti / nthreads, nf * (ti + 1) / nthreads);
+    work(0, nf / nthreads);
+    for (auto& t : pool) t.join();
+    if (!same) return LevenbergMarquardtOptimizer::solve(gfg, params);
   }
   double out[4];
   int rc;

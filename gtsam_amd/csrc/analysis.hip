@@ -397,7 +397,9 @@ void analyze(gtg_context& c) {
   if (!nd_forced && hi.user_order.empty() && c.n_red >= 24 * (int64_t)kTile && !ord_req) {
     double nnz = 0.0;
     for_each_block([&](int ra, int rb) { if (ra != rb) nnz += 2.0 * c.h_red_dim[ra] * c.h_red_dim[rb]; });
-    if (nnz <= 0.01 * (double)c.n_red * (double)c.n_red) nd_auto = 3;   // 8 leaves on 4 chain slots: sphere2500 1.39 ms (2 levels: 1.78, one chain: 4.6)
+    // 16 leaves on 8 chain slots (round 4, with the accumulator lanes of chol_dataflow.hip): sphere2500 1.07 ms, w20000 2.70 ms
+    // (3 levels on 4 slots, round 3: 1.38 / 5.05; 2 levels: 1.78; one chain: 4.6 / 18.4; 5 levels: no better)
+    if (nnz <= 0.01 * (double)c.n_red * (double)c.n_red) nd_auto = 4;
   }
   struct Joiner { std::thread t; std::exception_ptr err; ~Joiner() { if (t.joinable()) t.join(); } } block_level;   // (see below)
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -836,7 +838,7 @@ void analyze(gtg_context& c) {
   c.E.alloc(std::max<size_t>(kEStride * (size_t)c.n_obs, 1));
   c.vobs.alloc(std::max<size_t>(3 * (size_t)c.n_obs, 1));
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
-  c.S.alloc((size_t)c.plan.n_stored * kTileDoubles);   // the stored tiles only (context.h::SMat)
+  c.S.alloc((size_t)(c.plan.n_stored + (c.use_df ? c.df.n_scratch : 0)) * kTileDoubles);   // the stored tiles only (context.h::SMat) + the dataflow plan's scratch slots
   c.Dinv.alloc((NP / kTile) * (size_t)kTile * kTile);
   check_hip(hipMemsetAsync(c.Dinv.p, 0, sizeof(double) * c.Dinv.n, c.stream), "memset");
   c.chol_epoch_dev.alloc(1);

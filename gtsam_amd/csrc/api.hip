@@ -1001,7 +1001,11 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   CholPlan plan;
   build_chol_plan(plan, nt, nullptr, c->stream);   // dense: every lower tile + the rhs row has a slot
   DevBuf<double> S, Dinv, x, fail;
-  S.alloc((size_t)plan.n_stored * kTileDoubles); Dinv.alloc((size_t)nt * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
+  DfPlan df;
+  const char* sched = std::getenv("GTG_CHOL");
+  const bool use_df = !(sched && std::string(sched) == "streams");
+  if (use_df) build_df_plan(df, nt, nullptr, c->stream, plan.h_slot, plan.n_stored);   // (before S: the plan may want scratch slots behind the tiles)
+  S.alloc((size_t)(plan.n_stored + df.n_scratch) * kTileDoubles); Dinv.alloc((size_t)nt * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");
   if (!c->chol_epoch_dev.p) { c->chol_epoch_dev.alloc(1); check_hip(hipMemset(c->chol_epoch_dev.p, 0, sizeof(long long)), "memset"); }
   check_hip(hipMemsetAsync(fail.p, 0, 2 * sizeof(double), c->stream), "memset");
@@ -1019,12 +1023,9 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   pk[n - 1] = n >= 2 ? 1 : 2;
   DevBuf<unsigned char> dpk; dpk.upload(pk.data(), pk.size(), c->stream);
   DevBuf<double> dexp; dexp.alloc(NP / kTile + 1);
-  DfPlan df;
-  const char* sched = std::getenv("GTG_CHOL");
-  const bool use_df = !(sched && std::string(sched) == "streams");
   std::unique_lock<std::mutex> one_at_a_time;
   if (use_df) one_at_a_time = std::unique_lock<std::mutex>(df_device_lock(c->device));
-  if (use_df) { build_df_plan(df, nt, nullptr, c->stream, plan.h_slot, plan.n_stored); launch_cholesky_df(*c, Sm, NP, df, Dinv.p, fail.p, dpk.p, dexp.p); }
+  if (use_df) launch_cholesky_df(*c, Sm, NP, df, Dinv.p, fail.p, dpk.p, dexp.p);
   else launch_cholesky(*c, Sm, NP, plan, Dinv.p, fail.p, dpk.p, dexp.p);
   if (rhs) launch_backward_solve(*c, Sm, NP, plan, Dinv.p, x.p, fail.p);
   double hf2[2] = {0, 0};

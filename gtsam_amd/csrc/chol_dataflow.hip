@@ -327,7 +327,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 }
 
 
-__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD,
+__device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD, int G, int scratch,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
@@ -367,17 +367,42 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const unsigned lane_off = (unsigned)(lk * T + lr);
   double* Crow = C + (16 * rt) * T + 64 * h;
   v4f64 x[4];
-  long long* pflag_mine = part_flag + slotC;
-  if (piece > 0) {
-    // the tile holds the earlier pieces' partial result, written (write-through) by other workgroups -- possibly while an older
-    // version of it sat in this XCD's L2 (a piece before that one may have run here): read it past the L2
-    wait_flags(pflag_mine, epoch * kPieceBase + piece, pflag_mine, epoch * kPieceBase + piece, fail, sh, dbg, 7, I, J, piece);
+  // ---- where this piece's partial result lives.  The early pieces of a tile accumulate IN PLACE, one after the other (lane 0).  A tile
+  // whose contraction list is very long -- the diagonal tiles of a nested-dissection separator collect an update from every block
+  // column of the subtrees below them: 300 steps for the root of the 20 000-pose graph, all of them waiting for ONE chain of
+  // pieces while eight leaf chains produce their operands side by side -- has G accumulator LANES instead: early piece r belongs
+  // to lane r mod G, the lanes 1 .. G-1 accumulate from zero into scratch slots behind the stored tiles, and the final piece adds
+  // the lanes up in lane order (a fixed order: bit-reproducible).  G = 1 (every tile of the camera systems) is the in-place chain.
+  const int E = pieces - 1;                    // early pieces of the tile
+  const bool early = piece < E;
+  const int lane_g = (G > 1 && early) ? piece % G : 0, q = (G > 1 && early) ? piece / G : piece;
+  const int acc_slot = lane_g == 0 ? slotC : scratch + lane_g - 1;
+  double* AccRow = S + (int64_t)acc_slot * TT + (16 * rt) * T + 64 * h;
+  long long* pflag_mine = part_flag + acc_slot;
+  auto load_acc = [&](const double* row, bool add) {     // a partial result written (write-through) by another workgroup: read past the L1 (sc1)
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        x[c][r] = __hip_atomic_load((Crow + (4 * r) * T + 16 * c) + lane_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
+      for (int r = 0; r < 4; r++) {
+        const double v = __hip_atomic_load((row + (4 * r) * T + 16 * c) + lane_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x[c][r] = add ? x[c][r] + v : v;
+      }
+  };
+#pragma unroll
+  for (int c = 0; c < 4; c++) x[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (early ? q > 0 : E > 0) {
+    // lane 0 / this lane: the pieces before this one
+    const long long have = early ? q : (E + G - 1) / G;
+    wait_flags(pflag_mine, epoch * kPieceBase + have, pflag_mine, epoch * kPieceBase + have, fail, sh, dbg, 7, I, J, piece);
+    load_acc(AccRow, false);
+    if (!early)
+      for (int g = 1; g < G; g++) {            // the other lanes, in lane order
+        const long long ng = (E - g + G - 1) / G;
+        const long long* fg = part_flag + scratch + g - 1;
+        wait_flags(fg, epoch * kPieceBase + ng, fg, epoch * kPieceBase + ng, fail, sh, dbg, 7, I, J, piece);
+        load_acc(S + (int64_t)(scratch + g - 1) * TT + (16 * rt) * T + 64 * h, true);
+      }
+  } else if (lane_g == 0) {
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -433,14 +458,14 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   }
   if (tr && tid == 0) tr[1] = wall_clock64();
 
-  if (piece + 1 < pieces) {   // an early piece: the partial result goes back into the tile
+  if (early) {   // an early piece: the partial result goes back into its lane's tile
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
+      for (int r = 0; r < 4; r++) st_wt((AccRow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + piece + 1, sh);
+    if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + q + 1, sh);
     return;
   }
   if (I == J) {
@@ -475,7 +500,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 8 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J)
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -486,7 +511,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
 #if (GTG_DF_SAFE & 4)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and at the start of every task
 #endif
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -689,7 +714,9 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     std::vector<int> slot(nparts, 0);
     int nslots = 1;
     if (tree) {
-      static const int max_slots = std::max(1, std::min(8, getenv("GTG_DF_SLOTS") ? atoi(getenv("GTG_DF_SLOTS")) : 4));   // > 4: 16 reserved CUs
+      // (round 4: 8 slots = 16 reserved CUs by default -- with the accumulator lanes of the separators' diagonal tiles in place the leaf
+      // chains are the critical path of a pose graph, and they run side by side; up to 16 slots = 32 reserved CUs on request)
+      static const int max_slots = std::max(1, std::min(16, getenv("GTG_DF_SLOTS") ? atoi(getenv("GTG_DF_SLOTS")) : 8));
       std::vector<int> first_child(nparts, -1);
       for (int x = nparts - 1; x >= 0; x--) if ((*part_parent)[x] >= 0) first_child[(*part_parent)[x]] = x;
       int leaves = 0;
@@ -791,7 +818,21 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     return q;
   };
   {
-    std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 8);
+    // accumulator lanes of the tiles with very long contraction lists (run_task): G - 1 scratch slots each, behind the stored tiles
+    static const int lane_min = std::max(2, getenv("GTG_DF_LANE_MIN") ? atoi(getenv("GTG_DF_LANE_MIN")) : 8);   // early pieces from which a tile gets lanes
+    static const int lane_max = std::max(1, std::min(16, getenv("GTG_DF_LANES") ? atoi(getenv("GTG_DF_LANES")) : 8));
+    std::map<int32_t, std::pair<int32_t, int32_t>> lanes;   // slot of the tile -> (G, first scratch slot)
+    df.n_scratch = 0;
+    for (int64_t t = 0; t < df.n_tasks; t++) {
+      const int32_t* d = df.h_tasks.data() + 6 * t;
+      const int E = d[5] - 1;
+      if (d[4] != d[5] - 1 || E < lane_min || lane_max < 2) continue;       // (looked at once per tile: at its final piece)
+      const int G = std::min(lane_max, E / 4);
+      if (G < 2) continue;
+      lanes[slot_of(d[0], d[1])] = {G, (int32_t)(n_slots + df.n_scratch)};
+      df.n_scratch += G - 1;
+    }
+    std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 12);
     std::vector<int32_t> dk(2 * df.h_klist.size(), 0);
     std::vector<uint8_t> seen(df.h_klist.size(), 0);
     for (int64_t t = 0; t < df.n_tasks; t++) {
@@ -799,6 +840,8 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       const int I = d[0], J = d[1];
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
+      { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
+      dt.push_back(0); dt.push_back(0);
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
         dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);
@@ -815,7 +858,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
-  df.shadow = (n_slots + 511) / 512 * 512;   // (flag words by slot)
+  df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included)
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
@@ -854,7 +897,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   static std::map<std::pair<int, int>, DfStreams> per_device;   // (device, reserved CUs)
   static std::mutex per_device_mutex;
   DfStreams* dsp;
-  const int reserve = df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see below)
+  const int reserve = df.n_chain > 16 ? 32 : df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see below)
   { std::lock_guard<std::mutex> lock(per_device_mutex); dsp = &per_device[{c.device, reserve}]; }
   DfStreams& ds = *dsp;
   if (!ds.bulk) {

@@ -94,7 +94,8 @@ struct CholPlan {
 struct DfPlan {
   int nt = 0;
   int64_t n_tasks = 0;                          // bulk tasks: per block column J the diagonal accumulation PD(J), then the tiles (I, J) below, the rhs tile last
-  DevBuf<int32_t> tasks;                        // 6 per task: I, J, offset / count into klist, piece r of R (the last piece finishes the tile)
+  DevBuf<int32_t> tasks;                        // 12 per task: I, J, offset / count into klist, piece r of R (the last piece finishes the tile), slots, accumulator lanes
+  int64_t n_scratch = 0;                        // scratch slots behind the stored tiles of S: the accumulator lanes 1.. of the tiles with very long contraction lists
   DevBuf<long long> part_flag;                  // (nt + 1) x nt: kPieceBase epoch + pieces of the tile's contraction that are in
   DevBuf<int32_t> has_sub;                      // per diagonal tile J: tile (J, J-1) is stored (its update is streamed by the chain kernel)
   std::vector<int32_t> h_has_sub;

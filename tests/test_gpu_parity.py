@@ -162,12 +162,12 @@ def test_pose2_w20000_full_trajectory(gpu):
     assert rel(opt.values_packed(), g["final_values"]) <= 1e-4
 
 
-@pytest.mark.parametrize("sched,depth", [("dataflow", 2), ("dataflow", 3), ("dataflow", 0), ("streams", 2)])
+@pytest.mark.parametrize("sched,depth", [("dataflow", 2), ("dataflow", 3), ("dataflow", 4), ("dataflow", 0), ("streams", 2)])
 def test_nested_dissection_schedules_are_equivalent(gpu, monkeypatch, sched, depth):
     """Elimination-tree parallelism (the reference eliminates independent cliques concurrently, inference/ClusterTree-inst.h:218-317):
     a nested-dissection ordering (parts aligned to 256-column pairs, identity padding between them) gives the tile Cholesky
     independent parts.  dataflow: the parts are several diagonal chains inside the two persistent kernels (the default for
-    sparse pose graphs, 2 levels; chol_dataflow.hip::build_df_plan); streams: the round-1 tree schedule (chains on their own
+    sparse pose graphs: 4 levels on 8 chain slots since round 4; chol_dataflow.hip::build_df_plan); streams: the round-1 tree schedule (chains on their own
     streams, cross-part updates on one in-order stream); depth 0: one chain (RCM).  Every variant: the reference's damped solve
     and the reference's full LM trajectory on sphere2500."""
     from gtsam_amd.optimizer import DeviceLevenbergMarquardt
@@ -181,7 +181,7 @@ def test_nested_dissection_schedules_are_equivalent(gpu, monkeypatch, sched, dep
     assert pl["active"] == (sched == "dataflow")
     if sched == "dataflow":
         n_wg = len(pl["chain_off"]) - 1
-        assert (n_wg == 2) if depth == 0 else (2 < n_wg <= 8), n_wg
+        assert (n_wg == 2) if depth == 0 else (2 < n_wg <= 16), n_wg     # (<= 8 chain slots of two workgroups by default)
     dev.set_values(v0)
     dev.linearize()
     rc, out = dev.try_lambda(1e-5, False)

@@ -567,15 +567,24 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     __syncthreads();
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
-    const int dslot = chain_slots[2 * J], sslot = chain_slots[2 * J + 1];   // slots of (J, J) and of (J, J-1) (-1: not stored)
+    const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1), [3 J + 2]: of (J, J-2) (-1: not stored / not streamed)
     double* tile = S + (int64_t)dslot * TT;
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
-    if (sslot >= 0) {
-      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
+    // The updates of the two block columns right before this tile are applied HERE, in 32-column slices as the substitutions of the
+    // tiles (J, J-2) and (J, J-1) publish them: first column J-2's (its tile becomes final while the partner workgroup is still
+    // factoring tile J-1: this workgroup would be idle), then column J-1's (the last slice is the only thing left when that tile is
+    // final).  Column J-2 used to be the last step of PD(J), whose operand is final only ~30 us before PD(J) is needed: on a sixth of
+    // the columns PD(J) came 12 - 30 us late and the whole period stretched from 40 to 60 - 76 us (round 4 trace).  PD(J)'s
+    // youngest operand is column J-3 now: a whole period of slack.
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+      const int sslot = chain_slots[3 * J + 2 - pass];
+      if (sslot < 0) continue;
+      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-2), then tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
+        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 2 + pass, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
@@ -778,8 +787,14 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   std::vector<int32_t> has_sub(nt, 0);
   for (int J = 0; J < nt; J++) {
     // the contribution of block column J-1 to the diagonal tile is applied by k_df_chain itself (streamed): not in PD's list
+    // ... and, with ONE chain, so is the contribution of block column J-2 (bit 1; see chain_loop).  With several chains (parts of a
+    // nested dissection) the columns are taken in an interleaved order and J-2 need not be this chain's previous-but-one tile.
     ks = rowcols[J];
     if (!ks.empty() && ks.back() == J - 1) { ks.pop_back(); has_sub[J] = 1; }
+    // (measured, round 4: PD(J) is never late any more -- the p90 of the chain period falls from 59 to 54 us -- but the chain workgroup's
+    // extra 16 us of slices push the MEDIAN period from 40.0 to 41.6 us: 5.25 -> 5.49 ms on L1723.  Off by default; GTG_DF_STREAM2=1.)
+    static const bool stream2 = getenv("GTG_DF_STREAM2") && atoi(getenv("GTG_DF_STREAM2")) != 0;
+    if (stream2 && !tree && has_sub[J] && !ks.empty() && ks.back() == J - 2) { ks.pop_back(); has_sub[J] |= 2; }
     emit(J, J, ks);
     flops += t3 / 3.0 + (double)rowcols[J].size() * t3; stored++;
     for (int I = J + 1; I < nt; I++) {
@@ -796,8 +811,32 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // youngest operand is in place q - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
   // pieces that merely have to be done some columns later (with the early pieces of group q - 1 in front of them, the diagonal
   // accumulation was taken 30 us before it was needed and the chain waited 20 us for it every few columns)
-  auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
-  for (int q = 0; q < nt; q++) { put(finals[q]); if (q >= 1) put(early[q - 1]); }
+  auto put1 = [&](const Rec& t) { for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
+  auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) put1(t); };
+  // One chain: the two tasks of a column that the serial chain waits for -- PD(J) and the tile right below the diagonal tile -- are
+  // queued one group EARLIER than the rest of their column, in front of the previous group's burst of early pieces (and behind their
+  // own early pieces of that burst, so that a task still only waits for smaller tickets).  A burst is several hundred pieces of
+  // ~100 us: behind it PD(J) was taken 12 - 30 us too late on every sixth column of the L1723 shape and the chain period stretched
+  // from 40 to 60 - 76 us (round 4 trace: 19 of 121 periods, 0.4 ms of 5.2).  Taken early the two tasks just hold two of the 248
+  // workgroups a period longer.
+  // (GTG_DF_PULL = number of tiles below the diagonal tile that are pulled with it: the tiles (J+1..J+w, J) are the operands of the
+  // next columns' critical tasks; 0 switches the pulling off)
+  static const int pull_rows = tree ? -1 : (getenv("GTG_DF_PULL") ? atoi(getenv("GTG_DF_PULL")) - 1 : 1);
+  const bool pull = pull_rows >= 0;
+  auto critical = [&](const Rec& t, int c) { return t.J == c && t.I >= c && t.I <= c + pull_rows && t.I < nt; };   // (measured on L1723: 1 row 5.17 ms, 2 rows 5.17, 4 rows 5.19; off 5.30)
+  std::vector<char> pulled(nt + 1, 0);
+  for (int q = 0; q < nt; q++) {
+    for (const Rec& t : finals[q]) { if (pulled[q] && critical(t, q)) continue; put1(t); }
+    if (q >= 1) {
+      const int c = q + 1;            // the column whose critical tasks are pulled in front of early[q - 1]
+      if (pull && c < nt) {
+        for (const Rec& t : early[q - 1]) if (critical(t, c)) put1(t);
+        for (const Rec& t : finals[c]) if (critical(t, c)) put1(t);
+        pulled[c] = 1;
+        for (const Rec& t : early[q - 1]) if (!critical(t, c)) put1(t);
+      } else put(early[q - 1]);
+    }
+  }
   put(early[nt - 1]);
   df.nt = nt; df.n_tasks = (int64_t)df.h_tasks.size() / 6;
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
@@ -850,9 +889,9 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     }
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
-    std::vector<int32_t> cs(2 * (size_t)nt, -1);
-    for (int J = 0; J < nt; J++) { cs[2 * J] = slot_of(J, J); if (has_sub[J]) cs[2 * J + 1] = slot_of(J, J - 1); }
-    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1)
+    std::vector<int32_t> cs(3 * (size_t)nt, -1);
+    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); if (has_sub[J] & 2) cs[3 * J + 2] = slot_of(J, J - 2); }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slots of (J, J-1) / (J, J-2) or -1)
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);

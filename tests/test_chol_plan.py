@@ -190,6 +190,10 @@ def _execute_df(pl, df, t=8, seed=0):
         if I == J:
             # k_df_chain: the update of block column J-1 is its own (streamed behind the substitution of tile (J, J-1), which
             # must therefore precede PD(J) in ticket order -- it is the first task of column J-1's group), then the factorisation
+            # (round 4: with one chain also block column J-2's, applied in front of it; recognisable by its absence from PD's list)
+            if (J, J - 2) in owned and J - 2 not in seen_k[(J, J)]:
+                assert (J, J - 1) in owned and J - 1 not in seen_k[(J, J)]
+                acc = acc - L(J, J - 2) @ L(J, J - 2).T
             if (J, J - 1) in owned:
                 assert J - 1 not in seen_k[(J, J)], "PD(J) and the chain kernel would both apply block column J-1"
                 acc = acc - L(J, J - 1) @ L(J, J - 1).T
@@ -260,7 +264,7 @@ def _simulate_df(pl, df, n_bulk):
         for w in range(len(chain_at)):
             if chain_at[w] < coff[w + 1]:
                 J = int(ctiles[chain_at[w]])
-                if J in pd_done and ((J, J - 1) not in owned or (J, J - 1) in final):
+                if J in pd_done and ((J, J - 1) not in owned or (J, J - 1) in final) and ((J, J - 2) not in owned or (J, J - 2) in final):
                     diag_done.add(J); chain_at[w] += 1; progress = True
     assert done_tasks == len(tasks) and len(diag_done) == nt, \
         f"deadlock with {n_bulk} bulk workgroups: {done_tasks} of {len(tasks)} tasks, {len(diag_done)} of {nt} diagonal tiles"

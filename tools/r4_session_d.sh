@@ -5,7 +5,7 @@ out=gpurun_out/${1:-r4d}; mkdir -p $out
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline_parity.py tests/test_gpu_dataflow_protocol.py -x -q 2>&1 | tail -8 > $out/gpu_tests.log
 tail -3 $out/gpu_tests.log
 timeout 300 python bench.py --steps 16 --warmup 4 --cpu-baseline off --skip-dense-roofline --traffic off --host python > $out/bench.json 2> $out/bench.err
-timeout 300 python bench.py --workload sphere2500 --steps 16 --warmup 4 --cpu-baseline off --skip-dense-roofline --traffic off --host python > $out/bench_sphere2500.json 2> $out/bench_sphere2500.err
+
 timeout 300 python tools/df_trace.py --raw > $out/df_trace_summary.txt 2> $out/df_trace.err; cp gpurun_out/df_trace_raw.npz $out/ 2>/dev/null
 python - <<PY
 import json

@@ -760,8 +760,10 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // part_flag = kPieceBase epoch + r + 1) and is queued EARLIER than the tile's own column: right behind the block column of its
   // youngest operand, where everything it reads is final and it runs without waiting.  Only the last piece (the youngest
   // kFinal steps + the substitution) sits in the tile's column and streams behind the columns before it.
-  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 6);
-  static const int kFinal = std::max(1, getenv("GTG_DF_FINAL") ? atoi(getenv("GTG_DF_FINAL")) : 3);
+  // (kPiece, kFinal) swept on the L1723 shape in round 4 (Cholesky ms): (6,3) 5.17, (4,4) 5.09, (6,4) 5.10, (4,5) 5.11, (3,4) 5.14,
+  // (4,3) 5.15, (4,6) 5.16, (8,3) 5.32, (2,4) 5.32, (6,2) 5.48, (10,3) 5.51.
+  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 4);
+  static const int kFinal = std::max(1, getenv("GTG_DF_FINAL") ? atoi(getenv("GTG_DF_FINAL")) : 4);
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
   auto emit = [&](int I, int J, std::vector<int32_t>& ks) {

@@ -528,6 +528,24 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
   bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
+// one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
+__device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
+  double* Cb = A + boff(ib, cb);
+  const double* Li = X + ib * SB * PB;
+  const double* Lc = X + cb * SB * PB;
+  v4f64 acc;
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
+#pragma unroll
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
+    acc = MFMA(av, bv, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
+}
+
 // The diagonal tiles.  Two workgroups (even / odd J) take turns, so that everything before the last slice of tile J -- waiting for
 // PD(J), bringing the tile into LDS, the first three slices -- happens while the partner factors tile J-1 (with one workgroup
 // those 13 us per tile were on the serial chain).  Tile J: wait until PD(J) is in (every update but the one of block column J-1),
@@ -539,7 +557,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
                                            const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                            const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
-                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp, const int defer) {
+                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
@@ -551,7 +569,6 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1), [3 J + 2]: of (J, J-2) (-1: not stored / not streamed)
     double* tile = S + (int64_t)dslot * TT;
-    bool deferred = false;
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     // The updates of the two block columns right before this tile are applied HERE, in 32-column slices as the substitutions of the
     // tiles (J, J-2) and (J, J-1) publish them: first column J-2's (its tile becomes final while the partner workgroup is still
@@ -591,13 +608,6 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
           }
         }
         __syncthreads();
-        if (defer && pass == 1 && q == 3) {
-          // The LAST slice is on the serial chain of the factorisation (the tile left of this one became final a moment ago): only its
-          // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- is applied here (2 rounds of MFMA
-          // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).
-          for (int t = wave; t < 16; t += 8) slice_task(A, X, t >> 2, 0, (t >> 1) & 1, t & 1, lr, lk);
-          deferred = true;
-        } else
         for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
           const int blk = t >> 2;
           int ib = 0, rem = blk;
@@ -606,8 +616,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
-               deferred ? X : nullptr);
+    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
@@ -619,10 +628,10 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, dou
                                                      const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
-                                                     const int32_t* __restrict__ chain_tiles, const int defer) {
+                                                     const int32_t* __restrict__ chain_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
-             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, defer);
+             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): the first n_chain workgroups are the chain (dispatched first, so they are resident before
@@ -637,9 +646,9 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
-                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain, const int defer) {
+                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, defer); }
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
   else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
@@ -960,15 +969,13 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const long long epoch = ++c.chol_epoch;
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, epoch, df.ctrl.p);
   static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
-  // the part of the last slice that panel 0 does not read is applied under panel 0's pivot chain (chain_loop; GTG_DF_DEFER=0: the A/B)
-  static const int defer = getenv("GTG_DF_DEFER") ? atoi(getenv("GTG_DF_DEFER")) : 1;
   if (single) {
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
                        df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
-                       df.chain_off.p, df.chain_tiles.p, df.n_chain, defer);
+                       df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -985,7 +992,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
   hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p, defer);
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);

@@ -319,25 +319,6 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, doub
   }
 }
 
-// one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
-// [SB][PB] (a 32-column slice of the tile left of the diagonal tile: chol_dataflow.hip::chain_loop)
-__device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
-  double* Cb = A + boff(ib, cb);
-  const double* Li = X + ib * SB * PB;
-  const double* Lc = X + cb * SB * PB;
-  v4f64 acc;
-#pragma unroll
-  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
-#pragma unroll
-  for (int kk = 0; kk < SB; kk += 4) {
-    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
-    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
-    acc = MFMA(av, bv, acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
-}
-
 // ---- diagonal tile ------------------------------------------------------------------------------------------
 // One workgroup of 8 wavefronts; per 32-column panel jb of the tile:
 //   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 5: follower
@@ -378,12 +359,7 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* tile, double* __r
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ tile, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
-                                           const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr,
-                                           const double* Xdef = nullptr) {
-  // Xdef (dataflow schedule): the last 32-column slice of the tile left of this one, in LDS -- the caller has applied it to the blocks
-  // (ib, 0) only, which is all that panel 0 reads; its contribution to the six blocks right of panel 0 is applied HERE by the two
-  // wavefronts that have nothing to do during panel 0, under the pivot chain, before the barrier in front of P3 (which is the next
-  // to touch those blocks: the order of the sums on every entry is unchanged, the result bit-identical)
+                                           const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr) {
   const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
   // (host-counted): a word in device memory that every factorisation rewrites was read one factorisation stale by one of two
   // co-operating kernels under multi-handle contention (rate ~1e-3; tools/df_contention_diag.py, profiles/r03_df_contention.txt)
@@ -417,13 +393,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
     } else if (wave <= nfol || wave == 5) {
       stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt);
-    } else if (jb == 0) {
-      if (Xdef)
-        for (int t = wave - 6; t < 24; t += 2) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles
-          const int b2 = (t >> 2) * 2;
-          slice_task(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1, lr, lk);
-        }
-    } else {
+    } else if (jb > 0) {
       const int pj = jb - 1;                            // deferred work of panel pj
       const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
       // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers

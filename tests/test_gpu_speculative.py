@@ -55,7 +55,12 @@ def test_speculative_lambda_search_follows_the_sequential_trajectory(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GTG_QUIET="1",
                    GTG_CHOL="streams")
         procs.append(subprocess.Popen([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=900) for p in procs]
+    try:
+        outs = [p.communicate(timeout=600) for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("a replica did not finish within 600 s: " + " | ".join((p.communicate()[1] or "")[-800:] for p in procs))
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     recs = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so, _ in outs]

@@ -84,6 +84,66 @@ template <class F> static void run_threads(int nt, F f) {   // f(thread index) o
   if (err) std::rethrow_exception(err);
 }
 
+// ---- grouped Schur complement: its lists (context.h::SchurGroups; the layout is stated in numpy and pinned through the upload hashes in
+// tests/test_schur_groups_spec.py).  Host code over the landmark -> observation lists and the FINAL positions of the cameras; runs only
+// with GTG_SCHUR=groups.  Returns false (and leaves the pair-major kernel in charge) for a graph whose cells do not fit the kernel's
+// slot buffer or its 16-bit run lengths.
+static bool build_schur_groups(gtg_context& c, const std::vector<int64_t>& lm_ptr, const std::vector<int32_t>& lm_obs,
+                               const std::vector<int32_t>& obs_red, hipStream_t s) {
+  SchurGroups& g = c.sg;
+  const int G = kSchurGroup, nrv = c.n_red_vars;
+  const int64_t n_obs = (int64_t)lm_obs.size();
+  if (nrv == 0 || n_obs == 0 || (int64_t)((nrv + G - 1) / G) * ((nrv + G - 1) / G) >= ((int64_t)1 << 31)) return false;
+  const int NG = (nrv + G - 1) / G;
+  std::vector<int32_t> opos((size_t)n_obs), sobs((size_t)n_obs), pos_red((size_t)nrv);
+  for (int64_t o = 0; o < n_obs; o++) opos[(size_t)o] = c.h_red_pos[obs_red[(size_t)o]];
+  for (int r = 0; r < nrv; r++) pos_red[(size_t)c.h_red_pos[r]] = r;
+  struct Cell { uint32_t key; int32_t a0, b0, pq; };
+  std::vector<Cell> cells;
+  cells.reserve((size_t)n_obs);
+  std::vector<std::pair<int32_t, int32_t>> runs;   // (start in the segment, length) of every group of the landmark
+  bool ok = true;
+  for (size_t l = 0; l + 1 < lm_ptr.size(); l++) {
+    const int64_t b = lm_ptr[l], e = lm_ptr[l + 1];
+    std::copy(lm_obs.begin() + b, lm_obs.begin() + e, sobs.begin() + b);
+    std::stable_sort(sobs.begin() + b, sobs.begin() + e, [&](int32_t x, int32_t y) { return opos[(size_t)x] < opos[(size_t)y]; });
+    runs.clear();
+    for (int64_t i = b; i < e; i++) {
+      const int grp = opos[(size_t)sobs[(size_t)i]] / G;
+      if (runs.empty() || opos[(size_t)sobs[(size_t)(b + runs.back().first)]] / G != grp) runs.push_back({(int32_t)(i - b), 1});
+      else runs.back().second++;
+    }
+    for (size_t ia = 0; ia < runs.size(); ia++) {
+      const int ga = opos[(size_t)sobs[(size_t)(b + runs[ia].first)]] / G;
+      for (size_t ib = 0; ib <= ia; ib++) {
+        const int gb = opos[(size_t)sobs[(size_t)(b + runs[ib].first)]] / G;
+        const int p = runs[ia].second, q = runs[ib].second;
+        if (p > 0xffff || q > 0xffff || (ia == ib ? p : p + q) > kSchurChunkSlots) ok = false;
+        cells.push_back(Cell{(uint32_t)ga * (uint32_t)NG + (uint32_t)gb, (int32_t)(b + runs[ia].first), (int32_t)(b + runs[ib].first), p | (q << 16)});
+      }
+    }
+  }
+  if (!ok || cells.empty() || cells.size() >= ((size_t)1 << 31)) return false;
+  std::stable_sort(cells.begin(), cells.end(), [](const Cell& x, const Cell& y) { return x.key < y.key; });   // landmark order inside a group pair
+  std::vector<int32_t> a0(cells.size()), b0(cells.size()), pq(cells.size());
+  std::vector<int32_t> pair_key;
+  std::vector<int64_t> pair_ptr;
+  for (size_t i = 0; i < cells.size(); i++) {
+    a0[i] = cells[i].a0; b0[i] = cells[i].b0; pq[i] = cells[i].pq;
+    if (i == 0 || cells[i].key != cells[i - 1].key) { pair_key.push_back((int32_t)cells[i].key); pair_ptr.push_back((int64_t)i); }
+  }
+  pair_ptr.push_back((int64_t)cells.size());
+  std::vector<int32_t> order(pair_key.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pair_ptr[(size_t)x + 1] - pair_ptr[(size_t)x] > pair_ptr[(size_t)y + 1] - pair_ptr[(size_t)y]; });
+  g.NG = NG; g.n_pairs = (int64_t)pair_key.size(); g.n_cells = (int64_t)cells.size();
+  up(g.obs, sobs, s); up(g.cell_a0, a0, s); up(g.cell_b0, b0, s); up(g.cell_pq, pq, s);
+  up(g.pair_key, pair_key, s); up(g.pair_ptr, pair_ptr, s); up(g.order, order, s);
+  up(g.obs_pos, opos, s); up(g.pos_red, pos_red, s);
+  g.active = true;
+  return true;
+}
+
 // Three 20-bit pieces of the layout hash and a 1 go through the all-reduce: the sums must be n_shards times this shard's
 // own values (every shard derived the same layout AND the communicator spans n_shards ranks).
 void verify_layout(gtg_context& c) {
@@ -827,6 +887,25 @@ void analyze(gtg_context& c) {
     c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);
     if (c.n_pair_terms == 0) { c.pair_oa.alloc(1); c.pair_ob.alloc(1); }
   }
+
+  // ---- grouped Schur complement (GTG_SCHUR=groups; schur_groups.hip): lists from the final positions.  With the incidence lists built
+  // on the device they come back once (4 MB on the L1723 shape); a device version of this pass follows the kernel's first measurements.
+  c.sg.active = false;
+  { const char* sm = std::getenv("GTG_SCHUR");
+    if (sm && std::string(sm) == "groups" && c.n_shards == 1 && c.n_pairs > 0) {
+      if (device_terms) {
+        std::vector<int64_t> d_ptr((size_t)c.n_lm + 1);
+        std::vector<int32_t> d_obs((size_t)c.n_obs), d_red((size_t)c.n_obs);
+        check_hip(hipMemcpyAsync(d_ptr.data(), c.lm_obs_ptr.p, sizeof(int64_t) * d_ptr.size(), hipMemcpyDeviceToHost, s), "D2H");
+        check_hip(hipMemcpyAsync(d_obs.data(), c.lm_obs.p, sizeof(int32_t) * d_obs.size(), hipMemcpyDeviceToHost, s), "D2H");
+        check_hip(hipMemcpyAsync(d_red.data(), c.obs_red.p, sizeof(int32_t) * d_red.size(), hipMemcpyDeviceToHost, s), "D2H");
+        check_hip(hipStreamSynchronize(s), "sync");
+        (void)build_schur_groups(c, d_ptr, d_obs, d_red, s);
+      } else {
+        (void)build_schur_groups(c, lm_obs_ptr, lm_obs, obs_red, s);
+      }
+      clk.lap("grouped schur lists (GTG_SCHUR=groups)");
+    } }
 
   // ---- numeric buffers --------------------------------------------------------------------------
   const size_t NP = c.NP;

@@ -89,6 +89,24 @@ struct CholPlan {
   double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles
 };
 
+// Grouped Schur complement (schur_groups.hip; GTG_SCHUR=groups -- not the default): the cameras in groups of kSchurGroup consecutive
+// positions of the elimination order, one workgroup per pair of groups, its CELLS (one per landmark seen from both groups) in landmark
+// order.  Layout stated and pinned in tests/test_schur_groups_spec.py.
+constexpr int kSchurGroup = 8;                  // cameras per group = wavefronts per workgroup (one row camera each)
+constexpr int kSchurChunkSlots = 128;           // E slots of one chunk of cells in LDS
+struct SchurGroups {
+  bool active = false;
+  int NG = 0;                                   // groups
+  int64_t n_pairs = 0, n_cells = 0;
+  DevBuf<int32_t> obs;                          // every landmark's observations, sorted by the position of their camera (segments of lm_obs)
+  DevBuf<int32_t> cell_a0, cell_b0, cell_pq;    // per cell: runs of its A / B entries in `obs` (start, start, p | q << 16); cells sorted by group pair, landmark order inside
+  DevBuf<int32_t> pair_key;                     // ga * NG + gb of every group pair that has cells, ascending
+  DevBuf<int64_t> pair_ptr;                     // its cells
+  DevBuf<int32_t> order;                        // the group pairs by descending number of cells: workgroup b takes pair order[b]
+  DevBuf<int32_t> obs_pos;                      // observation -> position of its camera
+  DevBuf<int32_t> pos_red;                      // position -> reduced variable
+};
+
 // Dataflow schedule of the same factorisation (chol_dataflow.hip): one task per stored 128x128 tile, left-looking, executed by
 // persistent workgroups that take tasks in a fixed topological order; dependencies are epoch-stamped flags in HBM.
 struct DfPlan {
@@ -225,6 +243,7 @@ struct gtg_context {
   gt::DevBuf<int64_t> hoff_ptr;  gt::DevBuf<int32_t> hoff_fac;       // block -> between factors (sign bit = transposed)
   int64_t n_pairs = 0, n_pair_terms = 0;                             // Schur block pairs
   bool device_terms = false;                                         // their term lists were built on the device (device_analysis.hip)
+  gt::SchurGroups sg;                                                // the grouped form of the same sums (GTG_SCHUR=groups)
   gt::DevBuf<int32_t> pair_row, pair_col;
   gt::DevBuf<int64_t> pair_ptr;  gt::DevBuf<int32_t> pair_oa, pair_ob;
 

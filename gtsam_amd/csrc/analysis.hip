@@ -99,32 +99,70 @@ static bool build_schur_groups(gtg_context& c, const std::vector<int64_t>& lm_pt
   for (int64_t o = 0; o < n_obs; o++) opos[(size_t)o] = c.h_red_pos[obs_red[(size_t)o]];
   for (int r = 0; r < nrv; r++) pos_red[(size_t)c.h_red_pos[r]] = r;
   struct Cell { uint32_t key; int32_t a0, b0, pq; };
-  std::vector<Cell> cells;
-  cells.reserve((size_t)n_obs);
-  std::vector<std::pair<int32_t, int32_t>> runs;   // (start in the segment, length) of every group of the landmark
-  bool ok = true;
-  for (size_t l = 0; l + 1 < lm_ptr.size(); l++) {
-    const int64_t b = lm_ptr[l], e = lm_ptr[l + 1];
-    std::copy(lm_obs.begin() + b, lm_obs.begin() + e, sobs.begin() + b);
-    std::stable_sort(sobs.begin() + b, sobs.begin() + e, [&](int32_t x, int32_t y) { return opos[(size_t)x] < opos[(size_t)y]; });
-    runs.clear();
-    for (int64_t i = b; i < e; i++) {
-      const int grp = opos[(size_t)sobs[(size_t)i]] / G;
-      if (runs.empty() || opos[(size_t)sobs[(size_t)(b + runs.back().first)]] / G != grp) runs.push_back({(int32_t)(i - b), 1});
-      else runs.back().second++;
-    }
-    for (size_t ia = 0; ia < runs.size(); ia++) {
-      const int ga = opos[(size_t)sobs[(size_t)(b + runs[ia].first)]] / G;
-      for (size_t ib = 0; ib <= ia; ib++) {
-        const int gb = opos[(size_t)sobs[(size_t)(b + runs[ib].first)]] / G;
-        const int p = runs[ia].second, q = runs[ib].second;
-        if (p > 0xffff || q > 0xffff || (ia == ib ? p : p + q) > kSchurChunkSlots) ok = false;
-        cells.push_back(Cell{(uint32_t)ga * (uint32_t)NG + (uint32_t)gb, (int32_t)(b + runs[ia].first), (int32_t)(b + runs[ib].first), p | (q << 16)});
+  // per landmark (host threads over contiguous landmark ranges; the result does not depend on their number: a thread's cells are
+  // appended behind those of the threads before it, i.e. in landmark order)
+  const int n_lm = (int)lm_ptr.size() - 1;
+  const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_obs / 16384));
+  std::vector<std::vector<Cell>> part((size_t)nth);
+  std::vector<char> bad((size_t)nth, 0);
+  run_threads(nth, [&](int t) {
+    const int l0 = (int)((int64_t)n_lm * t / nth), l1 = (int)((int64_t)n_lm * (t + 1) / nth);
+    std::vector<Cell>& out = part[(size_t)t];
+    out.reserve((size_t)(lm_ptr[(size_t)l1] - lm_ptr[(size_t)l0]));
+    std::vector<std::pair<int32_t, int32_t>> runs;   // (start in the segment, length) of every group of the landmark
+    for (int l = l0; l < l1; l++) {
+      const int64_t b = lm_ptr[(size_t)l], e = lm_ptr[(size_t)l + 1];
+      std::copy(lm_obs.begin() + b, lm_obs.begin() + e, sobs.begin() + b);
+      std::stable_sort(sobs.begin() + b, sobs.begin() + e, [&](int32_t x, int32_t y) { return opos[(size_t)x] < opos[(size_t)y]; });
+      runs.clear();
+      for (int64_t i = b; i < e; i++) {
+        const int grp = opos[(size_t)sobs[(size_t)i]] / G;
+        if (runs.empty() || opos[(size_t)sobs[(size_t)(b + runs.back().first)]] / G != grp) runs.push_back({(int32_t)(i - b), 1});
+        else runs.back().second++;
+      }
+      for (size_t ia = 0; ia < runs.size(); ia++) {
+        const int ga = opos[(size_t)sobs[(size_t)(b + runs[ia].first)]] / G;
+        for (size_t ib = 0; ib <= ia; ib++) {
+          const int gb = opos[(size_t)sobs[(size_t)(b + runs[ib].first)]] / G;
+          const int p = runs[ia].second, q = runs[ib].second;
+          if (p > 0xffff || q > 0xffff || (ia == ib ? p : p + q) > kSchurChunkSlots) bad[(size_t)t] = 1;
+          out.push_back(Cell{(uint32_t)ga * (uint32_t)NG + (uint32_t)gb, (int32_t)(b + runs[ia].first), (int32_t)(b + runs[ib].first), p | (q << 16)});
+        }
       }
     }
+  });
+  size_t n_cells = 0;
+  for (int t = 0; t < nth; t++) { n_cells += part[(size_t)t].size(); if (bad[(size_t)t]) return false; }
+  if (n_cells == 0 || n_cells >= ((size_t)1 << 31)) return false;
+  // stable counting sort by group pair (landmark order inside a group pair): only the keys that occur get a bucket
+  std::vector<uint32_t> keys; keys.reserve(n_cells);
+  for (int t = 0; t < nth; t++) for (const Cell& x : part[(size_t)t]) keys.push_back(x.key);
+  std::vector<uint32_t> uniq;
+  const uint64_t key_space = (uint64_t)NG * (uint64_t)NG;
+  if (key_space <= ((uint64_t)1 << 24)) {   // the usual case: mark the keys that occur
+    std::vector<uint8_t> seen((size_t)key_space, 0);
+    for (uint32_t k : keys) seen[k] = 1;
+    for (size_t k = 0; k < seen.size(); k++) if (seen[k]) uniq.push_back((uint32_t)k);
+  } else {
+    uniq = keys;
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
   }
-  if (!ok || cells.empty() || cells.size() >= ((size_t)1 << 31)) return false;
-  std::stable_sort(cells.begin(), cells.end(), [](const Cell& x, const Cell& y) { return x.key < y.key; });   // landmark order inside a group pair
+  std::vector<int64_t> start(uniq.size() + 1, 0);
+  std::vector<uint32_t> bucket(n_cells);
+  if (key_space <= ((uint64_t)1 << 24)) {
+    std::vector<uint32_t> rank((size_t)key_space, 0);
+    for (size_t k = 0; k < uniq.size(); k++) rank[uniq[k]] = (uint32_t)k;
+    for (size_t i = 0; i < n_cells; i++) { bucket[i] = rank[keys[i]]; start[bucket[i] + 1]++; }
+  } else {
+    for (size_t i = 0; i < n_cells; i++) { bucket[i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), keys[i]) - uniq.begin()); start[bucket[i] + 1]++; }
+  }
+  for (size_t k = 0; k < uniq.size(); k++) start[k + 1] += start[k];
+  std::vector<Cell> cells(n_cells);
+  { std::vector<int64_t> at(start.begin(), start.end() - 1);
+    size_t i = 0;
+    for (int t = 0; t < nth; t++) for (const Cell& x : part[(size_t)t]) cells[(size_t)at[bucket[i++]]++] = x; }
+  part.clear();
   std::vector<int32_t> a0(cells.size()), b0(cells.size()), pq(cells.size());
   std::vector<int32_t> pair_key;
   std::vector<int64_t> pair_ptr;

@@ -1,0 +1,42 @@
+#!/bin/bash
+# tools/next_round_first_session.sh [tag] -- what round 4 left for the first GPU minutes of the next round (through gpurun, ~12 GPU-min):
+#   1. the grouped Schur complement's A/B against the default (bit-identity of factor / step / LM trace, four workloads), then its
+#      bench lines on the L1723 and Venice shapes next to the default's (phase_ms_per_call.schur is the number);
+#   2. the legacy tree stream schedule in a loop (the one test that hung once, profiles/r04_streams_tree_hang.txt): 40 runs of the
+#      test's child under a 120 s bound each; a run that does not return leaves the runtime's log of its last seconds behind.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/next_round_first_session.sh r05a'
+out=gpurun_out/${1:-r05a}; mkdir -p $out
+GTG_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_schur_groups.py -x -q -s 2>&1 | tail -25 > $out/schur_groups_ab.log
+tail -3 $out/schur_groups_ab.log
+B="python bench.py --steps 16 --warmup 4 --cpu-baseline off --skip-dense-roofline --traffic off --host python"
+for w in ladybug1723 venice1778; do
+  timeout 300 $B --workload $w > $out/bench_${w}_pairs.json 2> $out/bench_${w}_pairs.err
+  GTG_SCHUR=groups timeout 300 $B --workload $w > $out/bench_${w}_groups.json 2> $out/bench_${w}_groups.err
+done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob('$out/bench_*_*.json')):
+    try:
+        j = json.load(open(f)); print(f.split('/')[-1], round(j['value'], 2), 'it/s; schur', round(j['phase_ms_per_call']['schur'], 3), 'ms; error', j['converged_error'])
+    except Exception as e:
+        print(f, 'failed', open(f.replace('.json', '.err')).read()[-300:])
+PY
+# ---- the tree stream schedule, in a loop
+python - > $out/nd_child.py <<PY
+import re
+src = open('tests/test_gpu_parity.py').read()
+code = re.search(r'_ND_CHILD = r"""(.*?)"""', src, re.S).group(1)
+print(code % {"root": "$PWD", "sched": "streams", "depth": 2})
+PY
+ok=0; hung=0
+for i in $(seq 1 40); do
+  if GTG_CHOL=streams GTG_ND_DEPTH=2 timeout 120 python $out/nd_child.py > $out/nd_last.out 2> $out/nd_last.err; then ok=$((ok+1));
+  else
+    rc=$?; hung=$((hung+1)); cp $out/nd_last.err $out/nd_failed_$i.err
+    echo "run $i: rc $rc" >> $out/streams_loop.txt
+    # once more with the runtime's log, in case it is reproducible on this box
+    GTG_CHOL=streams GTG_ND_DEPTH=2 AMD_LOG_LEVEL=3 timeout 120 python $out/nd_child.py > /dev/null 2> $out/nd_amdlog_$i.err; tail -c 20000 $out/nd_amdlog_$i.err > $out/nd_amdlog_$i.tail; rm -f $out/nd_amdlog_$i.err
+    [ $hung -ge 3 ] && break
+  fi
+done
+echo "tree stream schedule: $ok clean, $hung not clean (rc 124 = did not return within 120 s)" | tee -a $out/streams_loop.txt

@@ -930,7 +930,8 @@ void analyze(gtg_context& c) {
   // on the device they come back once (4 MB on the L1723 shape); a device version of this pass follows the kernel's first measurements.
   c.sg.active = false;
   { const char* sm = std::getenv("GTG_SCHUR");
-    if (sm && std::string(sm) == "groups" && c.n_shards == 1 && c.n_pairs > 0) {
+    if (sm && (std::string(sm) == "groups" || std::string(sm) == "groups_pipe") && c.n_shards == 1 && c.n_pairs > 0) {
+      c.sg.pipelined = std::string(sm) == "groups_pipe";
       if (device_terms) {
         std::vector<int64_t> d_ptr((size_t)c.n_lm + 1);
         std::vector<int32_t> d_obs((size_t)c.n_obs), d_red((size_t)c.n_obs);

@@ -96,6 +96,7 @@ constexpr int kSchurGroup = 8;                  // cameras per group = wavefront
 constexpr int kSchurChunkSlots = 128;           // E slots of one chunk of cells in LDS
 struct SchurGroups {
   bool active = false;
+  bool pipelined = false;                       // GTG_SCHUR=groups_pipe: the next chunk's slots are fetched under the current chunk's multiplications
   int NG = 0;                                   // groups
   int64_t n_pairs = 0, n_cells = 0;
   DevBuf<int32_t> obs;                          // every landmark's observations, sorted by the position of their camera (segments of lm_obs)

@@ -49,7 +49,7 @@ def _run(workload, groups):
     env = dict(os.environ)
     env.pop("GTG_SCHUR", None)
     if groups:
-        env["GTG_SCHUR"] = "groups"
+        env["GTG_SCHUR"] = groups
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT, "workload": workload}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
@@ -60,8 +60,10 @@ def _run(workload, groups):
 def test_grouped_schur_complement_is_bit_identical(workload):
     import torch
     assert torch.cuda.is_available()
-    a = _run(workload, False); b = _run(workload, True)
-    assert a["rc"] == 0 and b["rc"] == 0
-    assert a["S"] == b["S"], "the factor of the reduced system differs"
-    assert a["delta"] == b["delta"] and a["trace"] == b["trace"], (a, b)
-    print(workload, "schur ms per try: pairs", a["schur_ms"], "groups", b["schur_ms"])
+    a = _run(workload, None)
+    for variant in ("groups", "groups_pipe"):          # groups_pipe: the next chunk fetched under the current chunk's multiplications
+        b = _run(workload, variant)
+        assert a["rc"] == 0 and b["rc"] == 0
+        assert a["S"] == b["S"], variant + ": the factor of the reduced system differs"
+        assert a["delta"] == b["delta"] and a["trace"] == b["trace"], (variant, a, b)
+        print(workload, "schur ms per try: pairs", a["schur_ms"], variant, b["schur_ms"])

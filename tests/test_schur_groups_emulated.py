@@ -38,8 +38,8 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-@pytest.mark.parametrize("workload,mixed_dims", [("bal:40:2500:3", True), ("bal:20:400:1", False)])
-def test_emulated_kernel_reproduces_the_pair_major_sums_bit_for_bit(emu, workload, mixed_dims):
+@pytest.mark.parametrize("workload,mixed_dims,pipelined", [("bal:40:2500:3", True, 0), ("bal:40:2500:3", True, 1), ("bal:20:400:1", False, 0), ("bal:20:400:1", False, 1)])
+def test_emulated_kernel_reproduces_the_pair_major_sums_bit_for_bit(emu, workload, mixed_dims, pipelined):
     problem, _ = HP.problem_for(workload)
     lm_ptr, lm_obs, obs_pos, nrv = incidence(problem)
     L = group_lists(lm_ptr, lm_obs, obs_pos, nrv)
@@ -56,11 +56,11 @@ def test_emulated_kernel_reproduces_the_pair_major_sums_bit_for_bit(emu, workloa
         E[o, :3 * d] = rng.standard_normal(3 * d)
     pos_red = np.arange(nrv, dtype=np.int32)            # positions = the caller's order (GTG_NO_REORDER)
     S1 = np.zeros((NP, NP)); S2 = np.zeros((NP, NP))
-    emu.emu_schur_groups.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 13 + [ctypes.c_int64]
+    emu.emu_schur_groups.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 13 + [ctypes.c_int64, ctypes.c_int]
     emu.emu_schur_pairs_reference.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 9 + [ctypes.c_int64]
     pk = L["pair_key"].astype(np.int32)
     rc = emu.emu_schur_groups(int(pk.size), int(L["NG"]), nrv, _ptr(L["order"]), _ptr(pk), _ptr(L["pair_ptr"]), _ptr(L["a0"]), _ptr(L["b0"]),
-                              _ptr(L["pq"]), _ptr(L["gs_obs"]), _ptr(obs_pos), _ptr(pos_red), _ptr(red_dim), _ptr(red_off), _ptr(E), _ptr(S1), NP)
+                              _ptr(L["pq"]), _ptr(L["gs_obs"]), _ptr(obs_pos), _ptr(pos_red), _ptr(red_dim), _ptr(red_off), _ptr(E), _ptr(S1), NP, pipelined)
     assert rc == 0
     oa, ob, ptr = _sort_based_term_lists(problem)
     prow = obs_pos[oa[ptr[:-1]]].astype(np.int32); pcol = obs_pos[ob[ptr[:-1]]].astype(np.int32)

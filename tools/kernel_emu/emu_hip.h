@@ -47,6 +47,8 @@ inline void run_workgroup(int nthreads, unsigned block, const std::function<void
 #define threadIdx (emu::t_idx)
 #define blockIdx (emu::b_idx)
 #define __global__
+#define __device__
+#define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
 

@@ -12,6 +12,7 @@ B="python bench.py --steps 16 --warmup 4 --cpu-baseline off --skip-dense-rooflin
 for w in ladybug1723 venice1778; do
   timeout 300 $B --workload $w > $out/bench_${w}_pairs.json 2> $out/bench_${w}_pairs.err
   GTG_SCHUR=groups timeout 300 $B --workload $w > $out/bench_${w}_groups.json 2> $out/bench_${w}_groups.err
+  GTG_SCHUR=groups_pipe timeout 300 $B --workload $w > $out/bench_${w}_groups_pipe.json 2> $out/bench_${w}_groups_pipe.err
 done
 python - <<PY
 import json, glob

@@ -2,7 +2,16 @@
 // schedule of per-column launches; chol_dataflow.hip: persistent dataflow kernels): MFMA helpers, the streamed 32-column
 // panel (chain wavefront + followers) and the diagonal-tile body built from it.
 #pragma once
+// (GT_KERNEL_EMU: tools/kernel_emu compiles this header for the host -- one thread per work-item -- and supplies the device vocabulary,
+// the constants of context.h it needs and the three macros below itself)
+#ifndef GT_KERNEL_EMU
 #include "kernels.h"
+#define GT_PIN(x) asm volatile("" : "+v"(x))                           // keeps a value in its register at this point of the schedule
+#define GT_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // this wavefront's stores are acknowledged
+#define GT_LDS_VOLATILE(T) __attribute__((address_space(3))) volatile T*    // explicit LDS pointers for volatile accesses
+#define GT_WAVE_SYNC() ((void)0)   // lanes of ONE wavefront exchange data through LDS here: in order on the hardware (the LDS operations of a
+                                   // wavefront complete in program order), a rendezvous of the wavefront's threads in the host emulation
+#endif
 
 namespace gt {
 
@@ -121,8 +130,8 @@ __device__ __forceinline__ double rcp_nr(double p) {
 // free (selects, trash address for the non-owner half) so that the scheduler can overlap the chain with the updates.
 constexpr int kLineTrash = SB * SB;   // doubles: lines[32][32], then 64 trash slots
 // explicit LDS pointers for the volatile accesses (address-space inference leaves volatile accesses as flat_*)
-typedef __attribute__((address_space(3))) volatile double* lds_vdouble_p;
-typedef __attribute__((address_space(3))) volatile int* lds_vint_p;
+typedef GT_LDS_VOLATILE(double) lds_vdouble_p;
+typedef GT_LDS_VOLATILE(int) lds_vint_p;
 
 template <int J>
 struct PotrfStep {
@@ -144,6 +153,7 @@ struct PotrfStep {
       double* line = lines + (J + 1) * SB;
       const int pos = 16 * (i & 1) + (i >> 1);
       *(lds_vdouble_p)((h == hN) ? line + pos : lines + kLineTrash + lane) = a[cN];
+      GT_WAVE_SYNC();
 #pragma unroll
       for (int cl = cN; cl < 16; cl++) cn[cl] = line[16 * h + cl];
       ownN = line[pos];               // A[i][J+1], written by the lane of row i in the owner half
@@ -160,7 +170,7 @@ struct PotrfStep {
     for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, cj[cl], a[cl]);
     // pin the row: keeps hipcc from deferring these updates across many steps (every step's broadcast values alive)
 #pragma unroll
-    for (int cl = cJ + 1; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    for (int cl = cJ + 1; cl < 16; cl++) GT_PIN(a[cl]);
     rinvs[J] = rinv;                // every lane stores the same value: no exec games on the chain wavefront
     if constexpr ((J & 3) == 3) *prog = progbase + J + 1;   // LDS operations of one wavefront complete in order
     PotrfStep<J + 1>::run(a, cn, ownN, lines, rinvs, prog, progbase, lane, i, h);
@@ -200,14 +210,17 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
   for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
   const int pos = 16 * (i & 1) + (i >> 1);
   *(lds_vdouble_p)((h == 0) ? lines + pos : lines + kLineTrash + lane) = a[0];
+  GT_WAVE_SYNC();
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) c0[cl] = lines[16 * h + cl];
   const double own0 = lines[pos];
   PotrfStep<0>::run(a, c0, own0, lines, (lds_vdouble_p)(rinvs + SB * jb), (lds_vint_p)prog, SB * jb, lane, i, h);
+  GT_WAVE_SYNC();
   const double rv = rinvs[SB * jb + i];
   // Eigen LLT: non-positive pivot -> NumericalIssue (NaN compares false too); checked once per panel, off the chain
   if (__builtin_amdgcn_ballot_w64(!(rv > 0.0 && rv < __builtin_inf())) != 0 && lane == 0) *fail = 1.0;
   *(lds_vdouble_p)(rs + SB * jb + pos) = rv * rsqrt_nr(rv);
+  GT_WAVE_SYNC();
   *(lds_vint_p)(prog + 1) = jb + 1;
   scale_columns(a, rs + SB * jb, h);
 #pragma unroll
@@ -242,7 +255,7 @@ struct FollowStep {
     for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, line[cl], a[cl]);
     // pin the row: otherwise the updates are sunk below the next wait loops and every step's u / line stays alive
 #pragma unroll
-    for (int cl = cJ; cl < 16; cl++) asm volatile("" : "+v"(a[cl]));
+    for (int cl = cJ; cl < 16; cl++) GT_PIN(a[cl]);
     FollowStep<J + 1>::run(a, lines, rinvs, prog, progbase, h);
   }
 };
@@ -419,7 +432,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     //   under them and the pivot chain does not stall; the substitution step q only has to be done before panel q+1 is.  The last
     //   panel's word follows its drain directly (it is the one on the serial chain of the factorisation).
     const bool late = wt && jb < 3;
-    if (wt && !late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wt && !late) GT_DRAIN_STORES();
     __syncthreads();
     if (tid == 0 && !late)
     {
@@ -431,7 +444,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     STAMP(3 + 3 * jb);
     // P3: panel jb+1 (its diagonal block and the blocks below it) must be complete before its chain / followers start
     for (int t = wave; t < 4 * (3 - jb); t += 8) tile_task(A, jb, jb + 1 + (t >> 2), jb + 1, (t >> 1) & 1, t & 1, lr, lk);
-    if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (late) GT_DRAIN_STORES();
     __syncthreads();
     if (tid == 0 && late)
     {

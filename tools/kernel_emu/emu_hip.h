@@ -91,3 +91,61 @@ inline emu_v4d emu_mfma_f64_16x16x4(double a, double b, emu_v4d c) {
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(v) (v)   // (only ever applied to wave-uniform values in the emulated kernels)
+
+// ---- the rest of the vocabulary of csrc/chol_device.h (the diagonal-tile body) ---------------------------------------------------------
+#define GT_KERNEL_EMU 1
+#define GT_PIN(x) ((void)0)
+#define GT_DRAIN_STORES() ((void)0)
+#define GT_LDS_VOLATILE(T) volatile T*
+#define GT_WAVE_SYNC() (__atomic_thread_fence(__ATOMIC_SEQ_CST), emu::wave().bar.arrive_and_wait())
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+template <class T, class V> inline void emu_atomic_store(T* p, V v) { T x = (T)v; __atomic_store(p, &x, __ATOMIC_SEQ_CST); }
+template <class T> inline T emu_atomic_load(const T* p) { T x; __atomic_load(const_cast<T*>(p), &x, __ATOMIC_SEQ_CST); return x; }
+template <class T, class V> inline T emu_atomic_exchange(T* p, V v) { T x = (T)v, old; __atomic_exchange(p, &x, &old, __ATOMIC_SEQ_CST); return old; }
+#define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
+#define __hip_atomic_load(p, order, scope) emu_atomic_load((p))
+#define __hip_atomic_exchange(p, v, order, scope) emu_atomic_exchange((p), (v))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) std::this_thread::yield()
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_memtime() 0ll
+#define __builtin_amdgcn_ballot_w64(p) __ballot(p)
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt(x))
+inline int __double2loint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b & 0xffffffffll); }
+inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned)lo; double v; std::memcpy(&v, &b, 8); return v; }
+inline long long __double_as_longlong(double v) { long long b; std::memcpy(&b, &v, 8); return b; }
+inline double __longlong_as_double(long long b) { double v; std::memcpy(&v, &b, 8); return v; }
+// v_readlane_b32: the value of lane `l` (wave-uniform) to every lane
+inline int emu_readlane(int v, int l) {
+  emu::Wave& w = emu::wave(); const int me = emu::lane();
+  w.li[me] = v; w.bar.arrive_and_wait();
+  const int r = (int)w.li[l & 63];
+  w.bar.arrive_and_wait();
+  return r;
+}
+#define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
+// v_permlane32_swap(a, b): lanes 32-63 of the first operand <-> lanes 0-31 of the second; returns {new first, new second}
+struct emu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline emu_u2 emu_permlane32_swap(unsigned a, unsigned b) {
+  emu::Wave& w = emu::wave(); const int me = emu::lane();
+  w.li[me] = ((long long)a << 32) | b; w.bar.arrive_and_wait();
+  emu_u2 r;
+  if (me < 32) { r.v[0] = a; r.v[1] = (unsigned)(w.li[me + 32] >> 32); }                 // second's lower half <- first's upper half
+  else { r.v[0] = (unsigned)(w.li[me - 32] & 0xffffffffll); r.v[1] = b; }                // first's upper half <- second's lower half
+  w.bar.arrive_and_wait();
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, x, y) emu_permlane32_swap((a), (b))
+// ds_bpermute_b32: lane reads the value of lane addr / 4
+inline int emu_ds_bpermute(int addr, int v) {
+  emu::Wave& w = emu::wave(); const int me = emu::lane();
+  w.li[me] = v; w.bar.arrive_and_wait();
+  const int r = (int)w.li[(addr >> 2) & 63];
+  w.bar.arrive_and_wait();
+  return r;
+}
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu_ds_bpermute((addr), (v))

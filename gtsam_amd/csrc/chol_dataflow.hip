@@ -48,7 +48,7 @@ constexpr long long kWaitTicks = 2000000;
 constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finished pieces of the tile's contraction (< kPieceBase pieces per tile)
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
-constexpr size_t kSmemPotrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
+constexpr size_t kSmemPotrf = sizeof(double) * kPotrfSmemDoubles;
 constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 * SB * PB;   // + one 128 x 32 slice of the tile below
 // flag values: epoch * 8 + steps; a tile (I, J) is final at 4 steps (its four 32-column blocks), a diagonal tile's word in
 // its Dinv slot counts released panels, pd_flag is epoch * 8 + 4 when the accumulated diagonal tile is in

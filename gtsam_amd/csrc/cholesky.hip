@@ -480,7 +480,7 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
   TreeStreams& g_ts = c.ts;
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
-  const size_t smem_potrf = sizeof(double) * (10 * SB * PB + 2 * T + SB * SB + 64 + 2);
+  const size_t smem_potrf = sizeof(double) * kPotrfSmemDoubles;
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;
   static std::set<int> attr_set;   // function attributes are per device

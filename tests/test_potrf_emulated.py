@@ -18,20 +18,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SRC = os.path.join(ROOT, "tools", "kernel_emu", "potrf_emu.cpp")
 LIB = os.path.join(ROOT, "tests", "_build", "libpotrf_emu.so")
+LIB_WINDOW = os.path.join(ROOT, "tests", "_build", "libpotrf_emu_window.so")
+
+
+def _build(path, flags):
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ to build the kernel emulator with")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    deps = [SRC, os.path.join(ROOT, "tools", "kernel_emu", "emu_hip.h"), os.path.join(ROOT, "gtsam_amd", "csrc", "chol_device.h")]
+    if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(d) for d in deps):
+        subprocess.run([CLANG, "-std=c++20", "-O2", "-pthread", "-fPIC", "-shared", "-Wno-psabi"] + flags + ["-o", path, SRC], check=True)
+    lib = ctypes.CDLL(path)
+    lib.emu_potrf128.restype = ctypes.c_longlong
+    lib.emu_potrf128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]
+    return lib
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if not os.path.exists(CLANG):
-        pytest.skip("no clang++ to build the kernel emulator with")
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    deps = [SRC, os.path.join(ROOT, "tools", "kernel_emu", "emu_hip.h"), os.path.join(ROOT, "gtsam_amd", "csrc", "chol_device.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(d) for d in deps):
-        subprocess.run([CLANG, "-std=c++20", "-O2", "-pthread", "-fPIC", "-shared", "-Wno-psabi", "-o", LIB, SRC], check=True)
-    lib = ctypes.CDLL(LIB)
-    lib.emu_potrf128.restype = ctypes.c_longlong
-    lib.emu_potrf128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]
-    return lib
+    return _build(LIB, [])
+
+
+@pytest.fixture(scope="module")
+def emu_window():
+    """The same body compiled with GT_POTRF_WINDOW=1: the chain wavefront keeps a window of 8 columns of the diagonal block, a helper
+    wavefront applies the published pivots to the columns beyond it and hands the next window over through LDS (chol_device.h)."""
+    return _build(LIB_WINDOW, ["-DGT_POTRF_WINDOW=1"])
 
 
 def _factor(lib, A, wt, epoch=1):
@@ -68,3 +80,25 @@ def test_emulated_body_flags_a_tile_that_is_not_positive_definite(emu):
     A[70, 70] = -1.0
     _, _, fail, flag = _factor(emu, A, 1)
     assert fail[0] == 1.0 and flag == 8 + 4       # an error, never a hang: every panel is still released
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_windowed_pivot_chain_is_bit_identical_to_the_default(emu, emu_window, seed):
+    """Every entry of the diagonal block sees the same operations in the same order whoever applies them (chain wavefront or helper):
+    factor, inverses and operand images of the windowed variant equal the default's bit for bit, repetition after repetition."""
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((128, 160)); A = M @ M.T + 64.0 * np.eye(128)
+    t0, X0, f0, g0 = _factor(emu, A, seed & 1, epoch=5)
+    for rep in range(3):
+        t1, X1, f1, g1 = _factor(emu_window, A, (seed + rep) & 1, epoch=5)
+        assert g1 == g0 == 5 * 8 + 4 and f1[0] == 0.0
+        assert np.array_equal(np.tril(t1), np.tril(t0))
+        assert np.array_equal(X1[:14336], X0[:14336])
+
+
+def test_windowed_body_flags_a_tile_that_is_not_positive_definite(emu_window):
+    rng = np.random.default_rng(8)
+    M = rng.standard_normal((128, 160)); A = M @ M.T + 64.0 * np.eye(128)
+    A[41, 41] = -2.0
+    _, _, fail, flag = _factor(emu_window, A, 0)
+    assert fail[0] == 1.0 and flag == 8 + 4

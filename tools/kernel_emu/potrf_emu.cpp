@@ -11,7 +11,7 @@ constexpr int kTileDoubles = kTile * kTile;
 // tile: 128 x 128 row-major (lower part read, factor written back in place); Xinv: 128 x 128 doubles (the four 32 x 32 inverses, the
 // operand images, the progress word at gt::kFlagOff); returns the progress word
 extern "C" long long emu_potrf128(double* tile, double* Xinv, double* fail, int write_through, long long epoch) {
-  static char smem[sizeof(double) * (10 * gt::SB * gt::PB + 2 * gt::T + gt::SB * gt::SB + 64 + 2) + 64];
+  static char smem[sizeof(double) * gt::kPotrfSmemDoubles + 64];
   long long* pflag = reinterpret_cast<long long*>(Xinv + gt::kFlagOff);
   emu::run_workgroup(512, 0, [&] {
     gt::potrf_body(smem, tile, 0, Xinv, fail, nullptr, epoch, pflag, 64, false, write_through != 0, nullptr, nullptr);

@@ -18,6 +18,9 @@
 #ifndef GT_POTRF_WINDOW
 #define GT_POTRF_WINDOW 0
 #endif
+#ifndef GT_POTRF_OWN_LDS
+#define GT_POTRF_OWN_LDS 0     // windowed variant only: 1 = the lane's own entry of the next column is read back from LDS as in the default body
+#endif
 
 namespace gt {
 
@@ -240,7 +243,13 @@ struct PotrfStepW {
 #pragma unroll
         for (int k = 0; k < 4; k++) cnn[k] = line[16 * h + (Wn + WIN) / 2 + k];
       }
-      ownN = line[pos];
+      // A[i][J+1] of this lane's row: out of the owner half's register by v_permlane32_swap instead of back out of LDS -- the
+      // multiplier of the NEXT step's chain no longer waits for an LDS write + read round trip
+#if GT_POTRF_OWN_LDS
+      ownN = line[pos];                       // (the A/B: as PotrfStep does it)
+#else
+      ownN = half_bcast<hN>(aw[kN]);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     const double u = own * rinv;
@@ -307,10 +316,14 @@ __device__ __forceinline__ void stage_helper(const double* A, const double* line
                                              int jb, int lane) {
   const int i = lane & 31, h = lane >> 5;
   const double* row = A + boff(jb, jb) + i * PB;
+  // the chain wavefront waits for this wavefront at every window boundary: it wins issue arbitration against the follower / deferred
+  // wavefront it shares its SIMD with
+  __builtin_amdgcn_s_setprio(3);
   double ah[16];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) ah[cl] = row[2 * cl + h];
   HelperStep<0>::run(ah, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, hand, (lds_vint_p)hprog, 4 * jb, lane, i, h);
+  __builtin_amdgcn_s_setprio(2);
 }
 #endif   // GT_POTRF_WINDOW
 

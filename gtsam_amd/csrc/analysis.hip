@@ -93,7 +93,7 @@ static bool build_schur_groups(gtg_context& c, const std::vector<int64_t>& lm_pt
   SchurGroups& g = c.sg;
   const int G = kSchurGroup, nrv = c.n_red_vars;
   const int64_t n_obs = (int64_t)lm_obs.size();
-  if (nrv == 0 || n_obs == 0 || (int64_t)((nrv + G - 1) / G) * ((nrv + G - 1) / G) >= ((int64_t)1 << 31)) return false;
+  if (nrv == 0 || n_obs == 0 || n_obs >= ((int64_t)1 << 28) || (int64_t)((nrv + G - 1) / G) * ((nrv + G - 1) / G) >= ((int64_t)1 << 31)) return false;
   const int NG = (nrv + G - 1) / G;
   std::vector<int32_t> opos((size_t)n_obs), sobs((size_t)n_obs), pos_red((size_t)nrv);
   for (int64_t o = 0; o < n_obs; o++) opos[(size_t)o] = c.h_red_pos[obs_red[(size_t)o]];
@@ -175,9 +175,10 @@ static bool build_schur_groups(gtg_context& c, const std::vector<int64_t>& lm_pt
   for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pair_ptr[(size_t)x + 1] - pair_ptr[(size_t)x] > pair_ptr[(size_t)y + 1] - pair_ptr[(size_t)y]; });
   g.NG = NG; g.n_pairs = (int64_t)pair_key.size(); g.n_cells = (int64_t)cells.size();
+  for (int64_t i = 0; i < n_obs; i++) sobs[(size_t)i] |= (opos[(size_t)sobs[(size_t)i]] % G) << 28;   // the camera's position inside its group rides along
   up(g.obs, sobs, s); up(g.cell_a0, a0, s); up(g.cell_b0, b0, s); up(g.cell_pq, pq, s);
   up(g.pair_key, pair_key, s); up(g.pair_ptr, pair_ptr, s); up(g.order, order, s);
-  up(g.obs_pos, opos, s); up(g.pos_red, pos_red, s);
+  up(g.pos_red, pos_red, s);
   g.active = true;
   return true;
 }

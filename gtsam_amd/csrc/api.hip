@@ -273,7 +273,7 @@ int gtg_destroy(gtg_handle c) {
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->smart_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
-  { SchurGroups& g = c->sg; for (DevBuf<int32_t>* b : {&g.obs, &g.cell_a0, &g.cell_b0, &g.cell_pq, &g.pair_key, &g.order, &g.obs_pos, &g.pos_red}) b->free(); g.pair_ptr.free(); }
+  { SchurGroups& g = c->sg; for (DevBuf<int32_t>* b : {&g.obs, &g.cell_a0, &g.cell_b0, &g.cell_pq, &g.pair_key, &g.order, &g.pos_red}) b->free(); g.pair_ptr.free(); }
   c->smart_params.free(); c->smart_cache_pose.free(); c->smart_cache_point.free();
   c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   free_df_plan(c->df);

@@ -99,12 +99,11 @@ struct SchurGroups {
   bool pipelined = false;                       // GTG_SCHUR=groups_pipe: the next chunk's slots are fetched under the current chunk's multiplications
   int NG = 0;                                   // groups
   int64_t n_pairs = 0, n_cells = 0;
-  DevBuf<int32_t> obs;                          // every landmark's observations, sorted by the position of their camera (segments of lm_obs)
+  DevBuf<int32_t> obs;                          // every landmark's observations, sorted by the position of their camera (segments of lm_obs): observation | (position mod 8) << 28
   DevBuf<int32_t> cell_a0, cell_b0, cell_pq;    // per cell: runs of its A / B entries in `obs` (start, start, p | q << 16); cells sorted by group pair, landmark order inside
   DevBuf<int32_t> pair_key;                     // ga * NG + gb of every group pair that has cells, ascending
   DevBuf<int64_t> pair_ptr;                     // its cells
   DevBuf<int32_t> order;                        // the group pairs by descending number of cells: workgroup b takes pair order[b]
-  DevBuf<int32_t> obs_pos;                      // observation -> position of its camera
   DevBuf<int32_t> pos_red;                      // position -> reduced variable
 };
 

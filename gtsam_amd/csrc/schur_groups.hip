@@ -33,11 +33,11 @@ void launch_schur_groups(gtg_context& c, SMat S) {
   if (!g.active || g.n_pairs == 0) return;
   if (g.pipelined)
     hipLaunchKernelGGL(k_schur_groups_pipe, dim3((unsigned)g.n_pairs), dim3(kThreads), 0, c.stream, (int)g.n_pairs, g.NG, c.n_red_vars, g.order.p,
-                       g.pair_key.p, g.pair_ptr.p, g.cell_a0.p, g.cell_b0.p, g.cell_pq.p, g.obs.p, g.obs_pos.p, g.pos_red.p, c.red_dim.p,
+                       g.pair_key.p, g.pair_ptr.p, g.cell_a0.p, g.cell_b0.p, g.cell_pq.p, g.obs.p, g.pos_red.p, c.red_dim.p,
                        c.red_off.p, c.E.p, S);
   else
     hipLaunchKernelGGL(k_schur_groups, dim3((unsigned)g.n_pairs), dim3(kThreads), 0, c.stream, (int)g.n_pairs, g.NG, c.n_red_vars, g.order.p,
-                       g.pair_key.p, g.pair_ptr.p, g.cell_a0.p, g.cell_b0.p, g.cell_pq.p, g.obs.p, g.obs_pos.p, g.pos_red.p, c.red_dim.p,
+                       g.pair_key.p, g.pair_ptr.p, g.cell_a0.p, g.cell_b0.p, g.cell_pq.p, g.obs.p, g.pos_red.p, c.red_dim.p,
                        c.red_off.p, c.E.p, S);
   check_hip(hipGetLastError(), "schur (grouped)");
 }

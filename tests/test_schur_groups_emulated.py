@@ -56,11 +56,11 @@ def test_emulated_kernel_reproduces_the_pair_major_sums_bit_for_bit(emu, workloa
         E[o, :3 * d] = rng.standard_normal(3 * d)
     pos_red = np.arange(nrv, dtype=np.int32)            # positions = the caller's order (GTG_NO_REORDER)
     S1 = np.zeros((NP, NP)); S2 = np.zeros((NP, NP))
-    emu.emu_schur_groups.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 13 + [ctypes.c_int64, ctypes.c_int]
+    emu.emu_schur_groups.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 12 + [ctypes.c_int64, ctypes.c_int]
     emu.emu_schur_pairs_reference.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 9 + [ctypes.c_int64]
     pk = L["pair_key"].astype(np.int32)
     rc = emu.emu_schur_groups(int(pk.size), int(L["NG"]), nrv, _ptr(L["order"]), _ptr(pk), _ptr(L["pair_ptr"]), _ptr(L["a0"]), _ptr(L["b0"]),
-                              _ptr(L["pq"]), _ptr(L["gs_obs"]), _ptr(obs_pos), _ptr(pos_red), _ptr(red_dim), _ptr(red_off), _ptr(E), _ptr(S1), NP, pipelined)
+                              _ptr(L["pq"]), _ptr(L["gs_obs_packed"]), _ptr(pos_red), _ptr(red_dim), _ptr(red_off), _ptr(E), _ptr(S1), NP, pipelined)
     assert rc == 0
     oa, ob, ptr = _sort_based_term_lists(problem)
     prow = obs_pos[oa[ptr[:-1]]].astype(np.int32); pcol = obs_pos[ob[ptr[:-1]]].astype(np.int32)

@@ -45,7 +45,8 @@ def incidence(problem):
 
 def group_lists(lm_ptr, lm_obs, obs_pos, nrv):
     """The lists of analysis.hip::build_schur_groups.
-       gs_obs       every landmark's observations, stably sorted by the position of their camera (same segments as lm_obs)
+       gs_obs       every landmark's observations, stably sorted by the position of their camera (same segments as lm_obs);
+                    uploaded as observation | (position mod 8) << 28 -- the camera's place inside its group rides along
        cells        per landmark, groups ascending g_0 < g_1 < ...: for ia, for ib <= ia: (key = g_ia NG + g_ib, a0, b0, p | q << 16),
                     a0 / b0 = index of the group's run in gs_obs, p / q = its length; then STABLE sort by key
        pair_key / pair_ptr   run-length encoding of the sorted keys
@@ -72,7 +73,8 @@ def group_lists(lm_ptr, lm_obs, obs_pos, nrv):
     pair_key = key[starts].astype(np.uint32)
     pair_ptr = np.concatenate([starts, [key.size]]).astype(np.int64)
     order = np.argsort(-(np.diff(pair_ptr)), kind="stable").astype(np.int32)
-    return dict(gs_obs=gs_obs, a0=a0, b0=b0, pq=pq, pair_key=pair_key, pair_ptr=pair_ptr, order=order, NG=NG)
+    gs_obs_packed = (gs_obs.astype(np.int64) | ((obs_pos[gs_obs].astype(np.int64) % G) << 28)).astype(np.uint32).view(np.int32)   # what is uploaded
+    return dict(gs_obs=gs_obs, gs_obs_packed=gs_obs_packed, a0=a0, b0=b0, pq=pq, pair_key=pair_key, pair_ptr=pair_ptr, order=order, NG=NG)
 
 
 def chunks_of(L, j):
@@ -164,10 +166,9 @@ def test_library_uploads_these_lists(workload):
     problem, _ = HP.problem_for(workload)
     lm_ptr, lm_obs, obs_pos, nrv = incidence(problem)
     L = group_lists(lm_ptr, lm_obs, obs_pos, nrv)
-    for name in ("gs_obs", "a0", "b0", "pq", "pair_key", "pair_ptr", "order"):
+    for name in ("gs_obs_packed", "a0", "b0", "pq", "pair_key", "pair_ptr", "order"):
         a = L[name]
         assert (a.nbytes, _fnv(a)) in have, name + " differs"
-    assert (obs_pos.nbytes, _fnv(obs_pos)) in have, "positions of the observations differ"
 
 
 def test_without_the_switch_nothing_of_it_is_built():

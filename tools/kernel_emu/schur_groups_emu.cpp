@@ -17,13 +17,13 @@ namespace gt { namespace {
 
 extern "C" int emu_schur_groups(int n_pairs, int NG, int nrv, const int32_t* order, const int32_t* pair_key, const int64_t* pair_ptr,
                                 const int32_t* cell_a0, const int32_t* cell_b0, const int32_t* cell_pq, const int32_t* gobs,
-                                const int32_t* obs_pos, const int32_t* pos_red, const int32_t* red_dim, const int64_t* red_off,
+                                const int32_t* pos_red, const int32_t* red_dim, const int64_t* red_off,
                                 const double* E, double* S, int64_t NP, int pipelined) {
   SMat sm{S, NP};
   for (int b = 0; b < n_pairs; b++)
     emu::run_workgroup(gt::kThreads, (unsigned)b, [&] {
-      if (pipelined) gt::k_schur_groups_pipe(n_pairs, NG, nrv, order, pair_key, pair_ptr, cell_a0, cell_b0, cell_pq, gobs, obs_pos, pos_red, red_dim, red_off, E, sm);
-      else gt::k_schur_groups(n_pairs, NG, nrv, order, pair_key, pair_ptr, cell_a0, cell_b0, cell_pq, gobs, obs_pos, pos_red, red_dim, red_off, E, sm);
+      if (pipelined) gt::k_schur_groups_pipe(n_pairs, NG, nrv, order, pair_key, pair_ptr, cell_a0, cell_b0, cell_pq, gobs, pos_red, red_dim, red_off, E, sm);
+      else gt::k_schur_groups(n_pairs, NG, nrv, order, pair_key, pair_ptr, cell_a0, cell_b0, cell_pq, gobs, pos_red, red_dim, red_off, E, sm);
     });
   return 0;
 }

@@ -31,6 +31,8 @@ def _build(path, flags):
     lib = ctypes.CDLL(path)
     lib.emu_potrf128.restype = ctypes.c_longlong
     lib.emu_potrf128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong]
+    lib.emu_potrf128_ranktest.restype = ctypes.c_longlong
+    lib.emu_potrf128_ranktest.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
 
@@ -102,3 +104,22 @@ def test_windowed_body_flags_a_tile_that_is_not_positive_definite(emu_window):
     A[41, 41] = -2.0
     _, _, fail, flag = _factor(emu_window, A, 0)
     assert fail[0] == 1.0 and flag == 8 + 4
+
+
+@pytest.mark.parametrize("variant", ["default", "window"])
+def test_emulated_rank_test_of_the_reference(emu, emu_window, variant):
+    """choleskyPartial's exponent test (base/cholesky.cpp:144-157) at the ends of the variables' pivot blocks: a tile of 9-dimensional
+    variables passes when it is well conditioned and raises the flag when the last pivot of one variable is 2^-13 of the one before."""
+    lib = emu if variant == "default" else emu_window
+    kinds = np.zeros(128, np.uint8)
+    kinds[8:126:9] = 1                                   # last pivot of every 9-dimensional variable
+    rng = np.random.default_rng(9)
+    M = rng.standard_normal((128, 160)); A = M @ M.T + 64.0 * np.eye(128)
+    for bad in (False, True):
+        B = A.copy()
+        if bad:                                          # variable 3 (columns 27..35): its last direction almost unobserved
+            L = np.linalg.cholesky(B); L[35, 35] *= 2.0 ** -14; B = L @ L.T
+        tile = B.copy(); X = np.zeros(128 * 128); fail = np.zeros(2); texp = np.zeros(4)
+        flag = lib.emu_potrf128_ranktest(tile.ctypes.data, X.ctypes.data, fail.ctypes.data, 1, 1, kinds.ctypes.data, texp.ctypes.data)
+        assert flag == 8 + 4
+        assert fail[0] == (1.0 if bad else 0.0), (variant, bad, fail)

@@ -18,3 +18,14 @@ extern "C" long long emu_potrf128(double* tile, double* Xinv, double* fail, int 
   });
   return *pflag;
 }
+
+// the same with the reference's rank test switched on (pivot kinds of the tile's 128 columns: chol_device.h::stage_potrf)
+extern "C" long long emu_potrf128_ranktest(double* tile, double* Xinv, double* fail, int write_through, long long epoch,
+                                           const unsigned char* pivot_kind, double* tile_exp) {
+  static char smem[sizeof(double) * gt::kPotrfSmemDoubles + 64];
+  long long* pflag = reinterpret_cast<long long*>(Xinv + gt::kFlagOff);
+  emu::run_workgroup(512, 0, [&] {
+    gt::potrf_body(smem, tile, 0, Xinv, fail, nullptr, epoch, pflag, 64, false, write_through != 0, pivot_kind, tile_exp);
+  });
+  return *pflag;
+}

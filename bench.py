@@ -319,7 +319,10 @@ def main():
                        "poses": int(((problem.var_type == 0) | (problem.var_type == 3)).sum()), "between_factors": int(problem.n_between),
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
                        "parallelism": (f"speculative-lambda x{world} (replicas; replica r tries the r-th lambda of the rejection sequence, decisions replayed in order: the sequential trajectory)"
-                                       if speculative else f"landmark-shard x{world}") if world > 1 else "single GPU"},
+                                       if speculative else f"landmark-shard x{world}") if world > 1 else "single GPU",
+                       "exchange": ("RCCL on the handles' device buffers" if getattr(comm, "device_backend", False) else
+                                    ("gloo through the host -- the device exchange raised: " + str(getattr(comm, "fell_back", None))) if getattr(comm, "fell_back", None)
+                                    else "gloo through the host") if (world > 1 and speculative) else None},
             "lambda_tries_per_s": cpp["lambda_tries_per_s"] if cpp_ok else tries / elapsed,
             # construction -> checkConvergence.  `time_to_converged_s` is the COLD figure when the C++ leg ran (first optimizer of a fresh
             # process: code-object load, first device allocations); warm = a later optimizer of the same process

@@ -46,38 +46,66 @@ class TorchComm:
         self.dist = dist; self.group = group
         self.rank = dist.get_rank(group); self.world = dist.get_world_size(group)
         self.device_backend = dist.get_backend(group) != "gloo"
+        # The device path (RCCL on the handle's own buffers) has only ever run in the CPU dry-run's place-holder form: no multi-GPU box
+        # was available to the builder.  A host-side group stands by: should the FIRST device exchange raise before anything was sent
+        # (every rank runs the same code on the same kind of box, so every rank raises at the same call), the search continues over
+        # gloo -- 2.7 MB per accepted step through the host on the L1723 shape -- and `fell_back` says so (bench.py reports it).
+        self.host_group = None
+        self.fell_back = None
+        if self.device_backend and group is None and self.world > 1:
+            try:
+                self.host_group = dist.new_group(backend="gloo")
+            except Exception:   # noqa: BLE001  (no gloo in this build of torch: the device path stands alone)
+                self.host_group = None
+
+    def _to_host_path(self, what, err):
+        import sys
+        if self.host_group is None:
+            raise err
+        self.fell_back = f"{what}: {type(err).__name__}: {err}"
+        sys.stderr.write(f"[gtsam_amd] speculative search: the device exchange failed in {what} ({type(err).__name__}: {err}); continuing over gloo\n")
+        self.device_backend = False
+        self.group = self.host_group
 
     def all_gather(self, vec):
         import torch
-        dev = "cuda" if self.device_backend else "cpu"
-        t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64, device=dev)
-        out = torch.empty((self.world, t.numel()), dtype=torch.float64, device=dev)
-        self.dist.all_gather_into_tensor(out, t, group=self.group) if self.device_backend else \
-            self.dist.all_gather(list(out.unbind(0)), t, group=self.group)
-        return out.cpu().numpy()
+        if self.device_backend:
+            try:
+                t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64, device="cuda")
+                out = torch.empty((self.world, t.numel()), dtype=torch.float64, device="cuda")
+                self.dist.all_gather_into_tensor(out, t, group=self.group)
+                return out.cpu().numpy()
+            except Exception as e:   # noqa: BLE001
+                self._to_host_path("all_gather", e)
+        t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64)
+        out = torch.empty((self.world, t.numel()), dtype=torch.float64)
+        self.dist.all_gather(list(out.unbind(0)), t, group=self.group)
+        return out.numpy()
 
     def broadcast_accepted(self, dev, src):
         """The accepted trial values of replica `src` become everybody's current values."""
         import torch
+        if self.rank == src:
+            dev.accept()                           # trial <-> current: the winner's current values are now the accepted ones
         if self.device_backend:
-            from .distributed import _DevicePtr
-            if self.rank == src:
-                dev.accept()                       # trial <-> current: the winner's current values are now the accepted ones
-            ptr, n, stream = dev.values_device_ptr(0)
-            t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
-            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else _null():
-                self.dist.broadcast(t, src=src, group=self.group)
-            if self.rank != src:
-                dev.values_changed()
+            try:
+                from .distributed import _DevicePtr
+                ptr, n, stream = dev.values_device_ptr(0)
+                t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else _null():
+                    self.dist.broadcast(t, src=src, group=self.group)
+                if self.rank != src:
+                    dev.values_changed()
+                return
+            except Exception as e:   # noqa: BLE001
+                self._to_host_path("broadcast", e)
+        if self.rank == src:
+            t = torch.from_numpy(dev.values())
         else:
-            if self.rank == src:
-                dev.accept()
-                t = torch.from_numpy(dev.values())
-            else:
-                t = torch.empty(dev.val_size, dtype=torch.float64)
-            self.dist.broadcast(t, src=src, group=self.group)
-            if self.rank != src:
-                dev.set_values(t.numpy())
+            t = torch.empty(dev.val_size, dtype=torch.float64)
+        self.dist.broadcast(t, src=src, group=self.group)
+        if self.rank != src:
+            dev.set_values(t.numpy())
 
 
 class _null:

@@ -9,6 +9,8 @@
 out=gpurun_out/${1:-r05a}; mkdir -p $out
 GTG_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_schur_groups.py -x -q -s 2>&1 | tail -25 > $out/schur_groups_ab.log
 tail -3 $out/schur_groups_ab.log
+GTG_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_window_variant.py -x -q 2>&1 | tail -12 > $out/window_ab.log
+tail -2 $out/window_ab.log
 B="python bench.py --steps 16 --warmup 4 --cpu-baseline off --skip-dense-roofline --traffic off --host python"
 for w in ladybug1723 venice1778; do
   timeout 300 $B --workload $w > $out/bench_${w}_pairs.json 2> $out/bench_${w}_pairs.err

@@ -933,7 +933,10 @@ void analyze(gtg_context& c) {
   { const char* sm = std::getenv("GTG_SCHUR");
     if (sm && (std::string(sm) == "groups" || std::string(sm) == "groups_pipe") && c.n_shards == 1 && c.n_pairs > 0) {
       c.sg.pipelined = std::string(sm) == "groups_pipe";
-      if (device_terms) {
+      const char* where = std::getenv("GTG_SCHUR_LISTS");
+      if (device_terms && where && std::string(where) == "device") {
+        (void)device_schur_groups(c);
+      } else if (device_terms) {
         std::vector<int64_t> d_ptr((size_t)c.n_lm + 1);
         std::vector<int32_t> d_obs((size_t)c.n_obs), d_red((size_t)c.n_obs);
         check_hip(hipMemcpyAsync(d_ptr.data(), c.lm_obs_ptr.p, sizeof(int64_t) * d_ptr.size(), hipMemcpyDeviceToHost, s), "D2H");

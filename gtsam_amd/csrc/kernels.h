@@ -16,6 +16,7 @@ void launch_retract(gtg_context& c);                                    // trial
 void launch_assemble(gtg_context& c);            // Hd, gred0, V, gp, Hoff, hdiag_red (lambda-invariant)
 void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin, double dmax);  // Linv, ylm, E
 void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax);    // S and rhs row
+bool device_schur_groups(gtg_context& c);            // schur_groups.hip: the lists of the grouped form built on the device (GTG_SCHUR_LISTS=device)
 void launch_schur_groups(gtg_context& c, SMat S);   // schur_groups.hip: the Schur complement's sums in the grouped form (GTG_SCHUR=groups)
 void launch_back_substitute(gtg_context& c);     // delta_lm from xred, ylm, E, Linv
 void launch_scatter_delta(gtg_context& c);       // delta (variable id order) from xred + delta_lm

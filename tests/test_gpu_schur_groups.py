@@ -45,11 +45,13 @@ print("RESULT " + json.dumps({"rc": int(rc), "S": hashlib.sha256(np.ascontiguous
 '''
 
 
-def _run(workload, groups):
+def _run(workload, groups, lists=None):
     env = dict(os.environ)
-    env.pop("GTG_SCHUR", None)
+    env.pop("GTG_SCHUR", None); env.pop("GTG_SCHUR_LISTS", None)
     if groups:
         env["GTG_SCHUR"] = groups
+    if lists:
+        env["GTG_SCHUR_LISTS"] = lists
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT, "workload": workload}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
@@ -61,9 +63,10 @@ def test_grouped_schur_complement_is_bit_identical(workload):
     import torch
     assert torch.cuda.is_available()
     a = _run(workload, None)
-    for variant in ("groups", "groups_pipe"):          # groups_pipe: the next chunk fetched under the current chunk's multiplications
-        b = _run(workload, variant)
+    # groups_pipe: the next chunk fetched under the current chunk's multiplications; lists=device: the cell lists built on the device
+    for variant, lists in (("groups", None), ("groups_pipe", None), ("groups", "device")):
+        b = _run(workload, variant, lists)
         assert a["rc"] == 0 and b["rc"] == 0
         assert a["S"] == b["S"], variant + ": the factor of the reduced system differs"
         assert a["delta"] == b["delta"] and a["trace"] == b["trace"], (variant, a, b)
-        print(workload, "schur ms per try: pairs", a["schur_ms"], variant, b["schur_ms"])
+        print(workload, "schur ms per try: pairs", a["schur_ms"], variant, lists or "host lists", b["schur_ms"])

@@ -80,3 +80,32 @@ def test_emulated_kernel_reproduces_the_pair_major_sums_bit_for_bit(emu, workloa
                     da, db = int(red_dim[pa]), int(red_dim[pb])
                     D[red_off[pa]:red_off[pa] + da, red_off[pb]:red_off[pb] + db] -= Ez[a, :da] @ Ez[b, :db].T
     assert np.abs(S1 - D).max() <= 1e-11 * max(1.0, np.abs(D).max())
+
+
+@pytest.mark.parametrize("workload", ["bal:40:2500:3", "baldup:40:3000:3"])
+def test_emulated_list_kernels_build_the_stated_lists(emu, workload):
+    """The device version of the list builder (schur_groups.hip::device_schur_groups, GTG_SCHUR_LISTS=device): its two per-landmark kernels run
+    on host threads, the stable sort by group pair done in numpy -- the sorted observation lists and the cells are those of the statement."""
+    problem, _ = HP.problem_for(workload)
+    lm_ptr, lm_obs, obs_pos, nrv = incidence(problem)
+    L = group_lists(lm_ptr, lm_obs, obs_pos, nrv)
+    n_lm = lm_ptr.size - 1; n_obs = lm_obs.size
+    obs_red = obs_pos.copy()                              # positions = the caller's order: observation -> reduced variable -> itself
+    red_pos = np.arange(nrv, dtype=np.int32)
+    gobs = np.zeros(n_obs, np.int32); gpos = np.zeros(n_obs, np.int32); cnt = np.zeros(n_lm + 1, np.int64)
+    emu.emu_sg_sort_count.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7
+    emu.emu_sg_emit.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 9
+    emu.emu_sg_sort_count(n_lm, _ptr(lm_ptr), _ptr(lm_obs), _ptr(obs_red), _ptr(red_pos), _ptr(gobs), _ptr(gpos), _ptr(cnt))
+    assert np.array_equal(gobs, L["gs_obs_packed"])
+    off = np.concatenate([[0], np.cumsum(cnt[:-1])]).astype(np.int64)
+    total = int(cnt.sum())
+    assert total == L["a0"].size
+    key = np.zeros(total, np.uint32); idx = np.zeros(total, np.uint32); a0 = np.zeros(total, np.int32); b0 = np.zeros(total, np.int32); pq = np.zeros(total, np.int32)
+    bad = np.zeros(4, np.int32)
+    emu.emu_sg_emit(n_lm, int(L["NG"]), _ptr(lm_ptr), _ptr(gpos), _ptr(off), _ptr(key), _ptr(idx), _ptr(a0), _ptr(b0), _ptr(pq), _ptr(bad))
+    assert bad[0] == 0 and np.array_equal(idx, np.arange(total, dtype=np.uint32))
+    srt = np.argsort(key, kind="stable")                  # = rocprim::radix_sort_pairs (stable) + k_sg_gather
+    assert np.array_equal(a0[srt], L["a0"]) and np.array_equal(b0[srt], L["b0"]) and np.array_equal(pq[srt], L["pq"])
+    ks = key[srt]
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    assert np.array_equal(ks[starts], L["pair_key"]) and np.array_equal(np.concatenate([starts, [total]]), L["pair_ptr"])

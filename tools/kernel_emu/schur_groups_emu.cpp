@@ -55,3 +55,21 @@ extern "C" int emu_schur_pairs_reference(int64_t n_pairs, const int32_t* prow, c
   }
   return 0;
 }
+
+// ---- the per-landmark kernels of the device-side list builder (csrc/schur_groups_lists_kernel.h), one workgroup of 256 host threads at a time
+namespace gt { namespace {
+#include "../../gtsam_amd/csrc/schur_groups_lists_kernel.h"
+} }
+
+extern "C" int emu_sg_sort_count(int n_lm, const int64_t* ptr, const int32_t* lm_obs, const int32_t* obs_red, const int32_t* red_pos,
+                                 int32_t* gobs, int32_t* gpos, int64_t* cnt) {
+  for (int b = 0; b < (n_lm + 1 + 255) / 256; b++)
+    emu::run_workgroup(256, (unsigned)b, [&] { gt::k_sg_sort_count(n_lm, ptr, lm_obs, obs_red, red_pos, gobs, gpos, cnt); });
+  return 0;
+}
+extern "C" int emu_sg_emit(int n_lm, int NG, const int64_t* ptr, const int32_t* gpos, const int64_t* off, uint32_t* key, uint32_t* idx,
+                           int32_t* a0, int32_t* b0, int32_t* pq, int32_t* bad) {
+  for (int b = 0; b < (n_lm + 255) / 256; b++)
+    emu::run_workgroup(256, (unsigned)b, [&] { gt::k_sg_emit(n_lm, NG, ptr, gpos, off, key, idx, a0, b0, pq, bad); });
+  return 0;
+}

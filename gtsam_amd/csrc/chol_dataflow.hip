@@ -54,8 +54,10 @@ constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 *
 // its Dinv slot counts released panels, pd_flag is epoch * 8 + 4 when the accumulated diagonal tile is in
 __device__ __forceinline__ long long final_of(long long epoch) { return epoch * 8 + 4; }
 
+#ifndef GT_KERNEL_EMU
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+#endif
 constexpr int kHandoffAux = 16;   // cache-policy bits of the LDS-DMA that reads handed-over data: sc1 (agent scope, past the CU's L1)
 
 // ---- cross-workgroup visibility without cache-wide fences -----------------------------------------------------------
@@ -89,7 +91,7 @@ __device__ __forceinline__ void stores_done() {   // this wavefront's stores are
 #if GTG_DF_FENCES
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GT_DRAIN_STORES();
 #endif
 }
 // Every flag is published TWICE: at its word and at a shadow word `sh` words further on (another line, another page).  A poller reads
@@ -175,8 +177,8 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
           dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
           // post-mortem (ctrl[2..3]): where the waiter runs
           unsigned xcc, hw;
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+          GT_XCC_ID(xcc);
+          GT_HW_ID(hw);
           dbg[-6] = (int)(xcc & 0xf); dbg[-5] = (int)hw;
         }
         // (write-through: the other XCDs' waiters poll this word and must see it while the kernels are still running)
@@ -228,7 +230,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   // per row tile (W[rt]: -X_{q-1}; then R_q -> operand layout; then -X_q), shared by the two wavefronts of the row tile; the B
   // operand images (<= 3 blocks L(p, q-1) + Linv(q,q)) come memory -> LDS by LDS-DMA, one memory latency per step.
   int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));
+  GT_PIN(tid_);
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 1;
@@ -335,7 +337,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
   // the persistent task loop and kept alive across it
   int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));
+  GT_PIN(tid_);
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 1, h = wave & 1;
@@ -504,8 +506,8 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      GT_HW_ID(hw);
+      GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
 #if (GTG_DF_SAFE & 4)
@@ -517,6 +519,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
   }
 }
 
+#ifndef GT_KERNEL_EMU   // (the emulation calls bulk_loop / chain_loop itself: dynamic LDS is a host buffer there)
 __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S, const int32_t* __restrict__ tasks,
                                                     int ntasks, const int32_t* __restrict__ klist,
                                                     long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
+#endif
 
 // one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
 __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
@@ -622,6 +626,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
   }
 }
 
+#ifndef GT_KERNEL_EMU
 __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, double* __restrict__ Xinv_all,
                                                      const long long* __restrict__ pd_flag, long long* tile_flag,
                                                      const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
@@ -653,8 +658,11 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
 }
 
 __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
+#endif   // GT_KERNEL_EMU
 
 }  // namespace
+
+#ifndef GT_KERNEL_EMU   // (host code from here on)
 
 // ---- host: task lists --------------------------------------------------------------------------------------------
 // tile_struct: (nt x nt) row-major bytes, lower triangle: tile (I, J) holds something before the factorisation
@@ -1016,3 +1024,6 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
 }
 
 }  // namespace gt
+#else
+}  // namespace gt   (emulation: the device code above only)
+#endif   // GT_KERNEL_EMU

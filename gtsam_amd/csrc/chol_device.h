@@ -9,6 +9,8 @@
 #define GT_PIN(x) asm volatile("" : "+v"(x))                           // keeps a value in its register at this point of the schedule
 #define GT_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // this wavefront's stores are acknowledged
 #define GT_LDS_VOLATILE(T) __attribute__((address_space(3))) volatile T*    // explicit LDS pointers for volatile accesses
+#define GT_XCC_ID(x) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x))   // where a workgroup runs (traces, post-mortems)
+#define GT_HW_ID(x) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x))
 #define GT_WAVE_SYNC() ((void)0)   // lanes of ONE wavefront exchange data through LDS here: in order on the hardware (the LDS operations of a
                                    // wavefront complete in program order), a rendezvous of the wavefront's threads in the host emulation
 #endif

@@ -109,7 +109,12 @@ template <class T, class V> inline T emu_atomic_exchange(T* p, V v) { T x = (T)v
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) std::this_thread::yield()
-#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// a fence at "wavefront" scope orders LDS traffic between the lanes of ONE wavefront: in order on the hardware, a rendezvous here
+inline void emu_fence(const char* scope) {
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  if (scope[0] == 'w' && scope[1] == 'a') emu::wave().bar.arrive_and_wait();
+}
+#define __builtin_amdgcn_fence(order, scope) emu_fence(scope)
 #define __builtin_amdgcn_s_memtime() 0ll
 #define __builtin_amdgcn_ballot_w64(p) __ballot(p)
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
@@ -149,3 +154,28 @@ inline int emu_ds_bpermute(int addr, int v) {
   return r;
 }
 #define __builtin_amdgcn_ds_bpermute(addr, v) emu_ds_bpermute((addr), (v))
+
+// ---- the rest of the vocabulary of csrc/chol_dataflow.hip (the two persistent kernels of the dataflow Cholesky) ------------------------
+#include <chrono>
+#define GT_XCC_ID(x) ((x) = 0)
+#define GT_HW_ID(x) ((x) = 0)
+typedef const void* gptr_t;
+typedef void* lptr_t;
+// global_load_lds_dwordx4: lane l moves 16 bytes from ITS global address to (wave-uniform LDS address) + 16 l
+inline void emu_global_load_lds(gptr_t g, lptr_t l, int bytes) { std::memcpy(static_cast<char*>(l) + (size_t)emu::lane() * bytes, g, (size_t)bytes); }
+#define __builtin_amdgcn_global_load_lds(g, l, bytes, off, aux) emu_global_load_lds((g), (l), (bytes))
+// the 100 MHz constant clock, slowed down 100 000 times: the kernels' 20 ms wait bounds must not fire at emulation speed
+inline long long wall_clock64() { return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 1000000); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicCAS(int* p, int expect, int v) { __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
+template <class T, class V> inline T emu_atomic_fetch_max(T* p, V v) {
+  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
+#define __hip_atomic_fetch_max(p, v, order, scope) emu_atomic_fetch_max((p), (v))
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST)
+// "am I the first lane": every thread says yes -- the single-lane read-modify-write polls are idempotent, and the v_readfirstlane that
+// follows them is the identity here
+#define __builtin_amdgcn_mbcnt_lo(a, b) 0u
+#define __builtin_amdgcn_mbcnt_hi(a, b) 0u

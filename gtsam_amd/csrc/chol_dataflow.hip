@@ -532,24 +532,6 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
 }
 #endif
 
-// one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
-__device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
-  double* Cb = A + boff(ib, cb);
-  const double* Li = X + ib * SB * PB;
-  const double* Lc = X + cb * SB * PB;
-  v4f64 acc;
-#pragma unroll
-  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
-#pragma unroll
-  for (int kk = 0; kk < SB; kk += 4) {
-    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
-    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
-    acc = MFMA(av, bv, acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
-}
-
 // The diagonal tiles.  Two workgroups (even / odd J) take turns, so that everything before the last slice of tile J -- waiting for
 // PD(J), bringing the tile into LDS, the first three slices -- happens while the partner factors tile J-1 (with one workgroup
 // those 13 us per tile were on the serial chain).  Tile J: wait until PD(J) is in (every update but the one of block column J-1),
@@ -573,6 +555,9 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1), [3 J + 2]: of (J, J-2) (-1: not stored / not streamed)
     double* tile = S + (int64_t)dslot * TT;
+#if GT_DF_DEFER_SLICE
+    bool deferred = false;
+#endif
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     // The updates of the two block columns right before this tile are applied HERE, in 32-column slices as the substitutions of the
     // tiles (J, J-2) and (J, J-1) publish them: first column J-2's (its tile becomes final while the partner workgroup is still
@@ -612,6 +597,16 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
           }
         }
         __syncthreads();
+#if GT_DF_DEFER_SLICE
+        if (pass == 1 && q == 3) {
+          // The LAST slice is on the serial chain of the factorisation (the tile left of this one became final a moment ago): only its
+          // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- is applied here (2 rounds of MFMA
+          // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4:
+          // 5.12 -> 5.07 ms on L1723 (profiles/r04_df_defer_ab.txt).
+          for (int t = wave; t < 16; t += 8) slice_task(A, X, t >> 2, 0, (t >> 1) & 1, t & 1, lr, lk);
+          deferred = true;
+        } else
+#endif
         for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
           const int blk = t >> 2;
           int ib = 0, rem = blk;
@@ -620,7 +615,12 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
+#if GT_DF_DEFER_SLICE
+    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
+               deferred ? X : nullptr);
+#else
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
+#endif
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }

@@ -20,6 +20,16 @@
 #ifndef GT_POTRF_WINDOW
 #define GT_POTRF_WINDOW 0
 #endif
+// GT_DF_DEFER_SLICE=1 (libgtsam_amd_defer.so: chol_dataflow.hip only, so that the stream schedule's kernels stay those of the product
+// library): the chain kernel applies the last slice of the tile left of a diagonal tile only to the blocks panel 0 reads and leaves
+// the rest to the two wavefronts that idle during panel 0 (potrf_body, Xdef).  Built and measured in round 4 (- 1.1 %, bit-identical),
+// taken out again with the round's last session (profiles/r04_streams_tree_hang.txt).
+#ifndef GT_DF_DEFER_SLICE
+#define GT_DF_DEFER_SLICE 0
+#endif
+#if GT_DF_DEFER_SLICE && GT_POTRF_WINDOW
+#error "the deferred slice uses wavefront 6 in panel 0, which is the windowed chain's helper"
+#endif
 #ifndef GT_POTRF_OWN_LDS
 #define GT_POTRF_OWN_LDS 0     // windowed variant only: 1 = the lane's own entry of the next column is read back from LDS as in the default body
 #endif
@@ -507,6 +517,24 @@ __device__ __forceinline__ void store_column(const double* A, double* tile, doub
   }
 }
 
+// one 16x16 MFMA tile (ti, tj) of  C(ib,cb) -= X(ib) X(cb)^T  on the packed LDS image of a diagonal tile, X = four 32x32 blocks
+__device__ __forceinline__ void slice_task(double* A, const double* X, int ib, int cb, int ti, int tj, int lr, int lk) {
+  double* Cb = A + boff(ib, cb);
+  const double* Li = X + ib * SB * PB;
+  const double* Lc = X + cb * SB * PB;
+  v4f64 acc;
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr];
+#pragma unroll
+  for (int kk = 0; kk < SB; kk += 4) {
+    const double av = -Li[(16 * ti + lr) * PB + kk + lk];
+    const double bv = Lc[(16 * tj + lr) * PB + kk + lk];
+    acc = MFMA(av, bv, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) Cb[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[r];
+}
+
 // ---- diagonal tile ------------------------------------------------------------------------------------------
 // One workgroup of 8 wavefronts; per 32-column panel jb of the tile:
 //   P1  wave 0: potrf32(jb), the pivot chain | waves 1..3-jb: followers of the row blocks below | wave 5: follower
@@ -547,7 +575,9 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* tile, double* __r
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ tile, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
-                                           const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr) {
+                                           const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr,
+                                           const double* Xdef = nullptr) {
+  // (Xdef: GT_DF_DEFER_SLICE only -- the last 32-column slice of the tile left of this one, in LDS; see chain_loop)
   const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
   // (host-counted): a word in device memory that every factorisation rewrites was read one factorisation stale by one of two
   // co-operating kernels under multi-handle contention (rate ~1e-3; tools/df_contention_diag.py, profiles/r03_df_contention.txt)
@@ -597,6 +627,14 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       // the helper of the windowed chain: wavefront 6 in panel 0 (it has nothing else to do there), the spare follower wavefront 3
       // afterwards (SIMD 3; the deferred work below is then shared by one wavefront less)
       stage_helper(A, lines, rinvs, prog, hand, hprog, jb, lane);
+#endif
+#if GT_DF_DEFER_SLICE
+    } else if (jb == 0) {
+      if (Xdef)
+        for (int t = wave - 6; t < 24; t += 2) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles
+          const int b2 = (t >> 2) * 2;
+          slice_task(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1, lr, lk);
+        }
 #endif
     } else if (jb > 0) {
       const int pj = jb - 1;                            // deferred work of panel pj

@@ -41,6 +41,12 @@ def exe():
 
 
 @pytest.fixture(scope="module")
+def exe_defer():
+    """the same kernels with the deferred last-slice update (chol_dataflow.hip / chol_device.h, GT_DF_DEFER_SLICE=1)"""
+    return _build(os.path.join(ROOT, "tests", "_build", "dataflow_emu_defer"), ["-DGT_DF_DEFER_SLICE=1"])
+
+
+@pytest.fixture(scope="module")
 def exe_window():
     """the same kernels with the windowed pivot chain in the diagonal-tile body (chol_device.h, GT_POTRF_WINDOW=1)"""
     return _build(EXE_WINDOW, ["-DGT_POTRF_WINDOW=1"])
@@ -154,3 +160,16 @@ def test_emulated_dataflow_factorisation_windowed_variant_is_bit_identical(exe, 
     S1, X1 = factor.last
     assert np.array_equal(S0, S1)
     assert np.array_equal(X0.reshape(4, T * T)[:, :14336], X1.reshape(4, T * T)[:, :14336])
+
+
+def test_emulated_dataflow_factorisation_deferred_slice_is_bit_identical(exe, exe_defer, tmp_path):
+    """The chain kernel applies the last slice of the tile left of a diagonal tile only to the blocks panel 0 reads; the rest runs under
+    panel 0's pivot chain on the two wavefronts that idle there, before the barrier in front of the next panel's updates: every entry
+    sees the same sums in the same order."""
+    factor(exe, 4, 3, 2, 1, tmp_path)
+    S0, X0 = factor.last
+    for rep in range(2):
+        factor(exe_defer, 4, 3, 2, 1, tmp_path)
+        S1, X1 = factor.last
+        assert np.array_equal(S0, S1)
+        assert np.array_equal(X0.reshape(4, T * T)[:, :14336], X1.reshape(4, T * T)[:, :14336])

@@ -15,6 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WINDOW = os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd_window.so")
+DEFER = os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd_defer.so")     # the deferred last-slice update of the chain kernel (GT_DF_DEFER_SLICE=1)
 
 _CHILD = r'''
 import hashlib, json, sys
@@ -50,5 +51,8 @@ def _run(workload, lib, sched):
 def test_windowed_pivot_chain_gives_the_same_bits(workload, sched):
     import torch
     assert torch.cuda.is_available() and os.path.exists(WINDOW)
-    a = _run(workload, None, sched); b = _run(workload, WINDOW, sched)
-    assert a == b, (a, b)
+    a = _run(workload, None, sched)
+    for lib in (WINDOW, DEFER):
+        assert os.path.exists(lib)
+        b = _run(workload, lib, sched)
+        assert a == b, (os.path.basename(lib), a, b)

@@ -28,11 +28,15 @@ PY
 # ---- the windowed pivot chain (libgtsam_amd_window.so: chol_device.h GT_POTRF_WINDOW=1; bit-identical to the default on host threads):
 # the parity files with it, then its bench line and chain trace next to the default's (phase_ms_per_call.cholesky, period_us)
 W=$PWD/gtsam_amd/lib/libgtsam_amd_window.so
+D=$PWD/gtsam_amd/lib/libgtsam_amd_defer.so     # the deferred last-slice update (GT_DF_DEFER_SLICE=1; its stream-schedule kernels are the product library's)
 GTSAM_AMD_LIB=$W timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline_parity.py -x -q -m gpu 2>&1 | tail -8 > $out/window_parity.log
 tail -2 $out/window_parity.log
+GTSAM_AMD_LIB=$D timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_headline_parity.py -x -q -m gpu 2>&1 | tail -8 > $out/defer_parity.log
+tail -2 $out/defer_parity.log
 for rep in 1 2; do
   timeout 300 $B > $out/bench_default_$rep.json 2> $out/bench_default_$rep.err
   GTSAM_AMD_LIB=$W timeout 300 $B > $out/bench_window_$rep.json 2> $out/bench_window_$rep.err
+  GTSAM_AMD_LIB=$D timeout 300 $B > $out/bench_defer_$rep.json 2> $out/bench_defer_$rep.err
 done
 timeout 300 python tools/df_trace.py > $out/df_trace_default.txt 2> /dev/null
 GTSAM_AMD_LIB=$W timeout 300 python tools/df_trace.py > $out/df_trace_window.txt 2> /dev/null
@@ -42,7 +46,7 @@ for w in sphere2500 w20000; do
 done
 python - <<PY
 import json, glob
-for f in sorted(glob.glob('$out/bench_default_*.json') + glob.glob('$out/bench_window_*.json') + glob.glob('$out/bench_sphere2500_*.json') + glob.glob('$out/bench_w20000_*.json')):
+for f in sorted(glob.glob('$out/bench_default_*.json') + glob.glob('$out/bench_window_*.json') + glob.glob('$out/bench_defer_*.json') + glob.glob('$out/bench_sphere2500_*.json') + glob.glob('$out/bench_w20000_*.json')):
     try:
         j = json.load(open(f)); print(f.split('/')[-1], round(j['lambda_tries_per_s'], 2), 'tries/s; cholesky', round(j['phase_ms_per_call']['cholesky'], 3), 'ms; error', repr(j['converged_error']))
     except Exception as e:

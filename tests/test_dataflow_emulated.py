@@ -154,22 +154,22 @@ def test_emulated_dataflow_factorisation_with_accumulator_lanes(exe, tmp_path):
 def test_emulated_dataflow_factorisation_windowed_variant_is_bit_identical(exe, exe_window, tmp_path):
     """The windowed pivot chain inside the chain kernel (tile image preloaded by the caller, last slices applied in front of it): the
     same factor, inverses and operand images as the default body, bit for bit."""
-    factor(exe, 4, 3, 2, 1, tmp_path)
+    factor(exe, 3, 2, 2, 1, tmp_path)
     S0, X0 = factor.last
-    factor(exe_window, 4, 3, 2, 1, tmp_path)
+    factor(exe_window, 3, 2, 2, 1, tmp_path)
     S1, X1 = factor.last
     assert np.array_equal(S0, S1)
-    assert np.array_equal(X0.reshape(4, T * T)[:, :14336], X1.reshape(4, T * T)[:, :14336])
+    assert np.array_equal(X0.reshape(3, T * T)[:, :14336], X1.reshape(3, T * T)[:, :14336])
 
 
 def test_emulated_dataflow_factorisation_deferred_slice_is_bit_identical(exe, exe_defer, tmp_path):
     """The chain kernel applies the last slice of the tile left of a diagonal tile only to the blocks panel 0 reads; the rest runs under
     panel 0's pivot chain on the two wavefronts that idle there, before the barrier in front of the next panel's updates: every entry
     sees the same sums in the same order."""
-    factor(exe, 4, 3, 2, 1, tmp_path)
+    factor(exe, 3, 2, 2, 1, tmp_path)
     S0, X0 = factor.last
     for rep in range(2):
-        factor(exe_defer, 4, 3, 2, 1, tmp_path)
+        factor(exe_defer, 3, 2, 2, 1, tmp_path)
         S1, X1 = factor.last
         assert np.array_equal(S0, S1)
-        assert np.array_equal(X0.reshape(4, T * T)[:, :14336], X1.reshape(4, T * T)[:, :14336])
+        assert np.array_equal(X0.reshape(3, T * T)[:, :14336], X1.reshape(3, T * T)[:, :14336])

@@ -569,7 +569,10 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
     check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
     while ((int)g_ts.panel.size() < nslots) {
       hipStream_t a, b;
-      if (getenv("GTG_TREE_NOPRIO")) check_hip(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "panel stream");
+      // (no stream priorities in the tree form since the end of round 4: it is an A/B and a last-resort fallback, not a fast path, and the
+      // one run of it that did not return -- profiles/r04_streams_tree_hang.txt -- leaves priority pre-emption beside polling workgroups
+      // among the suspects; GTG_TREE_PRIO=1 brings them back)
+      if (!getenv("GTG_TREE_PRIO") || getenv("GTG_TREE_NOPRIO")) check_hip(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "panel stream");
       else check_hip(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, hi), "panel stream");
       check_hip(hipStreamCreateWithFlags(&b, hipStreamNonBlocking), "update stream");
       g_ts.panel.push_back(a); g_ts.update.push_back(b);

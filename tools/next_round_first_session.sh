@@ -67,10 +67,12 @@ print(code % {"root": "$PWD", "sched": "streams", "depth": 2})
 PY
 ok=0; hung=0
 for i in $(seq 1 40); do
+  # odd runs with the stream priorities the schedule had when it hung (GTG_TREE_PRIO=1), even runs without (the default since then)
+  if [ $((i % 2)) = 1 ]; then export GTG_TREE_PRIO=1; else unset GTG_TREE_PRIO; fi
   if GTG_CHOL=streams GTG_ND_DEPTH=2 timeout 120 python $out/nd_child.py > $out/nd_last.out 2> $out/nd_last.err; then ok=$((ok+1));
   else
     rc=$?; hung=$((hung+1)); cp $out/nd_last.err $out/nd_failed_$i.err
-    echo "run $i: rc $rc" >> $out/streams_loop.txt
+    echo "run $i (GTG_TREE_PRIO=${GTG_TREE_PRIO:-0}): rc $rc" >> $out/streams_loop.txt
     # once more with the runtime's log, in case it is reproducible on this box
     GTG_CHOL=streams GTG_ND_DEPTH=2 AMD_LOG_LEVEL=3 timeout 120 python $out/nd_child.py > /dev/null 2> $out/nd_amdlog_$i.err; tail -c 20000 $out/nd_amdlog_$i.err > $out/nd_amdlog_$i.tail; rm -f $out/nd_amdlog_$i.err
     [ $hung -ge 3 ] && break

@@ -154,9 +154,12 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--skip-dense-roofline", action="store_true", help="do not run the extra dense-schedule factorisations (used for clean profiles)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="auto: measure roofline.traffic in this run (two rocprofv3 --pmc sub-runs)")
-    ap.add_argument("--parallelism", default="speculative", choices=["speculative", "shard"],
-                    help="N > 1: speculative = replicated handles, replica r tries the r-th lambda of the rejection sequence (gtsam_amd/speculative.py); "
-                         "shard = landmarks sharded, one all-reduce of the reduced camera system per try (SURVEY 8(e))")
+    ap.add_argument("--parallelism", default="shard", choices=["shard", "speculative"],
+                    help="N > 1: shard (default) = landmarks sharded, one RCCL all-reduce of the reduced camera system [S | g] per try (north_star, SURVEY 8(e)); "
+                         "speculative = replicated handles, replica r tries the r-th lambda of the rejection sequence (gtsam_amd/speculative.py)")
+    ap.add_argument("--extra-modes", default="auto", choices=["auto", "off"],
+                    help="N > 1, auto: after the headline (shard) the same line also carries `extra_modes`: the speculative-lambda replicas, the "
+                         "Venice-1778 shape sharded (BASELINE configs[5]) and the sharded PCG (implicit Schur complement) on the headline shape")
     ap.add_argument("--host", default="auto", choices=["auto", "python"], help="auto: the headline is timed in the C++ host (tools/cpp/bench_lm_gtsam.cpp) at N = 1")
     args = ap.parse_args()
 
@@ -174,15 +177,15 @@ def main():
     comm = None
     speculative = world > 1 and args.parallelism == "speculative"
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        if speculative:
-            from gtsam_amd.speculative import TorchComm
-            comm = TorchComm()
-        else:
-            from gtsam_amd.distributed import make_allreduce
-            allreduce = make_allreduce()
+        # (a bounded collective time-out: a rank that died inside an exchange ends the job with an error instead of hanging it)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+        from gtsam_amd.distributed import make_allreduce
+        from gtsam_amd.speculative import TorchComm
+        allreduce = make_allreduce()
+        comm = TorchComm()
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,12 +199,15 @@ def main():
     if args.workload in ("sphere2500", "w20000"):
         params = LevenbergMarquardtParams()                  # Pose3SLAMExample_g2o protocol with legacy LM
 
-    def fresh():
-        if speculative:     # every rank holds the whole graph
+    def fresh(problem_=None, values_=None, params_=None, mode=None):
+        problem_ = problem if problem_ is None else problem_; values_ = values0 if values_ is None else values_
+        params_ = params if params_ is None else params_
+        mode = ("speculative" if speculative else "shard") if mode is None else mode
+        if world > 1 and mode == "speculative":     # every rank holds the whole graph
             from gtsam_amd.speculative import SpeculativeLevenbergMarquardt
-            return SpeculativeLevenbergMarquardt(problem, values0, params, device=local_rank, comm=comm)
-        return DeviceLevenbergMarquardt(problem, values0, params, device=local_rank, shard=rank, n_shards=world,
-                                        allreduce=allreduce)
+            return SpeculativeLevenbergMarquardt(problem_, values_, params_, device=local_rank, comm=comm)
+        return DeviceLevenbergMarquardt(problem_, values_, params_, device=local_rank, shard=rank, n_shards=world,
+                                        allreduce=allreduce if world > 1 else None)
 
     torch.cuda.synchronize()
     mem_free0 = torch.cuda.mem_get_info()[0]
@@ -210,19 +216,47 @@ def main():
     handle_bytes = mem_free0 - torch.cuda.mem_get_info()[0]      # device memory one handle takes from the driver (the library keeps nothing aside by default)
     n_red = opt.dev.reduced_dim
 
-    def run_iterations(o, k):
+    def run_iterations(o, k, values_=None, params_=None):
         """k calls of iterate(); when the run converges it restarts from the initial values (same work/iteration)."""
+        values_ = values0 if values_ is None else values_; params_ = params if params_ is None else params_
         done = 0
         while done < k:
             before = o.error()
             o.iterate()
             done += 1
-            if check_convergence(params.relativeErrorTol, params.absoluteErrorTol, params.errorTol, before, o.error()) \
-                    or o.iterations() >= params.maxIterations:
-                o.dev.set_values(values0)
-                o._error = o.dev.error(); o._lambda = params.lambdaInitial; o._factor = params.lambdaFactor
+            if check_convergence(params_.relativeErrorTol, params_.absoluteErrorTol, params_.errorTol, before, o.error()) \
+                    or o.iterations() >= params_.maxIterations:
+                o.dev.set_values(values_)
+                o._error = o.dev.error(); o._lambda = params_.lambdaInitial; o._factor = params_.lambdaFactor
                 o._iterations = 0
         return done
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_mode(problem_, values_, params_, mode, steps, warmup):
+        """One more measured configuration of an N > 1 run (same protocol: warm-up, barrier, `steps` iterations, barrier, max over ranks)."""
+        o = fresh(problem_, values_, params_, mode)
+        run_iterations(o, warmup, values_, params_)
+        o.dev.enable_timing(True); o.dev.reset_timing()
+        i0 = o.getInnerIterations()
+        barrier()
+        tt = time.perf_counter()
+        run_iterations(o, steps, values_, params_)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - tt)
+        rec = {"value": steps / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+               "lambda_tries": int(o.getInnerIterations() - i0), "error_after": o.error(),
+               "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in o.dev.phase_ms().items()}}
+        if mode == "speculative":
+            rec["tries_computed_by_rank0"] = int(o.speculated); rec["tries_discarded_on_rank0"] = int(o.discarded)
+        o.dev.close()
+        return rec
 
     run_iterations(opt, args.warmup)
     opt.dev.enable_timing(True); opt.dev.reset_timing()
@@ -231,12 +265,7 @@ def main():
     t0 = time.perf_counter()
     run_iterations(opt, args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     tries = opt.getInnerIterations() - inner0
     phases = opt.dev.phase_ms()
     chol_ms, chol_calls = phases["cholesky"]
@@ -275,6 +304,47 @@ def main():
     full.optimize()
     barrier()
     ttc = time.perf_counter() - t1
+    full_rec = {"error": full.error(), "iterations": full.iterations(), "inner": full.getInnerIterations(), "initial_error": full.trace[0][1]}
+    full.dev.close()
+
+    # ---- N > 1: the other ways this loop can use N GPUs, measured in the same job and reported BESIDE the headline (never as `value`).
+    # Every leg runs on all ranks (they contain collectives); a leg that raises on a rank is reported as failed -- the ranks agree on
+    # that through an all-reduce of a flag before the next leg starts, so a failed leg does not leave ranks in different collectives.
+    extra = None
+    if world > 1 and args.extra_modes == "auto":
+        import torch.distributed as dist
+        extra = {}
+        esteps, ewarm = max(2, min(args.steps, 8)), max(1, min(args.warmup, 2))
+
+        def leg(name, fn):
+            ok, rec, err = 1.0, None, None
+            try:
+                rec = fn()
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0.0, f"{type(e).__name__}: {e}"[:300]
+            t = torch.tensor([ok], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            extra[name] = rec if float(t.item()) == 1.0 else {"failed": err or "raised on another rank"}
+
+        other = "speculative" if not speculative else "shard"
+        leg(other, lambda: dict(timed_mode(problem, values0, params, other, esteps, ewarm),
+                                what=("replicas with a speculative lambda search (gtsam_amd/speculative.py): the sequential trajectory, one try per iteration"
+                                      if other == "speculative" else "landmark shard + all-reduce of [S | g] per try")))
+        if args.workload == "ladybug1723":
+            def venice():
+                (pv, vv), dv = build_workload("venice1778")
+                return dict(timed_mode(pv, vv, LevenbergMarquardtParams.CeresDefaults(), "shard", esteps, ewarm), workload=dv,
+                            what="BASELINE configs[5]: landmark shard + all-reduce of [S | g]; the shape on which the sharded landmark phases are as long as the factorisation")
+            leg("venice1778_shard", venice)
+
+        def pcg():
+            pp = LevenbergMarquardtParams.CeresDefaults()
+            pp.linearSolverType = "Iterative"
+            return dict(timed_mode(problem, values0, pp, "shard", esteps, ewarm),
+                        what="landmark shard + block-Jacobi PCG on the implicit Schur complement (reference defaults: epsilon_rel 1e-3): every product S p is "
+                             "sharded, one all-reduce of the reduced vector per product -- no replicated factorisation")
+        if problem.n_sfm:
+            leg("pcg_shard", pcg)
 
     if rank == 0:
         # ALGORITHMIC flops of one factorisation = the elimination counted on the d x d variable blocks (sum over block columns of
@@ -285,7 +355,6 @@ def main():
         # HBM bytes per factorisation: measured in this run by two rocprofv3 --pmc sub-runs (measure_traffic); when that is not possible
         # (no rocprofv3, --traffic off, N > 1) the figure of the committed PMC passes of the same command is quoted and labelled as such
         traffic, traffic_source, traffic_kernels = None, None, {}
-        full.dev.close()
         if args.traffic == "auto" and world == 1:
             traffic, traffic_source, traffic_kernels = measure_traffic(args.workload)
         if traffic is None:
@@ -320,16 +389,22 @@ def main():
                        "observations": int(problem.n_sfm), "reduced_dim": int(n_red),
                        "parallelism": (f"speculative-lambda x{world} (replicas; replica r tries the r-th lambda of the rejection sequence, decisions replayed in order: the sequential trajectory)"
                                        if speculative else f"landmark-shard x{world}") if world > 1 else "single GPU",
-                       "exchange": ("RCCL on the handles' device buffers" if getattr(comm, "device_backend", False) else
-                                    ("gloo through the host -- the device exchange raised: " + str(getattr(comm, "fell_back", None))) if getattr(comm, "fell_back", None)
-                                    else "gloo through the host") if (world > 1 and speculative) else None},
+                       "exchange": (("RCCL" if getattr(comm, "device_backend", False) else "gloo through the host (dry run)") + (": gather of 5 doubles + broadcast of the accepted values per iteration" if speculative else ": all-reduce of the reduced camera system [S | g] at block granularity + landmark part of delta per try, Hessian diagonal per linearisation")) if world > 1 else None},
+            "extra_modes": extra,
+            # the cross-checks a reader needs, at the top level: tries per iteration of the timed loop and the device time per iteration
+            "lambda_tries": int(cpp["lambda_tries"]) if (cpp_ok and "lambda_tries" in cpp) else int(tries),
+            "tries_per_iteration": (cpp["lambda_tries"] / args.steps) if (cpp_ok and "lambda_tries" in cpp) else tries / args.steps,
+            "device_phase_ms_per_iteration": (cpp["device_phase_ms_one_optimisation"] / max(cpp["iterations_per_optimisation"], 1)) if (cpp_ok and cpp.get("device_phase_ms_one_optimisation"))
+                                             else sum(v[0] for v in phases.values()) / args.steps,
+            "device_phase_ms_source": "C++ host: HIP events around every phase of one more optimize() (not the timed region), divided by its iterations" if (cpp_ok and cpp.get("device_phase_ms_one_optimisation"))
+                                      else "Python mirror: HIP events around every phase of the timed loop",
             "lambda_tries_per_s": cpp["lambda_tries_per_s"] if cpp_ok else tries / elapsed,
             # construction -> checkConvergence.  `time_to_converged_s` is the COLD figure when the C++ leg ran (first optimizer of a fresh
             # process: code-object load, first device allocations); warm = a later optimizer of the same process
             "time_to_converged_s": cpp["cold_time_to_converged_s"] if cpp_ok else ttc,
             "time_to_converged_warm_s": cpp["warm_time_to_converged_s"] if cpp_ok else ttc,
-            "time_to_converged_python_mirror_warm_s": ttc, "time_to_converged_setup_s": t_setup, "device_memory_per_handle_bytes": int(handle_bytes), "converged_error": full.error(), "converged_iterations": full.iterations(),
-            "converged_inner_iterations": full.getInnerIterations(), "initial_error": full.trace[0][1],
+            "time_to_converged_python_mirror_warm_s": ttc, "time_to_converged_setup_s": t_setup, "device_memory_per_handle_bytes": int(handle_bytes), "converged_error": full_rec["error"], "converged_iterations": full_rec["iterations"],
+            "converged_inner_iterations": full_rec["inner"], "initial_error": full_rec["initial_error"],
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
             "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced camera system after RCM reordering: dataflow schedule, k_df_bulk + k_df_chain, one factorisation = one launch of each (flops_per_launch = the elimination counted at the granularity of the variable blocks, fill included = the algorithmic count `frac` is quoted on; flops_stored_tiles = what the kernels execute over the stored 128x128 tiles)",
                          "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -388,7 +463,10 @@ def main():
                                      "(-O3 -mavx2 -mfma, no TBB)",
                            "phase_ms": dict(zip(["linearize", "hessianDiagonal", "damp", "eliminate_solve", "linear_error_x2", "retract", "error", "total"],
                                                 [float(x) for x in ms])),
-                           "cores_used": 1, "host_cpus": os.cpu_count()}
+                           "cores_used": 1, "host_cpus": os.cpu_count(),
+                           "cores_note": "the reference build has no TBB (headers absent from the image): 1 thread is what gtsam itself uses here. ~95 % of the iteration is the "
+                                         "elimination of the reduced camera system, a serial chain of dense fronts (eliminateMultifrontal's root clique), so more threads would not change "
+                                         "the figure: see multi_thread, where linearize and the landmark eliminations are split over std::threads by the harness"}
                     # multi-thread variant (the library is built without TBB -- no headers in the image -- so the split is made in
                     # the harness, oracle/ref_harness.cpp ref_graph_iteration_mt: linearize and the landmark eliminations of the
                     # Schur ordering on `threads` std::threads, the camera system on one); reported next to the 1-thread figure,

@@ -24,7 +24,7 @@ sequential order (SmartProjectionFactor.h:127-183), so the replicas fall back to
 The landmark-sharded mode of SURVEY.md section 8(e) (gtsam_amd/distributed.py: one exchange of the reduced camera system per try)
 is the other way to use N GPUs; on this path it shortens the 1.4 ms in front of the factorisation and pays an all-reduce of 0.13 GB
 for it, while the 5.2 ms factorisation -- a serial chain of 122 diagonal tiles -- stays replicated.  bench.py --parallelism
-selects; the default for N > 1 is this one.
+selects; the default for N > 1 is the landmark shard (the partition north_star names), this mode is reported beside it.
 """
 from __future__ import annotations
 
@@ -39,44 +39,23 @@ from .optimizer import DeviceLevenbergMarquardt
 
 class TorchComm:
     """The two exchanges over torch.distributed: nccl (= RCCL over xGMI) on device tensors, gloo on host copies (CPU tests, or
-    several replicas on one GPU)."""
+    several replicas on one GPU).  The backend of the group decides; there is NO fall-back from one to the other: a device exchange
+    that raises is an error on the rank that sees it (RCCL errors are asynchronous and per rank, so ranks could not agree on a
+    switch of process groups without another collective that may hang in turn)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist = dist; self.group = group
         self.rank = dist.get_rank(group); self.world = dist.get_world_size(group)
         self.device_backend = dist.get_backend(group) != "gloo"
-        # The device path (RCCL on the handle's own buffers) has only ever run in the CPU dry-run's place-holder form: no multi-GPU box
-        # was available to the builder.  A host-side group stands by: should the FIRST device exchange raise before anything was sent
-        # (every rank runs the same code on the same kind of box, so every rank raises at the same call), the search continues over
-        # gloo -- 2.7 MB per accepted step through the host on the L1723 shape -- and `fell_back` says so (bench.py reports it).
-        self.host_group = None
-        self.fell_back = None
-        if self.device_backend and group is None and self.world > 1:
-            try:
-                self.host_group = dist.new_group(backend="gloo")
-            except Exception:   # noqa: BLE001  (no gloo in this build of torch: the device path stands alone)
-                self.host_group = None
-
-    def _to_host_path(self, what, err):
-        import sys
-        if self.host_group is None:
-            raise err
-        self.fell_back = f"{what}: {type(err).__name__}: {err}"
-        sys.stderr.write(f"[gtsam_amd] speculative search: the device exchange failed in {what} ({type(err).__name__}: {err}); continuing over gloo\n")
-        self.device_backend = False
-        self.group = self.host_group
 
     def all_gather(self, vec):
         import torch
         if self.device_backend:
-            try:
-                t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64, device="cuda")
-                out = torch.empty((self.world, t.numel()), dtype=torch.float64, device="cuda")
-                self.dist.all_gather_into_tensor(out, t, group=self.group)
-                return out.cpu().numpy()
-            except Exception as e:   # noqa: BLE001
-                self._to_host_path("all_gather", e)
+            t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64, device="cuda")
+            out = torch.empty((self.world, t.numel()), dtype=torch.float64, device="cuda")
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+            return out.cpu().numpy()
         t = torch.tensor(np.asarray(vec, np.float64), dtype=torch.float64)
         out = torch.empty((self.world, t.numel()), dtype=torch.float64)
         self.dist.all_gather(list(out.unbind(0)), t, group=self.group)
@@ -88,17 +67,14 @@ class TorchComm:
         if self.rank == src:
             dev.accept()                           # trial <-> current: the winner's current values are now the accepted ones
         if self.device_backend:
-            try:
-                from .distributed import _DevicePtr
-                ptr, n, stream = dev.values_device_ptr(0)
-                t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
-                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else _null():
-                    self.dist.broadcast(t, src=src, group=self.group)
-                if self.rank != src:
-                    dev.values_changed()
-                return
-            except Exception as e:   # noqa: BLE001
-                self._to_host_path("broadcast", e)
+            from .distributed import _DevicePtr
+            ptr, n, stream = dev.values_device_ptr(0)
+            t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else _null():
+                self.dist.broadcast(t, src=src, group=self.group)
+            if self.rank != src:
+                dev.values_changed()
+            return
         if self.rank == src:
             t = torch.from_numpy(dev.values())
         else:
@@ -106,6 +82,9 @@ class TorchComm:
         self.dist.broadcast(t, src=src, group=self.group)
         if self.rank != src:
             dev.set_values(t.numpy())
+
+
+_RC_RAISED = -99   # status of a speculated try whose device call raised (travels through the gather)
 
 
 class _null:
@@ -143,8 +122,15 @@ class SpeculativeLevenbergMarquardt(DeviceLevenbergMarquardt):
         comm = self.comm
         seq = self._lambda_sequence(comm.world)
         mine = seq[comm.rank]
+        # A speculated try may fail where the sequential search would never have gone (a time-out of a lambda the trajectory does
+        # not reach, any HIP error): the failure travels as a status code in the gathered vector -- every rank still takes part in
+        # the collective -- and is raised, on ALL ranks, only if the in-order replay actually reaches that try.
+        mine_error = None
         if mine is not None:
-            rc, out = self.dev.try_lambda(mine, p.diagonalDamping, p.minDiagonal, p.maxDiagonal)
+            try:
+                rc, out = self.dev.try_lambda(mine, p.diagonalDamping, p.minDiagonal, p.maxDiagonal)
+            except Exception as e:   # noqa: BLE001
+                rc, out, mine_error = _RC_RAISED, np.zeros(4), e
             self.speculated += 1
         else:
             rc, out = -1, np.zeros(4)
@@ -157,6 +143,10 @@ class SpeculativeLevenbergMarquardt(DeviceLevenbergMarquardt):
             if seq[k] is None:
                 break
             assert seq[k] == self._lambda, (seq, self._lambda)
+            if int(got[k, 0]) == _RC_RAISED:          # the trajectory needs a try that failed on its replica: an error everywhere
+                if k == comm.rank and mine_error is not None:
+                    raise mine_error
+                raise RuntimeError(f"speculative lambda search: the try of lambda = {seq[k]!r} failed on replica {k} (see that rank's error)")
             self.dev.try_lambda = lambda *a, _k=k: (int(got[_k, 0]), got[_k, 1:5].copy())
             accepted = {"yes": False}
             self.dev.accept = lambda: accepted.__setitem__("yes", True)

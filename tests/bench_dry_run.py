@@ -35,5 +35,5 @@ def _cpu_tensor(*a, **kw):
 torch.tensor = _cpu_tensor
 sys.argv = ["bench.py", "--gpus", os.environ.get("WORLD_SIZE", "1"), "--steps", "2", "--warmup", "1", "--workload", "dubrovnik16",
             "--cpu-baseline", "off", "--skip-dense-roofline", "--traffic", "off", "--host", "python",
-            "--parallelism", os.environ.get("BENCH_PARALLELISM", "speculative")]
+            "--parallelism", os.environ.get("BENCH_PARALLELISM", "shard")]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")

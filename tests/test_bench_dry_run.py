@@ -15,7 +15,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "data", "config", "roofline", "cpu_baseline", "time_to_converged_s", "time_to_converged_setup_s"}
 
 
-@pytest.mark.parametrize("world,mode", [(1, "speculative"), (2, "speculative"), (2, "shard")])
+@pytest.mark.parametrize("world,mode", [(1, "shard"), (2, "shard"), (2, "speculative")])
 def test_bench_contract_and_multi_rank_flow(world, mode):
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
         pytest.skip("libgtsam_amd.so not built")
@@ -39,4 +39,12 @@ def test_bench_contract_and_multi_rank_flow(world, mode):
     assert rec["scaling"] == "strong" and rec["dtype"] == "f64" and rec["data"] == "synthetic" and rec["vs_baseline"] is None
     assert "workload" in rec["config"] and "model" not in rec["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rec["roofline"])
+    if world > 1:     # the other modes ride along in the same line (bench.py --extra-modes auto)
+        other = "speculative" if mode == "shard" else "shard"
+        assert set(rec["extra_modes"]) == {other, "pcg_shard"}, rec["extra_modes"]
+        for k, v in rec["extra_modes"].items():
+            assert "failed" not in v and v["steps"] >= 2 and v["value"] > 0, (k, v)
+    else:
+        assert rec["extra_modes"] is None
+    assert {"lambda_tries", "tries_per_iteration", "device_phase_ms_per_iteration"} <= set(rec)
     assert rec["config"]["parallelism"].startswith("single GPU" if world == 1 else ("speculative-lambda x2" if mode == "speculative" else "landmark-shard x2"))

@@ -108,3 +108,68 @@ def test_speculative_replay_equals_the_sequential_search(world):
         rejections += v["inner"] - v["iterations"]
         assert v["rounds"] <= v["inner"]
     assert rejections > 0          # the problems do exercise rejected tries
+
+
+# ---- a speculated try that raises: the failure travels through the gather as a status code; every rank still takes part
+# in the collectives; the error is raised -- on ALL ranks -- only when the in-order replay reaches that try
+_CHILD_ERR = _CHILD.split("OPT.DeviceGraph = FakeDevice")[0] + r'''
+import os
+rank = int(os.environ["RANK"])
+mode = os.environ["FAIL_MODE"]
+_residual = residual
+def residual(kind, x):      # + a linear problem: every first try of an iteration is accepted, the second lambda is never reached
+    if kind == "linear":
+        return np.array([x[0] - 1.0, 2.0 * x[1] + 3.0, x[2] - x[3], x[3] - 0.5, x[0] + x[1]])
+    return _residual(kind, x)
+
+
+class FailingDevice(FakeDevice):
+    """replica 1's device raises on every try ("unreached": only lambdas the sequential search never gets to, i.e. its speculated
+    second lambda of an iteration whose first try is accepted; "reached": from the first rejected try on)"""
+    tries = 0
+    def try_lambda(self, lam, *a, **k):
+        if rank == 1 and mode == "always":
+            raise RuntimeError("injected: the step was not computed")
+        return super().try_lambda(lam, *a, **k)
+
+
+OPT.DeviceGraph = FailingDevice
+from gtsam_amd.speculative import SpeculativeLevenbergMarquardt, TorchComm
+prm = LMP.CeresDefaults(); prm.setMaxIterations(60)
+kind = os.environ["FAIL_KIND"]
+start = {"rosenbrock": [-1.2, 1.0, -0.5, 2.0], "linear": [0.5, 0.1, 0.2, 0.2]}[kind]
+pk = kind
+OPT.DeviceGraph = FakeDevice
+a = OPT.DeviceLevenbergMarquardt(FakeProblem(pk), start, prm); a.optimize()
+OPT.DeviceGraph = FailingDevice
+out = {"rejections": int(a.getInnerIterations() - a.iterations())}
+try:
+    b = SpeculativeLevenbergMarquardt(FakeProblem(pk), start, prm, comm=TorchComm()); b.optimize()
+    out["raised"] = None
+    out["same"] = bool(np.array_equal(np.array(a.trace)[:, :3], np.array(b.trace)[:, :3]) and np.array_equal(a.values_packed(), b.values_packed()))
+except RuntimeError as e:
+    out["raised"] = str(e)
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("kind", ["linear", "rosenbrock"])
+def test_a_failing_speculated_try_is_an_error_only_where_the_trajectory_reaches_it(kind):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAIL_MODE="always", FAIL_KIND=kind)
+        procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_ERR % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]          # (a rank left alone in a collective would run into this bound)
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    recs = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so, _ in outs]
+    assert (recs[0]["rejections"] == 0) == (kind == "linear")
+    if recs[0]["rejections"] == 0:
+        # replica 1 only ever speculates on lambdas behind an accepted first try: nobody raises, the trajectory is the sequential one
+        assert all(r["raised"] is None and r["same"] for r in recs), recs
+    else:
+        # the first rejection makes replica 1's try the next one in order: both ranks raise, rank 1 with its own error
+        assert all(r["raised"] for r in recs), recs
+        assert "injected" in recs[1]["raised"] and "replica 1" in recs[0]["raised"], recs

@@ -84,105 +84,6 @@ template <class F> static void run_threads(int nt, F f) {   // f(thread index) o
   if (err) std::rethrow_exception(err);
 }
 
-// ---- grouped Schur complement: its lists (context.h::SchurGroups; the layout is stated in numpy and pinned through the upload hashes in
-// tests/test_schur_groups_spec.py).  Host code over the landmark -> observation lists and the FINAL positions of the cameras; runs only
-// with GTG_SCHUR=groups.  Returns false (and leaves the pair-major kernel in charge) for a graph whose cells do not fit the kernel's
-// slot buffer or its 16-bit run lengths.
-static bool build_schur_groups(gtg_context& c, const std::vector<int64_t>& lm_ptr, const std::vector<int32_t>& lm_obs,
-                               const std::vector<int32_t>& obs_red, hipStream_t s) {
-  SchurGroups& g = c.sg;
-  const int G = kSchurGroup, nrv = c.n_red_vars;
-  const int64_t n_obs = (int64_t)lm_obs.size();
-  if (nrv == 0 || n_obs == 0 || n_obs >= ((int64_t)1 << 28) || (int64_t)((nrv + G - 1) / G) * ((nrv + G - 1) / G) >= ((int64_t)1 << 31)) return false;
-  const int NG = (nrv + G - 1) / G;
-  std::vector<int32_t> opos((size_t)n_obs), sobs((size_t)n_obs), pos_red((size_t)nrv);
-  for (int64_t o = 0; o < n_obs; o++) opos[(size_t)o] = c.h_red_pos[obs_red[(size_t)o]];
-  for (int r = 0; r < nrv; r++) pos_red[(size_t)c.h_red_pos[r]] = r;
-  struct Cell { uint32_t key; int32_t a0, b0, pq; };
-  // per landmark (host threads over contiguous landmark ranges; the result does not depend on their number: a thread's cells are
-  // appended behind those of the threads before it, i.e. in landmark order)
-  const int n_lm = (int)lm_ptr.size() - 1;
-  const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n_obs / 16384));
-  std::vector<std::vector<Cell>> part((size_t)nth);
-  std::vector<char> bad((size_t)nth, 0);
-  run_threads(nth, [&](int t) {
-    const int l0 = (int)((int64_t)n_lm * t / nth), l1 = (int)((int64_t)n_lm * (t + 1) / nth);
-    std::vector<Cell>& out = part[(size_t)t];
-    out.reserve((size_t)(lm_ptr[(size_t)l1] - lm_ptr[(size_t)l0]));
-    std::vector<std::pair<int32_t, int32_t>> runs;   // (start in the segment, length) of every group of the landmark
-    for (int l = l0; l < l1; l++) {
-      const int64_t b = lm_ptr[(size_t)l], e = lm_ptr[(size_t)l + 1];
-      std::copy(lm_obs.begin() + b, lm_obs.begin() + e, sobs.begin() + b);
-      std::stable_sort(sobs.begin() + b, sobs.begin() + e, [&](int32_t x, int32_t y) { return opos[(size_t)x] < opos[(size_t)y]; });
-      runs.clear();
-      for (int64_t i = b; i < e; i++) {
-        const int grp = opos[(size_t)sobs[(size_t)i]] / G;
-        if (runs.empty() || opos[(size_t)sobs[(size_t)(b + runs.back().first)]] / G != grp) runs.push_back({(int32_t)(i - b), 1});
-        else runs.back().second++;
-      }
-      for (size_t ia = 0; ia < runs.size(); ia++) {
-        const int ga = opos[(size_t)sobs[(size_t)(b + runs[ia].first)]] / G;
-        for (size_t ib = 0; ib <= ia; ib++) {
-          const int gb = opos[(size_t)sobs[(size_t)(b + runs[ib].first)]] / G;
-          const int p = runs[ia].second, q = runs[ib].second;
-          if (p > 0xffff || q > 0xffff || (ia == ib ? p : p + q) > kSchurChunkSlots) bad[(size_t)t] = 1;
-          out.push_back(Cell{(uint32_t)ga * (uint32_t)NG + (uint32_t)gb, (int32_t)(b + runs[ia].first), (int32_t)(b + runs[ib].first), p | (q << 16)});
-        }
-      }
-    }
-  });
-  size_t n_cells = 0;
-  for (int t = 0; t < nth; t++) { n_cells += part[(size_t)t].size(); if (bad[(size_t)t]) return false; }
-  if (n_cells == 0 || n_cells >= ((size_t)1 << 31)) return false;
-  // stable counting sort by group pair (landmark order inside a group pair): only the keys that occur get a bucket
-  std::vector<uint32_t> keys; keys.reserve(n_cells);
-  for (int t = 0; t < nth; t++) for (const Cell& x : part[(size_t)t]) keys.push_back(x.key);
-  std::vector<uint32_t> uniq;
-  const uint64_t key_space = (uint64_t)NG * (uint64_t)NG;
-  if (key_space <= ((uint64_t)1 << 24)) {   // the usual case: mark the keys that occur
-    std::vector<uint8_t> seen((size_t)key_space, 0);
-    for (uint32_t k : keys) seen[k] = 1;
-    for (size_t k = 0; k < seen.size(); k++) if (seen[k]) uniq.push_back((uint32_t)k);
-  } else {
-    uniq = keys;
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-  }
-  std::vector<int64_t> start(uniq.size() + 1, 0);
-  std::vector<uint32_t> bucket(n_cells);
-  if (key_space <= ((uint64_t)1 << 24)) {
-    std::vector<uint32_t> rank((size_t)key_space, 0);
-    for (size_t k = 0; k < uniq.size(); k++) rank[uniq[k]] = (uint32_t)k;
-    for (size_t i = 0; i < n_cells; i++) { bucket[i] = rank[keys[i]]; start[bucket[i] + 1]++; }
-  } else {
-    for (size_t i = 0; i < n_cells; i++) { bucket[i] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), keys[i]) - uniq.begin()); start[bucket[i] + 1]++; }
-  }
-  for (size_t k = 0; k < uniq.size(); k++) start[k + 1] += start[k];
-  std::vector<Cell> cells(n_cells);
-  { std::vector<int64_t> at(start.begin(), start.end() - 1);
-    size_t i = 0;
-    for (int t = 0; t < nth; t++) for (const Cell& x : part[(size_t)t]) cells[(size_t)at[bucket[i++]]++] = x; }
-  part.clear();
-  std::vector<int32_t> a0(cells.size()), b0(cells.size()), pq(cells.size());
-  std::vector<int32_t> pair_key;
-  std::vector<int64_t> pair_ptr;
-  for (size_t i = 0; i < cells.size(); i++) {
-    a0[i] = cells[i].a0; b0[i] = cells[i].b0; pq[i] = cells[i].pq;
-    if (i == 0 || cells[i].key != cells[i - 1].key) { pair_key.push_back((int32_t)cells[i].key); pair_ptr.push_back((int64_t)i); }
-  }
-  pair_ptr.push_back((int64_t)cells.size());
-  std::vector<int32_t> order(pair_key.size());
-  for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
-  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pair_ptr[(size_t)x + 1] - pair_ptr[(size_t)x] > pair_ptr[(size_t)y + 1] - pair_ptr[(size_t)y]; });
-  g.NG = NG; g.n_pairs = (int64_t)pair_key.size(); g.n_cells = (int64_t)cells.size();
-  for (int64_t i = 0; i < n_obs; i++) sobs[(size_t)i] |= (opos[(size_t)sobs[(size_t)i]] % G) << 28;   // the camera's position inside its group rides along
-  up(g.obs, sobs, s); up(g.cell_a0, a0, s); up(g.cell_b0, b0, s); up(g.cell_pq, pq, s);
-  up(g.pair_key, pair_key, s); up(g.pair_ptr, pair_ptr, s); up(g.order, order, s);
-  up(g.pos_red, pos_red, s);
-  g.active = true;
-  return true;
-}
-
 // Three 20-bit pieces of the layout hash and a 1 go through the all-reduce: the sums must be n_shards times this shard's
 // own values (every shard derived the same layout AND the communicator spans n_shards ranks).
 void verify_layout(gtg_context& c) {
@@ -611,8 +512,7 @@ void analyze(gtg_context& c) {
     // (device_ordering.hip: the same ordering position for position; GTG_HOST_ORDERING=1 keeps the host queue as the A/B).
     bool ordered_on_device = false;
     {
-      const char* oe = std::getenv("GTG_ORDERING");
-      const bool plain_rcm = !oe || std::string(oe) == "rcm";
+      const bool plain_rcm = !ord_req || std::string(ord_req) == "rcm";
       if (nd_depth == 0 && plain_rcm && kernels_can_run && c.n_shards == 1 && !std::getenv("GTG_HOST_ORDERING")) {
         std::vector<int32_t> ea, eb;
         for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } });
@@ -633,8 +533,7 @@ void analyze(gtg_context& c) {
     // above.  Both are scored by the block-level flops of the symbolic factorisation; "auto" keeps the cheaper one.  Measured on
     // the L1723 shape (cameras on a closed path: a cyclic band): RCM 136 GFLOP, minimum degree 145 GFLOP, natural order 782 --
     // the band wins there and its tiles are dense, so RCM stays the default and the 0.2 s of this search are opt-in.
-    const char* ord_env = std::getenv("GTG_ORDERING");
-    const std::string ord_mode = ord_env ? ord_env : "rcm";
+    const std::string ord_mode = ord_req ? ord_req : "rcm";
     if (parts.size() == 1 && (ord_mode == "mindegree" || ord_mode == "auto")) {
       ensure_adj();
       auto block_flops = [&](const std::vector<int32_t>& ord) {
@@ -831,8 +730,7 @@ void analyze(gtg_context& c) {
       const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
       // default schedule: the dataflow pass (chol_dataflow.hip), symbolic fill at 128-tile granularity.  GTG_CHOL=streams
       // selects the per-column launch sequence of cholesky.hip; the elimination-tree schedule only exists there.
-      const char* sched = std::getenv("GTG_CHOL");
-      c.use_df = !(sched && std::string(sched) == "streams");
+      c.use_df = dataflow_schedule_selected();
       free_df_plan(c.df);
       std::vector<int32_t> tile_part;                      // nested dissection: the part of every block column (parts are aligned to column pairs)
       if (!pair_part.empty()) { tile_part.resize(nt); for (int t = 0; t < nt; t++) tile_part[t] = pair_part[t / 2]; }
@@ -926,29 +824,6 @@ void analyze(gtg_context& c) {
     c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);
     if (c.n_pair_terms == 0) { c.pair_oa.alloc(1); c.pair_ob.alloc(1); }
   }
-
-  // ---- grouped Schur complement (GTG_SCHUR=groups; schur_groups.hip): lists from the final positions.  With the incidence lists built
-  // on the device they come back once (4 MB on the L1723 shape); a device version of this pass follows the kernel's first measurements.
-  c.sg.active = false;
-  { const char* sm = std::getenv("GTG_SCHUR");
-    if (sm && (std::string(sm) == "groups" || std::string(sm) == "groups_pipe") && c.n_shards == 1 && c.n_pairs > 0) {
-      c.sg.pipelined = std::string(sm) == "groups_pipe";
-      const char* where = std::getenv("GTG_SCHUR_LISTS");
-      if (device_terms && where && std::string(where) == "device") {
-        (void)device_schur_groups(c);
-      } else if (device_terms) {
-        std::vector<int64_t> d_ptr((size_t)c.n_lm + 1);
-        std::vector<int32_t> d_obs((size_t)c.n_obs), d_red((size_t)c.n_obs);
-        check_hip(hipMemcpyAsync(d_ptr.data(), c.lm_obs_ptr.p, sizeof(int64_t) * d_ptr.size(), hipMemcpyDeviceToHost, s), "D2H");
-        check_hip(hipMemcpyAsync(d_obs.data(), c.lm_obs.p, sizeof(int32_t) * d_obs.size(), hipMemcpyDeviceToHost, s), "D2H");
-        check_hip(hipMemcpyAsync(d_red.data(), c.obs_red.p, sizeof(int32_t) * d_red.size(), hipMemcpyDeviceToHost, s), "D2H");
-        check_hip(hipStreamSynchronize(s), "sync");
-        (void)build_schur_groups(c, d_ptr, d_obs, d_red, s);
-      } else {
-        (void)build_schur_groups(c, lm_obs_ptr, lm_obs, obs_red, s);
-      }
-      clk.lap("grouped schur lists (GTG_SCHUR=groups)");
-    } }
 
   // ---- numeric buffers --------------------------------------------------------------------------
   const size_t NP = c.NP;

@@ -273,7 +273,6 @@ int gtg_destroy(gtg_handle c) {
   DevBuf<int64_t>* i64[] = {&c->val_off, &c->dim_off, &c->red_off, &c->noise_off, &f.prior_off, &c->lm_obs_ptr,
                             &c->lm_pri_ptr, &c->red_inc_ptr, &c->hoff_ptr, &c->pair_ptr, &c->smart_ptr, &c->pad_index};
   for (auto* b : i64) b->free();
-  { SchurGroups& g = c->sg; for (DevBuf<int32_t>* b : {&g.obs, &g.cell_a0, &g.cell_b0, &g.cell_pq, &g.pair_key, &g.order, &g.pos_red}) b->free(); g.pair_ptr.free(); }
   c->smart_params.free(); c->smart_cache_pose.free(); c->smart_cache_point.free();
   c->chol_epoch_dev.free(); c->layout_probe.free(); c->xb_row_off.free(); c->xb_col_off.free(); c->xb_dim.free();
   free_df_plan(c->df);
@@ -623,14 +622,15 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   // updates are summed in another order: the same numbers to rounding).  The reduced system is assembled again each time, because
   // the factorisation works in place.
   // Sharded: the scalars are summed over the shards by read_scalars, so every shard sees the time-out of any shard and all repeat.
-  for (int attempt = 0; attempt < 3; attempt++) {
+  // (GTG_CHOL=streams: there is no other schedule to fall back to -- one repeat, then the error)
+  const int max_attempts = c->use_df ? 3 : 2;
+  for (int attempt = 0; attempt < max_attempts; attempt++) {
     const bool df = c->use_df && attempt != 2;
     check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
     { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
     { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
     if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
-      static const bool by_tiles = std::getenv("GTG_EXCHANGE_TILES") != nullptr;   // whole 128x128 tiles (the first version) instead of blocks
-      if (by_tiles || c->n_xb == 0) {
+      if (c->n_xb == 0) {     // (no block list: whole stored 128x128 tiles, the first version of the exchange)
         const int64_t nb = c->plan.n_exch * kTile * kTile;
         if ((int64_t)c->xbuf.n != nb) c->xbuf.alloc(nb);
         launch_pack_tiles(*c, smat(*c), c->plan, c->xbuf.p, false);
@@ -664,7 +664,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
       launch_smart_triangulate(*c, c->trial.p, gate, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, gate); }
     read_scalars(*c);
     if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
-    if (attempt < 2 && c->h_scalars[SC_TIMEOUT] != 0.0) {
+    if (attempt + 1 < max_attempts && c->h_scalars[SC_TIMEOUT] != 0.0) {
       static const bool quiet = std::getenv("GTG_QUIET") != nullptr;
       if (!quiet) {
         // post-mortem: which wait gave up (chol_dataflow.hip::wait_flags records the first one of a dataflow pass), what it saw, and
@@ -1003,8 +1003,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   build_chol_plan(plan, nt, nullptr, c->stream);   // dense: every lower tile + the rhs row has a slot
   DevBuf<double> S, Dinv, x, fail;
   DfPlan df;
-  const char* sched = std::getenv("GTG_CHOL");
-  const bool use_df = !(sched && std::string(sched) == "streams");
+  const bool use_df = dataflow_schedule_selected();
   if (use_df) build_df_plan(df, nt, nullptr, c->stream, plan.h_slot, plan.n_stored);   // (before S: the plan may want scratch slots behind the tiles)
   S.alloc((size_t)(plan.n_stored + df.n_scratch) * kTileDoubles); Dinv.alloc((size_t)nt * kTile * kTile); x.alloc(2 * (size_t)NP); fail.alloc(2);
   check_hip(hipMemset(Dinv.p, 0, sizeof(double) * Dinv.n), "memset");

@@ -573,8 +573,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, S);
-  if (c.sg.active) launch_schur_groups(c, S);           // GTG_SCHUR=groups (schur_groups.hip)
-  else if (c.n_pairs && c.n_pair_terms > 512 * c.n_pairs)   // few pairs, thousands of terms each
+  if (c.n_pairs && c.n_pair_terms > 512 * c.n_pairs)   // few pairs, thousands of terms each
     hipLaunchKernelGGL(k_schur_pairs_heavy, dim3((unsigned)c.n_pairs), dim3(64 * kPairWaves), 0, c.stream, c.n_pairs, c.pair_row.p,
                        c.pair_col.p, c.pair_ptr.p, c.pair_oa.p, c.pair_ob.p, c.red_dim.p, c.red_off.p, c.E.p, S);
   else if (c.n_pairs)

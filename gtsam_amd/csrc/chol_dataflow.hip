@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <map>
 #include <mutex>
 #include <set>
@@ -73,7 +74,7 @@ constexpr int kHandoffAux = 16;   // cache-policy bits of the LDS-DMA that reads
 //     kernel and of the partial tiles are relaxed agent-scope atomic loads.  sc1 stores + drained flag on the producer side and
 //     sc1 loads on the consumer side is one of the two valid forms of the hand-off on this target (MI355X_MICROARCH.md,
 //     "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md Guideline 16 R1); the other one --
-//     one agent-scope acquire after a matched flag, then plain loads -- is what -DGTG_DF_SAFE=1 adds on top.
+//     one agent-scope acquire after a matched flag, then plain loads -- was built and measured as an A/B in round 4 (bit-identical).
 // Rounds 1-3 read the data with PLAIN loads and no acquire ("nobody can hold a stale copy of a tile that is written once"): an
 // argument about this schedule, not about the memory model, and the verdict of round 3 was right to reject it.
 // -DGTG_DF_FENCES=1 builds the textbook release / acquire protocol for comparison.
@@ -121,32 +122,16 @@ __device__ __forceinline__ long long ld_flag_rmw(const long long* p) {
   const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
   return ((long long)hi << 32) | (unsigned)lo;
 }
-// GTG_DF_SAFE (A/B builds, `make safe`): bit 0 -- additionally ONE agent-scope acquire (buffer_inv sc1) after a flag matched (the
-// guide's other valid consumer form); bit 1 -- the flag itself read by a returning read-modify-write atomic instead of an sc1 load;
-// bit 2 -- round 3's "finding 3" experiment (an acquire every 256 polls and at every task start), kept to show that with the
-// producer-side drain in place it no longer changes any result
-#ifndef GTG_DF_SAFE
-#define GTG_DF_SAFE 0
-#endif
 __device__ __forceinline__ void acquired() {
-#if GTG_DF_FENCES || (GTG_DF_SAFE & 1)
+#if GTG_DF_FENCES
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
   asm volatile("" ::: "memory");
 #endif
 }
-__device__ __forceinline__ long long ld_flag(const long long* p) {
-#if (GTG_DF_SAFE & 2)
-  // wave-uniform address: one lane asks, the value is broadcast
-  long long v = 0;
-  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
-    v = __hip_atomic_fetch_or(const_cast<long long*>(p), 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-  return ((long long)hi << 32) | (unsigned)lo;
-#else
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
+// (polling EVERY flag with a returning read-modify-write atomic instead was measured in round 5: + 1.5 % on the L1723 factorisation --
+// a slower poll than an sc1 load; profiles/r05a_variants_ab.txt.  The RMW poll stays what a wait falls back to after 512 misses.)
+__device__ __forceinline__ long long ld_flag(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool timed_out(const double* fail) {
   return __hip_atomic_load(reinterpret_cast<const long long*>(fail + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
@@ -161,9 +146,6 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
     if ((++spins & 255) == 0) {
       if (timed_out(fail)) break;
       if (spins == 256) t0 = wall_clock64();
-#if (GTG_DF_SAFE & 4)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // experiment of round 3 ("finding 3"): an acquire every 256 polls ...
-#endif
       if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
         if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
         break;
@@ -194,9 +176,6 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
 __device__ __forceinline__ int tile_progress(const long long* f1, const long long* f2, long long flagbase) {
   const long long a = ld_flag(f1) - flagbase, b = ld_flag(f2) - flagbase;
   const long long m = a < b ? a : b;
-#if (GTG_DF_SAFE & 1)
-  acquired();
-#endif
   return __builtin_amdgcn_readfirstlane((int)(m < 0 ? 0 : m));
 }
 __device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail, long long sh,
@@ -244,9 +223,6 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   double* W = reinterpret_cast<double*>(smem_raw) + rt * (16 * PX);
   double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
   long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
-#if (GTG_DF_SAFE & 1)
-  acquired();
-#endif
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     if (pf < flagbase + q + 1) {
@@ -510,9 +486,6 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-#if (GTG_DF_SAFE & 4)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ... and at the start of every task
-#endif
     run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
@@ -553,27 +526,19 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     __syncthreads();
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
-    const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1), [3 J + 2]: of (J, J-2) (-1: not stored / not streamed)
+    const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1) (-1: not stored)
     double* tile = S + (int64_t)dslot * TT;
-#if GT_DF_DEFER_SLICE
     bool deferred = false;
-#endif
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
-    // The updates of the two block columns right before this tile are applied HERE, in 32-column slices as the substitutions of the
-    // tiles (J, J-2) and (J, J-1) publish them: first column J-2's (its tile becomes final while the partner workgroup is still
-    // factoring tile J-1: this workgroup would be idle), then column J-1's (the last slice is the only thing left when that tile is
-    // final).  Column J-2 used to be the last step of PD(J), whose operand is final only ~30 us before PD(J) is needed: on a sixth of
-    // the columns PD(J) came 12 - 30 us late and the whole period stretched from 40 to 60 - 76 us (round 4 trace).  PD(J)'s
-    // youngest operand is column J-3 now: a whole period of slack.
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-      const int sslot = chain_slots[3 * J + 2 - pass];
-      if (sslot < 0) continue;
-      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-2), then tile (J, J-1)
+    // The update of the block column right before this tile is applied HERE, in 32-column slices as the substitution of tile (J, J-1)
+    // publishes them (the last slice is the only thing left when that tile is final).
+    const int sslot = chain_slots[3 * J + 1];
+    if (sslot >= 0) {
+      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 2 + pass, q);
+        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
@@ -597,30 +562,25 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
           }
         }
         __syncthreads();
-#if GT_DF_DEFER_SLICE
-        if (pass == 1 && q == 3) {
+        if (q == 3) {
           // The LAST slice is on the serial chain of the factorisation (the tile left of this one became final a moment ago): only its
           // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- is applied here (2 rounds of MFMA
-          // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4:
-          // 5.12 -> 5.07 ms on L1723 (profiles/r04_df_defer_ab.txt).
+          // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4
+          // (5.12 -> 5.07 ms on L1723, profiles/r04_df_defer_ab.txt) and again in round 5 (profiles/r05a_variants_ab.txt).
           for (int t = wave; t < 16; t += 8) slice_task(A, X, t >> 2, 0, (t >> 1) & 1, t & 1, lr, lk);
           deferred = true;
-        } else
-#endif
-        for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
-          const int blk = t >> 2;
-          int ib = 0, rem = blk;
-          while (rem > ib) { rem -= ib + 1; ib++; }
-          slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
+        } else {
+          for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
+            const int blk = t >> 2;
+            int ib = 0, rem = blk;
+            while (rem > ib) { rem -= ib + 1; ib++; }
+            slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
+          }
         }
       }
     }
-#if GT_DF_DEFER_SLICE
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
                deferred ? X : nullptr);
-#else
-    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp);
-#endif
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
@@ -733,7 +693,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     if (tree) {
       // (round 4: 8 slots = 16 reserved CUs by default -- with the accumulator lanes of the separators' diagonal tiles in place the leaf
       // chains are the critical path of a pose graph, and they run side by side; up to 16 slots = 32 reserved CUs on request)
-      static const int max_slots = std::max(1, std::min(16, getenv("GTG_DF_SLOTS") ? atoi(getenv("GTG_DF_SLOTS")) : 8));
+      constexpr int max_slots = 8;   // (4 and 16 measured in round 4: no better)
       std::vector<int> first_child(nparts, -1);
       for (int x = nparts - 1; x >= 0; x--) if ((*part_parent)[x] >= 0) first_child[(*part_parent)[x]] = x;
       int leaves = 0;
@@ -770,8 +730,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // kFinal steps + the substitution) sits in the tile's column and streams behind the columns before it.
   // (kPiece, kFinal) swept on the L1723 shape in round 4 (Cholesky ms): (6,3) 5.17, (4,4) 5.09, (6,4) 5.10, (4,5) 5.11, (3,4) 5.14,
   // (4,3) 5.15, (4,6) 5.16, (8,3) 5.32, (2,4) 5.32, (6,2) 5.48, (10,3) 5.51.
-  static const int kPiece = std::max(2, getenv("GTG_DF_PIECE") ? atoi(getenv("GTG_DF_PIECE")) : 4);
-  static const int kFinal = std::max(1, getenv("GTG_DF_FINAL") ? atoi(getenv("GTG_DF_FINAL")) : 4);
+  constexpr int kPiece = 4, kFinal = 4;
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
   auto emit = [&](int I, int J, std::vector<int32_t>& ks) {
@@ -797,14 +756,11 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   std::vector<int32_t> has_sub(nt, 0);
   for (int J = 0; J < nt; J++) {
     // the contribution of block column J-1 to the diagonal tile is applied by k_df_chain itself (streamed): not in PD's list
-    // ... and, with ONE chain, so is the contribution of block column J-2 (bit 1; see chain_loop).  With several chains (parts of a
-    // nested dissection) the columns are taken in an interleaved order and J-2 need not be this chain's previous-but-one tile.
     ks = rowcols[J];
     if (!ks.empty() && ks.back() == J - 1) { ks.pop_back(); has_sub[J] = 1; }
-    // (measured, round 4: PD(J) is never late any more -- the p90 of the chain period falls from 59 to 54 us -- but the chain workgroup's
-    // extra 16 us of slices push the MEDIAN period from 40.0 to 41.6 us: 5.25 -> 5.49 ms on L1723.  Off by default; GTG_DF_STREAM2=1.)
-    static const bool stream2 = getenv("GTG_DF_STREAM2") && atoi(getenv("GTG_DF_STREAM2")) != 0;
-    if (stream2 && !tree && has_sub[J] && !ks.empty() && ks.back() == J - 2) { ks.pop_back(); has_sub[J] |= 2; }
+    // (also streaming column J-2's contribution in the chain workgroup was measured in round 4: PD(J) is never late then -- the p90 of
+    // the chain period falls from 59 to 54 us -- but the extra 16 us of slices push the MEDIAN period from 40.0 to 41.6 us: 5.25 ->
+    // 5.49 ms on L1723.  Removed.)
     emit(J, J, ks);
     flops += t3 / 3.0 + (double)rowcols[J].size() * t3; stored++;
     for (int I = J + 1; I < nt; I++) {
@@ -829,11 +785,11 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // ~100 us: behind it PD(J) was taken 12 - 30 us too late on every sixth column of the L1723 shape and the chain period stretched
   // from 40 to 60 - 76 us (round 4 trace: 19 of 121 periods, 0.4 ms of 5.2).  Taken early the two tasks just hold two of the 248
   // workgroups a period longer.
-  // (GTG_DF_PULL = number of tiles below the diagonal tile that are pulled with it: the tiles (J+1..J+w, J) are the operands of the
-  // next columns' critical tasks; 0 switches the pulling off)
-  static const int pull_rows = tree ? -1 : (getenv("GTG_DF_PULL") ? atoi(getenv("GTG_DF_PULL")) - 1 : 1);
+  // (pulled with the diagonal tile: the ONE tile below it; measured on L1723 in round 4: 0 rows below 5.17 ms, 1 row 5.17, 3 rows 5.19; no
+  // pulling at all 5.30)
+  const int pull_rows = tree ? -1 : 1;
   const bool pull = pull_rows >= 0;
-  auto critical = [&](const Rec& t, int c) { return t.J == c && t.I >= c && t.I <= c + pull_rows && t.I < nt; };   // (measured on L1723: 1 row 5.17 ms, 2 rows 5.17, 4 rows 5.19; off 5.30)
+  auto critical = [&](const Rec& t, int c) { return t.J == c && t.I >= c && t.I <= c + pull_rows && t.I < nt; };
   std::vector<char> pulled(nt + 1, 0);
   for (int q = 0; q < nt; q++) {
     for (const Rec& t : finals[q]) { if (pulled[q] && critical(t, q)) continue; put1(t); }
@@ -868,8 +824,8 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   };
   {
     // accumulator lanes of the tiles with very long contraction lists (run_task): G - 1 scratch slots each, behind the stored tiles
-    static const int lane_min = std::max(2, getenv("GTG_DF_LANE_MIN") ? atoi(getenv("GTG_DF_LANE_MIN")) : 8);   // early pieces from which a tile gets lanes
-    static const int lane_max = std::max(1, std::min(16, getenv("GTG_DF_LANES") ? atoi(getenv("GTG_DF_LANES")) : 8));
+    constexpr int lane_min = 8;   // early pieces from which a tile gets lanes
+    constexpr int lane_max = 8;
     std::map<int32_t, std::pair<int32_t, int32_t>> lanes;   // slot of the tile -> (G, first scratch slot)
     df.n_scratch = 0;
     for (int64_t t = 0; t < df.n_tasks; t++) {
@@ -900,8 +856,8 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
     std::vector<int32_t> cs(3 * (size_t)nt, -1);
-    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); if (has_sub[J] & 2) cs[3 * J + 2] = slot_of(J, J - 2); }
-    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slots of (J, J-1) / (J, J-2) or -1)
+    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, one spare word)
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
@@ -920,6 +876,13 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
 void free_df_plan(DfPlan& df) {
   df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.part_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
   df.chain_off.free(); df.chain_tiles.free();
+}
+
+// GTG_CHOL=streams selects the per-column launch sequence of cholesky.hip instead of the dataflow pass (the A/B of the tests; read per
+// call: a test switches it inside one process)
+bool dataflow_schedule_selected() {
+  const char* sched = getenv("GTG_CHOL");
+  return !(sched && std::string(sched) == "streams");
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
@@ -993,8 +956,9 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   // test hook (tests/test_gpu_dataflow_protocol.py): GTG_DF_TEST_TIMEOUT=n leaves the chain kernel out of the process's n-th dataflow
   // factorisation -- the bulk kernel's waits then run into their bound, exactly what a chain kernel that was never placed looks like
   // ("n:m": out of m consecutive ones from the n-th on -- two in a row make the repeated try time out as well)
-  static const int drop_at = getenv("GTG_DF_TEST_TIMEOUT") ? atoi(getenv("GTG_DF_TEST_TIMEOUT")) : 0;
-  static const int drop_n = (getenv("GTG_DF_TEST_TIMEOUT") && strchr(getenv("GTG_DF_TEST_TIMEOUT"), ':')) ? atoi(strchr(getenv("GTG_DF_TEST_TIMEOUT"), ':') + 1) : 1;
+  static const char* const drop_env = getenv("GTG_DF_TEST_TIMEOUT");
+  static const int drop_at = drop_env ? atoi(drop_env) : 0;
+  static const int drop_n = (drop_env && strchr(drop_env, ':')) ? atoi(strchr(drop_env, ':') + 1) : 1;
   static std::atomic<int> launches{0};
   const int launch_no = ++launches;
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
@@ -1007,13 +971,13 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
-  // with it (L1723, interleaved A/B on fresh boxes: 5.28-5.32 ms against 5.38-5.39 ms; GTG_DF_EXTRA=0 switches it off): the
+  // with it (L1723, interleaved A/B on fresh boxes: 5.28-5.32 ms against 5.38-5.39 ms): the
   // end of a stream is observed sooner behind a short kernel than directly behind a persistent one (an empty kernel behind the
   // bulk kernel instead has the same effect: 5.28 ms).  It must not
   // start earlier: a third persistent kernel beside the chain on the reserved CUs (tried: its own stream with the chain's
   // mask) starved the chain -- wait bounds hit.
-  static const int extra = getenv("GTG_DF_EXTRA") ? atoi(getenv("GTG_DF_EXTRA")) : 6;
-  if (extra > 0 && df.n_tasks > grid)
+  constexpr int extra = 6;
+  if (df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
                        df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");

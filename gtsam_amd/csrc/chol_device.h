@@ -15,25 +15,6 @@
                                    // wavefront complete in program order), a rendezvous of the wavefront's threads in the host emulation
 #endif
 
-// GT_POTRF_WINDOW=1 (not the default; libgtsam_amd_window.so): the pivot chain wavefront keeps an 8-column WINDOW of the diagonal block
-// instead of all 32 columns and a HELPER wavefront applies the pivots to the columns beyond it (stage_potrf / stage_helper below).
-#ifndef GT_POTRF_WINDOW
-#define GT_POTRF_WINDOW 0
-#endif
-// GT_DF_DEFER_SLICE=1 (libgtsam_amd_defer.so: chol_dataflow.hip only, so that the stream schedule's kernels stay those of the product
-// library): the chain kernel applies the last slice of the tile left of a diagonal tile only to the blocks panel 0 reads and leaves
-// the rest to the two wavefronts that idle during panel 0 (potrf_body, Xdef).  Built and measured in round 4 (- 1.1 %, bit-identical),
-// taken out again with the round's last session (profiles/r04_streams_tree_hang.txt).
-#ifndef GT_DF_DEFER_SLICE
-#define GT_DF_DEFER_SLICE 0
-#endif
-#if GT_DF_DEFER_SLICE && GT_POTRF_WINDOW
-#error "the deferred slice uses wavefront 6 in panel 0, which is the windowed chain's helper"
-#endif
-#ifndef GT_POTRF_OWN_LDS
-#define GT_POTRF_OWN_LDS 0     // windowed variant only: 1 = the lane's own entry of the next column is read back from LDS as in the default body
-#endif
-
 namespace gt {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -151,9 +132,8 @@ __device__ __forceinline__ double rcp_nr(double p) {
 // free (selects, trash address for the non-owner half) so that the scheduler can overlap the chain with the updates.
 constexpr int kLineTrash = SB * SB;   // doubles: lines[32][32], then 64 trash slots
 // LDS of the diagonal-tile body in doubles: the 10 packed sub-blocks, 1/pivot [T], 1/sqrt(pivot) [T], the published columns + trash, two
-// progress words; windowed variant: + the hand-over buffer of a window (4 values per lane of the helper) and the helper's progress word
-constexpr int kHandDoubles = GT_POTRF_WINDOW ? 4 * 64 + 2 : 0;
-constexpr int kPotrfSmemDoubles = 10 * SB * PB + 2 * T + SB * SB + 64 + 2 + kHandDoubles;
+// progress words
+constexpr int kPotrfSmemDoubles = 10 * SB * PB + 2 * T + SB * SB + 64 + 2;
 // explicit LDS pointers for the volatile accesses (address-space inference leaves volatile accesses as flat_*)
 typedef GT_LDS_VOLATILE(double) lds_vdouble_p;
 typedef GT_LDS_VOLATILE(int) lds_vint_p;
@@ -207,137 +187,10 @@ struct PotrfStep<SB> {
                                              int, int, int, int) {}
 };
 
-#if GT_POTRF_WINDOW
-// ---- windowed pivot chain (GT_POTRF_WINDOW=1) --------------------------------------------------------------------------------------
-// A step of PotrfStep is bound by instruction issue (~300 cycles: up to 16 FMAs and 8 LDS reads beside the ~90-cycle dependency chain
-// pivot -> 1/pivot -> next column).  Here the chain wavefront keeps only a WINDOW of 8 columns of the diagonal block (aw[k] =
-// A[i][Wb + 2 k + h], k = 0..3) and a HELPER wavefront on another SIMD, which holds all 32 columns in the old layout, applies every
-// published pivot to the columns BEYOND the window (HelperStep: the same u = own / pivot, the same products, so every entry sees the
-// same operations in the same order as in PotrfStep: bit-identical).  At the last pivot J = Wb + 7 of a window the chain wavefront stores
-// the finished window (unscaled; store_column applies 1/sqrt(pivot)), takes the next window from the helper -- which has applied the
-// pivots 0 .. J-1 to it and handed it over through LDS right after pivot J-1 was published, a whole chain step earlier -- and applies
-// pivot J to it itself.  Per step the chain wavefront issues <= 3 update FMAs and <= 4 LDS reads.
-constexpr int WIN = 8;
-
-template <int J>
-struct PotrfStepW {
-  static __device__ __forceinline__ void run(double (&aw)[4], const double (&cj)[4], const double (&cjn)[4], double own, double* blk_row,
-                                             double* lines, lds_vdouble_p rinvs, lds_vint_p prog, int progbase, const double* hand,
-                                             lds_vint_p hprog, int hbase, int lane, int i, int h) {
-    constexpr int Wb = J & ~(WIN - 1), l = J - Wb, hJ = J & 1, kJ = l >> 1;
-    constexpr bool sw = (l == WIN - 1) && (J + 1 < SB);   // last pivot of its window: column J+1 comes from the helper
-    const double piv = readlane_f64(aw[kJ], J + 32 * hJ);
-    const double rinv = rcp_nr(piv);
-    double cn[4] = {0.0, 0.0, 0.0, 0.0}, cnn[4] = {0.0, 0.0, 0.0, 0.0}, ownN = 0.0;
-    if constexpr (J + 1 < SB) {
-      constexpr int hN = (J + 1) & 1;
-      constexpr int kN = sw ? 0 : (l + 1) >> 1;
-      constexpr int Wn = sw ? Wb + WIN : Wb;              // the window of column J+1
-      const double s1 = readlane_f64(aw[kJ], J + 1 + 32 * hJ);   // A[J+1][J]
-      if constexpr (sw) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) blk_row[Wb + 2 * k + h] = aw[k];
-        while (*hprog < hbase + Wn / WIN) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-        for (int k = 0; k < 4; k++) aw[k] = hand[64 * k + lane];
-      }
-      aw[kN] = __builtin_fma(-((h == hN) ? own * s1 : 0.0), rinv, aw[kN]);
-      double* line = lines + (J + 1) * SB;
-      const int pos = 16 * (i & 1) + (i >> 1);
-      *(lds_vdouble_p)((h == hN) ? line + pos : lines + kLineTrash + lane) = aw[kN];
-      GT_WAVE_SYNC();
-      // line J+1 for the columns that are live at step J+1: its window's and, when J+1 is the last pivot of that window, the next one's
-#pragma unroll
-      for (int k = kN; k < 4; k++) cn[k] = line[16 * h + Wn / 2 + k];
-      constexpr bool next_sw = (J + 1 - Wn == WIN - 1) && (J + 2 < SB);
-      if constexpr (next_sw) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) cnn[k] = line[16 * h + (Wn + WIN) / 2 + k];
-      }
-      // A[i][J+1] of this lane's row: out of the owner half's register by v_permlane32_swap instead of back out of LDS -- the
-      // multiplier of the NEXT step's chain no longer waits for an LDS write + read round trip
-#if GT_POTRF_OWN_LDS
-      ownN = line[pos];                       // (the A/B: as PotrfStep does it)
-#else
-      ownN = half_bcast<hN>(aw[kN]);
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const double u = own * rinv;
-    if constexpr (!sw) {
-      if constexpr ((J & 1) == 1 && kJ + 1 < 4)   // J odd: the odd half's aw[kJ+1] is column J+2
-        aw[kJ + 1] = __builtin_fma(-((h == 1) ? u : 0.0), cj[kJ + 1], aw[kJ + 1]);
-      constexpr int c0 = (J & 1) ? kJ + 2 : kJ + 1;
-#pragma unroll
-      for (int k = c0; k < 4; k++) aw[k] = __builtin_fma(-u, cj[k], aw[k]);
-    } else {
-      // pivot J on the NEW window: column J+2 is the odd half's aw[0], the columns behind it in both halves
-      aw[0] = __builtin_fma(-((h == 1) ? u : 0.0), cjn[0], aw[0]);
-#pragma unroll
-      for (int k = 1; k < 4; k++) aw[k] = __builtin_fma(-u, cjn[k], aw[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) GT_PIN(aw[k]);
-    rinvs[J] = rinv;
-    *prog = progbase + J + 1;         // every pivot: the helper follows pivot by pivot (the followers look at multiples of 4)
-    PotrfStepW<J + 1>::run(aw, cn, cnn, ownN, blk_row, lines, rinvs, prog, progbase, hand, hprog, hbase, lane, i, h);
-  }
-};
-template <>
-struct PotrfStepW<SB> {
-  static __device__ __forceinline__ void run(double (&)[4], const double (&)[4], const double (&)[4], double, double*, double*, lds_vdouble_p,
-                                             lds_vint_p, int, const double*, lds_vint_p, int, int, int, int) {}
-};
-
-template <int J>
-struct HelperStep {
-  static __device__ __forceinline__ void run(double (&ah)[16], const double* lines, const double* rinvs, lds_vint_p prog, int progbase,
-                                             double* hand, lds_vint_p hprog, int hbase, int lane, int i, int h) {
-    constexpr int Wb = J & ~(WIN - 1), l = J - Wb;
-    constexpr int lo = (l == WIN - 1) ? Wb + 2 * WIN : Wb + WIN;   // first column this pivot is applied to HERE (the last pivot of a
-                                                                  // window is applied to the next window by the chain wavefront itself)
-    if constexpr (lo < SB) {
-      while (*prog < progbase + J + 1) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const double* line = lines + J * SB;
-      const double own = line[16 * (i & 1) + (i >> 1)];
-      const double u = own * rinvs[J];
-#pragma unroll
-      for (int cl = lo / 2; cl < 16; cl++) ah[cl] = __builtin_fma(-u, line[16 * h + cl], ah[cl]);
-#pragma unroll
-      for (int cl = lo / 2; cl < 16; cl++) GT_PIN(ah[cl]);
-    }
-    if constexpr (l == WIN - 2 && Wb + WIN < SB) {   // the pivots 0 .. J are in: the next window goes to the chain wavefront
-#pragma unroll
-      for (int k = 0; k < 4; k++) hand[64 * k + lane] = ah[(Wb + WIN) / 2 + k];
-      GT_WAVE_SYNC();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      *hprog = hbase + (Wb + WIN) / WIN;
-    }
-    HelperStep<J + 1>::run(ah, lines, rinvs, prog, progbase, hand, hprog, hbase, lane, i, h);
-  }
-};
-template <>
-struct HelperStep<SB> {
-  static __device__ __forceinline__ void run(double (&)[16], const double*, const double*, lds_vint_p, int, double*, lds_vint_p, int, int, int, int) {}
-};
-
-// the helper of the diagonal sub-block jb (its own wavefront, on another SIMD than the chain wavefront)
-__device__ __forceinline__ void stage_helper(const double* A, const double* lines, const double* rinvs, int* prog, double* hand, int* hprog,
-                                             int jb, int lane) {
-  const int i = lane & 31, h = lane >> 5;
-  const double* row = A + boff(jb, jb) + i * PB;
-  // the chain wavefront waits for this wavefront at every window boundary: it wins issue arbitration against the follower / deferred
-  // wavefront it shares its SIMD with
-  __builtin_amdgcn_s_setprio(3);
-  double ah[16];
-#pragma unroll
-  for (int cl = 0; cl < 16; cl++) ah[cl] = row[2 * cl + h];
-  HelperStep<0>::run(ah, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, hand, (lds_vint_p)hprog, 4 * jb, lane, i, h);
-  __builtin_amdgcn_s_setprio(2);
-}
-#endif   // GT_POTRF_WINDOW
+// (A WINDOWED pivot chain -- the chain wavefront keeps 8 columns, a helper wavefront on another SIMD applies every pivot to the columns
+// beyond the window and hands the next window over through LDS -- was built at the end of round 4 (29.5 instead of 34 instructions per
+// step, no spills, bit-identical) and measured in round 5: 5.24 - 5.27 ms against 5.12 - 5.14 on the L1723 factorisation; the three
+// hand-overs per panel cost more than the shorter steps save.  Removed; profiles/r05a_variants_ab.txt.)
 
 // The columns stay UNSCALED through the elimination (only 1/pivot is on the chain).  At the end of a panel the chain
 // wavefront computes the 32 values r_c = 1/sqrt(pivot_c) = sqrt(1/pivot_c) in parallel (lane c), publishes them in
@@ -354,7 +207,7 @@ __device__ __forceinline__ void scale_columns(double (&a)[16], const double* rs,
 // of R(c,c) is > -12; 0 -- no test (inside a variable, padding).  prev_exp carries the exponent of the pivot before this panel.
 __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __restrict__ rinvs, double* __restrict__ rs,
                                             double* __restrict__ lines, int* prog, int jb, int lane, double* fail,
-                                            const unsigned char* __restrict__ pk, int& prev_exp, double* hand = nullptr, int* hprog = nullptr) {
+                                            const unsigned char* __restrict__ pk, int& prev_exp) {
   const int i = lane & 31, h = lane >> 5;
   double* row = A + boff(jb, jb) + i * PB;
   // the pivot kinds of this panel's columns (rank test below): requested NOW, so that the global load's latency lies under the 32 pivots
@@ -362,27 +215,6 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
   // on the wavefront everybody waits for; the scheduling barriers inside the steps keep the load up here)
   unsigned kind = 0;
   if (pk) kind = pk[SB * jb + i];
-#if GT_POTRF_WINDOW
-  double aw[4], c0[4];
-  const double cz[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k = 0; k < 4; k++) aw[k] = row[2 * k + h];          // window 0
-  const int pos = 16 * (i & 1) + (i >> 1);
-  *(lds_vdouble_p)((h == 0) ? lines + pos : lines + kLineTrash + lane) = aw[0];
-  GT_WAVE_SYNC();
-#pragma unroll
-  for (int k = 0; k < 4; k++) c0[k] = lines[16 * h + k];
-  const double own0 = lines[pos];
-  PotrfStepW<0>::run(aw, c0, cz, own0, row, lines, (lds_vdouble_p)(rinvs + SB * jb), (lds_vint_p)prog, SB * jb, hand, (lds_vint_p)hprog, 4 * jb, lane, i, h);
-#pragma unroll
-  for (int k = 0; k < 4; k++) row[SB - WIN + 2 * k + h] = aw[k];   // the last window; the block stays UNSCALED in LDS (store_column scales)
-  GT_WAVE_SYNC();
-  const double rv = rinvs[SB * jb + i];
-  if (__builtin_amdgcn_ballot_w64(!(rv > 0.0 && rv < __builtin_inf())) != 0 && lane == 0) *fail = 1.0;
-  *(lds_vdouble_p)(rs + SB * jb + pos) = rv * rsqrt_nr(rv);
-  GT_WAVE_SYNC();
-  *(lds_vint_p)(prog + 1) = jb + 1;
-#else
   double a[16], c0[16];
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) a[cl] = row[2 * cl + h];
@@ -403,7 +235,6 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
   scale_columns(a, rs + SB * jb, h);
 #pragma unroll
   for (int cl = 0; cl < 16; cl++) row[2 * cl + h] = (2 * cl + h <= i) ? a[cl] : 0.0;
-#endif
   if (pk) {   // off the pivot chain: the panel is out, the followers are running
     const double Rii = rsqrt_nr(rv);   // sqrt(pivot) = the diagonal entry of the factor
     const int ex = (int)((__double_as_longlong(Rii) >> 52) & 0x7ff) - 1022;   // frexp exponent
@@ -496,19 +327,13 @@ __device__ __forceinline__ void tile_task(double* A, int jb, int ib, int cb, int
 
 // write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
 // strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
-// (rsd: windowed variant only -- the diagonal sub-block is still unscaled in LDS; its column c takes the factor rsd[16 (c & 1) + c / 2],
-// the 1/sqrt(pivot) values of the panel in (parity, index) order, here: the same product the chain wavefront formed before)
-__device__ __forceinline__ void store_column(const double* A, double* tile, double* Xinv, int jb, int t, int nthreads, bool wt = false,
-                                             const double* rsd = nullptr) {
+__device__ __forceinline__ void store_column(const double* A, double* tile, double* Xinv, int jb, int t, int nthreads, bool wt = false) {
   for (int e = t; e < (4 - jb) * 512; e += nthreads) {
     const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
     const double* sp = A + boff(ib, jb) + r * PB + c;
     double2 v;
     v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
     v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
-#if GT_POTRF_WINDOW
-    if (ib == jb && rsd) { v.x *= rsd[c >> 1]; v.y *= rsd[16 + (c >> 1)]; }
-#endif
     *reinterpret_cast<double2*>(tile + (SB * ib + r) * T + SB * jb + c) = v;   // (the tile itself is read by later kernels only)
     if (ib != jb) {
       double* o = Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c);
@@ -577,7 +402,8 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
                                            const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr,
                                            const double* Xdef = nullptr) {
-  // (Xdef: GT_DF_DEFER_SLICE only -- the last 32-column slice of the tile left of this one, in LDS; see chain_loop)
+  // (Xdef: the dataflow chain kernel only -- the last 32-column slice of the tile left of this one, in LDS, of which the blocks (ib, cb),
+  // cb >= 1, are still to be applied; see chain_loop.  nullptr: nothing deferred)
   const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
   // (host-counted): a word in device memory that every factorisation rewrites was read one factorisation stale by one of two
   // co-operating kernels under multi-handle contention (rate ~1e-3; tools/df_contention_diag.py, profiles/r03_df_contention.txt)
@@ -586,19 +412,12 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
   double* lines = rs + T;                             // [SB][SB] published columns of the current panel + 64 trash
   int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
-#if GT_POTRF_WINDOW
-  double* hand = lines + kLineTrash + 64 + 2;                   // [4][64]: the window the helper hands to the chain wavefront
-  int* hprog = reinterpret_cast<int*>(hand + 4 * 64);            // windows handed over so far (4 jb + m, monotonic over the tile)
-#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
   if (tid == 0) { prog[0] = 0; prog[1] = 0; }
-#if GT_POTRF_WINDOW
-  if (tid == 0) hprog[0] = 0;
-#endif
   STAMP(0);
   if (!preloaded) diag_tile_to_lds(tile, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();
@@ -612,37 +431,23 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   for (int jb = 0; jb < 4; jb++) {
     const int nfol = 3 - jb;   // row blocks below
     if (wave == 0) {
-#if GT_POTRF_WINDOW
-      stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail, pk, prev_exp, hand, hprog);
-#else
       stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail, pk, prev_exp);
-#endif
       if (jb == 3 && tile_exp && lane == 0) st_pub(tile_exp + k, __longlong_as_double((long long)prev_exp), true);
     } else if (wave == 4) {
       // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
     } else if (wave <= nfol || wave == 5) {
       stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt);
-#if GT_POTRF_WINDOW
-    } else if (wave == (jb == 0 ? 6 : 3)) {
-      // the helper of the windowed chain: wavefront 6 in panel 0 (it has nothing else to do there), the spare follower wavefront 3
-      // afterwards (SIMD 3; the deferred work below is then shared by one wavefront less)
-      stage_helper(A, lines, rinvs, prog, hand, hprog, jb, lane);
-#endif
-#if GT_DF_DEFER_SLICE
     } else if (jb == 0) {
+      // (the wavefronts 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that panel 0 does not
+      // read -- the chain kernel passes the slice as Xdef, chol_dataflow.hip::chain_loop -- runs here, under panel 0's pivots)
       if (Xdef)
         for (int t = wave - 6; t < 24; t += 2) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles
           const int b2 = (t >> 2) * 2;
           slice_task(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1, lr, lk);
         }
-#endif
     } else if (jb > 0) {
       const int pj = jb - 1;                            // deferred work of panel pj
-#if GT_POTRF_WINDOW
-      const int nh = 1 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);   // wavefronts 6, 7 and the spare followers below wavefront 3
-#else
       const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
-#endif
       // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
       // started): blocks (ib, cb), pj+2 <= cb <= ib
       const int nb = 3 - pj, ntask = (nb * (nb - 1) / 2) * 4;
@@ -652,11 +457,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
         while (rem > bi) { rem -= bi + 1; bi++; }
         tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
       }
-#if GT_POTRF_WINDOW
-      store_column(A, tile, Xinv, pj, hw * 64 + lane, nh * 64, wt, rs + SB * pj);
-#else
       store_column(A, tile, Xinv, pj, hw * 64 + lane, nh * 64, wt);
-#endif
     }
     // Panel jb is released to the workgroups waiting for it (the TRSM workgroups of this launch / the substitutions of the dataflow
     // schedule) once its inverse and every L(jb, q<jb) operand image are in memory.
@@ -691,11 +492,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     }
     STAMP(4 + 3 * jb);
   }
-#if GT_POTRF_WINDOW
-  store_column(A, tile, Xinv, 3, tid, 512, wt, rs + SB * 3);
-#else
   store_column(A, tile, Xinv, 3, tid, 512, wt);
-#endif
   STAMP(14);
 }
 

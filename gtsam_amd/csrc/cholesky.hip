@@ -477,7 +477,6 @@ void launch_pack_tiles(gtg_context& c, SMat S, const CholPlan& plan, double* buf
 void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, double* Xinv, double* fail,
                      const unsigned char* pivot_kind, double* tile_exp) {
   CholStreams& g_cs = c.cs;
-  TreeStreams& g_ts = c.ts;
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
   const size_t smem_potrf = sizeof(double) * kPotrfSmemDoubles;
@@ -504,7 +503,6 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
     check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
     check_hip(hipStreamCreateWithPriority(&g_cs.panel, hipStreamNonBlocking, hi), "panel stream");
     check_hip(hipEventCreateWithFlags(&g_cs.start, hipEventDisableTiming), "event");
-    check_hip(hipEventCreateWithFlags(&g_cs.done_tree, hipEventDisableTiming), "event");
   }
   while ((int)g_cs.P.size() < npairs) {
     hipEvent_t e1, e2;
@@ -512,24 +510,8 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
     check_hip(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "event");
     g_cs.P.push_back(e1); g_cs.N.push_back(e2);
   }
-  if (g_cs.reserve < 0) {
-    // Optional (GTG_CU_RESERVE=n): keep n CUs out of the bulk updates' stream (CU mask), so that the workgroups of the
-    // serial chain are dispatched at once instead of waiting for k_syrk workgroups to retire.  Measured on L1723 with
-    // the chain in stream order: no gain (8.0 ms with 0, 8.1 ms with 32 reserved), hence off by default.
-    const char* e = getenv("GTG_CU_RESERVE");
-    g_cs.reserve = e ? atoi(e) : 0;
-    if (g_cs.reserve > 0) {
-      hipDeviceProp_t prop;
-      check_hip(hipGetDeviceProperties(&prop, c.device), "props");
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int i = 0; i < ncu - std::min(g_cs.reserve, ncu / 2); i++) mask[i >> 5] |= 1u << (i & 31);
-      check_hip(hipExtStreamCreateWithCUMask(&g_cs.update, (uint32_t)mask.size(), mask.data()), "masked stream");
-      check_hip(hipEventCreateWithFlags(&g_cs.done, hipEventDisableTiming), "event");
-    }
-  }
-  const bool masked = g_cs.update && plan.dense_fraction < 0.75;   // dense plans are throughput bound: all CUs to the update
-  hipStream_t su = masked ? g_cs.update : c.stream, sp = g_cs.panel;
+  // (a CU-masked update stream that keeps CUs free for the chain was measured in round 1: no gain, removed)
+  hipStream_t su = c.stream, sp = g_cs.panel;
   const int32_t* rows = plan.rows.p;
   const int32_t* pairs = plan.pairs.p;
   auto panel = [&](int k) {    // factor block column k: diagonal tile, then every stored row tile below
@@ -539,10 +521,7 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
   };
   // everything queued on the update stream so far (building S) must precede the first panel
   check_hip(hipEventRecord(g_cs.start, c.stream), "record");
-  if (plan.pair_part.empty()) {   // (the tree schedule has its own streams: a stream that joins a capture must rejoin it)
-    check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
-    if (masked) check_hip(hipStreamWaitEvent(su, g_cs.start, 0), "wait");
-  }
+  check_hip(hipStreamWaitEvent(sp, g_cs.start, 0), "wait");
   auto update = [&](hipStream_t st, int k, const std::vector<int64_t>& off, const std::vector<int64_t>& cnt, int pi, bool latency) {
     if (cnt[pi] <= 0) return;
     if (latency && cnt[pi] <= kLatencyTiles)
@@ -551,113 +530,16 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
     else
       hipLaunchKernelGGL(k_syrk<2>, dim3(syrk_grid(cnt[pi])), dim3(512), smem_syrk, st, S, k, pairs + 2 * off[pi], (int)cnt[pi]);
   };
-  if (!plan.pair_part.empty()) {
-    // ---- elimination-tree schedule: the parts of a nested-dissection ordering are independent serial chains.  Every
-    // leaf chain gets its own (panel, update) stream pair and they run side by side; a separator starts when the
-    // updates its descendants owe it are in.  Those cross-part updates (anc) all go through ONE stream in issue order:
-    // two subtrees update the same separator tiles, and the fixed order keeps the sums deterministic.
-    const int nparts = (int)plan.part_parent.size();
-    std::vector<int> first(nparts, -1), last(nparts, -1), slot(nparts, -1), nchild(nparts, 0);
-    for (int p = 0; p < npairs; p++) { const int x = plan.pair_part[p]; if (first[x] < 0) first[x] = p; last[x] = p; }
-    for (int x = 0; x < nparts; x++) if (plan.part_parent[x] >= 0) nchild[plan.part_parent[x]]++;
-    int nslots = 0;
-    for (int x = 0; x < nparts; x++) {           // children come before parents: a leaf opens a slot, a separator
-      if (nchild[x] == 0) slot[x] = nslots++;    // inherits the slot of its first child
-      else for (int y = 0; y < x; y++) if (plan.part_parent[y] == x) { slot[x] = slot[y]; break; }
-    }
-    int lo = 0, hi = 0;
-    check_hip(hipDeviceGetStreamPriorityRange(&lo, &hi), "priority range");
-    while ((int)g_ts.panel.size() < nslots) {
-      hipStream_t a, b;
-      // (no stream priorities in the tree form since the end of round 4: it is an A/B and a last-resort fallback, not a fast path, and the
-      // one run of it that did not return -- profiles/r04_streams_tree_hang.txt -- leaves priority pre-emption beside polling workgroups
-      // among the suspects; GTG_TREE_PRIO=1 brings them back)
-      if (!getenv("GTG_TREE_PRIO") || getenv("GTG_TREE_NOPRIO")) check_hip(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "panel stream");
-      else check_hip(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, hi), "panel stream");
-      check_hip(hipStreamCreateWithFlags(&b, hipStreamNonBlocking), "update stream");
-      g_ts.panel.push_back(a); g_ts.update.push_back(b);
-    }
-    if (!g_ts.anc) check_hip(hipStreamCreateWithFlags(&g_ts.anc, hipStreamNonBlocking), "anc stream");
-    while ((int)g_ts.part_ev.size() < nparts) {
-      hipEvent_t e1, e2;
-      check_hip(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "event");
-      check_hip(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "event");
-      g_ts.part_ev.push_back(e1); g_ts.join_ev.push_back(e2);
-    }
-    hipStream_t sa = g_ts.anc;
-    check_hip(hipStreamWaitEvent(sa, g_cs.start, 0), "wait");
-    auto panel_on = [&](hipStream_t st, int k) {
-      double* Xk = Xinv + (size_t)k * T * T;
-      hipLaunchKernelGGL(k_panel128, dim3(1 + 2 * (unsigned)plan.trsm_cnt[k]), dim3(512), std::max(smem_potrf, smem_trsm), st,
-                         S, k, rows + plan.trsm_off[k], Xk, fail, (long long*)g_potrf_dbg, flagbase, pivot_kind, tile_exp);
-    };
-    // Issue order: round-robin over the chains that are ready, one pair of block columns at a time.  The host needs
-    // ~45 us to issue a pair (9-10 API calls) and a chain executes one in ~100 us, so a single host thread can keep two
-    // to three chains busy; issued chain after chain, the second chain would only start when the first is nearly done.
-    // A separator becomes ready when all its children are completely issued: the anc stream's position at that
-    // moment marks "every update into its columns is in" (the stream is in order).  The order is a pure function of
-    // the plan: the cross-part sums are deterministic.
-    std::vector<int> next(nparts, 0), pending(nparts, 0);
-    for (int x = 0; x < nparts; x++) { next[x] = first[x]; pending[x] = nchild[x]; }
-    std::vector<int> active;
-    auto activate = [&](int x) {
-      hipStream_t xp = g_ts.panel[slot[x]], xu = g_ts.update[slot[x]];
-      if (nchild[x] == 0) {
-        check_hip(hipStreamWaitEvent(xp, g_cs.start, 0), "wait");
-        check_hip(hipStreamWaitEvent(xu, g_cs.start, 0), "wait");
-      } else {
-        check_hip(hipEventRecord(g_ts.part_ev[x], sa), "record");
-        check_hip(hipStreamWaitEvent(xp, g_ts.part_ev[x], 0), "wait");
-      }
-      active.push_back(x);
-    };
-    for (int x = 0; x < nparts; x++) if (nchild[x] == 0 && first[x] >= 0) activate(x);
-    while (!active.empty()) {
-      std::vector<int> round = active;
-      for (int x : round) {
-        hipStream_t xp = g_ts.panel[slot[x]], xu = g_ts.update[slot[x]];
-        const int pi = next[x]++;
-        const int k = 2 * pi;
-        panel_on(xp, k);
-        if (k + 1 < nt) {
-          if (plan.s1_cnt[pi] <= kLatencyTiles)
-            hipLaunchKernelGGL((k_syrk<1, 0, 2>), dim3(syrk_grid(4 * plan.s1_cnt[pi])), dim3(512), smem_syrk / 2, xp, S, k,
-                               pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
-          else
-            hipLaunchKernelGGL(k_syrk<1>, dim3(syrk_grid(plan.s1_cnt[pi])), dim3(512), smem_syrk, xp, S, k,
-                               pairs + 2 * plan.s1_off[pi], (int)plan.s1_cnt[pi]);
-          panel_on(xp, k + 1);
-          if (pi > first[x]) check_hip(hipStreamWaitEvent(xp, g_cs.P[pi - 1], 0), "wait");
-          update(xp, k, plan.nar_off, plan.nar_cnt, pi, true);
-        }
-        check_hip(hipEventRecord(g_cs.N[pi], xp), "record");
-        if (plan.rest_cnt[pi] > 0 || pi == last[x]) {
-          check_hip(hipStreamWaitEvent(xu, g_cs.N[pi], 0), "wait");
-          if (k + 1 < nt) update(xu, k, plan.rest_off, plan.rest_cnt, pi, false);
-        }
-        check_hip(hipEventRecord(g_cs.P[pi], xu), "record");
-        if (plan.anc_cnt[pi] > 0) {
-          check_hip(hipStreamWaitEvent(sa, g_cs.N[pi], 0), "wait");
-          update(sa, k, plan.anc_off, plan.anc_cnt, pi, false);
-        }
-        if (pi == last[x]) {   // chain completely issued
-          active.erase(std::find(active.begin(), active.end(), x));
-          const int par = plan.part_parent[x];
-          if (par >= 0 && --pending[par] == 0 && first[par] >= 0) activate(par);
-        }
-      }
-    }
-    // join: the caller's stream continues after every chain and after the anc stream
-    for (int sl = 0; sl < nslots; sl++) {
-      check_hip(hipEventRecord(g_ts.join_ev[sl], g_ts.update[sl]), "record");   // update[sl] waited for its panel stream's last N
-      check_hip(hipStreamWaitEvent(c.stream, g_ts.join_ev[sl], 0), "wait");
-    }
-    check_hip(hipEventRecord(g_cs.done_tree, sa), "record");
-    check_hip(hipStreamWaitEvent(c.stream, g_cs.done_tree, 0), "wait");
-    check_hip(hipGetLastError(), "cholesky (tree schedule)");
-    return;
-  }
+  // A plan with PARTS (nested-dissection ordering; build_chol_plan's `anc` lists = the updates that cross into a separator) runs as the
+  // same single chain: the parts one after the other in elimination order, the cross-part updates behind the pair's own bulk updates
+  // on the update stream.  What is new at a part boundary: the first panel of the next part waits for EVERYTHING older on the update
+  // stream (the separator's columns collect `anc` updates from every pair of the subtrees below it, not only from the pair before).
+  // (Rounds 1-4 ran the parts as independent chains on their own stream pairs here -- up to 18 streams; it was never faster than the
+  // dataflow schedule, one run of it did not return on a shared box and was never explained (profiles/r04_streams_tree_hang.txt):
+  // removed in round 5.  This schedule is the A/B of the dataflow pass and the last attempt after a timed-out one, not a fast path.)
+  const bool tree = !plan.pair_part.empty();
   for (int pi = 0, k = 0; k < nt; k += 2, pi++) {
+    if (tree && pi > 0 && plan.pair_part[pi] != plan.pair_part[pi - 1]) check_hip(hipStreamWaitEvent(sp, g_cs.P[pi - 1], 0), "wait");
     panel(k);
     if (k + 1 < nt) {
       if (plan.s1_cnt[pi] <= kLatencyTiles)
@@ -675,11 +557,8 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
     check_hip(hipEventRecord(g_cs.N[pi], sp), "record");
     check_hip(hipStreamWaitEvent(su, g_cs.N[pi], 0), "wait");
     if (k + 1 < nt) update(su, k, plan.rest_off, plan.rest_cnt, pi, false);
+    if (tree) update(su, k, plan.anc_off, plan.anc_cnt, pi, false);
     check_hip(hipEventRecord(g_cs.P[pi], su), "record");
-  }
-  if (masked) {
-    check_hip(hipEventRecord(g_cs.done, su), "record");
-    check_hip(hipStreamWaitEvent(c.stream, g_cs.done, 0), "wait");
   }
   check_hip(hipGetLastError(), "cholesky");
 }
@@ -972,13 +851,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_bwd_sweep(SMat S, int NP, int
 // gtg_destroy: the handle's schedule streams and events
 void destroy_chol_streams(gtg_context& c) {
   CholStreams& cs = c.cs;
-  TreeStreams& ts = c.ts;
-  for (hipStream_t st : {cs.panel, cs.update, ts.anc}) if (st) (void)hipStreamDestroy(st);
-  for (hipStream_t st : ts.panel) (void)hipStreamDestroy(st);
-  for (hipStream_t st : ts.update) (void)hipStreamDestroy(st);
-  for (hipEvent_t e : {cs.done, cs.done_tree, cs.start}) if (e) (void)hipEventDestroy(e);
-  for (auto* v : {&cs.P, &cs.N, &ts.part_ev, &ts.join_ev}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
-  cs = CholStreams(); ts = TreeStreams();
+  if (cs.panel) (void)hipStreamDestroy(cs.panel);
+  if (cs.start) (void)hipEventDestroy(cs.start);
+  for (auto* v : {&cs.P, &cs.N}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+  cs = CholStreams();
 }
 
 // y = L^-1 g sits in row 0 of the rhs tiles after the factorisation: gathered into a contiguous vector for the backward solve

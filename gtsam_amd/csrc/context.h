@@ -89,23 +89,6 @@ struct CholPlan {
   double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles
 };
 
-// Grouped Schur complement (schur_groups.hip; GTG_SCHUR=groups -- not the default): the cameras in groups of kSchurGroup consecutive
-// positions of the elimination order, one workgroup per pair of groups, its CELLS (one per landmark seen from both groups) in landmark
-// order.  Layout stated and pinned in tests/test_schur_groups_spec.py.
-constexpr int kSchurGroup = 8;                  // cameras per group = wavefronts per workgroup (one row camera each)
-constexpr int kSchurChunkSlots = 128;           // E slots of one chunk of cells in LDS
-struct SchurGroups {
-  bool active = false;
-  bool pipelined = false;                       // GTG_SCHUR=groups_pipe: the next chunk's slots are fetched under the current chunk's multiplications
-  int NG = 0;                                   // groups
-  int64_t n_pairs = 0, n_cells = 0;
-  DevBuf<int32_t> obs;                          // every landmark's observations, sorted by the position of their camera (segments of lm_obs): observation | (position mod 8) << 28
-  DevBuf<int32_t> cell_a0, cell_b0, cell_pq;    // per cell: runs of its A / B entries in `obs` (start, start, p | q << 16); cells sorted by group pair, landmark order inside
-  DevBuf<int32_t> pair_key;                     // ga * NG + gb of every group pair that has cells, ascending
-  DevBuf<int64_t> pair_ptr;                     // its cells
-  DevBuf<int32_t> order;                        // the group pairs by descending number of cells: workgroup b takes pair order[b]
-  DevBuf<int32_t> pos_red;                      // position -> reduced variable
-};
 
 // Dataflow schedule of the same factorisation (chol_dataflow.hip): one task per stored 128x128 tile, left-looking, executed by
 // persistent workgroups that take tasks in a fixed topological order; dependencies are epoch-stamped flags in HBM.
@@ -159,16 +142,9 @@ namespace gt {
 // Streams and events of the factorisation schedule (cholesky.hip) -- owned by the handle: streams and events belong to
 // the device they were created on, and two handles driven from two host threads must not share them.
 struct CholStreams {
-  hipStream_t panel = nullptr;    // high-priority stream of the serial panel chain
-  hipStream_t update = nullptr;   // CU-masked stream of the bulk trailing updates (GTG_CU_RESERVE > 0), else unused
-  hipEvent_t done = nullptr, done_tree = nullptr, start = nullptr;
-  int reserve = -1;
+  hipStream_t panel = nullptr;    // high-priority stream of the serial panel chain (the bulk updates run on the handle's stream)
+  hipEvent_t start = nullptr;
   std::vector<hipEvent_t> P, N;   // per column pair: rest(p) finished / chain of pair p finished
-};
-struct TreeStreams {              // elimination-tree schedule (GTG_ND_DEPTH > 0)
-  std::vector<hipStream_t> panel, update;   // one pair of streams per concurrently running chain
-  hipStream_t anc = nullptr;                // the updates that cross into ancestor parts: one stream, fixed order
-  std::vector<hipEvent_t> part_ev, join_ev;
 };
 }  // namespace gt
 
@@ -176,7 +152,6 @@ struct gtg_context {
   int device = 0;
   hipStream_t stream = nullptr;
   gt::CholStreams cs;
-  gt::TreeStreams ts;
   std::vector<hipEvent_t> phase_events;   // 2 per phase (gtg_enable_timing)
   int shard = 0, n_shards = 1;
   bool uploaded = false, linearized = false, have_trial = false;
@@ -243,7 +218,6 @@ struct gtg_context {
   gt::DevBuf<int64_t> hoff_ptr;  gt::DevBuf<int32_t> hoff_fac;       // block -> between factors (sign bit = transposed)
   int64_t n_pairs = 0, n_pair_terms = 0;                             // Schur block pairs
   bool device_terms = false;                                         // their term lists were built on the device (device_analysis.hip)
-  gt::SchurGroups sg;                                                // the grouped form of the same sums (GTG_SCHUR=groups)
   gt::DevBuf<int32_t> pair_row, pair_col;
   gt::DevBuf<int64_t> pair_ptr;  gt::DevBuf<int32_t> pair_oa, pair_ob;
 

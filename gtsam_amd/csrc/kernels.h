@@ -16,8 +16,6 @@ void launch_retract(gtg_context& c);                                    // trial
 void launch_assemble(gtg_context& c);            // Hd, gred0, V, gp, Hoff, hdiag_red (lambda-invariant)
 void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin, double dmax);  // Linv, ylm, E
 void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax);    // S and rhs row
-bool device_schur_groups(gtg_context& c);            // schur_groups.hip: the lists of the grouped form built on the device (GTG_SCHUR_LISTS=device)
-void launch_schur_groups(gtg_context& c, SMat S);   // schur_groups.hip: the Schur complement's sums in the grouped form (GTG_SCHUR=groups)
 void launch_back_substitute(gtg_context& c);     // delta_lm from xred, ylm, E, Linv
 void launch_scatter_delta(gtg_context& c);       // delta (variable id order) from xred + delta_lm
 
@@ -60,6 +58,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
                         const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots);   // the device half
 void free_df_plan(DfPlan& df);
+bool dataflow_schedule_selected();   // false: GTG_CHOL=streams (the stream / event schedule of cholesky.hip, the A/B of the dataflow pass)
 void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
                         const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);
 

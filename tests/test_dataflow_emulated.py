@@ -20,7 +20,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SRC = os.path.join(ROOT, "tools", "kernel_emu", "dataflow_emu.cpp")
 EXE = os.path.join(ROOT, "tests", "_build", "dataflow_emu")
-EXE_WINDOW = os.path.join(ROOT, "tests", "_build", "dataflow_emu_window")
 T = 128
 
 
@@ -38,18 +37,6 @@ def _build(path, flags):
 @pytest.fixture(scope="module")
 def exe():
     return _build(EXE, [])
-
-
-@pytest.fixture(scope="module")
-def exe_defer():
-    """the same kernels with the deferred last-slice update (chol_dataflow.hip / chol_device.h, GT_DF_DEFER_SLICE=1)"""
-    return _build(os.path.join(ROOT, "tests", "_build", "dataflow_emu_defer"), ["-DGT_DF_DEFER_SLICE=1"])
-
-
-@pytest.fixture(scope="module")
-def exe_window():
-    """the same kernels with the windowed pivot chain in the diagonal-tile body (chol_device.h, GT_POTRF_WINDOW=1)"""
-    return _build(EXE_WINDOW, ["-DGT_POTRF_WINDOW=1"])
 
 
 def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
@@ -151,25 +138,14 @@ def test_emulated_dataflow_factorisation_with_accumulator_lanes(exe, tmp_path):
     assert P["lanes"] and P["n_scratch"] > 0
 
 
-def test_emulated_dataflow_factorisation_windowed_variant_is_bit_identical(exe, exe_window, tmp_path):
-    """The windowed pivot chain inside the chain kernel (tile image preloaded by the caller, last slices applied in front of it): the
-    same factor, inverses and operand images as the default body, bit for bit."""
-    factor(exe, 3, 2, 2, 1, tmp_path)
-    S0, X0 = factor.last
-    factor(exe_window, 3, 2, 2, 1, tmp_path)
-    S1, X1 = factor.last
-    assert np.array_equal(S0, S1)
-    assert np.array_equal(X0.reshape(3, T * T)[:, :14336], X1.reshape(3, T * T)[:, :14336])
-
-
-def test_emulated_dataflow_factorisation_deferred_slice_is_bit_identical(exe, exe_defer, tmp_path):
+def test_emulated_dataflow_factorisation_is_reproducible_with_the_deferred_last_slice(exe, tmp_path):
     """The chain kernel applies the last slice of the tile left of a diagonal tile only to the blocks panel 0 reads; the rest runs under
     panel 0's pivot chain on the two wavefronts that idle there, before the barrier in front of the next panel's updates: every entry
-    sees the same sums in the same order."""
+    sees the same sums in the same order whatever the host threads' timing (the default since round 5; the numpy check is in `factor`)."""
     factor(exe, 3, 2, 2, 1, tmp_path)
     S0, X0 = factor.last
     for rep in range(2):
-        factor(exe_defer, 3, 2, 2, 1, tmp_path)
+        factor(exe, 3, 2, 2, 1, tmp_path)
         S1, X1 = factor.last
         assert np.array_equal(S0, S1)
         assert np.array_equal(X0.reshape(3, T * T)[:, :14336], X1.reshape(3, T * T)[:, :14336])

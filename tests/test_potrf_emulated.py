@@ -18,7 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SRC = os.path.join(ROOT, "tools", "kernel_emu", "potrf_emu.cpp")
 LIB = os.path.join(ROOT, "tests", "_build", "libpotrf_emu.so")
-LIB_WINDOW = os.path.join(ROOT, "tests", "_build", "libpotrf_emu_window.so")
 
 
 def _build(path, flags):
@@ -39,13 +38,6 @@ def _build(path, flags):
 @pytest.fixture(scope="module")
 def emu():
     return _build(LIB, [])
-
-
-@pytest.fixture(scope="module")
-def emu_window():
-    """The same body compiled with GT_POTRF_WINDOW=1: the chain wavefront keeps a window of 8 columns of the diagonal block, a helper
-    wavefront applies the published pivots to the columns beyond it and hands the next window over through LDS (chol_device.h)."""
-    return _build(LIB_WINDOW, ["-DGT_POTRF_WINDOW=1"])
 
 
 def _factor(lib, A, wt, epoch=1):
@@ -84,33 +76,10 @@ def test_emulated_body_flags_a_tile_that_is_not_positive_definite(emu):
     assert fail[0] == 1.0 and flag == 8 + 4       # an error, never a hang: every panel is still released
 
 
-@pytest.mark.parametrize("seed", [3, 4, 5])
-def test_windowed_pivot_chain_is_bit_identical_to_the_default(emu, emu_window, seed):
-    """Every entry of the diagonal block sees the same operations in the same order whoever applies them (chain wavefront or helper):
-    factor, inverses and operand images of the windowed variant equal the default's bit for bit, repetition after repetition."""
-    rng = np.random.default_rng(seed)
-    M = rng.standard_normal((128, 160)); A = M @ M.T + 64.0 * np.eye(128)
-    t0, X0, f0, g0 = _factor(emu, A, seed & 1, epoch=5)
-    for rep in range(3):
-        t1, X1, f1, g1 = _factor(emu_window, A, (seed + rep) & 1, epoch=5)
-        assert g1 == g0 == 5 * 8 + 4 and f1[0] == 0.0
-        assert np.array_equal(np.tril(t1), np.tril(t0))
-        assert np.array_equal(X1[:14336], X0[:14336])
-
-
-def test_windowed_body_flags_a_tile_that_is_not_positive_definite(emu_window):
-    rng = np.random.default_rng(8)
-    M = rng.standard_normal((128, 160)); A = M @ M.T + 64.0 * np.eye(128)
-    A[41, 41] = -2.0
-    _, _, fail, flag = _factor(emu_window, A, 0)
-    assert fail[0] == 1.0 and flag == 8 + 4
-
-
-@pytest.mark.parametrize("variant", ["default", "window"])
-def test_emulated_rank_test_of_the_reference(emu, emu_window, variant):
+def test_emulated_rank_test_of_the_reference(emu):
     """choleskyPartial's exponent test (base/cholesky.cpp:144-157) at the ends of the variables' pivot blocks: a tile of 9-dimensional
     variables passes when it is well conditioned and raises the flag when the last pivot of one variable is 2^-13 of the one before."""
-    lib = emu if variant == "default" else emu_window
+    lib = emu
     kinds = np.zeros(128, np.uint8)
     kinds[8:126:9] = 1                                   # last pivot of every 9-dimensional variable
     rng = np.random.default_rng(9)
@@ -122,4 +91,4 @@ def test_emulated_rank_test_of_the_reference(emu, emu_window, variant):
         tile = B.copy(); X = np.zeros(128 * 128); fail = np.zeros(2); texp = np.zeros(4)
         flag = lib.emu_potrf128_ranktest(tile.ctypes.data, X.ctypes.data, fail.ctypes.data, 1, 1, kinds.ctypes.data, texp.ctypes.data)
         assert flag == 8 + 4
-        assert fail[0] == (1.0 if bad else 0.0), (variant, bad, fail)
+        assert fail[0] == (1.0 if bad else 0.0), (bad, fail)

@@ -47,7 +47,8 @@ def stub():
 @pytest.mark.parametrize("workload,nd", [("bal:300:20000:3", 0), ("sphere2500", 0), ("ladybug1723", 0), ("sphere2500", 2), ("sphere2500", 3),
                                          ("bal:300:20000:3", 2), ("w20000", 3)])
 def test_no_unordered_tile_conflicts(stub, workload, nd):
-    # the launch-sequence schedules: the elimination-tree one (GTG_ND_DEPTH) and the look-ahead one (GTG_CHOL=streams).  The
+    # the launch-sequence schedule (GTG_CHOL=streams: look-ahead on two streams), also over a nested-dissection plan (GTG_ND_DEPTH: the
+    # parts one after the other, their cross-part updates behind the bulk updates -- the form that replaced the multi-stream tree in round 5).  The
     # default dataflow schedule has two launches and orders its tile accesses through flags inside the kernels: its ordering
     # argument (a task only reads tiles that are final in ticket order) is what tests/test_chol_plan.py::_execute_df checks.
     env = {"GTG_CHOL": "streams", "GTG_ND_DEPTH": str(nd)}    # (since round 3 a nested-dissection plan runs on the dataflow kernels by default)
@@ -55,6 +56,6 @@ def test_no_unordered_tile_conflicts(stub, workload, nd):
     assert r["rc"] == 0 and r["factorisation_launches"] >= r["nt"]          # at least one panel launch per block column
     assert r["streams"] >= 2 and r["ordered_conflicts_checked"] > r["factorisation_launches"]
     if nd:
-        assert r["parts"] > 1 and r["streams"] >= 4                       # independent chains + the cross-part stream
+        assert r["parts"] > 1 and r["streams"] == 2                       # the parts as ONE chain: panel stream + the handle's stream
     assert r["races"] == 0, r["first_races"]
     assert r["without_events"] > 0                                         # the checker does see races when the edges are gone

@@ -87,6 +87,8 @@ struct GpuLevenbergMarquardtOptimizer::Impl {
   Values scratch;                        // the deep copy of the caller's Values (made beside the extraction); swapped into the State at the end of init
   std::vector<Value*> slots;             // variable id -> the GenericValue object of that variable inside the State's Values (heap objects
                                          // owned by the map's nodes: they stay where they are when the map is swapped into the next State)
+  const Values* published = nullptr;     // the Values object (inside the State THIS class published last) whose nodes `slots` point into:
+                                         // checked before every write through `slots` (adoptStateIfForeign)
   std::vector<std::pair<int32_t, int64_t>> fac_map;   // factor of graph_ -> (GTG_FAC_*, index in that type's table); (-1, 0): null
   std::vector<int64_t> dim_off;          // variable id -> offset in the tangent vector (delta)
   bool keep_linearization = false;       // iterate(): download the records right after gtg_linearize
@@ -463,21 +465,58 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   // Both constructors of LevenbergMarquardtState deep-copy the Values they are given (the Values&& one passes its argument on as an
   // lvalue, LevenbergMarquardtState.h:61-63): 16 ms for the 158 000 variables of the L1723 shape, per State.  So a State is built on
   // an EMPTY Values and this object's copy is swapped in (Values::swap, Values.h:344: the maps trade their nodes, O(1)).
+  // NonlinearOptimizerState declares `const Values values` (every member of the State is const; a State is replaced, never changed),
+  // so the swap goes through a const_cast on a heap object that nobody else holds yet.  By the letter that is outside the language
+  // rules for const subobjects; the alternative the API leaves is the deep copy (one heap object per variable: 16 ms per State on the
+  // L1723 shape, + 2.3 ms per LM iteration through optimize()).  What the scheme must guarantee itself is memory safety: `slots`
+  // points into the nodes of ONE Values object, and every use checks that this object is still the one inside state_
+  // (adoptStateIfForeign): a State published by anybody else -- the inherited public tryLambda() does that -- is adopted, not written over.
   {
     std::unique_ptr<State> fresh(new State(Values(), e0, params_.lambdaInitial, params_.lambdaFactor));
     const_cast<Values&>(fresh->values).swap(m.scratch);
     m.slots.clear(); m.slots.reserve(nvars);
     for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));
     state_ = std::move(fresh);
+    m.published = &state_->values;
   }
   const State* s = static_cast<const State*>(state_.get());
   m.error = s->error; m.lambda = s->lambda; m.factor = s->currentFactor; m.iterations = s->iterations; m.inner = s->totalNumberInnerIterations;
   lap("state");
 }
 
+// state_ was replaced by code outside this class since this class last published it (LevenbergMarquardtOptimizer::tryLambda is public
+// and non-virtual: it solves on the CPU and installs a State with a deep copy of ITS new values, LM.cpp:121-270): the device follows
+// the host -- values re-packed and uploaded, error / lambda / counters taken from that State -- and `slots` is rebuilt on its nodes.
+void GpuLevenbergMarquardtOptimizer::adoptStateIfForeign() const {
+  Impl& m = *impl_;
+  if (m.published == &state_->values && state_->values.size() == m.slots.size()) return;
+  const Values& v = state_->values;
+  if (v.size() != m.keys.size()) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
+  m.slots.clear(); m.slots.reserve(m.keys.size());
+  size_t id = 0;
+  for (const auto& kv : v) {
+    if (kv.key != m.keys[id]) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
+    double* p = m.packed.data() + m.val_off[id];
+    const int32_t t = m.var_type[id];
+    if (t == GTG_VAR_POINT3) { const Point3& q = kv.value.cast<Point3>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
+    else if (t == GTG_VAR_SFM_CAMERA) packCamera(kv.value.cast<SfmCamera>(), p);
+    else if (t == GTG_VAR_POSE3) packPose(kv.value.cast<Pose3>(), p);
+    else { const Pose2& q = kv.value.cast<Pose2>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
+    m.slots.push_back(const_cast<Value*>(&kv.value));
+    id++;
+  }
+  check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
+  const State* st = static_cast<const State*>(state_.get());
+  m.error = st->error; m.lambda = st->lambda; m.factor = st->currentFactor; m.iterations = st->iterations; m.inner = st->totalNumberInnerIterations;
+  m.host_values_stale = false;
+  m.published = &state_->values;
+}
+
 void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
   Impl& m = *impl_;
   if (!m.host_values_stale && !force) return;
+  if (m.published != &state_->values)     // (the public entry points adopt a foreign State before they touch the device: cannot happen through them)
+    throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State was replaced while the values were on the device");
   if (m.host_values_stale) {
     check(gtg_get_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_get_values");
     // overwrite the payloads of the State's Values in place (m.slots: the GenericValue objects by variable id), host threads
@@ -501,8 +540,9 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
   }
   // the next State takes the SAME Values object over (swap: O(1); see init) with the device's error / lambda / counters
   std::unique_ptr<State> fresh(new State(Values(), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
-  const_cast<Values&>(fresh->values).swap(const_cast<Values&>(state_->values));
+  const_cast<Values&>(fresh->values).swap(const_cast<Values&>(state_->values));   // (see init: the nodes -- and with them `slots` -- move on)
   state_ = std::move(fresh);
+  m.published = &state_->values;
   m.host_values_stale = false;
 }
 
@@ -615,6 +655,7 @@ void GpuLevenbergMarquardtOptimizer::iterateDevice() {
 
 GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::iterate() {
   Impl& m = *impl_;
+  adoptStateIfForeign();
   m.keep_linearization = true;   // what the reference returns: `linear`, the graph linearised at the values the iteration
   iterateDevice();               // started from (LevenbergMarquardtOptimizer.cpp:277,307)
   m.keep_linearization = false;
@@ -667,6 +708,7 @@ GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::downloadLineariz
 }
 
 GaussianFactorGraph::shared_ptr GpuLevenbergMarquardtOptimizer::linearize() const {
+  adoptStateIfForeign();
   const Impl& m = *impl_;
   if (m.host_values_stale) throw std::logic_error("GpuLevenbergMarquardtOptimizer::linearize: host values out of date");   // (cannot happen through the public entry points)
   check(gtg_linearize(m.h), "gtg_linearize");
@@ -764,6 +806,7 @@ VectorValues GpuLevenbergMarquardtOptimizer::solve(const GaussianFactorGraph& gf
 
 const Values& GpuLevenbergMarquardtOptimizer::optimize() {
   Impl& m = *impl_;
+  adoptStateIfForeign();
   const LevenbergMarquardtParams& p = params_;
   using std::cout; using std::endl;
   double currentError = m.error;

@@ -72,6 +72,7 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   void iterateDevice();              // LevenbergMarquardtOptimizer::iterate restated (logFile rows, SUMMARY header)
   void writeLogFileDevice(double currentError);
   void syncValuesToHost(bool force);
+  void adoptStateIfForeign() const;      // a State installed by the inherited tryLambda() (or anybody else): the device follows it
   gtsam::GaussianFactorGraph::shared_ptr downloadLinearization() const;   // the device's current records as JacobianFactors
 };
 

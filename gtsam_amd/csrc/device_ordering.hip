@@ -19,6 +19,7 @@
 // dozen to a few hundred nodes; the whole ordering is ~150 levels x 3 sweeps of barrier-separated steps), and nothing of the
 // O(edges) work is left on the host.  Levels of more than kMaxLevel nodes, graphs of more than 4 M nodes and the nested-dissection
 // orderings of the pose graphs stay with the host code (the function returns false and analysis.hip takes the host path).
+#include <cstdio>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 
@@ -196,7 +197,13 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   const size_t o_a = carve(4 * (size_t)m), o_b = carve(4 * (size_t)m), o_ptr = carve(4 * ((size_t)n + 1)), o_adj = carve(8 * (size_t)m);
   const size_t o_order = carve(4 * (size_t)n), o_queue = carve(4 * (size_t)n), o_claim = carve(4 * (size_t)n), o_vis = carve((size_t)n), o_act = carve((size_t)n);
   const size_t o_n = carve(16), o_status = carve(16);
-  DevBuf<unsigned char> ws; ws.alloc(off);
+  // (the workspace is released on every path; a HIP error inside -- an illegal key, a failed allocation, a driver error -- makes this
+  // function return false, as its contract says: the caller then runs the host ordering instead of failing the upload)
+  DevBuf<unsigned char> ws;
+  struct Release { DevBuf<unsigned char>& b; ~Release() { b.free(); } } release{ws};
+  int32_t status = 1;
+  try {
+  ws.alloc(off);
   auto at = [&](size_t o) { return ws.p + o; };
   uint64_t* k1 = reinterpret_cast<uint64_t*>(at(o_k1)); uint64_t* k2 = reinterpret_cast<uint64_t*>(at(o_k2));
   int32_t* da = reinterpret_cast<int32_t*>(at(o_a)); int32_t* db = reinterpret_cast<int32_t*>(at(o_b));
@@ -215,11 +222,14 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   hipLaunchKernelGGL(k_rcm, dim3(1), dim3(kRcmThreads), 0, s, n, dptr, dadj, dorder, dqueue, dclaim, at(o_vis), at(o_act), dstatus);
   hc(hipGetLastError(), "device ordering");
   order.resize((size_t)n);
-  int32_t status = 1;
   hc(hipMemcpyAsync(order.data(), dorder, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s), "D2H");
   hc(hipMemcpyAsync(&status, dstatus, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "device ordering");
-  ws.free();
+  } catch (const std::exception& e) {
+    (void)hipGetLastError();
+    std::fprintf(stderr, "[gtsam_amd] device ordering failed (%s): falling back to the host queue\n", e.what());
+    return false;
+  }
   return status == 0;
 }
 

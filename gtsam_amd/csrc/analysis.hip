@@ -833,6 +833,7 @@ void analyze(gtg_context& c) {
   c.Linv.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.ylm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.delta_lm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.E.alloc(std::max<size_t>(kEStride * (size_t)c.n_obs, 1));
+  c.wobs.alloc(std::max<size_t>(9 * (size_t)c.n_obs, 1));
   c.vobs.alloc(std::max<size_t>(3 * (size_t)c.n_obs, 1));
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
   c.S.alloc((size_t)(c.plan.n_stored + (c.use_df ? c.df.n_scratch : 0)) * kTileDoubles);   // the stored tiles only (context.h::SMat) + the dataflow plan's scratch slots
@@ -865,9 +866,11 @@ void analyze(gtg_context& c) {
   if (c.n_shards > 1 && c.allreduce) verify_layout(c);
 
   c.chol_flops = c.use_df ? c.df.flops : c.plan.flops;
-  // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements +
-  // variable blocks read, Jacobian records written and read once by the assembly, blocks written
-  c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + 2.0 * kSfmRec * 8) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +
+  // algorithmic HBM bytes of one linearize+assemble pass: factor indices + measurements + variable blocks read, blocks
+  // written; stored records: + the Jacobian records written and read once by the assembly.  GeneralSFM factors of a fused graph
+  // (fused.h) have no stored records: SURVEY.md section 8(d)'s fused figure -- indices, measurement and noise row read, the
+  // off-diagonal block W = Jc^T Jp written (216 B; here in its lambda-dependent form E, by the first point elimination).
+  c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + (c.fused_sfm ? 216.0 : 2.0 * kSfmRec * 8)) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +
                 (double)n_btw * (2 * 4 + 96 + 4 + 2.0 * kBetweenRec * 8) + (double)c.val_size * 8 +
                 (double)c.n_red_vars * 90 * 8 + (double)c.n_lm * 12 * 8 + (double)c.n_hoff * 36 * 8;
   block_level.t.join();

@@ -23,6 +23,11 @@
 #include "factors.h"
 #include "kernels.h"
 
+// GTG_FUSED_SFM=0 at compile time builds the stored-record form of rounds 1-4 for every graph (the A/B of the fused linearisation,
+// `make records`); the product library is built with 1
+#ifndef GTG_FUSED_SFM
+#define GTG_FUSED_SFM 1
+#endif
 namespace gt {
 
 static thread_local std::string g_last_error;
@@ -259,7 +264,7 @@ int gtg_destroy(gtg_handle c) {
   auto& f = c->f;
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
-                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->pcg_vec, &c->pcg_bj, &c->pcg_y, &c->delta_lm, &c->S,
+                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->wobs, &c->cam_part, &c->pcg_vec, &c->pcg_bj, &c->pcg_y, &c->delta_lm, &c->S,
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
@@ -301,6 +306,9 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
   std::vector<double> x_sfm_z;
   const int64_t n_smart = p_user->n_smart > 0 ? p_user->n_smart : 0;
   c->n_smart = n_smart; c->n_user_vars = p_user->n_vars; c->smart_obs0 = p_user->n_sfm;
+  // GeneralSFM records recomputed where they are needed instead of stored (fused.h) -- not with smart factors, whose measurements'
+  // records depend on the factor's triangulation status
+  c->fused_sfm = GTG_FUSED_SFM != 0 && n_smart == 0;
   if (n_smart) {
     if (!p_user->smart_ptr || !p_user->smart_cam || !p_user->smart_z || !p_user->smart_noise || !p_user->smart_params)
       throw std::invalid_argument("smart factor tables missing");
@@ -455,7 +463,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     }
     f.n_sfm = (int64_t)cam.size();
     up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
-    f.sfm_J.alloc(std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
+    f.sfm_J.alloc(c->fused_sfm ? 1 : std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
     hi.sfm_cam = std::move(cam); hi.sfm_point = std::move(pt);
   }
   { // projection
@@ -824,6 +832,14 @@ int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
     default: throw std::invalid_argument("unknown factor type");
   }
   if (n != cnt) throw std::invalid_argument("gtg_get_jacobians: wrong output size");
+  DevBuf<double> recomputed;
+  if (type == GTG_FAC_GENERAL_SFM && c->fused_sfm && cnt) {   // debug path: these records are not stored (fused.h) -- recomputed at the current values
+    recomputed.alloc((size_t)cnt);
+    launch_sfm_records(*c, recomputed.p);
+    check_hip(hipStreamSynchronize(c->stream), "sync");
+    src = recomputed.p;
+  }
+  struct Release { DevBuf<double>& b; ~Release() { b.free(); } } release{recomputed};
   if (cnt) check_hip(hipMemcpy(out, src, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H");
   return GTG_OK;
   GTG_CATCH

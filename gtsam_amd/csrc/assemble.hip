@@ -12,6 +12,7 @@
 // Cholesky, E = W L^-T, S = H_cc + lambda D - sum E E^T).  All sums run in a host-fixed order: no
 // floating-point atomics, results are bit-reproducible run to run.
 #include "factors.h"
+#include "fused.h"
 #include "kernels.h"
 #include "recio.h"
 
@@ -53,7 +54,8 @@ constexpr int kRedWaves = 16;   // waves per reduced variable: a 16-camera probl
 __global__ __launch_bounds__(64 * kRedWaves) void k_red_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, JTabs t, double* __restrict__ Hd, double* __restrict__ g,
-    double* __restrict__ hdiag) {
+    double* __restrict__ hdiag, int after_fused) {
+  // after_fused: the GeneralSFM contributions are in Hd / g / hdiag already (k_cam_fused): skip them here and ADD the rest
   __shared__ double part[kRedWaves][256];
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void k_red_diag(int32_t n_red_vars,
   v4f64a acc = {0.0, 0.0, 0.0, 0.0};
   for (int64_t k = beg + wave; k < end; k += kRedWaves) {
     const double* A; const double* b; int rows;
+    if (after_fused && inc_kind[k] == INC_SFM) continue;   // (wave-uniform)
     contribution(t, inc_kind[k], inc_idx[k], d, A, rows, b);
     const int boff = (int)(b - A);
     for (int q0 = 0; q0 < rows; q0 += 4) {
@@ -88,11 +91,118 @@ __global__ __launch_bounds__(64 * kRedWaves) void k_red_diag(int32_t n_red_vars,
 #pragma unroll
     for (int w = 0; w < kRedWaves; w++) s += part[w][idx];   // wave order: deterministic
     if (e < d * d) {
+      if (after_fused) s += Hd[(int64_t)81 * r + e];
       Hd[(int64_t)81 * r + e] = s;
       if (i == j) hdiag[red_off[r] + i] = s;
     } else {
+      if (after_fused) s += g[(int64_t)9 * r + i];
       g[(int64_t)9 * r + i] = s;
     }
+  }
+}
+
+// ---- the same sums without stored records (fused.h; north_star: "one-factor-per-wavefront kernels ... the small dense Jacobian blocks
+// reduced into J^T J / J^T r Hessian blocks staged in LDS").  One factor per LANE here, 64 per wavefront: a record is 2 rows of 13, and
+// the reduction over the factors of a camera is what runs wavefront-wide, on the matrix core, out of the LDS image.
+// k_cam_fused: the camera-sorted pass.  Workgroup (r, sp) takes the sp-th part of reduced variable r's contribution list; a wavefront
+// takes 64 GeneralSFM entries at a time: every lane recomputes its factor's record [Jc | Jp | b] into the wavefront's LDS image (gather of
+// the camera -- the same 17 doubles for the whole workgroup: L1 --, its point, its measurement), then the 128 rows [Jc | b] of the
+// image are contracted 4 at a time: C += [Jc]^T [Jc | b], 32 MFMAs per 64 factors with both operands read from LDS (conflict free:
+// the 64 lanes of a step read one contiguous 54-word window).  Wave partials combined in wave order, parts in part order: deterministic.
+constexpr int kCamWaves = 4;
+constexpr int kCamPartStride = 96;   // doubles per (variable, part) in the partial buffer (>= 9 * 9 + 9)
+__global__ __launch_bounds__(64 * kCamWaves) void k_cam_fused(int32_t n_red_vars, int splits, const int64_t* __restrict__ inc_ptr,
+    const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
+    const int64_t* __restrict__ red_off, SfmTabs t, double* __restrict__ Hd, double* __restrict__ g, double* __restrict__ hdiag,
+    double* __restrict__ part) {
+  typedef RecIO<kSfmRec> IO;
+  __shared__ double img[kCamWaves][IO::LDS_DOUBLES];
+  __shared__ double comb[kCamWaves][256];
+  const int r = blockIdx.x / splits, sp = blockIdx.x - r * splits;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t beg = inc_ptr[r], len = inc_ptr[r + 1] - beg;
+  const int64_t s0 = beg + len * sp / splits, s1 = beg + len * (sp + 1) / splits;
+  double* my = img[wave];
+  double* rec = my + lane * IO::PITCH;
+  const int col_off = lr < 9 ? lr : 24;                      // column lr of [Jc | b]: Jc[row][lr] at 9 row + lr, b[row] at 24 + row; lanes lr > 9 are masked
+  v4f64a acc = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t base = s0 + 64 * wave; base < s1; base += 64 * kCamWaves) {
+    const int64_t k = base + lane;
+    if (k < s1 && inc_kind[k] == INC_SFM) sfm_record(t, inc_idx[k], rec);
+    else
+#pragma unroll
+      for (int e = 0; e < kSfmRec; e++) rec[e] = 0.0;
+    IO::wave_sync();
+#pragma unroll 8
+    for (int m = 0; m < 32; m++) {
+      const int row = 4 * m + lk;
+      const double* R = my + (row >> 1) * IO::PITCH;
+      const double v = R[(lr < 9 ? 9 : 1) * (row & 1) + col_off];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lr < 9 ? v : 0.0, lr <= 9 ? v : 0.0, acc, 0, 0, 0);
+    }
+    IO::wave_sync();
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; rr++) comb[wave][rr * 64 + lane] = acc[rr];   // C[row = lk + 4 rr][col = lr]
+  __syncthreads();
+  const int e = threadIdx.x, nent = d * d + d;
+  if (e < nent) {
+    const int i = e < d * d ? e / d : e - d * d, j = e < d * d ? e % d : 9;
+    const int idx = (i >> 2) * 64 + 16 * (i & 3) + j;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kCamWaves; w++) s += comb[w][idx];
+    if (splits > 1) part[(int64_t)blockIdx.x * kCamPartStride + e] = s;
+    else if (e < d * d) { Hd[(int64_t)81 * r + e] = s; if (i == j) hdiag[red_off[r] + i] = s; }
+    else g[(int64_t)9 * r + i] = s;
+  }
+}
+// ... the parts of a variable added up in part order (graphs with few cameras and thousands of observations each)
+__global__ __launch_bounds__(128) void k_cam_combine(int32_t n_red_vars, int splits, const int32_t* __restrict__ red_dim,
+    const int64_t* __restrict__ red_off, const double* __restrict__ part, double* __restrict__ Hd, double* __restrict__ g,
+    double* __restrict__ hdiag) {
+  const int r = blockIdx.x, e = threadIdx.x;
+  if (r >= n_red_vars) return;
+  const int d = red_dim[r];
+  if (e >= d * d + d) return;
+  double s = 0.0;
+  for (int sp = 0; sp < splits; sp++) s += part[((int64_t)r * splits + sp) * kCamPartStride + e];
+  if (e < d * d) { Hd[(int64_t)81 * r + e] = s; if (e / d == e % d) hdiag[red_off[r] + e / d] = s; }
+  else g[(int64_t)9 * r + (e - d * d)] = s;
+}
+
+// k_lm_fused: the landmark-sorted pass.  One landmark per lane as k_lm_diag (same sums in the same order: V and gp are bit-identical
+// to the stored-record form), the GeneralSFM records of its observations recomputed one after the other in the lane's row of the LDS image.
+__global__ __launch_bounds__(kBlock) void k_lm_fused(int32_t n_lm, const int64_t* __restrict__ obs_ptr,
+    const int32_t* __restrict__ obs, const int64_t* __restrict__ pri_ptr, const int32_t* __restrict__ pri,
+    JTabs t, SfmTabs st, double* __restrict__ V, double* __restrict__ gp) {
+  typedef RecIO<kSfmRec> IO;
+  __shared__ double img[kBlock / 64][IO::LDS_DOUBLES];
+  double* rec = img[threadIdx.x >> 6] + (threadIdx.x & 63) * IO::PITCH;
+  for (int64_t l = blockIdx.x * (int64_t)kBlock + threadIdx.x; l < n_lm; l += (int64_t)gridDim.x * kBlock) {
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int64_t k = obs_ptr[l]; k < obs_ptr[l + 1]; k++) {
+      const int64_t o = obs[k];
+      const double *Jp, *b;
+      if (o < t.n_sfm) { sfm_record(st, o, rec); Jp = rec + 18; b = rec + 24; }
+      else { const double* J = t.proj_J + (int64_t)kProjRec * (o - t.n_sfm); Jp = J + 12; b = J + 18; }
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) v[3 * i + j] += Jp[i] * Jp[j] + Jp[3 + i] * Jp[3 + j];
+        g[i] += Jp[i] * b[0] + Jp[3 + i] * b[1];
+      }
+    }
+    for (int64_t k = pri_ptr[l]; k < pri_ptr[l + 1]; k++) {
+      const double* J = t.pr_J + (int64_t)kPriorRec * pri[k];
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) for (int q = 0; q < 3; q++) v[3 * i + j] += J[3 * q + i] * J[3 * q + j];
+        for (int q = 0; q < 3; q++) g[i] += J[3 * q + i] * J[81 + q];
+      }
+    }
+    for (int i = 0; i < 9; i++) V[9 * l + i] = v[i];
+    for (int i = 0; i < 3; i++) gp[3 * l + i] = g[i];
   }
 }
 
@@ -216,9 +326,12 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
 // E_o = Jc^T (Jp L^-T) for the observations [0, n) of one factor type, one observation per lane.  The Jacobian records
 // are read and the 256-byte E slots written through the wavefront's LDS image (recio.h): 1 KiB contiguous per memory
 // instruction in both directions.
-template <int REC, int DC>
-__global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __restrict__ J, const int32_t* __restrict__ obs_lm,
-    const double* __restrict__ Linv, double* __restrict__ E) {
+// FUSED (GeneralSFM records of a graph without smart factors): the record is recomputed in the image instead of loaded (fused.h).
+// Also out: w_o = E_o y_l (9 doubles per observation, zero padded), the observation's summand of the reduced right-hand side -- so that
+// k_build_diag reads 72 bytes per observation instead of the 216-byte E block and y (283 MB per try on the L1723 shape until round 4).
+template <int REC, int DC, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __restrict__ J, SfmTabs t, const int32_t* __restrict__ obs_lm,
+    const double* __restrict__ Linv, const double* __restrict__ ylm, double* __restrict__ E, double* __restrict__ W) {
   typedef RecIO<REC> IN;
   typedef RecIO<kEStride> OUT;
   __shared__ double img[kBlock / 64][OUT::LDS_DOUBLES > IN::LDS_DOUBLES ? OUT::LDS_DOUBLES : IN::LDS_DOUBLES];
@@ -228,13 +341,18 @@ __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __res
   for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
     const int64_t o = ch * 64 + lane, left = n - ch * 64;
     const int nrec = left < 64 ? (int)left : 64;
-    IN::load(my, J + (int64_t)REC * ch * 64, nrec, lane);
-    double Eo[kEStride];
+    if constexpr (FUSED) { if (o < n) sfm_record(t, o, my + lane * IN::PITCH); }
+    else IN::load(my, J + (int64_t)REC * ch * 64, nrec, lane);
+    double Eo[kEStride], w[9];
 #pragma unroll
     for (int k = 0; k < kEStride; k++) Eo[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) w[i] = 0.0;
     if (o < n) {
       const double* rec = my + lane * IN::PITCH;     // [Jc 2 x DC | Jp 2 x 3 | b 2]
-      const double* Li = Linv + 9 * (int64_t)obs_lm[o];
+      const int64_t lm = obs_lm[o];
+      const double* Li = Linv + 9 * lm;
+      const double* y = ylm + 3 * lm;
       double T[6];
 #pragma unroll
       for (int r = 0; r < 2; r++)
@@ -249,17 +367,27 @@ __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __res
       for (int i = 0; i < DC; i++)
 #pragma unroll
         for (int m = 0; m < 3; m++) Eo[3 * i + m] = rec[i] * T[m] + rec[DC + i] * T[3 + m];
+      const double y0 = y[0], y1 = y[1], y2 = y[2];
+#pragma unroll
+      for (int i = 0; i < DC; i++) w[i] = Eo[3 * i] * y0 + Eo[3 * i + 1] * y1 + Eo[3 * i + 2] * y2;
     }
     IN::wave_sync();   // every lane has read its record: the image becomes the E block
 #pragma unroll
     for (int k = 0; k < kEStride; k++) my[lane * OUT::PITCH + k] = Eo[k];
     OUT::store(my, E + (int64_t)kEStride * ch * 64, nrec, lane);
+#pragma unroll
+    for (int i = 0; i < 9; i++) my[lane * 9 + i] = w[i];
+    IN::wave_sync();
+    double* Wc = W + 9 * ch * 64;
+#pragma unroll
+    for (int u = 0; u < 9; u++) { const int e = u * 64 + lane; if (e < 9 * nrec) Wc[e] = my[e]; }
+    IN::wave_sync();   // the image may be overwritten afterwards
   }
 }
 
 // v_o = Jp^T (Jc x_cam) for the back-substitution, one observation per lane, records through LDS as above
-template <int REC, int DC>
-__global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __restrict__ J, const int32_t* __restrict__ obs_red,
+template <int REC, int DC, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __restrict__ J, SfmTabs t, const int32_t* __restrict__ obs_red,
     const int64_t* __restrict__ red_off, const double* __restrict__ x, double* __restrict__ v) {
   typedef RecIO<REC> IN;
   __shared__ double img[kBlock / 64][IN::LDS_DOUBLES];
@@ -268,7 +396,8 @@ __global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __res
   const int64_t nchunks = (n + 63) / 64, stride = (int64_t)gridDim.x * (kBlock / 64);
   for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += stride) {
     const int64_t o = ch * 64 + lane, left = n - ch * 64;
-    IN::load(my, J + (int64_t)REC * ch * 64, left < 64 ? (int)left : 64, lane);
+    if constexpr (FUSED) { if (o < n) sfm_record(t, o, my + lane * IN::PITCH); }     // (a lane reads its own record only)
+    else IN::load(my, J + (int64_t)REC * ch * 64, left < 64 ? (int)left : 64, lane);
     if (o < n) {
       const double* rec = my + lane * IN::PITCH;
       const double* xr = x + red_off[obs_red[o]];
@@ -281,13 +410,13 @@ __global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __res
   }
 }
 
-// One wavefront per reduced variable: damped diagonal block into S, rhs entries g - sum E y into the
-// extra row NP of S.
+// One wavefront per reduced variable: damped diagonal block into S, rhs entries g - sum E y (the summands w_o = E_o y_l come from
+// k_obs_E) into the extra row NP of S.
 __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
-    const int64_t* __restrict__ red_off, const int32_t* __restrict__ obs_lm, int64_t n_sfm,
+    const int64_t* __restrict__ red_off, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
-    const double* __restrict__ E, const double* __restrict__ ylm, double invsigma,
+    const double* __restrict__ W, double invsigma,
     int diag, double dmin, double dmax, int add_damping, SMat S) {
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
@@ -305,9 +434,8 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     const int kind = inc_kind[k];
     if (kind > INC_PROJ) continue;
     const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
-    const double* Eo = E + kEStride * o;
-    const double* y = ylm + 3 * (int64_t)obs_lm[o];
-    for (int i = 0; i < d; i++) acc[i] += Eo[3 * i] * y[0] + Eo[3 * i + 1] * y[1] + Eo[3 * i + 2] * y[2];
+    const double* wo = W + 9 * o;      // E_o y_l, formed by k_obs_E
+    for (int i = 0; i < d; i++) acc[i] += wo[i];
   }
   for (int i = 0; i < 9; i++)
     for (int s = 32; s > 0; s >>= 1) acc[i] += __shfl_down(acc[i], s, 64);
@@ -465,10 +593,25 @@ static JTabs jtabs(gtg_context& c) { return JTabs{c.f.sfm_J.p, c.f.proj_J.p, c.f
 
 void launch_assemble(gtg_context& c) {
   JTabs t = jtabs(c);
-  if (c.n_red_vars)
+  if (c.n_red_vars && c.fused_sfm) {
+    // several workgroups per camera where there are few cameras (a 16-camera graph has thousands of observations per camera)
+    const int splits = c.n_red_vars >= 512 ? 1 : std::min(16, (1024 + c.n_red_vars - 1) / c.n_red_vars);
+    if (splits > 1 && (int64_t)c.cam_part.n != (int64_t)c.n_red_vars * splits * kCamPartStride) c.cam_part.alloc((size_t)c.n_red_vars * splits * kCamPartStride);
+    hipLaunchKernelGGL(k_cam_fused, dim3((unsigned)(c.n_red_vars * splits)), dim3(64 * kCamWaves), 0, c.stream, c.n_red_vars, splits, c.red_inc_ptr.p,
+                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, sfm_tabs(c), c.Hd.p, c.gred0.p, c.hdiag_red.p, c.cam_part.p);
+    if (splits > 1)
+      hipLaunchKernelGGL(k_cam_combine, dim3((unsigned)c.n_red_vars), dim3(128), 0, c.stream, c.n_red_vars, splits, c.red_dim.p, c.red_off.p,
+                         c.cam_part.p, c.Hd.p, c.gred0.p, c.hdiag_red.p);
+    if (c.f.n_proj + c.f.n_between + c.f.n_prior > 0)     // the other factor types' contributions on top
+      hipLaunchKernelGGL(k_red_diag, dim3(c.n_red_vars), dim3(64 * kRedWaves), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
+                         c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, t, c.Hd.p, c.gred0.p, c.hdiag_red.p, 1);
+  } else if (c.n_red_vars)
     hipLaunchKernelGGL(k_red_diag, dim3(c.n_red_vars), dim3(64 * kRedWaves), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
-                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, t, c.Hd.p, c.gred0.p, c.hdiag_red.p);
-  if (c.n_lm)
+                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, t, c.Hd.p, c.gred0.p, c.hdiag_red.p, 0);
+  if (c.n_lm && c.fused_sfm)
+    hipLaunchKernelGGL(k_lm_fused, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_obs_ptr.p, c.lm_obs.p,
+                       c.lm_pri_ptr.p, c.lm_pri.p, t, sfm_tabs(c), c.V.p, c.gp.p);
+  else if (c.n_lm)
     hipLaunchKernelGGL(k_lm_diag, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_obs_ptr.p, c.lm_obs.p,
                        c.lm_pri_ptr.p, c.lm_pri.p, t, c.V.p, c.gp.p);
   if (c.n_hoff)
@@ -553,12 +696,16 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
   const double is = inv_sigma(lambda);
   hipLaunchKernelGGL(k_point_factor, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p, c.V.p,
                      c.gp.p, is, diag, dmin, dmax, c.Linv.p, c.ylm.p, c.scalars.p + SC_FAIL, c.n_smart ? c.lm_smart.p : nullptr, c.smart_lin_status.p);
-  if (c.f.n_sfm)
-    hipLaunchKernelGGL((k_obs_E<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
-                       c.obs_lm.p, c.Linv.p, c.E.p);
+  const SfmTabs st = sfm_tabs(c);
+  if (c.f.n_sfm && c.fused_sfm)
+    hipLaunchKernelGGL((k_obs_E<kSfmRec, 9, true>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
+                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p);
+  else if (c.f.n_sfm)
+    hipLaunchKernelGGL((k_obs_E<kSfmRec, 9, false>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
+                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p);
   if (c.f.n_proj)
-    hipLaunchKernelGGL((k_obs_E<kProjRec, 6>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
-                       c.f.proj_J.p, c.obs_lm.p + c.f.n_sfm, c.Linv.p, c.E.p + (int64_t)kEStride * c.f.n_sfm);
+    hipLaunchKernelGGL((k_obs_E<kProjRec, 6, false>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
+                       c.f.proj_J.p, st, c.obs_lm.p + c.f.n_sfm, c.Linv.p, c.ylm.p, c.E.p + (int64_t)kEStride * c.f.n_sfm, c.wobs.p + 9 * c.f.n_sfm);
   check_hip(hipGetLastError(), "point_eliminate");
 }
 
@@ -568,8 +715,8 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   launch_zero_tiles(c, S, c.plan);
   if (c.n_red_vars)
     hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
-                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.obs_lm.p, c.f.n_sfm, c.Hd.p,
-                       c.gred0.p, c.hdiag_red.p, c.E.p, c.ylm.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, S);
+                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.f.n_sfm, c.Hd.p,
+                       c.gred0.p, c.hdiag_red.p, c.wobs.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, S);
   if (c.n_hoff)
     hipLaunchKernelGGL(k_scatter_hoff, dim3((unsigned)c.n_hoff), dim3(64), 0, c.stream, c.n_hoff, c.hoff_row.p,
                        c.hoff_col.p, c.red_dim.p, c.red_off.p, c.Hoff.p, S);
@@ -586,12 +733,16 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
 }
 
 void launch_back_substitute(gtg_context& c) {
-  if (c.f.n_sfm && c.n_lm)
-    hipLaunchKernelGGL((k_obs_v<kSfmRec, 9>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p,
+  const SfmTabs st = sfm_tabs(c);
+  if (c.f.n_sfm && c.n_lm && c.fused_sfm)
+    hipLaunchKernelGGL((k_obs_v<kSfmRec, 9, true>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
+                       c.obs_red.p, c.red_off.p, c.xred.p, c.vobs.p);
+  else if (c.f.n_sfm && c.n_lm)
+    hipLaunchKernelGGL((k_obs_v<kSfmRec, 9, false>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
                        c.obs_red.p, c.red_off.p, c.xred.p, c.vobs.p);
   if (c.f.n_proj && c.n_lm)
-    hipLaunchKernelGGL((k_obs_v<kProjRec, 6>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
-                       c.f.proj_J.p, c.obs_red.p + c.f.n_sfm, c.red_off.p, c.xred.p, c.vobs.p + 3 * c.f.n_sfm);
+    hipLaunchKernelGGL((k_obs_v<kProjRec, 6, false>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
+                       c.f.proj_J.p, st, c.obs_red.p + c.f.n_sfm, c.red_off.p, c.xred.p, c.vobs.p + 3 * c.f.n_sfm);
   if (c.n_lm)
     hipLaunchKernelGGL(k_backsub_lm, dim3(grid1(c.n_lm)), dim3(kBlock), 0, c.stream, c.n_lm, c.lm_owned.p,
                        c.lm_obs_ptr.p, c.lm_obs.p, c.vobs.p, c.Linv.p, c.ylm.p, c.delta_lm.p);

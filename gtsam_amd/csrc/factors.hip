@@ -4,10 +4,13 @@
 // measurements are read coalesced; the variable blocks are gathered from the packed Values, which for
 // the BAL configs is a 234 KB camera table (L2-resident) plus one 24-byte point per factor; each lane
 // writes its whitened record [A1 | A2 | b] contiguously (208 B for an SFM factor).
+// (Since round 5 the records of GeneralSFM factors are NOT stored when the graph has no smart factors: every kernel that needs one
+// recomputes it in its wavefront's LDS image, fused.h; k_lin_sfm then only runs for gtg_get_jacobians.)
 // Replaces NonlinearFactorGraph::linearize (nonlinear/NonlinearFactorGraph.cpp:239-278),
 // NonlinearFactorGraph::error (:170-179), GaussianFactorGraph::error (linear/GaussianFactorGraph.cpp:71-78)
 // and Values::retract (nonlinear/Values.cpp:52-63).
 #include "factors.h"
+#include "fused.h"
 #include "kernels.h"
 #include "recio.h"
 
@@ -36,15 +39,6 @@ __device__ __forceinline__ double block_sum(double v) {
     for (int w = 0; w < kBlock / 64; w++) r += sm[w];
   return r;
 }
-
-struct NoiseTab {
-  const int32_t* kind;
-  const int64_t* off;
-  const double* data;
-  const int32_t* rkind;
-  const double* rk;
-  __device__ __forceinline__ NoiseRef ref(int i) const { return NoiseRef{kind[i], data + off[i], rkind[i], rk[i]}; }
-};
 
 // ---- linearize ------------------------------------------------------------------------------------
 // chunk c of 64 consecutive factors belongs to wavefront c of the grid (grid-stride over chunks)
@@ -153,11 +147,15 @@ struct ErrArgs {
   const int32_t *smart_of, *smart_status;   // smart factors: the factor of an sfm observation (or -1) and its triangulation status
 };
 
-// One launch covers all factor types: block b handles a fixed slice, so the summation order is fixed.
+// Block b handles a fixed slice, so the summation order is fixed.  TYPES: bit 0 -- the GeneralSFM factors, bit 1 -- the other three
+// types.  (One kernel for all four types -- rounds 1-4 -- needed 256 registers + scratch for the union of their evaluators: one
+// wavefront per SIMD, 32 us for the 0.68 M factors of the L1723 shape, a gather-and-evaluate kernel that lives on occupancy.)
+template <int TYPES>
 __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __restrict__ values, NoiseTab nt,
                                                   double* __restrict__ partials) {
   double acc = 0.0;
   const int64_t tid = blockIdx.x * (int64_t)kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+  if constexpr ((TYPES & 1) != 0)
   for (int64_t i = tid; i < a.n_sfm; i += stride) {
     double c[17], p[3], zz[2];
     const double* cp = values + a.val_off[a.sfm_cam[i]];
@@ -169,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     // (a smart factor whose landmark did not triangulate has error 0, SmartProjectionFactor.h:407-427)
     if (!(a.smart_of && a.smart_of[i] >= 0 && a.smart_status[a.smart_of[i]] != kTriValid)) acc += sfm_error(c, p, zz, nt.ref(ni));
   }
+  if constexpr ((TYPES & 2) != 0) {
   for (int64_t i = tid; i < a.n_proj; i += stride) {
     double T[12], p[3], zz[2], K[kCalibStride], S[12];
     const double* tp = values + a.val_off[a.proj_pose[i]];
@@ -201,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_error(ErrArgs a, const double* __res
     const int ni = a.pr_nz[i];
     acc += prior_error(a.var_type[v], values + a.val_off[v], a.pr_data + a.pr_off[i], nt.ref(ni));
   }
+  }
   const double s = block_sum(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -225,10 +225,34 @@ struct LinErrArgs {
   const int32_t* var_type; const int64_t* dim_off;
 };
 
-__global__ __launch_bounds__(kBlock) void k_linear_error(LinErrArgs a, const double* __restrict__ delta,
+// FUSED: the records of the GeneralSFM factors are recomputed (fused.h) instead of read: chunk c of 64 consecutive factors belongs to
+// wavefront c of the grid, as in k_lin_sfm
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_linear_error(LinErrArgs a, SfmTabs t, const double* __restrict__ delta,
                                                          double* __restrict__ partials) {
+  typedef RecIO<kSfmRec> IO;
+  __shared__ double img[FUSED ? kBlock / 64 : 1][FUSED ? IO::LDS_DOUBLES : 1];
   double e0 = 0.0, e1 = 0.0;
   const int64_t tid = blockIdx.x * (int64_t)kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+  if constexpr (FUSED) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* J = img[wave] + lane * IO::PITCH;
+    const int64_t nchunks = (a.n_sfm + 63) / 64, cstride = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t ch = blockIdx.x * (int64_t)(kBlock / 64) + wave; ch < nchunks; ch += cstride) {
+      const int64_t i = ch * 64 + lane;
+      if (i >= a.n_sfm) continue;
+      sfm_record(t, i, J);
+      const double* dc = delta + a.dim_off[a.sfm_cam[i]];
+      const double* dp = delta + a.dim_off[a.sfm_pt[i]];
+      for (int r = 0; r < 2; r++) {
+        const double b = J[24 + r];
+        double v = -b;
+        for (int k = 0; k < 9; k++) v += J[9 * r + k] * dc[k];
+        for (int k = 0; k < 3; k++) v += J[18 + 3 * r + k] * dp[k];
+        e0 += b * b; e1 += v * v;
+      }
+    }
+  } else {
   for (int64_t i = tid; i < a.n_sfm; i += stride) {
     const double* J = a.sfm_J + (int64_t)kSfmRec * i;
     const double* dc = delta + a.dim_off[a.sfm_cam[i]];
@@ -240,6 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_linear_error(LinErrArgs a, const dou
       for (int k = 0; k < 3; k++) v += J[18 + 3 * r + k] * dp[k];
       e0 += b * b; e1 += v * v;
     }
+  }
   }
   for (int64_t i = tid; i < a.n_proj; i += stride) {
     const double* J = a.proj_J + (int64_t)kProjRec * i;
@@ -300,6 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(int64_t n, const double* __res
 
 // ---- launchers --------------------------------------------------------------------------------------
 static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p, c.noise_rkind.p, c.noise_rk.p}; }
+SfmTabs sfm_tabs(gtg_context& c) { return SfmTabs{c.f.sfm_cam.p, c.f.sfm_point.p, c.f.sfm_noise.p, c.f.sfm_z.p, c.values.p, c.val_off.p, noise_tab(c)}; }
 
 // ---- smart factors: the landmark of every factor from the cameras in `values` ------------------------------------------
 // One factor per lane.  What SmartProjectionFactor::triangulateSafe does (SmartProjectionFactor.h:127-183): re-triangulate only
@@ -423,7 +449,7 @@ void launch_smart_triangulate(gtg_context& c, double* values, const double* gate
 void launch_linearize(gtg_context& c) {
   auto& f = c.f;
   NoiseTab nt = noise_tab(c);
-  if (f.n_sfm)
+  if (f.n_sfm && !c.fused_sfm)     // (fused: nobody reads stored records of these factors, fused.h)
     hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p,
                        f.sfm_point.p, f.sfm_z.p, f.sfm_noise.p, c.values.p, c.val_off.p, nt, f.sfm_J.p,
                        c.n_smart ? c.sfm_smart.p : nullptr, c.smart_lin_status.p);
@@ -446,6 +472,15 @@ void launch_linearize(gtg_context& c) {
   check_hip(hipGetLastError(), "linearize");
 }
 
+// debug (gtg_get_jacobians on a graph whose GeneralSFM records are not stored): the records as k_lin_sfm writes them, into `dst`
+void launch_sfm_records(gtg_context& c, double* dst) {
+  auto& f = c.f;
+  if (!f.n_sfm) return;
+  hipLaunchKernelGGL(k_lin_sfm, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p, f.sfm_point.p, f.sfm_z.p,
+                     f.sfm_noise.p, c.values.p, c.val_off.p, noise_tab(c), dst, nullptr, nullptr);
+  check_hip(hipGetLastError(), "sfm_records");
+}
+
 void launch_error(gtg_context& c, const double* values, int slot, const double* gate) {
   auto& f = c.f;
   ErrArgs a{f.n_sfm, f.n_proj, f.n_between, f.n_prior,
@@ -454,10 +489,12 @@ void launch_error(gtg_context& c, const double* values, int slot, const double* 
             f.between_v1.p, f.between_v2.p, f.between_noise.p, f.between_z.p,
             f.prior_var.p, f.prior_noise.p, f.prior_off.p, f.prior_data.p,
             c.var_type.p, c.val_off.p, c.n_smart ? c.sfm_smart.p : nullptr, c.smart_status.p};
-  const int64_t nmax = std::max(std::max(f.n_sfm, f.n_proj), std::max(f.n_between, f.n_prior));
-  const int g = grid_for(nmax);
-  hipLaunchKernelGGL(k_error, dim3(g), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p);
-  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 1, c.scalars.p, slot);
+  // the GeneralSFM factors and the other types in a kernel each, their block partials one behind the other
+  const int64_t nrest = std::max(f.n_proj, std::max(f.n_between, f.n_prior));
+  const int g1 = f.n_sfm ? std::min(grid_for(f.n_sfm), kMaxBlocks / 2) : 0, g2 = (nrest || !g1) ? std::min(grid_for(nrest), kMaxBlocks / 2) : 0;
+  if (g1) hipLaunchKernelGGL(k_error<1>, dim3(g1), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p);
+  if (g2) hipLaunchKernelGGL(k_error<2>, dim3(g2), dim3(kBlock), 0, c.stream, a, values, noise_tab(c), c.partials.p + g1);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g1 + g2, 1, c.scalars.p, slot);
   if (c.n_smart)
     hipLaunchKernelGGL(k_error_smart_at_infinity, dim3(1), dim3(kBlock), 0, c.stream, f.n_sfm - c.smart_obs0, c.smart_obs0, f.sfm_cam.p, f.sfm_point.p,
                        f.sfm_z.p, f.sfm_noise.p, values, c.val_off.p, noise_tab(c), c.sfm_smart.p, c.smart_status.p,
@@ -472,7 +509,8 @@ void launch_linear_error(gtg_context& c) {
                f.sfm_J.p, f.proj_J.p, f.between_J.p, f.prior_J.p, c.var_type.p, c.dim_off.p};
   const int64_t nmax = std::max(std::max(f.n_sfm, f.n_proj), std::max(f.n_between, f.n_prior));
   const int g = grid_for(nmax);
-  hipLaunchKernelGGL(k_linear_error, dim3(g), dim3(kBlock), 0, c.stream, a, c.delta.p, c.partials.p);
+  if (c.fused_sfm) hipLaunchKernelGGL(k_linear_error<true>, dim3(g), dim3(kBlock), 0, c.stream, a, sfm_tabs(c), c.delta.p, c.partials.p);
+  else hipLaunchKernelGGL(k_linear_error<false>, dim3(g), dim3(kBlock), 0, c.stream, a, sfm_tabs(c), c.delta.p, c.partials.p);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kBlock), 0, c.stream, c.partials.p, g, 2, c.scalars.p, (int)SC_LIN0);
   check_hip(hipGetLastError(), "linear_error");
 }

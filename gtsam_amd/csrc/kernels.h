@@ -7,7 +7,8 @@
 namespace gt {
 
 // factors.hip -------------------------------------------------------------------------------------
-void launch_linearize(gtg_context& c);                                  // fills *_J from c.values
+void launch_linearize(gtg_context& c);                                  // fills *_J from c.values (not the GeneralSFM records of a fused graph: fused.h)
+void launch_sfm_records(gtg_context& c, double* dst);                    // debug: the GeneralSFM records of the current values into dst
 void launch_error(gtg_context& c, const double* values, int scalar_slot, const double* gate = nullptr);  // nonlinear error -> scalars[slot] (gate: as launch_smart_triangulate)
 void launch_linear_error(gtg_context& c);                               // scalars[SC_LIN0], [SC_LIN1] from J, delta
 void launch_retract(gtg_context& c);                                    // trial = values (+) delta ; scalars[SC_DELTA_SQ]

@@ -210,10 +210,10 @@ def main():
                                         allreduce=allreduce if world > 1 else None)
 
     torch.cuda.synchronize()
-    mem_free0 = torch.cuda.mem_get_info()[0]
+    mem_free0 = torch.cuda.mem_get_info()[0]     # (the first handle of the process: nothing is in the library's block cache yet)
     opt = fresh()
     torch.cuda.synchronize()
-    handle_bytes = mem_free0 - torch.cuda.mem_get_info()[0]      # device memory one handle takes from the driver (the library keeps nothing aside by default)
+    handle_bytes = mem_free0 - torch.cuda.mem_get_info()[0]      # device memory one handle takes from the driver
     n_red = opt.dev.reduced_dim
 
     def run_iterations(o, k, values_=None, params_=None):

@@ -36,24 +36,24 @@ void check_hip(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// Optional (GTG_ALLOC_CACHE_MB=n, default 0 = off): the big buffers of a handle (>= 16 MB: the E slots, the Jacobian records, the
-// term lists, the stored tiles of the reduced system) are kept for the next handle of the process when one is released instead of
-// going back to the driver, at most n MB per DEVICE; a kept block serves a request of 80 - 100 % of its size on the same device.  On
-// boxes where the driver clears device memory as it hands it out a fresh hipMalloc costs ~30 ms per GB, and programs construct
-// optimizers one after the other (GncOptimizer: one per outer iteration).  It was on by default (8 GB) in round 3, when the reduced
-// system was a dense (NP + 128) x NP array (1.9 GB on the L1723 shape, 31 GB on w20000); with the tile-indexed storage of round 4
-// (0.45 GB / < 1 GB) the cache is no longer needed for the set-up times and holds no memory that the process's other users (torch,
-// RCCL) cannot see unless it is asked to.  When an allocation fails, every kept block of that device is released and the
-// allocation is tried once more; gtg_release_cached_memory() releases them at any time.  Every such buffer is fully written by the
-// kernels before it is read, so recycled contents are never observed (GTG_ALLOC_POISON=1 fills a recycled block with NaNs first:
-// a debug mode the parity suite can be run under).
+// The big buffers of a handle (>= 16 MB: the E slots, the term lists, the stored tiles of the reduced system) are kept for the next
+// handle of the process when one is released instead of going back to the driver, at most GTG_ALLOC_CACHE_MB per DEVICE (default
+// 2048 = about one handle of the headline size, 0.7 % of the device's memory; 0 switches it off); a kept block serves a request of
+// 80 - 100 % of its size on the same device.  On boxes where the driver clears device memory as it hands it out a fresh hipMalloc costs
+// ~30 ms per GB -- 10.9 of the 33 ms of a warm set-up of the L1723 shape in round 4, when the default was 0 -- and programs construct
+// optimizers one after the other (GncOptimizer: one per outer iteration; the reference's own timing programs).  History of the
+// default: 8192 in round 3 (the reduced system was a dense 1.9 GB - 31 GB array then), 0 in round 4, 2048 since round 5.  When an
+// allocation fails, every kept block of that device is released and the allocation is tried once more;
+// gtg_release_cached_memory() releases them at any time.  Every such buffer is fully written by the kernels before it is read, so
+// recycled contents are never observed (GTG_ALLOC_POISON=1 fills a recycled block with NaNs first: a debug mode the parity suite
+// can be run under).
 namespace {
 struct KeptBlock { void* p; size_t bytes; int device; };
 std::mutex g_kept_mu;
 std::vector<KeptBlock> g_kept;
 constexpr size_t kKeepMin = (size_t)16 << 20;
 size_t keep_limit() {
-  static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 0L) << 20; }();
+  static const size_t lim = [] { const char* e = std::getenv("GTG_ALLOC_CACHE_MB"); return (size_t)(e ? std::max(0L, std::atol(e)) : 2048L) << 20; }();
   return lim;
 }
 size_t kept_bytes_on(int dev) { size_t b = 0; for (const auto& k : g_kept) if (k.device == dev) b += k.bytes; return b; }   // (g_kept_mu held)

@@ -291,10 +291,9 @@ int gtg_debug_reduced_order(gtg_handle h, int32_t* var_of_position, int32_t n);
  * out[15], the second wanted value, is replaced by a host counter: the lambda tries of this handle that were repeated with the
  * stream schedule after a time-out of the dataflow pass) */
 int gtg_debug_df_ctrl(gtg_handle h, int32_t out[16]);
-/* Device memory kept aside for the next handle (opt-in: GTG_ALLOC_CACHE_MB=n keeps released blocks of >= 16 MB, at most n MB per
- * device; default 0 = nothing is kept -- until round 3 the default was 8192: a caller that constructs many optimizers, e.g. GncOptimizer, and
- * ran faster with the kept blocks sets the variable): give every kept block back to the driver.  Returns the bytes released.  (A failed allocation
- * does this by itself before it gives up.) */
+/* Device memory kept aside for the next handle (released blocks of >= 16 MB, at most GTG_ALLOC_CACHE_MB per device: default 2048,
+ * 0 = nothing is kept; the default was 8192 in round 3 and 0 in round 4): give every kept block back to the driver.  Returns the bytes
+ * released.  (A failed allocation does this by itself before it gives up.) */
 int64_t gtg_release_cached_memory(void);
 /* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
  * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */

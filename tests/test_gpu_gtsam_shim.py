@@ -16,5 +16,6 @@ def test_cpp_shim_matches_reference_optimizer():
     if not os.path.exists(exe) or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgtsam_ref.so")):
         pytest.skip("prebuilt shim test / oracle/_ref did not travel")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("FAIL")))     # (the failed expectations first: the output is long)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ALL PASSED" in r.stdout

@@ -246,10 +246,10 @@ print("RESULT " + json.dumps(out))
 
 
 def test_big_device_blocks_are_kept_for_the_next_handle(stub):
-    """api.hip can keep released device blocks of >= 16 MB for the next handle of the process (opt-in: GTG_ALLOC_CACHE_MB, per device;
-    off by default since the reduced system is stored by tiles): with it the second construction of the same problem asks the
-    runtime for less memory, a block is only re-issued for a request of 80 - 100 % of its size, and gtg_release_cached_memory()
-    gives everything back; without it every construction allocates the same."""
+    """api.hip keeps released device blocks of >= 16 MB for the next handle of the process (GTG_ALLOC_CACHE_MB per device, default
+    2048, 0 = off): with it the second construction of the same problem asks the runtime for less memory, a block is only re-issued
+    for a request of 80 - 100 % of its size, and gtg_release_cached_memory() gives everything back; switched off, every
+    construction allocates the same."""
     code = '''
 import ctypes, json
 from tools import host_profile as HP
@@ -267,10 +267,12 @@ released = int(L.load().gtg_release_cached_memory())
 print("RESULT " + json.dumps({"reduced_dim": np_, "marks": marks, "released": released}))
 '''
     on = HP.run_snippet(code, env_extra={"GTG_ALLOC_CACHE_MB": "4096"})
-    off = HP.run_snippet(code)
+    off = HP.run_snippet(code, env_extra={"GTG_ALLOC_CACHE_MB": "0"})
+    dflt = HP.run_snippet(code)
     first, second, small, again = np.diff(on["marks"])
     f0, s0, m0, a0 = np.diff(off["marks"])
-    assert f0 == s0 == a0 == first and off["released"] == 0    # default: nothing is kept, every construction allocates the same
+    assert f0 == s0 == a0 == first and off["released"] == 0    # switched off: nothing is kept, every construction allocates the same
+    assert np.diff(dflt["marks"])[1] <= first - (16 << 20) and dflt["released"] >= 16 << 20      # the default keeps them too
     assert second <= first - (16 << 20) and again <= first - (16 << 20)   # with the cache the big blocks are re-issued ...
     assert small == m0                                          # ... but not to a much smaller problem
     assert on["released"] >= 16 << 20                           # and the release call hands them back

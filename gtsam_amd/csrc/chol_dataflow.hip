@@ -50,7 +50,7 @@ constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finis
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
 constexpr size_t kSmemPotrf = sizeof(double) * kPotrfSmemDoubles;
-constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 * SB * PB;   // + one 128 x 32 slice of the tile below
+constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * (4 * SB * PB + kImgDoubles);   // + one 128 x 32 slice of the tile left of it + one operand image (hand-over)
 // flag values: epoch * 8 + steps; a tile (I, J) is final at 4 steps (its four 32-column blocks), a diagonal tile's word in
 // its Dinv slot counts released panels, pd_flag is epoch * 8 + 4 when the accumulated diagonal tile is in
 __device__ __forceinline__ long long final_of(long long epoch) { return epoch * 8 + 4; }
@@ -80,6 +80,9 @@ constexpr int kHandoffAux = 16;   // cache-policy bits of the LDS-DMA that reads
 // -DGTG_DF_FENCES=1 builds the textbook release / acquire protocol for comparison.
 #ifndef GTG_DF_FENCES
 #define GTG_DF_FENCES 0
+#endif
+#ifndef GT_DF_HANDOVER
+#define GT_DF_HANDOVER 1
 #endif
 __device__ __forceinline__ void st_wt(double* p, double v) {
 #if GTG_DF_FENCES
@@ -200,7 +203,9 @@ template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
                                            long long* __restrict__ myflag, const long long* __restrict__ pflag, double* __restrict__ Xinv_all,
                                            double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg,
-                                           long long* __restrict__ tr) {
+                                           long long* __restrict__ tr, const long long* __restrict__ img2_flag, long long* __restrict__ r3_flag) {
+  // (img2_flag / r3_flag != nullptr: this is the tile right below the diagonal tile of a single chain -- the HAND-OVER of chain_loop: the
+  // last block column stops at the residual R_3', which goes to the chain workgroup of the next diagonal tile)
   // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
   // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
   // L(p, q-1), p >= q, are out by then as well):
@@ -223,16 +228,21 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   double* W = reinterpret_cast<double*>(smem_raw) + rt * (16 * PX);
   double* img = reinterpret_cast<double*>(smem_raw) + 8 * 16 * PX;
   long long pf = ld_flag(pflag);   // released panels of the diagonal tile, as last seen (monotonic)
+  const bool handover = r3_flag != nullptr;   // (workgroup-uniform)
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    if (pf < flagbase + q + 1) {
+    // Step q needs panel q of the diagonal tile -- except the LAST step of a hand-over tile, which only goes as far as the update with
+    // L(3, 2): that image is released on a word of its own early in panel 3 (chol_device.h, PotrfHandover::img2_flag)
+    if (q == 3 && handover) {
+      wait_flags(img2_flag, final_of(epoch), img2_flag, final_of(epoch), fail, sh, dbg, 8, I, J, q);
+    } else if (pf < flagbase + q + 1) {
       wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, sh, dbg, 3, I, J, q);
       pf = flagbase + q + 1;
     }
     if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
-    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
-    __syncthreads();   // the previous step's images have been consumed; -X_{q-1} is complete in the W patches and out of every wavefront
-    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q, sh);
+    // (X_{q-1} was published at the end of step q - 1: behind its barrier the previous step's images have been consumed and -X_{q-1} is
+    // complete in the W patches.  Until round 4 the drain, the barrier and the flag of X_{q-1} stood HERE, behind the wait for panel q:
+    // 1.5 us of the serial chain's last step that did not belong there.)
     {  // images of this step: slots 0 .. 3-q = L(q + s, q - 1) (q > 0), slot 3 = Linv(q,q); wavefront w moves 1 KiB pieces
       // (w & 7) of the slots (w >> 3) and (w >> 3) + 2
 #pragma unroll
@@ -240,7 +250,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
         const int sl = (wave >> 3) + 2 * j;           // uniform
         const int p = q + sl;
         const int blk = (sl == 3) ? 6 + q : p * (p - 1) / 2 + (q - 1);
-        if ((sl == 3) || (q > 0 && p < 4))
+        if ((sl == 3 && !(q == 3 && handover)) || (sl != 3 && q > 0 && p < 4))
           __builtin_amdgcn_global_load_lds((gptr_t)(Xinv + kOpndBase + (size_t)blk * kImgDoubles + 128 * (wave & 7) + 2 * lane),
                                            (lptr_t)(img + sl * kImgDoubles + 128 * (wave & 7)), 16, 0, kHandoffAux);
       }
@@ -265,6 +275,22 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
           for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bl[s], x[2 * l + t]);
         }
       }
+    }
+    if (q == 3 && handover) {
+      // R_3' is complete in the accumulators of the column half h = 1: into the tile's last block column (where X_3 will stand), write-through,
+      // and the word that tells the chain workgroup of diagonal tile I.  This workgroup is done with the tile: X_3 = R_3' Linv(3,3)^T is
+      // formed by the chain workgroup itself the moment panel 3 is released (chain_loop) -- the same MFMAs on the same operands in the
+      // same order: the same bits.
+      if (h == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 32 + 16 * t) + lane_off, x[2 + t][r]);
+      }
+      stores_done();
+      __syncthreads();
+      if (tid == 0) st_flag(r3_flag, final_of(epoch), sh);
+      return;
     }
     __syncthreads();   // both wavefronts of a row tile have read -X_{q-1}: the patch is free for R_q
 #pragma unroll
@@ -298,10 +324,12 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
           st_wt((Crow + (4 * r) * T + 32 * l + 16 * t) + lane_off, v);
         }
     }
+    // X_q is out: every storing wavefront waits for its own stores, the workgroup barriers (which also fences the image slots and the W
+    // patches for the next step), one lane publishes
+    stores_done();
+    __syncthreads();
+    if (tid == 0) st_flag(myflag, flagbase + q + 1, sh);
   }
-  stores_done();
-  __syncthreads();
-  if (tid == 0) st_flag(myflag, flagbase + 4, sh);
 }
 
 
@@ -309,7 +337,11 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
-                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
+                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr,
+                                         int handover, int nt) {
+  // (handover: this tile's last block column is finished by the chain workgroup of diagonal tile I, see substitute / chain_loop; the
+  // words of the hand-over live behind the nt words of pd_flag: [nt + J] images of panel 2 of diagonal tile J out, [2 nt + J] R_3' of
+  // tile (J + 1, J) in memory)
   // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
   // the persistent task loop and kept alive across it
   int tid_ = threadIdx.x;
@@ -460,8 +492,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
-  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
+  const long long* img2 = handover ? pd_flag + nt + J : nullptr;
+  long long* r3 = handover ? pd_flag + 2 * nt + J : nullptr;
+  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr, img2, r3);
+  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr, img2, r3);
 }
 
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, const int32_t* __restrict__ tasks,
@@ -470,7 +504,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
                                           long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                           double* __restrict__ fail, const long long epoch, const long long sh,
-                                          long long* __restrict__ trace) {
+                                          long long* __restrict__ trace, int nt) {
   __shared__ int s_task;
   for (;;) {
     if (threadIdx.x == 0) s_task = atomicAdd(ctrl, 1);
@@ -478,7 +512,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot, hand-over
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -486,7 +520,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr, d[10], nt);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -499,9 +533,9 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                                     double* __restrict__ fail, const long long epoch, const long long sh,
-                                                    long long* __restrict__ trace) {
+                                                    long long* __restrict__ trace, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, nt);
 }
 #endif
 
@@ -512,13 +546,14 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
 // them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
 // substitution steps of the tiles below through the tile's progress word).
 __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, double* __restrict__ Xinv_all,
-                                           const long long* __restrict__ pd_flag, long long* tile_flag,
+                                           long long* __restrict__ pd_flag, long long* tile_flag,
                                            const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                            const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
-                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
+                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp, int nt) {
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
+  double* Li = X + 4 * SB * PB;                                                       // one operand image (hand-over): Linv(3,3) of the tile before
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   for (int it = 0; it < n_mine; it++) {
     const int J = my_tiles[it];
@@ -532,13 +567,27 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     // The update of the block column right before this tile is applied HERE, in 32-column slices as the substitution of tile (J, J-1)
     // publishes them (the last slice is the only thing left when that tile is final).
+    //
+    // THE HAND-OVER (round 5; one chain, chain_slots[3 J + 2] > 0).  Until round 4 the last slice travelled diagonal tile J-1 (panel 3
+    // released) -> bulk workgroup (poll, fetch of two operand images, two MFMA phases, X_3 stored and acknowledged, flag) -> here (poll,
+    // fetch of the slice): 9.7 + 4 us of a 40 us chain period, five dependent memory round trips (round 5 trace: "sub done after seeing
+    // panel 3" 8.8 us).  Now the bulk workgroup stops at the residual  R_3' = R_3 - X_0 L(3,0)^T - X_1 L(3,1)^T - X_2 L(3,2)^T  -- which
+    // needs nothing of panel 3: the image L(3, 2) is released on its own word early in panel 3 (PotrfHandover::img2_flag) -- and publishes
+    // it (pd_flag[2 nt + J - 1]); this workgroup, which is idle while its partner factors tile J-1, has R_3' in LDS before panel 3 is
+    // out, and when it is: ONE poll, ONE 8 KB fetch (Linv(3,3)), X_3 = R_3' Linv(3,3)^T on the matrix core -- the same products in the
+    // same order as substitute(): the same bits -- the slice update from LDS, pivots.  X_3 goes to memory write-through for everybody
+    // else, and its tile's final flag follows with panel 0's release (potrf_body: the first barrier behind which all stores are drained).
     const int sslot = chain_slots[3 * J + 1];
+    const bool handover = sslot >= 0 && chain_slots[3 * J + 2] > 0;
     if (sslot >= 0) {
-      const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
+      double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
+        const bool ho = q == 3 && handover;
+        const long long* wf = ho ? pd_flag + 2 * nt + (J - 1) : sflag;
+        const long long wv = ho ? final_of(epoch) : epoch * 8 + q + 1;
+        if (tid < 64) wait_flags(wf, wv, wf, wv, fail, sh, ctrl + 8, ho ? 9 : 5, J, J - 1, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
@@ -546,7 +595,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
-            const double* src = sub + row * T + SB * q + c2;   // X_q of the substitution: handed over (sc1 loads)
+            const double* src = sub + row * T + SB * q + c2;   // X_q of the substitution (hand-over: R_3'): handed over (sc1 loads)
 #if GTG_DF_FENCES
             v[u] = *reinterpret_cast<const double2*>(src);
 #else
@@ -559,6 +608,47 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
             const int e = u * 512 + tid, row = e >> 4, c2 = 2 * (e & 15);
             double* d = X + (row >> 5) * SB * PB + (row & 31) * PB + c2;
             d[0] = v[u].x; d[1] = v[u].y;
+          }
+        }
+        if (ho) {
+          // panel 3 of diagonal tile J-1 (its word is the flag word of that tile's slot): Linv(3,3) is out
+          const long long* pf = tile_flag + chain_slots[3 * (J - 1)];
+          if (tid < 64) wait_flags(pf, epoch * 8 + 4, pf, epoch * 8 + 4, fail, sh, ctrl + 8, 10, J, J - 1, 3);
+          __syncthreads();   // (also: R_3' is complete in X)
+          acquired();
+          {
+            const double* src = Xinv_all + (size_t)(J - 1) * T * T + kOpndBase + (size_t)9 * kImgDoubles + 2 * tid;   // image 6 + 3: Linv(3,3)
+            const double i0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double i1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Li[2 * tid] = i0; Li[2 * tid + 1] = i1;
+          }
+          __syncthreads();
+          {
+            // wavefront w: rows 16 w .. 16 w + 15 of X_3 = R_3' Linv(3,3)^T, both 16-column tiles; operands and order of substitute()
+            double* Rw = X + (wave >> 1) * SB * PB + ((wave & 1) * 16) * PB;
+            double a[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) a[s2] = Rw[lr * PB + 8 * lk + s2];
+            v4f64 xx[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+              double bi[8];
+#pragma unroll
+              for (int s2 = 0; s2 < 8; s2++) bi[s2] = Li[(t * 64 + lane) * 8 + s2];
+              xx[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int s2 = 0; s2 < 8; s2++) xx[t] = MFMA(a[s2], bi[s2], xx[t]);
+            }
+            GT_WAVE_SYNC();   // every lane of the wavefront has read its operands of R_3' before X_3 overwrites those rows
+            double* Gw = sub + (size_t)(16 * wave) * T + 3 * SB;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const double v = xx[t][r];
+                Rw[(lk + 4 * r) * PB + 16 * t + lr] = v;
+                st_wt(Gw + (lk + 4 * r) * T + 16 * t + lr, v);
+              }
           }
         }
         __syncthreads();
@@ -579,8 +669,11 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
+    PotrfHandover ho;
+    if (J + 1 < nt && chain_slots[3 * (J + 1) + 2] > 0) { ho.img2_flag = pd_flag + nt + J; ho.img2_value = final_of(epoch); }   // the tile below hands over
+    if (handover) { ho.sub_final_flag = tile_flag + sslot; ho.sub_final_value = epoch * 8 + 4; }                                // X_3 of the tile left of this one: stored above
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
-               deferred ? X : nullptr);
+               deferred ? X : nullptr, ho);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
@@ -588,15 +681,15 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
 
 #ifndef GT_KERNEL_EMU
 __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, double* __restrict__ Xinv_all,
-                                                     const long long* __restrict__ pd_flag, long long* tile_flag,
+                                                     long long* __restrict__ pd_flag, long long* tile_flag,
                                                      const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                                      const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
-                                                     const int32_t* __restrict__ chain_tiles) {
+                                                     const int32_t* __restrict__ chain_tiles, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
-             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
+             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, nt);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): the first n_chain workgroups are the chain (dispatched first, so they are resident before
@@ -611,10 +704,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
-                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
+                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
-  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, nt); }
+  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, nt);
 }
 
 __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
@@ -822,6 +915,10 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     if (q < 0) throw std::runtime_error("dataflow plan: a tile of the task list has no slot in the stored-tile list");
     return q;
   };
+  // The hand-over of the last block column between consecutive diagonal tiles (chain_loop) is planned for ONE chain: with several chains
+  // (parts of a nested dissection) the block columns are taken in an interleaved order and the critical tasks are not pulled forward.
+  // (GT_DF_HANDOVER=0 at compile time: the flow of rounds 2-4, the A/B; the fenced protocol build keeps that flow as well.)
+  const bool handover_plan = GT_DF_HANDOVER != 0 && GTG_DF_FENCES == 0 && df.n_chain == 2 && nt > 1;
   {
     // accumulator lanes of the tiles with very long contraction lists (run_task): G - 1 scratch slots each, behind the stored tiles
     constexpr int lane_min = 8;   // early pieces from which a tile gets lanes
@@ -846,7 +943,8 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
       { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
-      dt.push_back(0); dt.push_back(0);
+      // [10]: hand-over (substitute / chain_loop): the final piece of the tile right below a diagonal tile of a single chain
+      dt.push_back((handover_plan && I == J + 1 && I < nt && d[4] == d[5] - 1 && (has_sub[I] & 1)) ? 1 : 0); dt.push_back(0);
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
         dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);
@@ -856,14 +954,14 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
     std::vector<int32_t> cs(3 * (size_t)nt, -1);
-    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); }
-    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, one spare word)
+    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) { cs[3 * J + 1] = slot_of(J, J - 1); cs[3 * J + 2] = handover_plan ? 1 : -1; } }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, > 0: that tile's last block column is handed over as R_3')
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
-  df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included)
+  df.shadow = (std::max<int64_t>(n_slots + df.n_scratch, 3 * (int64_t)nt) + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included; pd_flag: nt words + 2 nt of the hand-over)
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
@@ -946,7 +1044,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
                        df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
-                       df.chain_off.p, df.chain_tiles.p, df.n_chain);
+                       df.chain_off.p, df.chain_tiles.p, df.n_chain, nt);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -964,10 +1062,10 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
   hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p, nt);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, nt);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
@@ -979,7 +1077,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   constexpr int extra = 6;
   if (df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, nt);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");

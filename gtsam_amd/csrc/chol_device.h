@@ -403,8 +403,10 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* tile, double* __r
 //               matters -- are in memory, i.e. early in panel 3 instead of with panel 3's release: the substitution of the tile below
 //               can then finish its residual R_3' = R_3 - X_0 L(3,0)^T - X_1 L(3,1)^T - X_2 L(3,2)^T while panel 3's pivots run.
 //   sub_final_flag : the flag word of the tile LEFT of this diagonal tile, whose last 32-column block X_3 the chain workgroup formed
-//               itself and stored write-through before it entered this body: published (sub_final_value) behind the first barrier at
-//               which every wavefront has drained its stores -- the late release of panel 0.
+//               itself and stored write-through right before it entered this body -- from every wavefront but the pivot wavefront 0,
+//               which must not wait for memory: the seven others wait for their own stores at the top of panel 0 and count; the last
+//               one publishes the word (sub_final_value).  Their panel-0 roles start ~2 us late and catch up (a follower step is a
+//               third of a pivot step).
 struct PotrfHandover {
   long long* img2_flag = nullptr; long long img2_value = 0;
   long long* sub_final_flag = nullptr; long long sub_final_value = 0;
@@ -430,11 +432,18 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-  if (tid == 0) { prog[0] = 0; prog[1] = 0; prog[2] = 0; }   // ([2]: wavefronts that have the images of panel 2 in memory, see ho.img2_flag)
+  if (tid == 0) { prog[0] = 0; prog[1] = 0; prog[2] = 0; prog[3] = 0; }   // ([2]: wavefronts that have the images of panel 2 in memory, [3]: ... X_3 of the tile left of this one: PotrfHandover)
   STAMP(0);
   if (!preloaded) diag_tile_to_lds(tile, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();
   STAMP(1);
+  if (ho.sub_final_flag && wave != 0) {
+    GT_DRAIN_STORES();
+    if (lane == 0 && atomicAdd(prog + 3, 1) == 6) {
+      (void)__hip_atomic_exchange(ho.sub_final_flag, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pflag_shadow) __hip_atomic_store(ho.sub_final_flag + pflag_shadow, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // rank test at the variables' block ends (see stage_potrf): pivot kinds of this tile's columns, exponent of the pivot before it
   const unsigned char* pk = pivot_kind ? pivot_kind + (size_t)k * T : nullptr;
   int prev_exp = 0;
@@ -511,10 +520,6 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     {
       (void)__hip_atomic_exchange(pflag, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (chol_dataflow.hip::st_flag)
       if (pflag_shadow) __hip_atomic_store(pflag + pflag_shadow, flagbase + jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (jb == 0 && ho.sub_final_flag) {   // every wavefront's stores of X_3 (made in front of this body) are acknowledged as well
-        (void)__hip_atomic_exchange(ho.sub_final_flag, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pflag_shadow) __hip_atomic_store(ho.sub_final_flag + pflag_shadow, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
     STAMP(4 + 3 * jb);
   }

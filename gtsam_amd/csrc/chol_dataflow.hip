@@ -543,13 +543,16 @@ __device__ __attribute__((noinline)) void chain_substitute_early(double* __restr
                                                            const long long* __restrict__ pf, const long long* __restrict__ img2,
                                                            const long long* __restrict__ rf, const double* __restrict__ Xinv,
                                                            double* __restrict__ fail, const long long epoch, const long long sh,
-                                                           int32_t* __restrict__ dbg, int J) {
+                                                           int32_t* __restrict__ dbg, int J, long long* __restrict__ tr) {
+  // (tr: GTG_DF_TRACE stamps of this diagonal tile: [2] contraction of the tile left of it seen, [3..5] X_0 .. X_2 in the slice buffer,
+  // [6] R_3' ready; chain_loop adds [7] panel 3 of the tile before seen)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const long long fb = epoch * 8;
   {
     if (tid < 64) wait_flags(rf, final_of(epoch), rf, final_of(epoch), fail, sh, dbg, 9, J, J - 1, 0);
     __syncthreads();
     acquired();
+    if (tr && tid == 0) tr[2] = wall_clock64();
   }
   v4f64 x[8];     // x[c][r] = R[16 wave + lk + 4 r][16 c + lr]
   {
@@ -574,8 +577,13 @@ __device__ __attribute__((noinline)) void chain_substitute_early(double* __restr
       const long long* wf = q == 3 ? img2 : pf;
       const long long wv = q == 3 ? final_of(epoch) : fb + q + 1;
       if (tid < 64) wait_flags(wf, wv, wf, wv, fail, sh, dbg, 10, J, J - 1, q);
-      __syncthreads();
+      // X_{q-1} for everybody else: its stores were issued a whole wait ago -- the acknowledgements have arrived for free (with the drain,
+      // the barrier and the flag at the END of step q - 1 a step took 8 us, more than the 6.5 us between two panels: this workgroup fell
+      // behind its partner; measured, profiles/r05d)
+      stores_done();
+      __syncthreads();   // (also: the slice update has read X_{q-1} long ago -- this step's patch may overwrite it)
       acquired();
+      if (tid == 0) st_flag(sflag, fb + q, sh);
 #pragma unroll
       for (int p = q; p < 4; p++) load_image(p * (p - 1) / 2 + (q - 1), p - q);
       __syncthreads();
@@ -599,6 +607,7 @@ __device__ __attribute__((noinline)) void chain_substitute_early(double* __restr
     if (q == 3) {
       // R_3' -> A-operand layout in this wavefront's own rows of the slice buffer (every lane has read its operands of X_2 above: the
       // MFMAs depend on them); the rest of the step belongs to chain_loop
+      if (tr && tid == 0) tr[6] = wall_clock64();
       GT_WAVE_SYNC();
 #pragma unroll
       for (int t = 0; t < 2; t++)
@@ -646,10 +655,8 @@ __device__ __attribute__((noinline)) void chain_substitute_early(double* __restr
         while (rem > ib) { rem -= ib + 1; ib++; }
         slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
       }
-      // X_q for everybody else: this workgroup has time here (its partner is in the middle of tile J-1)
-      stores_done();
-      __syncthreads();   // (also: the slice update has read X_q -- the next step's patch may overwrite it)
-      if (tid == 0) st_flag(sflag, fb + q + 1, sh);
+      if (tr && tid == 0) tr[3 + q] = wall_clock64();
+      // (X_q's flag: at the top of the next step, behind its wait)
     }
   }
 }
@@ -675,7 +682,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, sh, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
-    if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
+    if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[8 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1) (-1: not stored)
     double* tile = S + (int64_t)dslot * TT;
     bool deferred = false;
@@ -703,12 +710,13 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
       double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* pf = tile_flag + chain_slots[3 * (J - 1)];   // panels of diagonal tile J-1
       const double* Xinv = Xinv_all + (size_t)(J - 1) * T * T + kOpndBase;
-      chain_substitute_early(A, X, Li, sub, tile_flag + sslot, pf, pd_flag + nt + (J - 1), pd_flag + 2 * nt + (J - 1), Xinv, fail, epoch, sh, ctrl + 8, J);
+      chain_substitute_early(A, X, Li, sub, tile_flag + sslot, pf, pd_flag + nt + (J - 1), pd_flag + 2 * nt + (J - 1), Xinv, fail, epoch, sh, ctrl + 8, J, trace ? trace + 8 * J : nullptr);
       // ---- X_3 = R_3' Linv(3,3)^T: panel 3 of diagonal tile J-1 -- THE wait of the serial chain.  (The barrier behind it is also the one
       // that separates the slice buffer's patch writes of the call above from anybody's reads.)
       if (tid < 64) wait_flags(pf, epoch * 8 + 4, pf, epoch * 8 + 4, fail, sh, ctrl + 8, 11, J, J - 1, 3);
       __syncthreads();
       acquired();
+      if (trace && tid == 0) trace[8 * J + 7] = wall_clock64();
       {
         const double* src = Xinv + (size_t)9 * kImgDoubles + 2 * tid;   // image 6 + 3: Linv(3,3), 16 bytes per thread
         const double i0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -803,7 +811,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
                deferred ? X : nullptr, ho);
     __syncthreads();
-    if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
+    if (trace && tid == 0) trace[8 * J + 1] = wall_clock64();
   }
 }
 
@@ -1096,7 +1104,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
   df.shadow = (std::max<int64_t>(n_slots + df.n_scratch, 3 * (int64_t)nt) + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included; pd_flag: nt words + 2 nt of the hand-over)
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
-  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
+  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 8 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");

@@ -268,7 +268,7 @@ int gtg_destroy(gtg_handle c) {
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
-                            &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.proj_pose, &f.proj_point,
+                            &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.sfm_cam_at, &f.sfm_point_at, &f.proj_pose, &f.proj_point,
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
                             &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,
@@ -463,6 +463,10 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     }
     f.n_sfm = (int64_t)cam.size();
     up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
+    if (c->val_size >= (int64_t)1 << 31) throw std::invalid_argument("gtg_upload_problem: more than 2^31 packed value entries");
+    { std::vector<int32_t> ca(cam.size()), pa(pt.size());
+      for (size_t i = 0; i < cam.size(); i++) { ca[i] = (int32_t)c->h_val_off[cam[i]]; pa[i] = (int32_t)c->h_val_off[pt[i]]; }
+      up(f.sfm_cam_at, ca, s); up(f.sfm_point_at, pa, s); }
     f.sfm_J.alloc(c->fused_sfm ? 1 : std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
     hi.sfm_cam = std::move(cam); hi.sfm_point = std::move(pt);
   }

@@ -442,25 +442,29 @@ __global__ __launch_bounds__(kBlock) void k_obs_v(int64_t n, const double* __res
 
 // One wavefront per reduced variable: damped diagonal block into S, rhs entries g - sum E y (the summands w_o = E_o y_l come from
 // k_obs_E) into the extra row NP of S.
-__global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
+constexpr int kDiagWaves = 4;   // (one wavefront per variable until round 5: 1 723 wavefronts on 256 CUs walked ~6 dependent gathers each, 90 - 146 us)
+__global__ __launch_bounds__(64 * kDiagWaves) void k_build_diag(int32_t n_red_vars, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, int64_t n_sfm,
     const double* __restrict__ Hd, const double* __restrict__ g, const double* __restrict__ hdiag,
     const double* __restrict__ W, double invsigma,
     int diag, double dmin, double dmax, int add_damping, SMat S) {
+  __shared__ double part[kDiagWaves][9];
   const int r = blockIdx.x;
   if (r >= n_red_vars) return;
   const int d = red_dim[r];
   const int64_t off = red_off[r];
-  const int lane = threadIdx.x;
-  for (int e = lane; e < d * d; e += 64) {
-    const int i = e / d, j = e % d;
-    double v = Hd[(int64_t)81 * r + e];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < d * d) {
+    const int i = tid / d, j = tid % d;
+    double v = Hd[(int64_t)81 * r + tid];
     if (i == j && add_damping) v += damp_term(hdiag[off + i], invsigma, diag, dmin, dmax);
     if (double* q = S.at_stored(off + i, off + j)) *q = v;
   }
+  // rhs: g - sum of the observations' summands, each thread every (64 kDiagWaves)-th entry of the variable's list, then lanes, then
+  // wavefronts: a fixed order
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t k = inc_ptr[r] + lane; k < inc_ptr[r + 1]; k += 64) {
+  for (int64_t k = inc_ptr[r] + tid; k < inc_ptr[r + 1]; k += 64 * kDiagWaves) {
     const int kind = inc_kind[k];
     if (kind > INC_PROJ) continue;
     const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
@@ -468,9 +472,15 @@ __global__ __launch_bounds__(64) void k_build_diag(int32_t n_red_vars, const int
     for (int i = 0; i < d; i++) acc[i] += wo[i];
   }
   for (int i = 0; i < 9; i++)
-    for (int s = 32; s > 0; s >>= 1) acc[i] += __shfl_down(acc[i], s, 64);
+    for (int s2 = 32; s2 > 0; s2 >>= 1) acc[i] += __shfl_down(acc[i], s2, 64);
   if (lane == 0)
-    for (int i = 0; i < d; i++) *S.at((int64_t)kTile * S.nt, off + i) = g[(int64_t)9 * r + i] - acc[i];   // rhs row
+    for (int i = 0; i < 9; i++) part[wave][i] = acc[i];
+  __syncthreads();
+  if (tid < d) {
+    double sum = 0.0;
+    for (int w = 0; w < kDiagWaves; w++) sum += part[w][tid];
+    *S.at((int64_t)kTile * S.nt, off + tid) = g[(int64_t)9 * r + tid] - sum;   // rhs row
+  }
 }
 
 __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int32_t* __restrict__ row,
@@ -744,7 +754,7 @@ void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, 
   const SMat S = smat(c);
   launch_zero_tiles(c, S, c.plan);
   if (c.n_red_vars)
-    hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
+    hipLaunchKernelGGL(k_build_diag, dim3(c.n_red_vars), dim3(64 * kDiagWaves), 0, c.stream, c.n_red_vars, c.red_inc_ptr.p,
                        c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, c.f.n_sfm, c.Hd.p,
                        c.gred0.p, c.hdiag_red.p, c.wobs.p, is, diag, dmin, dmax, c.shard == 0 ? 1 : 0, S);
   if (c.n_hoff)

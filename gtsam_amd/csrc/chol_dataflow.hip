@@ -50,7 +50,7 @@ constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finis
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
 constexpr size_t kSmemPotrf = sizeof(double) * kPotrfSmemDoubles;
-constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * (4 * SB * PB + 3 * kImgDoubles);   // + one 128 x 32 slice of the tile left of it + three operand images (hand-over)
+constexpr size_t kSmemChain = (kSmemPotrf + 15) / 16 * 16 + sizeof(double) * 4 * SB * PB;   // + one 128 x 32 slice of the tile below
 // flag values: epoch * 8 + steps; a tile (I, J) is final at 4 steps (its four 32-column blocks), a diagonal tile's word in
 // its Dinv slot counts released panels, pd_flag is epoch * 8 + 4 when the accumulated diagonal tile is in
 __device__ __forceinline__ long long final_of(long long epoch) { return epoch * 8 + 4; }
@@ -80,9 +80,6 @@ constexpr int kHandoffAux = 16;   // cache-policy bits of the LDS-DMA that reads
 // -DGTG_DF_FENCES=1 builds the textbook release / acquire protocol for comparison.
 #ifndef GTG_DF_FENCES
 #define GTG_DF_FENCES 0
-#endif
-#ifndef GT_DF_HANDOVER
-#define GT_DF_HANDOVER 1
 #endif
 __device__ __forceinline__ void st_wt(double* p, double v) {
 #if GTG_DF_FENCES
@@ -140,43 +137,36 @@ __device__ __forceinline__ bool timed_out(const double* fail) {
 }
 // Every lane of the calling wavefront polls the same words (one broadcast load); bounded: see the file comment.
 // The first wait that gives up leaves a record (what it waited for) in dbg[0..7] (gtg_debug_df_ctrl).
-// The rare part of a wait -- looked at every 256 fruitless polls -- out of line: time-out test, shadow words, read-modify-write poll, the
-// post-mortem record.  (Inlined at each of the ~25 wait sites of the two kernels it cost every site the registers of its widest path; the
-// chain kernel, whose diagonal-tile body needs all 256, spilled around every wait.)  Returns true when the wait is over.
-__device__ __attribute__((noinline)) bool wait_slow(const long long* f1, long long v1, const long long* f2, long long v2, double* fail, long long sh,
-                                                    int32_t* dbg, int kind, int a, int b, int c, int spins, long long* t0) {
-  if (timed_out(fail)) return true;
-  if (spins == 256) *t0 = wall_clock64();
-  if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
-    if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
-    return true;
-  }
-  if ((spins & 1023) == 512 && ld_flag_rmw(f1) >= v1 && ld_flag_rmw(f2) >= v2) {    // ... or ask the point of coherence
-    if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 1, 1);   // ctrl[7]: waits that ended on the read-modify-write poll
-    return true;
-  }
-  if (wall_clock64() - *t0 > kWaitTicks) {
-    if (dbg && atomicCAS(dbg, 0, kind) == 0) {
-      dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
-      // post-mortem (ctrl[2..3]): where the waiter runs
-      unsigned xcc, hw;
-      GT_XCC_ID(xcc);
-      GT_HW_ID(hw);
-      dbg[-6] = (int)(xcc & 0xf); dbg[-5] = (int)hw;
-    }
-    // (write-through: the other XCDs' waiters poll this word and must see it while the kernels are still running)
-    __hip_atomic_store(fail + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-  }
-  return false;
-}
 __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail, long long sh,
                                            int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
   int spins = 0;
   long long t0 = 0;
   while (ld_flag(f1) < v1 || ld_flag(f2) < v2) {
     __builtin_amdgcn_s_sleep(4);
-    if ((++spins & 255) == 0 && wait_slow(f1, v1, f2, v2, fail, sh, dbg, kind, a, b, c, spins, &t0)) break;
+    if ((++spins & 255) == 0) {
+      if (timed_out(fail)) break;
+      if (spins == 256) t0 = wall_clock64();
+      if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
+        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
+        break;
+      }
+      if ((spins & 1023) == 512 && ld_flag_rmw(f1) >= v1 && ld_flag_rmw(f2) >= v2) {    // ... or ask the point of coherence
+        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 1, 1);   // ctrl[7]: waits that ended on the read-modify-write poll
+        break;
+      }
+      if (wall_clock64() - t0 > kWaitTicks) {
+        if (dbg && atomicCAS(dbg, 0, kind) == 0) {
+          dbg[1] = a; dbg[2] = b; dbg[3] = c; dbg[4] = (int)ld_flag(f1); dbg[5] = (int)ld_flag(f2); dbg[6] = (int)v1; dbg[7] = (int)v2;
+          // post-mortem (ctrl[2..3]): where the waiter runs
+          unsigned xcc, hw;
+          GT_XCC_ID(xcc);
+          GT_HW_ID(hw);
+          dbg[-6] = (int)(xcc & 0xf); dbg[-5] = (int)hw;
+        }
+        // (write-through: the other XCDs' waiters poll this word and must see it while the kernels are still running)
+        __hip_atomic_store(fail + 1, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+      }
+    }
   }
   acquired();
 }
@@ -319,10 +309,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
-                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr,
-                                         int handover, int nt) {
-  // (handover: this tile's substitution is run by the chain workgroup of diagonal tile I, see chain_loop; the words of the hand-over
-  // live behind the nt words of pd_flag: [nt + J] images of panel 2 of diagonal tile J out, [2 nt + J] contraction of tile (J + 1, J) in memory)
+                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
   // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
   // the persistent task loop and kept alive across it
   int tid_ = threadIdx.x;
@@ -473,19 +460,6 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (handover) {
-    // HAND-OVER (chain_loop has the whole story): this is the tile right below diagonal tile J of a single chain.  Its substitution -- the
-    // link between two consecutive diagonal tiles -- is run by the chain workgroup of diagonal tile I, out of registers and LDS; what
-    // leaves here is the finished contraction R, write-through into the tile's own slot, and the word that says so (pd_flag[2 nt + J]).
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
-    stores_done();
-    __syncthreads();
-    if (tid == 0) st_flag(pd_flag + 2 * nt + J, fin, sh);
-    return;
-  }
   if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
   else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
 }
@@ -496,7 +470,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
                                           long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                           double* __restrict__ fail, const long long epoch, const long long sh,
-                                          long long* __restrict__ trace, int nt) {
+                                          long long* __restrict__ trace) {
   __shared__ int s_task;
   for (;;) {
     if (threadIdx.x == 0) s_task = atomicAdd(ctrl, 1);
@@ -504,7 +478,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot, hand-over
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -512,7 +486,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr, d[10], nt);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -525,141 +499,11 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                                     double* __restrict__ fail, const long long epoch, const long long sh,
-                                                    long long* __restrict__ trace, int nt) {
+                                                    long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, nt);
+  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 #endif
-
-// The substitution of tile (J, J-1) inside the chain workgroup of diagonal tile J (the hand-over, see chain_loop): everything that can be
-// done BEFORE panel 3 of diagonal tile J-1 is out -- steps 0 .. 2 and the last block column's update with L(3, 2) -- ending with the residual
-// R_3' in this wavefront's rows of the slice buffer, in A-operand layout.  A function of its own, NOT inlined: it keeps the 128 x 128 tile
-// in 128 accumulator registers, and inlined next to the diagonal-tile body (which needs every register the kernel has) the scalar registers
-// of both spilled into vector registers that spilled to memory, around the barriers of the very hop this code exists to shorten.  What a
-// call costs -- callee-saved registers stored on entry, reloaded on exit -- falls in front of the wait for panel 3, where nobody waits.
-// The step that IS on the serial chain (X_3 from R_3' and Linv(3,3)) is inline in chain_loop and needs 40 registers.
-__device__ __attribute__((noinline)) void chain_substitute_early(double* __restrict__ A, double* __restrict__ X, double* __restrict__ Li,
-                                                           double* __restrict__ sub, long long* __restrict__ sflag,
-                                                           const long long* __restrict__ pf, const long long* __restrict__ img2,
-                                                           const long long* __restrict__ rf, const double* __restrict__ Xinv,
-                                                           double* __restrict__ fail, const long long epoch, const long long sh,
-                                                           int32_t* __restrict__ dbg, int J, long long* __restrict__ tr) {
-  // (tr: GTG_DF_TRACE stamps of this diagonal tile: [2] contraction of the tile left of it seen, [3..5] X_0 .. X_2 in the slice buffer,
-  // [6] R_3' ready; chain_loop adds [7] panel 3 of the tile before seen)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-  const long long fb = epoch * 8;
-  {
-    if (tid < 64) wait_flags(rf, final_of(epoch), rf, final_of(epoch), fail, sh, dbg, 9, J, J - 1, 0);
-    __syncthreads();
-    acquired();
-    if (tr && tid == 0) tr[2] = wall_clock64();
-  }
-  v4f64 x[8];     // x[c][r] = R[16 wave + lk + 4 r][16 c + lr]
-  {
-    const double* Rg = sub + (size_t)(16 * wave + lk) * T + lr;
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) x[c][r] = __hip_atomic_load(Rg + (4 * r) * T + 16 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  double* Xw = X + (16 * wave) * PB;          // this wavefront's 16 rows of the slice buffer (row r of the 128 at r * PB)
-  auto load_image = [&](int blk, int slot) {  // one operand image (8 KB) of diagonal tile J-1 -> LDS, 16 bytes per thread
-    const double* src = Xinv + (size_t)blk * kImgDoubles + 2 * tid;
-    const double i0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double i1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Li[slot * kImgDoubles + 2 * tid] = i0; Li[slot * kImgDoubles + 2 * tid + 1] = i1;
-  };
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    if (q > 0) {
-      // ---- R_p -= X_{q-1} L(p, q-1)^T, p = q .. 3.  The images of panel q - 1 are out with panel q's release -- those of panel 2
-      // early, on their own word.  X_{q-1} is still in the slice buffer (the slice update below has read it; a barrier since).
-      const long long* wf = q == 3 ? img2 : pf;
-      const long long wv = q == 3 ? final_of(epoch) : fb + q + 1;
-      if (tid < 64) wait_flags(wf, wv, wf, wv, fail, sh, dbg, 10, J, J - 1, q);
-      // X_{q-1} for everybody else: its stores were issued a whole wait ago -- the acknowledgements have arrived for free (with the drain,
-      // the barrier and the flag at the END of step q - 1 a step took 8 us, more than the 6.5 us between two panels: this workgroup fell
-      // behind its partner; measured, profiles/r05d)
-      stores_done();
-      __syncthreads();   // (also: the slice update has read X_{q-1} long ago -- this step's patch may overwrite it)
-      acquired();
-      if (tid == 0) st_flag(sflag, fb + q, sh);
-#pragma unroll
-      for (int p = q; p < 4; p++) load_image(p * (p - 1) / 2 + (q - 1), p - q);
-      __syncthreads();
-      double a[8];
-#pragma unroll
-      for (int s2 = 0; s2 < 8; s2++) a[s2] = -Xw[lr * PB + 8 * lk + s2];
-#pragma unroll
-      for (int p = q; p < 4; p++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          double bl[8];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; s2++) bl[s2] = Li[(p - q) * kImgDoubles + (t * 64 + lane) * 8 + s2];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; s2++) x[2 * p + t] = MFMA(a[s2], bl[s2], x[2 * p + t]);
-#ifndef GT_KERNEL_EMU
-          __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time: with all six sets of operands hoisted in front of the MFMAs the 128 accumulator registers spill
-#endif
-        }
-    }
-    if (q == 3) {
-      // R_3' -> A-operand layout in this wavefront's own rows of the slice buffer (every lane has read its operands of X_2 above: the
-      // MFMAs depend on them); the rest of the step belongs to chain_loop
-      if (tr && tid == 0) tr[6] = wall_clock64();
-      GT_WAVE_SYNC();
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Xw[(lk + 4 * r) * PB + 16 * t + lr] = x[6 + t][r];
-      return;
-    }
-    // ---- X_q = R_q Linv(q,q)^T: panel q of diagonal tile J-1
-    if (tid < 64) wait_flags(pf, fb + q + 1, pf, fb + q + 1, fail, sh, dbg, 11, J, J - 1, q);
-    __syncthreads();   // (also: every wavefront is through with the images of the update above / with the previous slice update)
-    acquired();
-    load_image(6 + q, 0);
-    // R_q: accumulator layout -> A-operand layout through this wavefront's own rows of the slice buffer
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) Xw[(lk + 4 * r) * PB + 16 * t + lr] = x[2 * q + t][r];
-    __syncthreads();   // the image is complete (the patch is wave-local)
-    {
-      double a[8];
-#pragma unroll
-      for (int s2 = 0; s2 < 8; s2++) a[s2] = Xw[lr * PB + 8 * lk + s2];
-      GT_WAVE_SYNC();   // every lane has its operands of R_q before X_q overwrites those rows
-      double* Gw = sub + (size_t)(16 * wave) * T + SB * q;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        double bi[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; s2++) bi[s2] = Li[(t * 64 + lane) * 8 + s2];
-        v4f64 xx = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s2 = 0; s2 < 8; s2++) xx = MFMA(a[s2], bi[s2], xx);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          Xw[(lk + 4 * r) * PB + 16 * t + lr] = xx[r];
-          st_wt(Gw + (lk + 4 * r) * T + 16 * t + lr, xx[r]);
-        }
-      }
-    }
-    __syncthreads();   // X_q is complete in the slice buffer
-    {
-      for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
-        const int blk = t >> 2;
-        int ib = 0, rem = blk;
-        while (rem > ib) { rem -= ib + 1; ib++; }
-        slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
-      }
-      if (tr && tid == 0) tr[3 + q] = wall_clock64();
-      // (X_q's flag: at the top of the next step, behind its wait)
-    }
-  }
-}
 
 // The diagonal tiles.  Two workgroups (even / odd J) take turns, so that everything before the last slice of tile J -- waiting for
 // PD(J), bringing the tile into LDS, the first three slices -- happens while the partner factors tile J-1 (with one workgroup
@@ -668,98 +512,28 @@ __device__ __attribute__((noinline)) void chain_substitute_early(double* __restr
 // them (the last slice is the only one left when that tile is final), factor (potrf_body releases its four panels to the
 // substitution steps of the tiles below through the tile's progress word).
 __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, double* __restrict__ Xinv_all,
-                                           long long* __restrict__ pd_flag, long long* tile_flag,
+                                           const long long* __restrict__ pd_flag, long long* tile_flag,
                                            const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                            const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
-                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp, int nt) {
+                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
-  double* Li = X + 4 * SB * PB;                                                       // three operand images (hand-over)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   for (int it = 0; it < n_mine; it++) {
     const int J = my_tiles[it];
     if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, sh, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
-    if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[8 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
+    if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
     const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1) (-1: not stored)
     double* tile = S + (int64_t)dslot * TT;
     bool deferred = false;
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
-    // The update of the block column right before this tile is applied HERE, in 32-column slices.
-    //
-    // Rounds 2-4 (and still: several chains, GT_DF_HANDOVER=0): the slices come from the bulk workgroup that runs the substitution of
-    // tile (J, J-1), through memory, as it publishes them; the last slice is the only thing left when that tile is final.  That made the
-    // hop between two diagonal tiles five dependent memory round trips: panel 3 released -> bulk workgroup (poll, fetch of two operand
-    // images, two MFMA phases, X_3 stored and acknowledged, flag: 8.8 us measured) -> here (poll, fetch of the slice, update: 4 us) --
-    // 13.7 of the 40 us of a chain period, while a panel-to-panel step INSIDE a diagonal tile costs 2.5.
-    //
-    // THE HAND-OVER (round 5; one chain, chain_slots[3 J + 2] > 0): this workgroup -- idle while its partner factors tile J-1 -- runs the
-    // substitution of tile (J, J-1) ITSELF.  The bulk workgroup delivers the finished contraction R (pd_flag[2 nt + J - 1]); R lives in
-    // this workgroup's registers (wavefront w: rows 16 w .. 16 w + 15, eight 16-column MFMA tiles); step q follows panel q of tile J-1:
-    // operand images by sc1 loads into LDS, R_p -= X_{q-1} L(p, q-1)^T, X_q = R_q Linv(q,q)^T -- the same MFMAs on the same operands in
-    // the same order as substitute(): the same bits -- and X_q goes (a) into the slice buffer, from where it updates this diagonal tile
-    // at once (no memory round trip, no flag), (b) to memory write-through for everybody else.  On the serial chain that leaves: ONE
-    // poll of panel 3's word, ONE 8 KB fetch (Linv(3,3); L(3, 2) was released early in panel 3, PotrfHandover::img2_flag, and its
-    // update is done by then), 16 MFMAs per wavefront, the slice update from LDS.  X_3's flag follows asynchronously early in panel 0
-    // (potrf_body: the wavefronts that stored it drain and count; the pivot wavefront stores nothing and waits for nobody).
+    // The update of the block column right before this tile is applied HERE, in 32-column slices as the substitution of tile (J, J-1)
+    // publishes them (the last slice is the only thing left when that tile is final).
     const int sslot = chain_slots[3 * J + 1];
-    const bool handover = sslot >= 0 && chain_slots[3 * J + 2] > 0;
-    if (handover) {
-      double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
-      const long long* pf = tile_flag + chain_slots[3 * (J - 1)];   // panels of diagonal tile J-1
-      const double* Xinv = Xinv_all + (size_t)(J - 1) * T * T + kOpndBase;
-      chain_substitute_early(A, X, Li, sub, tile_flag + sslot, pf, pd_flag + nt + (J - 1), pd_flag + 2 * nt + (J - 1), Xinv, fail, epoch, sh, ctrl + 8, J, trace ? trace + 8 * J : nullptr);
-      // ---- X_3 = R_3' Linv(3,3)^T: panel 3 of diagonal tile J-1 -- THE wait of the serial chain.  (The barrier behind it is also the one
-      // that separates the slice buffer's patch writes of the call above from anybody's reads.)
-      if (tid < 64) wait_flags(pf, epoch * 8 + 4, pf, epoch * 8 + 4, fail, sh, ctrl + 8, 11, J, J - 1, 3);
-      __syncthreads();
-      acquired();
-      if (trace && tid == 0) trace[8 * J + 7] = wall_clock64();
-      {
-        const double* src = Xinv + (size_t)9 * kImgDoubles + 2 * tid;   // image 6 + 3: Linv(3,3), 16 bytes per thread
-        const double i0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double i1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Li[2 * tid] = i0; Li[2 * tid + 1] = i1;
-      }
-      __syncthreads();
-      {
-        double* Xw = X + (16 * wave) * PB;
-        double a[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; s2++) a[s2] = Xw[lr * PB + 8 * lk + s2];
-        GT_WAVE_SYNC();   // every lane has its operands of R_3' before X_3 overwrites those rows
-        double* Gw = sub + (size_t)(16 * wave) * T + 3 * SB;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          double bi[8];
-#pragma unroll
-          for (int s2 = 0; s2 < 8; s2++) bi[s2] = Li[(t * 64 + lane) * 8 + s2];
-          v4f64 xx = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s2 = 0; s2 < 8; s2++) xx = MFMA(a[s2], bi[s2], xx);
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            Xw[(lk + 4 * r) * PB + 16 * t + lr] = xx[r];
-            // (the pivot wavefront of the diagonal-tile body must not have stores in flight -- it would have to wait for them before X_3's
-            // flag; its rows go out through wavefront 4, which idles in every panel, below)
-            if (wave != 0) st_wt(Gw + (lk + 4 * r) * T + 16 * t + lr, xx[r]);
-          }
-        }
-      }
-      __syncthreads();   // X_3 is complete in the slice buffer
-      if (wave == 4) {   // rows 0 .. 15 of X_3 (wavefront 0's) from the slice buffer to memory
-        double* G0 = sub + 3 * SB;
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int e = u * 64 + lane, row = e >> 5, col = e & 31; st_wt(G0 + row * T + col, X[row * PB + col]); }
-      }
-      // The LAST slice is on the serial chain of the factorisation: only its contribution to the four blocks (ib, 0) -- all that panel 0 of
-      // the diagonal tile reads -- is applied here (2 rounds of MFMA tiles instead of 5), the rest inside potrf_body under panel 0's pivot
-      // chain (Xdef).
-      for (int t = wave; t < 16; t += 8) slice_task(A, X, t >> 2, 0, (t >> 1) & 1, t & 1, lr, lk);
-      deferred = true;
-    } else if (sslot >= 0) {
+    if (sslot >= 0) {
       const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
@@ -805,27 +579,24 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    PotrfHandover ho;
-    if (J + 1 < nt && chain_slots[3 * (J + 1) + 2] > 0) { ho.img2_flag = pd_flag + nt + J; ho.img2_value = final_of(epoch); }   // the tile below hands over: it wants the images of panel 2 early
-    if (handover) { ho.sub_final_flag = tile_flag + sslot; ho.sub_final_value = epoch * 8 + 4; }                                // X_3 of the tile left of this one: stored above
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
-               deferred ? X : nullptr, ho);
+               deferred ? X : nullptr);
     __syncthreads();
-    if (trace && tid == 0) trace[8 * J + 1] = wall_clock64();
+    if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
 }
 
 #ifndef GT_KERNEL_EMU
 __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, double* __restrict__ Xinv_all,
-                                                     long long* __restrict__ pd_flag, long long* tile_flag,
+                                                     const long long* __restrict__ pd_flag, long long* tile_flag,
                                                      const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                                      const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
-                                                     const int32_t* __restrict__ chain_tiles, int nt) {
+                                                     const int32_t* __restrict__ chain_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
-                   chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, nt);
+             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): the first n_chain workgroups are the chain (dispatched first, so they are resident before
@@ -840,10 +611,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
-                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain, int nt) {
+                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, nt); }
-  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, nt);
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
+  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
 __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
@@ -1039,11 +810,6 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   df.h_has_sub = has_sub;
 }
 
-// GTG_DF_SINGLE=1: both roles in ONE kernel (k_df_single) -- the form rocprofv3's counter collection can measure.  The chain's code runs with
-// the bulk kernel's 128 registers there, so the hand-over (whose substitution keeps a 128 x 128 tile in the chain workgroup's registers) is
-// not planned in that form: the counters then see the rounds 2-4 flow, the same tiles read and written by other workgroups.
-static bool single_kernel_form() { static const bool single = getenv("GTG_DF_SINGLE") != nullptr; return single; }
-
 void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots) {
   const int nt = df.nt;
   const std::vector<int32_t>& has_sub = df.h_has_sub;
@@ -1056,10 +822,6 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     if (q < 0) throw std::runtime_error("dataflow plan: a tile of the task list has no slot in the stored-tile list");
     return q;
   };
-  // The hand-over of the last block column between consecutive diagonal tiles (chain_loop) is planned for ONE chain: with several chains
-  // (parts of a nested dissection) the block columns are taken in an interleaved order and the critical tasks are not pulled forward.
-  // (GT_DF_HANDOVER=0 at compile time: the flow of rounds 2-4, the A/B; the fenced protocol build keeps that flow as well.)
-  const bool handover_plan = GT_DF_HANDOVER != 0 && GTG_DF_FENCES == 0 && df.n_chain == 2 && nt > 1 && !single_kernel_form();
   {
     // accumulator lanes of the tiles with very long contraction lists (run_task): G - 1 scratch slots each, behind the stored tiles
     constexpr int lane_min = 8;   // early pieces from which a tile gets lanes
@@ -1084,8 +846,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
       { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
-      // [10]: hand-over (substitute / chain_loop): the final piece of the tile right below a diagonal tile of a single chain
-      dt.push_back((handover_plan && I == J + 1 && I < nt && d[4] == d[5] - 1 && (has_sub[I] & 1)) ? 1 : 0); dt.push_back(0);
+      dt.push_back(0); dt.push_back(0);
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
         dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);
@@ -1095,16 +856,16 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
     std::vector<int32_t> cs(3 * (size_t)nt, -1);
-    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) { cs[3 * J + 1] = slot_of(J, J - 1); cs[3 * J + 2] = handover_plan ? 1 : -1; } }
-    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, > 0: that tile's last block column is handed over as R_3')
+    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, one spare word)
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
-  df.shadow = (std::max<int64_t>(n_slots + df.n_scratch, 3 * (int64_t)nt) + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included; pd_flag: nt words + 2 nt of the hand-over)
+  df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included)
   df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
-  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 8 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
+  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");
@@ -1178,13 +939,14 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   // kernel of the previous factorisation wrote with a plain store
   const long long epoch = ++c.chol_epoch;
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, epoch, df.ctrl.p);
-  if (single_kernel_form()) {
+  static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
+  if (single) {
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
                        df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
-                       df.chain_off.p, df.chain_tiles.p, df.n_chain, nt);
+                       df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -1202,10 +964,10 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
   hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p, nt);
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, nt);
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
@@ -1217,7 +979,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   constexpr int extra = 6;
   if (df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, nt);
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");

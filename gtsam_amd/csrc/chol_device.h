@@ -397,26 +397,11 @@ __device__ __forceinline__ void diag_tile_to_lds(const double* tile, double* __r
   }
 }
 
-// The hand-over between consecutive diagonal tiles of ONE chain (dataflow schedule, round 5; chol_dataflow.hip::chain_loop has the whole
-// story): what the diagonal-tile body contributes to it.
-//   img2_flag : published (value img2_value, with its shadow word) as soon as the operand images of PANEL 2 -- L(3, 2) is the one that
-//               matters -- are in memory, i.e. early in panel 3 instead of with panel 3's release: the substitution of the tile below
-//               can then finish its residual R_3' = R_3 - X_0 L(3,0)^T - X_1 L(3,1)^T - X_2 L(3,2)^T while panel 3's pivots run.
-//   sub_final_flag : the flag word of the tile LEFT of this diagonal tile, whose last 32-column block X_3 the chain workgroup formed
-//               itself and stored write-through right before it entered this body -- from every wavefront but the pivot wavefront 0,
-//               which must not wait for memory: the seven others wait for their own stores at the top of panel 0 and count; the last
-//               one publishes the word (sub_final_value).  Their panel-0 roles start ~2 us late and catch up (a follower step is a
-//               third of a pivot step).
-struct PotrfHandover {
-  long long* img2_flag = nullptr; long long img2_value = 0;
-  long long* sub_final_flag = nullptr; long long sub_final_value = 0;
-};
-
 __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ tile, int k, double* __restrict__ Xinv,
                                            double* __restrict__ fail, long long* __restrict__ dbg,
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
                                            const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr,
-                                           const double* Xdef = nullptr, const PotrfHandover ho = PotrfHandover()) {
+                                           const double* Xdef = nullptr) {
   // (Xdef: the dataflow chain kernel only -- the last 32-column slice of the tile left of this one, in LDS, of which the blocks (ib, cb),
   // cb >= 1, are still to be applied; see chain_loop.  nullptr: nothing deferred)
   const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
@@ -432,18 +417,11 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-  if (tid == 0) { prog[0] = 0; prog[1] = 0; prog[2] = 0; prog[3] = 0; }   // ([2]: wavefronts that have the images of panel 2 in memory, [3]: ... X_3 of the tile left of this one: PotrfHandover)
+  if (tid == 0) { prog[0] = 0; prog[1] = 0; }
   STAMP(0);
   if (!preloaded) diag_tile_to_lds(tile, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();
   STAMP(1);
-  if (ho.sub_final_flag && wave != 0) {
-    GT_DRAIN_STORES();
-    if (lane == 0 && atomicAdd(prog + 3, 1) == 6) {
-      (void)__hip_atomic_exchange(ho.sub_final_flag, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (pflag_shadow) __hip_atomic_store(ho.sub_final_flag + pflag_shadow, ho.sub_final_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   // rank test at the variables' block ends (see stage_potrf): pivot kinds of this tile's columns, exponent of the pivot before it
   const unsigned char* pk = pivot_kind ? pivot_kind + (size_t)k * T : nullptr;
   int prev_exp = 0;
@@ -480,15 +458,6 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
         tile_task(A, pj, pj + 2 + bi, pj + 2 + rem, (t >> 1) & 1, t & 1, lr, lk);
       }
       store_column(A, tile, Xinv, pj, hw * 64 + lane, nh * 64, wt);
-      if (jb == 3 && ho.img2_flag) {
-        // the images of panel 2 are out once each of the nh wavefronts that share this write-back has its stores acknowledged: the
-        // last one to get there publishes the word (LDS counter; the publishing lane's own stores are drained like everybody's)
-        GT_DRAIN_STORES();
-        if (lane == 0 && atomicAdd(prog + 2, 1) == nh - 1) {
-          (void)__hip_atomic_exchange(ho.img2_flag, ho.img2_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pflag_shadow) __hip_atomic_store(ho.img2_flag + pflag_shadow, ho.img2_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
     }
     // Panel jb is released to the workgroups waiting for it (the TRSM workgroups of this launch / the substitutions of the dataflow
     // schedule) once its inverse and every L(jb, q<jb) operand image are in memory.

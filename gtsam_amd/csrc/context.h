@@ -120,6 +120,7 @@ struct FactorTables {
   // SFM
   int64_t n_sfm = 0;
   DevBuf<int32_t> sfm_cam, sfm_point, sfm_noise;
+  DevBuf<int32_t> sfm_cam_at, sfm_point_at;   // where the factor's camera / point start in the packed values (val_off of the two ids: one dependent gather less per recomputed record, fused.h)
   DevBuf<double> sfm_z, sfm_J;
   // projection
   int64_t n_proj = 0;

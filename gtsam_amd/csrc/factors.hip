@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_sumsq(int64_t n, const double* __res
 
 // ---- launchers --------------------------------------------------------------------------------------
 static NoiseTab noise_tab(gtg_context& c) { return NoiseTab{c.noise_kind.p, c.noise_off.p, c.noise_data.p, c.noise_rkind.p, c.noise_rk.p}; }
-SfmTabs sfm_tabs(gtg_context& c) { return SfmTabs{c.f.sfm_cam.p, c.f.sfm_point.p, c.f.sfm_noise.p, c.f.sfm_z.p, c.values.p, c.val_off.p, noise_tab(c)}; }
+SfmTabs sfm_tabs(gtg_context& c) { return SfmTabs{c.f.sfm_cam_at.p, c.f.sfm_point_at.p, c.f.sfm_noise.p, c.f.sfm_z.p, c.values.p, noise_tab(c)}; }
 
 // ---- smart factors: the landmark of every factor from the cameras in `values` ------------------------------------------
 // One factor per lane.  What SmartProjectionFactor::triangulateSafe does (SmartProjectionFactor.h:127-183): re-triangulate only

@@ -28,18 +28,17 @@ struct NoiseTab {
 
 // what the recomputation reads: the GeneralSFM factor table, the packed values, the noise table
 struct SfmTabs {
-  const int32_t *cam, *pt, *nz;
+  const int32_t *cam_at, *pt_at, *nz;   // per factor: offsets of its camera and its point in the packed values, noise row
   const double* z;
   const double* values;
-  const int64_t* val_off;
   NoiseTab nt;
 };
 
 // record of GeneralSFM factor i -> rec[0 .. kSfmRec) (a row of the calling wavefront's LDS image)
 __device__ __forceinline__ void sfm_record(const SfmTabs& t, int64_t i, double* rec) {
   double c[17], p[3], zz[2];
-  const double* cp = t.values + t.val_off[t.cam[i]];
-  const double* pp = t.values + t.val_off[t.pt[i]];
+  const double* cp = t.values + t.cam_at[i];
+  const double* pp = t.values + t.pt_at[i];
 #pragma unroll
   for (int k = 0; k < 17; k++) c[k] = cp[k];
 #pragma unroll

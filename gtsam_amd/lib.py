@@ -268,12 +268,12 @@ class DeviceGraph:
         return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist, chain_off=coff, chain_tiles=ctiles, seq=seq)
 
     def df_trace(self):
-        """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][8] stamps: tile in, factored, then the hand-over's) of the last factorisation, 100 MHz ticks."""
+        """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][2] stamps) of the last factorisation, 100 MHz ticks."""
         pl = self.df_plan()
-        n = 8 * pl["tasks"].shape[0] + 8 * pl["nt"]
+        n = 8 * pl["tasks"].shape[0] + 2 * pl["nt"]
         out = np.zeros(n, np.int64)
         _check(self.lib.gtg_debug_df_trace(self.h, out.ctypes.data, n), "gtg_debug_df_trace")
-        return out[:8 * pl["tasks"].shape[0]].reshape(-1, 8), out[8 * pl["tasks"].shape[0]:].reshape(-1, 8)
+        return out[:8 * pl["tasks"].shape[0]].reshape(-1, 8), out[8 * pl["tasks"].shape[0]:].reshape(-1, 2)
 
     def df_ctrl(self):
         out = np.zeros(16, np.int32)

@@ -295,8 +295,8 @@ int gtg_debug_df_ctrl(gtg_handle h, int32_t out[16]);
  * 0 = nothing is kept; the default was 8192 in round 3 and 0 in round 4): give every kept block back to the driver.  Returns the bytes
  * released.  (A failed allocation does this by itself before it gives up.) */
 int64_t gtg_release_cached_memory(void);
-/* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 8 nt: per task {taken,
- * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored, hand-over: contraction of the tile left of it seen, X_0 / X_1 / X_2 formed, R_3' ready, panel 3 of the tile before seen} (tools/df_trace.py) */
+/* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
+ * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */
 int gtg_debug_df_trace(gtg_handle h, int64_t* out, int64_t n);
 
 /* ---- wire format on the bundle-adjustment side of the path: BAL text files straight to / from the

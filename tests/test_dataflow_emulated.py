@@ -39,7 +39,7 @@ def exe():
     return _build(EXE, [])
 
 
-def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8, handover=True):
+def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
     """One chain over a dense lower triangle + the rhs row (tile row nt).  Slots: column by column."""
     slot = {}; n_slots = 0
     for J in range(nt):
@@ -75,20 +75,18 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8, handover=True):
         if t[4] == t[5] - 1 and E >= lane_min and min(lane_max, E // 4) >= 2:
             G = min(lane_max, E // 4)
             lanes[(t[0], t[1])] = (G, n_slots + n_scratch); n_scratch += G - 1
-    # [10]: the hand-over of the last block column of the tile right below a diagonal tile (its final piece) to the chain workgroup
-    tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) +
-             [1 if (handover and t[0] == t[1] + 1 and t[0] < nt and t[4] == t[5] - 1) else 0, 0] for t in order]
+    tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) + [0, 0] for t in order]
     chain_slots = []
     for J in range(nt):
-        chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, 1 if (handover and J > 0) else -1]
+        chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1]
     t0 = list(range(0, nt, 2)); t1 = list(range(1, nt, 2))
     return dict(slot=slot, n_slots=n_slots, n_scratch=n_scratch, tasks=np.array(tasks, np.int32), klist=np.array(klist, np.int32).reshape(-1, 2),
                 chain_slots=np.array(chain_slots, np.int32), chain_off=np.array([0, len(t0), nt], np.int32), chain_tiles=np.array(t0 + t1, np.int32),
                 max_pieces=max(t[5] for t in order), lanes=lanes)
 
 
-def factor(exe, nt, n_bulk, k_piece, k_final, tmp_path, seed=3, lane_min=8, handover=True):
-    P = plan_dense(nt, k_piece, k_final, lane_min=lane_min, handover=handover)
+def factor(exe, nt, n_bulk, k_piece, k_final, tmp_path, seed=3, lane_min=8):
+    P = plan_dense(nt, k_piece, k_final, lane_min=lane_min)
     rng = np.random.default_rng(seed)
     N = nt * T
     M = rng.standard_normal((N, N + 40)); A = M @ M.T + N * np.eye(N); g = rng.standard_normal(N)
@@ -138,20 +136,6 @@ def test_emulated_dataflow_factorisation_with_accumulator_lanes(exe, tmp_path):
     lanes (scratch slots behind the stored tiles, NaN before the run), added up by the final piece in lane order."""
     P = factor(exe, 11, 4, 1, 1, tmp_path)
     assert P["lanes"] and P["n_scratch"] > 0
-
-
-def test_emulated_hand_over_is_bit_identical_to_the_substitution_finishing_the_tile_itself(exe, tmp_path):
-    """Round 5: the last block column of the tile right below a diagonal tile is handed to the chain workgroup of the next diagonal tile
-    as the residual R_3' (the bulk workgroup stops there; the image L(3, 2) is released early in panel 3; X_3 = R_3' Linv(3,3)^T is formed
-    by the chain workgroup, which also publishes the tile).  Same products in the same order: factor, inverses and operand images are
-    bit-identical to the plan without the hand-over (the flow of rounds 2-4), run after run under host-thread timings."""
-    factor(exe, 4, 2, 2, 1, tmp_path, handover=False)
-    S0, X0 = factor.last
-    for rep in range(3):
-        factor(exe, 4, 2, 2, 1, tmp_path, handover=True)
-        S1, X1 = factor.last
-        assert np.array_equal(S0, S1)
-        assert np.array_equal(X0.reshape(4, T * T)[:, :14336], X1.reshape(4, T * T)[:, :14336])
 
 
 def test_emulated_dataflow_factorisation_is_reproducible_with_the_deferred_last_slice(exe, tmp_path):

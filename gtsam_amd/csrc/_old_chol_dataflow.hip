@@ -731,52 +731,24 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // (kPiece, kFinal) swept on the L1723 shape in round 4 (Cholesky ms): (6,3) 5.17, (4,4) 5.09, (6,4) 5.10, (4,5) 5.11, (3,4) 5.14,
   // (4,3) 5.15, (4,6) 5.16, (8,3) 5.32, (2,4) 5.32, (6,2) 5.48, (10,3) 5.51.
   constexpr int kPiece = 4, kFinal = 4;
-  // The DIAGONAL tile's last piece is shorter: PD(J) is on the serial chain -- the chain workgroup of tile J cannot start before it -- and a
-  // last piece of 4 steps is 72 us of contraction (18 us per step) that only starts when a workgroup takes its ticket.  Round 5 trace
-  // (profiles/r05f_late_pd.txt): on 13 of 120 block columns of the L1723 shape the ticket was taken 53 - 74 us before the tile was needed
-  // instead of the usual 77 - 120, PD(J) came 7 - 20 us late, and those 13 periods (57 us instead of 41) were 0.27 ms of the 5.05.
-  // The same holds for the tiles right below it: (J + 1, J) feeds the next diagonal tile through the chain kernel, (J + 2, J) is the youngest
-  // operand of PD(J + 2) AND of the critical tile (J + 2, J + 1) -- when its last piece was taken 40 - 60 us before its column's diagonal
-  // tile was out (normally: 100), it was final 25 us late and both were late with it -- and (J + 3, J) is the youngest operand of that one.
-  // Swept on the L1723 shape (profiles/r05_plan_cut_sweep.txt; Cholesky ms): last piece of the diagonal tile 1 / 2 / 3 / 4 steps 5.17 / 5.04 / 5.03 /
-  // 5.09; short pieces + pulled for 0 / 2 / 3 rows below it 5.07 / 5.03 / 5.00.
-#ifndef GT_DF_FINAL_DIAG
-#define GT_DF_FINAL_DIAG 2
-#endif
-#ifndef GT_DF_NEAR_ROWS
-#define GT_DF_NEAR_ROWS 3
-#endif
-  constexpr int kFinalDiag = GT_DF_FINAL_DIAG, kNearRows = GT_DF_NEAR_ROWS;
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
-  std::vector<int> diag_last_g(nt + 1, -1);                  // group of the last early piece of PD(J) (-1: none)
   auto emit = [&](int I, int J, std::vector<int32_t>& ks) {
     by_pos(ks);                                        // the steps in the order in which their operands come into being
     const int n = (int)ks.size(), G = pos[J];
-    const bool near = I - J <= kNearRows;              // the diagonal tile and the kNearRows tiles below it: on or next to the serial chain
-    int m = std::max(0, n - (near ? kFinalDiag : kFinal));   // older steps, in early pieces of at most kPiece; the last piece: the youngest
+    int m = std::max(0, n - kFinal);                 // older steps, in early pieces of at most kPiece; the last piece: the youngest
     while (m > 0 && pos[ks[m - 1]] > G - 3) m--;     // (an early piece sits two groups before its tile's column at the latest)
     const int f = n - m;
-    // the early steps cut into pieces of kPiece from the old end; a DIAGONAL tile's last early piece is short as well (kFinalDiag steps):
-    // the last piece cannot start before it is done, and 4 steps are 73 us (round 5 trace: PD(J) late whenever that piece had 4)
-    std::vector<int> cut;   // piece r = steps [cut[r], cut[r + 1])
-    {
-      const int tail = (near && m > kFinalDiag) ? kFinalDiag : 0;
-      for (int b = 0; b < m - tail; b += kPiece) cut.push_back(b);
-      if (tail) cut.push_back(m - tail);
-      cut.push_back(m);
-    }
-    const int R = (int)cut.size();     // early pieces + the last one
+    const int R = (m + kPiece - 1) / kPiece + 1;
     if (R >= (int)kPieceBase) throw std::runtime_error("dataflow plan: a contraction list needs more pieces than the part flags can count");
     const int32_t off = (int32_t)df.h_klist.size();
     df.h_klist.insert(df.h_klist.end(), ks.begin(), ks.end());
     int gprev = 0;
     for (int r = 0; r + 1 < R; r++) {
-      const int b = cut[r], e = cut[r + 1];
+      const int b = r * kPiece, e = std::min(m, (r + 1) * kPiece);
       const int last_k = ks[e - 1];
       const int g = std::max(pos[last_k] + 1, gprev);   // as early as its operands exist (<= G - 2)
       early[g].push_back(Rec{I, J, off + b, e - b, r, R}); gprev = g;
-      if (I == J) diag_last_g[J] = g;
     }
     finals[G].push_back(Rec{I, J, off + m, f, R - 1, R});
   };
@@ -813,29 +785,21 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // ~100 us: behind it PD(J) was taken 12 - 30 us too late on every sixth column of the L1723 shape and the chain period stretched
   // from 40 to 60 - 76 us (round 4 trace: 19 of 121 periods, 0.4 ms of 5.2).  Taken early the two tasks just hold two of the 248
   // workgroups a period longer.
-  // (pulled with the diagonal tile: the kNearRows tiles below it; measured on L1723 in round 4, with last pieces of 4 steps everywhere: 0 rows
-  // below 5.17 ms, 1 row 5.17, 3 rows 5.19; no pulling at all 5.30)
-  const int pull_rows = tree ? -1 : kNearRows;
+  // (pulled with the diagonal tile: the ONE tile below it; measured on L1723 in round 4: 0 rows below 5.17 ms, 1 row 5.17, 3 rows 5.19; no
+  // pulling at all 5.30)
+  const int pull_rows = tree ? -1 : 1;
   const bool pull = pull_rows >= 0;
   auto critical = [&](const Rec& t, int c) { return t.J == c && t.I >= c && t.I <= c + pull_rows && t.I < nt; };
-  // PD(c) itself goes one group further ahead (round 5): its last piece -- two contraction steps, 36 us, the second one streaming behind the
-  // substitution of tile (c, c - 2) -- was still taken only 20 - 25 us before the chain needed it on some columns of the L1723 shape
-  // (230 tickets behind the tile (c, c - 1) of the group before: profiles/r05i trace).  Allowed when all its early pieces sit in groups
-  // <= q - 1 (they are queued in front of it then: a task still only waits for smaller tickets; its operand tiles (c, c - 3), (c, c - 2)
-  // belong to columns <= q, whose own tasks are queued by then).
-  std::vector<char> pulled(nt + 1, 0), pd_out(nt + 2, 0);
-  auto is_pd = [&](const Rec& t, int c) { return t.I == c && t.J == c; };
+  std::vector<char> pulled(nt + 1, 0);
   for (int q = 0; q < nt; q++) {
     for (const Rec& t : finals[q]) { if (pulled[q] && critical(t, q)) continue; put1(t); }
     if (q >= 1) {
-      const int c = q + 1, c2 = q + 2;            // the columns whose critical tasks are pulled in front of early[q - 1]
+      const int c = q + 1;            // the column whose critical tasks are pulled in front of early[q - 1]
       if (pull && c < nt) {
-        const bool pd2 = c2 < nt && diag_last_g[c2] <= q - 1;
-        for (const Rec& t : early[q - 1]) if (critical(t, c) || (pd2 && is_pd(t, c2))) put1(t);
-        for (const Rec& t : finals[c]) if (critical(t, c) && !(is_pd(t, c) && pd_out[c])) put1(t);
+        for (const Rec& t : early[q - 1]) if (critical(t, c)) put1(t);
+        for (const Rec& t : finals[c]) if (critical(t, c)) put1(t);
         pulled[c] = 1;
-        if (pd2) { for (const Rec& t : finals[c2]) if (is_pd(t, c2)) put1(t); pd_out[c2] = 1; }
-        for (const Rec& t : early[q - 1]) if (!(critical(t, c) || (pd2 && is_pd(t, c2)))) put1(t);
+        for (const Rec& t : early[q - 1]) if (!critical(t, c)) put1(t);
       } else put(early[q - 1]);
     }
   }

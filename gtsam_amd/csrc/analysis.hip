@@ -833,7 +833,13 @@ void analyze(gtg_context& c) {
   c.Linv.alloc(std::max<size_t>(9 * (size_t)c.n_lm, 1)); c.ylm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.delta_lm.alloc(std::max<size_t>(3 * (size_t)c.n_lm, 1));
   c.E.alloc(std::max<size_t>(kEStride * (size_t)c.n_obs, 1));
-  c.wobs.alloc(std::max<size_t>(9 * (size_t)c.n_obs, 1));
+  {
+    const int64_t n_inc = (int64_t)c.red_inc_kind.n;
+    if (n_inc >= ((int64_t)1 << 31)) throw std::runtime_error("analysis: more than 2^31 entries in the contribution lists");
+    c.wobs.alloc(std::max<size_t>(9 * (size_t)n_inc, 1));
+    c.obs_wpos.alloc(std::max<size_t>((size_t)c.n_obs, 1));
+    launch_obs_wpos(c, n_inc);
+  }
   c.vobs.alloc(std::max<size_t>(3 * (size_t)c.n_obs, 1));
   c.Hoff.alloc(std::max<size_t>(81 * (size_t)c.n_hoff, 1));
   c.S.alloc((size_t)(c.plan.n_stored + (c.use_df ? c.df.n_scratch : 0)) * kTileDoubles);   // the stored tiles only (context.h::SMat) + the dataflow plan's scratch slots

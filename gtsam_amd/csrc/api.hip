@@ -268,7 +268,7 @@ int gtg_destroy(gtg_handle c) {
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
-                            &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.sfm_cam_at, &f.sfm_point_at, &f.proj_pose, &f.proj_point,
+                            &c->noise_kind, &c->noise_rkind, &f.sfm_cam, &f.sfm_point, &f.sfm_noise, &f.sfm_cam_at, &f.sfm_point_at, &c->obs_wpos, &f.proj_pose, &f.proj_point,
                             &f.proj_noise, &f.proj_calib, &f.proj_sensor, &f.between_v1, &f.between_v2, &f.between_noise,
                             &f.prior_var, &f.prior_noise, &c->obs_red, &c->obs_lm, &c->lm_obs, &c->lm_pri,
                             &c->red_inc_kind, &c->red_inc_idx, &c->hoff_row, &c->hoff_col, &c->hoff_fac, &c->pair_row,

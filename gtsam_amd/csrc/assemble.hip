@@ -357,11 +357,13 @@ __global__ __launch_bounds__(kBlock) void k_point_factor(int32_t n_lm, const int
 // are read and the 256-byte E slots written through the wavefront's LDS image (recio.h): 1 KiB contiguous per memory
 // instruction in both directions.
 // FUSED (GeneralSFM records of a graph without smart factors): the record is recomputed in the image instead of loaded (fused.h).
-// Also out: w_o = E_o y_l (9 doubles per observation, zero padded), the observation's summand of the reduced right-hand side -- so that
-// k_build_diag reads 72 bytes per observation instead of the 216-byte E block and y (283 MB per try on the L1723 shape until round 4).
+// Also out: w_o = E_o y_l (9 doubles per observation, zero padded), the observation's summand of the reduced right-hand side, stored at the
+// observation's place in its camera's contribution list -- so that k_build_diag reads 72 contiguous bytes per entry instead of gathering the
+// 216-byte E block and y (283 MB per try on the L1723 shape until round 4).
 template <int REC, int DC, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __restrict__ J, SfmTabs t, const int32_t* __restrict__ obs_lm,
-    const double* __restrict__ Linv, const double* __restrict__ ylm, double* __restrict__ E, double* __restrict__ W) {
+    const double* __restrict__ Linv, const double* __restrict__ ylm, double* __restrict__ E, double* __restrict__ W,
+    const int32_t* __restrict__ wpos) {
   typedef RecIO<REC> IN;
   typedef RecIO<kEStride> OUT;
   __shared__ double img[kBlock / 64][OUT::LDS_DOUBLES > IN::LDS_DOUBLES ? OUT::LDS_DOUBLES : IN::LDS_DOUBLES];
@@ -405,12 +407,13 @@ __global__ __launch_bounds__(kBlock) void k_obs_E(int64_t n, const double* __res
 #pragma unroll
     for (int k = 0; k < kEStride; k++) my[lane * OUT::PITCH + k] = Eo[k];
     OUT::store(my, E + (int64_t)kEStride * ch * 64, nrec, lane);
+    // w_o goes where k_build_diag reads it: to the observation's place in its camera's contribution list (wpos), so that the sum over a
+    // camera's observations is a sequential read (in observation order it was a 72-byte gather per observation: 92 us for 49 MB)
+    if (o < n) {
+      double* wo = W + 9 * (int64_t)wpos[o];
 #pragma unroll
-    for (int i = 0; i < 9; i++) my[lane * 9 + i] = w[i];
-    IN::wave_sync();
-    double* Wc = W + 9 * ch * 64;
-#pragma unroll
-    for (int u = 0; u < 9; u++) { const int e = u * 64 + lane; if (e < 9 * nrec) Wc[e] = my[e]; }
+      for (int i = 0; i < 9; i++) wo[i] = w[i];
+    }
     IN::wave_sync();   // the image may be overwritten afterwards
   }
 }
@@ -465,10 +468,8 @@ __global__ __launch_bounds__(64 * kDiagWaves) void k_build_diag(int32_t n_red_va
   // wavefronts: a fixed order
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t k = inc_ptr[r] + tid; k < inc_ptr[r + 1]; k += 64 * kDiagWaves) {
-    const int kind = inc_kind[k];
-    if (kind > INC_PROJ) continue;
-    const int64_t o = kind == INC_SFM ? (int64_t)inc_idx[k] : n_sfm + inc_idx[k];
-    const double* wo = W + 9 * o;      // E_o y_l, formed by k_obs_E
+    if (inc_kind[k] > INC_PROJ) continue;
+    const double* wo = W + 9 * k;      // E_o y_l of the observation behind entry k, put there by k_obs_E
     for (int i = 0; i < d; i++) acc[i] += wo[i];
   }
   for (int i = 0; i < 9; i++)
@@ -631,6 +632,21 @@ __global__ __launch_bounds__(kBlock) void k_scatter_delta(int32_t n_vars, const 
 static inline int grid1(int64_t n) { int64_t b = (n + kBlock - 1) / kBlock; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 static JTabs jtabs(gtg_context& c) { return JTabs{c.f.sfm_J.p, c.f.proj_J.p, c.f.between_J.p, c.f.prior_J.p, c.f.n_sfm}; }
 
+// observation -> its place in its camera's contribution list (once per graph, behind the incidence lists)
+__global__ __launch_bounds__(kBlock) void k_obs_wpos(int64_t n_inc, const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx,
+                                                     int64_t n_sfm, int32_t* __restrict__ wpos) {
+  for (int64_t k = blockIdx.x * (int64_t)kBlock + threadIdx.x; k < n_inc; k += (int64_t)gridDim.x * kBlock) {
+    const int kind = inc_kind[k];
+    if (kind == INC_SFM) wpos[inc_idx[k]] = (int32_t)k;
+    else if (kind == INC_PROJ) wpos[n_sfm + inc_idx[k]] = (int32_t)k;
+  }
+}
+void launch_obs_wpos(gtg_context& c, int64_t n_inc) {
+  if (n_inc > 0 && c.n_obs > 0)
+    hipLaunchKernelGGL(k_obs_wpos, dim3(grid1(n_inc)), dim3(kBlock), 0, c.stream, n_inc, c.red_inc_kind.p, c.red_inc_idx.p, c.f.n_sfm, c.obs_wpos.p);
+  check_hip(hipGetLastError(), "obs_wpos");
+}
+
 void launch_assemble(gtg_context& c) {
   JTabs t = jtabs(c);
   if (c.n_red_vars && c.fused_sfm) {
@@ -739,13 +755,13 @@ void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin
   const SfmTabs st = sfm_tabs(c);
   if (c.f.n_sfm && c.fused_sfm)
     hipLaunchKernelGGL((k_obs_E<kSfmRec, 9, true>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
-                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p);
+                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p, c.obs_wpos.p);
   else if (c.f.n_sfm)
     hipLaunchKernelGGL((k_obs_E<kSfmRec, 9, false>), dim3(grid1(c.f.n_sfm / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_sfm, c.f.sfm_J.p, st,
-                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p);
+                       c.obs_lm.p, c.Linv.p, c.ylm.p, c.E.p, c.wobs.p, c.obs_wpos.p);
   if (c.f.n_proj)
     hipLaunchKernelGGL((k_obs_E<kProjRec, 6, false>), dim3(grid1(c.f.n_proj / 4 + 1)), dim3(kBlock), 0, c.stream, c.f.n_proj,
-                       c.f.proj_J.p, st, c.obs_lm.p + c.f.n_sfm, c.Linv.p, c.ylm.p, c.E.p + (int64_t)kEStride * c.f.n_sfm, c.wobs.p + 9 * c.f.n_sfm);
+                       c.f.proj_J.p, st, c.obs_lm.p + c.f.n_sfm, c.Linv.p, c.ylm.p, c.E.p + (int64_t)kEStride * c.f.n_sfm, c.wobs.p, c.obs_wpos.p + c.f.n_sfm);
   check_hip(hipGetLastError(), "point_eliminate");
 }
 

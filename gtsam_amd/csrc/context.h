@@ -229,7 +229,8 @@ struct gtg_context {
   gt::DevBuf<double> Linv, ylm, E, delta_lm;    // per try: landmark L^-1 (9), y (3), E (32/obs), delta (3)
   gt::DevBuf<double> pcg_vec, pcg_bj, pcg_y;    // PCG solver: r, p, q1, q2, b (5 x NP); block-Jacobi factors (81 / reduced variable); y_l (3 / landmark)
   bool fused_sfm = false;                       // the GeneralSFM records are recomputed where they are needed instead of stored (fused.h): graphs without smart factors
-  gt::DevBuf<double> wobs;                      // per try: E_o y_l of every observation (9), the summands of the reduced right-hand side
+  gt::DevBuf<double> wobs;                      // per try: E_o y_l (9 doubles) per entry of the cameras' contribution lists: the summands of the reduced right-hand side
+  gt::DevBuf<int32_t> obs_wpos;                 // observation -> its entry in red_inc_* (where k_obs_E stores its summand)
   gt::DevBuf<double> cam_part;                  // k_cam_fused with several workgroups per camera: their partial sums
   gt::DevBuf<double> vobs;                      // per try: Jp^T (Jc x_cam) of every observation (3), for the back-substitution
   gt::DevBuf<double> S;                         // plan.n_stored slots of 128 x 128 doubles: the stored tiles of the reduced system + the rhs row's tiles

@@ -14,6 +14,7 @@ void launch_linear_error(gtg_context& c);                               // scala
 void launch_retract(gtg_context& c);                                    // trial = values (+) delta ; scalars[SC_DELTA_SQ]
 
 // assemble.hip ------------------------------------------------------------------------------------
+void launch_obs_wpos(gtg_context& c, int64_t n_inc);   // once per graph: observation -> place in its camera's contribution list (where k_obs_E puts w_o)
 void launch_assemble(gtg_context& c);            // Hd, gred0, V, gp, Hoff, hdiag_red (lambda-invariant)
 void launch_point_eliminate(gtg_context& c, double lambda, int diag, double dmin, double dmax);  // Linv, ylm, E
 void launch_build_reduced(gtg_context& c, double lambda, int diag, double dmin, double dmax);    // S and rhs row

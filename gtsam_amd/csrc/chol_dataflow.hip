@@ -464,44 +464,16 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
 }
 
-// Tickets (round 5: two queues).  `order` = {n_reg, n_express, reg[n_reg], express[n_express]}: the task list is still ONE topological
-// order G (a task only waits for tasks in front of it in G), but the tasks on and right next to the serial chain -- the last two pieces
-// of the diagonal tile and of the few tiles below it -- are handed out from their own counter to the first `express_wgs` workgroups that
-// START RUNNING (so they are resident by construction), everything else from the other counter to the rest.  Both lists are subsequences
-// of G and each is served in order by at least one running workgroup, so the earliest unfinished task of G is always either running or
-// the next one its queue hands out to a workgroup whose current task precedes it in G: no deadlock, as with one counter.  What it
-// buys: a task the chain waits for is no longer taken "when the burst of several hundred early pieces in front of it has been
-// handed out" (round 5 trace: PD(J) 230 tickets behind its neighbours on a tenth of the columns) but as soon as an express
-// workgroup is free -- they idle (poll) most of the time, which is the point.  A workgroup whose queue is exhausted serves the other one.
-// express_wgs = 0: `order` lists every task as regular.
-constexpr int kCtrlExpressTicket = 16, kCtrlArrivals = 17;   // (ctrl[8..15]: the record of the first wait that gave up)
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, const int32_t* __restrict__ tasks,
                                           int ntasks, const int32_t* __restrict__ klist,
                                           long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                           long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                           double* __restrict__ fail, const long long epoch, const long long sh,
-                                          long long* __restrict__ trace, const int32_t* __restrict__ order, const int express_wgs) {
+                                          long long* __restrict__ trace) {
   __shared__ int s_task;
-  __shared__ int s_express;
-  const int n_reg = order[0], n_exp = order[1];
-  const int32_t* reg = order + 2;
-  const int32_t* expr = order + 2 + n_reg;
-  if (threadIdx.x == 0) s_express = (express_wgs > 0 && n_exp > 0) ? (atomicAdd(ctrl + kCtrlArrivals, 1) < express_wgs) : 0;
   for (;;) {
-    if (threadIdx.x == 0) {
-      int t = ntasks;
-      if (s_express) {
-        const int i = atomicAdd(ctrl + kCtrlExpressTicket, 1);
-        if (i < n_exp) t = expr[i]; else s_express = 0;
-      }
-      if (t == ntasks) {
-        const int i = atomicAdd(ctrl, 1);
-        if (i < n_reg) t = reg[i];
-        else if (n_exp > 0) { const int i2 = atomicAdd(ctrl + kCtrlExpressTicket, 1); if (i2 < n_exp) t = expr[i2]; }
-      }
-      s_task = t;
-    }
+    if (threadIdx.x == 0) s_task = atomicAdd(ctrl, 1);
     __syncthreads();
     const int t = s_task;
     __syncthreads();
@@ -527,9 +499,9 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
                                                     double* __restrict__ fail, const long long epoch, const long long sh,
-                                                    long long* __restrict__ trace, const int32_t* __restrict__ order, const int express_wgs) {
+                                                    long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, order, express_wgs);
+  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 #endif
 
@@ -639,14 +611,13 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
                                                       const long long epoch, const long long sh, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
-                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain,
-                                                      const int32_t* __restrict__ order, const int express_wgs) {
+                                                      const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
-  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace, order, express_wgs);
+  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
 }
 
-__global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[kCtrlExpressTicket] = 0; ctrl[kCtrlArrivals] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
+__global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
 #endif   // GT_KERNEL_EMU
 
 }  // namespace
@@ -775,11 +746,8 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
 #ifndef GT_DF_NEAR_ROWS
 #define GT_DF_NEAR_ROWS 3
 #endif
-#ifndef GT_DF_EXPRESS_WGS
-#define GT_DF_EXPRESS_WGS 16     // workgroups of the bulk kernel that serve the express queue (0: one queue, rounds 2-4)
-#endif
-  constexpr int kFinalDiag = GT_DF_FINAL_DIAG, kNearRows = GT_DF_NEAR_ROWS, kExpressWgs = GT_DF_EXPRESS_WGS;
-  struct Rec { int32_t I, J, koff, kcnt, r, R; bool express = false; };
+  constexpr int kFinalDiag = GT_DF_FINAL_DIAG, kNearRows = GT_DF_NEAR_ROWS;
+  struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
   std::vector<int> diag_last_g(nt + 1, -1);                  // group of the last early piece of PD(J) (-1: none)
   auto emit = [&](int I, int J, std::vector<int32_t>& ks) {
@@ -792,10 +760,8 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     // the early steps cut into pieces of kPiece from the old end; a DIAGONAL tile's last early piece is short as well (kFinalDiag steps):
     // the last piece cannot start before it is done, and 4 steps are 73 us (round 5 trace: PD(J) late whenever that piece had 4)
     std::vector<int> cut;   // piece r = steps [cut[r], cut[r + 1])
-    const int tail = (near && m > kFinalDiag) ? kFinalDiag : 0;
-    // its last piece and that short early piece are handed out by the express queue (bulk_loop) when there is ONE chain
-    const bool express = near && !tree && I < nt && kExpressWgs > 0;
     {
+      const int tail = (near && m > kFinalDiag) ? kFinalDiag : 0;
       for (int b = 0; b < m - tail; b += kPiece) cut.push_back(b);
       if (tail) cut.push_back(m - tail);
       cut.push_back(m);
@@ -809,10 +775,10 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
       const int b = cut[r], e = cut[r + 1];
       const int last_k = ks[e - 1];
       const int g = std::max(pos[last_k] + 1, gprev);   // as early as its operands exist (<= G - 2)
-      early[g].push_back(Rec{I, J, off + b, e - b, r, R, express && tail && r == R - 2}); gprev = g;
+      early[g].push_back(Rec{I, J, off + b, e - b, r, R}); gprev = g;
       if (I == J) diag_last_g[J] = g;
     }
-    finals[G].push_back(Rec{I, J, off + m, f, R - 1, R, express});
+    finals[G].push_back(Rec{I, J, off + m, f, R - 1, R});
   };
   std::vector<int32_t> ks;
   std::vector<int32_t> has_sub(nt, 0);
@@ -839,8 +805,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // youngest operand is in place q - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
   // pieces that merely have to be done some columns later (with the early pieces of group q - 1 in front of them, the diagonal
   // accumulation was taken 30 us before it was needed and the chain waited 20 us for it every few columns)
-  df.h_express.clear();
-  auto put1 = [&](const Rec& t) { for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); df.h_express.push_back(t.express ? 1 : 0); };
+  auto put1 = [&](const Rec& t) { for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
   auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) put1(t); };
   // One chain: the two tasks of a column that the serial chain waits for -- PD(J) and the tile right below the diagonal tile -- are
   // queued one group EARLIER than the rest of their column, in front of the previous group's burst of early pieces (and behind their
@@ -924,19 +889,6 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
         seen[e] = 1;
       }
     }
-    // the two forms of the ticket order (bulk_loop): [0, 2 + n): with the express queue; [2 + n, 4 + 2 n): every task regular
-    {
-      const int32_t n = (int32_t)df.n_tasks;
-      std::vector<int32_t> ord; ord.reserve(4 + 2 * (size_t)n);
-      int32_t nx = 0; for (int64_t t = 0; t < n; t++) nx += df.h_express[t];
-      ord.push_back(n - nx); ord.push_back(nx);
-      for (int32_t t = 0; t < n; t++) if (!df.h_express[t]) ord.push_back(t);
-      for (int32_t t = 0; t < n; t++) if (df.h_express[t]) ord.push_back(t);
-      ord.push_back(n); ord.push_back(0);
-      for (int32_t t = 0; t < n; t++) ord.push_back(t);
-      df.order.upload(ord.data(), ord.size(), stream);
-      df.n_express = nx;
-    }
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
     std::vector<int32_t> cs(3 * (size_t)nt, -1);
@@ -948,18 +900,18 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
   df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included)
-  df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(32);
+  df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");
-  check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 32, stream), "memset");
+  check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 16, stream), "memset");
   check_hip(hipStreamSynchronize(stream), "df plan upload");
 }
 
 void free_df_plan(DfPlan& df) {
   df.tasks.free(); df.klist.free(); df.tile_flag.free(); df.part_flag.free(); df.pd_flag.free(); df.ctrl.free(); df.trace.free(); df.has_sub.free();
-  df.chain_off.free(); df.chain_tiles.free(); df.order.free();
+  df.chain_off.free(); df.chain_tiles.free();
 }
 
 // GTG_CHOL=streams selects the per-column launch sequence of cholesky.hip instead of the dataflow pass (the A/B of the tests; read per
@@ -1022,22 +974,15 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   // atomics, the flags by write-through stores and sc1 loads, and nothing the two kernels synchronise through is a word that a
   // kernel of the previous factorisation wrote with a plain store
   const long long epoch = ++c.chol_epoch;
-  // the express queue needs workgroups of its own AND workgroups for everything else: on a small grid (tests) everything is regular
-  auto order_for = [&](int grid, int& express_wgs) {
-    express_wgs = df.n_express > 0 ? std::min(GT_DF_EXPRESS_WGS, grid / 4) : 0;
-    return express_wgs > 0 ? df.order.p : df.order.p + 2 + df.n_tasks;
-  };
   hipLaunchKernelGGL(k_df_begin, dim3(1), dim3(1), 0, c.stream, c.chol_epoch_dev.p, epoch, df.ctrl.p);
   static const bool single = getenv("GTG_DF_SINGLE") != nullptr;
   if (single) {
     hipDeviceProp_t prop;
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
-    int xw1 = 0;
-    const int32_t* ord1 = order_for(g1 - df.n_chain, xw1);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
                        df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
-                       df.chain_off.p, df.chain_tiles.p, df.n_chain, ord1, xw1);
+                       df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
   }
@@ -1057,10 +1002,8 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
-  int xw = 0;
-  const int32_t* ord = order_for(grid, xw);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, ord, xw);
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
@@ -1072,7 +1015,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   constexpr int extra = 6;
   if (df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, ord, xw);
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");

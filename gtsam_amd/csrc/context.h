@@ -104,12 +104,9 @@ struct DfPlan {
   DevBuf<long long> tile_flag;                  // (nt + 1) x nt: epoch in which the tile became final
   DevBuf<long long> pd_flag;                    // nt: epoch in which the diagonal tile received all its updates
   int64_t shadow = 0;                           // every flag is also stored `shadow` words behind its word (chol_dataflow.hip::st_flag)
-  DevBuf<int32_t> ctrl;                         // [0] ticket counter of the bulk queue; [8..15] record of the first wait that gave up; [16] express tickets, [17] workgroups started
+  DevBuf<int32_t> ctrl;                         // [0] ticket counter of the bulk queue; [8..15] record of the first wait that gave up
   DevBuf<long long> trace;                      // GTG_DF_TRACE=1: 4 stamps per task + 2 per diagonal tile (gtg_debug_df_trace)
   std::vector<int32_t> h_tasks, h_klist;        // host copies (debug getters, CPU tests)
-  std::vector<uint8_t> h_express;               // per task: handed out by the express queue (the last two pieces of the tiles on / next to the serial chain)
-  DevBuf<int32_t> order;                        // the ticket order in its two forms (chol_dataflow.hip::bulk_loop): {n_reg, n_express, reg[], express[]}, then {n, 0, 0 .. n - 1}
-  int64_t n_express = 0;
   // the diagonal tiles by chain workgroup: workgroup w of k_df_chain factors chain_tiles[chain_off[w] .. chain_off[w + 1]) in that order.
   // One slot = two workgroups that alternate; several slots when a nested-dissection ordering gave the factorisation independent parts
   int n_chain = 0;

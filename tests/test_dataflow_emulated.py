@@ -39,15 +39,14 @@ def exe():
     return _build(EXE, [])
 
 
-def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8, near_rows=-1):
-    """One chain over a dense lower triangle + the rhs row (tile row nt).  Slots: column by column.
-    near_rows >= 0: the last two pieces of the diagonal tile and of that many tiles below it go to the express queue (bulk_loop)."""
+def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
+    """One chain over a dense lower triangle + the rhs row (tile row nt).  Slots: column by column."""
     slot = {}; n_slots = 0
     for J in range(nt):
         for I in range(J, nt + 1):
             slot[(I, J)] = n_slots; n_slots += 1
     finals = [[] for _ in range(nt)]; early = [[] for _ in range(nt)]
-    klist = []; express = set()
+    klist = []
     for J in range(nt):
         for I in list(range(J, nt)) + [nt]:
             ks = list(range(0, J - 1)) if I == J else list(range(0, J))        # PD(J): block column J-1 is the chain workgroup's
@@ -63,11 +62,7 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8, near_rows=-1):
                 b, e = r * k_piece, min(m, (r + 1) * k_piece)
                 g = max(ks[e - 1] + 1, gprev)
                 early[g].append([I, J, off + b, e - b, r, R]); gprev = g
-                if I < nt and I - J <= near_rows and r == R - 2:
-                    express.add((I, J, r))
             finals[J].append([I, J, off + m, n - m, R - 1, R])
-            if I < nt and I - J <= near_rows:
-                express.add((I, J, R - 1))
     order = []
     for q in range(nt):
         order += finals[q]
@@ -81,19 +76,17 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8, near_rows=-1):
             G = min(lane_max, E // 4)
             lanes[(t[0], t[1])] = (G, n_slots + n_scratch); n_scratch += G - 1
     tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) + [0, 0] for t in order]
-    is_x = [(t[0], t[1], t[4]) in express for t in order]
-    reg = [i for i, x in enumerate(is_x) if not x]; exp = [i for i, x in enumerate(is_x) if x]
     chain_slots = []
     for J in range(nt):
         chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1]
     t0 = list(range(0, nt, 2)); t1 = list(range(1, nt, 2))
     return dict(slot=slot, n_slots=n_slots, n_scratch=n_scratch, tasks=np.array(tasks, np.int32), klist=np.array(klist, np.int32).reshape(-1, 2),
                 chain_slots=np.array(chain_slots, np.int32), chain_off=np.array([0, len(t0), nt], np.int32), chain_tiles=np.array(t0 + t1, np.int32),
-                max_pieces=max(t[5] for t in order), lanes=lanes, order=np.array([len(reg), len(exp)] + reg + exp, np.int32))
+                max_pieces=max(t[5] for t in order), lanes=lanes)
 
 
-def factor(exe, nt, n_bulk, k_piece, k_final, tmp_path, seed=3, lane_min=8, express_wgs=0, near_rows=-1):
-    P = plan_dense(nt, k_piece, k_final, lane_min=lane_min, near_rows=near_rows)
+def factor(exe, nt, n_bulk, k_piece, k_final, tmp_path, seed=3, lane_min=8):
+    P = plan_dense(nt, k_piece, k_final, lane_min=lane_min)
     rng = np.random.default_rng(seed)
     N = nt * T
     M = rng.standard_normal((N, N + 40)); A = M @ M.T + N * np.eye(N); g = rng.standard_normal(N)
@@ -106,20 +99,18 @@ def factor(exe, nt, n_bulk, k_piece, k_final, tmp_path, seed=3, lane_min=8, expr
     S[P["n_slots"]:] = np.nan                                  # scratch slots of the accumulator lanes: whatever was there before
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
-        f.write(np.array([nt, n_all, len(P["tasks"]), len(P["klist"]), 2, n_bulk, 4096, express_wgs], np.int64).tobytes())
-        if express_wgs == 0:      # launch_cholesky_df::order_for: without express workgroups the order lists every task as regular
-            P["order"] = np.array([len(P["tasks"]), 0] + list(range(len(P["tasks"]))), np.int32)
-        for a in (S, P["tasks"], P["klist"], P["chain_slots"], P["chain_off"], P["chain_tiles"], P["order"]):
+        f.write(np.array([nt, n_all, len(P["tasks"]), len(P["klist"]), 2, n_bulk, 4096], np.int64).tobytes())
+        for a in (S, P["tasks"], P["klist"], P["chain_slots"], P["chain_off"], P["chain_tiles"]):
             f.write(np.ascontiguousarray(a).tobytes())
     r = subprocess.run([exe, fin, fout], timeout=1500)
     assert r.returncode == 0
     raw = open(fout, "rb").read()
     So = np.frombuffer(raw, np.float64, n_all * T * T, 0).reshape(n_all, T, T)
     o = So.nbytes + nt * T * T * 8
-    fail = np.frombuffer(raw, np.float64, 2, o); ctrl = np.frombuffer(raw, np.int32, 32, o + 16)
+    fail = np.frombuffer(raw, np.float64, 2, o); ctrl = np.frombuffer(raw, np.int32, 16, o + 16)
     factor.last = (So.copy(), np.frombuffer(raw, np.float64, nt * T * T, So.nbytes).copy())
     assert fail[0] == 0.0 and fail[1] == 0.0, (fail, ctrl)
-    assert ctrl[0] >= P["order"][0] and ctrl[16] >= P["order"][1] and ctrl[1] == nt        # every ticket of both queues taken, every diagonal tile factored
+    assert ctrl[0] >= len(P["tasks"]) and ctrl[1] == nt        # every ticket taken, every diagonal tile factored
     L = np.linalg.cholesky(A); y = np.linalg.solve(L, g)
     for J in range(nt):
         for I in range(J, nt):
@@ -145,19 +136,6 @@ def test_emulated_dataflow_factorisation_with_accumulator_lanes(exe, tmp_path):
     lanes (scratch slots behind the stored tiles, NaN before the run), added up by the final piece in lane order."""
     P = factor(exe, 11, 4, 1, 1, tmp_path)
     assert P["lanes"] and P["n_scratch"] > 0
-
-
-@pytest.mark.parametrize("n_bulk,express_wgs", [(3, 1), (3, 2), (2, 0)])   # (2, 0): what the host does on a small grid -- every task regular
-def test_emulated_dataflow_factorisation_with_the_express_queue(exe, tmp_path, n_bulk, express_wgs):
-    """The last two pieces of the diagonal tile and the two tiles below it are handed out from their own counter to the first
-    workgroups that start (one / two of three; a workgroup whose queue is exhausted serves the other one): the same bits as with one
-    queue -- every sum keeps its order -- and no wait runs into its bound."""
-    factor(exe, 6, 3, 2, 1, tmp_path)
-    S0, X0 = factor.last
-    P = factor(exe, 6, n_bulk, 2, 1, tmp_path, express_wgs=express_wgs, near_rows=2)
-    assert P["order"][1] >= (12 if express_wgs else 0)
-    S1, X1 = factor.last
-    assert np.array_equal(S0, S1)
 
 
 def test_emulated_dataflow_factorisation_is_reproducible_with_the_deferred_last_slice(exe, tmp_path):

@@ -3,10 +3,9 @@
 // process's static storage), one thread per work-item, device memory = a shared mapping, so that the chain and the bulk workgroups run
 // side by side and talk through flags exactly as on the device.  tests/test_dataflow_emulated.py factors a small dense system with it.
 //   dataflow_emu <in.bin> <out.bin>
-//   in : int64 header {nt, n_slots, n_tasks, n_kpairs, n_chain_wg, n_bulk_wg, sh, express_wgs}, S [n_slots][128][128] f64, tasks [n_tasks][12] i32,
-//        klist [n_kpairs][2] i32, chain_slots [3 nt] i32, chain_off [n_chain_wg + 1] i32, chain_tiles [nt] i32,
-//        order [2 + n_tasks] i32 (bulk_loop: n_reg, n_express, the regular tasks, the express tasks)
-//   out: S, Xinv [nt][128][128] f64, fail [2] f64, ctrl [32] i32
+//   in : int64 header {nt, n_slots, n_tasks, n_kpairs, n_chain_wg, n_bulk_wg, sh}, S [n_slots][128][128] f64, tasks [n_tasks][12] i32,
+//        klist [n_kpairs][2] i32, chain_slots [3 nt] i32, chain_off [n_chain_wg + 1] i32, chain_tiles [nt] i32
+//   out: S, Xinv [nt][128][128] f64, fail [2] f64, ctrl [16] i32
 #include "emu_hip.h"
 
 #include <sys/mman.h>
@@ -30,11 +29,10 @@ int main(int argc, char** argv) {
   if (argc < 3) return 2;
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 2;
-  int64_t h[8];
-  if (std::fread(h, sizeof(int64_t), 8, f) != 8) return 2;
+  int64_t h[7];
+  if (std::fread(h, sizeof(int64_t), 7, f) != 7) return 2;
   const int nt = (int)h[0], n_slots = (int)h[1], n_tasks = (int)h[2], n_kp = (int)h[3], n_chain = (int)h[4], n_bulk = (int)h[5];
   const long long sh = h[6];
-  const int express_wgs = (int)h[7];
   double* S = shared_alloc<double>((size_t)n_slots * kTileDoubles);
   double* Xinv = shared_alloc<double>((size_t)nt * kTileDoubles);
   int32_t* tasks = shared_alloc<int32_t>((size_t)12 * n_tasks);
@@ -45,13 +43,11 @@ int main(int argc, char** argv) {
   long long* tile_flag = shared_alloc<long long>((size_t)n_slots + sh + 8);
   long long* part_flag = shared_alloc<long long>((size_t)n_slots + sh + 8);
   long long* pd_flag = shared_alloc<long long>((size_t)nt + sh + 8);
-  int32_t* ctrl = shared_alloc<int32_t>(32);
-  int32_t* order = shared_alloc<int32_t>((size_t)n_tasks + 2);
+  int32_t* ctrl = shared_alloc<int32_t>(16);
   double* fail = shared_alloc<double>(2);
   auto rd = [&](void* p, size_t bytes) { if (bytes && std::fread(p, 1, bytes, f) != bytes) { std::fprintf(stderr, "short input\n"); std::exit(2); } };
   rd(S, sizeof(double) * (size_t)n_slots * kTileDoubles); rd(tasks, 4 * (size_t)12 * n_tasks); rd(klist, 4 * (size_t)2 * n_kp);
   rd(chain_slots, 4 * (size_t)3 * nt); rd(chain_off, 4 * ((size_t)n_chain + 1)); rd(chain_tiles, 4 * (size_t)nt);
-  rd(order, 4 * ((size_t)n_tasks + 2));
   std::fclose(f);
   ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1;
   const long long epoch = 1;
@@ -69,7 +65,7 @@ int main(int argc, char** argv) {
       } else {
         static char smem[gt::kSmemBulk + 64];
         emu::run_workgroup(gt::kBulkThreads, (unsigned)(w - n_chain), [&] {
-          gt::bulk_loop(smem, S, tasks, n_tasks, klist, tile_flag, part_flag, pd_flag, Xinv, ctrl, fail, epoch, sh, nullptr, order, express_wgs);
+          gt::bulk_loop(smem, S, tasks, n_tasks, klist, tile_flag, part_flag, pd_flag, Xinv, ctrl, fail, epoch, sh, nullptr);
         });
       }
       _exit(0);
@@ -83,7 +79,7 @@ int main(int argc, char** argv) {
   std::fwrite(S, sizeof(double), (size_t)n_slots * kTileDoubles, o);
   std::fwrite(Xinv, sizeof(double), (size_t)nt * kTileDoubles, o);
   std::fwrite(fail, sizeof(double), 2, o);
-  std::fwrite(ctrl, sizeof(int32_t), 32, o);
+  std::fwrite(ctrl, sizeof(int32_t), 16, o);
   std::fclose(o);
   return bad ? 3 : 0;
 }

@@ -276,7 +276,7 @@ def main():
     # every tile stored) -- the regime where the trailing update (k_syrk) dominates and the MFMA roofline applies.
     dense = None
     if world == 1 and not args.skip_dense_roofline:
-        os.environ["GTG_NO_REORDER"] = "1"; os.environ["GTG_DENSE_PLAN"] = "1"
+        os.environ["GTG_ORDERING"] = "natural"; os.environ["GTG_DENSE_PLAN"] = "1"
         try:
             od = fresh()
             od.iterate()
@@ -288,7 +288,7 @@ def main():
             dense = {"flops_per_launch": od.dev.cholesky_flops(), "ms_per_launch": dms / max(dcalls, 1)}
             od.dev.close()
         finally:
-            os.environ.pop("GTG_NO_REORDER", None); os.environ.pop("GTG_DENSE_PLAN", None)
+            os.environ.pop("GTG_ORDERING", None); os.environ.pop("GTG_DENSE_PLAN", None)
 
     # time-to-converged-chi^2: one full optimize() from the initial values (construction -> checkConvergence), as a program pays
     # it that optimises one problem after the other: the handle of the timed loop is released first (the library keeps its big

@@ -393,7 +393,8 @@ void analyze(gtg_context& c) {
   const char* nd_env = std::getenv("GTG_ND_DEPTH");
   const bool nd_forced = nd_env != nullptr;
   int nd_auto = 0;
-  const char* ord_req = std::getenv("GTG_ORDERING");   // an explicitly requested ordering method (rcm, mindegree, auto) is one chain
+  const char* ord_req = std::getenv("GTG_ORDERING");   // an explicitly requested ordering method (rcm, mindegree, auto; natural = the caller's order) is one chain
+  const bool keep_order = ord_req && std::string(ord_req) == "natural";
   if (!nd_forced && hi.user_order.empty() && c.n_red >= 24 * (int64_t)kTile && !ord_req) {
     double nnz = 0.0;
     for_each_block([&](int ra, int rb) { if (ra != rb) nnz += 2.0 * c.h_red_dim[ra] * c.h_red_dim[rb]; });
@@ -408,7 +409,7 @@ void analyze(gtg_context& c) {
   bool retry_rcm = false;
   std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
   std::vector<int32_t> part_parent;          // parent part (-1: root) of every part, parts numbered in elimination order
-  if (hi.user_order.empty() && c.n_red_vars >= 16 && !std::getenv("GTG_NO_REORDER")) {
+  if (hi.user_order.empty() && c.n_red_vars >= 16 && !keep_order) {
     const int nrv2 = c.n_red_vars;
     std::vector<std::vector<int32_t>> adj(nrv2);
     bool have_adj = false;
@@ -762,13 +763,23 @@ void analyze(gtg_context& c) {
       // sharded: the block-granular exchange list (diagonal blocks, then the off-diagonal blocks of the whole graph)
       c.n_xb = 0;
       {
+        // the block SET identifies the layout (a commutative sum over the blocks: a sharded handle lists them in bitmap order, a single
+        // one in term order); only a sharded handle, or one whose pose pairs can carry two kinds of blocks, needs the list itself
+        uint64_t hb = 0;
+        auto mix_block = [&](int64_t ro, int64_t co, int32_t dd) {
+          uint64_t z = (uint64_t)ro * 0x9E3779B97F4A7C15ull ^ ((uint64_t)co + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)dd;
+          z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+          hb += z;
+        };
         std::vector<int64_t> xro, xco; std::vector<int32_t> xd;
-        for (int r = 0; r < c.n_red_vars; r++) { xro.push_back(c.h_red_off[r]); xco.push_back(c.h_red_off[r]); xd.push_back(c.h_red_dim[r] | (c.h_red_dim[r] << 8)); }
+        const bool need_list = c.n_shards > 1 || (!pair_row.empty() && !hoff_row.empty());
+        auto add_block = [&](int64_t ro, int64_t co, int32_t dd) { if (need_list) { xro.push_back(ro); xco.push_back(co); xd.push_back(dd); } else mix_block(ro, co, dd); };
+        for (int r = 0; r < c.n_red_vars; r++) add_block(c.h_red_off[r], c.h_red_off[r], c.h_red_dim[r] | (c.h_red_dim[r] << 8));
         for_each_block([&](int ra, int rb) {
           if (ra == rb) return;                                  // a camera's Schur terms with itself: the diagonal block above
           const bool a_later = c.h_red_pos[ra] > c.h_red_pos[rb];
           const int rr = a_later ? ra : rb, rc = a_later ? rb : ra;
-          xro.push_back(c.h_red_off[rr]); xco.push_back(c.h_red_off[rc]); xd.push_back(c.h_red_dim[rr] | (c.h_red_dim[rc] << 8));
+          add_block(c.h_red_off[rr], c.h_red_off[rc], c.h_red_dim[rr] | (c.h_red_dim[rc] << 8));
         });
         if (c.n_shards > 1) { c.n_xb = (int64_t)xd.size(); up(c.xb_row_off, xro, s); up(c.xb_col_off, xco, s); up(c.xb_dim, xd, s); }
         else if (!pair_row.empty() && !hoff_row.empty()) {   // a pose pair can carry a Schur block AND a between block: one entry in the set
@@ -780,13 +791,7 @@ void analyze(gtg_context& c) {
             if (k == 0 || xro[idx[k]] != xro[idx[k - 1]] || xco[idx[k]] != xco[idx[k - 1]]) { r2.push_back(xro[idx[k]]); c2.push_back(xco[idx[k]]); d2.push_back(xd[idx[k]]); }
           xro.swap(r2); xco.swap(c2); xd.swap(d2);
         }
-        // the block SET identifies the layout; a sharded handle lists it in bitmap order, a single one in term order
-        uint64_t hb = 0;
-        for (size_t i = 0; i < xd.size(); i++) {
-          uint64_t z = (uint64_t)xro[i] * 0x9E3779B97F4A7C15ull ^ ((uint64_t)xco[i] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)xd[i];
-          z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
-          hb += z;
-        }
+        for (size_t i = 0; i < xd.size(); i++) mix_block(xro[i], xco[i], xd[i]);
         mix(&hb, sizeof(hb));
       }
       c.structure_hash = h;

@@ -264,7 +264,7 @@ int gtg_destroy(gtg_handle c) {
   auto& f = c->f;
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,
-                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->wobs, &c->cam_part, &c->pcg_vec, &c->pcg_bj, &c->pcg_y, &c->delta_lm, &c->S,
+                           &c->hdiag_red, &c->V, &c->gp, &c->Hoff, &c->Linv, &c->ylm, &c->E, &c->vobs, &c->wobs, &c->cam_part, &c->cam_pack, &c->pcg_vec, &c->pcg_bj, &c->pcg_y, &c->delta_lm, &c->S,
                            &c->Dinv, &c->xred, &c->partials, &c->scalars, &c->noise_rk};
   for (auto* b : dbl) b->free();
   DevBuf<int32_t>* i32[] = {&c->var_type, &c->lm_var, &c->red_var, &c->red_dim, &c->lm_index, &c->red_index, &c->lm_owned,
@@ -433,9 +433,10 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
   { // SFM
     std::vector<int32_t> cam, pt, nz; std::vector<double> z;
     for (int64_t i = 0; i < p->n_sfm; i++) { check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor"); }
-    if (n_shards == 1) {   // the whole table: block copies
-      cam.assign(p->sfm_cam, p->sfm_cam + p->n_sfm); pt.assign(p->sfm_point, p->sfm_point + p->n_sfm);
-      nz.assign(p->sfm_noise, p->sfm_noise + p->n_sfm); z.assign(p->sfm_z, p->sfm_z + 2 * p->n_sfm);
+    const bool whole = n_shards == 1 && p->n_sfm > 0;   // the whole table: noise rows and measurements go up straight from the caller's arrays
+    if (n_shards == 1) {
+      cam.assign(p->sfm_cam, p->sfm_cam + p->n_sfm); pt.assign(p->sfm_point, p->sfm_point + p->n_sfm);   // (kept by the host index: gtg_set_reduced_ordering analyses again)
+      if (!whole) { nz.assign(p->sfm_noise, p->sfm_noise + p->n_sfm); z.assign(p->sfm_z, p->sfm_z + 2 * p->n_sfm); }
     } else {
       for (int64_t i = 0; i < p->n_sfm; i++) {
         if (!own_lm(p->sfm_point[i])) continue;
@@ -462,11 +463,12 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
       up(c->sfm_smart, of_local, s);
     }
     f.n_sfm = (int64_t)cam.size();
-    up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s); up(f.sfm_noise, nz, s); up(f.sfm_z, z, s);
+    up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s);
+    if (whole) { f.sfm_noise.upload(p->sfm_noise, (size_t)p->n_sfm, s); f.sfm_z.upload(p->sfm_z, 2 * (size_t)p->n_sfm, s); }
+    else { up(f.sfm_noise, nz, s); up(f.sfm_z, z, s); }
     if (c->val_size >= (int64_t)1 << 31) throw std::invalid_argument("gtg_upload_problem: more than 2^31 packed value entries");
-    { std::vector<int32_t> ca(cam.size()), pa(pt.size());
-      for (size_t i = 0; i < cam.size(); i++) { ca[i] = (int32_t)c->h_val_off[cam[i]]; pa[i] = (int32_t)c->h_val_off[pt[i]]; }
-      up(f.sfm_cam_at, ca, s); up(f.sfm_point_at, pa, s); }
+    f.sfm_cam_at.alloc(std::max<size_t>(cam.size(), 1)); f.sfm_point_at.alloc(std::max<size_t>(pt.size(), 1));
+    launch_sfm_value_offsets(*c);     // where each factor's camera / point start in the packed values (a gather through val_off, on the device)
     f.sfm_J.alloc(c->fused_sfm ? 1 : std::max<size_t>((size_t)kSfmRec * f.n_sfm, 1));
     hi.sfm_cam = std::move(cam); hi.sfm_point = std::move(pt);
   }

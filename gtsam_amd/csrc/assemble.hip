@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void k_red_diag(int32_t n_red_vars,
 constexpr int kCamWaves = 4;
 constexpr int kCamPartStride = 96;   // doubles per (variable, part) in the partial buffer (>= 9 * 9 + 9)
 __global__ __launch_bounds__(64 * kCamWaves) void k_cam_fused(int32_t n_red_vars, int splits, const int64_t* __restrict__ inc_ptr,
-    const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx, const int32_t* __restrict__ red_dim,
+    const CamPack* __restrict__ pack, const int32_t* __restrict__ red_dim,
     const int64_t* __restrict__ red_off, SfmTabs t, double* __restrict__ Hd, double* __restrict__ g, double* __restrict__ hdiag,
     double* __restrict__ part) {
   typedef RecIO<kSfmRec> IO;
@@ -131,10 +131,12 @@ __global__ __launch_bounds__(64 * kCamWaves) void k_cam_fused(int32_t n_red_vars
   v4f64a acc = {0.0, 0.0, 0.0, 0.0};
   for (int64_t base = s0 + 64 * wave; base < s1; base += 64 * kCamWaves) {
     const int64_t k = base + lane;
-    if (k < s1 && inc_kind[k] == INC_SFM) sfm_record(t, inc_idx[k], rec);
+    CamPack e; e.cam_at = -1;
+    if (k < s1) e = pack[k];
+    if (e.cam_at >= 0) sfm_record_at(t, e.cam_at, e.pt_at, e.nz, e.z0, e.z1, rec);
     else
 #pragma unroll
-      for (int e = 0; e < kSfmRec; e++) rec[e] = 0.0;
+      for (int q = 0; q < kSfmRec; q++) rec[q] = 0.0;
     IO::wave_sync();
 #pragma unroll 8
     for (int m = 0; m < 32; m++) {
@@ -641,9 +643,29 @@ __global__ __launch_bounds__(kBlock) void k_obs_wpos(int64_t n_inc, const int32_
     else if (kind == INC_PROJ) wpos[n_sfm + inc_idx[k]] = (int32_t)k;
   }
 }
+// once per graph: the camera-sorted contribution lists' GeneralSFM entries packed in list order (fused.h::CamPack)
+__global__ __launch_bounds__(kBlock) void k_cam_pack(int64_t n_inc, const int32_t* __restrict__ inc_kind, const int32_t* __restrict__ inc_idx,
+    const int32_t* __restrict__ cam_at, const int32_t* __restrict__ pt_at, const int32_t* __restrict__ nz, const double* __restrict__ z,
+    CamPack* __restrict__ pack) {
+  for (int64_t k = blockIdx.x * (int64_t)kBlock + threadIdx.x; k < n_inc; k += (int64_t)gridDim.x * kBlock) {   // (grid1 caps the grid)
+    CamPack e; e.cam_at = -1; e.pt_at = 0; e.nz = 0; e.pad = 0; e.z0 = 0.0; e.z1 = 0.0;
+    if (inc_kind[k] == INC_SFM) {
+      const int64_t i = inc_idx[k];
+      e.cam_at = cam_at[i]; e.pt_at = pt_at[i]; e.nz = nz[i]; e.z0 = z[2 * i]; e.z1 = z[2 * i + 1];
+    }
+    pack[k] = e;
+  }
+}
 void launch_obs_wpos(gtg_context& c, int64_t n_inc) {
   if (n_inc > 0 && c.n_obs > 0)
     hipLaunchKernelGGL(k_obs_wpos, dim3(grid1(n_inc)), dim3(kBlock), 0, c.stream, n_inc, c.red_inc_kind.p, c.red_inc_idx.p, c.f.n_sfm, c.obs_wpos.p);
+  if (c.fused_sfm) {
+    static_assert(sizeof(CamPack) == 4 * sizeof(double), "CamPack is stored in a buffer of doubles");
+    c.cam_pack.alloc(4 * (size_t)std::max<int64_t>(n_inc, 1));
+    if (n_inc > 0)
+      hipLaunchKernelGGL(k_cam_pack, dim3(grid1(n_inc)), dim3(kBlock), 0, c.stream, n_inc, c.red_inc_kind.p, c.red_inc_idx.p, c.f.sfm_cam_at.p,
+                         c.f.sfm_point_at.p, c.f.sfm_noise.p, c.f.sfm_z.p, reinterpret_cast<CamPack*>(c.cam_pack.p));
+  }
   check_hip(hipGetLastError(), "obs_wpos");
 }
 
@@ -654,7 +676,7 @@ void launch_assemble(gtg_context& c) {
     const int splits = c.n_red_vars >= 512 ? 1 : std::min(16, (1024 + c.n_red_vars - 1) / c.n_red_vars);
     if (splits > 1 && (int64_t)c.cam_part.n != (int64_t)c.n_red_vars * splits * kCamPartStride) c.cam_part.alloc((size_t)c.n_red_vars * splits * kCamPartStride);
     hipLaunchKernelGGL(k_cam_fused, dim3((unsigned)(c.n_red_vars * splits)), dim3(64 * kCamWaves), 0, c.stream, c.n_red_vars, splits, c.red_inc_ptr.p,
-                       c.red_inc_kind.p, c.red_inc_idx.p, c.red_dim.p, c.red_off.p, sfm_tabs(c), c.Hd.p, c.gred0.p, c.hdiag_red.p, c.cam_part.p);
+                       reinterpret_cast<const CamPack*>(c.cam_pack.p), c.red_dim.p, c.red_off.p, sfm_tabs(c), c.Hd.p, c.gred0.p, c.hdiag_red.p, c.cam_part.p);
     if (splits > 1)
       hipLaunchKernelGGL(k_cam_combine, dim3((unsigned)c.n_red_vars), dim3(128), 0, c.stream, c.n_red_vars, splits, c.red_dim.p, c.red_off.p,
                          c.cam_part.p, c.Hd.p, c.gred0.p, c.hdiag_red.p);

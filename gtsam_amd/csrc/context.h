@@ -232,6 +232,7 @@ struct gtg_context {
   gt::DevBuf<double> wobs;                      // per try: E_o y_l (9 doubles) per entry of the cameras' contribution lists: the summands of the reduced right-hand side
   gt::DevBuf<int32_t> obs_wpos;                 // observation -> its entry in red_inc_* (where k_obs_E stores its summand)
   gt::DevBuf<double> cam_part;                  // k_cam_fused with several workgroups per camera: their partial sums
+  gt::DevBuf<double> cam_pack;                  // fused.h::CamPack per entry of the camera-sorted contribution lists (4 doubles each), once per graph
   gt::DevBuf<double> vobs;                      // per try: Jp^T (Jc x_cam) of every observation (3), for the back-substitution
   gt::DevBuf<double> S;                         // plan.n_stored slots of 128 x 128 doubles: the stored tiles of the reduced system + the rhs row's tiles
   gt::DevBuf<double> yred;                      // NP: y = L^-1 g gathered from the rhs tiles for the backward solve

@@ -472,6 +472,23 @@ void launch_linearize(gtg_context& c) {
   check_hip(hipGetLastError(), "linearize");
 }
 
+// once per graph: the packed-value offsets of every GeneralSFM factor's camera and point (fused.h::SfmTabs)
+__global__ __launch_bounds__(kBlock) void k_sfm_value_offsets(int64_t n, const int32_t* __restrict__ cam, const int32_t* __restrict__ pt,
+                                                              const int64_t* __restrict__ val_off, int32_t* __restrict__ cam_at,
+                                                              int32_t* __restrict__ pt_at) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {   // (grid_for caps the grid)
+    cam_at[i] = (int32_t)val_off[cam[i]];
+    pt_at[i] = (int32_t)val_off[pt[i]];
+  }
+}
+void launch_sfm_value_offsets(gtg_context& c) {
+  auto& f = c.f;
+  if (!f.n_sfm) return;
+  hipLaunchKernelGGL(k_sfm_value_offsets, dim3(grid_for(f.n_sfm)), dim3(kBlock), 0, c.stream, f.n_sfm, f.sfm_cam.p, f.sfm_point.p, c.val_off.p,
+                     f.sfm_cam_at.p, f.sfm_point_at.p);
+  check_hip(hipGetLastError(), "sfm_value_offsets");
+}
+
 // debug (gtg_get_jacobians on a graph whose GeneralSFM records are not stored): the records as k_lin_sfm writes them, into `dst`
 void launch_sfm_records(gtg_context& c, double* dst) {
   auto& f = c.f;

@@ -34,17 +34,24 @@ struct SfmTabs {
   NoiseTab nt;
 };
 
-// record of GeneralSFM factor i -> rec[0 .. kSfmRec) (a row of the calling wavefront's LDS image)
-__device__ __forceinline__ void sfm_record(const SfmTabs& t, int64_t i, double* rec) {
-  double c[17], p[3], zz[2];
-  const double* cp = t.values + t.cam_at[i];
-  const double* pp = t.values + t.pt_at[i];
+// One entry of the CAMERA-SORTED contribution lists, packed once per graph (assemble.hip::k_cam_pack): what sfm_record reads through the
+// factor index -- five 4 / 8-byte gathers out of five tables when the list is not in factor order (325 MB of 64-byte sectors per pass on
+// the L1723 shape, whose factors are landmark-major) -- lies in list order here: two 16-byte loads per lane, coalesced.
+struct alignas(16) CamPack { int32_t cam_at, pt_at, nz, pad; double z0, z1; };   // cam_at < 0: not a GeneralSFM entry
+
+__device__ __forceinline__ void sfm_record_at(const SfmTabs& t, int cam_at, int pt_at, int nz, double z0, double z1, double* rec) {
+  double c[17], p[3], zz[2] = {z0, z1};
+  const double* cp = t.values + cam_at;
+  const double* pp = t.values + pt_at;
 #pragma unroll
   for (int k = 0; k < 17; k++) c[k] = cp[k];
 #pragma unroll
   for (int k = 0; k < 3; k++) p[k] = pp[k];
-  zz[0] = t.z[2 * i]; zz[1] = t.z[2 * i + 1];
-  sfm_linearize(c, p, zz, t.nt.ref(t.nz[i]), rec);
+  sfm_linearize(c, p, zz, t.nt.ref(nz), rec);
+}
+// record of GeneralSFM factor i -> rec[0 .. kSfmRec) (a row of the calling wavefront's LDS image)
+__device__ __forceinline__ void sfm_record(const SfmTabs& t, int64_t i, double* rec) {
+  sfm_record_at(t, t.cam_at[i], t.pt_at[i], t.nz[i], t.z[2 * i], t.z[2 * i + 1], rec);
 }
 
 }  // namespace gt

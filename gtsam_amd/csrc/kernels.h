@@ -8,6 +8,7 @@ namespace gt {
 
 // factors.hip -------------------------------------------------------------------------------------
 void launch_linearize(gtg_context& c);                                  // fills *_J from c.values (not the GeneralSFM records of a fused graph: fused.h)
+void launch_sfm_value_offsets(gtg_context& c);                            // once per graph: f.sfm_cam_at / sfm_point_at = val_off[f.sfm_cam / sfm_point]
 void launch_sfm_records(gtg_context& c, double* dst);                    // debug: the GeneralSFM records of the current values into dst
 void launch_error(gtg_context& c, const double* values, int scalar_slot, const double* gate = nullptr);  // nonlinear error -> scalars[slot] (gate: as launch_smart_triangulate)
 void launch_linear_error(gtg_context& c);                               // scalars[SC_LIN0], [SC_LIN1] from J, delta

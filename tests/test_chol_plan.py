@@ -315,7 +315,7 @@ def test_schedule_reproduces_a_dense_cholesky(stub, workload, nd):
 
 
 def test_forced_dense_schedule(stub):
-    d = HP.run_snippet(_CHILD % {"root": ROOT, "workload": "bal:60:6000:7"}, env_extra={"GTG_DENSE_PLAN": "1", "GTG_NO_REORDER": "1"})
+    d = HP.run_snippet(_CHILD % {"root": ROOT, "workload": "bal:60:6000:7"}, env_extra={"GTG_DENSE_PLAN": "1", "GTG_ORDERING": "natural"})
     pl = dict(d)
     for k in ("rows", "pairs", "bcols", "pair_part", "part_parent"):
         pl[k] = np.array(d[k], np.int64)

@@ -4,7 +4,7 @@ The host builds the Schur term lists with bucketed counting sorts on threads (cs
 lists are to come from three data-parallel primitives: enumerate every landmark's observation pairs at the offsets of an
 exclusive scan, STABLE radix sort of the terms by their block key (row position * n + column position), run-length encode
 the sorted keys.  This test states that formulation in numpy and checks that it reproduces, bit for bit, the term lists the
-library uploads (compared through the upload hashes of tools/hipstub, with GTG_NO_REORDER=1 so that the positions are the
+library uploads (compared through the upload hashes of tools/hipstub, with GTG_ORDERING=natural so that the positions are the
 caller's order): same terms, same order inside every block (landmark order -- the summation order of the device), same
 handling of a camera that observes a landmark twice."""
 import os
@@ -88,7 +88,7 @@ def _sort_based_term_lists(problem):
 def test_sort_based_formulation_reproduces_the_host_lists(workload):
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
         pytest.skip("libgtsam_amd.so not built")
-    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_NO_REORDER": "1"})
+    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_ORDERING": "natural"})
     have = {(int(n), int(h)) for n, h in recs}
     problem, _ = HP.problem_for(workload)
     oa, ob, ptr = _sort_based_term_lists(problem)
@@ -132,7 +132,7 @@ def test_sort_based_incidence_lists_reproduce_the_host_lists(workload):
     variable -> factors): the sort-based formulation against the lists the host's counting sorts upload."""
     if not os.path.exists(os.path.join(ROOT, "gtsam_amd", "lib", "libgtsam_amd.so")):
         pytest.skip("libgtsam_amd.so not built")
-    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_NO_REORDER": "1"})
+    recs = HP.run_snippet(_CHILD % {"root": ROOT, "workload": workload}, env_extra={"GTG_ORDERING": "natural"})
     have = {(int(n), int(h)) for n, h in recs}
     problem, _ = HP.problem_for(workload)
     if workload.startswith("smart:"):          # the library's own view of a smart graph: hidden landmarks, measurements as observations

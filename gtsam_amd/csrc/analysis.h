@@ -37,6 +37,7 @@ struct StageClock {   // GTG_DEBUG_TIMING=1 prints the host-side setup breakdown
   }
 };
 
+void join_block_level(gtg_context& c);       // waits for the handle's block-level flop count (analysis.hip: it runs on a thread of the handle)
 HostIndex& host_index(gtg_context* c);     // the handle's host-side index arrays (created on first use)
 void drop_index(gtg_context* c);
 // landmark classification, CSR incidence lists, Schur block / term lists, ordering of the reduced variables, tile schedule

@@ -402,9 +402,9 @@ void analyze(gtg_context& c) {
     // (3 levels on 4 slots, round 3: 1.38 / 5.05; 2 levels: 1.78; one chain: 4.6 / 18.4; 5 levels: no better)
     if (nnz <= 0.01 * (double)c.n_red * (double)c.n_red) nd_auto = 4;
   }
-  struct Joiner { std::thread t; std::exception_ptr err; ~Joiner() { if (t.joinable()) t.join(); } } block_level;   // (see below)
+  join_block_level(c);      // the flop count of a previous analysis of this handle (below) may still be running
   for (int attempt = 0; attempt < 2; attempt++) {
-  if (block_level.t.joinable()) block_level.t.join();   // a second attempt rewrites the ordering the thread reads
+  join_block_level(c);
   const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : nd_auto) : 0;
   bool retry_rcm = false;
   std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
@@ -662,18 +662,24 @@ void analyze(gtg_context& c) {
   // ---- block-level symbolic factorisation: the flops the elimination needs at the granularity of the variables (d x d
   // blocks, fill included) -- sum over block columns of f^3/3 + f^2 s + f s^2 (f = the variable's dimension, s = the dimension
   // of its below-diagonal structure), the count SURVEY section 8(d) asks for next to the stored-tile count the kernels execute.
-  // It only feeds a getter, so it runs on its own host thread beside the tile schedule and the uploads (read-only on the block
-  // lists; joined before analyze() returns, also when something below throws).
-  block_level.t = std::thread([&] { try {
-    const int n = c.n_red_vars;
+  // It only feeds a getter (gtg_cholesky_flops_block_level), so it runs on a host thread of the HANDLE, on its own copies of the block
+  // list and the ordering, and is joined by whoever needs it next: the getter, the next analysis of the handle, gtg_destroy (round 5:
+  // analyze() used to wait 1.3 ms for it on the L1723 shape).
+  {
+  std::vector<int32_t> bl_a, bl_b;                      // the off-diagonal blocks by position (min, max)
+  for_each_block([&](int ra, int rb) {
+    if (ra == rb) return;
+    const int pa = c.h_red_pos[ra], pb = c.h_red_pos[rb];
+    bl_a.push_back(std::min(pa, pb)); bl_b.push_back(std::max(pa, pb));
+  });
+  std::vector<int32_t> dim_at_pos(c.n_red_vars);
+  for (int r = 0; r < c.n_red_vars; r++) dim_at_pos[c.h_red_pos[r]] = c.h_red_dim[r];
+  gtg_context* cp = &c;
+  c.block_level_err = nullptr;
+  c.block_level_thread = std::thread([cp, bl_a = std::move(bl_a), bl_b = std::move(bl_b), dim_at = std::move(dim_at_pos)] { try {
+    const int n = (int)dim_at.size();
     std::vector<std::vector<int32_t>> below(n);          // positions > own position
-    for_each_block([&](int ra, int rb) {
-      if (ra == rb) return;
-      const int pa = c.h_red_pos[ra], pb = c.h_red_pos[rb];
-      below[std::min(pa, pb)].push_back(std::max(pa, pb));
-    });
-    std::vector<int32_t> dim_at(n);
-    for (int r = 0; r < n; r++) dim_at[c.h_red_pos[r]] = c.h_red_dim[r];
+    for (size_t i = 0; i < bl_a.size(); i++) below[bl_a[i]].push_back(bl_b[i]);
     std::vector<std::vector<int32_t>> children(n);
     std::vector<int32_t> merged;
     double fl = 0.0;
@@ -693,21 +699,14 @@ void analyze(gtg_context& c) {
       fl += f * f * f / 3.0 + f * f * sdim + f * sdim * sdim;
       if (!sj.empty()) children[sj.front()].push_back(j);
     }
-    c.chol_flops_block = fl;
-  } catch (...) { block_level.err = std::current_exception(); } });
+    cp->chol_flops_block = fl;
+  } catch (...) { cp->block_level_err = std::current_exception(); } });
+  }
 
   // ---- tile structure of the reduced system -> Cholesky schedule ------------------------------------------------
   {
     const int nt = c.NP / kTile, np2 = (nt + 1) / 2;
-    std::vector<uint8_t> B2((size_t)np2 * np2, 0);
-    auto mark = [&](int ra, int rb) {
-      const int64_t a0 = c.h_red_off[ra] / (2 * kTile), a1 = (c.h_red_off[ra] + c.h_red_dim[ra] - 1) / (2 * kTile);
-      const int64_t b0 = c.h_red_off[rb] / (2 * kTile), b1 = (c.h_red_off[rb] + c.h_red_dim[rb] - 1) / (2 * kTile);
-      for (int64_t a = a0; a <= a1; a++)
-        for (int64_t b = b0; b <= b1; b++) B2[(size_t)std::max(a, b) * np2 + std::min(a, b)] = 1;
-    };
-    for (int r = 0; r < c.n_red_vars; r++) mark(r, r);
-    for_each_block(mark);
+    std::vector<uint8_t> B2((size_t)np2 * np2, 0);      // the same structure over 256-wide column pairs (filled from T1 below)
     std::vector<int32_t> pair_part;
     if (!part_of_pos.empty()) {
       pair_part.assign(np2, -1);
@@ -724,8 +723,28 @@ void analyze(gtg_context& c) {
           for (int64_t b = b0; b <= b1; b++) T1[(size_t)std::max(a, b) * nt + std::min(a, b)] = 1;
         for (int64_t a = a0; a <= a1; a++) rhs[(size_t)a] = 1;
       };
-      for (int r = 0; r < c.n_red_vars; r++) mark1(r, r);
-      for_each_block(mark1);
+      // ONE pass over the blocks (203 k on the L1723 shape) marks the tiles and feeds the identity of the block set (below)
+      // the block SET identifies the layout (a commutative sum over the blocks: a sharded handle lists them in bitmap order, a single
+      // one in term order); only a sharded handle, or one whose pose pairs can carry two kinds of blocks, needs the list itself
+      uint64_t hb = 0;
+      auto mix_block = [&](int64_t ro, int64_t co, int32_t dd) {
+        uint64_t z = (uint64_t)ro * 0x9E3779B97F4A7C15ull ^ ((uint64_t)co + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)dd;
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        hb += z;
+      };
+      std::vector<int64_t> xro, xco; std::vector<int32_t> xd;
+      const bool need_list = c.n_shards > 1 || (!pair_row.empty() && !hoff_row.empty());
+      auto add_block = [&](int64_t ro, int64_t co, int32_t dd) { if (need_list) { xro.push_back(ro); xco.push_back(co); xd.push_back(dd); } else mix_block(ro, co, dd); };
+      for (int r = 0; r < c.n_red_vars; r++) { mark1(r, r); add_block(c.h_red_off[r], c.h_red_off[r], c.h_red_dim[r] | (c.h_red_dim[r] << 8)); }
+      for_each_block([&](int ra, int rb) {
+        mark1(ra, rb);
+        if (ra == rb) return;                                  // a camera's Schur terms with itself: the diagonal block above
+        const bool a_later = c.h_red_pos[ra] > c.h_red_pos[rb];
+        const int rr = a_later ? ra : rb, rc = a_later ? rb : ra;
+        add_block(c.h_red_off[rr], c.h_red_off[rc], c.h_red_dim[rr] | (c.h_red_dim[rc] << 8));
+      });
+      for (int a = 0; a < nt; a++)
+        for (int b2 = 0; b2 <= a; b2++) if (T1[(size_t)a * nt + b2]) B2[(size_t)(a / 2) * np2 + (size_t)(b2 / 2)] = 1;
       for (int64_t i : c.h_pad_index) T1[(size_t)(i / kTile) * nt + (size_t)(i / kTile)] = 1;
       std::vector<int32_t> ex;
       const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
@@ -763,24 +782,6 @@ void analyze(gtg_context& c) {
       // sharded: the block-granular exchange list (diagonal blocks, then the off-diagonal blocks of the whole graph)
       c.n_xb = 0;
       {
-        // the block SET identifies the layout (a commutative sum over the blocks: a sharded handle lists them in bitmap order, a single
-        // one in term order); only a sharded handle, or one whose pose pairs can carry two kinds of blocks, needs the list itself
-        uint64_t hb = 0;
-        auto mix_block = [&](int64_t ro, int64_t co, int32_t dd) {
-          uint64_t z = (uint64_t)ro * 0x9E3779B97F4A7C15ull ^ ((uint64_t)co + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)dd;
-          z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
-          hb += z;
-        };
-        std::vector<int64_t> xro, xco; std::vector<int32_t> xd;
-        const bool need_list = c.n_shards > 1 || (!pair_row.empty() && !hoff_row.empty());
-        auto add_block = [&](int64_t ro, int64_t co, int32_t dd) { if (need_list) { xro.push_back(ro); xco.push_back(co); xd.push_back(dd); } else mix_block(ro, co, dd); };
-        for (int r = 0; r < c.n_red_vars; r++) add_block(c.h_red_off[r], c.h_red_off[r], c.h_red_dim[r] | (c.h_red_dim[r] << 8));
-        for_each_block([&](int ra, int rb) {
-          if (ra == rb) return;                                  // a camera's Schur terms with itself: the diagonal block above
-          const bool a_later = c.h_red_pos[ra] > c.h_red_pos[rb];
-          const int rr = a_later ? ra : rb, rc = a_later ? rb : ra;
-          add_block(c.h_red_off[rr], c.h_red_off[rc], c.h_red_dim[rr] | (c.h_red_dim[rc] << 8));
-        });
         if (c.n_shards > 1) { c.n_xb = (int64_t)xd.size(); up(c.xb_row_off, xro, s); up(c.xb_col_off, xco, s); up(c.xb_dim, xd, s); }
         else if (!pair_row.empty() && !hoff_row.empty()) {   // a pose pair can carry a Schur block AND a between block: one entry in the set
           std::vector<size_t> idx(xd.size());
@@ -884,9 +885,11 @@ void analyze(gtg_context& c) {
   c.lin_bytes = (double)n_sfm * (2 * 4 + 16 + 4 + (c.fused_sfm ? 216.0 : 2.0 * kSfmRec * 8)) + (double)n_proj * (2 * 4 + 16 + 12 + 2.0 * kProjRec * 8) +
                 (double)n_btw * (2 * 4 + 96 + 4 + 2.0 * kBetweenRec * 8) + (double)c.val_size * 8 +
                 (double)c.n_red_vars * 90 * 8 + (double)c.n_lm * 12 * 8 + (double)c.n_hoff * 36 * 8;
-  block_level.t.join();
-  if (block_level.err) std::rethrow_exception(block_level.err);
-  clk.lap("block-level symbolic factorisation (own thread: wait)");
+}
+
+void join_block_level(gtg_context& c) {
+  if (c.block_level_thread.joinable()) c.block_level_thread.join();
+  if (c.block_level_err) { std::exception_ptr e = c.block_level_err; c.block_level_err = nullptr; std::rethrow_exception(e); }
 }
 
 }  // namespace gt

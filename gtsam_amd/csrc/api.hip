@@ -259,6 +259,7 @@ int gtg_create(gtg_handle* out, int device_id) {
 
 int gtg_destroy(gtg_handle c) {
   if (!c) return GTG_OK;
+  try { join_block_level(*c); } catch (...) {}
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   auto& f = c->f;
@@ -900,7 +901,11 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
   return GTG_OK;
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
-double gtg_cholesky_flops_block_level(gtg_handle c) { return c ? c->chol_flops_block : 0.0; }
+double gtg_cholesky_flops_block_level(gtg_handle c) {
+  if (!c) return 0.0;
+  try { join_block_level(*c); } catch (...) { return 0.0; }
+  return c->chol_flops_block;
+}
 int64_t gtg_structure_hash(gtg_handle c) { return c ? (int64_t)(c->structure_hash & 0x7FFFFFFFFFFFFFFFull) : -1; }
 double gtg_linearize_bytes(gtg_handle c) { return c ? c->lin_bytes : 0.0; }
 

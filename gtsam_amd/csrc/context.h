@@ -14,6 +14,8 @@
 #include <stdint.h>
 
 #include <string>
+#include <exception>
+#include <thread>
 #include <vector>
 
 #include "../../include/gtsam_amd.h"
@@ -270,6 +272,8 @@ struct gtg_context {
   int64_t phase_calls[GTG_PH_COUNT] = {0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double chol_flops = 0, chol_flops_block = 0, lin_bytes = 0;
+  std::thread block_level_thread;               // computes chol_flops_block beside / after analyze() (analysis.hip::join_block_level)
+  std::exception_ptr block_level_err;
 };
 
 namespace gt {

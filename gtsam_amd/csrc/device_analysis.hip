@@ -33,26 +33,68 @@ namespace gt {
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_da_count(int n_lm, const int64_t* __restrict__ ptr, const int32_t* __restrict__ lm_obs,
-                                                  const int32_t* __restrict__ obs_pos, int64_t* __restrict__ cnt) {
+// The Schur terms of a landmark seen by k cameras: one per pair (a, b), b <= a, of its observations, in the order a = 0 .. k - 1,
+// b = 0 .. a -- term i = a (a + 1) / 2 + b -- plus one more right behind a pair of two DIFFERENT observations by the SAME camera (rare:
+// a camera that sees a landmark twice).  Rounds 3 - 4 walked that double loop with one lane per landmark, twice (count, then emit): the
+// lanes of a wavefront waited for its longest track and every store was a scattered 4 / 8 bytes (0.78 + 1.85 ms on the L1723 shape).
+// Now one lane per TERM: the landmark by binary search in the offsets, (a, b) in closed form, coalesced stores.  Landmarks with such a
+// double sighting are counted by the same walk over the nominal pairs and emitted by the old per-landmark loop (k_da_emit_dups).
+__device__ __forceinline__ int64_t tri(int64_t a) { return a * (a + 1) / 2; }
+__device__ __forceinline__ int da_find(const int64_t* __restrict__ off, int n, int64_t t) {   // the l with off[l] <= t < off[l + 1]
+  int lo = 0, hi = n;            // off[0] = 0 <= t < off[n]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ void da_pair(int64_t i, int& a, int& b) {
+  int64_t x = (int64_t)((sqrt(8.0 * (double)i + 1.0) - 1.0) * 0.5);
+  while (tri(x + 1) <= i) x++;
+  while (tri(x) > i) x--;
+  a = (int)x; b = (int)(i - tri(x));
+}
+__global__ __launch_bounds__(256) void k_da_nominal(int n_lm, const int64_t* __restrict__ ptr, int64_t* __restrict__ cnt, int32_t* __restrict__ dup) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l > n_lm) return;
-  if (l == n_lm) { cnt[l] = 0; return; }
-  const int64_t b0 = ptr[l], k = ptr[l + 1] - b0;
-  int64_t c = k * (k + 1) / 2;
-  for (int64_t a = 1; a < k; a++) {
-    const int pa = obs_pos[lm_obs[b0 + a]];
-    for (int64_t b = 0; b < a; b++) c += obs_pos[lm_obs[b0 + b]] == pa;
-  }
-  cnt[l] = c;
+  if (l == n_lm) { cnt[l] = 0; dup[l] = 0; return; }     // (dup[n_lm]: the number of landmarks with a double sighting)
+  cnt[l] = tri(ptr[l + 1] - ptr[l]); dup[l] = 0;
+}
+// one lane per nominal pair: a pair of two observations by the same camera adds a term to its landmark
+__global__ __launch_bounds__(256) void k_da_dups(int64_t total0, int n_lm, const int64_t* __restrict__ off0, const int64_t* __restrict__ ptr,
+                                                 const int32_t* __restrict__ lm_obs, const int32_t* __restrict__ obs_pos, int32_t* __restrict__ dup) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total0) return;
+  const int l = da_find(off0, n_lm, t);
+  int a, b; da_pair(t - off0[l], a, b);
+  if (b == a) return;
+  const int64_t b0 = ptr[l];
+  if (obs_pos[lm_obs[b0 + a]] == obs_pos[lm_obs[b0 + b]]) { if (atomicAdd(dup + l, 1) == 0) atomicAdd(dup + n_lm, 1); }
+}
+__global__ __launch_bounds__(256) void k_da_add_dups(int n_lm, int64_t* __restrict__ cnt, const int32_t* __restrict__ dup) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < n_lm) cnt[l] += dup[l];
 }
 
-__global__ __launch_bounds__(256) void k_da_emit(int n_lm, int nrv, const int64_t* __restrict__ ptr, const int32_t* __restrict__ lm_obs,
-                                                 const int32_t* __restrict__ obs_pos, const int64_t* __restrict__ off,
+// one lane per term (landmarks without a double sighting; the others: k_da_emit_dups)
+__global__ __launch_bounds__(256) void k_da_emit(int64_t total, int n_lm, int nrv, const int64_t* __restrict__ ptr, const int32_t* __restrict__ lm_obs,
+                                                 const int32_t* __restrict__ obs_pos, const int64_t* __restrict__ off, const int32_t* __restrict__ dup,
                                                  uint64_t* __restrict__ key, uint32_t* __restrict__ idx, int32_t* __restrict__ oa_out,
                                                  int32_t* __restrict__ ob_out) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= total) return;
+  const int l = da_find(off, n_lm, w);
+  if (dup[l]) return;
+  int a, b; da_pair(w - off[l], a, b);
+  const int64_t b0 = ptr[l];
+  int32_t oa = lm_obs[b0 + a], ob = lm_obs[b0 + b];
+  int pa = obs_pos[oa], pb = obs_pos[ob];
+  if (pa < pb) { const int32_t t = oa; oa = ob; ob = t; const int u = pa; pa = pb; pb = u; }
+  key[w] = (uint64_t)pa * (uint64_t)nrv + (uint64_t)pb; idx[w] = (uint32_t)w; oa_out[w] = oa; ob_out[w] = ob;
+}
+__global__ __launch_bounds__(256) void k_da_emit_dups(int n_lm, int nrv, const int64_t* __restrict__ ptr, const int32_t* __restrict__ lm_obs,
+                                                      const int32_t* __restrict__ obs_pos, const int64_t* __restrict__ off, const int32_t* __restrict__ dup,
+                                                      uint64_t* __restrict__ key, uint32_t* __restrict__ idx, int32_t* __restrict__ oa_out,
+                                                      int32_t* __restrict__ ob_out) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= n_lm) return;
+  if (l >= n_lm || !dup[l]) return;
   const int64_t b0 = ptr[l], k = ptr[l + 1] - b0;
   int64_t w = off[l];
   for (int64_t a = 0; a < k; a++) {
@@ -155,17 +197,32 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   DevBuf<int64_t> d_cnt, d_off; d_cnt.alloc((size_t)n_lm + 1); d_off.alloc((size_t)n_lm + 1);
   size_t tmp_bytes = 0, need = 0; void* tmp = nullptr;
   auto ensure = [&](size_t n) { if (n > tmp_bytes) { if (tmp) (void)hipFree(tmp); hc(hipMalloc(&tmp, n), "hipMalloc"); tmp_bytes = n; } };
-  hipLaunchKernelGGL(k_da_count, dim3((unsigned)((n_lm + 1 + 255) / 256)), dim3(256), 0, s, n_lm, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_cnt.p);
+  DevBuf<int32_t> d_dup; d_dup.alloc((size_t)n_lm + 1);
+  hipLaunchKernelGGL(k_da_nominal, dim3((unsigned)((n_lm + 1 + 255) / 256)), dim3(256), 0, s, n_lm, c.lm_obs_ptr.p, d_cnt.p, d_dup.p);
   hc(rocprim::exclusive_scan(nullptr, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan"); ensure(need);
   hc(rocprim::exclusive_scan(tmp, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan");
   int64_t total = 0;
   hc(hipMemcpyAsync(&total, d_off.p + n_lm, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
   if (total < 0 || total >= ((int64_t)1 << 31)) throw std::runtime_error("device analysis: term count out of range");
+  int32_t n_dup_lm = 0;
+  if (total > 0) {   // landmarks that a camera sees twice have one more term per such pair: count them, and offset again if there are any
+    hipLaunchKernelGGL(k_da_dups, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n_lm, d_off.p, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_dup.p);
+    hc(hipMemcpyAsync(&n_dup_lm, d_dup.p + n_lm, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
+    hc(hipStreamSynchronize(s), "sync");
+    if (n_dup_lm > 0) {
+      hipLaunchKernelGGL(k_da_add_dups, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, d_cnt.p, d_dup.p);
+      need = tmp_bytes;
+      hc(rocprim::exclusive_scan(tmp, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan");
+      hc(hipMemcpyAsync(&total, d_off.p + n_lm, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
+      hc(hipStreamSynchronize(s), "sync");
+      if (total < 0 || total >= ((int64_t)1 << 31)) throw std::runtime_error("device analysis: term count out of range");
+    }
+  }
   c.n_pair_terms = total;
   c.pair_oa.alloc((size_t)std::max<int64_t>(total, 1)); c.pair_ob.alloc((size_t)std::max<int64_t>(total, 1));
   block_keys.clear(); block_ptr.assign(1, 0);
-  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); if (tmp) (void)hipFree(tmp); c.pair_ptr.upload(block_ptr.data(), 1, s); return; }
+  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); if (tmp) (void)hipFree(tmp); c.pair_ptr.upload(block_ptr.data(), 1, s); return; }
   // one scratch allocation for everything that does not outlive the call (a dozen separate hipMalloc / hipFree of tens of
   // megabytes cost more than the kernels)
   const size_t N = (size_t)total;
@@ -191,8 +248,11 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   int32_t* runs = reinterpret_cast<int32_t*>(take(4 * (N + 1))); int64_t* pp = reinterpret_cast<int64_t*>(take(8 * (N + 1)));
   int32_t* d_nruns = reinterpret_cast<int32_t*>(take(16));
   void* cub_tmp = take(need_tmp);
-  hipLaunchKernelGGL(k_da_emit, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
-                     key, idx, t_oa, t_ob);
+  hipLaunchKernelGGL(k_da_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
+                     d_dup.p, key, idx, t_oa, t_ob);
+  if (n_dup_lm > 0)
+    hipLaunchKernelGGL(k_da_emit_dups, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
+                       d_dup.p, key, idx, t_oa, t_ob);
   need = need_sort; hc(rocprim::radix_sort_pairs(cub_tmp, need, key, key2, idx, idx2, (size_t)total, 0u, (unsigned)bits, s), "sort");
   hipLaunchKernelGGL(k_da_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, idx2, t_oa, t_ob, c.pair_oa.p, c.pair_ob.p);
   need = need_rle; hc(rocprim::run_length_encode(cub_tmp, need, key2, (unsigned)total, uniq, runs, d_nruns, s), "rle");
@@ -207,7 +267,7 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   c.pair_ptr.alloc((size_t)nruns + 1);
   hc(hipMemcpyAsync(c.pair_ptr.p, pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToDevice, s), "D2D");
   hc(hipStreamSynchronize(s), "sync");
-  d_pos.free(); d_cnt.free(); d_off.free();
+  d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free();
   if (tmp) (void)hipFree(tmp);
   pool_buf.free();
 }

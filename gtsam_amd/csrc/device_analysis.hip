@@ -2,15 +2,18 @@
 //
 // What the host does in analysis.hip for every landmark -- every pair of its observations is one term E_a E_b^T of the block
 // (row = the later position, column = the earlier one), terms grouped by block, the terms of a block in landmark order -- as
-// four data-parallel passes (the formulation is pinned bit for bit against the host lists by tests/test_device_analysis_spec.py
+// data-parallel passes (the formulation is pinned bit for bit against the host lists by tests/test_device_analysis_spec.py
 // and, on the GPU, by tests/test_gpu_device_analysis.py):
-//   k_da_count    one landmark per lane: number of terms = k (k + 1) / 2 + pairs of observations by the same camera
-//   ExclusiveSum                       -> term offsets (emission order = landmark order)
-//   k_da_emit     one landmark per lane: key = row position * n + column position, oriented (oa, ob), mirrored duplicates
+//   k_da_nominal  one landmark per lane: k (k + 1) / 2 terms;  ExclusiveSum -> term offsets (emission order = landmark order)
+//   k_da_dups     one NOMINAL PAIR per lane: a pair of two observations by the same camera is one more term of its landmark
+//                 (none on the usual graphs; otherwise the offsets are summed again)
+//   k_da_emit     one TERM per lane (round 5; rounds 3 - 4: one landmark per lane): the landmark by binary search in the offsets,
+//                 the pair in closed form; key = row position * n + column position, oriented (oa, ob); landmarks with a double
+//                 sighting: k_da_emit_dups, the per-landmark loop with its mirrored duplicates
 //   DeviceRadixSort::SortPairs         stable, so the terms of a block keep the landmark order (= the summation order of
 //                                      k_schur_pairs: the device's results do not depend on which side built the lists)
 //   gather (oa, ob) into the final lists, DeviceRunLengthEncode::Encode -> the unique blocks, ExclusiveSum -> pair_ptr
-// The 6 M terms of the L1723 shape take 2.8 ms (profiles/r02_device_analysis_proto.log) against 12 ms on 32 host threads, and
+// The 6 M terms of the L1723 shape take 1.3 ms (2.8 with one landmark per lane, profiles/r02_device_analysis_proto.log) against 12 ms on 32 host threads, and
 // 49 MB of term lists never cross PCIe; the host gets back the 0.2 M block keys and offsets it needs for the ordering and the
 // tile schedule.  After the ordering the terms of the blocks whose orientation flips are swapped in place (k_da_flip).
 // The incidence lists in front of that pass -- observation -> (reduced variable, landmark, position), landmark -> observations,

@@ -316,15 +316,26 @@ def main():
         extra = {}
         esteps, ewarm = max(2, min(args.steps, 8)), max(1, min(args.warmup, 2))
 
+        broken = []     # the process group itself failed in an extra leg: no further legs, the headline line is printed all the same
+
         def leg(name, fn):
+            if broken:
+                extra[name] = {"failed": "skipped: " + broken[0]}
+                return
             ok, rec, err = 1.0, None, None
             try:
                 rec = fn()
             except Exception as e:  # noqa: BLE001
                 ok, err = 0.0, f"{type(e).__name__}: {e}"[:300]
-            t = torch.tensor([ok], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            extra[name] = rec if float(t.item()) == 1.0 else {"failed": err or "raised on another rank"}
+            try:
+                t = torch.tensor([ok], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                agreed = float(t.item()) == 1.0
+            except Exception as e:  # noqa: BLE001  (a collective that timed out inside the leg leaves the communicator unusable)
+                broken.append(f"the agreement all-reduce after '{name}' raised {type(e).__name__}: {e}"[:300])
+                extra[name] = {"failed": err or broken[0]}
+                return
+            extra[name] = rec if agreed else {"failed": err or "raised on another rank"}
 
         other = "speculative" if not speculative else "shard"
         leg(other, lambda: dict(timed_mode(problem, values0, params, other, esteps, ewarm),
@@ -505,7 +516,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001  (a communicator an extra leg broke: the line is out, nothing left to do)
+            pass
 
 
 if __name__ == "__main__":

@@ -114,23 +114,61 @@ def measure_traffic(workload):
                                                   "dataflow factorisation in its single-kernel form (GTG_DF_SINGLE=1), FETCH_SIZE x 2 (gfx950), KB units"), per
 
 
-def cpp_host_leg(workload, steps, warmup):
-    """The headline as north_star defines the host: tools/cpp/bench_lm_gtsam.cpp -- GTSAM's loader, GTSAM's NonlinearFactorGraph / Values /
-    LevenbergMarquardtParams, gtsam_amd::GpuLevenbergMarquardtOptimizer::optimize() through the C ABI; exactly `steps` LM iterations timed."""
-    import subprocess
-    import tempfile
+BAL_GENERATORS = {"ladybug1723": "ladybug_1723", "dubrovnik16": "dubrovnik_16", "venice1778": "venice_1778", "streets1723": "streets_1723"}
+POSE_FIXTURES = {"sphere2500": ("sphere2500.npz", True), "w20000": ("pose2_w20000.npz", False)}
+
+
+def write_workload_file(workload, path):
+    """The input file of the C++ bench programs: a BAL file of the synthetic shape (gtsam_amd/datasets.py), or a g2o file made of the
+    golden fixture's edges, noise models and initial poses at full precision (read back by GTSAM's own readG2o)."""
     from gtsam_amd import datasets as D
     from gtsam_amd import io as IO
-    exe = os.path.join(ROOT, "tests", "_build", "bench_lm_gtsam")
-    gens = {"ladybug1723": D.ladybug_1723, "dubrovnik16": D.dubrovnik_16, "venice1778": D.venice_1778, "streets1723": D.streets_1723}
-    if workload not in gens:
-        return {"failed": "not a BAL workload (the C++ bench program is timing/timeSFMBAL.cpp's protocol)"}
-    if not os.path.exists(exe):
-        return {"failed": "tests/_build/bench_lm_gtsam not built (make -C gtsam_amd/host; needs GTSAM's headers = /root/reference)"}
+    if workload in BAL_GENERATORS:
+        IO.write_bal(path, *getattr(D, BAL_GENERATORS[workload])())
+        return
+    fixture, is3d = POSE_FIXTURES[workload]
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", fixture)))
+    n = int(max(g["v1"].max(), g["v2"].max())) + 1
+    d = dict(v1=g["v1"], v2=g["v2"], z=g["z"], noise_kind=g["noise_kind"], noise=g["noise"])
+    IO.write_g2o(path, d, vertex_keys=np.arange(n), vertex_poses=np.asarray(g["values0"]).reshape(n, -1), full_precision=True)
+
+
+def start_workload_file(workload):
+    """Write the workload's input file in a child process (CPU only: the Venice shape takes the generator the better part of a minute),
+    so that it is ready when its leg comes up.  -> (Popen, path)"""
+    import subprocess
+    import tempfile
     path = os.path.join(tempfile.gettempdir(), f"gtsam_amd_bench_{workload}_{os.getpid()}.txt")
+    code = "import sys; sys.path.insert(0, %r); import bench; bench.write_workload_file(%r, %r)" % (ROOT, workload, path)
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True), path
+
+
+def cpp_host_leg(workload, steps, warmup, prepared=None, cpu_baseline=True):
+    """The headline as north_star defines the host: a C++ program against GTSAM's own API -- GTSAM's loader, NonlinearFactorGraph / Values /
+    LevenbergMarquardtParams, gtsam_amd::GpuLevenbergMarquardtOptimizer::optimize() through the C ABI; exactly `steps` LM iterations timed.
+    BAL shapes: tools/cpp/bench_lm_gtsam.cpp (timing/timeSFMBAL.cpp's protocol); pose graphs: tools/cpp/bench_lm_pose3.cpp
+    (examples/Pose3SLAMExample_g2o.cpp's protocol with LM, the reference's own optimizer timed beside it in the same process).
+    `prepared` = (Popen, path) of start_workload_file."""
+    import subprocess
+    import tempfile
+    pose = workload in POSE_FIXTURES
+    if not pose and workload not in BAL_GENERATORS:
+        return {"failed": "no C++ bench program for this workload"}
+    exe = os.path.join(ROOT, "tests", "_build", "bench_lm_pose3" if pose else "bench_lm_gtsam")
+    if not os.path.exists(exe):
+        return {"failed": "tests/_build/%s not built (make -C gtsam_amd/host; needs GTSAM's headers = /root/reference)" % os.path.basename(exe)}
+    path = prepared[1] if prepared else os.path.join(tempfile.gettempdir(), f"gtsam_amd_bench_{workload}_{os.getpid()}.txt")
     try:
-        IO.write_bal(path, *gens[workload]())
-        r = subprocess.run([exe, path, "--steps", str(steps), "--warmup", str(warmup)], capture_output=True, text=True, timeout=900)
+        if prepared:
+            _, err = prepared[0].communicate(timeout=600)
+            if prepared[0].returncode != 0:
+                return {"failed": "writing the input file failed: " + (err or "")[-300:]}
+        else:
+            write_workload_file(workload, path)
+        cmd = [exe, path, "--steps", str(steps), "--warmup", str(warmup)]
+        if pose:
+            cmd += ["--cpu-baseline", "1" if cpu_baseline else "0"] + ([] if POSE_FIXTURES[workload][1] else ["--pose2"])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if not line:
             return {"failed": ("no output; stderr: " + r.stderr[-300:])}
@@ -143,6 +181,32 @@ def cpp_host_leg(workload, steps, warmup):
     finally:
         if os.path.exists(path):
             os.unlink(path)
+
+
+def workload_record(workload, desc, cpp):
+    """One entry of the line's `workloads`: the C++ host's figures of another workload, with the roofline of ITS dominant kernel (the
+    factorisation: block-level flops x launches / HIP-event time of the Cholesky phase of one optimisation) and the reference beside it."""
+    if "failed" in cpp and "iterations_per_s" not in cpp:
+        return {"workload": desc, "failed": cpp["failed"]}
+    ms = cpp.get("device_phase_ms", {}).get("cholesky", 0.0); calls = cpp.get("device_phase_calls", {}).get("cholesky", 0)
+    fb, ft = cpp.get("cholesky_flops_block_level", 0.0), cpp.get("cholesky_flops_stored_tiles", 0.0)
+    ach = fb * calls / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    ach_t = ft * calls / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    rec = {"workload": desc, "value": cpp["iterations_per_s"], "unit": "iterations/s", "ms_per_step": cpp["ms_per_step"], "steps": cpp["steps"],
+           "lambda_tries_per_s": cpp["lambda_tries_per_s"], "lambda_tries": cpp["lambda_tries"],
+           "time_to_converged_cold_s": cpp["cold_time_to_converged_s"], "time_to_converged_warm_s": cpp["warm_time_to_converged_s"],
+           "converged_error": cpp["final_error"], "converged_iterations": cpp["iterations_per_optimisation"],
+           "converged_inner_iterations": cpp["inner_iterations_per_optimisation"], "reduced_dim": cpp.get("reduced_dim"),
+           "device_phase_ms_per_try": {k: v / max(cpp["inner_iterations_per_optimisation"], 1) for k, v in cpp.get("device_phase_ms", {}).items()},
+           "roofline": {"bound": "mfma", "kernel": "tile-sparse FP64 Cholesky of the reduced system (k_df_bulk + k_df_chain), flops counted on the variable blocks",
+                        "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                        "flops_per_launch": fb, "flops_stored_tiles": ft, "ms_per_launch": ms / max(calls, 1), "launches": calls,
+                        "frac_stored_tiles": ach_t / FP64_MATRIX_PEAK_TFLOPS},
+           "cpu_baseline": cpp.get("cpu_baseline"), "trajectory_matches_reference": cpp.get("trajectory_matches_reference"),
+           "value_source": cpp.get("program"), "cpp_host": cpp}
+    if "failed" in cpp:
+        rec["failed"] = cpp["failed"]
+    return rec
 
 
 def main():
@@ -161,7 +225,15 @@ def main():
                     help="N > 1, auto: after the headline (shard) the same line also carries `extra_modes`: the speculative-lambda replicas, the "
                          "Venice-1778 shape sharded (BASELINE configs[5]) and the sharded PCG (implicit Schur complement) on the headline shape")
     ap.add_argument("--host", default="auto", choices=["auto", "python"], help="auto: the headline is timed in the C++ host (tools/cpp/bench_lm_gtsam.cpp) at N = 1")
+    ap.add_argument("--workloads", default="auto",
+                    help="N = 1, headline workload: the same line also carries `workloads` -- north_star's second headline (sphere2500, with the reference's own "
+                         "optimizer as its cpu_baseline) and the Venice-1778 shape, each timed in its C++ host program.  auto = sphere2500,venice1778; off; or a comma list")
     args = ap.parse_args()
+    extra_workloads = []
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "ladybug1723" and args.host == "auto" and args.workloads != "off":
+        extra_workloads = ["sphere2500", "venice1778"] if args.workloads == "auto" else [w for w in args.workloads.split(",") if w]
+    # (input files of the slow generators are written by child processes from the start, CPU only)
+    prepared = {w: start_workload_file(w) for w in extra_workloads if w in ("venice1778",)}
 
     import torch
     from gtsam_amd.optimizer import DeviceLevenbergMarquardt, check_convergence
@@ -308,15 +380,19 @@ def main():
     full.dev.close()
 
     # ---- N > 1: the other ways this loop can use N GPUs, measured in the same job and reported BESIDE the headline (never as `value`).
-    # Every leg runs on all ranks (they contain collectives); a leg that raises on a rank is reported as failed -- the ranks agree on
-    # that through an all-reduce of a flag before the next leg starts, so a failed leg does not leave ranks in different collectives.
+    # Every leg runs on all ranks (they contain collectives).  A leg that raises on ONE rank leaves the others inside the leg's own
+    # RCCL collectives until the process group's time-out ends them, and a device collective of another size issued meanwhile would be
+    # undefined behaviour -- so the ranks agree on a leg's outcome over a separate HOST (gloo) group, and after the first leg that
+    # failed anywhere no further leg is started (the device communicator may be unusable): they are reported as skipped.
     extra = None
     if world > 1 and args.extra_modes == "auto":
+        import datetime
         import torch.distributed as dist
         extra = {}
         esteps, ewarm = max(2, min(args.steps, 8)), max(1, min(args.warmup, 2))
+        agree_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
 
-        broken = []     # the process group itself failed in an extra leg: no further legs, the headline line is printed all the same
+        broken = []     # a leg failed on some rank: no further legs, the headline line is printed all the same
 
         def leg(name, fn):
             if broken:
@@ -328,14 +404,16 @@ def main():
             except Exception as e:  # noqa: BLE001
                 ok, err = 0.0, f"{type(e).__name__}: {e}"[:300]
             try:
-                t = torch.tensor([ok], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                t = torch.tensor([ok], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=agree_group)
                 agreed = float(t.item()) == 1.0
-            except Exception as e:  # noqa: BLE001  (a collective that timed out inside the leg leaves the communicator unusable)
-                broken.append(f"the agreement all-reduce after '{name}' raised {type(e).__name__}: {e}"[:300])
-                extra[name] = {"failed": err or broken[0]}
-                return
-            extra[name] = rec if agreed else {"failed": err or "raised on another rank"}
+            except Exception as e:  # noqa: BLE001
+                agreed, err = False, err or f"the agreement over the host group after '{name}' raised {type(e).__name__}: {e}"[:300]
+            if agreed:
+                extra[name] = rec
+            else:
+                extra[name] = {"failed": err or "raised on another rank"}
+                broken.append(f"the leg '{name}' failed on a rank ({extra[name]['failed'][:120]}); the device communicator is not trusted after that")
 
         other = "speculative" if not speculative else "shard"
         leg(other, lambda: dict(timed_mode(problem, values0, params, other, esteps, ewarm),
@@ -483,25 +561,23 @@ def main():
                            "cores_used": 1, "host_cpus": os.cpu_count(),
                            "cores_note": "the reference build has no TBB (headers absent from the image): 1 thread is what gtsam itself uses here. ~95 % of the iteration is the "
                                          "elimination of the reduced camera system, a serial chain of dense fronts (eliminateMultifrontal's root clique), so more threads would not change "
-                                         "the figure: see multi_thread, where linearize and the landmark eliminations are split over std::threads by the harness"}
-                    # multi-thread variant (the library is built without TBB -- no headers in the image -- so the split is made in
-                    # the harness, oracle/ref_harness.cpp ref_graph_iteration_mt: linearize and the landmark eliminations of the
-                    # Schur ordering on `threads` std::threads, the camera system on one); reported next to the 1-thread figure,
-                    # whichever is faster is `value`
+                                         "the figure: see `assisted`, where linearize and the landmark eliminations are split over std::threads by the harness"}
+                    # harness-ASSISTED multi-thread variant (the library is built without TBB -- no headers in the
+                    # image -- so the split is made in the harness, oracle/ref_harness.cpp ref_graph_iteration_mt: linearize and the
+                    # landmark eliminations of the Schur ordering on `threads` std::threads, the camera system on one).  It is NOT
+                    # GTSAM's own figure and never `value`: it rides along as `assisted`
                     try:
                         nth = max(1, min(8, os.cpu_count() or 1))
                         rc_mt, ms_mt, res_mt = g.iteration_mt(values0, params.lambdaInitial, params.diagonalDamping, nth)
-                        cpu["multi_thread"] = {
+                        cpu["assisted"] = {
                             "threads": nth, "value": 1e3 / ms_mt[4], "unit": "iterations/s", "status": int(rc_mt),
                             "what": "same iteration, linearize + per-landmark-group eliminatePartialSequential split over std::threads in the "
                                     "harness (what TBB would run in parallel), remaining camera system eliminated on one thread",
                             "phase_ms": dict(zip(["linearize", "eliminate_landmarks", "eliminate_solve_cameras", "back_substitute", "total"],
                                                  [float(x) for x in ms_mt])),
                             "delta_norm2_rel_vs_1_thread": rel(res_mt[4], ref_res[4])}
-                        if rc_mt == 0 and cpu["multi_thread"]["value"] > cpu["value"]:
-                            cpu["value_1_thread"] = cpu["value"]; cpu["value"] = cpu["multi_thread"]["value"]; cpu["cores"] = nth; cpu["cores_used"] = nth
                     except Exception as e:  # noqa: BLE001
-                        cpu["multi_thread"] = {"value": None, "failed": str(e)}
+                        cpu["assisted"] = {"value": None, "failed": str(e)}
                 else:
                     from oracle import gtsam_oracle as O
                     from gtsam_amd import datasets as D
@@ -513,6 +589,21 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
         out["cpu_baseline"] = cpu
+        # north_star's other workloads, measured the same way in the same run (C++ host, own roofline; sphere2500 with the reference's own
+        # optimizer on the same graph in the same process as its cpu_baseline)
+        if extra_workloads:
+            out["workloads"] = {}
+            for w in extra_workloads:
+                try:
+                    wdesc = {"sphere2500": "sphere2500 pose graph (the reference's examples/Data/sphere2500.txt through the golden fixture, written as g2o at full precision and read by GTSAM's readG2o): Pose3SLAMExample_g2o protocol with LevenbergMarquardt (legacy params), prior on pose 0, odometry-chain init",
+                             "venice1778": "BAL Venice problem-1778-993923 shape (synthetic, seed 42): timeSFMBAL protocol"}.get(w, w)
+                    wsteps = args.steps if w in POSE_FIXTURES else max(2, min(args.steps, 10))
+                    cppw = cpp_host_leg(w, wsteps, min(args.warmup, 2), prepared=prepared.get(w), cpu_baseline=args.cpu_baseline != "off")
+                    out["workloads"][w] = workload_record(w, wdesc, cppw)
+                    if w == "venice1778" and "failed" not in out["workloads"][w]:
+                        out["workloads"][w]["cpu_baseline"] = {"value": None, "kind": "reference", "sample": "not run: one reference iteration of this shape takes minutes on one thread (L1723, a seventh of the observations: 33 s)"}
+                except Exception as e:  # noqa: BLE001
+                    out["workloads"][w] = {"failed": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -52,6 +52,7 @@
 #include <limits>
 #include <algorithm>
 #include <map>
+#include <new>
 #include <stdexcept>
 #include <thread>
 
@@ -72,6 +73,29 @@ struct SmartAccess : SmartFactor {
   static SmartProjectionParams SmartFactor::* params() { return &SmartAccess::params_; }
 };
 typedef internal::LevenbergMarquardtState State;
+
+// The States THIS class publishes have a dynamic type of their own: that -- not an address, which the allocator hands out again -- is
+// how a State somebody else installed is told from one of ours (the base class's decreaseLambda() makes plain LevenbergMarquardtStates).
+struct GpuState : State {
+  using State::State;
+  // Both constructors of LevenbergMarquardtState deep-copy the Values they are given (the Values&& one passes its argument on as an
+  // lvalue, LevenbergMarquardtState.h:61-63): 16 ms for the 158 000 variables of the L1723 shape, per State.  So a GpuState is built on
+  // an EMPTY Values, and the caller's map is then MOVED into the member's storage: the empty member is destroyed and a new Values is
+  // constructed in its place from an rvalue (Values(Values&&), Values.h:118: the map's nodes change hands, O(1)).  `values` is declared
+  // const in NonlinearOptimizerState, so it cannot be assigned or swapped -- but ending the lifetime of a const member SUBOBJECT of a heap
+  // object and creating a new object of the same type in its storage is storage reuse, not modification of a const object ([basic.life]:
+  // the restriction on re-creating const objects covers complete objects of static / thread / automatic storage; since C++20 the new
+  // member is "transparently replaceable" under its old name, and implementations treat earlier dialects alike -- it is what
+  // std::vector<T>::emplace does for a T with a const member).  Rounds 3-5 swapped through a const_cast instead, which IS a
+  // modification of a const object.
+  static std::unique_ptr<GpuState> make(Values&& v, double error, double lambda, double factor, unsigned iterations, unsigned inner) {
+    std::unique_ptr<GpuState> s(new GpuState(Values(), error, lambda, factor, iterations, inner));
+    void* at = const_cast<void*>(static_cast<const void*>(&s->values));
+    s->values.~Values();
+    ::new (at) Values(std::move(v));     // (Values' move constructor moves a std::map: it does not throw)
+    return s;
+  }
+};
 
 struct GpuLevenbergMarquardtOptimizer::Impl {
   gtg_handle h = nullptr;
@@ -462,20 +486,14 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   copier.join();
   lap("wait for the copies of the graph and the Values");
   if (copyErr) std::rethrow_exception(copyErr);
-  // Both constructors of LevenbergMarquardtState deep-copy the Values they are given (the Values&& one passes its argument on as an
-  // lvalue, LevenbergMarquardtState.h:61-63): 16 ms for the 158 000 variables of the L1723 shape, per State.  So a State is built on
-  // an EMPTY Values and this object's copy is swapped in (Values::swap, Values.h:344: the maps trade their nodes, O(1)).
-  // NonlinearOptimizerState declares `const Values values` (every member of the State is const; a State is replaced, never changed),
-  // so the swap goes through a const_cast on a heap object that nobody else holds yet.  By the letter that is outside the language
-  // rules for const subobjects; the alternative the API leaves is the deep copy (one heap object per variable: 16 ms per State on the
-  // L1723 shape, + 2.3 ms per LM iteration through optimize()).  What the scheme must guarantee itself is memory safety: `slots`
-  // points into the nodes of ONE Values object, and every use checks that this object is still the one inside state_
-  // (adoptStateIfForeign): a State published by anybody else -- the inherited public tryLambda() does that -- is adopted, not written over.
+  // The State: the deep copy made beside the extraction moves into a GpuState (see GpuState::make: no second copy).  `slots` points
+  // into the nodes of that Values' map -- heap objects that stay where they are when the map moves on into the next State -- and every
+  // use checks first that state_ is still a State of this class holding that map (adoptStateIfForeign): a State published by anybody
+  // else -- the inherited public tryLambda() does that -- is adopted, not written over.
   {
-    std::unique_ptr<State> fresh(new State(Values(), e0, params_.lambdaInitial, params_.lambdaFactor));
-    const_cast<Values&>(fresh->values).swap(m.scratch);
+    std::unique_ptr<GpuState> fresh = GpuState::make(std::move(m.scratch), e0, params_.lambdaInitial, params_.lambdaFactor, 0, 0);
     m.slots.clear(); m.slots.reserve(nvars);
-    for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));
+    for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));   // (the GenericValue objects are non-const heap objects owned by the map's nodes)
     state_ = std::move(fresh);
     m.published = &state_->values;
   }
@@ -484,32 +502,39 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   lap("state");
 }
 
-// state_ was replaced by code outside this class since this class last published it (LevenbergMarquardtOptimizer::tryLambda is public
-// and non-virtual: it solves on the CPU and installs a State with a deep copy of ITS new values, LM.cpp:121-270): the device follows
-// the host -- values re-packed and uploaded, error / lambda / counters taken from that State -- and `slots` is rebuilt on its nodes.
+// state_ was replaced or changed by code outside this class since this class last published it.  LevenbergMarquardtOptimizer::tryLambda is
+// public and non-virtual: it solves (through the overridden solve()), retracts and evaluates on the CPU, and then EITHER installs a new plain
+// LevenbergMarquardtState with a deep copy of ITS new values (accepted step, LM.cpp:246-249) OR raises lambda IN PLACE on the State it
+// found (rejected step, LM.cpp:262-268).  The device follows the host in both cases:
+//  - a State that is not a GpuState, or a GpuState that does not hold the map `slots` points into: values re-packed and uploaded, `slots`
+//    rebuilt on its nodes (identity = the dynamic type; an address can be handed out again by the allocator between two foreign States);
+//  - in every case the scalars (error, lambda, factor, both counters) are taken from the State: an in-place increaseLambda() on our own
+//    State changes nothing else.
 void GpuLevenbergMarquardtOptimizer::adoptStateIfForeign() const {
   Impl& m = *impl_;
-  if (m.published == &state_->values && state_->values.size() == m.slots.size()) return;
-  const Values& v = state_->values;
-  if (v.size() != m.keys.size()) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
-  m.slots.clear(); m.slots.reserve(m.keys.size());
-  size_t id = 0;
-  for (const auto& kv : v) {
-    if (kv.key != m.keys[id]) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
-    double* p = m.packed.data() + m.val_off[id];
-    const int32_t t = m.var_type[id];
-    if (t == GTG_VAR_POINT3) { const Point3& q = kv.value.cast<Point3>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
-    else if (t == GTG_VAR_SFM_CAMERA) packCamera(kv.value.cast<SfmCamera>(), p);
-    else if (t == GTG_VAR_POSE3) packPose(kv.value.cast<Pose3>(), p);
-    else { const Pose2& q = kv.value.cast<Pose2>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
-    m.slots.push_back(const_cast<Value*>(&kv.value));
-    id++;
-  }
-  check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
   const State* st = static_cast<const State*>(state_.get());
+  const bool ours = dynamic_cast<const GpuState*>(state_.get()) != nullptr && m.published == &state_->values && state_->values.size() == m.slots.size();
+  if (!ours) {
+    const Values& v = state_->values;
+    if (v.size() != m.keys.size()) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
+    m.slots.clear(); m.slots.reserve(m.keys.size());
+    size_t id = 0;
+    for (const auto& kv : v) {
+      if (kv.key != m.keys[id]) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the optimizer's State holds other variables than the graph was uploaded with");
+      double* p = m.packed.data() + m.val_off[id];
+      const int32_t t = m.var_type[id];
+      if (t == GTG_VAR_POINT3) { const Point3& q = kv.value.cast<Point3>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
+      else if (t == GTG_VAR_SFM_CAMERA) packCamera(kv.value.cast<SfmCamera>(), p);
+      else if (t == GTG_VAR_POSE3) packPose(kv.value.cast<Pose3>(), p);
+      else { const Pose2& q = kv.value.cast<Pose2>(); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
+      m.slots.push_back(const_cast<Value*>(&kv.value));
+      id++;
+    }
+    check(gtg_set_values(m.h, m.packed.data(), (int64_t)m.packed.size()), "gtg_set_values");
+    m.host_values_stale = false;
+    m.published = &state_->values;
+  }
   m.error = st->error; m.lambda = st->lambda; m.factor = st->currentFactor; m.iterations = st->iterations; m.inner = st->totalNumberInnerIterations;
-  m.host_values_stale = false;
-  m.published = &state_->values;
 }
 
 void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
@@ -538,9 +563,21 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
     work(0, nv / nthreads);
     for (auto& t : pool) t.join();
   }
-  // the next State takes the SAME Values object over (swap: O(1); see init) with the device's error / lambda / counters
-  std::unique_ptr<State> fresh(new State(Values(), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner));
-  const_cast<Values&>(fresh->values).swap(const_cast<Values&>(state_->values));   // (see init: the nodes -- and with them `slots` -- move on)
+  // the next State, with the device's error / lambda / counters
+  std::unique_ptr<GpuState> fresh;
+  if (dynamic_cast<const GpuState*>(state_.get())) {
+    // ours: it takes the map of the current one over (O(1); the nodes -- and with them `slots` -- move on).  The object in the current
+    // State's `values` storage is the one GpuState::make created there by placement new -- an object of type Values, not const Values --
+    // so it may be moved from, through a pointer to that object (std::launder).
+    Values* current = std::launder(static_cast<Values*>(const_cast<void*>(static_cast<const void*>(&state_->values))));
+    fresh = GpuState::make(std::move(*current), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner);
+  } else {
+    // a State the base class published and this class adopted: its `values` IS a const member -- deep copy (once; from here on the
+    // States are ours again), `slots` follows the copy's nodes
+    fresh = GpuState::make(Values(state_->values), m.error, m.lambda, m.factor, (unsigned)m.iterations, (unsigned)m.inner);
+    m.slots.clear();
+    for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));
+  }
   state_ = std::move(fresh);
   m.published = &state_->values;
   m.host_values_stale = false;
@@ -847,5 +884,14 @@ std::vector<double> GpuLevenbergMarquardtOptimizer::phaseMilliseconds() const {
   gtg_get_phase_ms(impl_->h, ms.data(), calls.data(), GTG_PH_COUNT);
   return ms;
 }
+
+std::vector<long long> GpuLevenbergMarquardtOptimizer::phaseCalls() const {
+  std::vector<double> ms(GTG_PH_COUNT, 0.0);
+  std::vector<int64_t> calls(GTG_PH_COUNT, 0);
+  gtg_get_phase_ms(impl_->h, ms.data(), calls.data(), GTG_PH_COUNT);
+  return std::vector<long long>(calls.begin(), calls.end());
+}
+
+gtg_handle GpuLevenbergMarquardtOptimizer::handle() const { return impl_->h; }
 
 }  // namespace gtsam_amd

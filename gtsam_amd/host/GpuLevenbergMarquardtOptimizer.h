@@ -63,6 +63,10 @@ class GpuLevenbergMarquardtOptimizer : public gtsam::LevenbergMarquardtOptimizer
   /// per-phase device timings (ms, accumulated since enablePhaseTiming(true)) -- names via gtg_phase_name()
   void enablePhaseTiming(bool on);
   std::vector<double> phaseMilliseconds() const;
+  std::vector<long long> phaseCalls() const;
+  /// The C-ABI handle behind this optimizer, for the library's read-only getters (gtg_cholesky_flops_block_level, gtg_reduced_dim,
+  /// gtg_get_phase_ms, ...).  Calls that change the handle's state behind the optimizer's back are the caller's responsibility.
+  gtg_handle handle() const;
 
  private:
   struct Impl;

@@ -296,15 +296,16 @@ def _information(kind, params, dim):
     return R.T @ R
 
 
-def write_g2o(path, d, vertex_keys=None, vertex_poses=None):
+def write_g2o(path, d, vertex_keys=None, vertex_poses=None, full_precision=False):
     """writeG2o (slam/dataset.cpp:636-735): VERTEX_SE2 / VERTEX_SE3:QUAT lines of the estimate, then EDGE_SE2 /
     EDGE_SE3:QUAT lines of the BetweenFactors with the upper triangle of their information matrix (EDGE_SE3:QUAT in g2o's
     t,R block order), numbers at the stream's default precision.  `d` is what read_2d / read_g2o3d return; the estimate
-    defaults to d's vertices (pass the optimised poses to write a result)."""
+    defaults to d's vertices (pass the optimised poses to write a result).  full_precision: shortest round-trip digits instead of the
+    stream's six (not what writeG2o does: for files that carry a problem to another program without rounding it)."""
     vk = d["vertex_keys"] if vertex_keys is None else np.asarray(vertex_keys)
     vp = d["vertex_poses"] if vertex_poses is None else np.asarray(vertex_poses, np.float64)
     is3d = d["z"].shape[1] == 12
-    g = lambda x: f"{float(x):g}"      # noqa: E731  (`stream << double`)
+    g = (lambda x: repr(float(x))) if full_precision else (lambda x: f"{float(x):g}")      # noqa: E731  (`stream << double`)
     with open(path, "w") as f:
         for k, p in zip(vk, vp.reshape(len(vk), 12 if is3d else 3)):
             if is3d:

@@ -169,6 +169,55 @@ static void foreignStateTest(const char* name, const NonlinearFactorGraph& graph
   std::printf("%-22s a State published by the base class's tryLambda() is adopted: %zu iterations, error %.12g (reference %.12g)\n", name, gpu.iterations(), gpu.error(), cpu.error());
 }
 
+// Two further ways the base class changes the State behind the subclass's back:
+//  (1) two base-class tryLambda() calls in a row with no GPU entry point between them: State A (the subclass's) is freed, B allocated,
+//      freed, C allocated -- C may well sit at A's address, so "the State at the address I published" is no identity;
+//  (2) a REJECTED step: tryLambda() calls increaseLambda() IN PLACE on the State the subclass published (LM.cpp:262-268,
+//      LevenbergMarquardtState.h:70-76): same object, other lambda / factor / inner-iteration count -- the device must follow.
+// Both: the same sequence of calls on the reference's optimizer ends in the same numbers.
+static void foreignStateTwiceAndRejectedTest(const char* name, const NonlinearFactorGraph& graph, const Values& initial, LevenbergMarquardtParams params, double tolMid) {
+  params.diagonalDamping = false;
+  {
+    gtsam_amd::GpuLevenbergMarquardtOptimizer gpu(graph, initial, params);
+    LevenbergMarquardtOptimizer cpu(graph, initial, params);
+    gpu.iterate(); cpu.iterate();
+    const GaussianFactorGraph::shared_ptr lg = gpu.linearize(), lc = cpu.linearize();
+    for (int rep = 0; rep < 3; rep++) {   // back to back, each on the linearisation taken before the first (what the reference does with it, it does on both sides)
+      const bool doneG = gpu.LevenbergMarquardtOptimizer::tryLambda(*lg, VectorValues());
+      const bool doneC = cpu.tryLambda(*lc, VectorValues());
+      EXPECT(doneG == doneC, "%s back-to-back tryLambda() %d: %d vs %d", name, rep, (int)doneG, (int)doneC);
+    }
+    EXPECT(std::abs(gpu.error() - cpu.error()) <= tolMid * std::abs(cpu.error()) + 1e-12, "%s back-to-back: error %.15g vs %.15g", name, gpu.error(), cpu.error());
+    gpu.iterate(); cpu.iterate();
+    EXPECT(gpu.iterations() == cpu.iterations() && gpu.getInnerIterations() == cpu.getInnerIterations(), "%s back-to-back: iterations %zu / %d vs %zu / %d", name,
+           gpu.iterations(), gpu.getInnerIterations(), cpu.iterations(), cpu.getInnerIterations());
+    EXPECT(std::abs(gpu.error() - cpu.error()) <= tolMid * std::abs(cpu.error()) + 1e-12, "%s back-to-back: error after iterate() %.15g vs %.15g", name, gpu.error(), cpu.error());
+    EXPECT(std::abs(graph.error(gpu.values()) - gpu.error()) <= 1e-9 * std::abs(gpu.error()) + 1e-12, "%s back-to-back: values()/error() out of sync", name);
+    const Values rg = gpu.optimize(), rc = cpu.optimize();
+    EXPECT(std::abs(gpu.error() - cpu.error()) <= 1e-6 * std::abs(cpu.error()) + 1e-12, "%s back-to-back: final error %.15g vs %.15g", name, gpu.error(), cpu.error());
+    EXPECT(valuesDiff(rc, rg) <= 1e-5, "%s back-to-back: optimised values differ by %.3g", name, valuesDiff(rc, rg));
+  }
+  {
+    LevenbergMarquardtParams strict = params;
+    strict.minModelFidelity = 2.0;         // no step is ever good enough: every try is rejected and lambda raised
+    strict.lambdaUpperBound = 1e3;
+    gtsam_amd::GpuLevenbergMarquardtOptimizer gpu(graph, initial, strict);
+    LevenbergMarquardtOptimizer cpu(graph, initial, strict);
+    const GaussianFactorGraph::shared_ptr lg = gpu.linearize(), lc = cpu.linearize();
+    const bool doneG = gpu.LevenbergMarquardtOptimizer::tryLambda(*lg, VectorValues());
+    const bool doneC = cpu.tryLambda(*lc, VectorValues());
+    EXPECT(!doneG && !doneC, "%s rejected step: tryLambda() should have asked for another lambda (%d, %d)", name, (int)doneG, (int)doneC);
+    EXPECT(gpu.lambda() == cpu.lambda() && gpu.getInnerIterations() == 1, "%s rejected step: lambda %.6g vs %.6g, inner %d", name, gpu.lambda(), cpu.lambda(), gpu.getInnerIterations());
+    gpu.iterate(); cpu.iterate();          // goes on from the raised lambda until lambdaUpperBound ends the search
+    EXPECT(gpu.getInnerIterations() == cpu.getInnerIterations(), "%s rejected step: inner iterations after iterate() %d vs %d (the device did not follow the raised lambda)", name,
+           gpu.getInnerIterations(), cpu.getInnerIterations());
+    EXPECT(std::abs(gpu.lambda() - cpu.lambda()) <= 1e-12 * cpu.lambda(), "%s rejected step: lambda after iterate() %.12g vs %.12g", name, gpu.lambda(), cpu.lambda());
+    EXPECT(gpu.iterations() == cpu.iterations(), "%s rejected step: iterations %zu vs %zu", name, gpu.iterations(), cpu.iterations());
+    EXPECT(std::abs(gpu.error() - cpu.error()) <= 1e-9 * std::abs(cpu.error()) + 1e-12, "%s rejected step: error %.15g vs %.15g", name, gpu.error(), cpu.error());
+  }
+  std::printf("%-22s back-to-back base-class tryLambda() calls and an in-place lambda raise are followed by the device\n", name);
+}
+
 static bool g_skip_ab = false;
 static void compare(const char* name, const NonlinearFactorGraph& graph, const Values& initial, const LevenbergMarquardtParams& params,
                     double tol) {
@@ -274,6 +323,7 @@ int main() {
     for (int j = 0; j < np; j++) initial.insert(P(j), Point3(pts[j] + Point3(0.05 * N(rng), 0.05 * N(rng), 0.05 * N(rng))));
     compare("BAL legacy/COLAMD", graph, initial, LevenbergMarquardtParams(), 1e-6);
     foreignStateTest("BAL legacy/COLAMD", graph, initial, LevenbergMarquardtParams(), 5e-3);
+    foreignStateTwiceAndRejectedTest("BAL legacy/COLAMD", graph, initial, LevenbergMarquardtParams(), 5e-3);
     compare("BAL legacy/Iterative PCG", graph, initial, iterativeParams(LevenbergMarquardtParams()), 1e-6);
     LevenbergMarquardtParams ceres; LevenbergMarquardtParams::SetCeresDefaults(&ceres);
     Ordering ordering;   // Schur ordering of timing/timeSFMBAL.h:74-83
@@ -300,6 +350,7 @@ int main() {
     for (int i = 0; i < n; i++) initial.insert(X(i), truth[i].retract((Vector(6) << 0.1 * N(rng), 0.1 * N(rng), 0.1 * N(rng), 0.3 * N(rng), 0.3 * N(rng), 0.3 * N(rng)).finished()));
     compare("Pose3 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
     foreignStateTest("Pose3 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
+    foreignStateTwiceAndRejectedTest("Pose3 graph legacy", graph, initial, LevenbergMarquardtParams(), 1e-6);
     compare("Pose3 graph Iterative PCG", graph, initial, iterativeParams(LevenbergMarquardtParams()), 1e-6);
     // same graph with outlier loop closures and noiseModel::Robust on the loops (Huber) and the odometry (Cauchy)
     NonlinearFactorGraph robust;

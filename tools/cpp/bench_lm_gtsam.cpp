@@ -5,37 +5,22 @@
 //
 //   bench_lm_gtsam <BALfile> --steps K --warmup W
 //
-// A step is one LM iteration (LevenbergMarquardtOptimizer::iterate: linearize once + lambda tries until a step is accepted) as
-// optimize() runs it.  An optimisation of this problem converges after a handful of iterations, so K steps are K iterations spread
-// over as many optimize() calls as it takes: optimizers are CONSTRUCTED before the timed region (graph extracted, tables and values
-// resident in HBM), the last one is capped by maxIterations so that the timed region holds exactly K iterations.  What is timed is
-// optimize() as a user calls it -- including the refresh of the returned gtsam::Values at its end.  Warm-up: W iterations the same way.
-// Also reported: construction -> converged of the FIRST optimizer of the process (cold: code-object load, first device allocations)
-// and of a later one (warm).  Prints ONE JSON line.
-#include <GpuLevenbergMarquardtOptimizer.h>
+// Timing protocol and JSON keys: bench_lm_common.h (shared with bench_lm_pose3.cpp).  Prints ONE JSON line.
+#include "bench_lm_common.h"
+
 #include <gtsam/geometry/Cal3Bundler.h>
 #include <gtsam/geometry/PinholeCamera.h>
 #include <gtsam/inference/Symbol.h>
-#include <gtsam/nonlinear/LevenbergMarquardtOptimizer.h>
 #include <gtsam/sfm/SfmData.h>
 #include <gtsam/slam/GeneralSFMFactor.h>
-#include <hip/hip_runtime_api.h>
 
-#include <chrono>
-#include <cstdio>
 #include <cstring>
-#include <memory>
-#include <string>
-#include <vector>
 
 using namespace gtsam;
 using symbol_shorthand::C;
 using symbol_shorthand::P;
 typedef PinholeCamera<Cal3Bundler> Camera;
 typedef GeneralSFMFactor<Camera, Point3> SfmFactor;
-typedef std::chrono::high_resolution_clock Clock;
-
-static double ms(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
 
 int main(int argc, char* argv[]) {
   if (argc < 2) { std::printf("usage: bench_lm_gtsam <BALfile> [--steps K] [--warmup W]\n"); return 2; }
@@ -60,68 +45,10 @@ int main(int argc, char* argv[]) {
   for (size_t ii = 0; ii < db.numberCameras(); ii++) ordering.push_back(C(ii));
   params.setOrdering(ordering);
 
-  // ---- cold: the first optimizer of the process, construction -> converged (the metric's time-to-converged)
-  const auto c0 = Clock::now();
-  size_t itsPerRun; int innerPerRun; double e0, eFinal, hostError;
-  double coldConstruct, coldOptimize;
-  {
-    gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial, params);
-    const auto c1 = Clock::now();
-    e0 = lm.error();
-    const Values result = lm.optimize();
-    const auto c2 = Clock::now();
-    coldConstruct = ms(c0, c1); coldOptimize = ms(c1, c2);
-    itsPerRun = lm.iterations(); innerPerRun = lm.getInnerIterations(); eFinal = lm.error();
-    hostError = graph.error(result);   // the reference's own evaluation of the returned Values
-  }
-  if (itsPerRun == 0) { std::printf("{\"failed\": \"the optimisation made no iteration\"}\n"); return 1; }
-  // ---- warm: the same once more (what a program that optimises one problem after the other pays)
-  double warmConstruct, warmOptimize;
-  {
-    const auto w0 = Clock::now();
-    gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial, params);
-    const auto w1 = Clock::now();
-    lm.optimize();
-    warmConstruct = ms(w0, w1); warmOptimize = ms(w1, Clock::now());
-  }
-  // ---- warm-up and timed region: optimizers built up front, optimize() calls timed
-  auto plan = [&](int n) {   // maxIterations of the optimize() calls that make n iterations
-    std::vector<int> caps;
-    while (n > 0) { const int k = std::min<int>(n, (int)itsPerRun); caps.push_back(k); n -= k; }
-    return caps;
-  };
-  auto build = [&](const std::vector<int>& caps) {
-    std::vector<std::unique_ptr<gtsam_amd::GpuLevenbergMarquardtOptimizer>> v;
-    for (int k : caps) { LevenbergMarquardtParams p = params; p.maxIterations = k; v.emplace_back(new gtsam_amd::GpuLevenbergMarquardtOptimizer(graph, initial, p)); }
-    return v;
-  };
-  { auto w = build(plan(warmup)); for (auto& o : w) o->optimize(); }
-  auto timed = build(plan(steps));
-  size_t done = 0; int tries = 0;
-  (void)hipDeviceSynchronize();
-  const auto t0 = Clock::now();
-  for (auto& o : timed) o->optimize();
-  (void)hipDeviceSynchronize();
-  const auto t1 = Clock::now();
-  for (auto& o : timed) { done += o->iterations(); tries += o->getInnerIterations(); }
-  // device time of the phases of one more optimisation (events around every phase: not part of the timed region)
-  double deviceMs = 0.0; std::vector<double> phase;
-  {
-    gtsam_amd::GpuLevenbergMarquardtOptimizer lm(graph, initial, params);
-    lm.enablePhaseTiming(true);
-    lm.optimize();
-    phase = lm.phaseMilliseconds();
-    for (double v : phase) deviceMs += v;
-  }
-  const double elapsed = ms(t0, t1);
+  const benchlm::Result r = benchlm::run(graph, initial, params, steps, warmup);
+  if (r.itsPerRun == 0) { std::printf("{\"failed\": \"the optimisation made no iteration\"}\n"); return 1; }
   std::printf("{\"program\": \"tools/cpp/bench_lm_gtsam.cpp: GTSAM graph + gtsam_amd::GpuLevenbergMarquardtOptimizer::optimize(), C++ host end to end\", "
-              "\"cameras\": %zu, \"points\": %zu, \"factors\": %zu, \"steps\": %zu, \"steps_requested\": %d, \"warmup\": %d, \"elapsed_ms\": %.4f, "
-              "\"ms_per_step\": %.5f, \"iterations_per_s\": %.4f, \"lambda_tries\": %d, \"lambda_tries_per_s\": %.4f, \"optimize_calls\": %zu, "
-              "\"iterations_per_optimisation\": %zu, \"inner_iterations_per_optimisation\": %d, \"initial_error\": %.12g, \"final_error\": %.12g, "
-              "\"final_error_recomputed_by_gtsam_on_host\": %.12g, \"cold_construct_ms\": %.2f, \"cold_optimize_ms\": %.2f, \"cold_time_to_converged_s\": %.5f, "
-              "\"warm_construct_ms\": %.2f, \"warm_optimize_ms\": %.2f, \"warm_time_to_converged_s\": %.5f, \"device_phase_ms_one_optimisation\": %.3f}\n",
-              db.numberCameras(), db.numberTracks(), graph.size(), done, steps, warmup, elapsed, elapsed / std::max<size_t>(done, 1),
-              1e3 * done / elapsed, tries, 1e3 * tries / elapsed, timed.size(), itsPerRun, innerPerRun, e0, eFinal, hostError, coldConstruct, coldOptimize,
-              (coldConstruct + coldOptimize) * 1e-3, warmConstruct, warmOptimize, (warmConstruct + warmOptimize) * 1e-3, deviceMs);
-  return (done == (size_t)steps && std::abs(hostError - eFinal) <= 1e-9 * std::abs(hostError)) ? 0 : 1;
+              "\"cameras\": %zu, \"points\": %zu, \"factors\": %zu, %s}\n",
+              db.numberCameras(), db.numberTracks(), graph.size(), benchlm::json(r, steps, warmup).c_str());
+  return r.ok(steps) ? 0 : 1;
 }

@@ -115,6 +115,8 @@ void mat3_mul(const double A[9], const double B[9], double C[9]) {
 
 }  // namespace
 
+namespace gtg_io { void set_error(const std::string& s) { io_error = s; } }   // (io_g2o.cpp reports through the same thread-local text)
+
 extern "C" {
 
 const char* gtg_io_last_error(void) { return io_error.c_str(); }

@@ -124,7 +124,7 @@ def information_to_noise(m):
     return NOISE_GAUSSIAN, out
 
 
-def read_g2o3d(path):
+def read_g2o3d_py(path):
     """-> dict(v1, v2, z [n,12], noise_kind, noise [n,36], vertex_keys, vertex_poses [m,12]) like the reference's
     load3D: vertices only when the file has VERTEX lines (it does *not* create missing ones, dataset.cpp:922-944)."""
     v1, v2, zs, nk, nd, vk, vp = [], [], [], [], [], [], []
@@ -212,7 +212,60 @@ def read_g2o(path, is_3d=False):
     return read_g2o3d(path) if is_3d else read_2d(path, noise_format=NOISE_FORMAT_G2O)
 
 
+# ---- the native readers / writer (gtsam_amd/csrc/io_g2o.cpp behind the C ABI: gtg_io_g2o_sizes / gtg_io_read_g2o / gtg_io_write_g2o);
+# the *_py functions of this module are the token-by-token restatements they are checked against (tests/test_io.py)
+_NOISE_FORMAT_ID = {NOISE_FORMAT_AUTO: 0, NOISE_FORMAT_G2O: 1, NOISE_FORMAT_TORO: 2, NOISE_FORMAT_GRAPH: 3, NOISE_FORMAT_COV: 4}
+
+
+def _read_g2o_native(path, is_3d, noise_format):
+    import ctypes as C
+    from .lib import load
+    lib = load()
+    if noise_format not in _NOISE_FORMAT_ID:
+        raise ValueError("load2D: invalid noise format")
+    fmt = _NOISE_FORMAT_ID[noise_format]
+    ne, nv = C.c_int64(), C.c_int64()
+    if lib.gtg_io_g2o_sizes(str(path).encode(), int(is_3d), fmt, C.byref(ne), C.byref(nv)) != 0:
+        raise ValueError(lib.gtg_io_last_error().decode())
+    ne, nv = ne.value, nv.value
+    dz, dn = (12, 36) if is_3d else (3, 9)
+    v1 = np.zeros(ne, np.int64); v2 = np.zeros(ne, np.int64); z = np.zeros((ne, dz)); nk = np.zeros(ne, np.int32); nd = np.zeros((ne, dn))
+    vk = np.zeros(nv, np.int64); vp = np.zeros((nv, dz))
+    if lib.gtg_io_read_g2o(str(path).encode(), int(is_3d), fmt, ne, nv, v1.ctypes.data, v2.ctypes.data, z.ctypes.data, nk.ctypes.data,
+                           nd.ctypes.data, vk.ctypes.data, vp.ctypes.data) != 0:
+        raise ValueError(lib.gtg_io_last_error().decode())
+    return dict(v1=v1, v2=v2, z=z, noise_kind=nk, noise=nd, vertex_keys=vk, vertex_poses=vp)
+
+
+def read_g2o3d(path):
+    """load3D / readG2o(path, true) (slam/dataset.cpp:738-944) -> dict(v1, v2, z [n,12], noise_kind, noise [n,36], vertex_keys,
+    vertex_poses [m,12]); vertices only where the file has VERTEX lines.  Native parser (csrc/io_g2o.cpp)."""
+    return _read_g2o_native(path, True, NOISE_FORMAT_AUTO)
+
+
 def read_2d(path, noise_format=NOISE_FORMAT_AUTO):
+    """load2D (slam/dataset.cpp:179-330, 505-570; `noise_format` = load2D's parameter of that name: "AUTO" | "G2O" | "TORO" | "GRAPH" |
+    "COV") -> dict(v1, v2, z [n,3], noise_kind, noise [n,9], vertex_keys, vertex_poses [m,3]), vertices a pure odometry file does not
+    list created along the chain.  Native parser (csrc/io_g2o.cpp)."""
+    return _read_g2o_native(path, False, noise_format)
+
+
+def write_g2o(path, d, vertex_keys=None, vertex_poses=None, full_precision=False):
+    """writeG2o (slam/dataset.cpp:636-735) through the native writer (csrc/io_g2o.cpp); arguments as write_g2o_py."""
+    from .lib import load
+    lib = load()
+    vk = np.ascontiguousarray(d["vertex_keys"] if vertex_keys is None else vertex_keys, np.int64)
+    is3d = d["z"].shape[1] == 12
+    vp = np.ascontiguousarray(d["vertex_poses"] if vertex_poses is None else vertex_poses, np.float64).reshape(len(vk), 12 if is3d else 3)
+    v1 = np.ascontiguousarray(d["v1"], np.int64); v2 = np.ascontiguousarray(d["v2"], np.int64)
+    z = np.ascontiguousarray(d["z"], np.float64); nk = np.ascontiguousarray(d["noise_kind"], np.int32)
+    nd = np.ascontiguousarray(d["noise"], np.float64).reshape(len(v1), 36 if is3d else 9)
+    if lib.gtg_io_write_g2o(str(path).encode(), int(is3d), len(v1), v1.ctypes.data, v2.ctypes.data, z.ctypes.data, nk.ctypes.data, nd.ctypes.data,
+                            len(vk), vk.ctypes.data, vp.ctypes.data, int(full_precision)) != 0:
+        raise RuntimeError(lib.gtg_io_last_error().decode())
+
+
+def read_2d_py(path, noise_format=NOISE_FORMAT_AUTO):
     """load2D (slam/dataset.cpp:179-330, defaults: maxIndex 0, smart noise, NoiseFormatAUTO, no kernel; `noise_format` =
     load2D's parameter of that name: "AUTO" | "G2O" | "TORO" | "GRAPH" | "COV"): VERTEX2 /
     VERTEX_SE2 / VERTEX lines -> initial Pose2 (x, y, theta); EDGE2 / EDGE / EDGE_SE2 / ODOMETRY lines ->
@@ -296,7 +349,7 @@ def _information(kind, params, dim):
     return R.T @ R
 
 
-def write_g2o(path, d, vertex_keys=None, vertex_poses=None, full_precision=False):
+def write_g2o_py(path, d, vertex_keys=None, vertex_poses=None, full_precision=False):
     """writeG2o (slam/dataset.cpp:636-735): VERTEX_SE2 / VERTEX_SE3:QUAT lines of the estimate, then EDGE_SE2 /
     EDGE_SE3:QUAT lines of the BetweenFactors with the upper triangle of their information matrix (EDGE_SE3:QUAT in g2o's
     t,R block order), numbers at the stream's default precision.  `d` is what read_2d / read_g2o3d return; the estimate

@@ -314,6 +314,28 @@ int gtg_io_read_bal(const char* path, int64_t n_cams, int64_t n_points, int64_t 
 int gtg_io_write_bal(const char* path, int64_t n_cams, int64_t n_points, int64_t n_obs, const double* cams17,
                      const double* points3, const int32_t* obs_cam, const int32_t* obs_point, const double* obs_z);
 
+/* ---- wire formats on the pose-graph side of the path: g2o (VERTEX_SE2 / EDGE_SE2 / VERTEX_SE3:QUAT /
+ * EDGE_SE3:QUAT) and TORO (VERTEX2 / EDGE2 / VERTEX3 / EDGE3, also VERTEX / EDGE / ODOMETRY) text files straight to / from the arrays the
+ * between-factor tables of gtg_problem are filled from.  Host-only.  Replaces readG2o / load2D / load3D (gtsam/slam/dataset.cpp:505-570,
+ * 621-633, 738-944) and writeG2o (:636-735).
+ *   is_3d = 1: poses are 12 doubles (R row-major 9, t 3), noise parameters 36 doubles per edge; vertices only where the file lists them
+ *              (load3D does not create missing ones);
+ *   is_3d = 0: poses are (x, y, theta), noise parameters 9 doubles per edge; `noise_format` says what the six numbers of an edge line
+ *              are (readG2o: GTG_IO_NOISE_G2O; load2D's default: GTG_IO_NOISE_AUTO); a vertex an edge refers to and the file does not
+ *              list is created along the odometry chain like load2D does;
+ *   edge_noise_kind / edge_noise: GTG_NOISE_* + sigma | sigmas | R row-major, the model Gaussian::Information / Covariance(M, smart = true)
+ *              returns (linear/NoiseModel.cpp:83-131);  vertices sorted by key (the order gtsam::Values iterates in).
+ * gtg_io_write_g2o: VERTEX_* lines of the estimate, then EDGE_* lines with the upper triangle of the information matrix (3-D: in g2o's
+ * t,R block order); numbers at the stream's default precision (%g) as writeG2o prints them, or -- full_precision = 1 -- with 17 digits.
+ * Errors: GTG_ERR_USAGE with gtg_io_last_error() (file missing = the reference's invalid_argument text). */
+enum { GTG_IO_NOISE_AUTO = 0, GTG_IO_NOISE_G2O = 1, GTG_IO_NOISE_TORO = 2, GTG_IO_NOISE_GRAPH = 3, GTG_IO_NOISE_COV = 4 };
+int gtg_io_g2o_sizes(const char* path, int is_3d, int noise_format, int64_t* n_edges, int64_t* n_vertices);
+int gtg_io_read_g2o(const char* path, int is_3d, int noise_format, int64_t n_edges, int64_t n_vertices, int64_t* edge_v1, int64_t* edge_v2,
+                    double* edge_z, int32_t* edge_noise_kind, double* edge_noise, int64_t* vertex_key, double* vertex_pose);
+int gtg_io_write_g2o(const char* path, int is_3d, int64_t n_edges, const int64_t* edge_v1, const int64_t* edge_v2, const double* edge_z,
+                     const int32_t* edge_noise_kind, const double* edge_noise, int64_t n_vertices, const int64_t* vertex_key,
+                     const double* vertex_pose, int full_precision);
+
 #ifdef __cplusplus
 }
 #endif

@@ -289,3 +289,87 @@ def test_read_g2o_2d_reads_information_matrices_and_round_trips(tmp_path):
         IO.read_2d(str(p))
     with pytest.raises(ValueError):
         IO.read_2d(str(out), noise_format="nonsense")
+
+
+# ---- native g2o / TORO readers and writer (gtsam_amd/csrc/io_g2o.cpp behind the C ABI; host-only, no GPU) ---------------------------
+# io.read_g2o3d / io.read_2d / io.write_g2o ARE the native ones (the tests above compare them with the reference's loaders and its
+# writer); here: against the token-by-token restatements (*_py) on the reference's files and on files written here, and the errors.
+@pytest.mark.parametrize("name,is3d", [("pose3example.txt", True), ("pose3example-offdiagonal.txt", True), ("pose3example-grid.txt", True),
+                                       ("sphere2500.txt", True), ("noisyToyGraph.txt", False), ("w100.graph", False), ("w20000.txt", False)])
+def test_native_g2o_reader_and_writer_match_the_restatement(tmp_path, name, is3d):
+    path = DATA + name
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this machine")
+    nat = io.read_g2o3d(path) if is3d else io.read_2d(path)
+    py = io.read_g2o3d_py(path) if is3d else io.read_2d_py(path)
+    for k in ("v1", "v2", "noise_kind", "vertex_keys"):
+        assert np.array_equal(nat[k], py[k]), k
+    for k in ("z", "noise", "vertex_poses"):
+        assert nat[k].shape == py[k].shape and (nat[k].size == 0 or np.abs(nat[k] - py[k]).max() <= 1e-13 * max(1.0, np.abs(py[k]).max())), k
+    a, b = str(tmp_path / "nat.g2o"), str(tmp_path / "py.g2o")
+    io.write_g2o(a, nat); io.write_g2o_py(b, py)
+    assert open(a).read() == open(b).read()          # `stream << double` = %g on both sides
+
+
+def _random_graph_3d(rng, n=9):
+    from oracle import gtsam_oracle as O
+    R = O.so3_expmap(rng.normal(0, 1.0, (n, 3)))
+    poses = np.concatenate([R.reshape(n, 9), rng.normal(0, 3, (n, 3))], 1)
+    v1 = np.arange(n - 1); v2 = v1 + 1
+    Rz = O.so3_expmap(rng.normal(0, 0.5, (n - 1, 3)))
+    z = np.concatenate([Rz.reshape(n - 1, 9), rng.normal(0, 1, (n - 1, 3))], 1)
+    kinds = np.array([k % 4 for k in range(n - 1)], np.int32)           # unit, isotropic, diagonal, full Gaussian in turn
+    noise = np.zeros((n - 1, 36))
+    for k in range(n - 1):
+        if kinds[k] == 1:
+            noise[k, 0] = 0.3 + 0.1 * k
+        elif kinds[k] == 2:
+            noise[k, :6] = rng.uniform(0.1, 2.0, 6)
+        elif kinds[k] == 3:
+            A = rng.normal(size=(6, 6)); noise[k] = np.linalg.cholesky(A @ A.T + 6 * np.eye(6)).T.reshape(-1)
+    return dict(v1=v1, v2=v2, z=z, noise_kind=kinds, noise=noise, vertex_keys=np.arange(n), vertex_poses=poses)
+
+
+def test_native_g2o_full_precision_round_trip_3d_and_2d(tmp_path):
+    """What gtg_io_write_g2o writes with full_precision, gtg_io_read_g2o reads back to rounding (quaternion and information-matrix round
+    trips), with every noise-model kind; the restatement reads the same file to the same arrays."""
+    rng = np.random.default_rng(11)
+    d = _random_graph_3d(rng)
+    p = str(tmp_path / "g3.g2o")
+    io.write_g2o(p, d, full_precision=True)
+    for back in (io.read_g2o3d(p), io.read_g2o3d_py(p)):
+        assert np.array_equal(back["v1"], d["v1"]) and np.array_equal(back["vertex_keys"], d["vertex_keys"])
+        assert np.array_equal(back["noise_kind"], d["noise_kind"])
+        assert np.abs(back["z"] - d["z"]).max() <= 1e-14 and np.abs(back["vertex_poses"] - d["vertex_poses"]).max() <= 1e-14 * 10
+        assert np.abs(back["noise"] - d["noise"]).max() <= 1e-12
+    # 2-D: a pure odometry file (no VERTEX lines) is chained by the reader; G2O order = information matrix
+    p2 = tmp_path / "odo.g2o"
+    p2.write_text("EDGE_SE2 0 1 1.0 0.0 0.5 4 0 0 9 0 16\nEDGE_SE2 1 2 1.0 0.1 -0.2 1 0 0 1 0 1\nEDGE_SE2 2 0 -1.7 0.4 -0.3 5 1 0 6 0.5 7\n")
+    nat, py = io.read_g2o(str(p2)), io.read_2d_py(str(p2), noise_format=io.NOISE_FORMAT_G2O)
+    assert list(nat["vertex_keys"]) == [0, 1, 2] and list(nat["noise_kind"]) == [2, 0, 3]
+    for k in ("z", "noise", "vertex_poses"):
+        assert np.abs(nat[k] - py[k]).max() <= 1e-14, k
+    assert np.allclose(nat["vertex_poses"][1], [1.0, 0.0, 0.5]) and np.allclose(nat["noise"][0, :3], [0.5, 1 / 3.0, 0.25])
+    out = str(tmp_path / "w2.g2o")
+    io.write_g2o(out, nat, full_precision=True)
+    back = io.read_g2o(out)
+    assert np.abs(back["noise"] - nat["noise"]).max() <= 1e-13 and np.abs(back["z"] - nat["z"]).max() <= 1e-15
+
+
+def test_native_g2o_errors(tmp_path):
+    with pytest.raises(ValueError, match="can not find file"):
+        io.read_g2o3d(str(tmp_path / "missing.g2o"))
+    p = tmp_path / "bad.g2o"
+    p.write_text("VERTEX_SE2 0 0 0 0\nVERTEX_SE2 0 1 0 0.1\n")
+    with pytest.raises(ValueError, match="twice"):
+        io.read_2d(str(p))
+    p.write_text("EDGE_SE2 0 1 1.0 0.0 0.5 4 1 1 9 1 16\n")
+    with pytest.raises(ValueError, match="unrecognized covariance matrix format"):
+        io.read_2d(str(p))                                   # AUTO cannot guess this zero pattern (dataset.cpp:218-232)
+    with pytest.raises(ValueError, match="not TORO matrix order"):
+        p.write_text("EDGE2 0 1 1.0 0.0 0.5 4 0 0 0 0 0\n"); io.read_2d(str(p), noise_format=io.NOISE_FORMAT_TORO)
+    p.write_text("EDGE_SE3:QUAT 0 1 0 0 0 0 0 0 1 1 0 0\n")
+    with pytest.raises(ValueError, match="malformed edge"):
+        io.read_g2o3d(str(p))
+    with pytest.raises(ValueError, match="invalid noise format"):
+        io.read_2d(str(p), noise_format="nonsense")

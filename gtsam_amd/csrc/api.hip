@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <set>
 #include <memory>
 #include <new>
 #include <sys/mman.h>
@@ -29,6 +30,10 @@
 #define GTG_FUSED_SFM 1
 #endif
 namespace gt {
+
+// gtg_prewarm's registry (kernels.h): filled by the static PrewarmUnit objects of the translation units
+static std::vector<void (*)(int)>& prewarm_units() { static std::vector<void (*)(int)> v; return v; }
+PrewarmUnit::PrewarmUnit(void (*fn)(int device)) { prewarm_units().push_back(fn); }
 
 static thread_local std::string g_last_error;
 
@@ -253,6 +258,34 @@ int gtg_create(gtg_handle* out, int device_id) {
   check_hip(hipStreamCreate(&c->stream), "hipStreamCreate");
   ensure_events(*c);
   *out = c;
+  return GTG_OK;
+  GTG_CATCH
+}
+
+// The one-time work of a process on a device, done ahead of the first handle: runtime start and device context, the code objects of
+// the library's translation units and the function objects of their kernels (every unit registers its list, kernels.h), the default
+// pair of CU-masked streams of the dataflow factorisation, a first stream / event.  Idempotent per device; safe to call from a helper
+// thread while the caller prepares its problem (the C++ shim's constructor does: GpuLevenbergMarquardtOptimizer.cpp).
+int gtg_prewarm(int device_id) {
+  GTG_TRY
+  static std::mutex mu;
+  static std::set<int> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(device_id)) return GTG_OK;
+  int ndev = 0;
+  check_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+  if (device_id < 0 || device_id >= ndev) throw std::invalid_argument("bad device id (no HIP device visible?)");
+  check_hip(hipSetDevice(device_id), "hipSetDevice");
+  (void)hipFree(nullptr);
+  hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+  check_hip(hipStreamCreate(&st), "hipStreamCreate");
+  check_hip(hipEventCreate(&ev), "hipEventCreate");
+  for (auto fn : prewarm_units()) fn(device_id);
+  (void)hipEventRecord(ev, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(st);
+  done.insert(device_id);
   return GTG_OK;
   GTG_CATCH
 }

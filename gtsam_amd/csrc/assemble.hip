@@ -833,4 +833,14 @@ void launch_scatter_delta(gtg_context& c) {
   check_hip(hipGetLastError(), "scatter_delta");
 }
 
+// gtg_prewarm: this unit's kernels (kernels.h)
+static void prewarm_assemble(int) {
+  prewarm_kernels({(const void*)k_red_diag, (const void*)k_cam_fused, (const void*)k_cam_combine, (const void*)k_lm_fused, (const void*)k_lm_diag, (const void*)k_hoff,
+                   (const void*)k_point_factor, (const void*)k_obs_E<kSfmRec, 9, true>, (const void*)k_obs_E<kSfmRec, 9, false>, (const void*)k_obs_E<kProjRec, 6, false>,
+                   (const void*)k_obs_v<kSfmRec, 9, true>, (const void*)k_obs_v<kSfmRec, 9, false>, (const void*)k_obs_v<kProjRec, 6, false>, (const void*)k_build_diag,
+                   (const void*)k_scatter_hoff, (const void*)k_schur_pairs, (const void*)k_schur_pairs_heavy, (const void*)k_pad_diag, (const void*)k_backsub_lm,
+                   (const void*)k_scatter_delta, (const void*)k_obs_wpos, (const void*)k_cam_pack, (const void*)k_smart_hdiag, (const void*)k_smart_lin1});
+}
+static PrewarmUnit prewarm_assemble_registered(prewarm_assemble);
+
 }  // namespace gt

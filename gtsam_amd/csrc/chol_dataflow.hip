@@ -921,33 +921,28 @@ bool dataflow_schedule_selected() {
   return !(sched && std::string(sched) == "streams");
 }
 
-// fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
-void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xinv, double* fail,
-                        const unsigned char* pivot_kind, double* tile_exp) {
-  const int nt = NP / T;
-  double* S = Sm.p;
-  if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
+// The dynamic-LDS attributes of the three kernels and the device's two CU-masked streams: once per (device, reserved CUs), created by the
+// first factorisation of a process -- or ahead of it by gtg_prewarm (below).
+struct DfStreams { hipStream_t bulk = nullptr, chain = nullptr; hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr; int grid = 0; };
+static DfStreams& df_streams(int device, int reserve) {
   static std::set<int> attr_set;
   static std::mutex attr_mutex;
   {
     std::lock_guard<std::mutex> lock(attr_mutex);
-    if (!attr_set.count(c.device)) {
+    if (!attr_set.count(device)) {
       check_hip(hipFuncSetAttribute((const void*)k_df_bulk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemBulk), "smem attr");
       check_hip(hipFuncSetAttribute((const void*)k_df_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemChain), "smem attr");
       check_hip(hipFuncSetAttribute((const void*)k_df_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(kSmemChain, kSmemBulk)), "smem attr");
-      attr_set.insert(c.device);
+      attr_set.insert(device);
     }
   }
   // The two CU-masked streams and their events belong to the DEVICE, not to the handle: a process runs one dataflow
   // factorisation per device at a time (the caller holds that device's lock, api.hip), and creating masked streams costs
   // milliseconds -- per handle that was 5 ms on the first lambda try of every new optimizer.
-  struct DfStreams { hipStream_t bulk = nullptr, chain = nullptr; hipEvent_t ev_start = nullptr, ev_chain = nullptr, ev_bulk = nullptr; int grid = 0; };
   static std::map<std::pair<int, int>, DfStreams> per_device;   // (device, reserved CUs)
   static std::mutex per_device_mutex;
-  DfStreams* dsp;
-  const int reserve = df.n_chain > 16 ? 32 : df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see below)
-  { std::lock_guard<std::mutex> lock(per_device_mutex); dsp = &per_device[{c.device, reserve}]; }
-  DfStreams& ds = *dsp;
+  std::lock_guard<std::mutex> lock(per_device_mutex);            // (held over the creation: gtg_prewarm's thread and a first factorisation may meet here)
+  DfStreams& ds = per_device[{device, reserve}];
   if (!ds.bulk) {
     // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
     // of LDS, the whole register file of its SIMDs) can only be placed on exactly those -- so it is placed at once, whatever
@@ -958,7 +953,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
     // it; an XCD whose bits are ALL zero is not excluded but fully enabled.  A mask that really confines a kernel therefore
     // needs a bit in every XCD: the chain's mask is the last CU of every XCD (8 CUs, 3 % of the chip), the bulk's the rest.
     hipDeviceProp_t prop;
-    check_hip(hipGetDeviceProperties(&prop, c.device), "props");
+    check_hip(hipGetDeviceProperties(&prop, device), "props");
     const int ncu = std::max(prop.multiProcessorCount, 16);
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u), inv((ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu; i++) (i < ncu - reserve ? mask : inv)[i >> 5] |= 1u << (i & 31);
@@ -970,6 +965,17 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
     const char* g = getenv("GTG_DF_GRID");
     ds.grid = g ? atoi(g) : (ncu - reserve);
   }
+  return ds;
+}
+
+// fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
+void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xinv, double* fail,
+                        const unsigned char* pivot_kind, double* tile_exp) {
+  const int nt = NP / T;
+  double* S = Sm.p;
+  if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
+  const int reserve = df.n_chain > 16 ? 32 : df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see df_streams)
+  DfStreams& ds = df_streams(c.device, reserve);
   // the factorisation's epoch: counted on the host and handed to both kernels BY VALUE -- the ticket counter is only ever touched by
   // atomics, the flags by write-through stores and sc1 loads, and nothing the two kernels synchronise through is a word that a
   // kernel of the previous factorisation wrote with a plain store
@@ -1022,6 +1028,13 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_bulk, 0), "wait");
   check_hip(hipGetLastError(), "cholesky (dataflow)");
 }
+
+// gtg_prewarm: this unit's kernels, their dynamic-LDS attributes and the default pair of masked streams (kernels.h)
+static void prewarm_chol_dataflow(int device) {
+  prewarm_kernels({(const void*)k_df_bulk, (const void*)k_df_chain, (const void*)k_df_single, (const void*)k_df_begin});
+  (void)df_streams(device, 8);
+}
+static PrewarmUnit prewarm_chol_dataflow_registered(prewarm_chol_dataflow);
 
 }  // namespace gt
 #else

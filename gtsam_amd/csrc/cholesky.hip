@@ -892,4 +892,10 @@ void launch_backward_solve(gtg_context& c, SMat S, int NP, const CholPlan& plan,
   check_hip(hipGetLastError(), "backward_solve");
 }
 
+// gtg_prewarm: this unit's kernels of the default path (the stream schedule's k_panel128 / k_syrk are the fall-back and the A/B: first use pays)
+static void prewarm_cholesky(int) {
+  prewarm_kernels({(const void*)k_set_epoch, (const void*)k_pack_blocks, (const void*)k_inv_tiles, (const void*)k_bwd_sweep, (const void*)k_gather_rhs});
+}
+static PrewarmUnit prewarm_cholesky_registered(prewarm_cholesky);
+
 }  // namespace gt

@@ -4,15 +4,15 @@
 // (row = the later position, column = the earlier one), terms grouped by block, the terms of a block in landmark order -- as
 // data-parallel passes (the formulation is pinned bit for bit against the host lists by tests/test_device_analysis_spec.py
 // and, on the GPU, by tests/test_gpu_device_analysis.py):
-//   k_da_nominal  one landmark per lane: k (k + 1) / 2 terms;  ExclusiveSum -> term offsets (emission order = landmark order)
+//   k_da_nominal  one landmark per lane: k (k + 1) / 2 terms;  prim::exclusive_scan -> term offsets (emission order = landmark order)
 //   k_da_dups     one NOMINAL PAIR per lane: a pair of two observations by the same camera is one more term of its landmark
 //                 (none on the usual graphs; otherwise the offsets are summed again)
 //   k_da_emit     one TERM per lane (round 5; rounds 3 - 4: one landmark per lane): the landmark by binary search in the offsets,
 //                 the pair in closed form; key = row position * n + column position, oriented (oa, ob); landmarks with a double
 //                 sighting: k_da_emit_dups, the per-landmark loop with its mirrored duplicates
-//   DeviceRadixSort::SortPairs         stable, so the terms of a block keep the landmark order (= the summation order of
+//   prim::sort_pairs (primitives.hip)  stable, so the terms of a block keep the landmark order (= the summation order of
 //                                      k_schur_pairs: the device's results do not depend on which side built the lists)
-//   gather (oa, ob) into the final lists, DeviceRunLengthEncode::Encode -> the unique blocks, ExclusiveSum -> pair_ptr
+//   gather (oa, ob) into the final lists, prim::runs -> the unique blocks and pair_ptr (the first term of every block)
 // The 6 M terms of the L1723 shape take 1.3 ms (2.8 with one landmark per lane, profiles/r02_device_analysis_proto.log) against 12 ms on 32 host threads, and
 // 49 MB of term lists never cross PCIe; the host gets back the 0.2 M block keys and offsets it needs for the ordering and the
 // tile schedule.  After the ordering the terms of the blocks whose orientation flips are swapped in place (k_da_flip).
@@ -24,13 +24,10 @@
 // The host version stays: it serves the sharded upload (a shard needs the blocks of the WHOLE graph but only its own terms)
 // and the dry-run runtime of the CPU tests, which cannot run kernels.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_run_length_encode.hpp>
-#include <rocprim/device/device_scan.hpp>
-
 #include <stdexcept>
 
 #include "kernels.h"
+#include "primitives.h"
 
 namespace gt {
 
@@ -198,12 +195,10 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   hipStream_t s = c.stream;
   const int n_lm = c.n_lm;
   DevBuf<int64_t> d_cnt, d_off; d_cnt.alloc((size_t)n_lm + 1); d_off.alloc((size_t)n_lm + 1);
-  size_t tmp_bytes = 0, need = 0; void* tmp = nullptr;
-  auto ensure = [&](size_t n) { if (n > tmp_bytes) { if (tmp) (void)hipFree(tmp); hc(hipMalloc(&tmp, n), "hipMalloc"); tmp_bytes = n; } };
+  DevBuf<unsigned char> scan_tmp; scan_tmp.alloc(prim::scan_scratch_bytes((size_t)n_lm + 1));
   DevBuf<int32_t> d_dup; d_dup.alloc((size_t)n_lm + 1);
   hipLaunchKernelGGL(k_da_nominal, dim3((unsigned)((n_lm + 1 + 255) / 256)), dim3(256), 0, s, n_lm, c.lm_obs_ptr.p, d_cnt.p, d_dup.p);
-  hc(rocprim::exclusive_scan(nullptr, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan"); ensure(need);
-  hc(rocprim::exclusive_scan(tmp, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan");
+  prim::exclusive_scan(d_cnt.p, d_off.p, (size_t)n_lm + 1, scan_tmp.p, s);
   int64_t total = 0;
   hc(hipMemcpyAsync(&total, d_off.p + n_lm, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
@@ -215,8 +210,7 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
     hc(hipStreamSynchronize(s), "sync");
     if (n_dup_lm > 0) {
       hipLaunchKernelGGL(k_da_add_dups, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, d_cnt.p, d_dup.p);
-      need = tmp_bytes;
-      hc(rocprim::exclusive_scan(tmp, need, d_cnt.p, d_off.p, (int64_t)0, (size_t)n_lm + 1, rocprim::plus<int64_t>(), s), "scan");
+      prim::exclusive_scan(d_cnt.p, d_off.p, (size_t)n_lm + 1, scan_tmp.p, s);
       hc(hipMemcpyAsync(&total, d_off.p + n_lm, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
       hc(hipStreamSynchronize(s), "sync");
       if (total < 0 || total >= ((int64_t)1 << 31)) throw std::runtime_error("device analysis: term count out of range");
@@ -225,21 +219,17 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   c.n_pair_terms = total;
   c.pair_oa.alloc((size_t)std::max<int64_t>(total, 1)); c.pair_ob.alloc((size_t)std::max<int64_t>(total, 1));
   block_keys.clear(); block_ptr.assign(1, 0);
-  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); if (tmp) (void)hipFree(tmp); c.pair_ptr.upload(block_ptr.data(), 1, s); return; }
+  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); scan_tmp.free(); c.pair_ptr.upload(block_ptr.data(), 1, s); return; }
   // one scratch allocation for everything that does not outlive the call (a dozen separate hipMalloc / hipFree of tens of
   // megabytes cost more than the kernels)
   const size_t N = (size_t)total;
   auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
   int bits = 1;
   while (((uint64_t)1 << bits) < (uint64_t)nrv * (uint64_t)nrv) bits++;
-  size_t need_sort = 0, need_rle = 0, need_scan = 0;
-  // (rocPRIM: a stable LSD radix sort over the `bits` significant key bits -- stability is what keeps the landmark order inside a
-  // block, i.e. the summation order of the Schur complement --, run-length encode, exclusive scan)
-  hc(rocprim::radix_sort_pairs(nullptr, need_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)total, 0u, (unsigned)bits, s), "sort");
-  hc(rocprim::run_length_encode(nullptr, need_rle, (uint64_t*)nullptr, (unsigned)total, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, s), "rle");
-  hc(rocprim::exclusive_scan(nullptr, need_scan, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)total + 1, rocprim::plus<int64_t>(), s), "scan");
-  const size_t need_tmp = std::max(need_sort, std::max(need_rle, need_scan));
-  const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(4 * (N + 1)) + al(8 * (N + 1)) + al(16) + al(need_tmp);
+  // (a stable LSD radix sort over the `bits` significant key bits -- stability is what keeps the landmark order inside a block, i.e. the
+  // summation order of the Schur complement --, then the runs of the sorted keys: primitives.hip)
+  const size_t need_tmp = std::max(prim::sort_scratch_bytes(N), prim::runs_scratch_bytes(N));
+  const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(8 * (N + 1)) + al(16) + al(need_tmp);
   DevBuf<unsigned char> pool_buf; pool_buf.alloc(bytes);     // (through DevBuf: a block of this size is kept for the next handle, api.hip)
   char* pool = reinterpret_cast<char*>(pool_buf.p);
   size_t at = 0;
@@ -248,30 +238,27 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   uint64_t* uniq = reinterpret_cast<uint64_t*>(take(8 * N));
   int32_t* t_oa = reinterpret_cast<int32_t*>(take(4 * N)); int32_t* t_ob = reinterpret_cast<int32_t*>(take(4 * N));
   uint32_t* idx = reinterpret_cast<uint32_t*>(take(4 * N)); uint32_t* idx2 = reinterpret_cast<uint32_t*>(take(4 * N));
-  int32_t* runs = reinterpret_cast<int32_t*>(take(4 * (N + 1))); int64_t* pp = reinterpret_cast<int64_t*>(take(8 * (N + 1)));
+  int64_t* pp = reinterpret_cast<int64_t*>(take(8 * (N + 1)));
   int32_t* d_nruns = reinterpret_cast<int32_t*>(take(16));
-  void* cub_tmp = take(need_tmp);
+  void* prim_tmp = take(need_tmp);
   hipLaunchKernelGGL(k_da_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
                      d_dup.p, key, idx, t_oa, t_ob);
   if (n_dup_lm > 0)
     hipLaunchKernelGGL(k_da_emit_dups, dim3((unsigned)((n_lm + 255) / 256)), dim3(256), 0, s, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
                        d_dup.p, key, idx, t_oa, t_ob);
-  need = need_sort; hc(rocprim::radix_sort_pairs(cub_tmp, need, key, key2, idx, idx2, (size_t)total, 0u, (unsigned)bits, s), "sort");
+  prim::sort_pairs(key, key2, idx, idx2, N, bits, prim_tmp, s);
   hipLaunchKernelGGL(k_da_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, idx2, t_oa, t_ob, c.pair_oa.p, c.pair_ob.p);
-  need = need_rle; hc(rocprim::run_length_encode(cub_tmp, need, key2, (unsigned)total, uniq, runs, d_nruns, s), "rle");
+  prim::runs(key2, N, uniq, pp, d_nruns, prim_tmp, s);     // uniq = the blocks, pp = the first term of every block (+ the total behind the last)
   int nruns = 0;
   hc(hipMemcpyAsync(&nruns, d_nruns, sizeof(int), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
-  hc(hipMemsetAsync(runs + nruns, 0, sizeof(int32_t), s), "memset");
-  need = need_scan; hc(rocprim::exclusive_scan(cub_tmp, need, runs, pp, (int64_t)0, (size_t)nruns + 1, rocprim::plus<int64_t>(), s), "scan");   // int32 counts -> int64 offsets
   block_keys.resize((size_t)nruns); block_ptr.resize((size_t)nruns + 1);
   hc(hipMemcpyAsync(block_keys.data(), uniq, sizeof(uint64_t) * (size_t)nruns, hipMemcpyDeviceToHost, s), "D2H");
   hc(hipMemcpyAsync(block_ptr.data(), pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToHost, s), "D2H");
   c.pair_ptr.alloc((size_t)nruns + 1);
   hc(hipMemcpyAsync(c.pair_ptr.p, pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToDevice, s), "D2D");
   hc(hipStreamSynchronize(s), "sync");
-  d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free();
-  if (tmp) (void)hipFree(tmp);
+  d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); scan_tmp.free();
   pool_buf.free();
 }
 
@@ -296,10 +283,7 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   int bits_lm = 1, bits_red = 1;
   while (((uint64_t)1 << bits_lm) < (uint64_t)n_lm + 1) bits_lm++;
   while (((uint64_t)1 << bits_red) < (uint64_t)nrv + 2) bits_red++;
-  size_t need_a = 0, need_b = 0;
-  hc(rocprim::radix_sort_pairs(nullptr, need_a, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)std::max<int64_t>(n_obs, 1), 0u, (unsigned)bits_lm, s), "sort");
-  hc(rocprim::radix_sort_pairs(nullptr, need_b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, N, 0u, (unsigned)bits_red, s), "sort");
-  const size_t need_tmp = std::max(need_a, need_b);
+  const size_t need_tmp = prim::sort_scratch_bytes(N);
   DevBuf<unsigned char> pool_buf; pool_buf.alloc(4 * al(4 * N) + al(16) + al(need_tmp));
   char* pool = reinterpret_cast<char*>(pool_buf.p);
   size_t at = 0;
@@ -310,11 +294,10 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   void* tmp = take(need_tmp);
   hc(hipMemsetAsync(bad, 0, 16, s), "memset");
   auto grid = [](int64_t n) { return dim3((unsigned)((std::max<int64_t>(n, 1) + 255) / 256)); };
-  size_t need;
   if (n_obs) {
     hipLaunchKernelGGL(k_da_obs, grid(n_obs), dim3(256), 0, s, n_sfm, n_proj, f.sfm_cam.p, f.sfm_point.p, f.proj_pose.p, f.proj_point.p, c.var_type.p,
                        c.red_index.p, c.lm_index.p, d_red_pos.p, c.obs_red.p, c.obs_lm.p, d_pos.p, key, val, bad);
-    need = need_tmp; hc(rocprim::radix_sort_pairs(tmp, need, key, key2, val, val2, (size_t)n_obs, 0u, (unsigned)bits_lm, s), "sort");
+    prim::sort_pairs(key, key2, val, val2, (size_t)n_obs, bits_lm, tmp, s);
     hipLaunchKernelGGL(k_da_u32_to_i32, grid(n_obs), dim3(256), 0, s, n_obs, val2, c.lm_obs.p);
   }
   hipLaunchKernelGGL(k_da_offsets, grid(n_lm + 1), dim3(256), 0, s, n_obs, key2, n_lm, c.lm_obs_ptr.p);
@@ -322,7 +305,7 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   hc(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s), "D2H");
   hipLaunchKernelGGL(k_da_inc_keys, grid(M), dim3(256), 0, s, n_sfm, n_proj, n_btw, n_pri, f.sfm_cam.p, f.proj_pose.p, f.between_v1.p, f.between_v2.p,
                      f.prior_var.p, c.red_index.p, (uint32_t)nrv, key, val);
-  need = need_tmp; hc(rocprim::radix_sort_pairs(tmp, need, key, key2, val, val2, (size_t)M, 0u, (unsigned)bits_red, s), "sort");
+  prim::sort_pairs(key, key2, val, val2, (size_t)M, bits_red, tmp, s);
   hipLaunchKernelGGL(k_da_offsets, grid(nrv + 1), dim3(256), 0, s, M, key2, nrv, c.red_inc_ptr.p);
   int64_t n_inc = 0;
   hc(hipMemcpyAsync(&n_inc, c.red_inc_ptr.p + nrv, sizeof(int64_t), hipMemcpyDeviceToHost, s), "D2H");
@@ -347,5 +330,12 @@ void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped) {
   check_hip(hipStreamSynchronize(c.stream), "sync");
   d_which.free();
 }
+
+// gtg_prewarm: this unit's kernels (kernels.h)
+static void prewarm_device_analysis(int) {
+  prewarm_kernels({(const void*)k_da_nominal, (const void*)k_da_dups, (const void*)k_da_add_dups, (const void*)k_da_emit, (const void*)k_da_emit_dups, (const void*)k_da_gather,
+                   (const void*)k_da_flip, (const void*)k_da_obs, (const void*)k_da_inc_keys, (const void*)k_da_inc_decode, (const void*)k_da_offsets, (const void*)k_da_u32_to_i32});
+}
+static PrewarmUnit prewarm_device_analysis_registered(prewarm_device_analysis);
 
 }  // namespace gt

@@ -20,13 +20,12 @@
 // O(edges) work is left on the host.  Levels of more than kMaxLevel nodes, graphs of more than 4 M nodes and the nested-dissection
 // orderings of the pose graphs stay with the host code (the function returns false and analysis.hip takes the host path).
 #include <cstdio>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
 
 #include <climits>
 #include <stdexcept>
 
 #include "kernels.h"
+#include "primitives.h"
 
 namespace gt {
 
@@ -188,9 +187,7 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   // one workspace, carved (a dozen separate allocations and their releases cost more than the ordering itself)
   int bits = 33;
   while (bits < 64 && ((uint64_t)n >> (bits - 32)) != 0) bits++;
-  size_t need_sort = 0, need_uniq = 0;
-  hc(rocprim::radix_sort_keys(nullptr, need_sort, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)(2 * m), 0u, (unsigned)bits, s), "sort");
-  hc(rocprim::unique(nullptr, need_uniq, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (size_t)(2 * m), rocprim::equal_to<uint64_t>(), s), "unique");
+  const size_t need_sort = prim::sort_scratch_bytes((size_t)(2 * m)), need_uniq = prim::runs_scratch_bytes((size_t)(2 * m));
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) / 256 * 256; return at; };
   const size_t o_k1 = carve(16 * (size_t)m), o_k2 = carve(16 * (size_t)m), o_tmp = carve(std::max(need_sort, need_uniq) + 16);
@@ -213,10 +210,8 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   hc(hipMemcpyAsync(da, ea.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
   hc(hipMemcpyAsync(db, eb.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
   hipLaunchKernelGGL(k_edge_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, da, db, k1);
-  size_t need = need_sort;
-  hc(rocprim::radix_sort_keys(at(o_tmp), need, k1, k2, (size_t)(2 * m), 0u, (unsigned)bits, s), "sort");
-  need = need_uniq;
-  hc(rocprim::unique(at(o_tmp), need, k2, k1, dn, (size_t)(2 * m), rocprim::equal_to<uint64_t>(), s), "unique");
+  prim::sort_keys(k1, k2, (size_t)(2 * m), bits, at(o_tmp), s);
+  prim::runs(k2, (size_t)(2 * m), k1, nullptr, dn, at(o_tmp), s);     // the distinct keys, ascending
   // (the lists carry no block of a variable with itself: analysis.hip filters a == b)
   hipLaunchKernelGGL(k_csr, dim3((unsigned)std::max<int64_t>((n + 256) / 256, 64)), dim3(256), 0, s, n, k1, dn, dptr, dadj);
   hipLaunchKernelGGL(k_rcm, dim3(1), dim3(kRcmThreads), 0, s, n, dptr, dadj, dorder, dqueue, dclaim, at(o_vis), at(o_act), dstatus);
@@ -232,5 +227,9 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   }
   return status == 0;
 }
+
+// gtg_prewarm: this unit's kernels (kernels.h)
+static void prewarm_device_ordering(int) { prewarm_kernels({(const void*)k_edge_keys, (const void*)k_csr, (const void*)k_rcm}); }
+static PrewarmUnit prewarm_device_ordering_registered(prewarm_device_ordering);
 
 }  // namespace gt

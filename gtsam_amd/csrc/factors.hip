@@ -542,3 +542,14 @@ void launch_retract(gtg_context& c) {
 }
 
 }  // namespace gt
+
+// ---- gtg_prewarm: this unit's kernels (kernels.h)
+namespace {
+void prewarm_factors(int) {
+  gt::prewarm_kernels({(const void*)gt::k_lin_sfm, (const void*)gt::k_lin_proj, (const void*)gt::k_lin_between, (const void*)gt::k_lin_prior,
+                       (const void*)gt::k_error<1>, (const void*)gt::k_error<2>, (const void*)gt::k_final_sum, (const void*)gt::k_linear_error<true>,
+                       (const void*)gt::k_linear_error<false>, (const void*)gt::k_retract, (const void*)gt::k_sumsq, (const void*)gt::k_smart_triangulate,
+                       (const void*)gt::k_lin_smart_at_infinity, (const void*)gt::k_error_smart_at_infinity, (const void*)gt::k_sfm_value_offsets});
+}
+gt::PrewarmUnit prewarm_factors_registered(prewarm_factors);
+}  // namespace

@@ -1,5 +1,6 @@
 // kernels.h -- host-callable launchers of the HIP kernels (all stream-ordered on ctx.stream).
 #pragma once
+#include <initializer_list>
 #include <vector>
 
 #include "context.h"
@@ -71,5 +72,15 @@ int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax
                double epsilon_rel, double epsilon_abs, double* gamma0, double* gamma_end);
 
 void check_hip(hipError_t e, const char* what);
+
+// gtg_prewarm (api.hip): every translation unit with kernels registers a function that makes the runtime load the unit's code object and
+// create the function objects of its kernels (hipFuncGetAttributes does both, without a launch) -- the work a kernel's FIRST launch
+// would otherwise do (measured on the L1723 shape, tools/cpp/cold_start_probe.cpp: ~37 ms inside the first gtg_upload_problem and ~20 ms
+// inside the first gtg_try_lambda of a process).
+struct PrewarmUnit { explicit PrewarmUnit(void (*fn)(int device)); };
+inline void prewarm_kernels(std::initializer_list<const void*> kernels) {
+  hipFuncAttributes a;
+  for (const void* k : kernels) (void)hipFuncGetAttributes(&a, k);
+}
 
 }  // namespace gt

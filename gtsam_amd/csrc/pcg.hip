@@ -475,4 +475,8 @@ int launch_pcg(gtg_context& c, double lambda, int diag, double dmin, double dmax
   return (int)h[ST_K] - 1;
 }
 
+// gtg_prewarm: loads this unit's code object (the solver is opt-in: its other kernels pay their first launch)
+static void prewarm_pcg(int) { prewarm_kernels({(const void*)k_pcg_setup}); }
+static PrewarmUnit prewarm_pcg_registered(prewarm_pcg);
+
 }  // namespace gt

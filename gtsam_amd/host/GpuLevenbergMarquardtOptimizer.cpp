@@ -264,31 +264,33 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   //    inside a State, and BOTH constructors of LevenbergMarquardtState deep-copy what they are given (the Values&& one passes
   //    its argument on as an lvalue, LevenbergMarquardtState.h:61-63), so the cheapest way to a current State is to overwrite the
   //    payloads of this copy in place (syncValuesToHost) and let the constructor copy it.
+  //  - `slots` (variable id -> the GenericValue object of the copy): one walk over the copy's map, made by the same thread.
   std::exception_ptr copyErr;
-  std::thread copier([&] { try { graph_ = graph; m.scratch = initial; } catch (...) { copyErr = std::current_exception(); } });
+  std::thread copier([&] {
+    try {
+      graph_ = graph; m.scratch = initial;
+      m.slots.clear(); m.slots.reserve(m.scratch.size());
+      for (const auto& kv : m.scratch) m.slots.push_back(const_cast<Value*>(&kv.value));   // (the GenericValue objects are non-const heap objects owned by the map's nodes)
+    } catch (...) { copyErr = std::current_exception(); }
+  });
   struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } joinCopier{copier};
+  // The one-time work of the process -- HIP runtime start, code-object load, function objects of every kernel -- starts on a helper
+  // thread now and runs under the host passes below (gtg_prewarm is idempotent: later constructions return at once).
+  std::thread prewarmer([device] { gtg_prewarm(device); });
+  Join joinPrewarmer{prewarmer};
 
-  // ---- variables: Values order (sorted by Key, Values.h:74-79); one pass, packed as they are classified ---------------
+  // ---- variables: Values order (sorted by Key, Values.h:74-79).  One serial walk over the map collects keys and value pointers (the
+  // walk is pointer chasing: it does not split); classification (a chain of dynamic_casts) runs on the extraction's threads below, each
+  // thread its range; the values are packed on threads while the factor tables are merged.
   const size_t nvars = initial.size();
-  m.keys.reserve(nvars); m.var_type.reserve(nvars); m.val_off.reserve(nvars + 1); m.dim_off.reserve(nvars + 1);
-  m.val_off.push_back(0); m.dim_off.push_back(0);
-  m.packed.reserve(17 * nvars / 4 + 64);
-  for (const auto& kv : initial) {
-    int32_t t;
-    const size_t at = m.packed.size();
-    if (auto* v = dynamic_cast<const GenericValue<Point3>*>(&kv.value)) { t = GTG_VAR_POINT3; const Point3& q = v->value(); m.packed.insert(m.packed.end(), {q.x(), q.y(), q.z()}); }
-    else if (auto* v = dynamic_cast<const GenericValue<SfmCamera>*>(&kv.value)) { t = GTG_VAR_SFM_CAMERA; m.packed.resize(at + 17); packCamera(v->value(), m.packed.data() + at); }
-    else if (auto* v = dynamic_cast<const GenericValue<Pose3>*>(&kv.value)) { t = GTG_VAR_POSE3; m.packed.resize(at + 12); packPose(v->value(), m.packed.data() + at); }
-    else if (auto* v = dynamic_cast<const GenericValue<Pose2>*>(&kv.value)) { t = GTG_VAR_POSE2; const Pose2& q = v->value(); m.packed.insert(m.packed.end(), {q.x(), q.y(), q.theta()}); }
-    else throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported value type for key " + DefaultKeyFormatter(kv.key));
-    m.keys.push_back(kv.key); m.var_type.push_back(t);
-    m.val_off.push_back((int64_t)m.packed.size());
-    m.dim_off.push_back(m.dim_off.back() + (t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3));
-  }
+  m.keys.reserve(nvars);
+  std::vector<const Value*> vptr; vptr.reserve(nvars);
+  for (const auto& kv : initial) { m.keys.push_back(kv.key); vptr.push_back(&kv.value); }
+  m.var_type.assign(nvars, -1);
   // Key -> variable id: the keys are sorted, so a binary search over the contiguous array (a std::map of 158 000 keys cost 0.2 s of
   // pointer chasing for the 1.35 M lookups of the L1723 shape)
   auto idOf = [&](Key k) { return m.idOf(k); };
-  lap("variables: classify + pack");
+  lap("variables: keys + value pointers");
 
   // ---- factors: dynamic_cast to the supported types (anything else is a hard error), on host threads ------------------
   const size_t nfac = graph.size();
@@ -302,6 +304,11 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
     const size_t b = nfac * ti / nthreads, e = nfac * (ti + 1) / nthreads;
     x.fac_map.reserve(e - b);
     x.sm_ptr.push_back(0);
+    for (size_t v = nvars * ti / nthreads; v < nvars * (ti + 1) / nthreads; v++) {   // this thread's variables: their types (-1: unsupported, reported below)
+      const Value* val = vptr[v];
+      m.var_type[v] = dynamic_cast<const GenericValue<Point3>*>(val) ? GTG_VAR_POINT3 : dynamic_cast<const GenericValue<SfmCamera>*>(val) ? GTG_VAR_SFM_CAMERA :
+                      dynamic_cast<const GenericValue<Pose3>*>(val) ? GTG_VAR_POSE3 : dynamic_cast<const GenericValue<Pose2>*>(val) ? GTG_VAR_POSE2 : -1;
+    }
     size_t i = b;
     try {
       for (; i < e; i++) {
@@ -395,8 +402,33 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
     work(0);
     for (auto& t : pool) t.join();
   }
+  for (size_t v = 0; v < nvars; v++)
+    if (m.var_type[v] < 0) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: unsupported value type for key " + DefaultKeyFormatter(m.keys[v]));
   for (const Extract& x : part) if (x.err) std::rethrow_exception(x.err);   // the first offending factor in graph order
-  lap("factors: extraction (host threads)");
+  lap("factors: extraction, variables: classification (host threads)");
+  // offsets of the packed values / of the tangent vector, then the packing itself on threads beside the merge of the factor tables
+  m.val_off.resize(nvars + 1); m.dim_off.resize(nvars + 1);
+  m.val_off[0] = 0; m.dim_off[0] = 0;
+  for (size_t v = 0; v < nvars; v++) {
+    const int32_t t = m.var_type[v];
+    m.val_off[v + 1] = m.val_off[v] + (t == GTG_VAR_POSE3 ? 12 : t == GTG_VAR_SFM_CAMERA ? 17 : 3);
+    m.dim_off[v + 1] = m.dim_off[v] + (t == GTG_VAR_POSE3 ? 6 : t == GTG_VAR_SFM_CAMERA ? 9 : 3);
+  }
+  m.packed.resize((size_t)m.val_off[nvars]);
+  auto pack = [&](size_t b, size_t e) {
+    for (size_t v = b; v < e; v++) {
+      double* p = m.packed.data() + m.val_off[v];
+      const int32_t t = m.var_type[v];
+      if (t == GTG_VAR_POINT3) { const Point3& q = static_cast<const GenericValue<Point3>*>(vptr[v])->value(); p[0] = q.x(); p[1] = q.y(); p[2] = q.z(); }
+      else if (t == GTG_VAR_SFM_CAMERA) packCamera(static_cast<const GenericValue<SfmCamera>*>(vptr[v])->value(), p);
+      else if (t == GTG_VAR_POSE3) packPose(static_cast<const GenericValue<Pose3>*>(vptr[v])->value(), p);
+      else { const Pose2& q = static_cast<const GenericValue<Pose2>*>(vptr[v])->value(); p[0] = q.x(); p[1] = q.y(); p[2] = q.theta(); }
+    }
+  };
+  const size_t npack = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nthreads, 8), nvars / 8192 + 1));
+  std::vector<std::thread> packers;
+  for (size_t ti = 0; ti < npack; ti++) packers.emplace_back(pack, nvars * ti / npack, nvars * (ti + 1) / npack);
+  struct JoinAll { std::vector<std::thread>& v; ~JoinAll() { for (auto& t : v) if (t.joinable()) t.join(); } } joinPackers{packers};
 
   // ---- merge in graph order: concatenate the tables, hand out the rows of the noise / calibration tables -----------------
   NoiseTable nt;
@@ -473,6 +505,10 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
 
   if (shards.n_shards < 1 || shards.shard < 0 || shards.shard >= shards.n_shards) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: bad ShardSpec");
   if (shards.n_shards > 1 && !shards.allreduce) throw std::invalid_argument("GpuLevenbergMarquardtOptimizer: n_shards > 1 needs an all-reduce callback");
+  for (auto& t : packers) t.join();
+  lap("variables: packed (threads, beside the merge)");
+  prewarmer.join();
+  lap("wait for the prewarm thread");
   check(gtg_create(&m.h, device), "gtg_create");
   if (shards.allreduce) check(gtg_set_allreduce(m.h, shards.allreduce, shards.user), "gtg_set_allreduce");   // before the upload: it verifies the layout across the shards
   check(gtg_upload_problem(m.h, &pb, shards.shard, shards.n_shards), "gtg_upload_problem");
@@ -491,9 +527,8 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   // use checks first that state_ is still a State of this class holding that map (adoptStateIfForeign): a State published by anybody
   // else -- the inherited public tryLambda() does that -- is adopted, not written over.
   {
-    std::unique_ptr<GpuState> fresh = GpuState::make(std::move(m.scratch), e0, params_.lambdaInitial, params_.lambdaFactor, 0, 0);
-    m.slots.clear(); m.slots.reserve(nvars);
-    for (const auto& kv : fresh->values) m.slots.push_back(const_cast<Value*>(&kv.value));   // (the GenericValue objects are non-const heap objects owned by the map's nodes)
+    if (m.slots.size() != nvars) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the copy of the Values lost variables");
+    std::unique_ptr<GpuState> fresh = GpuState::make(std::move(m.scratch), e0, params_.lambdaInitial, params_.lambdaFactor, 0, 0);   // (`slots`, collected by the copier thread, points into the nodes that move here)
     state_ = std::move(fresh);
     m.published = &state_->values;
   }

@@ -21,7 +21,7 @@ PHASES = ["linearize", "assemble", "point_eliminate", "schur", "cholesky", "solv
           "retract", "error"]
 
 # every symbol include/gtsam_amd.h declares (tests check the .so exports all of them)
-SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_upload_problem",
+SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_prewarm", "gtg_last_error", "gtg_version", "gtg_upload_problem",
            "gtg_set_reduced_ordering", "gtg_values_size", "gtg_tangent_size", "gtg_set_values",
            "gtg_get_values", "gtg_get_trial_values", "gtg_error", "gtg_linearize", "gtg_try_lambda", "gtg_try_lambda_pcg",
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
@@ -30,7 +30,8 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_last_error", "gtg_version", "gtg_up
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
            "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal",
-           "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o"]
+           "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o",
+           "gtg_debug_scan", "gtg_debug_sort_pairs", "gtg_debug_runs"]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
@@ -98,6 +99,9 @@ def load():
     lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
     lib.gtg_io_write_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
+    lib.gtg_debug_scan.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.gtg_debug_sort_pairs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gtg_debug_runs.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gtg_io_g2o_sizes.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_g2o.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 7
     lib.gtg_io_write_g2o.argtypes = [C.c_char_p, C.c_int, C.c_int64] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]

@@ -142,6 +142,10 @@ typedef struct gtg_problem {
 /* ---- lifetime -------------------------------------------------------------------------------- */
 int gtg_create(gtg_handle* out, int device_id);
 int gtg_destroy(gtg_handle h);
+/* Optional: do the one-time work of the process on `device_id` now (HIP runtime start, code-object load, function objects of every
+ * kernel, the factorisation's masked streams) instead of inside the first gtg_create / gtg_upload_problem / gtg_try_lambda.  Idempotent
+ * and thread-safe: meant to run on a helper thread while the caller loads or extracts its problem. */
+int gtg_prewarm(int device_id);
 const char* gtg_last_error(void);
 const char* gtg_version(void);
 
@@ -298,6 +302,12 @@ int64_t gtg_release_cached_memory(void);
 /* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
  * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */
 int gtg_debug_df_trace(gtg_handle h, int64_t* out, int64_t n);
+
+/* tests: the hand-written scan / stable radix sort / run detection of the set-up passes (csrc/primitives.hip) on host arrays.
+ * gtg_debug_sort_pairs: key_bytes 4 or 8; val NULL sorts keys only (8-byte keys).  Returns 0, or GTG_ERR_HIP. */
+int gtg_debug_scan(int device, const int64_t* in, int64_t n, int64_t* out);
+int gtg_debug_sort_pairs(int device, int key_bytes, const void* key, const uint32_t* val, int64_t n, int bits, void* key_out, uint32_t* val_out);
+int gtg_debug_runs(int device, const uint64_t* sorted, int64_t n, uint64_t* uniq, int64_t* start, int32_t* n_runs);
 
 /* ---- wire format on the bundle-adjustment side of the path: BAL text files straight to / from the
  * SoA arrays of gtg_problem.  Host-only (no GPU needed).  Replaces SfmData::FromBalFile (gtsam/sfm/SfmData.cpp:189-246: every

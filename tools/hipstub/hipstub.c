@@ -113,6 +113,7 @@ hipError_t hipLaunchKernel(const void* f, dim3s grid, dim3s block, void** args, 
   return 0;
 }
 hipError_t hipFuncSetAttribute(const void* f, int attr, int v) { (void)f; (void)attr; (void)v; return 0; }
+hipError_t hipFuncGetAttributes(void* attr, const void* f) { (void)attr; (void)f; return 0; }   /* gtg_prewarm: nothing to load here */
 
 /* ---- devices ---- */
 hipError_t hipGetDeviceCount(int* n) { *n = 8; return 0; }   /* a node: one process per "device" in the multi-rank dry runs */

@@ -433,7 +433,7 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     std::vector<double> rk(p->n_noise, 0.0);
     for (int i = 0; i < p->n_noise; i++) {
       if (p->noise_robust) rkind[i] = p->noise_robust[i];
-      if (rkind[i] < GTG_ROBUST_NONE || rkind[i] > GTG_ROBUST_GEMANMCCLURE) throw std::invalid_argument("unsupported m-estimator");
+      if (rkind[i] < GTG_ROBUST_NONE || rkind[i] > GTG_ROBUST_L2WITHDEADZONE) throw std::invalid_argument("unsupported m-estimator");
       if (rkind[i] != GTG_ROBUST_NONE) {
         rk[i] = p->noise_robust_param ? p->noise_robust_param[i] : 0.0;
         if (!(rk[i] > 0.0)) throw std::invalid_argument("m-estimator parameter must be > 0");   // LossFunctions.cpp ctor checks
@@ -1049,6 +1049,17 @@ int gtg_debug_df_ctrl(gtg_handle c, int32_t out[16]) {
   DeviceGuard on_device(c->device);
   check_hip(hipMemcpy(out, c->df.ctrl.p, sizeof(int32_t) * 16, hipMemcpyDeviceToHost), "D2H");
   out[15] = (int32_t)c->df_fallbacks;   // (host counter) lambda tries repeated with the stream schedule after a time-out
+  return GTG_OK;
+  GTG_CATCH
+}
+
+int gtg_debug_df_poll_stats(gtg_handle c, int64_t out[5]) {
+  GTG_TRY
+  if (!c || !c->uploaded || !out || !c->df.ctrl.p) throw std::invalid_argument("gtg_debug_df_poll_stats: no dataflow schedule");
+  DeviceGuard on_device(c->device);
+  int32_t w[32];
+  check_hip(hipMemcpy(w, c->df.ctrl.p, sizeof w, hipMemcpyDeviceToHost), "D2H");
+  out[0] = w[18]; out[1] = w[7]; out[2] = w[16]; out[3] = w[6]; out[4] = w[17];
   return GTG_OK;
   GTG_CATCH
 }

@@ -95,24 +95,25 @@ __device__ __forceinline__ void stores_done() {   // this wavefront's stores are
   GT_DRAIN_STORES();
 #endif
 }
-// Every flag is published TWICE: at its word and at a shadow word `sh` words further on (another line, another page).  A poller reads
-// the first; when a wait drags on (1024 polls) it also looks at the shadow.  Reason: in a process with several handles on one device
-// a polled line is occasionally left STUCK in the poller's XCD L2 with the value it had when the polling began -- sc1 loads (served
-// by that L2) return the old flag for seconds while memory holds the new one and every other XCD sees it (about one wait in 1e8;
-// tools/df_contention_diag.py, profiles/r03_df_contention.txt).  The shadow is not polled while it changes, so it is fetched fresh.
-// Round 4: the word itself is published by a READ-MODIFY-WRITE atomic (an exchange whose result is not used), and a wait that drags
-// on also looks at the word with one (wait_flags: fetch_max with 0).  Agent-scope RMW atomics are executed at the device's point of
-// coherence -- the ticket counter of the bulk kernel relies on exactly that across the 8 XCDs -- so neither a store lingering on
-// the producer's side nor a line lingering on the poller's side can come between the two (the post-mortems of the stuck waits,
-// profiles/r04_df_handoff.txt, do not tell the two apart: all that is known is that the poller's sc1 loads kept returning an
-// older value of a word that memory held the new value of once the kernels had drained).
-__device__ __forceinline__ void st_flag(long long* p, long long v, long long sh) {
+// Flags and stale lines (rounds 3 - 6).  In a process with several handles on one device a polled line is occasionally left STUCK in the
+// poller's XCD L2 with the value it had when the polling began -- sc1 loads (served by that L2) return the old flag for seconds while memory
+// holds the new one and every other XCD sees it (tools/df_contention_diag.py, profiles/r03_df_contention.txt).  Rounds 3 - 5 therefore
+// published every flag twice (a shadow word in another page, looked at after 1024 fruitless polls) and, since round 4, also asked the
+// device's point of coherence with a read-modify-write atomic after 512 (wait_flags: fetch_max with 0; agent-scope RMW atomics execute
+// at the point of coherence -- the ticket counter of the bulk kernel relies on exactly that across the 8 XCDs).  Round 6 counted what
+// ends those long waits (profiles/r06e_poll_statistics.txt; 3.5e8 waits of >= 256 polls in three 60 s stress runs): of 1.43 M waits that
+// ended on the RMW poll NONE found its word still old with the next sc1 load -- they are flags that changed in the microsecond between the
+// iteration's sc1 poll and the RMW (0.4 % of the long waits, the ratio of that window to a wait), not stale lines, and the RMW leaves
+// the line current --; of 0.21 M waits that ended on the shadow word 1 397 DID still read the old value from the word itself (all but one
+// with three handles in flight): that is the stuck line, rare (1.6e-5 of the long waits) and real, and the shadow read ends the wait
+// without curing it.  So the shadow words are gone: the flag is ONE word published by an exchange, a long wait asks the point of coherence
+// every 512 polls.
+__device__ __forceinline__ void st_flag(long long* p, long long v) {
 #if GTG_DF_FENCES
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
   (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-  __hip_atomic_store(p + sh, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the word as the point of coherence holds it (flags only grow: max with 0 leaves them alone); wave-uniform address: one lane asks
 __device__ __forceinline__ long long ld_flag_rmw(const long long* p) {
@@ -137,7 +138,7 @@ __device__ __forceinline__ bool timed_out(const double* fail) {
 }
 // Every lane of the calling wavefront polls the same words (one broadcast load); bounded: see the file comment.
 // The first wait that gives up leaves a record (what it waited for) in dbg[0..7] (gtg_debug_df_ctrl).
-__device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail, long long sh,
+__device__ __forceinline__ void wait_flags(const long long* f1, long long v1, const long long* f2, long long v2, double* fail,
                                            int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
   int spins = 0;
   long long t0 = 0;
@@ -145,13 +146,10 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 255) == 0) {
       if (timed_out(fail)) break;
-      if (spins == 256) t0 = wall_clock64();
-      if ((spins & 1023) == 0 && ld_flag(f1 + sh) >= v1 && ld_flag(f2 + sh) >= v2) {   // the words themselves are stuck in this XCD's L2
-        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 2, 1);   // ctrl[6]: waits that ended on the shadow words
-        break;
-      }
-      if ((spins & 1023) == 512 && ld_flag_rmw(f1) >= v1 && ld_flag_rmw(f2) >= v2) {    // ... or ask the point of coherence
-        if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg - 1, 1);   // ctrl[7]: waits that ended on the read-modify-write poll
+      if (spins == 256) { t0 = wall_clock64(); if (dbg && (threadIdx.x & 63) == 0) atomicAdd(dbg + 10, 1); }   // ctrl[18]: waits that got this long
+      if ((spins & 511) == 0 && ld_flag_rmw(f1) >= v1 && ld_flag_rmw(f2) >= v2) {    // ask the point of coherence (see the comment above st_flag)
+        // ctrl[7]: waits that ended here; ctrl[16]: ... and whose word the next sc1 load still finds old (0 of 1.43 M in round 6's count)
+        if (dbg && (threadIdx.x & 63) == 0) { atomicAdd(dbg - 1, 1); if (ld_flag(f1) < v1 || ld_flag(f2) < v2) atomicAdd(dbg + 8, 1); }
         break;
       }
       if (wall_clock64() - t0 > kWaitTicks) {
@@ -178,9 +176,9 @@ __device__ __forceinline__ int tile_progress(const long long* f1, const long lon
   const long long m = a < b ? a : b;
   return __builtin_amdgcn_readfirstlane((int)(m < 0 ? 0 : m));
 }
-__device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail, long long sh,
+__device__ __forceinline__ int wait_progress(const long long* f1, const long long* f2, long long flagbase, int need, double* fail,
                                              int32_t* dbg, int kind, int a, int b, int c) {
-  wait_flags(f1, flagbase + need, f2, flagbase + need, fail, sh, dbg, kind, a, b, c);
+  wait_flags(f1, flagbase + need, f2, flagbase + need, fail, dbg, kind, a, b, c);
   return need;   // (at least; the caller asks again when it needs more)
 }
 
@@ -199,7 +197,7 @@ constexpr int kBulkThreads = 1024;
 template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
                                            long long* __restrict__ myflag, const long long* __restrict__ pflag, double* __restrict__ Xinv_all,
-                                           double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg,
+                                           double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg,
                                            long long* __restrict__ tr) {
   // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
   // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
@@ -226,13 +224,13 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     if (pf < flagbase + q + 1) {
-      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, sh, dbg, 3, I, J, q);
+      wait_flags(pflag, flagbase + q + 1, pflag, flagbase + q + 1, fail, dbg, 3, I, J, q);
       pf = flagbase + q + 1;
     }
     if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
     if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
     __syncthreads();   // the previous step's images have been consumed; -X_{q-1} is complete in the W patches and out of every wavefront
-    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q, sh);
+    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
     {  // images of this step: slots 0 .. 3-q = L(q + s, q - 1) (q > 0), slot 3 = Linv(q,q); wavefront w moves 1 KiB pieces
       // (w & 7) of the slots (w >> 3) and (w >> 3) + 2
 #pragma unroll
@@ -301,7 +299,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   }
   stores_done();
   __syncthreads();
-  if (tid == 0) st_flag(myflag, flagbase + 4, sh);
+  if (tid == 0) st_flag(myflag, flagbase + 4);
 }
 
 
@@ -309,7 +307,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
                                          const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
-                                         double* __restrict__ fail, long long epoch, long long sh, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
+                                         double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
   // the thread index is laundered per task: everything derived from it is recomputed here instead of being hoisted out of
   // the persistent task loop and kept alive across it
   int tid_ = threadIdx.x;
@@ -371,13 +369,13 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   if (early ? q > 0 : E > 0) {
     // lane 0 / this lane: the pieces before this one
     const long long have = early ? q : (E + G - 1) / G;
-    wait_flags(pflag_mine, epoch * kPieceBase + have, pflag_mine, epoch * kPieceBase + have, fail, sh, dbg, 7, I, J, piece);
+    wait_flags(pflag_mine, epoch * kPieceBase + have, pflag_mine, epoch * kPieceBase + have, fail, dbg, 7, I, J, piece);
     load_acc(AccRow, false);
     if (!early)
       for (int g = 1; g < G; g++) {            // the other lanes, in lane order
         const long long ng = (E - g + G - 1) / G;
         const long long* fg = part_flag + scratch + g - 1;
-        wait_flags(fg, epoch * kPieceBase + ng, fg, epoch * kPieceBase + ng, fail, sh, dbg, 7, I, J, piece);
+        wait_flags(fg, epoch * kPieceBase + ng, fg, epoch * kPieceBase + ng, fail, dbg, 7, I, J, piece);
         load_acc(S + (int64_t)(scratch + g - 1) * TT + (16 * rt) * T + 64 * h, true);
       }
   } else if (lane_g == 0) {
@@ -393,7 +391,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     // tiles are long final and the test is a scalar compare; for the last step (block column J-1, whose tiles become final
     // behind the diagonal tile that is being factored right now) the contraction streams behind the substitution.
     int ka = kl[0], kb = kl[1];
-    int cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, 1, fail, sh, dbg, 1, I, J, ka);   // progress known for the current step
+    int cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, 1, fail, dbg, 1, I, J, ka);   // progress known for the current step
     const double* Ak = S + (int64_t)ka * TT;
     const double* Bk = S + (int64_t)kb * TT;
     stage(Ak, Bk, 0, 0);
@@ -411,10 +409,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         const int cur = ch & 1;
         if (ch + 1 < T / KC) {
           const int need = ch + 2;   // chunk ch + 1 = the operand tiles' 32-column block ch + 1
-          if (cp < need) { cp = tile_progress(tile_flag + ka, tile_flag + kb, flagbase); if (cp < need) cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, need, fail, sh, dbg, 2, I, J, ka); }
+          if (cp < need) { cp = tile_progress(tile_flag + ka, tile_flag + kb, flagbase); if (cp < need) cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, need, fail, dbg, 2, I, J, ka); }
           stage(Ak, Bk, ch + 1, cur ^ 1);
         } else if (ki + 1 < kcnt) {
-          if (np < 1) np = wait_progress(tile_flag + kna, tile_flag + knb, flagbase, 1, fail, sh, dbg, 2, I, J, kna);
+          if (np < 1) np = wait_progress(tile_flag + kna, tile_flag + knb, flagbase, 1, fail, dbg, 2, I, J, kna);
           stage(An, Bn, 0, cur ^ 1);
         }
         const char* Ac = smem_raw + cur * 2 * CH;
@@ -443,7 +441,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int r = 0; r < 4; r++) st_wt((AccRow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + q + 1, sh);
+    if (tid == 0) st_flag(pflag_mine, epoch * kPieceBase + q + 1);
     return;
   }
   if (I == J) {
@@ -454,14 +452,14 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       for (int r = 0; r < 4; r++) st_wt((Crow + (4 * r) * T + 16 * c) + lane_off, x[c][r]);
     stores_done();
     __syncthreads();
-    if (tid == 0) st_flag(pd_flag + J, fin, sh);
+    if (tid == 0) st_flag(pd_flag + J, fin);
     return;
   }
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
-  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, sh, dbg, tr);
+  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr);
+  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr);
 }
 
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, const int32_t* __restrict__ tasks,
@@ -469,7 +467,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
                                           long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                           long long* __restrict__ pd_flag,
                                           double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
-                                          double* __restrict__ fail, const long long epoch, const long long sh,
+                                          double* __restrict__ fail, const long long epoch,
                                           long long* __restrict__ trace) {
   __shared__ int s_task;
   for (;;) {
@@ -486,7 +484,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, sh, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -498,10 +496,10 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
                                                     long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                                     long long* __restrict__ pd_flag,
                                                     double* __restrict__ Xinv_all, int32_t* __restrict__ ctrl,
-                                                    double* __restrict__ fail, const long long epoch, const long long sh,
+                                                    double* __restrict__ fail, const long long epoch,
                                                     long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, trace);
 }
 #endif
 
@@ -514,7 +512,7 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_bulk(double* __restrict__ S
 __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ S, double* __restrict__ Xinv_all,
                                            const long long* __restrict__ pd_flag, long long* tile_flag,
                                            const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
-                                           const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
+                                           const long long epoch, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
                                            const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
   double* A = reinterpret_cast<double*>(smem_raw);
@@ -522,7 +520,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   for (int it = 0; it < n_mine; it++) {
     const int J = my_tiles[it];
-    if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, sh, ctrl + 8, 4, J, J, 0);
+    if (tid < 64) wait_flags(pd_flag + J, final_of(epoch), pd_flag + J, final_of(epoch), fail, ctrl + 8, 4, J, J, 0);
     __syncthreads();
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
@@ -538,7 +536,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
       const long long* sflag = tile_flag + sslot;
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, sh, ctrl + 8, 5, J, J - 1, q);
+        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, ctrl + 8, 5, J, J - 1, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
@@ -579,7 +577,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, sh, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
+    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, 0, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
                deferred ? X : nullptr);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
@@ -590,12 +588,12 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
 __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, double* __restrict__ Xinv_all,
                                                      const long long* __restrict__ pd_flag, long long* tile_flag,
                                                      const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
-                                                     const long long epoch, const long long sh, int32_t* __restrict__ ctrl,
+                                                     const long long epoch, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
                                                      const int32_t* __restrict__ chain_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
+  chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
              chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
 }
 
@@ -609,12 +607,12 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
                                                       long long* __restrict__ pd_flag,
                                                       const int32_t* __restrict__ chain_slots, double* __restrict__ Xinv_all,
                                                       int32_t* __restrict__ ctrl, double* __restrict__ fail,
-                                                      const long long epoch, const long long sh, long long* __restrict__ trace,
+                                                      const long long epoch, long long* __restrict__ trace,
                                                       const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
                                                       const int32_t* __restrict__ chain_off, const int32_t* __restrict__ chain_tiles, int n_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
-  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, sh, trace);
+  if ((int)blockIdx.x < n_chain) { if (threadIdx.x < 512) chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, ctrl, trace ? trace + 8 * (int64_t)ntasks : nullptr, chain_tiles + chain_off[blockIdx.x], chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp); }
+  else bulk_loop(smem_raw, S, tasks, ntasks, klist, tile_flag, part_flag, pd_flag, Xinv_all, ctrl, fail, epoch, trace);
 }
 
 __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
@@ -898,14 +896,13 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
-  // every flag array twice (st_flag): the shadow words lie `shadow` words behind the flags, the same distance in all three arrays
-  df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // (flag words by slot, the scratch slots of the accumulator lanes included)
-  df.tile_flag.alloc(2 * (size_t)df.shadow); df.part_flag.alloc(2 * (size_t)df.shadow); df.pd_flag.alloc(2 * (size_t)df.shadow); df.ctrl.alloc(16);
+  df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // flag words by slot, the scratch slots of the accumulator lanes included (the name is from rounds 3 - 5, when every flag had a shadow word this far behind it)
+  df.tile_flag.alloc((size_t)df.shadow); df.part_flag.alloc((size_t)df.shadow); df.pd_flag.alloc((size_t)df.shadow); df.ctrl.alloc(32);
   if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");
-  check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 16, stream), "memset");
+  check_hip(hipMemsetAsync(df.ctrl.p, 0, sizeof(int32_t) * 32, stream), "memset");
   check_hip(hipStreamSynchronize(stream), "df plan upload");
 }
 
@@ -987,7 +984,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
     check_hip(hipGetDeviceProperties(&prop, c.device), "props");
     const int g1 = (int)std::min<int64_t>(prop.multiProcessorCount, df.n_tasks + df.n_chain);
     hipLaunchKernelGGL(k_df_single, dim3(g1), dim3(kBulkThreads), std::max(kSmemChain, kSmemBulk), c.stream, S, df.tasks.p, (int)df.n_tasks,
-                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p, pivot_kind, tile_exp,
+                       df.klist.p, df.tile_flag.p, df.part_flag.p, df.pd_flag.p, df.has_sub.p, Xinv, df.ctrl.p, fail, epoch, df.trace.p, pivot_kind, tile_exp,
                        df.chain_off.p, df.chain_tiles.p, df.n_chain);
     check_hip(hipGetLastError(), "cholesky (dataflow, single kernel)");
     return;
@@ -1005,11 +1002,11 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const int launch_no = ++launches;
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
-  hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, (long long)df.shadow, df.ctrl.p,
+  hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, df.ctrl.p,
                      df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
+                     df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, df.trace.p);
   // A short second launch of the bulk kernel BEHIND the chain kernel in its stream (six workgroups on the reserved CUs, same
   // ticket counter).  It was meant to share the tail of the factorisation; the profile shows that it finds next to nothing to do
   // (4 us: the tail after the last diagonal tile is 5 us of work) -- and yet the factorisation is reproducibly 1.5 % shorter
@@ -1021,7 +1018,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   constexpr int extra = 6;
   if (df.n_tasks > grid)
     hipLaunchKernelGGL(k_df_bulk, dim3(extra), dim3(kBulkThreads), kSmemBulk, ds.chain, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
-                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, (long long)df.shadow, df.trace.p);
+                       df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, df.trace.p);
   check_hip(hipEventRecord(ds.ev_chain, ds.chain), "record");
   check_hip(hipEventRecord(ds.ev_bulk, ds.bulk), "record");
   check_hip(hipStreamWaitEvent(c.stream, ds.ev_chain, 0), "wait");

@@ -29,6 +29,8 @@ GT_HD double robust_weight(int rkind, double k, double d) {
     case 4: { if (a <= k) { const double t = 1.0 - d * d / (k * k); return t * t; } return 0.0; }   // Tukey :250-256
     case 5: return exp(-(d * d) / (k * k));                                // Welsch :289-292
     case 6: { const double c2 = k * k, c4 = c2 * c2, ce = c2 + d * d; return c4 / (ce * ce); }     // Geman-McClure :320-325
+    case 7: { const double e2 = d * d; if (e2 > k) { const double w = 2.0 * k / (k + e2); return w * w; } return 1.0; }   // DCS :355-364
+    case 8: return (a <= k) ? 0.0 : (-k + a) / a;                          // L2WithDeadZone :402-409 (distance = a norm: >= 0)
     default: return 1.0;
   }
 }
@@ -41,6 +43,8 @@ GT_HD double robust_loss(int rkind, double k, double d) {
     case 4: { if (a <= k) { const double t = 1.0 - d * d / (k * k); return k * k * (1 - t * t * t) / 6.0; } return k * k / 6.0; }  // :258-267
     case 5: return k * k * 0.5 * -expm1(-(d * d) / (k * k));                                         // :294-297
     case 6: { const double c2 = k * k, e2 = d * d; return 0.5 * (c2 * e2) / (c2 + e2); }             // :327-331
+    case 7: { const double e2 = d * d, e4 = e2 * e2, c2 = k * k; return (c2 * e2 + k * e4) / ((e2 + k) * (e2 + k)); }   // DCS :366-375
+    case 8: return (a < k) ? 0.0 : 0.5 * (k - a) * (k - a);                                          // L2WithDeadZone :411-414
     default: return 0.5 * d * d;
   }
 }
@@ -100,6 +104,11 @@ GT_HD bool sfm_linearize_at_infinity(const double* cam, const double* dir, const
   whiten_cols<2>(n.kind, n.data, J, 9);
   whiten_cols<2>(n.kind, n.data, J + 18, 3);
   whiten_cols<2>(n.kind, n.data, J + 24, 1);
+  // A Robust model here: the factor's own linearize() whitens H1, H2 and b ONE AT A TIME through Robust::Whiten(Matrix), whose
+  // WhitenSystem sees an empty b -- the m-estimator's weight is evaluated at distance 0 (slam/GeneralSFMFactor.h:162-168,
+  // linear/NoiseModel.h:711-714).  That is exactly 1 for every estimator but L2WithDeadZone, whose weight(0) is 0: the reference
+  // drops the factor from the linear system (and keeps it in the error); so does this.
+  if (n.rkind) { const double w = sqrt(robust_weight(n.rkind, n.rk, 0.0)); if (w != 1.0) for (int i = 0; i < kSfmRec; i++) J[i] *= w; }
   return true;
 }
 // its share of SmartFactorBase::totalReprojectionError<Unit3> (SmartFactorBase.h:296-303): 0.5 |whitened (h - z)|^2

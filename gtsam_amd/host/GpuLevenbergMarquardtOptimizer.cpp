@@ -163,7 +163,14 @@ struct NoiseTable {
     else if (auto p = std::dynamic_pointer_cast<me::Tukey>(e)) { *rk = GTG_ROBUST_TUKEY; *k = p->modelParameter(); }
     else if (auto p = std::dynamic_pointer_cast<me::Welsch>(e)) { *rk = GTG_ROBUST_WELSCH; *k = p->modelParameter(); }
     else if (auto p = std::dynamic_pointer_cast<me::GemanMcClure>(e)) { *rk = GTG_ROBUST_GEMANMCCLURE; *k = p->modelParameter(); }
-    else throw std::invalid_argument("m-estimator outside the GPU path (supported: Fair, Huber, Cauchy, Tukey, Welsch, GemanMcClure)");
+    else if (auto p = std::dynamic_pointer_cast<me::DCS>(e)) { *rk = GTG_ROBUST_DCS; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::L2WithDeadZone>(e)) { *rk = GTG_ROBUST_L2WITHDEADZONE; *k = p->modelParameter(); }
+    // the asymmetric estimators differ from their symmetric namesakes for NEGATIVE distances only (LossFunctions.cpp:433-500); what a
+    // Robust noise model hands them is a norm (NoiseModel.h:716-718, NoiseModel.cpp:697-730), so on this path they are Tukey / Cauchy
+    else if (auto p = std::dynamic_pointer_cast<me::AsymmetricTukey>(e)) { *rk = GTG_ROBUST_TUKEY; *k = p->modelParameter(); }
+    else if (auto p = std::dynamic_pointer_cast<me::AsymmetricCauchy>(e)) { *rk = GTG_ROBUST_CAUCHY; *k = p->modelParameter(); }
+    else throw std::invalid_argument("m-estimator outside the GPU path (supported: Fair, Huber, Cauchy, Tukey, Welsch, GemanMcClure, DCS, L2WithDeadZone, "
+                                     "AsymmetricTukey, AsymmetricCauchy; not: Custom)");
   }
   int32_t add(const SharedNoiseModel& outer, size_t expect_dim) {
     if (!outer) throw std::invalid_argument("factor without a noise model is not supported");

@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_prewarm", "gtg_last_error", "gtg_ve
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_values_device_ptr", "gtg_values_changed",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal",
            "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o",
            "gtg_debug_scan", "gtg_debug_sort_pairs", "gtg_debug_runs"]
@@ -95,6 +95,7 @@ def load():
     lib.gtg_debug_reduced_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
     lib.gtg_debug_df_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.gtg_debug_df_poll_stats.argtypes = [C.c_void_p, C.c_void_p]
     lib.gtg_io_last_error.restype = C.c_char_p
     lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
@@ -282,6 +283,12 @@ class DeviceGraph:
         out = np.zeros(n, np.int64)
         _check(self.lib.gtg_debug_df_trace(self.h, out.ctypes.data, n), "gtg_debug_df_trace")
         return out[:8 * pl["tasks"].shape[0]].reshape(-1, 8), out[8 * pl["tasks"].shape[0]:].reshape(-1, 2)
+
+    def df_poll_stats(self):
+        """(long waits, ended on the RMW poll, of those still stale for the sc1 load, ended on the shadow word, of those still stale)"""
+        out = (C.c_int64 * 5)()
+        _check(self.lib.gtg_debug_df_poll_stats(self.h, out), "gtg_debug_df_poll_stats")
+        return [int(x) for x in out]
 
     def df_ctrl(self):
         out = np.zeros(16, np.int32)

@@ -16,7 +16,7 @@ import numpy as np
 VAR_POSE3, VAR_SFM_CAMERA, VAR_POINT3, VAR_POSE2 = 0, 1, 2, 3
 FAC_GENERAL_SFM, FAC_PROJECTION, FAC_BETWEEN_POSE3, FAC_PRIOR = 0, 1, 2, 3
 NOISE_UNIT, NOISE_ISOTROPIC, NOISE_DIAGONAL, NOISE_GAUSSIAN = 0, 1, 2, 3
-ROBUST_NONE, ROBUST_FAIR, ROBUST_HUBER, ROBUST_CAUCHY, ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE = range(7)
+ROBUST_NONE, ROBUST_FAIR, ROBUST_HUBER, ROBUST_CAUCHY, ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE, ROBUST_DCS, ROBUST_L2WITHDEADZONE = range(9)
 
 STORAGE = {VAR_POSE3: 12, VAR_SFM_CAMERA: 17, VAR_POINT3: 3, VAR_POSE2: 3}    # Pose2 = (x, y, theta)
 TANGENT = {VAR_POSE3: 6, VAR_SFM_CAMERA: 9, VAR_POINT3: 3, VAR_POSE2: 3}

@@ -62,7 +62,9 @@ enum { GTG_NOISE_UNIT = 0, GTG_NOISE_ISOTROPIC = 1, GTG_NOISE_DIAGONAL = 2, GTG_
  * whitens H1, H2, b one at a time through Robust::Whiten(Matrix), slam/GeneralSFMFactor.h:162-168, where the
  * weight evaluates to 1); the m-estimator only enters their error(). */
 enum { GTG_ROBUST_NONE = 0, GTG_ROBUST_FAIR = 1, GTG_ROBUST_HUBER = 2, GTG_ROBUST_CAUCHY = 3, GTG_ROBUST_TUKEY = 4,
-       GTG_ROBUST_WELSCH = 5, GTG_ROBUST_GEMANMCCLURE = 6 };
+       GTG_ROBUST_WELSCH = 5, GTG_ROBUST_GEMANMCCLURE = 6, GTG_ROBUST_DCS = 7, GTG_ROBUST_L2WITHDEADZONE = 8 };
+/* (AsymmetricTukey / AsymmetricCauchy, LossFunctions.cpp:433-500: on this path the distance is a norm, >= 0, where they coincide with
+ * Tukey / Cauchy -- the C++ shim maps them.) */
 
 /* The factor graph in structure-of-arrays form: what the extractor produces by walking a
  * gtsam::NonlinearFactorGraph once (FactorGraph.h:92 factors_, Factor.h keys_). Variable ids are
@@ -295,6 +297,11 @@ int gtg_debug_reduced_order(gtg_handle h, int32_t* var_of_position, int32_t n);
  * out[15], the second wanted value, is replaced by a host counter: the lambda tries of this handle that were repeated with the
  * stream schedule after a time-out of the dataflow pass) */
 int gtg_debug_df_ctrl(gtg_handle h, int32_t out[16]);
+/* Poll statistics of the dataflow factorisation's dependency waits, counted over the handle's life (round 6): out[0] waits that lasted
+ * >= 256 polls, out[1] of those the ones that ended on the read-modify-write poll, out[2] of THOSE the ones whose next ordinary (sc1)
+ * load of the same words still returned the old value -- a line the XCD's L2 kept serving --, out[3] / out[4] the same for the shadow
+ * words (chol_dataflow.hip::wait_flags; tools/df_stress.py prints them). */
+int gtg_debug_df_poll_stats(gtg_handle h, int64_t out[5]);
 /* Device memory kept aside for the next handle (released blocks of >= 16 MB, at most GTG_ALLOC_CACHE_MB per device: default 2048,
  * 0 = nothing is kept; the default was 8192 in round 3 and 0 in round 4): give every kept block back to the driver.  Returns the bytes
  * released.  (A failed allocation does this by itself before it gives up.) */

@@ -25,7 +25,7 @@ import numpy as np
 from gtsam_amd.problem import (FAC_BETWEEN_POSE3, FAC_GENERAL_SFM, FAC_PRIOR, FAC_PROJECTION,
                                NOISE_DIAGONAL, NOISE_GAUSSIAN, NOISE_ISOTROPIC, NOISE_UNIT,
                                ROBUST_CAUCHY, ROBUST_FAIR, ROBUST_GEMANMCCLURE, ROBUST_HUBER, ROBUST_NONE,
-                               ROBUST_TUKEY, ROBUST_WELSCH,
+                               ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_DCS, ROBUST_L2WITHDEADZONE,
                                STORAGE, TANGENT, VAR_POINT3, VAR_POSE2, VAR_POSE3, VAR_SFM_CAMERA, Problem)
 
 EPS = np.finfo(np.float64).eps
@@ -342,6 +342,10 @@ def robust_weight(rkind, k, d):
         return np.exp(-(d * d) / (k * k))
     if rkind == ROBUST_GEMANMCCLURE:
         return (k ** 4) / (k * k + d * d) ** 2
+    if rkind == ROBUST_DCS:                                  # :355-364 (the parameter is compared with the SQUARED distance)
+        return np.where(d * d > k, (2.0 * k / (k + d * d)) ** 2, 1.0)
+    if rkind == ROBUST_L2WITHDEADZONE:                       # :402-409 (distance >= 0 on this path)
+        return np.where(a <= k, 0.0, (a - k) / np.where(a > 0, a, 1.0))
     return np.ones_like(d)
 
 
@@ -360,6 +364,11 @@ def robust_loss(rkind, k, d):
         return k * k * 0.5 * -np.expm1(-(d * d) / (k * k))
     if rkind == ROBUST_GEMANMCCLURE:
         return 0.5 * (k * k * d * d) / (k * k + d * d)
+    if rkind == ROBUST_DCS:                                  # :366-375
+        e2 = d * d
+        return (k * k * e2 + k * e2 * e2) / ((e2 + k) * (e2 + k))
+    if rkind == ROBUST_L2WITHDEADZONE:                       # :411-414
+        return np.where(a < k, 0.0, 0.5 * (k - a) ** 2)
     return 0.5 * d * d
 
 
@@ -402,12 +411,21 @@ def _loss_many(p, noise_idx, b):
 def linearize(p: Problem, values):
     """As _linearize_whitened, followed by the m-estimator re-weighting of Robust noise models for the factors that
     linearize through NoiseModelFactor::linearize -> WhitenSystem (NonlinearFactor.cpp:150-182).  GeneralSFMFactor is
-    NOT re-weighted: its own linearize whitens H1, H2, b one by one through Robust::Whiten(Matrix), whose internal
-    WhitenSystem sees an empty b and hence weight 1 (GeneralSFMFactor.h:162-168, NoiseModel.h:705-709; measured on
-    the live reference)."""
+    NOT re-weighted by its residual: its own linearize whitens H1, H2, b one by one through Robust::Whiten(Matrix), whose internal
+    WhitenSystem sees an empty b and hence weight(0) -- 1 for every estimator but L2WithDeadZone (GeneralSFMFactor.h:162-168,
+    NoiseModel.h:705-709; measured on the live reference)."""
     lin = _linearize_whitened(p, values)
     if getattr(p, "noise_robust", None) is None or not np.any(p.noise_robust):
         return lin
+    if FAC_GENERAL_SFM in lin:          # weight(0): 1 for every estimator but L2WithDeadZone (0: the factor leaves the linear system)
+        A1, A2, b = lin[FAC_GENERAL_SFM][:3]
+        for ni in np.unique(p.sfm_noise):
+            rk, k = _robust_of(p, int(ni))
+            if rk != ROBUST_NONE:
+                w = float(np.sqrt(robust_weight(rk, k, 0.0)))
+                if w != 1.0:
+                    sel = p.sfm_noise == ni
+                    A1[sel] *= w; A2[sel] *= w; b[sel] *= w
     if FAC_PROJECTION in lin:
         _reweight_many(p, p.proj_noise, *lin[FAC_PROJECTION])
     if FAC_BETWEEN_POSE3 in lin:

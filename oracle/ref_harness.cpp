@@ -165,6 +165,8 @@ SharedNoiseModel makeNoise(const gtg_problem* p, int idx) {
     case GTG_ROBUST_CAUCHY: est = noiseModel::mEstimator::Cauchy::Create(c); break;
     case GTG_ROBUST_TUKEY: est = noiseModel::mEstimator::Tukey::Create(c); break;
     case GTG_ROBUST_WELSCH: est = noiseModel::mEstimator::Welsch::Create(c); break;
+    case GTG_ROBUST_DCS: est = noiseModel::mEstimator::DCS::Create(c); break;
+    case GTG_ROBUST_L2WITHDEADZONE: est = noiseModel::mEstimator::L2WithDeadZone::Create(c); break;
     default: est = noiseModel::mEstimator::GemanMcClure::Create(c); break;
   }
   return noiseModel::Robust::Create(est, base);

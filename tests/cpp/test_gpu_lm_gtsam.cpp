@@ -365,6 +365,23 @@ int main() {
     robust.emplace_shared<BetweenFactor<Pose3>>(X(2), X(30), Pose3(Rot3::RzRyRx(0.5, -0.4, 1.0), Point3(4, -3, 2)), rloop);   // gross outliers
     robust.emplace_shared<BetweenFactor<Pose3>>(X(7), X(21), Pose3(Rot3::RzRyRx(-1.0, 0.2, 0.3), Point3(-5, 1, 1)), rloop);
     compare("Pose3 graph robust (Huber + Cauchy)", robust, initial, LevenbergMarquardtParams(), 1e-6);
+    // round 6: DCS, L2WithDeadZone and the asymmetric estimators (which a Robust noise model only ever hands a norm: Tukey / Cauchy on this path)
+    NonlinearFactorGraph robust2;
+    auto dodo = noiseModel::Robust::Create(noiseModel::mEstimator::DCS::Create(1.0), odo);
+    auto aloop = noiseModel::Robust::Create(noiseModel::mEstimator::AsymmetricCauchy::Create(2.0), loop);
+    auto tloop = noiseModel::Robust::Create(noiseModel::mEstimator::AsymmetricTukey::Create(4.6851), loop);
+    auto zloop = noiseModel::Robust::Create(noiseModel::mEstimator::L2WithDeadZone::Create(0.5), loop);
+    int nloop = 0;
+    for (const auto& f : graph) {
+      auto b = std::dynamic_pointer_cast<BetweenFactor<Pose3>>(f);
+      if (!b) { robust2.push_back(f); continue; }
+      const bool isLoop = b->noiseModel().get() == loop.get();
+      SharedNoiseModel nm = dodo;
+      if (isLoop) { nm = (nloop % 3 == 0) ? SharedNoiseModel(aloop) : (nloop % 3 == 1) ? SharedNoiseModel(tloop) : SharedNoiseModel(zloop); nloop++; }
+      robust2.emplace_shared<BetweenFactor<Pose3>>(b->key1(), b->key2(), b->measured(), nm);
+    }
+    robust2.emplace_shared<BetweenFactor<Pose3>>(X(2), X(30), Pose3(Rot3::RzRyRx(0.5, -0.4, 1.0), Point3(4, -3, 2)), aloop);
+    compare("Pose3 graph robust (DCS + asymmetric + dead zone)", robust2, initial, LevenbergMarquardtParams(), 1e-6);
   }
   {  // ---- Pose2 pose graph, as examples/Pose2SLAMExample_g2o.cpp (with LM) on a Manhattan-like loop ----------------------
     NonlinearFactorGraph graph; Values initial;
@@ -524,10 +541,17 @@ int main() {
   {  // ---- unsupported content is a hard error, not a silent fallback -------------------------------------------------
     NonlinearFactorGraph graph; Values initial;
     initial.insert(X(0), Pose3()); initial.insert(X(1), Pose3());
-    graph.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Robust::Create(noiseModel::mEstimator::DCS::Create(1.0), noiseModel::Unit::Create(6)));
+    graph.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Robust::Create(noiseModel::mEstimator::Custom::Create([](double) { return 1.0; }, [](double d) { return 0.5 * d * d; }, noiseModel::mEstimator::Base::Block, "user"), noiseModel::Unit::Create(6)));
     bool threw = false;
     try { gtsam_amd::GpuLevenbergMarquardtOptimizer bad(graph, initial); } catch (const std::invalid_argument&) { threw = true; }
-    EXPECT(threw, "m-estimators outside the supported six must be rejected");
+    EXPECT(threw, "a Custom m-estimator (host functions) must be rejected");
+    {
+      NonlinearFactorGraph gs;
+      gs.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Robust::Create(noiseModel::mEstimator::Huber::Create(1.0, noiseModel::mEstimator::Base::Scalar), noiseModel::Unit::Create(6)));
+      threw = false;
+      try { gtsam_amd::GpuLevenbergMarquardtOptimizer bad(gs, initial); } catch (const std::invalid_argument&) { threw = true; }
+      EXPECT(threw, "the Scalar re-weighting scheme must be rejected");
+    }
     NonlinearFactorGraph g2;
     g2.emplace_shared<BetweenFactor<Pose3>>(X(0), X(1), Pose3(), noiseModel::Constrained::All(6));
     threw = false;

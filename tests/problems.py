@@ -3,7 +3,8 @@ import numpy as np
 
 from gtsam_amd import datasets as D
 from gtsam_amd.problem import (NOISE_DIAGONAL, NOISE_ISOTROPIC, NOISE_UNIT, ROBUST_CAUCHY, ROBUST_FAIR, ROBUST_HUBER,
-                               ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE, bal_problem, pose_graph_problem)
+                               ROBUST_TUKEY, ROBUST_WELSCH, ROBUST_GEMANMCCLURE, ROBUST_DCS, ROBUST_L2WITHDEADZONE, bal_problem,
+                               pose_graph_problem)
 
 
 def dubrovnik_timesfm(g):
@@ -58,6 +59,9 @@ SYNTH = {
     "projection_cauchy": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_CAUCHY, 3.0),
     "projection_tukey": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_TUKEY, 4.6851),
     "projection_gm": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_GEMANMCCLURE, 5.0),
+    # (round 6) DCS -- its parameter is compared with the SQUARED distance -- and the dead zone, inside which a factor drops out of the system
+    "posegraph_dcs": lambda: robustify(D.random_pose_graph(14, 6, seed=3), ROBUST_DCS, 1.0),
+    "projection_deadzone": lambda: robustify(D.random_projection_graph(seed=2), ROBUST_L2WITHDEADZONE, 0.75),
     "dubrovnik_huber": lambda: _dubrovnik_robust(ROBUST_HUBER, 1.345),
     "dubrovnik_cauchy": lambda: _dubrovnik_robust(ROBUST_CAUCHY, 5.0),
 }
@@ -117,10 +121,11 @@ SMART = {"smart_orbit": lambda: smart_orbit(False), "smart_orbit_degenerate": la
          "smart_far_jacobian_svd": lambda: smart_far(2, linearization_mode=3, init_noise=(0.002, 0.01), spread=1.8)}
 
 ROBUST_SYNTH = ("posegraph_huber", "posegraph_fair", "posegraph_welsch", "projection_cauchy", "projection_tukey",
-                "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy")
+                "projection_gm", "dubrovnik_huber", "dubrovnik_cauchy", "posegraph_dcs", "projection_deadzone")
 SYNTH_ORDERING = {"posegraph_small": 0, "posegraph_bigrot": 0, "projection_small": 1, "projection_ds2": 1, "bal_small_unit": 1, "bal_small_iso": 1,
                   "posegraph_huber": 0, "posegraph_fair": 0, "posegraph_welsch": 0, "projection_cauchy": 1,
-                  "projection_tukey": 1, "projection_gm": 1, "dubrovnik_huber": 1, "dubrovnik_cauchy": 1}
+                  "projection_tukey": 1, "projection_gm": 1, "dubrovnik_huber": 1, "dubrovnik_cauchy": 1, "posegraph_dcs": 0,
+                  "projection_deadzone": 1}
 
 
 def robust_prior_literal():

@@ -100,7 +100,7 @@ LM_CASES = [
     ("dubrovnik_sfmex", "legacy", "sfmex_"),
     ("posegraph_small", "legacy", ""), ("posegraph_bigrot", "legacy", ""),
     ("bal_small_unit", "ceres", ""), ("bal_small_iso", "ceres", ""),
-] + [(n, "legacy", "") for n in PB.ROBUST_SYNTH]      # noiseModel::Robust, all six m-estimators
+] + [(n, "legacy", "") for n in PB.ROBUST_SYNTH]      # noiseModel::Robust, all eight m-estimators of the path
 
 
 @pytest.mark.parametrize("name,preset,prefix", LM_CASES, ids=[c[0] for c in LM_CASES])

@@ -44,7 +44,7 @@ def main():
             opt = DeviceLevenbergMarquardt(p, v0, prm)
             opt.optimize()
             ctl = opt.dev.df_ctrl()
-            out[i] = (np.array(opt.trace)[:, :3], opt.values_packed(), int(ctl[15]), int(ctl[6]), int(ctl[7]))
+            out[i] = (np.array(opt.trace)[:, :3], opt.values_packed(), int(ctl[15]), int(ctl[6]), int(ctl[7]), opt.dev.df_poll_stats())
             opt.dev.close()
         except Exception as e:  # noqa: BLE001
             out[i] = str(e)
@@ -52,6 +52,7 @@ def main():
     ref = [None]; run(ref, 0)
     assert not isinstance(ref[0], str), ref[0]
     n = diff = err = fb = rnd = shadow = rmw = 0
+    poll = np.zeros(5, np.int64)   # long waits, ended on the RMW poll, of those still stale for sc1, ended on the shadow word, of those still stale
     t0 = time.time()
     while time.time() - t0 < seconds:
         res = [None] * nthreads
@@ -62,7 +63,7 @@ def main():
             n += 1
             if isinstance(r, str):
                 err += 1; print(json.dumps({"round": rnd, "error": r[:200]}), flush=True); continue
-            fb += r[2]; shadow += r[3]; rmw += r[4]
+            fb += r[2]; shadow += r[3]; rmw += r[4]; poll += np.array(r[5], np.int64)
             if r[0].shape != ref[0][0].shape or not np.array_equal(r[0], ref[0][0]) or not np.array_equal(r[1], ref[0][1]):
                 diff += 1
                 msg = f"shape {r[0].shape} vs {ref[0][0].shape}"
@@ -74,6 +75,7 @@ def main():
         rnd += 1
     print(json.dumps({"problem": problem, "lib": os.path.basename(L.LIB_PATH), "threads": nthreads, "seconds": round(time.time() - t0, 1),
                       "optimisations": n, "different": diff, "errors": err, "fallbacks": fb, "waits_ended_on_shadow_words": shadow, "waits_ended_on_rmw_poll": rmw,
+                      "waits_of_256_polls_or_more": int(poll[0]), "rmw_ended_and_next_sc1_load_still_old": int(poll[2]), "shadow_ended_and_next_sc1_load_still_old": int(poll[4]),
                       "factorisations_per_optimisation": int(ref[0][0].shape[0])}), flush=True)
     return 0 if diff == 0 and err == 0 else 1
 

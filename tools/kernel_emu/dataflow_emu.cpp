@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   long long* tile_flag = shared_alloc<long long>((size_t)n_slots + sh + 8);
   long long* part_flag = shared_alloc<long long>((size_t)n_slots + sh + 8);
   long long* pd_flag = shared_alloc<long long>((size_t)nt + sh + 8);
-  int32_t* ctrl = shared_alloc<int32_t>(16);
+  int32_t* ctrl = shared_alloc<int32_t>(32);
   double* fail = shared_alloc<double>(2);
   auto rd = [&](void* p, size_t bytes) { if (bytes && std::fread(p, 1, bytes, f) != bytes) { std::fprintf(stderr, "short input\n"); std::exit(2); } };
   rd(S, sizeof(double) * (size_t)n_slots * kTileDoubles); rd(tasks, 4 * (size_t)12 * n_tasks); rd(klist, 4 * (size_t)2 * n_kp);
@@ -59,13 +59,13 @@ int main(int argc, char** argv) {
       if (w < n_chain) {
         static char smem[gt::kSmemChain + 64];
         emu::run_workgroup(512, (unsigned)w, [&] {
-          gt::chain_loop(smem, S, Xinv, pd_flag, tile_flag, chain_slots, fail, epoch, sh, ctrl, nullptr, chain_tiles + chain_off[w],
+          gt::chain_loop(smem, S, Xinv, pd_flag, tile_flag, chain_slots, fail, epoch, ctrl, nullptr, chain_tiles + chain_off[w],
                          chain_off[w + 1] - chain_off[w], nullptr, nullptr);
         });
       } else {
         static char smem[gt::kSmemBulk + 64];
         emu::run_workgroup(gt::kBulkThreads, (unsigned)(w - n_chain), [&] {
-          gt::bulk_loop(smem, S, tasks, n_tasks, klist, tile_flag, part_flag, pd_flag, Xinv, ctrl, fail, epoch, sh, nullptr);
+          gt::bulk_loop(smem, S, tasks, n_tasks, klist, tile_flag, part_flag, pd_flag, Xinv, ctrl, fail, epoch, nullptr);
         });
       }
       _exit(0);

@@ -1115,5 +1115,6 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
 }
 
 int64_t gtg_release_cached_memory(void) { return (int64_t)release_kept(-1); }
+int64_t gtg_cached_memory_bytes(void) { std::lock_guard<std::mutex> lk(g_kept_mu); size_t b = 0; for (const auto& k : g_kept) b += k.bytes; return (int64_t)b; }
 
 }  // extern "C"

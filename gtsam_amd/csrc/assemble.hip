@@ -13,6 +13,8 @@
 // floating-point atomics, results are bit-reproducible run to run.
 #include "factors.h"
 #include "fused.h"
+#include <string>
+
 #include "kernels.h"
 #include "recio.h"
 
@@ -499,44 +501,61 @@ __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int
 
 // One wavefront per block pair (a,b) of the reduced system: S_ab -= sum_t E_a(t) E_b(t)^T over the landmarks seen
 // by both, on the FP64 matrix core: one v_mfma_f64_16x16x4 per term, the contraction index being the 3 landmark
-// coordinates (k = 3 is a zero lane group; rows/columns >= d masked to zero).  Lane (row lr, k lk) reads entry
-// 3 lr + lk of the 9x3 block, so the 64 lanes of a load cover exactly ONE 216-byte E slot (two 128-byte lines): the
-// kernel is bound by vector-memory instruction issue, and this is the cheapest form of it (an earlier version with
-// lanes gathering from up to 8 slots per load was 1.4x slower; one with lanes owning output entries 2x).  The term's
-// slot indices are wave-uniform scalar loads.  Fixed summation order: deterministic.
+// coordinates (k = 3 is a zero lane group; rows/columns >= d masked to zero); lane (row lr, k lk) supplies entry 3 lr + lk
+// of the 9x3 block.  The term's slot indices are wave-uniform scalar loads.  Fixed summation order: deterministic.
+// The kernel is bound by the memory system's rate for scattered 256-byte granules (12 M slot fetches on the L1723 shape,
+// 89 M on Venice; rounds 2 - 5 measured six re-orderings of the same fetches without a gain).  Round 6: one load instruction
+// fetches the four E slots of TWO terms with 16-byte lanes (lanes 0-15: a(t), 16-31: b(t), 32-47: a(t+1), 48-63: b(t+1);
+// 16 lanes x 16 B = one 256-byte slot), the wavefront's 1 KB goes through its private LDS patch (LDS operations of one
+// wavefront complete in program order: no barrier) and every lane picks its MFMA operands out of it.  Per two terms:
+// 1 global_load_dwordx4 + 1 ds_write_b128 + 4 ds_read_b64 + 2 MFMA, against 4 global_load_dwordx2 + 2 MFMA with rounds
+// 1 - 5's 8-byte lanes (one load = one slot): the same terms in the same order, S bit for bit, a quarter of the
+// vector-memory instructions -- 0.829 -> 0.786 ms on L1723, 4.41 -> 4.04 ms on Venice (profiles/r06h_schur_wide_ab.txt).
 typedef double v4f64s __attribute__((ext_vector_type(4)));
+constexpr int kWidePairs = 4;       // load instructions in flight per wavefront (8 terms)
 __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
     const double* __restrict__ E, SMat S) {
+  __shared__ double patch[4][kWidePairs][4 * kEStride];      // [wavefront][load in flight][4 slots]
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = blockIdx.x * (int64_t)4 + wv;
   if (p >= n_pairs) return;
   const int ra = prow[p], rb = pcol[p];
   const int da = red_dim[ra], db = red_dim[rb];
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int grp = lane >> 4, piece = lane & 15;      // as a loader: slot `grp` of the four, its doubles 2 piece, 2 piece + 1
   const int64_t k0 = pptr[p], k1 = pptr[p + 1];
   const bool ina = lr < da && lk < 3, inb = lr < db && lk < 3;
-  // branch-free operand fetch: masked lanes read entry 0 of the slot (same lines) and select zero afterwards
   const int ea = ina ? 3 * lr + lk : 0, eb = inb ? 3 * lr + lk : 0;
   v4f64s acc = {0.0, 0.0, 0.0, 0.0};
+  double (*my)[4 * kEStride] = patch[wv];
   int64_t t = k0;
-  for (; t + 4 <= k1; t += 4) {   // 4 terms in flight: 8 scalar index loads, 8 coalesced vector loads, 4 MFMAs
-    int ia[4], ib[4];
-    double av[4], bv[4];
+  for (; t + 2 * kWidePairs <= k1; t += 2 * kWidePairs) {
+    double2 v[kWidePairs];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { ia[u] = oa[t + u]; ib[u] = ob[t + u]; }
+    for (int u = 0; u < kWidePairs; u++) {
+      const int ia0 = oa[t + 2 * u], ib0 = ob[t + 2 * u], ia1 = oa[t + 2 * u + 1], ib1 = ob[t + 2 * u + 1];   // wave-uniform (scalar loads)
+      const int slot = grp == 0 ? ia0 : grp == 1 ? ib0 : grp == 2 ? ia1 : ib1;
+      v[u] = *reinterpret_cast<const double2*>(E + kEStride * (int64_t)slot + 2 * piece);
+    }
 #pragma unroll
-    for (int u = 0; u < 4; u++) { av[u] = E[kEStride * (int64_t)ia[u] + ea]; bv[u] = E[kEStride * (int64_t)ib[u] + eb]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? av[u] : 0.0, inb ? bv[u] : 0.0, acc, 0, 0, 0);
+    for (int u = 0; u < kWidePairs; u++) {
+      *reinterpret_cast<double2*>(&my[u][2 * lane]) = v[u];
+      const double a0 = my[u][ea], b0 = my[u][kEStride + eb], a1 = my[u][2 * kEStride + ea], b1 = my[u][3 * kEStride + eb];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a0 : 0.0, inb ? b0 : 0.0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a1 : 0.0, inb ? b1 : 0.0, acc, 0, 0, 0);
+    }
   }
-  for (; t < k1; t++) {
-    const double av = E[kEStride * (int64_t)oa[t] + ea], bv = E[kEStride * (int64_t)ob[t] + eb];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? av : 0.0, inb ? bv : 0.0, acc, 0, 0, 0);
+  for (; t < k1; t += 2) {      // the tail: two terms, or one (its slots are fetched twice: the second copy is not used)
+    const bool two = t + 1 < k1;
+    const int ia0 = oa[t], ib0 = ob[t], ia1 = two ? oa[t + 1] : ia0, ib1 = two ? ob[t + 1] : ib0;
+    const int slot = grp == 0 ? ia0 : grp == 1 ? ib0 : grp == 2 ? ia1 : ib1;
+    *reinterpret_cast<double2*>(&my[0][2 * lane]) = *reinterpret_cast<const double2*>(E + kEStride * (int64_t)slot + 2 * piece);
+    const double a0 = my[0][ea], b0 = my[0][kEStride + eb], a1 = my[0][2 * kEStride + ea], b1 = my[0][3 * kEStride + eb];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a0 : 0.0, inb ? b0 : 0.0, acc, 0, 0, 0);
+    if (two) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a1 : 0.0, inb ? b1 : 0.0, acc, 0, 0, 0);
   }
-  // accumulator register r holds C[row = lk + 4 r][col = lr]
   const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
 #pragma unroll
   for (int r = 0; r < 4; r++) {

@@ -799,6 +799,12 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     ks = rowcols[J];
     emit(nt, J, ks);   // rhs row: y_J (flops not counted, as in the right-looking plan)
   }
+  // (Round 6, measured and removed -- profiles/r06i_level_sweep.txt, tools/df_plan_load.py: early pieces are queued As Soon As Possible, and
+  // on a banded system they arrive in bursts: the work of a ticket-order iteration swings between 0.4 and 1.9 times what 246 workgroups get
+  // done in a chain period, 39 of 122 iterations of the L1723 shape are over.  A forward sweep that moved the pieces with the latest
+  // deadlines out of overfull iterations (same pieces, same order inside a tile: bit-identical) levelled that profile completely -- and the
+  // factorisation went from 5.00 to 5.97 ms (capacity = 100 % of a period's work; 9.2 ms at 90 %, no change at 120 - 150 %).  The aggregate
+  // is not what binds: a tile's pieces are a serial chain of ~70 us links, and every deferral shortens the time that chain has.)
   // ticket order: the own tasks of the column in place q (diagonal accumulation, the tile below it, ...), then the early pieces whose
   // youngest operand is in place q - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
   // pieces that merely have to be done some columns later (with the early pieces of group q - 1 in front of them, the diagonal

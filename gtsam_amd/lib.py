@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_prewarm", "gtg_last_error", "gtg_ve
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_values_device_ptr", "gtg_values_changed",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_cached_memory_bytes", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal",
            "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o",
            "gtg_debug_scan", "gtg_debug_sort_pairs", "gtg_debug_runs"]
@@ -96,6 +96,7 @@ def load():
     lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
     lib.gtg_debug_df_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.gtg_debug_df_poll_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gtg_cached_memory_bytes.restype = C.c_int64
     lib.gtg_io_last_error.restype = C.c_char_p
     lib.gtg_io_bal_sizes.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.gtg_io_read_bal.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5

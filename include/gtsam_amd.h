@@ -306,6 +306,9 @@ int gtg_debug_df_poll_stats(gtg_handle h, int64_t out[5]);
  * 0 = nothing is kept; the default was 8192 in round 3 and 0 in round 4): give every kept block back to the driver.  Returns the bytes
  * released.  (A failed allocation does this by itself before it gives up.) */
 int64_t gtg_release_cached_memory(void);
+/* bytes of released device blocks the library currently keeps for the next handle of the process (all devices; GTG_ALLOC_CACHE_MB caps it per device,
+ * default 2048, 0 = keep nothing) */
+int64_t gtg_cached_memory_bytes(void);
 /* GTG_DF_TRACE=1 (read at upload): 100 MHz time stamps of the last factorisation, n = 8 n_tasks + 2 nt: per task {taken,
  * contraction done, done, xcc << 32 | HW_ID, panel 0..3 of the diagonal tile seen}, then per diagonal tile {accumulated tile in, factored} (tools/df_trace.py) */
 int gtg_debug_df_trace(gtg_handle h, int64_t* out, int64_t n);

@@ -324,9 +324,21 @@ def main():
         run_iterations(o, steps, values_, params_)
         barrier()
         el = max_over_ranks(time.perf_counter() - tt)
+        ph = o.dev.phase_ms()
         rec = {"value": steps / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
-               "lambda_tries": int(o.getInnerIterations() - i0), "error_after": o.error(),
-               "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in o.dev.phase_ms().items()}}
+               "lambda_tries": int(o.getInnerIterations() - i0), "lambda_tries_per_s": (o.getInnerIterations() - i0) / el, "error_after": o.error(),
+               "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ph.items()}}
+        # the same roofline keys as the headline: the replicated factorisation of the direct solver (every rank factorises the summed system);
+        # the iterative solver has no factorisation -- its time is the `solve` phase (HBM-bound products over the E slots)
+        cms, ccalls = ph["cholesky"]
+        if ccalls and cms > 0:
+            fb, ft = o.dev.cholesky_flops_block_level(), o.dev.cholesky_flops()
+            rec["roofline"] = {"bound": "mfma", "achieved": fb * ccalls / (cms * 1e-3) / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fb * ccalls / (cms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "traffic": None, "flops_per_launch": fb,
+                               "flops_stored_tiles": ft, "ms_per_launch": cms / ccalls, "frac_stored_tiles": ft * ccalls / (cms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS}
+        else:
+            rec["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                               "note": "no factorisation in this mode: see phase_ms_per_call.solve (PCG products, two passes over the E slots each)"}
         if mode == "speculative":
             rec["tries_computed_by_rank0"] = int(o.speculated); rec["tries_discarded_on_rank0"] = int(o.discarded)
         o.dev.close()

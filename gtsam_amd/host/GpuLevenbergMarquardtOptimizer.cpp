@@ -605,7 +605,7 @@ void GpuLevenbergMarquardtOptimizer::syncValuesToHost(bool force) {
       }
     };
     const char* thr_env = std::getenv("GTG_HOST_THREADS");
-    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(std::max(1u, std::thread::hardware_concurrency()), 8u)), nv / 8192 + 1}));
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(std::max(1u, std::thread::hardware_concurrency()), 32u)), nv / 8192 + 1}));   // (8 until round 6: the 1.8 M payloads of the Venice shape took 12 % of its optimize())
     std::vector<std::thread> pool;
     for (size_t ti = 1; ti < nthreads; ti++) pool.emplace_back(work, nv * ti / nthreads, nv * (ti + 1) / nthreads);
     work(0, nv / nthreads);

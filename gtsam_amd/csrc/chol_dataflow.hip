@@ -691,7 +691,10 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     if (tree) {
       // (round 4: 8 slots = 16 reserved CUs by default -- with the accumulator lanes of the separators' diagonal tiles in place the leaf
       // chains are the critical path of a pose graph, and they run side by side; up to 16 slots = 32 reserved CUs on request)
-      constexpr int max_slots = 8;   // (4 and 16 measured in round 4: no better)
+      // (16 slots = 32 reserved CUs since round 6: one slot per leaf of a 4-level dissection with room to spare; measured against 8 / 12
+      // slots, profiles/r06j_slots_sweep.txt: sphere2500 0.913 / 0.892 / 0.892 ms, w20000 2.71 / 2.78 / 2.58 ms -- the pose graphs' bulk
+      // work is a few GFLOP, the CUs cost nothing; what bounds them is the serial top of the tree, profiles/r06k_trace_sphere2500.json)
+      constexpr int max_slots = 16;
       std::vector<int> first_child(nparts, -1);
       for (int x = nparts - 1; x >= 0; x--) if ((*part_parent)[x] >= 0) first_child[(*part_parent)[x]] = x;
       int leaves = 0;

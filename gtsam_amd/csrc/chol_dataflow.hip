@@ -950,6 +950,17 @@ static DfStreams& df_streams(int device, int reserve) {
   std::lock_guard<std::mutex> lock(per_device_mutex);            // (held over the creation: gtg_prewarm's thread and a first factorisation may meet here)
   DfStreams& ds = per_device[{device, reserve}];
   if (!ds.bulk) {
+    // ONE pair of masked streams per device: an idle second pair (another number of reserved CUs: a pose graph behind a camera system, or
+    // the pair gtg_prewarm made) costs the running one 10 % -- sphere2500 0.89 -> 0.99 ms per factorisation with the prewarmed 8-CU pair
+    // beside its own 32-CU pair (round 6, tools/r06_sphere_ab.sh: the runtime multiplexes streams onto a few hardware queues).  The caller
+    // holds the device's factorisation lock (api.hip), so the other pairs are idle: they go.
+    for (auto it = per_device.begin(); it != per_device.end();) {
+      if (it->first.first == device && it->first.second != reserve && it->second.bulk) {
+        (void)hipStreamDestroy(it->second.bulk); (void)hipStreamDestroy(it->second.chain);
+        (void)hipEventDestroy(it->second.ev_start); (void)hipEventDestroy(it->second.ev_chain); (void)hipEventDestroy(it->second.ev_bulk);
+        it = per_device.erase(it);
+      } else ++it;
+    }
     // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
     // of LDS, the whole register file of its SIMDs) can only be placed on exactly those -- so it is placed at once, whatever
     // the order in which the two kernels reach the dispatcher.  (With an unmasked chain stream the dispatcher may pick a

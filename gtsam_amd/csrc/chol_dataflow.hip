@@ -950,17 +950,6 @@ static DfStreams& df_streams(int device, int reserve) {
   std::lock_guard<std::mutex> lock(per_device_mutex);            // (held over the creation: gtg_prewarm's thread and a first factorisation may meet here)
   DfStreams& ds = per_device[{device, reserve}];
   if (!ds.bulk) {
-    // ONE pair of masked streams per device: an idle second pair (another number of reserved CUs: a pose graph behind a camera system, or
-    // the pair gtg_prewarm made) costs the running one 10 % -- sphere2500 0.89 -> 0.99 ms per factorisation with the prewarmed 8-CU pair
-    // beside its own 32-CU pair (round 6, tools/r06_sphere_ab.sh: the runtime multiplexes streams onto a few hardware queues).  The caller
-    // holds the device's factorisation lock (api.hip), so the other pairs are idle: they go.
-    for (auto it = per_device.begin(); it != per_device.end();) {
-      if (it->first.first == device && it->first.second != reserve && it->second.bulk) {
-        (void)hipStreamDestroy(it->second.bulk); (void)hipStreamDestroy(it->second.chain);
-        (void)hipEventDestroy(it->second.ev_start); (void)hipEventDestroy(it->second.ev_chain); (void)hipEventDestroy(it->second.ev_bulk);
-        it = per_device.erase(it);
-      } else ++it;
-    }
     // Two CU-masked streams with complementary masks: the bulk kernel's workgroups stay off a few CUs, and k_df_chain (97 KB
     // of LDS, the whole register file of its SIMDs) can only be placed on exactly those -- so it is placed at once, whatever
     // the order in which the two kernels reach the dispatcher.  (With an unmasked chain stream the dispatcher may pick a
@@ -1046,10 +1035,13 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   check_hip(hipGetLastError(), "cholesky (dataflow)");
 }
 
-// gtg_prewarm: this unit's kernels, their dynamic-LDS attributes and the default pair of masked streams (kernels.h)
-static void prewarm_chol_dataflow(int device) {
+// gtg_prewarm: this unit's kernels (kernels.h).  NOT the masked streams: which pair a graph needs (8, 16 or 32 reserved CUs) is only known
+// after its analysis, and an idle second pair costs the running one 10 % -- sphere2500 0.89 -> 0.99 ms per factorisation with a prewarmed
+// 8-CU pair beside its own 32-CU pair (round 6; the runtime multiplexes streams onto a few hardware queues).  Destroying the pair that is
+// not needed any more was tried and is not an option either: in the full GPU suite (three builds of the library in one process) it ended
+// in a memory access fault of the device.  A process that factorises camera systems AND pose graphs keeps both pairs and pays that 10 %.
+static void prewarm_chol_dataflow(int) {
   prewarm_kernels({(const void*)k_df_bulk, (const void*)k_df_chain, (const void*)k_df_single, (const void*)k_df_begin});
-  (void)df_streams(device, 8);
 }
 static PrewarmUnit prewarm_chol_dataflow_registered(prewarm_chol_dataflow);
 

@@ -676,6 +676,7 @@ void analyze(gtg_context& c) {
   for (int r = 0; r < c.n_red_vars; r++) dim_at_pos[c.h_red_pos[r]] = c.h_red_dim[r];
   gtg_context* cp = &c;
   c.block_level_err = nullptr;
+  c.chol_flops_block = 0.0;      // (never the previous analysis's number while the new count runs)
   c.block_level_thread = std::thread([cp, bl_a = std::move(bl_a), bl_b = std::move(bl_b), dim_at = std::move(dim_at_pos)] { try {
     const int n = (int)dim_at.size();
     std::vector<std::vector<int32_t>> below(n);          // positions > own position
@@ -887,9 +888,11 @@ void analyze(gtg_context& c) {
                 (double)c.n_red_vars * 90 * 8 + (double)c.n_lm * 12 * 8 + (double)c.n_hoff * 36 * 8;
 }
 
+// (the count is a diagnostic: a failure of its thread -- bad_alloc -- must not fail the NEXT, unrelated upload or ordering call that joins
+// it; the stored exception is dropped and the count reads 0)
 void join_block_level(gtg_context& c) {
   if (c.block_level_thread.joinable()) c.block_level_thread.join();
-  if (c.block_level_err) { std::exception_ptr e = c.block_level_err; c.block_level_err = nullptr; std::rethrow_exception(e); }
+  if (c.block_level_err) { c.block_level_err = nullptr; c.chol_flops_block = 0.0; }
 }
 
 }  // namespace gt

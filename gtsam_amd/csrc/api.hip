@@ -873,13 +873,13 @@ int gtg_get_jacobians(gtg_handle c, int type, double* out, int64_t n) {
   }
   if (n != cnt) throw std::invalid_argument("gtg_get_jacobians: wrong output size");
   DevBuf<double> recomputed;
+  struct Release { DevBuf<double>& b; ~Release() { b.free(); } } release{recomputed};   // (declared before the allocation: a throwing launch / sync frees it too)
   if (type == GTG_FAC_GENERAL_SFM && c->fused_sfm && cnt) {   // debug path: these records are not stored (fused.h) -- recomputed at the current values
     recomputed.alloc((size_t)cnt);
     launch_sfm_records(*c, recomputed.p);
     check_hip(hipStreamSynchronize(c->stream), "sync");
     src = recomputed.p;
   }
-  struct Release { DevBuf<double>& b; ~Release() { b.free(); } } release{recomputed};
   if (cnt) check_hip(hipMemcpy(out, src, sizeof(double) * cnt, hipMemcpyDeviceToHost), "D2H");
   return GTG_OK;
   GTG_CATCH

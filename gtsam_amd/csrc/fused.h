@@ -6,7 +6,9 @@
 // records on the L1723 shape).  Since round 5 the record of a GeneralSFM factor only ever exists in the LDS image of the wavefront
 // that needs it: a lane gathers its camera (17 doubles out of the L2-resident camera table), its point and its measurement -- 52 bytes
 // of HBM traffic per factor instead of 208 -- and evaluates factors.h::sfm_linearize in place.  The record is a pure function of
-// (values, measurement, noise row), so every kernel sees the same bits that k_lin_sfm would have stored.
+// (values, measurement, noise row); k_lin_sfm's output is compared bit for bit with the stored-record build (tests/test_gpu_fused_linearization.py),
+// and the step of the fused build with that build's.  (Between the six kernels that inline sfm_linearize the compiler is free to contract
+// FMAs differently: they agree to rounding, not necessarily to the bit -- nothing relies on more.)
 //
 // Not for graphs with smart factors: the records of their measurements depend on the triangulation status of the factor and are
 // overwritten by a second kernel for points at infinity (factors.hip) -- those graphs keep the stored records.

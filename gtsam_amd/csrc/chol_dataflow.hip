@@ -514,7 +514,8 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
                                            const int32_t* __restrict__ chain_slots, double* __restrict__ fail,
                                            const long long epoch, int32_t* __restrict__ ctrl,
                                            long long* __restrict__ trace, const int32_t* __restrict__ my_tiles, int n_mine,
-                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp) {
+                                           const unsigned char* __restrict__ pivot_kind, double* __restrict__ tile_exp,
+                                           long long* __restrict__ stamps = nullptr) {   // GTG_DF_TRACE: 64 stamps per diagonal tile (potrf_body's STAMPs + per-wavefront stage ends)
   double* A = reinterpret_cast<double*>(smem_raw);
   double* X = reinterpret_cast<double*>(smem_raw + (kSmemPotrf + 15) / 16 * 16);   // [4][SB][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
@@ -577,7 +578,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         }
       }
     }
-    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, nullptr, epoch, tile_flag + dslot, 0, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
+    potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, stamps ? stamps + 64 * (int64_t)J : nullptr, epoch, tile_flag + dslot, 0, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
                deferred ? X : nullptr);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
@@ -591,10 +592,10 @@ __global__ __launch_bounds__(512, 2) void k_df_chain(double* __restrict__ S, dou
                                                      const long long epoch, int32_t* __restrict__ ctrl,
                                                      long long* __restrict__ trace, const unsigned char* __restrict__ pivot_kind,
                                                      double* __restrict__ tile_exp, const int32_t* __restrict__ chain_off,
-                                                     const int32_t* __restrict__ chain_tiles) {
+                                                     const int32_t* __restrict__ chain_tiles, long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   chain_loop(smem_raw, S, Xinv_all, pd_flag, tile_flag, chain_slots, fail, epoch, ctrl, trace, chain_tiles + chain_off[blockIdx.x],
-             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp);
+             chain_off[blockIdx.x + 1] - chain_off[blockIdx.x], pivot_kind, tile_exp, stamps);
 }
 
 // Both roles in ONE kernel (GTG_DF_SINGLE=1): the first n_chain workgroups are the chain (dispatched first, so they are resident before
@@ -907,7 +908,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
   df.chain_tiles.upload(df.h_chain_tiles.data(), df.h_chain_tiles.size(), stream);
   df.shadow = (n_slots + df.n_scratch + 511) / 512 * 512;   // flag words by slot, the scratch slots of the accumulator lanes included (the name is from rounds 3 - 5, when every flag had a shadow word this far behind it)
   df.tile_flag.alloc((size_t)df.shadow); df.part_flag.alloc((size_t)df.shadow); df.pd_flag.alloc((size_t)df.shadow); df.ctrl.alloc(32);
-  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 2 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
+  if (getenv("GTG_DF_TRACE")) { df.trace.alloc(8 * (size_t)df.n_tasks + 66 * (size_t)nt); check_hip(hipMemsetAsync(df.trace.p, 0, sizeof(long long) * df.trace.n, stream), "memset"); }
   check_hip(hipMemsetAsync(df.tile_flag.p, 0, sizeof(long long) * df.tile_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.pd_flag.p, 0, sizeof(long long) * df.pd_flag.n, stream), "memset");
   check_hip(hipMemsetAsync(df.part_flag.p, 0, sizeof(long long) * df.part_flag.n, stream), "memset");
@@ -1012,7 +1013,8 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
   const bool drop_chain = drop_at > 0 && launch_no >= drop_at && launch_no < drop_at + drop_n;
   if (!drop_chain)
   hipLaunchKernelGGL(k_df_chain, dim3(df.n_chain), dim3(512), kSmemChain, ds.chain, S, Xinv, df.pd_flag.p, df.tile_flag.p, df.has_sub.p, fail, epoch, df.ctrl.p,
-                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p);
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks : nullptr, pivot_kind, tile_exp, df.chain_off.p, df.chain_tiles.p,
+                     df.trace.p ? df.trace.p + 8 * df.n_tasks + 2 * (int64_t)nt : nullptr);
   const int grid = (int)std::min<int64_t>(ds.grid, df.n_tasks);
   hipLaunchKernelGGL(k_df_bulk, dim3(grid), dim3(kBulkThreads), kSmemBulk, ds.bulk, S, df.tasks.p, (int)df.n_tasks, df.klist.p,
                      df.tile_flag.p, df.part_flag.p, df.pd_flag.p, Xinv, df.ctrl.p, fail, epoch, df.trace.p);

@@ -125,7 +125,7 @@ __device__ __forceinline__ double rcp_nr(double p) {
 // J, stores dinv[J] = r and bumps the progress counter.  All 32 lines stay in LDS.
 //
 // Every other 32-row block below (rows of L(ib,jb), i.e. the TRSM X L^T = A) and the rows of the identity (which
-// turn into L^-T, i.e. the inverse needed by k_trsm128 / k_bwd_diag) are FOLLOWERS (FollowStep): they replay the same
+// turn into L^-T, i.e. the inverse needed by k_trsm128 / k_bwd_diag) are FOLLOWERS (FollowGroup): they replay the same
 // elimination on their own rows from the published (line J, r_J), a few pivots behind wavefront 0, and are done a
 // few hundred cycles after it.  They never feed back into the chain, so the chain wavefront never waits.
 // The step index is a template parameter: every register index is static.  The chain wavefront's code is branch
@@ -246,31 +246,61 @@ __device__ __forceinline__ void stage_potrf(double* __restrict__ A, double* __re
   }
 }
 
+#ifndef GT_KERNEL_EMU
+#define GT_STAMP_CLOCK() wall_clock64()
+#else
+#define GT_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
+// The replay runs four pivots at a time (the chain wavefront publishes its progress every fourth pivot) with the LDS operands of a step
+// -- its line and 1/pivot -- requested two steps ahead into two register buffers; scheduling barriers keep the requests where they are.
+// (Rounds 1 - 5 replayed step by step and left the order to the compiler, which put the eight reads of a step's line right in front of its
+// 16 FMAs: one LDS round trip exposed per pivot, ~350 cycles per pivot against the chain's ~265 -- the followers ended 1.2 - 1.7 us
+// after the chain wavefront, the inverse last.  Now they end 0.1 - 0.4 us after it: profiles/r06q_potrf_followers_ab.txt.)
 template <int J>
-struct FollowStep {
+__device__ __forceinline__ void follow_load(double (&ln)[16], double& rv, const double* lines, const double* rinvs, int h) {
+  constexpr int lo = (J >> 1) & ~1;   // first column pair the step reads, 16-byte aligned
+  rv = rinvs[J];
+#pragma unroll
+  for (int cl = lo; cl < 16; cl++) ln[cl] = lines[J * SB + 16 * h + cl];
+}
+template <int J>
+__device__ __forceinline__ void follow_apply(double (&a)[16], const double (&ln)[16], double rv, int h) {
+  constexpr int hJ = J & 1, cJ = J >> 1;
+  const double own = half_bcast<hJ>(a[cJ]);
+  const double u = own * rv;
+  if constexpr (J + 1 < SB && ((J + 1) & 1) == 1)
+    a[cJ] = __builtin_fma(-((h == 1) ? u : 0.0), ln[cJ], a[cJ]);   // column J+1 lives in the odd half's a[cJ]
+#pragma unroll
+  for (int cl = cJ + 1; cl < 16; cl++) a[cl] = __builtin_fma(-u, ln[cl], a[cl]);
+#pragma unroll
+  for (int cl = cJ; cl < 16; cl++) GT_PIN(a[cl]);
+}
+template <int J0>
+struct FollowGroup {
   static __device__ __forceinline__ void run(double (&a)[16], const double* lines, const double* rinvs,
                                              lds_vint_p prog, int progbase, int h) {
-    if constexpr ((J & 3) == 0) {   // pivots J .. J+3 published?
-      while (*prog < progbase + J + 4) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    constexpr int hJ = J & 1, cJ = J >> 1;
-    const double own = half_bcast<hJ>(a[cJ]);
-    const double u = own * rinvs[J];
-    const double* line = lines + J * SB + 16 * h;
-    if constexpr (J + 1 < SB && ((J + 1) & 1) == 1)
-      a[cJ] = __builtin_fma(-((h == 1) ? u : 0.0), line[cJ], a[cJ]);   // column J+1 lives in the odd half's a[cJ]
-    constexpr int c0 = cJ + 1;
-#pragma unroll
-    for (int cl = c0; cl < 16; cl++) a[cl] = __builtin_fma(-u, line[cl], a[cl]);
-    // pin the row: otherwise the updates are sunk below the next wait loops and every step's u / line stays alive
-#pragma unroll
-    for (int cl = cJ; cl < 16; cl++) GT_PIN(a[cl]);
-    FollowStep<J + 1>::run(a, lines, rinvs, prog, progbase, h);
+    while (*prog < progbase + J0 + 4) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double l0[16], l1[16], r0, r1;   // two line buffers: the operands of step s+2 are requested into the registers of step s as soon as it is applied
+    follow_load<J0>(l0, r0, lines, rinvs, h);
+    follow_load<J0 + 1>(l1, r1, lines, rinvs, h);
+    __builtin_amdgcn_sched_barrier(0);
+    follow_apply<J0>(a, l0, r0, h);
+    __builtin_amdgcn_sched_barrier(0);
+    follow_load<J0 + 2>(l0, r0, lines, rinvs, h);
+    __builtin_amdgcn_sched_barrier(0);
+    follow_apply<J0 + 1>(a, l1, r1, h);
+    __builtin_amdgcn_sched_barrier(0);
+    follow_load<J0 + 3>(l1, r1, lines, rinvs, h);
+    __builtin_amdgcn_sched_barrier(0);
+    follow_apply<J0 + 2>(a, l0, r0, h);
+    follow_apply<J0 + 3>(a, l1, r1, h);
+    __builtin_amdgcn_sched_barrier(0);
+    FollowGroup<J0 + 4>::run(a, lines, rinvs, prog, progbase, h);
   }
 };
 template <>
-struct FollowStep<SB> {
+struct FollowGroup<SB> {
   static __device__ __forceinline__ void run(double (&)[16], const double*, const double*, lds_vint_p, int, int) {}
 };
 
@@ -278,16 +308,29 @@ struct FollowStep<SB> {
 // ib < 0 -> the rows of the identity become L(jb,jb)^-T: lane i ends up with column i of the inverse, written
 // plain (Xout, row-major) and as the MFMA operand image (Xop)
 __device__ __forceinline__ void stage_follow(double* A, const double* lines, const double* rinvs, const double* rs,
-                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop, bool wt = false) {
+                                             const int* prog, int jb, int ib, int lane, double* Xout, double* Xop, bool wt = false, long long* fdbg = nullptr) {
+#define FSTAMP(n) do { if (fdbg && lane == 0) fdbg[n] = (long long)GT_STAMP_CLOCK(); } while (0)
   const int i = lane & 31, h = lane >> 5;
   const bool inv = ib < 0;
   double* R = A + boff(inv ? jb : ib, jb) + i * PB;
   double a[16];
+  if (inv) {
+    // (the row index goes through GT_PIN: left visible, the 16 constants are hoisted out of the panel loop of potrf_body, spilled, and
+    // reloaded here one scratch round trip at a time)
+    int iv = i;
+    GT_PIN(iv);
 #pragma unroll
-  for (int cl = 0; cl < 16; cl++) a[cl] = inv ? ((2 * cl + h == i) ? 1.0 : 0.0) : R[2 * cl + h];
-  FollowStep<0>::run(a, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, h);
+    for (int cl = 0; cl < 16; cl++) a[cl] = (2 * cl + h == iv) ? 1.0 : 0.0;
+  } else {
+#pragma unroll
+    for (int cl = 0; cl < 16; cl++) a[cl] = R[2 * cl + h];
+  }
+  FSTAMP(0);
+  FollowGroup<0>::run(a, lines, rinvs + SB * jb, (lds_vint_p)prog, SB * jb, h);
+  FSTAMP(1);
   while (*(lds_vint_p)(prog + 1) < jb + 1) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  FSTAMP(2);
   scale_columns(a, rs + SB * jb, h);
   if (inv) {
     // two base addresses + compile-time offsets (row 2 cl + h of the inverse: opnd_off(6 + jb, 2 cl + h, i) = its value at cl = 0 plus
@@ -304,7 +347,8 @@ __device__ __forceinline__ void stage_follow(double* A, const double* lines, con
   } else {
 #pragma unroll
     for (int cl = 0; cl < 16; cl++) R[2 * cl + h] = a[cl];
-  }
+  }  FSTAMP(3);
+#undef FSTAMP
 }
 
 // one 16x16 MFMA tile (ti, tj) of the update A(ib,cb) -= L(ib,jb) L(cb,jb)^T inside the diagonal tile
@@ -366,7 +410,11 @@ __device__ __forceinline__ void slice_task(double* A, const double* X, int ib, i
 //       producing the inverse | wave 4 idle (same SIMD as wave 0) | the remaining waves: everything of panel jb-1
 //       that nobody is waiting for (the off-chain MFMA updates and the write-back of its finished blocks)
 //   P3  the update of the NEXT panel (diagonal block + the blocks below it), all waves.
+#ifndef GT_KERNEL_EMU
+#define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)wall_clock64(); } while (0)   // 100 MHz, like the other stamps of GTG_DF_TRACE
+#else
 #define STAMP(n) do { if (dbg && threadIdx.x == 0) dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#endif
 constexpr int kFlagOff = kOpndBase + 10 * 2 * 64 * 8;   // doubles: progress word of the tile, after the operand images
 // the lower 32x32 sub-blocks of a diagonal tile -> the packed LDS image: 10 blocks x 512 16-byte pieces, 10 per lane, all
 // loads in flight before the writes (512 threads)
@@ -412,7 +460,8 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
   double* lines = rs + T;                             // [SB][SB] published columns of the current panel + 64 trash
   int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the roles below are scalar branches)
+  const int wave_hw = wave; (void)wave_hw;
   const int lr = lane & 15, lk = lane >> 4;
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
@@ -430,18 +479,23 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
 #pragma unroll 1
   for (int jb = 0; jb < 4; jb++) {
     const int nfol = 3 - jb;   // row blocks below
+    // from panel 1 on the inverse follower runs on wavefront 7 (SIMD 3, whose other wavefront -- 3 -- is no follower any more) instead of
+    // wavefront 5, which shares SIMD 1 with the follower wavefront 1
+    const int wave = (jb >= 1 && wave_hw == 5) ? 7 : (jb >= 1 && wave_hw == 7) ? 5 : wave_hw;
     if (wave == 0) {
       stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail, pk, prev_exp);
       if (jb == 3 && tile_exp && lane == 0) st_pub(tile_exp + k, __longlong_as_double((long long)prev_exp), true);
-    } else if (wave == 4) {
-      // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound
+    } else if (wave == 4 && !(jb == 0 && Xdef)) {
+      // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound (except in panel 0 of the dataflow
+      // chain, where it takes a third of the deferred slice tasks: MFMAs, one issue slot per 64 cycles)
     } else if (wave <= nfol || wave == 5) {
-      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt);
+      stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt,
+                   dbg && jb == 2 && (wave_hw == 1 || wave_hw == 5 || wave_hw == 7) ? dbg + 48 + 4 * (wave_hw == 1 ? 0 : wave_hw == 5 ? 1 : 2) : nullptr);
     } else if (jb == 0) {
-      // (the wavefronts 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that panel 0 does not
+      // (the wavefronts 4, 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that panel 0 does not
       // read -- the chain kernel passes the slice as Xdef, chol_dataflow.hip::chain_loop -- runs here, under panel 0's pivots)
       if (Xdef)
-        for (int t = wave - 6; t < 24; t += 2) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles
+        for (int t = (wave == 4 ? 2 : wave - 6); t < 24; t += 3) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles
           const int b2 = (t >> 2) * 2;
           slice_task(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1, lr, lk);
         }
@@ -471,6 +525,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     //   under them and the pivot chain does not stall; the substitution step q only has to be done before panel q+1 is.  The last
     //   panel's word follows its drain directly (it is the one on the serial chain of the factorisation).
     const bool late = wt && jb < 3;
+    if (dbg && lane == 0) dbg[16 + 8 * jb + wave_hw] = (long long)GT_STAMP_CLOCK();   // trace: when each wavefront was done with its part of the stage
     if (wt && !late) GT_DRAIN_STORES();
     __syncthreads();
     if (tid == 0 && !late)

@@ -280,10 +280,12 @@ class DeviceGraph:
     def df_trace(self):
         """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][2] stamps) of the last factorisation, 100 MHz ticks."""
         pl = self.df_plan()
-        n = 8 * pl["tasks"].shape[0] + 2 * pl["nt"]
+        nt8, nt = 8 * pl["tasks"].shape[0], pl["nt"]
+        n = nt8 + 66 * nt
         out = np.zeros(n, np.int64)
         _check(self.lib.gtg_debug_df_trace(self.h, out.ctypes.data, n), "gtg_debug_df_trace")
-        return out[:8 * pl["tasks"].shape[0]].reshape(-1, 8), out[8 * pl["tasks"].shape[0]:].reshape(-1, 2)
+        self.potrf_stamps = out[nt8 + 2 * nt:].reshape(-1, 64)     # per diagonal tile: the 15 stamps of chol_device.h::potrf_body
+        return out[:nt8].reshape(-1, 8), out[nt8:nt8 + 2 * nt].reshape(-1, 2)
 
     def df_poll_stats(self):
         """(long waits, ended on the RMW poll, of those still stale for the sc1 load, ended on the shadow word, of those still stale)"""

@@ -187,12 +187,18 @@ __device__ __forceinline__ int wait_progress(const long long* f1, const long lon
 // 8-wave workgroups per CU gave the same contraction rate, but the END of a task -- the substitution, which is a link of a
 // serial chain -- then shared the matrix pipe with a neighbour in the middle of its contraction: 12 us from the last panel of the
 // diagonal tile to the finished tile, against 2.5 us with the CU to itself (measured with the single-kernel form).
-// Wavefront (rt, h) = (wave >> 1, wave & 1) owns rows 16 rt .. 16 rt + 15 and the column half h (64 columns = the 32-column
+// Wavefront (rt, h) = (bulk_rt(wave), bulk_h(wave)) owns rows 16 rt .. 16 rt + 15 and the column half h (64 columns = the 32-column
 // blocks 2 h and 2 h + 1): 1 x 4 MFMA tiles, 32 accumulator registers -- the substitution runs in the same layout (a row of
 // L(I,J) depends on the same row of R only), every register index is a compile-time constant, nothing spills.
 // Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by LDS-DMA, double buffered, 16-byte slots
 // XOR-swizzled on the source address and on the operand reads.
 constexpr int kBulkThreads = 1024;
+// wavefront -> (row tile, column half).  Wavefronts go to the four SIMDs of the CU with period four, and the substitution's later steps
+// occupy the wavefronts of ONE column half only (blocks 2, 3: half 1): with h = wave & 1 (rounds 2 - 5) those eight wavefronts shared
+// two SIMDs and the other two matrix pipes idled -- 2.8 us for the 32 MFMAs of step 2 (profiles/r06t_substitution_steps.txt).  With h taken
+// from bit 2 every SIMD holds two wavefronts of each half.
+__device__ __forceinline__ int bulk_rt(int wave) { return (wave & 3) + 4 * (wave >> 3); }
+__device__ __forceinline__ int bulk_h(int wave) { return (wave >> 2) & 1; }
 
 template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
@@ -210,7 +216,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
   GT_PIN(tid_);
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rt = wave >> 1;
+  const int rt = bulk_rt(wave);
   constexpr int h = H;
   const int lr = lane & 15, lk = lane >> 4;
   const long long flagbase = epoch * 8;
@@ -228,9 +234,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
       pf = flagbase + q + 1;
     }
     if (tr && tid == 0) tr[4 + q] = wall_clock64();   // panel q seen
-    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
-    __syncthreads();   // the previous step's images have been consumed; -X_{q-1} is complete in the W patches and out of every wavefront
-    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
+    // (the previous step's images have been consumed: barrier at the end of the loop body)
     {  // images of this step: slots 0 .. 3-q = L(q + s, q - 1) (q > 0), slot 3 = Linv(q,q); wavefront w moves 1 KiB pieces
       // (w & 7) of the slots (w >> 3) and (w >> 3) + 2
 #pragma unroll
@@ -243,7 +247,11 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
                                            (lptr_t)(img + sl * kImgDoubles + 128 * (wave & 7)), 16, 0, kHandoffAux);
       }
     }
-    __syncthreads();   // (drains the DMA)
+    // The image fetch and the acknowledgement of X_{q-1}'s write-through stores are two memory round trips; rounds 3 - 5 took them one after
+    // the other (drain, barrier, flag, fetch, barrier), now the fetch is in flight while the stores drain (s_waitcnt vmcnt(0) covers both)
+    if (q > 0) stores_done();   // X_{q-1} of this wavefront is in memory
+    __syncthreads();   // (drains the DMA); -X_{q-1} is complete in the W patches and out of every wavefront
+    if (q > 0 && tid == 0) st_flag(myflag, flagbase + q);
     if (q > 0) {
       double a[8];
 #pragma unroll
@@ -265,6 +273,9 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
       }
     }
     __syncthreads();   // both wavefronts of a row tile have read -X_{q-1}: the patch is free for R_q
+    // the next panel's flag, requested a step's arithmetic ahead of its use: a poll is a memory round trip even when the panel is long out.
+    // (In front of this step's write-through stores: the memory counter is in order, a load issued behind them returns with their acknowledgements)
+    if (q < 3 && pf < flagbase + q + 2) pf = ld_flag(pflag);
 #pragma unroll
     for (int l = 0; l < 2; l++) {
       if (2 * h + l != q) continue;   // (compile-time)
@@ -296,6 +307,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
           st_wt((Crow + (4 * r) * T + 32 * l + 16 * t) + lane_off, v);
         }
     }
+    if (q < 3) __syncthreads();   // this step's images have been consumed by every wavefront: the next step may fetch over them
   }
   stores_done();
   __syncthreads();
@@ -314,7 +326,7 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   GT_PIN(tid_);
   const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rt = wave >> 1, h = wave & 1;
+  const int rt = bulk_rt(wave), h = bulk_h(wave);
   const int lr = lane & 15, lk = lane >> 4;
   // slotC: the slot of tile (I, J), slotD: of the diagonal tile (J, J); a contraction step is the pair of slots of its two operand
   // tiles (I, k), (J, k) -- tiles and their flag words are both indexed by slot
@@ -420,10 +432,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
           const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-          const double a = -*reinterpret_cast<const double*>(Ac + a_row_off + so);
+          const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));   // (single 8-byte reads: chol_device.h::lds_ld)
           double b[4];
 #pragma unroll
-          for (int t = 0; t < 4; t++) b[t] = *reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so);
+          for (int t = 0; t < 4; t++) b[t] = lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so));
 #pragma unroll
           for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
         }
@@ -528,6 +540,7 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1) (-1: not stored)
     double* tile = S + (int64_t)dslot * TT;
     bool deferred = false;
+    long long* sdbg = stamps ? stamps + 64 * (int64_t)J : nullptr;
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     // The update of the block column right before this tile is applied HERE, in 32-column slices as the substitution of tile (J, J-1)
     // publishes them (the last slice is the only thing left when that tile is final).
@@ -535,11 +548,14 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     if (sslot >= 0) {
       const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
+      long long seen = 0;   // the tile's progress word as last read (monotonic)
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
-        if (tid < 64) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, ctrl + 8, 5, J, J - 1, q);
+        // (the word was read once more before the previous slice's tasks -- a poll is a memory round trip even when the flag has long been there)
+        if (tid < 64 && seen < epoch * 8 + q + 1) wait_flags(sflag, epoch * 8 + q + 1, sflag, epoch * 8 + q + 1, fail, ctrl + 8, 5, J, J - 1, q);
         __syncthreads();   // also: the tile image is complete (q = 0) / the slice buffer is free (q > 0)
         acquired();
+        if (sdbg && tid == 0 && q >= 2) sdbg[60 + 2 * (q - 2)] = wall_clock64();   // trace: slice q seen ...
         {  // slice q: rows 0..127, columns 32 q .. 32 q + 31 of the tile below-left -> X[4][SB][PB], 16 bytes x 4 per thread
           double2 v[4];
 #pragma unroll
@@ -561,19 +577,26 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
           }
         }
         __syncthreads();
+        if (sdbg && tid == 0 && q >= 2) sdbg[61 + 2 * (q - 2)] = wall_clock64();   // ... and in LDS
+        if (tid < 64 && q < 3) seen = ld_flag(sflag);   // in flight under the slice tasks
         if (q == 3) {
           // The LAST slice is on the serial chain of the factorisation (the tile left of this one became final a moment ago): only its
           // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- is applied here (2 rounds of MFMA
           // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4
           // (5.12 -> 5.07 ms on L1723, profiles/r04_df_defer_ab.txt) and again in round 5 (profiles/r05a_variants_ab.txt).
-          for (int t = wave; t < 16; t += 8) slice_task(A, X, t >> 2, 0, (t >> 1) & 1, t & 1, lr, lk);
+          {   // 16 tiles, two per wavefront
+            const int t = wave, u = wave + 8;
+            const TilePatch p0 = slice_patch(A, X, t >> 2, 0, (t >> 1) & 1, t & 1), p1 = slice_patch(A, X, u >> 2, 0, (u >> 1) & 1, u & 1);
+            upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
+          }
           deferred = true;
         } else {
-          for (int t = wave; t < 40; t += 8) {   // 10 lower blocks x 4 MFMA tiles
-            const int blk = t >> 2;
-            int ib = 0, rem = blk;
-            while (rem > ib) { rem -= ib + 1; ib++; }
-            slice_task(A, X, ib, rem, (t >> 1) & 1, t & 1, lr, lk);
+          for (int t = wave; t < 40; t += 16) {   // 10 lower blocks x 4 MFMA tiles: five per wavefront, two at a time
+            const int u = t + 8 < 40 ? t + 8 : t;
+            int ib, cb, ib1, cb1;
+            lower_block(t >> 2, ib, cb); lower_block(u >> 2, ib1, cb1);
+            const TilePatch p0 = slice_patch(A, X, ib, cb, (t >> 1) & 1, t & 1), p1 = slice_patch(A, X, ib1, cb1, (u >> 1) & 1, u & 1);
+            upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, u != t, lr, lk);
           }
         }
       }

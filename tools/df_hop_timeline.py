@@ -4,7 +4,8 @@ whose left neighbour (J, J-1) is stored, the events between the start of potrf(J
 after potrf(J-1)'s first stamp:
   panel q of (J-1, J-1) released (the stamp after the flag store of chol_device.h::potrf_body),
   the substitution task of tile (J, J-1) sees panel q (chol_dataflow.hip::substitute, tr[4 + q]), its contraction done, the task done,
-  the chain workgroup of tile J: PD(J) seen (trace[2 J]), potrf_body(J) starts (stamp 0), its image complete (stamp 1)."""
+  the chain workgroup of tile J: PD(J) seen (trace[2 J]), the slices 2 and 3 of tile (J, J-1) seen / in LDS (stamps 60 - 63), potrf_body(J)
+  starts (stamp 0), its image complete (stamp 1)."""
 import json
 import os
 import sys
@@ -43,12 +44,12 @@ def main():
         t0 = st[j - 1, 0]
         rel = [st[j - 1, 4] - t0, st[j - 1, 7] - t0, st[j - 1, 10] - t0, st[j - 1, 11] - t0, st[j - 1, 14] - t0,      # panels 0-2 (late flags), panel 3, last column stored
                tk[s, 0] - t0, tk[s, 1] - t0, tk[s, 4] - t0, tk[s, 5] - t0, tk[s, 6] - t0, tk[s, 7] - t0, tk[s, 2] - t0,   # sub task: taken, contraction done, sees panel 0..3, done
-               ch[j, 0] - t0, st[j, 0] - t0, st[j, 1] - t0, st[j, 0] - st[j - 1, 0]]
+               ch[j, 0] - t0, st[j, 60] - t0, st[j, 61] - t0, st[j, 62] - t0, st[j, 63] - t0, st[j, 0] - t0, st[j, 1] - t0, st[j, 0] - st[j - 1, 0]]
         rows.append(rel)
     rows = np.array(rows)
     names = ["panel 0 released", "panel 1 released", "panel 2 released", "panel 3 released", "potrf(J-1) last column stored",
              "sub task taken", "sub contraction done", "sub sees panel 0", "sub sees panel 1", "sub sees panel 2", "sub sees panel 3", "sub task done (tile (J,J-1) final)",
-             "chain(J): PD(J) seen", "potrf_body(J) starts", "potrf_body(J): barrier after image", "period"]
+             "chain(J): PD(J) seen", "chain(J): slice 2 seen", "chain(J): slice 2 in LDS", "chain(J): slice 3 seen", "chain(J): slice 3 in LDS", "potrf_body(J) starts", "potrf_body(J): barrier after image", "period"]
     out = {"workload": w, "tiles": len(rows), "median_us_after_potrf_start": {n: round(float(np.median(rows[:, k])), 2) for k, n in enumerate(names)},
            "p10": {n: round(float(np.percentile(rows[:, k], 10)), 2) for k, n in enumerate(names)},
            "p90": {n: round(float(np.percentile(rows[:, k], 90)), 2) for k, n in enumerate(names)},

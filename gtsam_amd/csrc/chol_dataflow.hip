@@ -142,6 +142,8 @@ __device__ __forceinline__ void wait_flags(const long long* f1, long long v1, co
                                            int32_t* dbg = nullptr, int kind = 0, int a = 0, int b = 0, int c = 0) {
   int spins = 0;
   long long t0 = 0;
+  // (two polls in flight, half a round trip apart, were measured in round 6: 4.63 -> 4.71 ms -- the polling traffic costs more than the
+  // earlier notice saves; profiles/r06z_poll_depth.txt)
   while (ld_flag(f1) < v1 || ld_flag(f2) < v2) {
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 255) == 0) {
@@ -355,6 +357,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   const unsigned lane_off = (unsigned)(lk * T + lr);
   double* Crow = C + (16 * rt) * T + 64 * h;
   v4f64 x[4];
+  long long waited = 0;   // GTG_DF_TRACE: ticks this workgroup spent in the flag waits of the accumulation / contraction phase
+#define GT_TIMED(call) do { if (tr) { const long long w0_ = wall_clock64(); call; waited += wall_clock64() - w0_; } else { call; } } while (0)
   // ---- where this piece's partial result lives.  The early pieces of a tile accumulate IN PLACE, one after the other (lane 0).  A tile
   // whose contraction list is very long -- the diagonal tiles of a nested-dissection separator collect an update from every block
   // column of the subtrees below them: 300 steps for the root of the 20 000-pose graph, all of them waiting for ONE chain of
@@ -381,13 +385,13 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
   if (early ? q > 0 : E > 0) {
     // lane 0 / this lane: the pieces before this one
     const long long have = early ? q : (E + G - 1) / G;
-    wait_flags(pflag_mine, epoch * kPieceBase + have, pflag_mine, epoch * kPieceBase + have, fail, dbg, 7, I, J, piece);
+    GT_TIMED(wait_flags(pflag_mine, epoch * kPieceBase + have, pflag_mine, epoch * kPieceBase + have, fail, dbg, 7, I, J, piece));
     load_acc(AccRow, false);
     if (!early)
       for (int g = 1; g < G; g++) {            // the other lanes, in lane order
         const long long ng = (E - g + G - 1) / G;
         const long long* fg = part_flag + scratch + g - 1;
-        wait_flags(fg, epoch * kPieceBase + ng, fg, epoch * kPieceBase + ng, fail, dbg, 7, I, J, piece);
+        GT_TIMED(wait_flags(fg, epoch * kPieceBase + ng, fg, epoch * kPieceBase + ng, fail, dbg, 7, I, J, piece));
         load_acc(S + (int64_t)(scratch + g - 1) * TT + (16 * rt) * T + 64 * h, true);
       }
   } else if (lane_g == 0) {
@@ -403,7 +407,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     // tiles are long final and the test is a scalar compare; for the last step (block column J-1, whose tiles become final
     // behind the diagonal tile that is being factored right now) the contraction streams behind the substitution.
     int ka = kl[0], kb = kl[1];
-    int cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, 1, fail, dbg, 1, I, J, ka);   // progress known for the current step
+    int cp = 0;
+    GT_TIMED(cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, 1, fail, dbg, 1, I, J, ka));   // progress known for the current step
     const double* Ak = S + (int64_t)ka * TT;
     const double* Bk = S + (int64_t)kb * TT;
     stage(Ak, Bk, 0, 0);
@@ -421,10 +426,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         const int cur = ch & 1;
         if (ch + 1 < T / KC) {
           const int need = ch + 2;   // chunk ch + 1 = the operand tiles' 32-column block ch + 1
-          if (cp < need) { cp = tile_progress(tile_flag + ka, tile_flag + kb, flagbase); if (cp < need) cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, need, fail, dbg, 2, I, J, ka); }
+          if (cp < need) { cp = tile_progress(tile_flag + ka, tile_flag + kb, flagbase); if (cp < need) GT_TIMED(cp = wait_progress(tile_flag + ka, tile_flag + kb, flagbase, need, fail, dbg, 2, I, J, ka)); }
           stage(Ak, Bk, ch + 1, cur ^ 1);
         } else if (ki + 1 < kcnt) {
-          if (np < 1) np = wait_progress(tile_flag + kna, tile_flag + knb, flagbase, 1, fail, dbg, 2, I, J, kna);
+          if (np < 1) GT_TIMED(np = wait_progress(tile_flag + kna, tile_flag + knb, flagbase, 1, fail, dbg, 2, I, J, kna));
           stage(An, Bn, 0, cur ^ 1);
         }
         const char* Ac = smem_raw + cur * 2 * CH;
@@ -444,7 +449,8 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
       ka = kna; kb = knb; Ak = An; Bk = Bn; cp = np;
     }
   }
-  if (tr && tid == 0) tr[1] = wall_clock64();
+  if (tr && tid == 0) { tr[1] = wall_clock64(); tr[3] |= waited << 40; }   // (bits 40..: ticks waited; below: where the workgroup runs)
+#undef GT_TIMED
 
   if (early) {   // an early piece: the partial result goes back into its lane's tile
 #pragma unroll
@@ -591,12 +597,13 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
           }
           deferred = true;
         } else {
-          for (int t = wave; t < 40; t += 16) {   // 10 lower blocks x 4 MFMA tiles: five per wavefront, two at a time
-            const int u = t + 8 < 40 ? t + 8 : t;
-            int ib, cb, ib1, cb1;
-            lower_block(t >> 2, ib, cb); lower_block(u >> 2, ib1, cb1);
-            const TilePatch p0 = slice_patch(A, X, ib, cb, (t >> 1) & 1, t & 1), p1 = slice_patch(A, X, ib1, cb1, (u >> 1) & 1, u & 1);
-            upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, u != t, lr, lk);
+          {   // 10 lower blocks: one whole block per wavefront (0 .. 7), then one tile each of the blocks 8 and 9
+            int ib, cb;
+            lower_block(wave, ib, cb);
+            upd_block4(A + boff(ib, cb), X + ib * SB * PB, X + cb * SB * PB, lr, lk);
+            lower_block(8 + (wave >> 2), ib, cb);
+            const TilePatch p0 = slice_patch(A, X, ib, cb, (wave >> 1) & 1, wave & 1);
+            upd_tiles2(p0.C, p0.A, p0.B, p0.C, p0.A, p0.B, false, lr, lk);
           }
         }
       }

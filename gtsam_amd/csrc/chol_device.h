@@ -387,6 +387,35 @@ __device__ __forceinline__ void upd_tiles2(double* C0, const double* A0, const d
     for (int r = 0; r < 4; r++) C0[(lk + 4 * r) * PB + lr] = acc0[r];
   }
 }
+// A whole 32 x 32 block:  C -= A B^T  with A, B 32 x 32 patches (2 x 2 MFMA tiles, four accumulation chains, every operand row read once:
+// 40 LDS reads for 32 MFMAs, against 40 for 16 with two unrelated tiles).  Per tile the order of the accumulation is unchanged.
+__device__ __forceinline__ void upd_block4(double* C, const double* A, const double* B, int lr, int lk) {
+  v4f64 acc[2][2];
+  double a[2][8], b[2][8];
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[ti][tj][r] = lds_ld(C + (16 * ti + lk + 4 * r) * PB + 16 * tj + lr);
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+    for (int s = 0; s < 8; s++) { a[tt][s] = -lds_ld(A + (16 * tt + lr) * PB + 4 * s + lk); b[tt][s] = lds_ld(B + (16 * tt + lr) * PB + 4 * s + lk); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 8; s++)
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++) acc[ti][tj] = MFMA(a[ti][s], b[tj][s], acc[ti][tj]);
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) C[(16 * ti + lk + 4 * r) * PB + 16 * tj + lr] = acc[ti][tj][r];
+}
 // the (ti, tj) tile of the update A(ib,cb) -= L(ib,jb) L(cb,jb)^T inside the diagonal tile: its three patches
 struct TilePatch { double* C; const double* A; const double* B; };
 __device__ __forceinline__ TilePatch tile_patch(double* A, int jb, int ib, int cb, int ti, int tj) {
@@ -405,16 +434,37 @@ __device__ __forceinline__ void lower_block(int blk, int& ib, int& cb) {
 // write the finished sub-blocks (ib, jb), ib = jb..3, back to the tile (diagonal one with its upper part zeroed; the
 // strictly-upper sub-blocks of the tile are never read by anyone) and, for ib > jb, as operand images for k_trsm128
 __device__ __forceinline__ void store_column(const double* A, double* tile, double* Xinv, int jb, int t, int nthreads, bool wt = false) {
-  for (int e = t; e < (4 - jb) * 512; e += nthreads) {
-    const int ib = jb + (e >> 9), w = e & 511, r = w >> 4, c = 2 * (w & 15);
-    const double* sp = A + boff(ib, jb) + r * PB + c;
-    double2 v;
-    v.x = (ib != jb || c <= r) ? sp[0] : 0.0;
-    v.y = (ib != jb || c + 1 <= r) ? sp[1] : 0.0;
-    *reinterpret_cast<double2*>(tile + (SB * ib + r) * T + SB * jb + c) = v;   // (the tile itself is read by later kernels only)
-    if (ib != jb) {
-      double* o = Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, r, c);
-      if (wt) { st_pub(o, v.x, true); st_pub(o + 1, v.y, true); } else *reinterpret_cast<double2*>(o) = v;
+  // Block by block (the block index is uniform: what depends on the lane is the 16-byte piece w = 16 r + c / 2 of a 32 x 32 block only),
+  // up to three pieces per lane and block with their LDS reads in flight together.  (One flat loop over all pieces, decoding block, row
+  // and column per piece, cost ~70 VALU instructions and an exposed LDS round trip per piece: 2.6 us for panel 0's write-back on three
+  // wavefronts that share their SIMDs with the followers -- what panel 1's stage waited for.)
+  for (int ib = jb; ib < 4; ib++) {
+    const double* blk = A + boff(ib, jb);
+    double* trow = tile + (SB * ib) * T + SB * jb;
+    double* img = Xinv + kOpndBase + opnd_off(ib * (ib - 1) / 2 + jb, 0, 0);
+    const bool diag = ib == jb;
+    for (int w0 = t; w0 < 512; w0 += 3 * nthreads) {
+      double2 v[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int w = w0 + u * nthreads, r = w >> 4, c = 2 * (w & 15);
+        v[u].x = 0.0; v[u].y = 0.0;
+        if (w < 512) {
+          if (!diag || c <= r) v[u].x = blk[r * PB + c];
+          if (!diag || c + 1 <= r) v[u].y = blk[r * PB + c + 1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int w = w0 + u * nthreads, r = w >> 4, c = 2 * (w & 15);
+        if (w < 512) {
+          *reinterpret_cast<double2*>(trow + r * T + c) = v[u];   // (the tile itself is read by later kernels only)
+          if (!diag) {
+            double* o = img + opnd_off(0, r, c);
+            if (wt) { st_pub(o, v[u].x, true); st_pub(o + 1, v[u].y, true); } else *reinterpret_cast<double2*>(o) = v[u];
+          }
+        }
+      }
     }
   }
 }
@@ -507,6 +557,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt,
                    dbg && jb == 2 && (wave_hw == 1 || wave_hw == 5 || wave_hw == 7) ? dbg + 48 + 4 * (wave_hw == 1 ? 0 : wave_hw == 5 ? 1 : 2) : nullptr);
     } else if (jb == 0) {
+      __builtin_amdgcn_s_setprio(1);   // deferred work yields issue slots to the followers it shares a SIMD with
       // (the wavefronts 4, 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that panel 0 does not
       // read -- the chain kernel passes the slice as Xdef, chol_dataflow.hip::chain_loop -- runs here, under panel 0's pivots)
       if (Xdef)
@@ -517,6 +568,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
           upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, u < 24, lr, lk);
         }
     } else if (jb > 0) {
+      __builtin_amdgcn_s_setprio(1);   // (see above)
       const int pj = jb - 1;                            // deferred work of panel pj
       const int nh = 2 + jb, hw = wave >= 6 ? wave - 6 : 2 + (wave - nfol - 1);
       // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
@@ -543,6 +595,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     //   For the panels 0..2 the wait is taken AFTER the updates of the next panel (P3: LDS only), so the acknowledgements arrive
     //   under them and the pivot chain does not stall; the substitution step q only has to be done before panel q+1 is.  The last
     //   panel's word follows its drain directly (it is the one on the serial chain of the factorisation).
+    if (wave_hw != 0) __builtin_amdgcn_s_setprio(2);
     const bool late = wt && jb < 3;
     if (dbg && lane == 0) dbg[16 + 8 * jb + wave_hw] = (long long)GT_STAMP_CLOCK();   // trace: when each wavefront was done with its part of the stage
     if (wt && !late) GT_DRAIN_STORES();

@@ -52,8 +52,9 @@ def main():
            "sum_periods_us": float(rows[:, 4].sum()),
            "task_resident_us_total": float(busy), "task_contraction_phase_us_total": float(accum),
            "ksteps_total": int(kcnt.sum()), "us_per_kstep_resident": float(accum / max(kcnt.sum(), 1)),
+           "contraction_phase_waiting_us_total": float((tasks[:, 3] >> 40).sum() / 100.0),
            "first_task_start_us": float(start.min()), "chain_first_in_us": float(c_in[0]),
-           "workgroup_slots": int(len(set(tasks[:, 3].tolist())))}
+           "workgroup_slots": int(len(set((tasks[:, 3] & ((1 << 40) - 1)).tolist())))}
     print(json.dumps(out))
     if "--raw" in sys.argv:
         np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "df_trace_raw.npz"),

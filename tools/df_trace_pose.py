@@ -36,7 +36,7 @@ def main():
     off, tiles = ch["chain_off"], ch["chain_tiles"]
     out = {"workload": name, "nt": int(nt), "n_tasks": int(len(T)), "total_us": float(total), "n_chain_workgroups": int(len(off) - 1),
            "ksteps": int(kc.sum()), "pieces_max_per_tile": int(R.max()), "task_resident_us_total": float((done - start).sum()),
-           "workgroups_seen": int(len(set(tasks[:, 3].tolist())))}
+           "workgroups_seen": int(len(set((tasks[:, 3] & ((1 << 40) - 1)).tolist())))}
     rows = []
     for w in range(len(off) - 1):
         mine = tiles[off[w]:off[w + 1]]

@@ -318,7 +318,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 
 
 __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD, int G, int scratch,
-                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
+                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces, bool rhs_row,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
                                          double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
@@ -414,6 +414,10 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     stage(Ak, Bk, 0, 0);
     __syncthreads();
     const int a_row_off = (16 * rt + lr) * ROWB, b_row_off = (64 * h + lr) * ROWB;
+    // The right-hand-side row (tile row nt: the forward solve rides along with the factorisation) has ONE non-zero row: only the wavefronts of
+    // row tile 0 multiply -- the other fourteen kept the matrix pipes busy with zeros, 6 % of the bulk kernel's resident time on L1723
+    // (tools/df_wait_analysis.py).  Their accumulators are and stay zero either way.
+    const bool idle_rows = rhs_row && rt != 0;
     const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr;
     for (int ki = 0; ki < kcnt; ki++) {
       // the flags of the next contraction step, fetched a whole step ahead of their use
@@ -434,15 +438,17 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         }
         const char* Ac = smem_raw + cur * 2 * CH;
         const char* Bc = Ac + CH;
+        if (!idle_rows) {
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-          const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-          const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));   // (single 8-byte reads: chol_device.h::lds_ld)
-          double b[4];
+          for (int kk = 0; kk < KC; kk += 4) {
+            const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
+            const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));   // (single 8-byte reads: chol_device.h::lds_ld)
+            double b[4];
 #pragma unroll
-          for (int t = 0; t < 4; t++) b[t] = lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so));
+            for (int t = 0; t < 4; t++) b[t] = lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so));
 #pragma unroll
-          for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
+            for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
+          }
         }
         __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
       }
@@ -494,7 +500,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot, [10]: the tile is a right-hand-side row
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -502,7 +508,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], d[10] != 0, tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -920,7 +926,8 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
       { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
-      dt.push_back(0); dt.push_back(0);
+      dt.push_back(I == nt ? 1 : 0);   // right-hand-side row: one non-zero row (run_task)
+      dt.push_back(0);
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
         dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);

@@ -531,7 +531,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
   // its own followers
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-  if (tid == 0) { prog[0] = 0; prog[1] = 0; }
+  if (tid == 0) { *(lds_vint_p)prog = 0; *(lds_vint_p)(prog + 1) = 0; }   // (volatile: as one 8-byte store of a hoisted zero pair the compiler spilled the pair and reloaded it here, a scratch round trip per tile)
   STAMP(0);
   if (!preloaded) diag_tile_to_lds(tile, A, tid);   // (preloaded: the caller filled the image and synchronises below)
   __syncthreads();

@@ -717,7 +717,16 @@ void analyze(gtg_context& c) {
     {  // tiles that hold something before the factorisation: diagonal blocks, pose-pose blocks, Schur pairs, rhs row
       std::vector<uint8_t> T1((size_t)nt * nt, 0);
       std::vector<uint8_t> rhs((size_t)nt, 0);
+      // the same structure at the granularity of 16 rows / columns (kSub): column c of the strip matrix = a bit set over the strips below it.
+      // Its symbolic factorisation (below) tells the bulk kernel which 16 x 16 sub-tiles of an operand tile are structurally zero.
+      const int n16 = c.NP / kSub, w16 = (n16 + 63) / 64;
+      std::vector<uint64_t> M16((size_t)n16 * w16, 0);
+      auto mark16 = [&](int64_t ra0, int64_t ra1, int64_t rb0, int64_t rb1) {
+        for (int64_t a = ra0; a <= ra1; a++)
+          for (int64_t b = rb0; b <= rb1; b++) { const int64_t hi = std::max(a, b), lo = std::min(a, b); M16[(size_t)lo * w16 + (hi >> 6)] |= 1ull << (hi & 63); }
+      };
       auto mark1 = [&](int ra, int rb) {
+        mark16(c.h_red_off[ra] / kSub, (c.h_red_off[ra] + c.h_red_dim[ra] - 1) / kSub, c.h_red_off[rb] / kSub, (c.h_red_off[rb] + c.h_red_dim[rb] - 1) / kSub);
         const int64_t a0 = c.h_red_off[ra] / kTile, a1 = (c.h_red_off[ra] + c.h_red_dim[ra] - 1) / kTile;
         const int64_t b0 = c.h_red_off[rb] / kTile, b1 = (c.h_red_off[rb] + c.h_red_dim[rb] - 1) / kTile;
         for (int64_t a = a0; a <= a1; a++)
@@ -747,6 +756,40 @@ void analyze(gtg_context& c) {
       for (int a = 0; a < nt; a++)
         for (int b2 = 0; b2 <= a; b2++) if (T1[(size_t)a * nt + b2]) B2[(size_t)(a / 2) * np2 + (size_t)(b2 / 2)] = 1;
       for (int64_t i : c.h_pad_index) T1[(size_t)(i / kTile) * nt + (size_t)(i / kTile)] = 1;
+      clk.lap("tile structure (marks of every block)");
+      // Symbolic factorisation of the strip matrix: the structure of column c of L is that of S plus the structures of its children in the
+      // elimination tree (parent = first strip below the diagonal), so every column is merged into ONE other column.  sub16[I nt + J], I >= J:
+      // bit 8 r + q = the 16 x 16 sub-tile (r, q) of tile (I, J) of L can be non-zero.
+      std::vector<uint64_t> sub16((size_t)nt * nt, 0);
+      {
+        for (int q = 0; q < n16; q++) M16[(size_t)q * w16 + (q >> 6)] |= 1ull << (q & 63);
+        for (int q = 0; q < n16; q++) {
+          const uint64_t* col = M16.data() + (size_t)q * w16;
+          int parent = -1;
+          for (int w = (q + 1) >> 6; w < w16 && parent < 0; w++) {
+            uint64_t bits = col[w];
+            if (w == ((q + 1) >> 6)) bits &= ~0ull << ((q + 1) & 63);
+            if (bits) parent = w * 64 + __builtin_ctzll(bits);
+          }
+          if (parent < 0) continue;
+          uint64_t* pc = M16.data() + (size_t)parent * w16;
+          for (int w = parent >> 6; w < w16; w++) { uint64_t bits = col[w]; if (w == (parent >> 6)) bits &= ~0ull << (parent & 63); pc[w] |= bits; }
+        }
+        constexpr int per = kTile / kSub;
+        for (int q = 0; q < n16; q++) {
+          const uint64_t* col = M16.data() + (size_t)q * w16;
+          const int J = q / per, cq = q % per;
+          for (int w = q >> 6; w < w16; w++) {
+            uint64_t bits = col[w];
+            while (bits) {
+              const int r16 = w * 64 + __builtin_ctzll(bits); bits &= bits - 1;
+              if (r16 < q) continue;
+              sub16[(size_t)(r16 / per) * nt + J] |= 1ull << (8 * (r16 % per) + cq);
+            }
+          }
+        }
+      }
+      clk.lap("strip-level symbolic factorisation (sub-tile masks)");
       std::vector<int32_t> ex;
       const bool dense = std::getenv("GTG_DENSE_PLAN") != nullptr;
       // default schedule: the dataflow pass (chol_dataflow.hip), symbolic fill at 128-tile granularity.  GTG_CHOL=streams
@@ -765,7 +808,9 @@ void analyze(gtg_context& c) {
         catch (...) { if (dfh.joinable()) dfh.join(); throw; }
         if (dfh.joinable()) dfh.join();
         if (dferr) std::rethrow_exception(dferr);
-        if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored);
+        clk.lap("tile schedules (task lists of both passes, two threads)");
+        if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored, dense ? nullptr : &sub16);
+        clk.lap("dataflow plan resolved to slots + uploaded");
       }
       for (int a = 0; a < nt; a++)
         for (int b = 0; b <= a; b++) if (dense || T1[(size_t)a * nt + b]) { ex.push_back(a); ex.push_back(b); }
@@ -798,11 +843,11 @@ void analyze(gtg_context& c) {
       }
       c.structure_hash = h;
     }
-    clk.lap("cholesky tile schedule");
+    clk.lap("exchange list + layout hash");
     if (clk.on) std::fprintf(stderr, "[gtsam_amd setup] reduced system n = %lld, %d tiles, stored tile fraction %.3f, %.3f GFLOP per factorisation, critical path %d of %d column pairs\n",
                              (long long)c.n_red, nt, c.plan.dense_fraction, c.plan.flops * 1e-9, c.plan.critical_pairs, np2);
-    if (clk.on && c.use_df) std::fprintf(stderr, "[gtsam_amd setup] dataflow plan: %lld tasks, %.3f GFLOP over the stored tiles (fraction %.3f), %d chain workgroups, longest chain slot %d of %d diagonal tiles\n",
-                                         (long long)c.df.n_tasks, c.df.flops * 1e-9, c.df.dense_fraction, c.df.n_chain, c.df.critical_tiles, nt);
+    if (clk.on && c.use_df) std::fprintf(stderr, "[gtsam_amd setup] dataflow plan: %lld tasks, %.3f GFLOP over the stored tiles (fraction %.3f; %.3f GFLOP after skipping structurally empty 16 x 16 sub-tiles), %d chain workgroups, longest chain slot %d of %d diagonal tiles\n",
+                                         (long long)c.df.n_tasks, c.df.flops * 1e-9, c.df.dense_fraction, c.df.flops_executed * 1e-9, c.df.n_chain, c.df.critical_tiles, nt);
     // keep the nested-dissection ordering only where it pays: the chains must get clearly shorter and the problem must be
     // in the latency-bound regime (separators cost fill: on the L1723 shape +60 % flops for a 30 % shorter path)
     if (!part_of_pos.empty() && !nd_forced) {

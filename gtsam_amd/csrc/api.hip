@@ -934,6 +934,7 @@ int gtg_get_phase_ms(gtg_handle c, double* ms, int64_t* calls, int n) {
   return GTG_OK;
 }
 double gtg_cholesky_flops(gtg_handle c) { return c ? c->chol_flops : 0.0; }
+double gtg_cholesky_flops_executed(gtg_handle c) { return !c ? 0.0 : (c->use_df && c->df.flops_executed > 0.0) ? c->df.flops_executed : c->chol_flops; }
 double gtg_cholesky_flops_block_level(gtg_handle c) {
   if (!c) return 0.0;
   try { join_block_level(*c); } catch (...) { return 0.0; }

@@ -47,6 +47,7 @@ constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of 
 // try is then repeated with the other schedule, api.hip) -- the bound used to be 4 M polls, more than a second per stuck wait.
 constexpr long long kWaitTicks = 2000000;
 constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finished pieces of the tile's contraction (< kPieceBase pieces per tile)
+constexpr int kStepWords = 6;      // words of a contraction step in the device klist: slots of (I, k), (J, k), their two 64-bit sub-tile masks
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
 constexpr size_t kSmemPotrf = sizeof(double) * kPotrfSmemDoubles;
@@ -195,12 +196,15 @@ __device__ __forceinline__ int wait_progress(const long long* f1, const long lon
 // Panel chunks (128 rows x 16 columns of L(I,k) and of L(J,k)) go L2/HBM -> LDS by LDS-DMA, double buffered, 16-byte slots
 // XOR-swizzled on the source address and on the operand reads.
 constexpr int kBulkThreads = 1024;
-// wavefront -> (row tile, column half).  Wavefronts go to the four SIMDs of the CU with period four, and the substitution's later steps
-// occupy the wavefronts of ONE column half only (blocks 2, 3: half 1): with h = wave & 1 (rounds 2 - 5) those eight wavefronts shared
-// two SIMDs and the other two matrix pipes idled -- 2.8 us for the 32 MFMAs of step 2 (profiles/r06t_substitution_steps.txt).  With h taken
-// from bit 2 every SIMD holds two wavefronts of each half.
-__device__ __forceinline__ int bulk_rt(int wave) { return (wave & 3) + 4 * (wave >> 3); }
-__device__ __forceinline__ int bulk_h(int wave) { return (wave >> 2) & 1; }
+// wavefront -> (row tile, column half).  Wavefronts go to the four SIMDs of the CU with period four.  Two things are wanted of the
+// wavefronts that share a SIMD: (i) both column halves -- the substitution's later steps occupy ONE half only (blocks 2, 3: half 1); with
+// h = wave & 1 (rounds 2 - 5) those eight wavefronts shared two SIMDs and the other two matrix pipes idled, 2.8 us for the 32 MFMAs of
+// step 2 (profiles/r06t_substitution_steps.txt); (ii) row tiles that lie apart -- the structurally empty sub-tiles of an operand tile are
+// a staircase (the rows near the band's edge start further right), so the row tiles with work in a 16-column strip are a prefix 0 .. n-1,
+// and a SIMD that holds two neighbouring row tiles in both halves is fully busy as soon as n > 4.  SIMD s holds the row tiles
+// s & 1, 2 + (s & 1), 4 + (s & 1), 6 + (s & 1) with alternating halves.
+__device__ __forceinline__ int bulk_rt(int wave) { return 2 * (wave >> 2) + (wave & 1); }
+__device__ __forceinline__ int bulk_h(int wave) { return ((wave >> 2) + (wave >> 1)) & 1; }
 
 template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
@@ -318,7 +322,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 
 
 __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD, int G, int scratch,
-                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces, bool rhs_row,
+                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
                                          double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
@@ -414,14 +418,32 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
     stage(Ak, Bk, 0, 0);
     __syncthreads();
     const int a_row_off = (16 * rt + lr) * ROWB, b_row_off = (64 * h + lr) * ROWB;
-    // The right-hand-side row (tile row nt: the forward solve rides along with the factorisation) has ONE non-zero row: only the wavefronts of
-    // row tile 0 multiply -- the other fourteen kept the matrix pipes busy with zeros, 6 % of the bulk kernel's resident time on L1723
-    // (tools/df_wait_analysis.py).  Their accumulators are and stay zero either way.
-    const bool idle_rows = rhs_row && rt != 0;
+    // Structural zeros inside the operand tiles (round 6).  A stored 128 x 128 tile is rarely full: at the granularity of MFMA tiles the
+    // contraction steps of the L1723 shape carry 21 % structurally-zero products (tools/df_subtile_count.py).  Every step brings the
+    // 8 x 8-bit masks of its two operand tiles (strip-level symbolic factorisation, analysis.hip); per 16-column strip a wavefront
+    // multiplies only if ITS 16 rows of L(I, k) can be non-zero there, and only into the column tiles t whose rows of L(J, k) can: `live`
+    // holds those four bits for each of the eight strips.  A skipped product is a sum of exact zeros: the factor is unchanged.  (The
+    // right-hand-side row, tile row nt, is the extreme case: one live row tile -- fourteen wavefronts multiplied zeros, 6 % of the bulk
+    // kernel's resident time, tools/df_wait_analysis.py.)
+    auto live_bits = [&](const int32_t* w) {
+      const unsigned long long ma = (unsigned)w[2] | ((unsigned long long)(unsigned)w[3] << 32), mb = (unsigned)w[4] | ((unsigned long long)(unsigned)w[5] << 32);
+      const unsigned arow = (unsigned)(ma >> (8 * rt)) & 0xFFu;
+      unsigned lv = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const unsigned bcol = (unsigned)(mb >> (8 * (4 * h + t))) & 0xFFu & arow;   // strips where column tile t of this wavefront has work
+#pragma unroll
+        for (int sp = 0; sp < 8; sp++) lv |= ((bcol >> sp) & 1u) << (4 * sp + t);
+      }
+      return __builtin_amdgcn_readfirstlane(lv);
+    };
+    unsigned live = live_bits(kl);
     const int half = (lk & 1) * 8, hi = lk >> 1, sw = lr;
     for (int ki = 0; ki < kcnt; ki++) {
       // the flags of the next contraction step, fetched a whole step ahead of their use
-      const int kna = (ki + 1 < kcnt) ? kl[2 * ki + 2] : ka, knb = (ki + 1 < kcnt) ? kl[2 * ki + 3] : kb;
+      const int32_t* kn = kl + kStepWords * (ki + 1 < kcnt ? ki + 1 : ki);
+      const int kna = kn[0], knb = kn[1];
+      const unsigned live_next = live_bits(kn);
       int np = tile_progress(tile_flag + kna, tile_flag + knb, flagbase);
       const double* An = S + (int64_t)kna * TT;
       const double* Bn = S + (int64_t)knb * TT;
@@ -438,21 +460,34 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
         }
         const char* Ac = smem_raw + cur * 2 * CH;
         const char* Bc = Ac + CH;
-        if (!idle_rows) {
 #pragma unroll
-          for (int kk = 0; kk < KC; kk += 4) {
-            const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
-            const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));   // (single 8-byte reads: chol_device.h::lds_ld)
-            double b[4];
+        for (int sp = 0; sp < KC / kSub; sp++) {   // the chunk's two 16-column strips
+          const unsigned m = (live >> (4 * (ch * (KC / kSub) + sp))) & 15u;
+          if (m == 15u) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) b[t] = lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so));
+            for (int kk = kSub * sp; kk < kSub * (sp + 1); kk += 4) {
+              const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
+              const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));   // (single 8-byte reads: chol_device.h::lds_ld)
+              double b[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
+              for (int t = 0; t < 4; t++) b[t] = lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so));
+#pragma unroll
+              for (int t = 0; t < 4; t++) x[t] = MFMA(a, b[t], x[t]);
+            }
+          } else if (m != 0u) {
+#pragma unroll
+            for (int kk = kSub * sp; kk < kSub * (sp + 1); kk += 4) {
+              const int so = (((kk >> 1) + hi) ^ sw) * 16 + half;
+              const double a = -lds_ld(reinterpret_cast<const double*>(Ac + a_row_off + so));
+#pragma unroll
+              for (int t = 0; t < 4; t++)
+                if (m & (1u << t)) x[t] = MFMA(a, lds_ld(reinterpret_cast<const double*>(Bc + b_row_off + t * 16 * ROWB + so)), x[t]);
+            }
           }
         }
         __syncthreads();   // drains the DMA of the next chunk (vmcnt) and fences the buffer just read
       }
-      ka = kna; kb = knb; Ak = An; Bk = Bn; cp = np;
+      ka = kna; kb = knb; Ak = An; Bk = Bn; cp = np; live = live_next;
     }
   }
   if (tr && tid == 0) { tr[1] = wall_clock64(); tr[3] |= waited << 40; }   // (bits 40..: ticks waited; below: where the workgroup runs)
@@ -500,7 +535,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot, [10]: the tile is a right-hand-side row
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -508,7 +543,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + 2 * (int64_t)d[2], d[3], d[4], d[5], d[10] != 0, tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + kStepWords * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -890,7 +925,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   df.h_has_sub = has_sub;
 }
 
-void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots) {
+void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16) {
   const int nt = df.nt;
   const std::vector<int32_t>& has_sub = df.h_has_sub;
   // Device form: tiles AND their flag words are addressed by SLOT (context.h::SMat; the slots come from the stream schedule's plan,
@@ -918,7 +953,11 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       df.n_scratch += G - 1;
     }
     std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 12);
-    std::vector<int32_t> dk(2 * df.h_klist.size(), 0);
+    std::vector<int32_t> dk(kStepWords * df.h_klist.size(), 0);
+    // sub-tile masks of a contraction step's operand tiles (analysis.hip: strip-level symbolic factorisation; none = every sub-tile): the
+    // right-hand-side row has one row of sub-tiles
+    auto mask_of = [&](int I, int k) -> uint64_t { return I >= nt ? 0xFFull : sub16 ? (*sub16)[(size_t)I * nt + k] : ~0ull; };
+    double skipped = 0.0;
     std::vector<uint8_t> seen(df.h_klist.size(), 0);
     for (int64_t t = 0; t < df.n_tasks; t++) {
       const int32_t* d = df.h_tasks.data() + 6 * t;
@@ -926,16 +965,29 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
       { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
-      dt.push_back(I == nt ? 1 : 0);   // right-hand-side row: one non-zero row (run_task)
-      dt.push_back(0);
+      dt.push_back(0); dt.push_back(0);
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
-        dk[2 * (size_t)e] = slot_of(I, k); dk[2 * (size_t)e + 1] = slot_of(J, k);
+        int32_t* w = dk.data() + kStepWords * (size_t)e;
+        const uint64_t ma = mask_of(I, k), mb = mask_of(J, k);
+        w[0] = slot_of(I, k); w[1] = slot_of(J, k);
+        w[2] = (int32_t)(uint32_t)ma; w[3] = (int32_t)(uint32_t)(ma >> 32); w[4] = (int32_t)(uint32_t)mb; w[5] = (int32_t)(uint32_t)(mb >> 32);
+        if (!seen[e]) {   // MFMAs the step leaves out: per 16-column strip (row tiles with a live A sub-tile) x (column tiles with a live B sub-tile), 4 each
+          int live = 0;
+          for (int sp = 0; sp < 8; sp++) {
+            int ra = 0, cb = 0;
+            for (int r = 0; r < 8; r++) { ra += (int)((ma >> (8 * r + sp)) & 1); cb += (int)((mb >> (8 * r + sp)) & 1); }
+            live += 4 * ra * cb;
+          }
+          const int rows = I >= nt ? 1 : 8;   // (the flop count has always taken the right-hand-side row as a full tile row; its 7 idle row tiles are not counted as skipped work here)
+          skipped += (I == J ? 0.5 : 1.0) * (double)(4 * 8 * rows * 8 - live) * 2048.0 * (I >= nt ? 0.0 : 1.0);
+        }
         seen[e] = 1;
       }
     }
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
+    df.flops_executed = df.flops - skipped;
     std::vector<int32_t> cs(3 * (size_t)nt, -1);
     for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); }
     df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, one spare word)

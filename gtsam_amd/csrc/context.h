@@ -24,6 +24,7 @@ namespace gt {
 
 constexpr int kTile = 128;  // dense tile / panel width of the reduced-system Cholesky
 constexpr int kTileDoubles = kTile * kTile;
+constexpr int kSub = 16;    // granularity of the structural masks of a tile (one MFMA tile: 8 x 8 bits per 128 x 128 tile; DfPlan, analysis.hip)
 
 // ---- storage of the reduced system: BY TILES -----------------------------------------------------------------------------
 // Every 128 x 128 tile of the lower triangle that the symbolic factorisation says can become non-zero (fill included), and every
@@ -102,7 +103,8 @@ struct DfPlan {
   DevBuf<long long> part_flag;                  // (nt + 1) x nt: kPieceBase epoch + pieces of the tile's contraction that are in
   DevBuf<int32_t> has_sub;                      // per diagonal tile J: tile (J, J-1) is stored (its update is streamed by the chain kernel)
   std::vector<int32_t> h_has_sub;
-  DevBuf<int32_t> klist;                        // contraction lists: the column tiles k < J with both (I, k) and (J, k) stored
+  DevBuf<int32_t> klist;                        // contraction lists: the column tiles k < J with both (I, k) and (J, k) stored; 6 words per step: the two slots, then the
+                                                // 64-bit sub-tile masks of (I, k) and (J, k) (bit 8 r + q: rows 16 r.., columns 16 q.. can be non-zero)
   DevBuf<long long> tile_flag;                  // (nt + 1) x nt: epoch in which the tile became final
   DevBuf<long long> pd_flag;                    // nt: epoch in which the diagonal tile received all its updates
   int64_t shadow = 0;                           // every flag is also stored `shadow` words behind its word (chol_dataflow.hip::st_flag)
@@ -116,6 +118,7 @@ struct DfPlan {
   std::vector<int32_t> h_chain_off, h_chain_tiles, h_seq;   // h_seq: the order in which the block columns are taken (ticket groups)
   int critical_tiles = 0;                       // diagonal tiles of the longest slot
   double flops = 0.0, dense_fraction = 1.0;
+  double flops_executed = 0.0;                  // flops minus the contraction MFMAs skipped on structurally empty 16 x 16 sub-tiles (upload_df_plan)
 };
 
 struct FactorTables {

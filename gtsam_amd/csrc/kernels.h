@@ -60,7 +60,7 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
                    const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct,             // the host half (no runtime call)
                         const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
-void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots);   // the device half
+void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16 = nullptr);   // the device half
 void free_df_plan(DfPlan& df);
 bool dataflow_schedule_selected();   // false: GTG_CHOL=streams (the stream / event schedule of cholesky.hip, the A/B of the dataflow pass)
 void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,

@@ -27,7 +27,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_prewarm", "gtg_last_error", "gtg_ve
            "gtg_accept", "gtg_get_delta", "gtg_get_gradient", "gtg_get_hessian_diagonal",
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
-           "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
+           "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_cholesky_flops_executed", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
            "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_cached_memory_bytes", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal",
            "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o",
@@ -64,6 +64,8 @@ def load():
     lib.gtg_cholesky_flops.restype = C.c_double
     lib.gtg_cholesky_flops.argtypes = [C.c_void_p]
     lib.gtg_cholesky_flops_block_level.restype = C.c_double
+    lib.gtg_cholesky_flops_executed.restype = C.c_double
+    lib.gtg_cholesky_flops_executed.argtypes = [C.c_void_p]
     lib.gtg_cholesky_flops_block_level.argtypes = [C.c_void_p]
     lib.gtg_linearize_bytes.restype = C.c_double
     lib.gtg_linearize_bytes.argtypes = [C.c_void_p]
@@ -241,6 +243,7 @@ class DeviceGraph:
 
     def cholesky_flops(self): return self.lib.gtg_cholesky_flops(self.h)
     def cholesky_flops_block_level(self): return self.lib.gtg_cholesky_flops_block_level(self.h)
+    def cholesky_flops_executed(self): return self.lib.gtg_cholesky_flops_executed(self.h)
     def structure_hash(self): return int(self.lib.gtg_structure_hash(self.h))
     def linearize_bytes(self): return self.lib.gtg_linearize_bytes(self.h)
 

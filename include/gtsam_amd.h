@@ -260,6 +260,10 @@ double gtg_cholesky_flops(gtg_handle h);
  * of f^3/3 + f^2 s + f s^2 -- the flops a perfectly sparse elimination would need; gtg_cholesky_flops() counts what the 128x128
  * tile kernels execute (zeros inside stored tiles included) */
 double gtg_cholesky_flops_block_level(gtg_handle h);
+/* What the dataflow factorisation executes: gtg_cholesky_flops() minus the contraction products it skips because one of their 16 x 16
+ * operand sub-tiles is structurally zero (strip-level symbolic factorisation; round 6).  Equal to gtg_cholesky_flops() for the stream
+ * schedule and for dense plans. */
+double gtg_cholesky_flops_executed(gtg_handle h);
 /* identity (63-bit hash) of the layout of the reduced system: elimination order of the reduced variables, their offsets,
  * padding, tile structure and the list of exchanged tiles.  It is derived from the WHOLE graph, so every shard of one job
  * reports the same value; gtg_upload_problem verifies that through the all-reduce callback and fails if they differ. */

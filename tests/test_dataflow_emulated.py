@@ -56,7 +56,9 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
                 m -= 1
             R = (m + k_piece - 1) // k_piece + 1
             off = len(klist)
-            klist += [(slot[(I, k)], slot[(J, k)]) for k in ks]
+            # a contraction step: the slots of its operand tiles (I, k), (J, k) and their 64-bit sub-tile masks (dense system: every 16 x 16
+            # sub-tile; the right-hand-side row has one row of them), chol_dataflow.hip::kStepWords
+            klist += [(slot[(I, k)], slot[(J, k)], 0xFF if I == nt else -1, 0 if I == nt else -1, -1, -1) for k in ks]
             gprev = 0
             for r in range(R - 1):
                 b, e = r * k_piece, min(m, (r + 1) * k_piece)
@@ -80,7 +82,7 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
     for J in range(nt):
         chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1]
     t0 = list(range(0, nt, 2)); t1 = list(range(1, nt, 2))
-    return dict(slot=slot, n_slots=n_slots, n_scratch=n_scratch, tasks=np.array(tasks, np.int32), klist=np.array(klist, np.int32).reshape(-1, 2),
+    return dict(slot=slot, n_slots=n_slots, n_scratch=n_scratch, tasks=np.array(tasks, np.int32), klist=np.array(klist, np.int64).astype(np.int32).reshape(-1, 6),
                 chain_slots=np.array(chain_slots, np.int32), chain_off=np.array([0, len(t0), nt], np.int32), chain_tiles=np.array(t0 + t1, np.int32),
                 max_pieces=max(t[5] for t in order), lanes=lanes)
 

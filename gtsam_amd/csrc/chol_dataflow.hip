@@ -628,13 +628,16 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
         if (tid < 64 && q < 3) seen = ld_flag(sflag);   // in flight under the slice tasks
         if (q == 3) {
           // The LAST slice is on the serial chain of the factorisation (the tile left of this one became final a moment ago): only its
-          // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- is applied here (2 rounds of MFMA
-          // tiles instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4
+          // contribution to the four blocks (ib, 0) -- all that panel 0 of the diagonal tile reads -- and to (1,1), (2,1) is applied here (3 MFMA
+          // tiles per wavefront instead of 5), the rest inside potrf_body under panel 0's pivot chain (Xdef).  Bit-identical; measured in round 4
           // (5.12 -> 5.07 ms on L1723, profiles/r04_df_defer_ab.txt) and again in round 5 (profiles/r05a_variants_ab.txt).
-          {   // 16 tiles, two per wavefront
+          {   // 16 tiles of the blocks (ib, 0), two per wavefront, then one each of the blocks (1,1) and (2,1), which the update of panel 1 reads
+            // (8 more tiles here cost 0.6 us; left to potrf_body's panel 0 they needed a third wavefront there, on the pivot chain's SIMD)
             const int t = wave, u = wave + 8;
             const TilePatch p0 = slice_patch(A, X, t >> 2, 0, (t >> 1) & 1, t & 1), p1 = slice_patch(A, X, u >> 2, 0, (u >> 1) & 1, u & 1);
             upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
+            const TilePatch p2 = slice_patch(A, X, 1 + (wave >> 2), 1, (wave >> 1) & 1, wave & 1);
+            upd_tiles2(p2.C, p2.A, p2.B, p2.C, p2.A, p2.B, false, lr, lk);
           }
           deferred = true;
         } else {

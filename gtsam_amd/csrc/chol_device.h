@@ -525,7 +525,11 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
   double* rs = rinvs + T;                             // [T]  1 / sqrt(pivot), (parity, index) order inside a panel
   double* lines = rs + T;                             // [SB][SB] published columns of the current panel + 64 trash
   int* prog = reinterpret_cast<int*>(lines + kLineTrash + 64);   // [0] pivots published so far (monotonic over the tile), [1] panels whose rs are published
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the roles below are scalar branches)
+  // (the thread index is laundered per call: what is derived from it is recomputed for every tile instead of being hoisted out of the chain
+  // kernel's tile loop, spilled -- the kernel uses all 256 registers -- and reloaded here one scratch round trip after the other)
+  int tid_ = threadIdx.x;
+  GT_PIN(tid_);
+  const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the roles below are scalar branches)
   const int wave_hw = wave; (void)wave_hw;
   const int lr = lane & 15, lk = lane >> 4;
   // critical-path kernel: win issue arbitration against co-resident k_syrk waves, and the chain wavefront against
@@ -550,22 +554,25 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     if (wave == 0) {
       stage_potrf(A, rinvs, rs, lines, prog, jb, lane, fail, pk, prev_exp);
       if (jb == 3 && tile_exp && lane == 0) st_pub(tile_exp + k, __longlong_as_double((long long)prev_exp), true);
-    } else if (wave == 4 && !(jb == 0 && Xdef)) {
-      // idle: wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound (except in panel 0 of the dataflow
-      // chain, where it takes a third of the deferred slice tasks: MFMAs, one issue slot per 64 cycles)
+    } else if (wave == 4) {
+      // wavefront 4 shares SIMD 0 with the chain wavefront (wave id mod 4), which is issue bound: no arithmetic here (a third of panel 0's
+      // deferred slice tasks, MFMAs, was tried in round 6: the chain wavefront's 32 pivots then take 6.2 us instead of 3.7), only its share of
+      // the previous panel's write-back
+      if (jb > 0) { __builtin_amdgcn_s_setprio(1); store_column(A, tile, Xinv, jb - 1, (2 + jb) * 64 + lane, (3 + jb) * 64, wt); }
     } else if (wave <= nfol || wave == 5) {
       stage_follow(A, lines, rinvs, rs, prog, jb, wave == 5 ? -1 : jb + wave, lane, Xinv + (int64_t)jb * SB * SB, Xinv + kOpndBase, wt,
                    dbg && jb == 2 && (wave_hw == 1 || wave_hw == 5 || wave_hw == 7) ? dbg + 48 + 4 * (wave_hw == 1 ? 0 : wave_hw == 5 ? 1 : 2) : nullptr);
     } else if (jb == 0) {
       __builtin_amdgcn_s_setprio(1);   // deferred work yields issue slots to the followers it shares a SIMD with
-      // (the wavefronts 4, 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that panel 0 does not
-      // read -- the chain kernel passes the slice as Xdef, chol_dataflow.hip::chain_loop -- runs here, under panel 0's pivots)
+      // (the wavefronts 6 and 7 have nothing of their own to do in panel 0: the part of the last slice's update that neither panel 0 nor the
+      // update of panel 1 reads -- the blocks (2,2), (3,1), (3,2), (3,3); the chain kernel passes the slice as Xdef and has applied it to the
+      // blocks (ib, 0), (1,1), (2,1) itself, chol_dataflow.hip::chain_loop -- runs here, under panel 0's pivots)
       if (Xdef)
-        for (int t = (wave == 4 ? 2 : wave - 6); t < 24; t += 6) {         // blocks (ib, cb), 1 <= cb <= ib: (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), x 4 MFMA tiles; two tiles at a time
-          const int b2 = (t >> 2) * 2, u = t + 3, c2 = (u >> 2) * 2;
+        for (int t = 8 + (wave - 6); t < 24; t += 4) {   // tile t: block t / 4 of (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), MFMA tile t % 4; two at a time
+          const int b2 = (t >> 2) * 2, u = t + 2, c2 = (u >> 2) * 2;
           const TilePatch p0 = slice_patch(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1);
           const TilePatch p1 = slice_patch(A, Xdef, (0xFE9 >> c2) & 3, (0xE65 >> c2) & 3, (u >> 1) & 1, u & 1);
-          upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, u < 24, lr, lk);
+          upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
         }
     } else if (jb > 0) {
       __builtin_amdgcn_s_setprio(1);   // (see above)
@@ -574,6 +581,11 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       // updates of the blocks right of panel pj+1 (those of panel pj+1 itself were done in P3, before its followers
       // started): blocks (ib, cb), pj+2 <= cb <= ib
       const int nb = 3 - pj, ntask = (nb * (nb - 1) / 2) * 4;
+      if (ntask == 4 * nh) {                             // (panel 1: three blocks for three wavefronts) a whole 32 x 32 block each
+        int bi, rem;
+        lower_block(hw, bi, rem);
+        upd_block4(A + boff(pj + 2 + bi, pj + 2 + rem), A + boff(pj + 2 + bi, pj), A + boff(pj + 2 + rem, pj), lr, lk);
+      } else
       for (int t = hw; t < ntask; t += 2 * nh) {         // two tiles at a time
         const int u = t + nh < ntask ? t + nh : t;
         int bi, rem, bi1, rem1;                          // (bi, rem): 0 <= rem <= bi < nb - 1
@@ -582,7 +594,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
         const TilePatch p1 = tile_patch(A, pj, pj + 2 + bi1, pj + 2 + rem1, (u >> 1) & 1, u & 1);
         upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, u != t, lr, lk);
       }
-      store_column(A, tile, Xinv, pj, hw * 64 + lane, nh * 64, wt);
+      store_column(A, tile, Xinv, pj, hw * 64 + lane, (nh + 1) * 64, wt);   // (wavefront 4 is the last share)
     }
     // Panel jb is released to the workgroups waiting for it (the TRSM workgroups of this launch / the substitutions of the dataflow
     // schedule) once its inverse and every L(jb, q<jb) operand image are in memory.
@@ -624,7 +636,11 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
     }
     STAMP(4 + 3 * jb);
   }
-  store_column(A, tile, Xinv, 3, tid, 512, wt);
+  // (the thread index is laundered: left visible, this block's LDS address is computed once per kernel, spilled, and reloaded here behind an
+  // s_waitcnt vmcnt(0) that also waits for every store of the tile that is still in flight -- 0.4 us at the end of the serial chain's link)
+  int tl = tid;
+  GT_PIN(tl);
+  store_column(A, tile, Xinv, 3, tl, 512, wt);
   STAMP(14);
 }
 

@@ -47,6 +47,7 @@ constexpr int PX = SB + 2;        // LDS pitch (doubles) of a 128 x 32 block of 
 // try is then repeated with the other schedule, api.hip) -- the bound used to be 4 M polls, more than a second per stuck wait.
 constexpr long long kWaitTicks = 2000000;
 constexpr long long kPieceBase = 4096;   // part_flag = kPieceBase epoch + finished pieces of the tile's contraction (< kPieceBase pieces per tile)
+constexpr int kChainWords = 4;     // words per diagonal tile in the chain kernel's table: slot of (J, J), slot of (J, J-1) or -1, the 64-bit sub-tile mask of (J, J-1)
 constexpr int kStepWords = 6;      // words of a contraction step in the device klist: slots of (I, k), (J, k), their two 64-bit sub-tile masks
 constexpr int kImgDoubles = 2 * 64 * 8;   // one MFMA operand image of a 32x32 block (chol_device.h opnd_off): 8 KB
 constexpr size_t kSmemBulk = std::max<size_t>(4 * (size_t)CH, sizeof(double) * (T * PX + 4 * kImgDoubles));
@@ -584,17 +585,25 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
     __syncthreads();
     acquired();
     if (tid == 0) { atomicAdd(ctrl + 1, 1); if (trace) trace[2 * J] = wall_clock64(); }   // debug: diagonal tiles started (all chains)
-    const int dslot = chain_slots[3 * J];   // slot of (J, J); [3 J + 1]: of (J, J-1) (-1: not stored)
+    const int dslot = chain_slots[kChainWords * J];   // slot of (J, J); [+ 1]: of (J, J-1) (-1: not stored); [+ 2, + 3]: that tile's sub-tile mask
     double* tile = S + (int64_t)dslot * TT;
     bool deferred = false;
     long long* sdbg = stamps ? stamps + 64 * (int64_t)J : nullptr;
     diag_tile_to_lds<GTG_DF_FENCES == 0>(tile, A, tid);   // PD(J)'s result, handed over by a bulk workgroup
     // The update of the block column right before this tile is applied HERE, in 32-column slices as the substitution of tile (J, J-1)
     // publishes them (the last slice is the only thing left when that tile is final).
-    const int sslot = chain_slots[3 * J + 1];
+    const int sslot = chain_slots[kChainWords * J + 1];
     if (sslot >= 0) {
       const double* sub = S + (int64_t)sslot * TT;   // tile (J, J-1)
       const long long* sflag = tile_flag + sslot;
+      // Sub-tile mask of tile (J, J-1) (analysis.hip): a 16 x 16 MFMA tile of the update C -= X_q X_q^T whose two operand patches have no
+      // 16-column strip of slice q in common is a sum of exact zeros and is left out.  On a camera system the tile next to the diagonal is
+      // full; on a pose graph a fifth of it is (sphere2500: 13.5 live sub-tiles of 64, w20000: 8).
+      const unsigned long long xmask = (unsigned)chain_slots[kChainWords * J + 2] | ((unsigned long long)(unsigned)chain_slots[kChainWords * J + 3] << 32);
+      auto live = [&](int q, int ra, int rb) {   // row strips ra, rb (16 rows each) of X, slice q = column strips 2 q, 2 q + 1
+        const unsigned a = (unsigned)(xmask >> (8 * ra + 2 * q)) & 3u, b = (unsigned)(xmask >> (8 * rb + 2 * q)) & 3u;
+        return (a & b) != 0u;
+      };
       long long seen = 0;   // the tile's progress word as last read (monotonic)
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
@@ -635,25 +644,30 @@ __device__ __forceinline__ void chain_loop(char* smem_raw, double* __restrict__ 
             // (8 more tiles here cost 0.6 us; left to potrf_body's panel 0 they needed a third wavefront there, on the pivot chain's SIMD)
             const int t = wave, u = wave + 8;
             const TilePatch p0 = slice_patch(A, X, t >> 2, 0, (t >> 1) & 1, t & 1), p1 = slice_patch(A, X, u >> 2, 0, (u >> 1) & 1, u & 1);
-            upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
-            const TilePatch p2 = slice_patch(A, X, 1 + (wave >> 2), 1, (wave >> 1) & 1, wave & 1);
-            upd_tiles2(p2.C, p2.A, p2.B, p2.C, p2.A, p2.B, false, lr, lk);
+            const bool l0 = live(3, 2 * (t >> 2) + ((t >> 1) & 1), t & 1), l1 = live(3, 2 * (u >> 2) + ((u >> 1) & 1), u & 1);
+            if (l0 && l1) upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
+            else if (l0) upd_tiles2(p0.C, p0.A, p0.B, p0.C, p0.A, p0.B, false, lr, lk);
+            else if (l1) upd_tiles2(p1.C, p1.A, p1.B, p1.C, p1.A, p1.B, false, lr, lk);
+            const int ib2 = 1 + (wave >> 2);
+            const TilePatch p2 = slice_patch(A, X, ib2, 1, (wave >> 1) & 1, wave & 1);
+            if (live(3, 2 * ib2 + ((wave >> 1) & 1), 2 + (wave & 1))) upd_tiles2(p2.C, p2.A, p2.B, p2.C, p2.A, p2.B, false, lr, lk);
           }
           deferred = true;
         } else {
           {   // 10 lower blocks: one whole block per wavefront (0 .. 7), then one tile each of the blocks 8 and 9
             int ib, cb;
             lower_block(wave, ib, cb);
-            upd_block4(A + boff(ib, cb), X + ib * SB * PB, X + cb * SB * PB, lr, lk);
+            if (live(q, 2 * ib, 2 * cb) || live(q, 2 * ib, 2 * cb + 1) || live(q, 2 * ib + 1, 2 * cb) || live(q, 2 * ib + 1, 2 * cb + 1))
+              upd_block4(A + boff(ib, cb), X + ib * SB * PB, X + cb * SB * PB, lr, lk);
             lower_block(8 + (wave >> 2), ib, cb);
             const TilePatch p0 = slice_patch(A, X, ib, cb, (wave >> 1) & 1, wave & 1);
-            upd_tiles2(p0.C, p0.A, p0.B, p0.C, p0.A, p0.B, false, lr, lk);
+            if (live(q, 2 * ib + ((wave >> 1) & 1), 2 * cb + (wave & 1))) upd_tiles2(p0.C, p0.A, p0.B, p0.C, p0.A, p0.B, false, lr, lk);
           }
         }
       }
     }
     potrf_body(smem_raw, tile, J, Xinv_all + (size_t)J * T * T, fail, stamps ? stamps + 64 * (int64_t)J : nullptr, epoch, tile_flag + dslot, 0, true, GTG_DF_FENCES == 0, pivot_kind, tile_exp,
-               deferred ? X : nullptr);
+               deferred ? X : nullptr, deferred ? chain_slots[kChainWords * J + 2] : -1, deferred ? chain_slots[kChainWords * J + 3] : -1);
     __syncthreads();
     if (trace && tid == 0) trace[2 * J + 1] = wall_clock64();
   }
@@ -991,9 +1005,16 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
     df.flops_executed = df.flops - skipped;
-    std::vector<int32_t> cs(3 * (size_t)nt, -1);
-    for (int J = 0; J < nt; J++) { cs[3 * J] = slot_of(J, J); if (has_sub[J] & 1) cs[3 * J + 1] = slot_of(J, J - 1); }
-    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: slot of (J, J), slot of (J, J-1) or -1, one spare word)
+    std::vector<int32_t> cs(kChainWords * (size_t)nt, -1);
+    for (int J = 0; J < nt; J++) {
+      cs[kChainWords * J] = slot_of(J, J);
+      if (has_sub[J] & 1) {
+        cs[kChainWords * J + 1] = slot_of(J, J - 1);
+        const uint64_t m = mask_of(J, J - 1);
+        cs[kChainWords * J + 2] = (int32_t)(uint32_t)m; cs[kChainWords * J + 3] = (int32_t)(uint32_t)(m >> 32);
+      }
+    }
+    df.has_sub.upload(cs.data(), cs.size(), stream);   // (per diagonal tile: kChainWords)
     check_hip(hipStreamSynchronize(stream), "df plan upload");
   }
   df.chain_off.upload(df.h_chain_off.data(), df.h_chain_off.size(), stream);

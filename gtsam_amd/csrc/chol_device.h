@@ -514,7 +514,7 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
                                            double* __restrict__ fail, long long* __restrict__ dbg,
                                            long long epoch, long long* __restrict__ pflag, long long pflag_shadow, bool preloaded = false, bool wt = false,
                                            const unsigned char* __restrict__ pivot_kind = nullptr, double* __restrict__ tile_exp = nullptr,
-                                           const double* Xdef = nullptr) {
+                                           const double* Xdef = nullptr, int xmask_lo = -1, int xmask_hi = -1) {
   // (Xdef: the dataflow chain kernel only -- the last 32-column slice of the tile left of this one, in LDS, of which the blocks (ib, cb),
   // cb >= 1, are still to be applied; see chain_loop.  nullptr: nothing deferred)
   const long long flagbase = epoch * 8;   // progress words are monotonic over factorisations: no reset.  The epoch is a kernel ARGUMENT
@@ -570,9 +570,17 @@ __device__ __forceinline__ void potrf_body(char* smem_raw, double* __restrict__ 
       if (Xdef)
         for (int t = 8 + (wave - 6); t < 24; t += 4) {   // tile t: block t / 4 of (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), MFMA tile t % 4; two at a time
           const int b2 = (t >> 2) * 2, u = t + 2, c2 = (u >> 2) * 2;
-          const TilePatch p0 = slice_patch(A, Xdef, (0xFE9 >> b2) & 3, (0xE65 >> b2) & 3, (t >> 1) & 1, t & 1);
-          const TilePatch p1 = slice_patch(A, Xdef, (0xFE9 >> c2) & 3, (0xE65 >> c2) & 3, (u >> 1) & 1, u & 1);
-          upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
+          const int ib0 = (0xFE9 >> b2) & 3, cb0 = (0xE65 >> b2) & 3, ib1 = (0xFE9 >> c2) & 3, cb1 = (0xE65 >> c2) & 3;
+          const TilePatch p0 = slice_patch(A, Xdef, ib0, cb0, (t >> 1) & 1, t & 1);
+          const TilePatch p1 = slice_patch(A, Xdef, ib1, cb1, (u >> 1) & 1, u & 1);
+          // (xmask: the sub-tile mask of the tile the slice belongs to, chol_dataflow.hip::chain_loop -- a tile of the update whose two
+          // operand patches share no live 16-column strip of the last slice, strips 6 and 7, is left out)
+          const unsigned long long xm = (unsigned)xmask_lo | ((unsigned long long)(unsigned)xmask_hi << 32);
+          const bool l0 = ((xm >> (8 * (2 * ib0 + ((t >> 1) & 1)) + 6)) & (xm >> (8 * (2 * cb0 + (t & 1)) + 6)) & 3ull) != 0;
+          const bool l1 = ((xm >> (8 * (2 * ib1 + ((u >> 1) & 1)) + 6)) & (xm >> (8 * (2 * cb1 + (u & 1)) + 6)) & 3ull) != 0;
+          if (l0 && l1) upd_tiles2(p0.C, p0.A, p0.B, p1.C, p1.A, p1.B, true, lr, lk);
+          else if (l0) upd_tiles2(p0.C, p0.A, p0.B, p0.C, p0.A, p0.B, false, lr, lk);
+          else if (l1) upd_tiles2(p1.C, p1.A, p1.B, p1.C, p1.A, p1.B, false, lr, lk);
         }
     } else if (jb > 0) {
       __builtin_amdgcn_s_setprio(1);   // (see above)

@@ -80,7 +80,7 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
     tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) + [1 if t[0] == nt else 0, 0] for t in order]   # [10]: right-hand-side row
     chain_slots = []
     for J in range(nt):
-        chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1]
+        chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1, -1]   # + the sub-tile mask of (J, J-1): dense
     t0 = list(range(0, nt, 2)); t1 = list(range(1, nt, 2))
     return dict(slot=slot, n_slots=n_slots, n_scratch=n_scratch, tasks=np.array(tasks, np.int32), klist=np.array(klist, np.int64).astype(np.int32).reshape(-1, 6),
                 chain_slots=np.array(chain_slots, np.int32), chain_off=np.array([0, len(t0), nt], np.int32), chain_tiles=np.array(t0 + t1, np.int32),

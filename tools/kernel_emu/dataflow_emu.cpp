@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   double* Xinv = shared_alloc<double>((size_t)nt * kTileDoubles);
   int32_t* tasks = shared_alloc<int32_t>((size_t)12 * n_tasks);
   int32_t* klist = shared_alloc<int32_t>((size_t)6 * n_kp);   // 6 words per contraction step: two slots, two 64-bit sub-tile masks (chol_dataflow.hip::kStepWords)
-  int32_t* chain_slots = shared_alloc<int32_t>((size_t)3 * nt);
+  int32_t* chain_slots = shared_alloc<int32_t>((size_t)4 * nt);   // chol_dataflow.hip::kChainWords
   int32_t* chain_off = shared_alloc<int32_t>((size_t)n_chain + 1);
   int32_t* chain_tiles = shared_alloc<int32_t>((size_t)nt);
   long long* tile_flag = shared_alloc<long long>((size_t)n_slots + sh + 8);
@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
   double* fail = shared_alloc<double>(2);
   auto rd = [&](void* p, size_t bytes) { if (bytes && std::fread(p, 1, bytes, f) != bytes) { std::fprintf(stderr, "short input\n"); std::exit(2); } };
   rd(S, sizeof(double) * (size_t)n_slots * kTileDoubles); rd(tasks, 4 * (size_t)12 * n_tasks); rd(klist, 4 * (size_t)6 * n_kp);
-  rd(chain_slots, 4 * (size_t)3 * nt); rd(chain_off, 4 * ((size_t)n_chain + 1)); rd(chain_tiles, 4 * (size_t)nt);
+  rd(chain_slots, 4 * (size_t)4 * nt); rd(chain_off, 4 * ((size_t)n_chain + 1)); rd(chain_tiles, 4 * (size_t)nt);
   std::fclose(f);
   ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1;
   const long long epoch = 1;

@@ -211,7 +211,9 @@ template <int H>
 __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double* __restrict__ C, int I, int J,
                                            long long* __restrict__ myflag, const long long* __restrict__ pflag, double* __restrict__ Xinv_all,
                                            double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg,
-                                           long long* __restrict__ tr) {
+                                           long long* __restrict__ tr, bool row_live) {
+  // (row_live: the 16 rows of this wavefront can be non-zero in tile (I, J) -- its sub-tile mask; a row tile without a live sub-tile stays
+  // exactly zero through the substitution and its wavefronts leave the MFMAs out: half of the row tiles of a pose graph's tiles)
   // ---- L(I,J) = R L(J,J)^-T: right-looking block substitution over the 32-column blocks q.
   // Step q runs when k_df_chain has released panel q of the diagonal tile (inverse of its diagonal block; the operand images
   // L(p, q-1), p >= q, are out by then as well):
@@ -274,8 +276,9 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
           const double2* op = reinterpret_cast<const double2*>(img + (p - q) * kImgDoubles + (t * 64 + lane) * 8);
 #pragma unroll
           for (int u = 0; u < 4; u++) { const double2 v = op[u]; bl[2 * u] = v.x; bl[2 * u + 1] = v.y; }
+          if (row_live)
 #pragma unroll
-          for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bl[s], x[2 * l + t]);
+            for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bl[s], x[2 * l + t]);
         }
       }
     }
@@ -301,8 +304,9 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 #pragma unroll
         for (int u = 0; u < 4; u++) { const double2 v = op[u]; bi[2 * u] = v.x; bi[2 * u + 1] = v.y; }
         x[2 * l + t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        if (row_live)
 #pragma unroll
-        for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bi[s], x[2 * l + t]);
+          for (int s = 0; s < 8; s++) x[2 * l + t] = MFMA(a[s], bi[s], x[2 * l + t]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // operand reads of R_q before -X_q overwrites the patch
 #pragma unroll
@@ -323,7 +327,7 @@ __device__ __forceinline__ void substitute(char* smem_raw, v4f64 (&x)[4], double
 
 
 __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S, int I, int J, int slotC, int slotD, int G, int scratch,
-                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces,
+                                         const int32_t* __restrict__ kl, int kcnt, int piece, int pieces, unsigned long long out_mask,
                                          long long* __restrict__ tile_flag, long long* __restrict__ part_flag,
                                          long long* __restrict__ pd_flag, double* __restrict__ Xinv_all,
                                          double* __restrict__ fail, long long epoch, int32_t* __restrict__ dbg, long long* __restrict__ tr) {
@@ -518,8 +522,9 @@ __device__ __forceinline__ void run_task(char* smem_raw, double* __restrict__ S,
 
   // the substitution, specialised for the column half (the wavefront-uniform branch keeps every "is block p mine / still open"
   // test a compile-time constant: with run-time tests the compiler merged the accumulators through scratch at every step)
-  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr);
-  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr);
+  const bool row_live = ((out_mask >> (8 * rt)) & 0xFFull) != 0;
+  if (h == 0) substitute<0>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr, row_live);
+  else substitute<1>(smem_raw, x, C, I, J, tile_flag + slotC, tile_flag + slotD, Xinv_all, fail, epoch, dbg, tr, row_live);
 }
 
 __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S, const int32_t* __restrict__ tasks,
@@ -536,7 +541,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
     const int t = s_task;
     __syncthreads();
     if (t >= ntasks) return;
-    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot
+    const int32_t* d = tasks + 12 * (int64_t)t;   // I, J, offset / count of the step list, piece r of R, slot of (I, J), slot of (J, J), accumulator lanes, first scratch slot, [10, 11]: the tile's own sub-tile mask
     long long* tr = trace ? trace + 8 * (int64_t)t : nullptr;   // GTG_DF_TRACE: 100 MHz stamps (taken, contraction done, done), place
     if (tr && threadIdx.x == 0) {
       unsigned hw, xcc;
@@ -544,7 +549,7 @@ __device__ __forceinline__ void bulk_loop(char* smem_raw, double* __restrict__ S
       GT_XCC_ID(xcc);
       tr[0] = wall_clock64(); tr[3] = ((long long)(xcc & 0xf) << 32) | hw;
     }
-    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + kStepWords * (int64_t)d[2], d[3], d[4], d[5], tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
+    run_task(smem_raw, S, d[0], d[1], d[6], d[7], d[8], d[9], klist + kStepWords * (int64_t)d[2], d[3], d[4], d[5], (unsigned)d[10] | ((unsigned long long)(unsigned)d[11] << 32), tile_flag, part_flag, pd_flag, Xinv_all, fail, epoch, ctrl + 8, tr);
     __syncthreads();   // the substitution buffers / staging buffers are reused by the next task
     if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   }
@@ -982,7 +987,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       for (int x = 0; x < 6; x++) dt.push_back(d[x]);
       dt.push_back(slot_of(I, J)); dt.push_back(slot_of(J, J));
       { const auto it = lanes.find(slot_of(I, J)); dt.push_back(it == lanes.end() ? 1 : it->second.first); dt.push_back(it == lanes.end() ? -1 : it->second.second); }
-      dt.push_back(0); dt.push_back(0);
+      { const uint64_t m = I == J ? ~0ull : mask_of(I, J); dt.push_back((int32_t)(uint32_t)m); dt.push_back((int32_t)(uint32_t)(m >> 32)); }   // sub-tile mask of the tile itself (substitute)
       for (int32_t e = d[2]; e < d[2] + d[3]; e++) {   // (the pieces of a tile share one list: every entry is visited once)
         const int k = df.h_klist[e];
         int32_t* w = dk.data() + kStepWords * (size_t)e;

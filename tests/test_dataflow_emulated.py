@@ -77,7 +77,7 @@ def plan_dense(nt, k_piece, k_final, lane_min=8, lane_max=8):
         if t[4] == t[5] - 1 and E >= lane_min and min(lane_max, E // 4) >= 2:
             G = min(lane_max, E // 4)
             lanes[(t[0], t[1])] = (G, n_slots + n_scratch); n_scratch += G - 1
-    tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) + [1 if t[0] == nt else 0, 0] for t in order]   # [10]: right-hand-side row
+    tasks = [t + [slot[(t[0], t[1])], slot[(t[1], t[1])]] + list(lanes.get((t[0], t[1]), (1, -1))) + ([0xFF, 0] if t[0] == nt else [-1, -1]) for t in order]   # [10, 11]: the tile's own sub-tile mask (dense; one row of sub-tiles in the right-hand-side row)
     chain_slots = []
     for J in range(nt):
         chain_slots += [slot[(J, J)], slot[(J, J - 1)] if J > 0 else -1, -1, -1]   # + the sub-tile mask of (J, J-1): dense

@@ -264,11 +264,8 @@ void analyze(gtg_context& c) {
   std::vector<int32_t> pair_row, pair_col;
   std::vector<int64_t> pair_ptr;
   if (device_terms) {
-    std::vector<uint64_t> keys;
-    device_schur_terms(c, d_obs_pos, nrv, keys, pair_ptr);
+    device_schur_terms(c, d_obs_pos, nrv, pos_to_red, pair_row, pair_col, pair_ptr);   // (the block list itself stays in c.pair_row / c.pair_col)
     n_terms = c.n_pair_terms;
-    pair_row.resize(keys.size()); pair_col.resize(keys.size());
-    for (size_t i = 0; i < keys.size(); i++) { pair_row[i] = pos_to_red[keys[i] / (uint64_t)nrv]; pair_col[i] = pos_to_red[keys[i] % (uint64_t)nrv]; }
     clk.lap("incidence lists, schur terms + block list (device)");
   } else {
   std::vector<int> lm_cut(nth + 1, c.n_lm);      // landmark ranges with equal numbers of terms
@@ -515,10 +512,16 @@ void analyze(gtg_context& c) {
     {
       const bool plain_rcm = !ord_req || std::string(ord_req) == "rcm";
       if (nd_depth == 0 && plain_rcm && kernels_can_run && c.n_shards == 1 && !std::getenv("GTG_HOST_ORDERING")) {
+        StageClock sub;
         std::vector<int32_t> ea, eb;
-        for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } });
+        const bool edges_on_device = device_terms && hoff_row.empty();    // the device's own block list is the edge list
+        if (!edges_on_device) for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } });
+        sub.lap("  (ordering: edge list)");
         PartRec leaf; leaf.parent = -1;
-        if (device_rcm(c, nrv2, ea, eb, leaf.nodes)) { parts.push_back(std::move(leaf)); ordered_on_device = true; }
+        if (device_rcm(c, nrv2, ea, eb, leaf.nodes, edges_on_device ? c.pair_row.p : nullptr, edges_on_device ? c.pair_col.p : nullptr, (int64_t)pair_row.size())) {
+          parts.push_back(std::move(leaf)); ordered_on_device = true;
+        }
+        sub.lap("  (ordering: device RCM)");
       }
     }
     if (!ordered_on_device) { ensure_adj(); dissect(all, nd_depth); }
@@ -634,14 +637,15 @@ void analyze(gtg_context& c) {
     while (o2 % align) c.h_pad_index.push_back(o2++);
     c.NP = (int)o2;
     // re-orient the blocks: the row variable is the one placed later
-    std::vector<int64_t> flipped;
-    for (size_t i = 0; i < pair_row.size(); i++)
-      if (c.h_red_pos[pair_row[i]] < c.h_red_pos[pair_col[i]]) {
-        std::swap(pair_row[i], pair_col[i]);
-        if (device_terms) flipped.push_back((int64_t)i);
-        else for (int64_t t = pair_ptr[i]; t < pair_ptr[i + 1]; t++) std::swap(pair_oa[t], pair_ob[t]);
-      }
-    device_flip_terms(c, flipped);
+    // (device-built lists: c.pair_row / c.pair_col and the terms are re-oriented in place by one kernel; the host's copy of the block list
+    // keeps the orientation it has -- every host pass that still reads it looks at the positions itself)
+    if (device_terms) device_orient_blocks(c, (int64_t)pair_row.size(), c.h_red_pos);
+    else
+      for (size_t i = 0; i < pair_row.size(); i++)
+        if (c.h_red_pos[pair_row[i]] < c.h_red_pos[pair_col[i]]) {
+          std::swap(pair_row[i], pair_col[i]);
+          for (int64_t t = pair_ptr[i]; t < pair_ptr[i + 1]; t++) std::swap(pair_oa[t], pair_ob[t]);
+        }
     for (size_t i = 0; i < hoff_row.size(); i++)
       if (c.h_red_pos[hoff_row[i]] < c.h_red_pos[hoff_col[i]]) {
         std::swap(hoff_row[i], hoff_col[i]);
@@ -666,21 +670,23 @@ void analyze(gtg_context& c) {
   // list and the ordering, and is joined by whoever needs it next: the getter, the next analysis of the handle, gtg_destroy (round 5:
   // analyze() used to wait 1.3 ms for it on the L1723 shape).
   {
-  std::vector<int32_t> bl_a, bl_b;                      // the off-diagonal blocks by position (min, max)
-  for_each_block([&](int ra, int rb) {
-    if (ra == rb) return;
-    const int pa = c.h_red_pos[ra], pb = c.h_red_pos[rb];
-    bl_a.push_back(std::min(pa, pb)); bl_b.push_back(std::max(pa, pb));
-  });
+  // (its own copies of the block list: plain vector copies -- the loop that turns them into positions runs on the thread as well)
+  std::vector<int32_t> bl_a, bl_b;                      // the off-diagonal blocks (reduced indices)
+  if (c.n_shards > 1) { bl_a = sb_row; bl_b = sb_col; }
+  else { bl_a = pair_row; bl_b = pair_col; bl_a.insert(bl_a.end(), hoff_row.begin(), hoff_row.end()); bl_b.insert(bl_b.end(), hoff_col.begin(), hoff_col.end()); }
   std::vector<int32_t> dim_at_pos(c.n_red_vars);
   for (int r = 0; r < c.n_red_vars; r++) dim_at_pos[c.h_red_pos[r]] = c.h_red_dim[r];
   gtg_context* cp = &c;
   c.block_level_err = nullptr;
   c.chol_flops_block = 0.0;      // (never the previous analysis's number while the new count runs)
-  c.block_level_thread = std::thread([cp, bl_a = std::move(bl_a), bl_b = std::move(bl_b), dim_at = std::move(dim_at_pos)] { try {
+  c.block_level_thread = std::thread([cp, bl_a = std::move(bl_a), bl_b = std::move(bl_b), dim_at = std::move(dim_at_pos), red_pos = c.h_red_pos] { try {
     const int n = (int)dim_at.size();
     std::vector<std::vector<int32_t>> below(n);          // positions > own position
-    for (size_t i = 0; i < bl_a.size(); i++) below[bl_a[i]].push_back(bl_b[i]);
+    for (size_t i = 0; i < bl_a.size(); i++) {
+      if (bl_a[i] == bl_b[i]) continue;
+      const int pa = red_pos[bl_a[i]], pb = red_pos[bl_b[i]];
+      below[std::min(pa, pb)].push_back(std::max(pa, pb));
+    }
     std::vector<std::vector<int32_t>> children(n);
     std::vector<int32_t> merged;
     double fl = 0.0;
@@ -745,8 +751,17 @@ void analyze(gtg_context& c) {
       std::vector<int64_t> xro, xco; std::vector<int32_t> xd;
       const bool need_list = c.n_shards > 1 || (!pair_row.empty() && !hoff_row.empty());
       auto add_block = [&](int64_t ro, int64_t co, int32_t dd) { if (need_list) { xro.push_back(ro); xco.push_back(co); xd.push_back(dd); } else mix_block(ro, co, dd); };
+      // The marks of the Schur blocks come from the DEVICE where the block list is its own (single shard, real runtime: one lane per
+      // block, device_analysis.hip::k_da_tile_marks, over the device's own re-oriented block list; 3 ms of this loop on the L1723 shape).
+      // GTG_HOST_SYMBOLIC=1 keeps the host loop as the A/B (tests/test_gpu_device_analysis.py: same hash, same masks).
+      const bool marks_on_device = device_terms && !need_list && pair_row.size() >= 4096 && !std::getenv("GTG_HOST_SYMBOLIC");
+      if (marks_on_device) {
+        std::vector<RedLayout> lay(c.n_red_vars);
+        for (int r = 0; r < c.n_red_vars; r++) lay[r] = RedLayout{c.h_red_off[r], c.h_red_dim[r]};
+        device_tile_marks(c, (int64_t)pair_row.size(), lay, nt, n16, w16, T1, M16, &hb);
+      }
       for (int r = 0; r < c.n_red_vars; r++) { mark1(r, r); add_block(c.h_red_off[r], c.h_red_off[r], c.h_red_dim[r] | (c.h_red_dim[r] << 8)); }
-      for_each_block([&](int ra, int rb) {
+      if (!marks_on_device) for_each_block([&](int ra, int rb) {
         mark1(ra, rb);
         if (ra == rb) return;                                  // a camera's Schur terms with itself: the diagonal block above
         const bool a_later = c.h_red_pos[ra] > c.h_red_pos[rb];
@@ -809,7 +824,7 @@ void analyze(gtg_context& c) {
         if (dfh.joinable()) dfh.join();
         if (dferr) std::rethrow_exception(dferr);
         clk.lap("tile schedules (task lists of both passes, two threads)");
-        if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored, dense ? nullptr : &sub16);
+        if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored, dense ? nullptr : &sub16, kernels_can_run ? c.plan.slot.p : nullptr);
         clk.lap("dataflow plan resolved to slots + uploaded");
       }
       for (int a = 0; a < nt; a++)
@@ -870,7 +885,7 @@ void analyze(gtg_context& c) {
   }
   up(c.lm_pri_ptr, lm_pri_ptr, s); up(c.lm_pri, lm_pri, s);
   up(c.hoff_row, hoff_row, s); up(c.hoff_col, hoff_col, s); up(c.hoff_ptr, hoff_ptr, s); up(c.hoff_fac, hoff_fac, s);
-  up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s);
+  if (!device_terms) { up(c.pair_row, pair_row, s); up(c.pair_col, pair_col, s); }   // (else: built and re-oriented in place by the device passes)
   if (!device_terms) {   // (the device built pair_ptr / pair_oa / pair_ob in place)
     up(c.pair_ptr, pair_ptr, s);
     c.pair_oa.upload(pair_oa.get(), (size_t)c.n_pair_terms, s); c.pair_ob.upload(pair_ob.get(), (size_t)c.n_pair_terms, s);

@@ -218,6 +218,45 @@ static void ensure_events(gtg_context& c) {   // the handle's own events, on its
   c.phase_events.resize(2 * GTG_PH_COUNT, nullptr);
   for (auto& e : c.phase_events) check_hip(hipEventCreate(&e), "event");
 }
+// A handle's stream and events outlive it: gtg_destroy parks them (idle) per device and the next gtg_create of the process takes them from
+// there -- creating a stream and 18 events cost 1.7 ms of every construction of an optimizer (tools/cpp/cold_start_probe.cpp), a third of
+// what the whole symbolic analysis of the L1723 shape takes now.  At most kParkedMax sets per device are kept; gtg_release_cached_memory()
+// destroys them with the cached device memory.
+struct ParkedQueue { int device; hipStream_t stream; hipStream_t copy_stream; std::vector<hipEvent_t> events; };
+static std::mutex g_parked_mu;
+static std::vector<ParkedQueue> g_parked;
+constexpr size_t kParkedMax = 4;
+static bool take_parked(gtg_context& c) {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  for (size_t i = 0; i < g_parked.size(); i++)
+    if (g_parked[i].device == c.device) {
+      c.stream = g_parked[i].stream; c.copy_stream = g_parked[i].copy_stream; c.phase_events = std::move(g_parked[i].events);
+      g_parked.erase(g_parked.begin() + (long)i);
+      return true;
+    }
+  return false;
+}
+static bool park_queue(gtg_context& c) {   // (the caller has synchronised the streams)
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  size_t n = 0;
+  for (const auto& q : g_parked) n += q.device == c.device;
+  if (n >= kParkedMax) return false;
+  g_parked.push_back(ParkedQueue{c.device, c.stream, c.copy_stream, std::move(c.phase_events)});
+  c.stream = nullptr; c.copy_stream = nullptr; c.phase_events.clear();
+  return true;
+}
+static void destroy_parked() {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  int cur = 0; (void)hipGetDevice(&cur);
+  for (auto& q : g_parked) {
+    (void)hipSetDevice(q.device);
+    for (hipEvent_t e : q.events) if (e) (void)hipEventDestroy(e);
+    if (q.stream) (void)hipStreamDestroy(q.stream);
+    if (q.copy_stream) (void)hipStreamDestroy(q.copy_stream);
+  }
+  g_parked.clear();
+  (void)hipSetDevice(cur);
+}
 static void collect(gtg_context& c, std::initializer_list<int> phases) {
   if (!c.timing) return;
   for (int ph : phases) {
@@ -255,8 +294,11 @@ int gtg_create(gtg_handle* out, int device_id) {
   check_hip(hipSetDevice(device_id), "hipSetDevice");
   gtg_context* c = new gtg_context;
   c->device = device_id;
-  check_hip(hipStreamCreate(&c->stream), "hipStreamCreate");
-  ensure_events(*c);
+  if (!take_parked(*c)) {
+    check_hip(hipStreamCreate(&c->stream), "hipStreamCreate");
+    check_hip(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), "hipStreamCreate");   // uploads beside the analysis (gtg_upload_problem)
+    ensure_events(*c);
+  }
   *out = c;
   return GTG_OK;
   GTG_CATCH
@@ -317,8 +359,12 @@ int gtg_destroy(gtg_handle c) {
   free_df_plan(c->df);
   c->pivot_kind.free(); c->tile_exp.free();
   destroy_chol_streams(*c);
-  for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(c->stream);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  if (!park_queue(*c)) {
+    for (hipEvent_t e : c->phase_events) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  }
   drop_index(c);
   delete c;
   return GTG_OK;
@@ -464,6 +510,8 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     hi.all_obs_point.assign(p->sfm_point, p->sfm_point + p->n_sfm); hi.all_obs_point.insert(hi.all_obs_point.end(), p->proj_point, p->proj_point + p->n_proj);
     hi.all_between_v1.assign(p->between_v1, p->between_v1 + p->n_between); hi.all_between_v2.assign(p->between_v2, p->between_v2 + p->n_between);
   }
+  std::thread side_upload; std::exception_ptr side_err;
+  struct JoinSide { std::thread& t; ~JoinSide() { if (t.joinable()) t.join(); } } join_side{side_upload};
   { // SFM
     std::vector<int32_t> cam, pt, nz; std::vector<double> z;
     for (int64_t i = 0; i < p->n_sfm; i++) { check_var(p->sfm_cam[i]); check_var(p->sfm_point[i]); check_noise(p->sfm_noise[i], 2, "GeneralSFMFactor"); }
@@ -498,7 +546,22 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
     }
     f.n_sfm = (int64_t)cam.size();
     up(f.sfm_cam, cam, s); up(f.sfm_point, pt, s);
-    if (whole) { f.sfm_noise.upload(p->sfm_noise, (size_t)p->n_sfm, s); f.sfm_z.upload(p->sfm_z, 2 * (size_t)p->n_sfm, s); }
+    if (whole) {
+      // the noise rows and the measurements (20 bytes per factor: 13.5 MB on the L1723 shape, 1.2 ms from pageable memory) are not read by
+      // the symbolic analysis: they go up on a helper thread and the handle's copy stream beside it (joined below, before this call returns)
+      f.sfm_noise.alloc((size_t)p->n_sfm); f.sfm_z.alloc(2 * (size_t)p->n_sfm);
+      const int dev = c->device; hipStream_t cs = c->copy_stream;
+      int32_t* d_nz = f.sfm_noise.p; double* d_z = f.sfm_z.p;
+      const int32_t* h_nz = p->sfm_noise; const double* h_z = p->sfm_z; const size_t n = (size_t)p->n_sfm;
+      side_upload = std::thread([dev, cs, d_nz, d_z, h_nz, h_z, n, &side_err] {
+        try {
+          check_hip(hipSetDevice(dev), "hipSetDevice");
+          check_hip(hipMemcpyAsync(d_nz, h_nz, sizeof(int32_t) * n, hipMemcpyHostToDevice, cs), "H2D");
+          check_hip(hipMemcpyAsync(d_z, h_z, sizeof(double) * 2 * n, hipMemcpyHostToDevice, cs), "H2D");
+          check_hip(hipStreamSynchronize(cs), "sync");
+        } catch (...) { side_err = std::current_exception(); }
+      });
+    }
     else { up(f.sfm_noise, nz, s); up(f.sfm_z, z, s); }
     if (c->val_size >= (int64_t)1 << 31) throw std::invalid_argument("gtg_upload_problem: more than 2^31 packed value entries");
     f.sfm_cam_at.alloc(std::max<size_t>(cam.size(), 1)); f.sfm_point_at.alloc(std::max<size_t>(pt.size(), 1));
@@ -563,6 +626,8 @@ int gtg_upload_problem(gtg_handle c, const gtg_problem* p_user, int shard, int n
   }
   clk.lap("factor tables (shard filter + upload)");
   analyze(*c);
+  if (side_upload.joinable()) side_upload.join();
+  if (side_err) std::rethrow_exception(side_err);
   if (c->n_smart) {   // landmark index of every smart factor's hidden variable
     std::vector<int32_t> lm_smart((size_t)std::max(c->n_lm, 1), -1);
     for (int64_t i = 0; i < c->n_smart; i++) {
@@ -1015,6 +1080,20 @@ int gtg_debug_df_plan(gtg_handle c, int64_t sizes[4], int32_t* tasks, int32_t* k
   GTG_CATCH
 }
 
+int gtg_debug_df_device_tables(gtg_handle c, int64_t sizes[3], int32_t* tasks, int32_t* steps, int32_t* chain) {
+  GTG_TRY
+  if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_df_device_tables: no problem uploaded");
+  const DfPlan& df = c->df;
+  sizes[0] = (int64_t)df.tasks.n; sizes[1] = (int64_t)df.klist.n; sizes[2] = (int64_t)df.has_sub.n;
+  (void)hipSetDevice(c->device);
+  if (tasks && df.tasks.n) check_hip(hipMemcpyAsync(tasks, df.tasks.p, sizeof(int32_t) * df.tasks.n, hipMemcpyDeviceToHost, c->stream), "D2H");
+  if (steps && df.klist.n) check_hip(hipMemcpyAsync(steps, df.klist.p, sizeof(int32_t) * df.klist.n, hipMemcpyDeviceToHost, c->stream), "D2H");
+  if (chain && df.has_sub.n) check_hip(hipMemcpyAsync(chain, df.has_sub.p, sizeof(int32_t) * df.has_sub.n, hipMemcpyDeviceToHost, c->stream), "D2H");
+  check_hip(hipStreamSynchronize(c->stream), "sync");
+  return GTG_OK;
+  GTG_CATCH
+}
+
 int gtg_debug_df_chains(gtg_handle c, int64_t sizes[3], int32_t* chain_off, int32_t* chain_tiles, int32_t* seq) {
   GTG_TRY
   if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_df_chains: no problem uploaded");
@@ -1115,7 +1194,7 @@ int gtg_dense_cholesky_host(gtg_handle c, double* A, int32_t n, double* rhs) {
   GTG_CATCH
 }
 
-int64_t gtg_release_cached_memory(void) { return (int64_t)release_kept(-1); }
+int64_t gtg_release_cached_memory(void) { destroy_parked(); return (int64_t)release_kept(-1); }
 int64_t gtg_cached_memory_bytes(void) { std::lock_guard<std::mutex> lk(g_kept_mu); size_t b = 0; for (const auto& k : g_kept) b += k.bytes; return (int64_t)b; }
 
 }  // extern "C"

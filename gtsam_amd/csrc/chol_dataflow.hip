@@ -710,6 +710,45 @@ __global__ __launch_bounds__(kBulkThreads) void k_df_single(double* __restrict__
 }
 
 __global__ void k_df_begin(long long* epoch, long long value, int32_t* ctrl) { *epoch = value; ctrl[0] = 0; ctrl[1] = 0; ctrl[8] = 0; ctrl[2] = ctrl[3] = ctrl[4] = ctrl[5] = -1; }   // (ctrl[6], ctrl[7]: counted over the handle's life)
+
+// The plan's device tables from its host lists (upload_df_plan): one lane per task.  A task (I, J, offset / count of its steps, piece, pieces)
+// gets the slots of its tile and of the diagonal tile, its accumulator lanes and the tile's own sub-tile mask; every contraction step k of
+// its list the slots of the operand tiles (I, k), (J, k) and their two sub-tile masks.  acc[0] += the MFMAs the step leaves out on
+// structurally empty sub-tiles, in half units of 4 MFMAs (a diagonal tile's step counts once, any other twice: integers, so the sum does
+// not depend on the order); acc[1] += tiles of the lists without a slot (the host throws).
+__global__ __launch_bounds__(256) void k_df_resolve(int64_t n_tasks, int nt, const int32_t* __restrict__ t6, const int32_t* __restrict__ kl,
+                                                    const int32_t* __restrict__ slot, const unsigned long long* __restrict__ sub16,
+                                                    const int32_t* __restrict__ lane_tab, int32_t* __restrict__ t12, int32_t* __restrict__ steps,
+                                                    unsigned long long* __restrict__ acc) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  const int32_t* d = t6 + 6 * t;
+  const int I = d[0], J = d[1];
+  int bad = 0;
+  auto slot_of = [&](int a, int b) { const int q = slot[(int64_t)a * nt + b]; if (q < 0) bad++; return q; };
+  auto mask_of = [&](int a, int k) -> unsigned long long { return a >= nt ? 0xFFull : sub16 ? sub16[(int64_t)a * nt + k] : ~0ull; };
+  int32_t* o = t12 + 12 * t;
+  const int q = slot_of(I, J);
+  for (int x = 0; x < 6; x++) o[x] = d[x];
+  o[6] = q; o[7] = slot_of(J, J);
+  o[8] = q >= 0 ? lane_tab[2 * q] : 1; o[9] = q >= 0 ? lane_tab[2 * q + 1] : -1;
+  { const unsigned long long m = I == J ? ~0ull : mask_of(I, J); o[10] = (int32_t)(uint32_t)m; o[11] = (int32_t)(uint32_t)(m >> 32); }
+  unsigned long long skipped = 0;
+  for (int32_t e = d[2]; e < d[2] + d[3]; e++) {
+    const int k = kl[e];
+    int32_t* w = steps + kStepWords * (int64_t)e;
+    const unsigned long long ma = mask_of(I, k), mb = mask_of(J, k);
+    w[0] = slot_of(I, k); w[1] = slot_of(J, k);
+    w[2] = (int32_t)(uint32_t)ma; w[3] = (int32_t)(uint32_t)(ma >> 32); w[4] = (int32_t)(uint32_t)mb; w[5] = (int32_t)(uint32_t)(mb >> 32);
+    if (I < nt) {
+      int live = 0;
+      for (int sp = 0; sp < 8; sp++) live += 4 * __popcll(ma & (0x0101010101010101ull << sp)) * __popcll(mb & (0x0101010101010101ull << sp));
+      skipped += (unsigned long long)(2048 - live) * (I == J ? 1u : 2u);
+    }
+  }
+  if (skipped) atomicAdd(&acc[0], skipped);
+  if (bad) atomicAdd(&acc[1], (unsigned long long)bad);
+}
 #endif   // GT_KERNEL_EMU
 
 }  // namespace
@@ -947,7 +986,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   df.h_has_sub = has_sub;
 }
 
-void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16) {
+void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16, const int32_t* d_slot) {
   const int nt = df.nt;
   const std::vector<int32_t>& has_sub = df.h_has_sub;
   // Device form: tiles AND their flag words are addressed by SLOT (context.h::SMat; the slots come from the stream schedule's plan,
@@ -974,12 +1013,43 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
       lanes[slot_of(d[0], d[1])] = {G, (int32_t)(n_slots + df.n_scratch)};
       df.n_scratch += G - 1;
     }
-    std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 12);
-    std::vector<int32_t> dk(kStepWords * df.h_klist.size(), 0);
     // sub-tile masks of a contraction step's operand tiles (analysis.hip: strip-level symbolic factorisation; none = every sub-tile): the
     // right-hand-side row has one row of sub-tiles
     auto mask_of = [&](int I, int k) -> uint64_t { return I >= nt ? 0xFFull : sub16 ? (*sub16)[(size_t)I * nt + k] : ~0ull; };
     double skipped = 0.0;
+    if (d_slot && df.n_tasks >= 1024 && !getenv("GTG_HOST_SYMBOLIC")) {
+      // On the DEVICE (k_df_resolve, one lane per task; d_slot = the device copy of `slot`): the host lists go up as they are (6 words per
+      // task, one per step) instead of the resolved tables (12 and 6 words), and the 64 x 64 bit products of the skipped-MFMA count run
+      // there as well (2.4 ms of host loop on the L1723 shape).  GTG_HOST_SYMBOLIC=1 keeps the loop below: same tables, same count
+      // (tests/test_gpu_device_analysis.py); so do the dry-run runtime of the CPU tests and small plans.
+      std::vector<int32_t> lane_tab(2 * (size_t)n_slots);
+      for (int64_t q = 0; q < n_slots; q++) { lane_tab[2 * q] = 1; lane_tab[2 * q + 1] = -1; }
+      for (const auto& kv : lanes) { lane_tab[2 * (size_t)kv.first] = kv.second.first; lane_tab[2 * (size_t)kv.first + 1] = kv.second.second; }
+      auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+      const size_t b_t6 = al(4 * df.h_tasks.size()), b_kl = al(4 * df.h_klist.size()), b_lane = al(4 * lane_tab.size()), b_sub = sub16 ? al(8 * sub16->size()) : 0;
+      DevBuf<unsigned char> ws; ws.alloc(b_t6 + b_kl + b_lane + b_sub + 256);
+      struct Release { DevBuf<unsigned char>& b; ~Release() { b.free(); } } release{ws};
+      int32_t* d_t6 = reinterpret_cast<int32_t*>(ws.p); int32_t* d_kl = reinterpret_cast<int32_t*>(ws.p + b_t6);
+      int32_t* d_lane = reinterpret_cast<int32_t*>(ws.p + b_t6 + b_kl);
+      unsigned long long* d_sub = sub16 ? reinterpret_cast<unsigned long long*>(ws.p + b_t6 + b_kl + b_lane) : nullptr;
+      unsigned long long* d_acc = reinterpret_cast<unsigned long long*>(ws.p + b_t6 + b_kl + b_lane + b_sub);
+      check_hip(hipMemcpyAsync(d_t6, df.h_tasks.data(), 4 * df.h_tasks.size(), hipMemcpyHostToDevice, stream), "H2D");
+      check_hip(hipMemcpyAsync(d_kl, df.h_klist.data(), 4 * df.h_klist.size(), hipMemcpyHostToDevice, stream), "H2D");
+      check_hip(hipMemcpyAsync(d_lane, lane_tab.data(), 4 * lane_tab.size(), hipMemcpyHostToDevice, stream), "H2D");
+      if (sub16) check_hip(hipMemcpyAsync(d_sub, sub16->data(), 8 * sub16->size(), hipMemcpyHostToDevice, stream), "H2D");
+      check_hip(hipMemsetAsync(d_acc, 0, 16, stream), "memset");
+      df.tasks.alloc(12 * (size_t)df.n_tasks); df.klist.alloc(kStepWords * df.h_klist.size());
+      hipLaunchKernelGGL(k_df_resolve, dim3((unsigned)((df.n_tasks + 255) / 256)), dim3(256), 0, stream, df.n_tasks, nt, d_t6, d_kl, d_slot, d_sub, d_lane,
+                         df.tasks.p, df.klist.p, d_acc);
+      check_hip(hipGetLastError(), "df plan resolve");
+      unsigned long long acc[2] = {0, 0};
+      check_hip(hipMemcpyAsync(acc, d_acc, 16, hipMemcpyDeviceToHost, stream), "D2H");
+      check_hip(hipStreamSynchronize(stream), "df plan resolve");
+      if (acc[1]) throw std::runtime_error("dataflow plan: a tile of the task list has no slot in the stored-tile list");
+      skipped = (double)acc[0] * 0.5 * 2048.0;
+    } else {
+    std::vector<int32_t> dt; dt.reserve((size_t)df.n_tasks * 12);
+    std::vector<int32_t> dk(kStepWords * df.h_klist.size(), 0);
     std::vector<uint8_t> seen(df.h_klist.size(), 0);
     for (int64_t t = 0; t < df.n_tasks; t++) {
       const int32_t* d = df.h_tasks.data() + 6 * t;
@@ -996,11 +1066,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
         w[2] = (int32_t)(uint32_t)ma; w[3] = (int32_t)(uint32_t)(ma >> 32); w[4] = (int32_t)(uint32_t)mb; w[5] = (int32_t)(uint32_t)(mb >> 32);
         if (!seen[e]) {   // MFMAs the step leaves out: per 16-column strip (row tiles with a live A sub-tile) x (column tiles with a live B sub-tile), 4 each
           int live = 0;
-          for (int sp = 0; sp < 8; sp++) {
-            int ra = 0, cb = 0;
-            for (int r = 0; r < 8; r++) { ra += (int)((ma >> (8 * r + sp)) & 1); cb += (int)((mb >> (8 * r + sp)) & 1); }
-            live += 4 * ra * cb;
-          }
+          for (int sp = 0; sp < 8; sp++) live += 4 * __builtin_popcountll(ma & (0x0101010101010101ull << sp)) * __builtin_popcountll(mb & (0x0101010101010101ull << sp));
           const int rows = I >= nt ? 1 : 8;   // (the flop count has always taken the right-hand-side row as a full tile row; its 7 idle row tiles are not counted as skipped work here)
           skipped += (I == J ? 0.5 : 1.0) * (double)(4 * 8 * rows * 8 - live) * 2048.0 * (I >= nt ? 0.0 : 1.0);
         }
@@ -1009,6 +1075,7 @@ void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& 
     }
     df.tasks.upload(dt.data(), dt.size(), stream);
     df.klist.upload(dk.data(), dk.size(), stream);
+    }
     df.flops_executed = df.flops - skipped;
     std::vector<int32_t> cs(kChainWords * (size_t)nt, -1);
     for (int J = 0; J < nt; J++) {
@@ -1161,7 +1228,7 @@ void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xin
 // not needed any more was tried and is not an option either: in the full GPU suite (three builds of the library in one process) it ended
 // in a memory access fault of the device.  A process that factorises camera systems AND pose graphs keeps both pairs and pays that 10 %.
 static void prewarm_chol_dataflow(int) {
-  prewarm_kernels({(const void*)k_df_bulk, (const void*)k_df_chain, (const void*)k_df_single, (const void*)k_df_begin});
+  prewarm_kernels({(const void*)k_df_bulk, (const void*)k_df_chain, (const void*)k_df_single, (const void*)k_df_begin, (const void*)k_df_resolve});
 }
 static PrewarmUnit prewarm_chol_dataflow_registered(prewarm_chol_dataflow);
 

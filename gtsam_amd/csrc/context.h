@@ -159,6 +159,7 @@ struct gtg_context {
   hipStream_t stream = nullptr;
   gt::CholStreams cs;
   std::vector<hipEvent_t> phase_events;   // 2 per phase (gtg_enable_timing)
+  hipStream_t copy_stream = nullptr;      // non-blocking: the uploads that run beside the symbolic analysis (gtg_upload_problem)
   int shard = 0, n_shards = 1;
   bool uploaded = false, linearized = false, have_trial = false;
 

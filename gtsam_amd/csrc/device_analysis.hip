@@ -15,7 +15,7 @@
 //   gather (oa, ob) into the final lists, prim::runs -> the unique blocks and pair_ptr (the first term of every block)
 // The 6 M terms of the L1723 shape take 1.3 ms (2.8 with one landmark per lane, profiles/r02_device_analysis_proto.log) against 12 ms on 32 host threads, and
 // 49 MB of term lists never cross PCIe; the host gets back the 0.2 M block keys and offsets it needs for the ordering and the
-// tile schedule.  After the ordering the terms of the blocks whose orientation flips are swapped in place (k_da_flip).
+// tile schedule.  After the ordering the blocks whose orientation flips are swapped in place, indices and terms (k_da_orient).
 // The incidence lists in front of that pass -- observation -> (reduced variable, landmark, position), landmark -> observations,
 // reduced variable -> its factors -- are built here as well (device_incidence_lists: one kernel per observation with the role
 // check of the factor keys, two stable radix sorts, CSR offsets by binary search in the sorted keys; 4.6 ms of host passes over the
@@ -118,14 +118,27 @@ __global__ __launch_bounds__(256) void k_da_gather(int64_t n, const uint32_t* __
 }
 
 // one wavefront per flagged block: swap the two sides of its terms
-__global__ __launch_bounds__(256) void k_da_flip(int64_t n_flip, const int64_t* __restrict__ which, const int64_t* __restrict__ pptr,
-                                                 int32_t* __restrict__ oa, int32_t* __restrict__ ob) {
-  const int64_t w = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
-  if (w >= n_flip) return;
-  const int64_t p = which[w];
-  for (int64_t t = pptr[p] + (threadIdx.x & 63); t < pptr[p + 1]; t += 64) { const int32_t x = oa[t]; oa[t] = ob[t]; ob[t] = x; }
+// the block list as pairs of reduced indices: key = row position * n + column position (positions at the time of the emission)
+__global__ __launch_bounds__(256) void k_da_split(int64_t n, int nrv, const uint64_t* __restrict__ key, const int32_t* __restrict__ pos_to_red,
+                                                  int32_t* __restrict__ row, int32_t* __restrict__ col) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = key[i];
+  row[i] = pos_to_red[k / (uint64_t)nrv]; col[i] = pos_to_red[k % (uint64_t)nrv];
 }
-
+// After the ordering, one wavefront per block: a block whose row variable is now placed EARLIER than its column variable changes
+// orientation -- its two indices and the (oa, ob) of every one of its terms are swapped (the host used to walk the 0.2 M blocks, send the
+// list of the flipped ones and k_da_flip swapped their terms)
+__global__ __launch_bounds__(256) void k_da_orient(int64_t n, const int32_t* __restrict__ pos, int32_t* __restrict__ row, int32_t* __restrict__ col,
+                                                   const int64_t* __restrict__ pptr, int32_t* __restrict__ oa, int32_t* __restrict__ ob) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int32_t r = row[i], q = col[i];
+  if (pos[r] >= pos[q]) return;
+  for (int64_t t = pptr[i] + lane; t < pptr[i + 1]; t += 64) { const int32_t a = oa[t]; oa[t] = ob[t]; ob[t] = a; }
+  if (lane == 0) { row[i] = q; col[i] = r; }
+}
 // one observation per lane: its reduced variable, landmark and position; the keys' roles (GeneralSFMFactor: SFM_CAMERA + POINT3,
 // GenericProjectionFactor: POSE3 + POINT3) checked on the way -> bad[0] = 1 / 2
 __global__ __launch_bounds__(256) void k_da_obs(int64_t n_sfm, int64_t n_proj, const int32_t* __restrict__ sfm_cam, const int32_t* __restrict__ sfm_point,
@@ -190,8 +203,8 @@ inline void hc(hipError_t e, const char* what) { check_hip(e, what); }
 // Fills c.pair_oa / c.pair_ob / c.pair_ptr (device, final buffers) from the landmark -> observation lists (already uploaded to
 // c.lm_obs_ptr / c.lm_obs) and the positions of the observations' cameras; returns the unique block keys (row position * nrv +
 // column position, ascending) and the term offsets of the blocks to the host.
-void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys,
-                        std::vector<int64_t>& block_ptr) {
+void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, const std::vector<int32_t>& pos_to_red, std::vector<int32_t>& block_row,
+                        std::vector<int32_t>& block_col, std::vector<int64_t>& block_ptr) {
   hipStream_t s = c.stream;
   const int n_lm = c.n_lm;
   DevBuf<int64_t> d_cnt, d_off; d_cnt.alloc((size_t)n_lm + 1); d_off.alloc((size_t)n_lm + 1);
@@ -218,8 +231,8 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   }
   c.n_pair_terms = total;
   c.pair_oa.alloc((size_t)std::max<int64_t>(total, 1)); c.pair_ob.alloc((size_t)std::max<int64_t>(total, 1));
-  block_keys.clear(); block_ptr.assign(1, 0);
-  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); scan_tmp.free(); c.pair_ptr.upload(block_ptr.data(), 1, s); return; }
+  block_row.clear(); block_col.clear(); block_ptr.assign(1, 0);
+  if (total == 0) { d_pos.free(); d_cnt.free(); d_off.free(); d_dup.free(); scan_tmp.free(); c.pair_ptr.upload(block_ptr.data(), 1, s); c.pair_row.alloc(1); c.pair_col.alloc(1); return; }
   // one scratch allocation for everything that does not outlive the call (a dozen separate hipMalloc / hipFree of tens of
   // megabytes cost more than the kernels)
   const size_t N = (size_t)total;
@@ -229,7 +242,7 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   // (a stable LSD radix sort over the `bits` significant key bits -- stability is what keeps the landmark order inside a block, i.e. the
   // summation order of the Schur complement --, then the runs of the sorted keys: primitives.hip)
   const size_t need_tmp = std::max(prim::sort_scratch_bytes(N), prim::runs_scratch_bytes(N));
-  const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(8 * (N + 1)) + al(16) + al(need_tmp);
+  const size_t bytes = 3 * al(8 * N) + 4 * al(4 * N) + al(8 * (N + 1)) + al(16) + al(need_tmp) + al(4 * (size_t)nrv);
   DevBuf<unsigned char> pool_buf; pool_buf.alloc(bytes);     // (through DevBuf: a block of this size is kept for the next handle, api.hip)
   char* pool = reinterpret_cast<char*>(pool_buf.p);
   size_t at = 0;
@@ -241,6 +254,7 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   int64_t* pp = reinterpret_cast<int64_t*>(take(8 * (N + 1)));
   int32_t* d_nruns = reinterpret_cast<int32_t*>(take(16));
   void* prim_tmp = take(need_tmp);
+  int32_t* d_p2r = reinterpret_cast<int32_t*>(take(4 * (size_t)nrv));   // position -> reduced index (k_da_split)
   hipLaunchKernelGGL(k_da_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, n_lm, nrv, c.lm_obs_ptr.p, c.lm_obs.p, d_pos.p, d_off.p,
                      d_dup.p, key, idx, t_oa, t_ob);
   if (n_dup_lm > 0)
@@ -252,8 +266,16 @@ void device_schur_terms(gtg_context& c, DevBuf<int32_t>& d_pos, int nrv, std::ve
   int nruns = 0;
   hc(hipMemcpyAsync(&nruns, d_nruns, sizeof(int), hipMemcpyDeviceToHost, s), "D2H");
   hc(hipStreamSynchronize(s), "sync");
-  block_keys.resize((size_t)nruns); block_ptr.resize((size_t)nruns + 1);
-  hc(hipMemcpyAsync(block_keys.data(), uniq, sizeof(uint64_t) * (size_t)nruns, hipMemcpyDeviceToHost, s), "D2H");
+  // the blocks as (row, column) reduced indices: they STAY on the device (c.pair_row / c.pair_col: the ordering's edge list, the tile marks
+  // and k_schur_pairs read them there; k_da_orient re-orients them after the ordering), the host gets a copy for its own passes
+  block_row.resize((size_t)nruns); block_col.resize((size_t)nruns); block_ptr.resize((size_t)nruns + 1);
+  c.pair_row.alloc(std::max<size_t>((size_t)nruns, 1)); c.pair_col.alloc(std::max<size_t>((size_t)nruns, 1));
+  {
+    hc(hipMemcpyAsync(d_p2r, pos_to_red.data(), sizeof(int32_t) * pos_to_red.size(), hipMemcpyHostToDevice, s), "H2D");
+    if (nruns) hipLaunchKernelGGL(k_da_split, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, (int64_t)nruns, nrv, uniq, d_p2r, c.pair_row.p, c.pair_col.p);
+  }
+  hc(hipMemcpyAsync(block_row.data(), c.pair_row.p, sizeof(int32_t) * (size_t)nruns, hipMemcpyDeviceToHost, s), "D2H");
+  hc(hipMemcpyAsync(block_col.data(), c.pair_col.p, sizeof(int32_t) * (size_t)nruns, hipMemcpyDeviceToHost, s), "D2H");
   hc(hipMemcpyAsync(block_ptr.data(), pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToHost, s), "D2H");
   c.pair_ptr.alloc((size_t)nruns + 1);
   hc(hipMemcpyAsync(c.pair_ptr.p, pp, sizeof(int64_t) * ((size_t)nruns + 1), hipMemcpyDeviceToDevice, s), "D2D");
@@ -321,20 +343,80 @@ void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos,
   d_red_pos.free();
 }
 
-// After the ordering: blocks whose row variable is now placed EARLIER than their column variable change orientation.
-void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped) {
-  if (flipped.empty()) return;
-  DevBuf<int64_t> d_which; d_which.upload(flipped.data(), flipped.size(), c.stream);
-  hipLaunchKernelGGL(k_da_flip, dim3((unsigned)((flipped.size() + 3) / 4)), dim3(256), 0, c.stream, (int64_t)flipped.size(), d_which.p, c.pair_ptr.p,
+// After the ordering: blocks whose row variable is now placed EARLIER than their column variable change orientation (c.pair_row / c.pair_col
+// and the terms' (oa, ob), all in place on the device; red_pos = the new position of every reduced variable).
+void device_orient_blocks(gtg_context& c, int64_t n_blocks, const std::vector<int32_t>& red_pos) {
+  if (n_blocks == 0) return;
+  DevBuf<int32_t> d_pos; d_pos.upload(red_pos.data(), red_pos.size(), c.stream);
+  hipLaunchKernelGGL(k_da_orient, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, c.stream, n_blocks, d_pos.p, c.pair_row.p, c.pair_col.p, c.pair_ptr.p,
                      c.pair_oa.p, c.pair_ob.p);
   check_hip(hipStreamSynchronize(c.stream), "sync");
-  d_which.free();
+  d_pos.free();
+}
+
+// ---- the marks of the Schur blocks in the tile / strip structure of the reduced system (after the ordering) ---------------------------
+// What analysis.hip's host loop does for every block of the block list (0.2 M on the L1723 shape, 3 ms): one lane per block sets the
+// 128 x 128 tiles its d x d entries touch (T1, bytes), the 16-row strips (M16: column = strip, a bit set over the strips at and below it:
+// the input of the strip-level symbolic factorisation) and adds the block's term to the commutative sum that identifies the block set
+// (structure_hash: same mixing function as the host's, wrap-around 64-bit sum = order-free).  Blocks of a variable with itself (a
+// camera's own Schur terms) only touch what the host marks for every variable's diagonal block anyway and are skipped.
+namespace {
+__global__ __launch_bounds__(256) void k_da_tile_marks(int64_t nb, const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                                       const RedLayout* __restrict__ lay, int nt, int w16, unsigned char* __restrict__ T1,
+                                                       unsigned long long* __restrict__ M16, unsigned long long* __restrict__ hsum) {
+  __shared__ unsigned long long wg_sum;
+  if (threadIdx.x == 0) wg_sum = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb && row[i] != col[i]) {
+    const RedLayout a = lay[row[i]], b = lay[col[i]];     // (row = the variable placed later: re-oriented by the host after the ordering)
+    const int64_t a_end = a.off + a.dim - 1, b_end = b.off + b.dim - 1;
+    for (int64_t ta = a.off / kTile; ta <= a_end / kTile; ta++)
+      for (int64_t tb = b.off / kTile; tb <= b_end / kTile; tb++) T1[(ta > tb ? ta : tb) * nt + (ta > tb ? tb : ta)] = 1;
+    for (int64_t sa = a.off / kSub; sa <= a_end / kSub; sa++)
+      for (int64_t sb = b.off / kSub; sb <= b_end / kSub; sb++) {
+        const int64_t hi = sa > sb ? sa : sb, lo = sa > sb ? sb : sa;
+        atomicOr(&M16[lo * w16 + (hi >> 6)], 1ull << (hi & 63));
+      }
+    unsigned long long z = (unsigned long long)a.off * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)b.off + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^
+                           (unsigned long long)(a.dim | (b.dim << 8));
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    atomicAdd(&wg_sum, z);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_sum) atomicAdd(hsum, wg_sum);
+}
+}  // namespace
+
+// In: c.pair_row / c.pair_col (device, re-oriented), the layout of the reduced variables.  Out: T1 (nt x nt) and M16 (n16 x w16) with the
+// marks of the off-diagonal Schur blocks (the caller adds the diagonal blocks and the padding), *block_sum += the blocks' identity terms.
+void device_tile_marks(gtg_context& c, int64_t n_blocks, const std::vector<RedLayout>& layout, int nt, int n16, int w16,
+                       std::vector<uint8_t>& T1, std::vector<uint64_t>& M16, uint64_t* block_sum) {
+  hipStream_t s = c.stream;
+  const size_t b_t1 = ((size_t)nt * nt + 255) & ~(size_t)255, b_m16 = (size_t)n16 * w16 * 8, b_lay = (layout.size() * sizeof(RedLayout) + 255) & ~(size_t)255;
+  DevBuf<unsigned char> ws; ws.alloc(b_t1 + b_m16 + 256 + b_lay);
+  struct Release { DevBuf<unsigned char>& b; ~Release() { b.free(); } } release{ws};
+  unsigned char* d_t1 = ws.p;
+  unsigned long long* d_m16 = reinterpret_cast<unsigned long long*>(ws.p + b_t1);
+  unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(ws.p + b_t1 + b_m16);
+  RedLayout* d_lay = reinterpret_cast<RedLayout*>(ws.p + b_t1 + b_m16 + 256);
+  hc(hipMemsetAsync(ws.p, 0, b_t1 + b_m16 + 256, s), "memset");
+  hc(hipMemcpyAsync(d_lay, layout.data(), layout.size() * sizeof(RedLayout), hipMemcpyHostToDevice, s), "H2D");
+  hipLaunchKernelGGL(k_da_tile_marks, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, n_blocks, c.pair_row.p, c.pair_col.p, d_lay, nt, w16, d_t1, d_m16, d_sum);
+  hc(hipGetLastError(), "tile marks");
+  uint64_t sum = 0;
+  T1.resize((size_t)nt * nt); M16.resize((size_t)n16 * w16);
+  hc(hipMemcpyAsync(T1.data(), d_t1, (size_t)nt * nt, hipMemcpyDeviceToHost, s), "D2H");
+  hc(hipMemcpyAsync(M16.data(), d_m16, b_m16, hipMemcpyDeviceToHost, s), "D2H");
+  hc(hipMemcpyAsync(&sum, d_sum, sizeof(sum), hipMemcpyDeviceToHost, s), "D2H");
+  hc(hipStreamSynchronize(s), "tile marks");
+  *block_sum += sum;
 }
 
 // gtg_prewarm: this unit's kernels (kernels.h)
 static void prewarm_device_analysis(int) {
   prewarm_kernels({(const void*)k_da_nominal, (const void*)k_da_dups, (const void*)k_da_add_dups, (const void*)k_da_emit, (const void*)k_da_emit_dups, (const void*)k_da_gather,
-                   (const void*)k_da_flip, (const void*)k_da_obs, (const void*)k_da_inc_keys, (const void*)k_da_inc_decode, (const void*)k_da_offsets, (const void*)k_da_u32_to_i32});
+                   (const void*)k_da_split, (const void*)k_da_orient, (const void*)k_da_obs, (const void*)k_da_inc_keys, (const void*)k_da_inc_decode, (const void*)k_da_offsets, (const void*)k_da_u32_to_i32, (const void*)k_da_tile_marks});
 }
 static PrewarmUnit prewarm_device_analysis_registered(prewarm_device_analysis);
 

@@ -22,6 +22,7 @@
 #include <cstdio>
 
 #include <climits>
+#include <mutex>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -33,17 +34,19 @@ namespace {
 
 constexpr int kRcmThreads = 1024;
 constexpr int kMaxLevel = 4096;          // keys of one level in LDS (32 KB)
+constexpr int kRcmLdsNodes = 8192;       // k_rcm<true>: 14 bytes of LDS per node (+ the 32 KB of level keys): 147 KB of the CU's 160 KB
 
-__global__ __launch_bounds__(256) void k_edge_keys(int64_t m, const int32_t* __restrict__ a, const int32_t* __restrict__ b, uint64_t* __restrict__ key) {
+__global__ __launch_bounds__(256) void k_edge_keys(int64_t m, int n, const int32_t* __restrict__ a, const int32_t* __restrict__ b, uint64_t* __restrict__ key) {
   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
   if (i >= m) return;
   const uint64_t u = (uint32_t)a[i], v = (uint32_t)b[i];
-  // (a block of a variable with itself is not an edge: both keys become the same harmless self-key, dropped by k_csr)
-  key[2 * i] = (u << 32) | v;
-  key[2 * i + 1] = (v << 32) | u;
+  // (a block of a variable with itself is not an edge: both keys become the key of a node n, which sorts behind every node's -- k_csr's
+  // offsets end in front of it)
+  key[2 * i] = u == v ? (uint64_t)(uint32_t)n << 32 : (u << 32) | v;
+  key[2 * i + 1] = u == v ? (uint64_t)(uint32_t)n << 32 : (v << 32) | u;
 }
 
-// ptr[u] = first key whose source is >= u (self edges excluded beforehand by construction of the key list below)
+// ptr[u] = first key whose source is >= u (a self pair's key belongs to node n: behind ptr[n])
 __global__ __launch_bounds__(256) void k_csr(int n, const uint64_t* __restrict__ key, const int32_t* __restrict__ nkeys, int32_t* __restrict__ ptr,
                                               int32_t* __restrict__ adj) {
   const int m = *nkeys;
@@ -141,12 +144,25 @@ __device__ int far_node(const Rcm& g, int start, int32_t* __restrict__ q) {
   return pos == INT_MAX ? q[le - 1] : q[pos];
 }
 
+// kLds (graphs of up to kRcmLdsNodes nodes -- every camera system of the bench shapes): the per-node state (CSR offsets, claims, the
+// visited / active marks, the queue) lives in LDS instead of global memory.  A BFS level is a chain of dependent accesses -- queue ->
+// offsets -> neighbour -> marks -> claim, twice -- and with all of them in global memory a level cost 4.9 us (2.2 ms for the ~450 levels
+// of the three sweeps on the L1723 shape); only the neighbour lists are fetched from memory now.
+template <bool kLds>
 __global__ __launch_bounds__(kRcmThreads) void k_rcm(int n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ adj, int32_t* __restrict__ order,
                                                      int32_t* __restrict__ queue, int32_t* __restrict__ claim, unsigned char* __restrict__ visited,
                                                      unsigned char* __restrict__ active, int32_t* __restrict__ status) {
   __shared__ unsigned long long keys[kMaxLevel];
   __shared__ int sh[4];
+  extern __shared__ __attribute__((aligned(16))) char rcm_dyn[];
   const int tid = threadIdx.x;
+  if (kLds) {
+    int32_t* ptr_s = reinterpret_cast<int32_t*>(rcm_dyn);
+    for (int i = tid; i <= n; i += kRcmThreads) ptr_s[i] = ptr[i];
+    claim = ptr_s + (n + 1); queue = claim + n;
+    visited = reinterpret_cast<unsigned char*>(queue + n); active = visited + n;
+    ptr = ptr_s;
+  }
   Rcm g{n, ptr, adj, claim, visited, active, keys, sh};
   for (int i = tid; i < n; i += kRcmThreads) active[i] = 1;
   if (tid == 0) sh[2] = 0;
@@ -163,12 +179,14 @@ __global__ __launch_bounds__(kRcmThreads) void k_rcm(int n, const int32_t* __res
     if (seed == INT_MAX) break;
     const int start = far_node(g, far_node(g, seed, queue), queue);
     int lb;
-    const int len = bfs(g, start, true, order + done, &lb);
-    for (int p = tid; p < len; p += kRcmThreads) active[order[done + p]] = 0;
+    const int len = bfs(g, start, true, kLds ? queue : order + done, &lb);
+    if (kLds) for (int p = tid; p < len; p += kRcmThreads) order[done + p] = queue[p];
+    for (int p = tid; p < len; p += kRcmThreads) active[kLds ? queue[p] : order[done + p]] = 0;
     __syncthreads();
     done += len;
     if (sh[2]) break;
   }
+  __syncthreads();
   // reversed
   for (int i = tid; i < n / 2; i += kRcmThreads) { const int a = order[i], b = order[n - 1 - i]; order[i] = b; order[n - 1 - i] = a; }
   if (tid == 0) status[0] = (sh[2] || done != n) ? 1 : 0;
@@ -180,8 +198,9 @@ void hc(hipError_t e, const char* what) { check_hip(e, what); }
 
 // edges: the off-diagonal blocks of the reduced system as pairs of reduced indices (either orientation, repeats allowed).
 // Returns false when the graph is outside what the kernel handles (the caller then runs the host ordering).
-bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std::vector<int32_t>& eb, std::vector<int32_t>& order) {
-  const int64_t m = (int64_t)ea.size();
+bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std::vector<int32_t>& eb, std::vector<int32_t>& order,
+                const int32_t* d_ea, const int32_t* d_eb, int64_t d_edges) {
+  const int64_t m = d_ea ? d_edges : (int64_t)ea.size();
   if (n < 2 || n >= (1 << 22) || m == 0 || 2 * m >= INT_MAX) return false;
   hipStream_t s = c.stream;
   // one workspace, carved (a dozen separate allocations and their releases cost more than the ordering itself)
@@ -207,14 +226,21 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
   int32_t* dptr = reinterpret_cast<int32_t*>(at(o_ptr)); int32_t* dadj = reinterpret_cast<int32_t*>(at(o_adj));
   int32_t* dorder = reinterpret_cast<int32_t*>(at(o_order)); int32_t* dqueue = reinterpret_cast<int32_t*>(at(o_queue));
   int32_t* dclaim = reinterpret_cast<int32_t*>(at(o_claim)); int32_t* dn = reinterpret_cast<int32_t*>(at(o_n)); int32_t* dstatus = reinterpret_cast<int32_t*>(at(o_status));
-  hc(hipMemcpyAsync(da, ea.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
-  hc(hipMemcpyAsync(db, eb.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
-  hipLaunchKernelGGL(k_edge_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, da, db, k1);
+  if (!d_ea) {
+    hc(hipMemcpyAsync(da, ea.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
+    hc(hipMemcpyAsync(db, eb.data(), 4 * (size_t)m, hipMemcpyHostToDevice, s), "H2D");
+  }
+  hipLaunchKernelGGL(k_edge_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, n, d_ea ? d_ea : da, d_ea ? d_eb : db, k1);
   prim::sort_keys(k1, k2, (size_t)(2 * m), bits, at(o_tmp), s);
   prim::runs(k2, (size_t)(2 * m), k1, nullptr, dn, at(o_tmp), s);     // the distinct keys, ascending
-  // (the lists carry no block of a variable with itself: analysis.hip filters a == b)
   hipLaunchKernelGGL(k_csr, dim3((unsigned)std::max<int64_t>((n + 256) / 256, 64)), dim3(256), 0, s, n, k1, dn, dptr, dadj);
-  hipLaunchKernelGGL(k_rcm, dim3(1), dim3(kRcmThreads), 0, s, n, dptr, dadj, dorder, dqueue, dclaim, at(o_vis), at(o_act), dstatus);
+  if (n <= kRcmLdsNodes) {
+    const size_t lds = 4 * ((size_t)n + 1) + 10 * (size_t)n + 16;
+    static std::once_flag attr_once;     // (the attribute is per function, the largest request once)
+    std::call_once(attr_once, [] { hc(hipFuncSetAttribute((const void*)k_rcm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 14 * kRcmLdsNodes + 32), "smem attr"); });
+    hipLaunchKernelGGL(k_rcm<true>, dim3(1), dim3(kRcmThreads), lds, s, n, dptr, dadj, dorder, dqueue, dclaim, at(o_vis), at(o_act), dstatus);
+  } else
+    hipLaunchKernelGGL(k_rcm<false>, dim3(1), dim3(kRcmThreads), 0, s, n, dptr, dadj, dorder, dqueue, dclaim, at(o_vis), at(o_act), dstatus);
   hc(hipGetLastError(), "device ordering");
   order.resize((size_t)n);
   hc(hipMemcpyAsync(order.data(), dorder, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s), "D2H");
@@ -229,7 +255,7 @@ bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& ea, const std
 }
 
 // gtg_prewarm: this unit's kernels (kernels.h)
-static void prewarm_device_ordering(int) { prewarm_kernels({(const void*)k_edge_keys, (const void*)k_csr, (const void*)k_rcm}); }
+static void prewarm_device_ordering(int) { prewarm_kernels({(const void*)k_edge_keys, (const void*)k_csr, (const void*)k_rcm<true>, (const void*)k_rcm<false>}); }
 static PrewarmUnit prewarm_device_ordering_registered(prewarm_device_ordering);
 
 }  // namespace gt

@@ -39,10 +39,18 @@ int64_t exchange_block_doubles(const gtg_context& c);                    // size
 void launch_pack_blocks(gtg_context& c, SMat S, int NP, double* buf, bool unpack);
 // device_analysis.hip: the Schur term lists built on the device (single shard, real runtime)
 void device_incidence_lists(gtg_context& c, const std::vector<int32_t>& red_pos, gt::DevBuf<int32_t>& d_pos);
-void device_schur_terms(gtg_context& c, gt::DevBuf<int32_t>& d_pos, int nrv, std::vector<uint64_t>& block_keys, std::vector<int64_t>& block_ptr);
-void device_flip_terms(gtg_context& c, const std::vector<int64_t>& flipped);
+void device_schur_terms(gtg_context& c, gt::DevBuf<int32_t>& d_pos, int nrv, const std::vector<int32_t>& pos_to_red, std::vector<int32_t>& block_row,
+                        std::vector<int32_t>& block_col, std::vector<int64_t>& block_ptr);   // blocks stay in c.pair_row / c.pair_col; host copies out
+void device_orient_blocks(gtg_context& c, int64_t n_blocks, const std::vector<int32_t>& red_pos);   // after the ordering: row = the later position
+// after the ordering: the marks of the off-diagonal Schur blocks (c.pair_row / c.pair_col, already on the device) in the tile structure T1
+// (nt x nt bytes), the strip structure M16 (n16 columns of w16 words) and the commutative sum over the block set (structure_hash)
+struct RedLayout { int64_t off, dim; };      // scalar offset and dimension of a reduced variable in S
+void device_tile_marks(gtg_context& c, int64_t n_blocks, const std::vector<RedLayout>& layout, int nt, int n16, int w16,
+                       std::vector<uint8_t>& T1, std::vector<uint64_t>& M16, uint64_t* block_sum);
 // device_ordering.hip: reverse Cuthill-McKee of the reduced variables' block graph on the device (false: outside what the kernel handles)
-bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& edge_a, const std::vector<int32_t>& edge_b, std::vector<int32_t>& order);
+// (edges on the host: uploaded; d_edge_a / d_edge_b non-null: m edges already on the device, pairs a == b among them are skipped)
+bool device_rcm(gtg_context& c, int n, const std::vector<int32_t>& edge_a, const std::vector<int32_t>& edge_b, std::vector<int32_t>& order,
+                const int32_t* d_edge_a = nullptr, const int32_t* d_edge_b = nullptr, int64_t d_edges = 0);
 // smart factors (SmartProjectionFactor): triangulation of the hidden landmarks from the cameras in `values` (gated: only when the
 // linear cost change of the current try is >= 0), Schur-complement correction of the Hessian diagonal, constant of linear.error
 void launch_smart_triangulate(gtg_context& c, double* values, const double* gate, bool for_linearize);   // gate: scalars with the linear errors (trial point) or null
@@ -60,7 +68,8 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
                    const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
 void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct,             // the host half (no runtime call)
                         const std::vector<int32_t>* tile_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
-void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16 = nullptr);   // the device half
+void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16 = nullptr,
+                    const int32_t* d_slot = nullptr);   // the device half (d_slot: the device copy of `slot` -- the tables are resolved by a kernel then)
 void free_df_plan(DfPlan& df);
 bool dataflow_schedule_selected();   // false: GTG_CHOL=streams (the stream / event schedule of cholesky.hip, the A/B of the dataflow pass)
 void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,

@@ -274,7 +274,10 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   //  - `slots` (variable id -> the GenericValue object of the copy): one walk over the copy's map, made by the same thread.
   // Two threads: the two copies are as long as each other (18 + 16 ms on the L1723 shape) and as the whole of the library's set-up beside them.
   std::exception_ptr copyErr, copyErr2;
-  std::thread copier([&] { try { graph_ = graph; } catch (...) { copyErr = std::current_exception(); } });
+  // (graph_: the copy used to run on a thread of its own -- a second pass of cache misses over the 0.68 M factors beside the extraction's,
+  // and with the deep copy of the Values the last thing the constructor waited for.  The extraction threads make it now, each factor
+  // while it is in the thread's cache anyway.)
+  std::thread copier([&] { try { graph_.resize(graph.size()); } catch (...) { copyErr = std::current_exception(); } });
   std::thread copier2([&] {
     try {
       m.scratch = initial;
@@ -289,13 +292,58 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   std::thread prewarmer([device] { gtg_prewarm(device); });
   Join joinPrewarmer{prewarmer};
 
-  // ---- variables: Values order (sorted by Key, Values.h:74-79).  One serial walk over the map collects keys and value pointers (the
-  // walk is pointer chasing: it does not split); classification (a chain of dynamic_casts) runs on the extraction's threads below, each
-  // thread its range; the values are packed on threads while the factor tables are merged.
+  // ---- variables: Values order (sorted by Key, Values.h:74-79).  The walk over the map that collects keys and value pointers is pointer
+  // chasing (1.5 - 5 ms for the 158 000 variables of the L1723 shape, beside the two copier threads); it is cut into key ranges walked
+  // side by side: the range boundaries are lower_bound()s of keys interpolated inside every symbol's index range (Symbol keys: character
+  // in the top byte, Key.h / Symbol.h; plain integer keys are one such range), so the pieces are equal where the indices are dense and
+  // merely unequal where they are not.  Classification (a chain of dynamic_casts) runs on the extraction's threads below, each thread its
+  // range; the values are packed on threads while the factor tables are merged.
+  lap("(threads started)");
   const size_t nvars = initial.size();
   m.keys.reserve(nvars);
   std::vector<const Value*> vptr; vptr.reserve(nvars);
-  for (const auto& kv : initial) { m.keys.push_back(kv.key); vptr.push_back(&kv.value); }
+  {
+    const char* walk_env = std::getenv("GTG_VALUES_WALKERS");   // (tests: the split walk on small graphs)
+    const size_t walkers = nvars < 2 ? 1 : walk_env ? (size_t)std::max(1, std::atoi(walk_env)) : nvars >= 32768 ? 4 : 1;
+    std::vector<Values::deref_iterator> cut;           // walker t takes [cut[t], cut[t + 1])
+    cut.push_back(initial.begin());
+    if (walkers > 1) {
+      struct Seg { Key first, last; };
+      std::vector<Seg> segs;                            // the keys of one symbol character each
+      for (auto it = initial.begin(); it != initial.end();) {
+        const Key first = (*it).key, top = first >> 56;
+        auto next = top == 0xFF ? initial.end() : initial.lower_bound((top + 1) << 56);
+        auto last = next; --last.it_;
+        segs.push_back(Seg{first, (*last).key});
+        it = next;
+      }
+      long double total = 0;
+      for (const Seg& g : segs) total += (long double)(g.last - g.first) + 1;
+      size_t gi = 0; long double before = 0;
+      for (size_t t = 1; t < walkers; t++) {
+        const long double want = total * t / walkers;
+        while (gi + 1 < segs.size() && before + (long double)(segs[gi].last - segs[gi].first) + 1 <= want) { before += (long double)(segs[gi].last - segs[gi].first) + 1; gi++; }
+        const Key k = segs[gi].first + (Key)std::min<long double>(want - before, (long double)(segs[gi].last - segs[gi].first));
+        cut.push_back(initial.lower_bound(k));
+      }
+    }
+    cut.push_back(initial.end());
+    lap("(variables: key ranges)");
+    const size_t pieces = cut.size() - 1;
+    std::vector<std::vector<Key>> pk(pieces);
+    std::vector<std::vector<const Value*>> pv(pieces);
+    auto walk = [&](size_t t) {
+      pk[t].reserve(nvars / pieces + 16); pv[t].reserve(nvars / pieces + 16);
+      for (auto it = cut[t]; it != cut[t + 1]; ++it) { const auto kv = *it; pk[t].push_back(kv.key); pv[t].push_back(&kv.value); }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < pieces; t++) pool.emplace_back(walk, t);
+    walk(0);
+    for (auto& th : pool) th.join();
+    lap("(variables: walk)");
+    for (size_t t = 0; t < pieces; t++) { m.keys.insert(m.keys.end(), pk[t].begin(), pk[t].end()); vptr.insert(vptr.end(), pv[t].begin(), pv[t].end()); }
+    if (m.keys.size() != nvars) throw std::logic_error("GpuLevenbergMarquardtOptimizer: the walk over the Values lost variables");
+  }
   m.var_type.assign(nvars, -1);
   // Key -> variable id: the keys are sorted, so a binary search over the contiguous array (a std::map of 158 000 keys cost 0.2 s of
   // pointer chasing for the 1.35 M lookups of the L1723 shape)
@@ -322,7 +370,7 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
     size_t i = b;
     try {
       for (; i < e; i++) {
-        const auto& f = graph[i];
+        const auto& f = (graph_.at(i) = graph.begin()[i]);   // (graph[i] returns a COPY of the pointer: two more atomic operations per factor)
         if (!f) { x.fac_map.emplace_back(-1, 0); continue; }
         if (auto s = dynamic_cast<const SfmFactor*>(f.get())) {
           x.fac_map.emplace_back(GTG_FAC_GENERAL_SFM, (int64_t)x.sfm_cam.size());
@@ -406,6 +454,8 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
       }
     } catch (...) { x.err = std::current_exception(); x.err_at = i; }
   };
+  copier.join();
+  if (copyErr) std::rethrow_exception(copyErr);
   {
     std::vector<std::thread> pool;
     for (size_t ti = 1; ti < nthreads; ti++) pool.emplace_back(work, ti);
@@ -529,7 +579,7 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   double e0 = 0.0;
   check(gtg_error(m.h, &e0), "gtg_error");
   lap("device: initial error");
-  copier.join(); copier2.join();
+  copier2.join();
   lap("wait for the copies of the graph and the Values");
   if (copyErr) std::rethrow_exception(copyErr);
   if (copyErr2) std::rethrow_exception(copyErr2);

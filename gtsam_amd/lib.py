@@ -28,7 +28,7 @@ SYMBOLS = ["gtg_create", "gtg_destroy", "gtg_prewarm", "gtg_last_error", "gtg_ve
            "gtg_get_jacobians", "gtg_reduced_dim", "gtg_get_reduced_matrix", "gtg_set_allreduce",
            "gtg_enable_timing", "gtg_get_phase_ms", "gtg_reset_timing", "gtg_phase_name",
            "gtg_cholesky_flops", "gtg_cholesky_flops_block_level", "gtg_cholesky_flops_executed", "gtg_linearize_bytes", "gtg_dense_cholesky_host", "gtg_structure_hash",
-           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_cached_memory_bytes", "gtg_values_device_ptr", "gtg_values_changed",
+           "gtg_debug_plan_sizes", "gtg_debug_plan_lists", "gtg_debug_df_plan", "gtg_debug_df_device_tables", "gtg_debug_df_chains", "gtg_debug_reduced_order", "gtg_debug_df_ctrl", "gtg_debug_df_poll_stats", "gtg_debug_df_trace", "gtg_release_cached_memory", "gtg_cached_memory_bytes", "gtg_values_device_ptr", "gtg_values_changed",
            "gtg_io_last_error", "gtg_io_bal_sizes", "gtg_io_read_bal", "gtg_io_write_bal",
            "gtg_io_g2o_sizes", "gtg_io_read_g2o", "gtg_io_write_g2o",
            "gtg_debug_scan", "gtg_debug_sort_pairs", "gtg_debug_runs"]
@@ -93,6 +93,7 @@ def load():
     lib.gtg_debug_plan_sizes.argtypes = [C.c_void_p, C.c_void_p]
     lib.gtg_debug_plan_lists.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.gtg_debug_df_plan.argtypes = [C.c_void_p] * 4
+    lib.gtg_debug_df_device_tables.argtypes = [C.c_void_p] * 5
     lib.gtg_debug_df_chains.argtypes = [C.c_void_p] * 5
     lib.gtg_debug_reduced_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.gtg_debug_df_ctrl.argtypes = [C.c_void_p] * 2
@@ -279,6 +280,15 @@ class DeviceGraph:
         coff = np.zeros(int(cs[0]) + 1, np.int32); ctiles = np.zeros(int(cs[1]), np.int32); seq = np.zeros(int(cs[2]), np.int32)
         _check(self.lib.gtg_debug_df_chains(self.h, cs.ctypes.data, coff.ctypes.data, ctiles.ctypes.data, seq.ctypes.data), "gtg_debug_df_chains")
         return dict(nt=int(sz[0]), active=bool(sz[3]), tasks=tasks, klist=klist, chain_off=coff, chain_tiles=ctiles, seq=seq)
+
+    def df_device_tables(self):
+        """Test hook: the dataflow schedule as the kernels read it, copied back from the device (gtg_debug_df_device_tables):
+        (tasks[n][12], steps[m][6], chain words)."""
+        sz = np.zeros(3, np.int64)
+        _check(self.lib.gtg_debug_df_device_tables(self.h, sz.ctypes.data, None, None, None), "gtg_debug_df_device_tables")
+        tasks = np.zeros(int(sz[0]), np.int32); steps = np.zeros(int(sz[1]), np.int32); chain = np.zeros(int(sz[2]), np.int32)
+        _check(self.lib.gtg_debug_df_device_tables(self.h, sz.ctypes.data, tasks.ctypes.data, steps.ctypes.data, chain.ctypes.data), "gtg_debug_df_device_tables")
+        return tasks.reshape(-1, 12), steps.reshape(-1, 6), chain
 
     def df_trace(self):
         """GTG_DF_TRACE=1: (tasks[n][8] stamps, chain[nt][2] stamps) of the last factorisation, 100 MHz ticks."""

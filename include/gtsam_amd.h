@@ -287,6 +287,12 @@ int gtg_debug_plan_lists(gtg_handle h, int32_t* rows, int32_t* pairs, int32_t* b
  * row; a long contraction is cut into pieces that accumulate in place, the last piece finishes the tile), in the order in which
  * the persistent workgroups take them.  Executed in numpy by tests/test_chol_plan.py. */
 int gtg_debug_df_plan(gtg_handle h, int64_t sizes[4], int32_t* tasks, int32_t* klist);
+/* The same schedule as the kernels read it, copied back from the device: sizes = {int32 words of the task table (12 per task: the six
+ * above, slot of the tile, slot of its diagonal tile, accumulator lanes, first scratch slot, the tile's 64-bit sub-tile mask), words of
+ * the step table (6 per contraction step: slots of the two operand tiles, their sub-tile masks), words of the chain table}.  The tables
+ * are resolved by a kernel (k_df_resolve) on a real runtime and by a host loop otherwise / with GTG_HOST_SYMBOLIC=1:
+ * tests/test_gpu_device_analysis.py compares the two word for word. */
+int gtg_debug_df_device_tables(gtg_handle h, int64_t sizes[3], int32_t* tasks, int32_t* steps, int32_t* chain);
 /* The diagonal chains of the same schedule: sizes = {chain workgroups W, diagonal tiles, block columns}; workgroup w of the chain
  * kernel factors chain_tiles[chain_off[w] .. chain_off[w + 1]) in that order (one chain = two workgroups that alternate; several
  * chains when a nested-dissection ordering gave the elimination tree independent subtrees -- the reference's parallel elimination of

@@ -82,3 +82,44 @@ def test_device_ordering_equals_host_ordering(name, p, monkeypatch):
     b = run()
     assert np.array_equal(a[0], b[0]), (np.flatnonzero(a[0] != b[0])[:10], a[0][:10], b[0][:10])
     assert a[1] == b[1] and a[2] == b[2]
+
+
+def _symbolic_problems():
+    from tools import host_profile as HP
+    from gtsam_amd import datasets as D
+    from gtsam_amd.problem import bal_problem
+    yield "bal_300_cameras", HP.problem_for("bal:300:20000:3")
+    yield "streets1723 (long-range loop closures)", HP.problem_for("streets1723")
+    yield "ladybug1723 (the bench shape)", bal_problem(*D.ladybug_1723())
+    yield "dubrovnik16 (below the device pass's size: host either way)", bal_problem(*D.dubrovnik_16())
+
+
+@pytest.mark.parametrize("name,pv", list(_symbolic_problems()), ids=[n for n, _ in _symbolic_problems()])
+def test_device_tile_marks_and_plan_tables_equal_host(name, pv, monkeypatch):
+    """After the ordering: the marks of the Schur blocks in the tile / strip structure (device_analysis.hip::k_da_tile_marks) and the
+    dataflow plan's device tables (chol_dataflow.hip::k_df_resolve) against the host loops they replace (GTG_HOST_SYMBOLIC=1): the same
+    layout hash (tile structure, exchange list, block set), the same flop counts (stored tiles; executed = after the sub-tile masks of
+    the strip-level symbolic factorisation), the same task / step / chain tables word for word, and the same step bit for bit."""
+    import torch
+    assert torch.cuda.is_available()
+    from gtsam_amd import lib as L
+    p, v0 = pv
+
+    def run():
+        dev = L.DeviceGraph(p)
+        dev.set_values(v0)
+        dev.linearize()
+        rc, out = dev.try_lambda(1e-3, True)
+        res = (rc, out.copy(), dev.delta().copy(), dev.structure_hash(), dev.cholesky_flops(), dev.cholesky_flops_executed(), dev.df_device_tables())
+        dev.close()
+        return res
+
+    monkeypatch.delenv("GTG_HOST_SYMBOLIC", raising=False)
+    a = run()
+    monkeypatch.setenv("GTG_HOST_SYMBOLIC", "1")
+    b = run()
+    assert a[0] == b[0] == 0
+    assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+    for x, y in zip(a[6], b[6]):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])

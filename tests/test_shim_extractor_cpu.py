@@ -63,7 +63,9 @@ def test_cpp_and_python_extractors_hand_the_library_identical_tables():
             cpp[parts[1]] = parts[2:]
     # the extraction runs on host threads (a contiguous range of the graph each, tables concatenated in graph order, rows of the noise /
     # calibration tables handed out afterwards in first-occurrence order): the same tables for any thread count
-    env_mt = dict(env); env_mt["GTG_HOST_THREADS"] = "5"; env_mt["GTG_EXTRACT_GRAIN"] = "3"
+    # (and the walk over the Values cut into key ranges -- three walkers over the two symbol ranges of the SfM example, over the plain
+    # integer keys of the pose graphs: the same variable order)
+    env_mt = dict(env); env_mt["GTG_HOST_THREADS"] = "5"; env_mt["GTG_EXTRACT_GRAIN"] = "3"; env_mt["GTG_VALUES_WALKERS"] = "3"
     r_mt = subprocess.run([EXE, DATA], env=env_mt, capture_output=True, text=True, timeout=300)
     assert r_mt.returncode == 0 and "ALL PASSED" in r_mt.stdout, r_mt.stdout[-2000:] + r_mt.stderr[-2000:]
     assert [ln for ln in r_mt.stdout.splitlines() if ln.startswith("CASE ")] == [ln for ln in r.stdout.splitlines() if ln.startswith("CASE ")]

@@ -171,6 +171,7 @@ void analyze(gtg_context& c) {
   DevBuf<int32_t> d_obs_pos;                    // (device pass: observation -> position of its camera, consumed by device_schur_terms)
   if (device_terms) {
     device_incidence_lists(c, c.h_red_pos, d_obs_pos);
+    clk.lap("variable roles (host); incidence lists (device)");
   } else {
   obs_red.resize(c.n_obs); obs_lm.resize(c.n_obs);
   for (int64_t i = 0; i < n_sfm; i++) { obs_red[i] = c.h_red_index[hi.sfm_cam[i]]; obs_lm[i] = c.h_lm_index[hi.sfm_point[i]]; }
@@ -234,7 +235,7 @@ void analyze(gtg_context& c) {
   hoff_ptr.push_back(n_btw);
   c.n_hoff = (int64_t)hoff_row.size();
 
-  clk.lap(device_terms ? "variable classification, between / prior lists" : "incidence lists");
+  clk.lap(device_terms ? "landmark priors, between blocks (host)" : "incidence lists");
   // Schur block pairs: for every landmark, every pair of its observations is one term E_a E_b^T of the block
   // (row = the later position, column = the earlier one).  Terms are bucketed by the row position of their block
   // (counting sort), then every row bucket is sorted by column position (stable: the generation order = landmark
@@ -818,11 +819,13 @@ void analyze(gtg_context& c) {
       // and uploaded when both are done.
       {
         std::thread dfh; std::exception_ptr dferr;
-        if (c.use_df) dfh = std::thread([&] { try { build_df_plan_host(c.df, nt, dense ? nullptr : &T1, &tile_part, &part_parent); } catch (...) { dferr = std::current_exception(); } });
-        try { build_chol_plan(c.plan, nt, dense ? nullptr : &B2, s, &pair_part, &part_parent); }
+        double df_ms = 0.0;
+        if (c.use_df) dfh = std::thread([&] { try { StageClock k; build_df_plan_host(c.df, nt, dense ? nullptr : &T1, &tile_part, &part_parent); df_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - k.t).count(); } catch (...) { dferr = std::current_exception(); } });
+        try { StageClock k; build_chol_plan(c.plan, nt, dense ? nullptr : &B2, s, &pair_part, &part_parent); k.lap("  (stream schedule + slots, this thread)"); }
         catch (...) { if (dfh.joinable()) dfh.join(); throw; }
         if (dfh.joinable()) dfh.join();
         if (dferr) std::rethrow_exception(dferr);
+        if (clk.on) std::fprintf(stderr, "[gtsam_amd setup]   (dataflow task lists, second thread) %8.2f ms\n", df_ms);
         clk.lap("tile schedules (task lists of both passes, two threads)");
         if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored, dense ? nullptr : &sub16, kernels_can_run ? c.plan.slot.p : nullptr);
         clk.lap("dataflow plan resolved to slots + uploaded");

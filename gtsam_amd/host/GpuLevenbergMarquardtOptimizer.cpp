@@ -355,13 +355,22 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const char* thr_env = std::getenv("GTG_HOST_THREADS");
   const size_t grain = std::getenv("GTG_EXTRACT_GRAIN") ? std::max(1, std::atoi(std::getenv("GTG_EXTRACT_GRAIN"))) : 4096;   // factors per thread at least (tests: 1)
-  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(hw, 32u)), nfac / grain + 1}));
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(thr_env ? std::max(1, std::atoi(thr_env)) : (int)std::min(hw, 16u)), nfac / grain + 1}));
   std::vector<Extract> part(nthreads);
   auto work = [&](size_t ti) {
     Extract& x = part[ti];
     const size_t b = nfac * ti / nthreads, e = nfac * (ti + 1) / nthreads;
     x.fac_map.reserve(e - b);
     x.sm_ptr.push_back(0);
+    // (a chunk is nearly always one kind of factor: room for that kind up front -- vectors that grow by doubling go through mmap / munmap
+    // above 128 KB, and 16 threads doing that held up the thread that deep-copies the Values: it was the last thing the constructor
+    // waited for, 7 ms with 32 extraction threads, 0.3 ms with 16 -- round 6, L1723 shape)
+    if (b < e && graph.begin()[b]) {
+      const NonlinearFactor* f0 = graph.begin()[b].get();
+      if (dynamic_cast<const SfmFactor*>(f0)) { x.sfm_cam.reserve(e - b); x.sfm_pt.reserve(e - b); x.sfm_z.reserve(2 * (e - b)); }
+      else if (dynamic_cast<const ProjFactor*>(f0) || dynamic_cast<const ProjFactorDS2*>(f0)) { x.pj_pose.reserve(e - b); x.pj_pt.reserve(e - b); x.pj_sen.reserve(e - b); x.pj_z.reserve(2 * (e - b)); x.pj_cal.reserve(e - b); }
+      else if (dynamic_cast<const BetweenFactor<Pose3>*>(f0) || dynamic_cast<const BetweenFactor<Pose2>*>(f0)) { x.bt_1.reserve(e - b); x.bt_2.reserve(e - b); x.bt_z.reserve(12 * (e - b)); x.bt_dim.reserve(e - b); }
+    }
     for (size_t v = nvars * ti / nthreads; v < nvars * (ti + 1) / nthreads; v++) {   // this thread's variables: their types (-1: unsupported, reported below)
       const Value* val = vptr[v];
       m.var_type[v] = dynamic_cast<const GenericValue<Point3>*>(val) ? GTG_VAR_POINT3 : dynamic_cast<const GenericValue<SfmCamera>*>(val) ? GTG_VAR_SFM_CAMERA :

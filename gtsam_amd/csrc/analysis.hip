@@ -404,6 +404,8 @@ void analyze(gtg_context& c) {
   for (int attempt = 0; attempt < 2; attempt++) {
   join_block_level(c);
   const int nd_depth_try = attempt == 0 ? (nd_env ? std::atoi(nd_env) : nd_auto) : 0;
+  // (no nested dissection = one chain = two chain workgroups: that plan's masked stream pair can be on its way before the ordering)
+  if (nd_depth_try == 0 && kernels_can_run && dataflow_schedule_selected()) df_prepare_streams_async(c.device, 2);
   bool retry_rcm = false;
   std::vector<int32_t> part_of_pos;          // nested-dissection part of every position (empty: one part)
   std::vector<int32_t> part_parent;          // parent part (-1: root) of every part, parts numbered in elimination order
@@ -874,7 +876,11 @@ void analyze(gtg_context& c) {
     }
   }
 
-  if (!retry_rcm) break;
+  if (!retry_rcm) {
+    // the plan stands: its masked stream pair is created on a helper thread from here on (chol_dataflow.hip::df_prepare_streams_async)
+    if (c.use_df && kernels_can_run) df_prepare_streams_async(c.device, c.df.n_chain);
+    break;
+  }
   }
 
   // ---- upload -----------------------------------------------------------------------------------

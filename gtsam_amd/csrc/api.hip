@@ -335,6 +335,7 @@ int gtg_prewarm(int device_id) {
 int gtg_destroy(gtg_handle c) {
   if (!c) return GTG_OK;
   try { join_block_level(*c); } catch (...) {}
+  try { df_join_prepared(); } catch (...) {}
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   auto& f = c->f;
@@ -695,17 +696,35 @@ int gtg_error(gtg_handle c, double* error) {
   GTG_CATCH
 }
 
+// GTG_DEBUG_TIMING=1: the host time of every phase of the FIRST linearisation and the FIRST lambda try of the process, each behind a stream
+// synchronisation -- what a cold process pays there once (40 - 50 ms on the L1723 shape against 6 ms for every later iteration).
+struct FirstCallClock {
+  bool on; hipStream_t s; std::chrono::high_resolution_clock::time_point t;
+  FirstCallClock(std::atomic<int>& calls, hipStream_t stream) : on(std::getenv("GTG_DEBUG_TIMING") != nullptr && calls.fetch_add(1) == 0), s(stream), t(std::chrono::high_resolution_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const auto n = std::chrono::high_resolution_clock::now();
+    std::fprintf(stderr, "[gtsam_amd first ] %-40s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+static std::atomic<int> g_first_linearize{0}, g_first_try{0};
+
 int gtg_linearize(gtg_handle c) {
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_linearize: no problem uploaded");
   DeviceGuard on_device(c->device);
   if (c->n_smart) check_hip(hipMemsetAsync(c->scalars.p + SC_UNSUPPORTED, 0, sizeof(double), c->stream), "memset");
+  FirstCallClock first(g_first_linearize, c->stream);
   { PhaseTimer t(*c, GTG_PH_LINEARIZE, c->phase_events.data()); launch_smart_triangulate(*c, c->values.p, nullptr, true); launch_linearize(*c); }
+  first.lap("linearize");
   { PhaseTimer t(*c, GTG_PH_ASSEMBLE, c->phase_events.data()); launch_assemble(*c);
     if (c->n_smart) {   // the cameras' Hessian diagonal is that of the Schur-complemented smart factors: needs their E blocks (undamped)
       launch_point_eliminate(*c, 1.0, 0, 1e-6, 1e32);
       launch_smart_hdiag(*c);
     } }
+  first.lap("assemble");
   exchange(*c, c->hdiag_red.p, c->NP);   // damping needs the full diagonal on every shard
   if (c->n_smart) {   // (sharded: every shard must see what any shard met)
     if (c->n_shards > 1) exchange(*c, c->scalars.p + SC_UNSUPPORTED, 1);
@@ -737,11 +756,14 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
   // Sharded: the scalars are summed over the shards by read_scalars, so every shard sees the time-out of any shard and all repeat.
   // (GTG_CHOL=streams: there is no other schedule to fall back to -- one repeat, then the error)
   const int max_attempts = c->use_df ? 3 : 2;
+  FirstCallClock first(g_first_try, c->stream);
   for (int attempt = 0; attempt < max_attempts; attempt++) {
     const bool df = c->use_df && attempt != 2;
     check_hip(hipMemsetAsync(c->scalars.p + SC_FAIL, 0, 3 * sizeof(double), c->stream), "memset");
     { PhaseTimer t(*c, GTG_PH_POINT_ELIM, c->phase_events.data()); launch_point_eliminate(*c, lambda, diag, dmin, dmax); }
+    first.lap("point elimination");
     { PhaseTimer t(*c, GTG_PH_SCHUR, c->phase_events.data()); launch_build_reduced(*c, lambda, diag, dmin, dmax); }
+    first.lap("reduced system");
     if (c->n_shards > 1) {   // the one big exchange: reduced Hessian + rhs
       if (c->n_xb == 0) {     // (no block list: whole stored 128x128 tiles, the first version of the exchange)
         const int64_t nb = c->plan.n_exch * kTile * kTile;
@@ -762,9 +784,11 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     { PhaseTimer t(*c, GTG_PH_CHOLESKY, c->phase_events.data());
       if (df) launch_cholesky_df(*c, smat(*c), c->NP, c->df, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p);
       else launch_cholesky(*c, smat(*c), c->NP, c->plan, c->Dinv.p, c->scalars.p + SC_FAIL, c->pivot_kind.p, c->tile_exp.p); }
+    first.lap("factorisation");
     { PhaseTimer t(*c, GTG_PH_SOLVE, c->phase_events.data());
       launch_backward_solve(*c, smat(*c), c->NP, c->plan, c->Dinv.p, c->xred.p, c->scalars.p + SC_FAIL);
       launch_back_substitute(*c);
+      first.lap("solves");
       if (c->n_shards > 1 && one_at_a_time.owns_lock()) {   // sharded: the exchange below may wait for another handle of this
         check_hip(hipStreamSynchronize(c->stream), "sync");   // process (two shards on one device in the tests): the factorisation is
         one_at_a_time.unlock();                                // done, let the other one start before waiting for it
@@ -775,6 +799,7 @@ int gtg_try_lambda(gtg_handle c, double lambda, int diag, double dmin, double dm
     { PhaseTimer t(*c, GTG_PH_RETRACT, c->phase_events.data()); launch_retract(*c); }
     { PhaseTimer t(*c, GTG_PH_ERROR, c->phase_events.data()); const double* gate = c->scalars.p + (smart_gate(*c) ? 2 * SC_COUNT : 0);
       launch_smart_triangulate(*c, c->trial.p, gate, false); launch_error(*c, c->trial.p, SC_TRIAL_ERROR, gate); }
+    first.lap("linear error, retract, error");
     read_scalars(*c);
     if (one_at_a_time.owns_lock()) one_at_a_time.unlock();
     if (attempt + 1 < max_attempts && c->h_scalars[SC_TIMEOUT] != 0.0) {

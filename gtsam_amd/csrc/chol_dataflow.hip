@@ -23,6 +23,7 @@
 // as "not positive definite"), after which every wait falls through and both kernels drain.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1160,14 +1161,40 @@ static DfStreams& df_streams(int device, int reserve) {
   return ds;
 }
 
+// The masked stream pair a plan needs (and the kernels' dynamic-LDS attributes) ahead of its first factorisation: analysis.hip calls this as
+// soon as the plan's chains are known, and the creation -- 22 ms in a cold process, all of it inside the first lambda try before (round 6,
+// GTG_DEBUG_TIMING's "first" lines) -- runs on a helper thread under the rest of the upload, the caller's set-up and the first
+// linearisation; launch_cholesky_df joins it.  A pair that exists already costs a map lookup.  (One thread per (device, reserved CUs) for
+// the life of the process; gtg_destroy joins what is still running, so that no thread outlives the library's last handle.)
+static int df_reserve_for(int n_chain) { return n_chain > 16 ? 32 : n_chain > 8 ? 16 : 8; }   // one CU per chain workgroup, a bit in every XCD (see df_streams)
+static std::mutex g_prepare_mu;
+static std::map<std::pair<int, int>, std::thread> g_prepare;
+void df_prepare_streams_async(int device, int n_chain) {
+  const int reserve = df_reserve_for(n_chain);
+  std::lock_guard<std::mutex> lock(g_prepare_mu);
+  if (g_prepare.count({device, reserve})) return;
+  g_prepare[{device, reserve}] = std::thread([device, reserve] {
+    try { check_hip(hipSetDevice(device), "hipSetDevice"); (void)df_streams(device, reserve); } catch (...) { (void)hipGetLastError(); }   // (a failure shows again, with its message, in the first factorisation)
+  });
+}
+void df_join_prepared() {
+  std::lock_guard<std::mutex> lock(g_prepare_mu);
+  for (auto& kv : g_prepare) if (kv.second.joinable()) kv.second.join();
+}
+
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound
 void launch_cholesky_df(gtg_context& c, SMat Sm, int NP, DfPlan& df, double* Xinv, double* fail,
                         const unsigned char* pivot_kind, double* tile_exp) {
   const int nt = NP / T;
   double* S = Sm.p;
   if (df.nt != nt) throw std::runtime_error("dataflow cholesky plan does not match the matrix");
-  const int reserve = df.n_chain > 16 ? 32 : df.n_chain > 8 ? 16 : 8;   // one CU per chain workgroup, a bit in every XCD (see df_streams)
+  const int reserve = df_reserve_for(df.n_chain);
+  df_join_prepared();
+  const auto pair_t0 = std::chrono::high_resolution_clock::now();
   DfStreams& ds = df_streams(c.device, reserve);
+  { static std::atomic<int> first{0};    // GTG_DEBUG_TIMING: what the first factorisation of the process pays for the kernels' attributes and its masked stream pair
+    if (first.fetch_add(1) == 0 && std::getenv("GTG_DEBUG_TIMING"))
+      std::fprintf(stderr, "[gtsam_amd first ] %-40s %8.2f ms\n", "(attributes + masked stream pair)", std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - pair_t0).count()); }
   // the factorisation's epoch: counted on the host and handed to both kernels BY VALUE -- the ticket counter is only ever touched by
   // atomics, the flags by write-through stores and sc1 loads, and nothing the two kernels synchronise through is a word that a
   // kernel of the previous factorisation wrote with a plain store

@@ -71,6 +71,8 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
 void upload_df_plan(DfPlan& df, hipStream_t s, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16 = nullptr,
                     const int32_t* d_slot = nullptr);   // the device half (d_slot: the device copy of `slot` -- the tables are resolved by a kernel then)
 void free_df_plan(DfPlan& df);
+void df_prepare_streams_async(int device, int n_chain);   // the masked stream pair of a plan with n_chain chain workgroups, created on a helper thread ahead of the first factorisation
+void df_join_prepared();                                       // (joined by the first factorisation and by gtg_destroy)
 bool dataflow_schedule_selected();   // false: GTG_CHOL=streams (the stream / event schedule of cholesky.hip, the A/B of the dataflow pass)
 void launch_cholesky_df(gtg_context& c, SMat S, int NP, DfPlan& df, double* Xinv, double* fail_flags,
                         const unsigned char* pivot_kind = nullptr, double* tile_exp = nullptr);

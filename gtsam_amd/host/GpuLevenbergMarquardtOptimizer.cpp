@@ -969,7 +969,9 @@ const Values& GpuLevenbergMarquardtOptimizer::optimize() {
   const auto tOpt = std::chrono::high_resolution_clock::now();
   do {   // NonlinearOptimizer::defaultOptimize, NonlinearOptimizer.cpp:86-105
     currentError = newError;
+    const auto tIt = std::chrono::high_resolution_clock::now();
     iterateDevice();
+    if (timing) std::fprintf(stderr, "[gtsam_amd shim ]   iteration %zu: %.2f ms\n", m.iterations, std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tIt).count());
     newError = m.error;
     if (p.iterationHook) { syncValuesToHost(false); p.iterationHook(m.iterations, currentError, newError); }
     if (p.verbosity >= NonlinearOptimizerParams::VALUES) { syncValuesToHost(false); values().print("newValues"); }

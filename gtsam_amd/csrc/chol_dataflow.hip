@@ -1167,19 +1167,23 @@ static DfStreams& df_streams(int device, int reserve) {
 // linearisation; launch_cholesky_df joins it.  A pair that exists already costs a map lookup.  (One thread per (device, reserved CUs) for
 // the life of the process; gtg_destroy joins what is still running, so that no thread outlives the library's last handle.)
 static int df_reserve_for(int n_chain) { return n_chain > 16 ? 32 : n_chain > 8 ? 16 : 8; }   // one CU per chain workgroup, a bit in every XCD (see df_streams)
+// (the thread objects live in a map that is never destroyed: a process that uploads a problem and exits without a factorisation or a
+// gtg_destroy must not run into std::terminate for a joinable thread; exit joins them as well)
 static std::mutex g_prepare_mu;
-static std::map<std::pair<int, int>, std::thread> g_prepare;
+static std::map<std::pair<int, int>, std::thread>& prepare_threads() { static auto* m = new std::map<std::pair<int, int>, std::thread>; return *m; }
+void df_join_prepared() {
+  std::lock_guard<std::mutex> lock(g_prepare_mu);
+  for (auto& kv : prepare_threads()) if (kv.second.joinable()) kv.second.join();
+}
 void df_prepare_streams_async(int device, int n_chain) {
   const int reserve = df_reserve_for(n_chain);
   std::lock_guard<std::mutex> lock(g_prepare_mu);
-  if (g_prepare.count({device, reserve})) return;
-  g_prepare[{device, reserve}] = std::thread([device, reserve] {
+  auto& threads = prepare_threads();
+  if (threads.count({device, reserve})) return;
+  if (threads.empty()) std::atexit([] { df_join_prepared(); });
+  threads[{device, reserve}] = std::thread([device, reserve] {
     try { check_hip(hipSetDevice(device), "hipSetDevice"); (void)df_streams(device, reserve); } catch (...) { (void)hipGetLastError(); }   // (a failure shows again, with its message, in the first factorisation)
   });
-}
-void df_join_prepared() {
-  std::lock_guard<std::mutex> lock(g_prepare_mu);
-  for (auto& kv : g_prepare) if (kv.second.joinable()) kv.second.join();
 }
 
 // fail[0]: non-positive pivot (Eigen LLT NumericalIssue); fail[1]: a dependency wait hit its bound

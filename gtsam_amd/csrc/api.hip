@@ -227,6 +227,7 @@ static std::mutex g_parked_mu;
 static std::vector<ParkedQueue> g_parked;
 constexpr size_t kParkedMax = 4;
 static bool take_parked(gtg_context& c) {
+  if (std::getenv("GTG_NO_PARKED_STREAMS")) return false;   // (A/B: every handle creates its own stream and events)
   std::lock_guard<std::mutex> lk(g_parked_mu);
   for (size_t i = 0; i < g_parked.size(); i++)
     if (g_parked[i].device == c.device) {
@@ -237,6 +238,7 @@ static bool take_parked(gtg_context& c) {
   return false;
 }
 static bool park_queue(gtg_context& c) {   // (the caller has synchronised the streams)
+  if (std::getenv("GTG_NO_PARKED_STREAMS")) return false;
   std::lock_guard<std::mutex> lk(g_parked_mu);
   size_t n = 0;
   for (const auto& q : g_parked) n += q.device == c.device;

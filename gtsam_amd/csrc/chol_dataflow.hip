@@ -1176,6 +1176,7 @@ void df_join_prepared() {
   for (auto& kv : prepare_threads()) if (kv.second.joinable()) kv.second.join();
 }
 void df_prepare_streams_async(int device, int n_chain) {
+  if (std::getenv("GTG_SYNC_STREAM_PAIR")) return;   // (A/B: the pair is created by the first factorisation, as before round 6)
   const int reserve = df_reserve_for(n_chain);
   std::lock_guard<std::mutex> lock(g_prepare_mu);
   auto& threads = prepare_threads();

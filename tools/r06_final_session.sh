@@ -21,6 +21,8 @@ import bench
 bench.write_workload_file("ladybug1723", "/tmp/l1723.txt")
 PY
 GTG_DEBUG_TIMING=1 tests/_build/bench_lm_gtsam /tmp/l1723.txt --steps 20 --warmup 5 > $out/cpp_bench_with_breakdown.json 2> $out/cpp_host_setup_breakdown.txt
+for i in 1 2 3; do GTG_DEBUG_TIMING=1 tests/_build/bench_lm_gtsam /tmp/l1723.txt --steps 7 --warmup 0 > $out/cold_process_$i.json 2> $out/cold_process_$i.txt; done   # three cold processes: first-iteration anatomy
+GTG_HOST_SYMBOLIC=1 GTG_DEBUG_TIMING=1 tests/_build/bench_lm_gtsam /tmp/l1723.txt --steps 7 --warmup 0 > /dev/null 2> $out/cpp_host_setup_breakdown_host_symbolic.txt   # the host loops the device passes replace
 tests/_build/cold_start_probe /tmp/l1723.txt > $out/cold_start_probe.txt 2>&1
 tests/_build/cold_start_probe /tmp/l1723.txt --prewarm > $out/cold_start_probe_prewarmed.txt 2>&1
 timeout 300 python tools/df_stress.py 90 3 > $out/stress.txt 2> $out/stress.err

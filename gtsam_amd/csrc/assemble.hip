@@ -512,12 +512,25 @@ __global__ __launch_bounds__(64) void k_scatter_hoff(int64_t n_blocks, const int
 // 1 - 5's 8-byte lanes (one load = one slot): the same terms in the same order, S bit for bit, a quarter of the
 // vector-memory instructions -- 0.829 -> 0.786 ms on L1723, 4.41 -> 4.04 ms on Venice (profiles/r06h_schur_wide_ab.txt).
 typedef double v4f64s __attribute__((ext_vector_type(4)));
-constexpr int kWidePairs = 4;       // load instructions in flight per wavefront (8 terms)
+// Last session of round 6 (profiles/r06_schur_sweep.txt): with its occupancy cut by untouched dynamic LDS the kernel slows nearly in
+// proportion -- 0.77 / 1.08 / 1.72 / 3.10 ms at 32 / 20 / 12 / 4 wavefronts per CU on L1723 -- so what it needs is round trips in flight.
+// Now: kWidePairs = 8 load instructions in flight per wavefront (4 before), the loads of a block's LAST group clamped to its last term
+// instead of a tail loop that fetched two terms per round trip (a block of 30 terms: 2 round trips, 6 before), every lane fetching the
+// index of its own slot (no scalar index walk), and ONE 1 KB patch per wavefront used load after load -- LDS operations of a wavefront
+// complete in program order.  Same terms in the same order: S bit for bit.  0.773 -> 0.70 ms (L1723), 4.02 -> 3.75 ms (Venice).
+// Measured beside it and not kept: 6 / 12 / 16 loads in flight (0.72 / 0.77 / 0.90 ms: registers cost wavefronts), the two terms of a
+// load on accumulators of their own (0.78: the dependent MFMA chain is not what a wavefront waits for), XCD-contiguous block ranges
+// (0.73 / 4.27 ms, as in round 5).
+#ifndef GT_SCHUR_WIDE
+#define GT_SCHUR_WIDE 8
+#endif
+
+constexpr int kWidePairs = GT_SCHUR_WIDE;       // load instructions in flight per wavefront (2 terms each)
 __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int32_t* __restrict__ prow,
     const int32_t* __restrict__ pcol, const int64_t* __restrict__ pptr, const int32_t* __restrict__ oa,
     const int32_t* __restrict__ ob, const int32_t* __restrict__ red_dim, const int64_t* __restrict__ red_off,
     const double* __restrict__ E, SMat S) {
-  __shared__ double patch[4][kWidePairs][4 * kEStride];      // [wavefront][load in flight][4 slots]
+  __shared__ double patch[4][4 * kEStride];      // [wavefront][4 slots]
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = blockIdx.x * (int64_t)4 + wv;
   if (p >= n_pairs) return;
@@ -529,33 +542,37 @@ __global__ __launch_bounds__(256) void k_schur_pairs(int64_t n_pairs, const int3
   const bool ina = lr < da && lk < 3, inb = lr < db && lk < 3;
   const int ea = ina ? 3 * lr + lk : 0, eb = inb ? 3 * lr + lk : 0;
   v4f64s acc = {0.0, 0.0, 0.0, 0.0};
-  double (*my)[4 * kEStride] = patch[wv];
-  int64_t t = k0;
-  for (; t + 2 * kWidePairs <= k1; t += 2 * kWidePairs) {
+  double* my = patch[wv];
+  // every lane fetches the index of ITS slot (lane groups 0 / 2: oa of the pair's first / second term, 1 / 3: ob): per-lane loads, all
+  // kWidePairs of them in flight, then the kWidePairs slot loads -- no scalar branch between them (the wave-uniform form made hipcc walk the
+  // four indices of a load under exec-mask branches, one scalar round trip after the other)
+  const int32_t* __restrict__ my_idx = (grp & 1) ? ob : oa;
+  const int64_t last = k1 - 1;
+  for (int64_t t = k0; t < k1; t += 2 * kWidePairs) {
+    int slot[kWidePairs];
+#pragma unroll
+    for (int u = 0; u < kWidePairs; u++) {
+      const int64_t tt = t + 2 * u + (grp >> 1);
+      slot[u] = my_idx[tt < last ? tt : last];    // (terms behind the block's last one: its slots once more -- an L1 hit, never multiplied)
+    }
     double2 v[kWidePairs];
 #pragma unroll
-    for (int u = 0; u < kWidePairs; u++) {
-      const int ia0 = oa[t + 2 * u], ib0 = ob[t + 2 * u], ia1 = oa[t + 2 * u + 1], ib1 = ob[t + 2 * u + 1];   // wave-uniform (scalar loads)
-      const int slot = grp == 0 ? ia0 : grp == 1 ? ib0 : grp == 2 ? ia1 : ib1;
-      v[u] = *reinterpret_cast<const double2*>(E + kEStride * (int64_t)slot + 2 * piece);
-    }
+    for (int u = 0; u < kWidePairs; u++) v[u] = *reinterpret_cast<const double2*>(E + kEStride * (int64_t)slot[u] + 2 * piece);
+    // all kWidePairs loads are issued before the first one is waited for: hipcc sinks each load to its use otherwise (one round trip after
+    // the other); the empty asm statements make every loaded value live HERE, in the straight-line code behind the last load
+#pragma unroll
+    for (int u = 0; u < kWidePairs; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
+    // (the patch traffic is unconditional -- it keeps every load of the group in the straight-line code in front of it: with the whole
+    // step under the "term exists" test hipcc sank each load to its use, one in flight at a time -- only the MFMAs are skipped)
 #pragma unroll
     for (int u = 0; u < kWidePairs; u++) {
-      *reinterpret_cast<double2*>(&my[u][2 * lane]) = v[u];
-      const double a0 = my[u][ea], b0 = my[u][kEStride + eb], a1 = my[u][2 * kEStride + ea], b1 = my[u][3 * kEStride + eb];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a0 : 0.0, inb ? b0 : 0.0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a1 : 0.0, inb ? b1 : 0.0, acc, 0, 0, 0);
+      *reinterpret_cast<double2*>(&my[2 * lane]) = v[u];
+      const double a0 = my[ea], b0 = my[kEStride + eb], a1 = my[2 * kEStride + ea], b1 = my[3 * kEStride + eb];
+      if (t + 2 * u < k1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a0 : 0.0, inb ? b0 : 0.0, acc, 0, 0, 0);
+      if (t + 2 * u + 1 < k1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a1 : 0.0, inb ? b1 : 0.0, acc, 0, 0, 0);
     }
   }
-  for (; t < k1; t += 2) {      // the tail: two terms, or one (its slots are fetched twice: the second copy is not used)
-    const bool two = t + 1 < k1;
-    const int ia0 = oa[t], ib0 = ob[t], ia1 = two ? oa[t + 1] : ia0, ib1 = two ? ob[t + 1] : ib0;
-    const int slot = grp == 0 ? ia0 : grp == 1 ? ib0 : grp == 2 ? ia1 : ib1;
-    *reinterpret_cast<double2*>(&my[0][2 * lane]) = *reinterpret_cast<const double2*>(E + kEStride * (int64_t)slot + 2 * piece);
-    const double a0 = my[0][ea], b0 = my[0][kEStride + eb], a1 = my[0][2 * kEStride + ea], b1 = my[0][3 * kEStride + eb];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a0 : 0.0, inb ? b0 : 0.0, acc, 0, 0, 0);
-    if (two) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ina ? a1 : 0.0, inb ? b1 : 0.0, acc, 0, 0, 0);
-  }
+
   const int64_t oa_ = red_off[ra], ob_ = red_off[rb];
 #pragma unroll
   for (int r = 0; r < 4; r++) {

@@ -43,6 +43,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstring>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -501,8 +503,14 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
 
   // ---- merge in graph order: concatenate the tables, hand out the rows of the noise / calibration tables -----------------
   NoiseTable nt;
-  std::vector<int32_t> sfm_cam, sfm_pt, sfm_nz, pj_pose, pj_pt, pj_nz, pj_cal, pj_sen, bt_1, bt_2, bt_nz, pr_var, pr_nz;
-  std::vector<double> sfm_z, pj_z, calib, sensor, bt_z, pr_data;
+  // (the GeneralSFM tables and the factor map -- 30 MB on the L1723 shape -- are filled by threads, one chunk each, after this loop has
+  // handed out the offsets and the noise rows in graph order: plain buffers, not value-initialised)
+  struct RawI { std::unique_ptr<int32_t[]> p; size_t n = 0; void alloc(size_t k) { p.reset(new int32_t[k ? k : 1]); n = k; } int32_t* data() { return p.get(); } size_t size() const { return n; } };
+  struct RawD { std::unique_ptr<double[]> p; size_t n = 0; void alloc(size_t k) { p.reset(new double[k ? k : 1]); n = k; } double* data() { return p.get(); } size_t size() const { return n; } };
+  RawI sfm_cam, sfm_pt, sfm_nz;
+  RawD sfm_z;
+  std::vector<int32_t> pj_pose, pj_pt, pj_nz, pj_cal, pj_sen, bt_1, bt_2, bt_nz, pr_var, pr_nz;
+  std::vector<double> pj_z, calib, sensor, bt_z, pr_data;
   std::vector<int64_t> pr_off;
   std::map<const void*, int32_t> calib_id;   // shared calibration objects (Cal3_S2 or Cal3DS2) -> row of the calibration table
   std::vector<double> calib_dist;            // k1 k2 p1 p2 per row (zero for a Cal3_S2)
@@ -513,20 +521,22 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
   {
     size_t n_sfm = 0, n_pj = 0, n_bt = 0, n_pr = 0, n_smc = 0, n_sm = 0;
     for (const Extract& x : part) { n_sfm += x.sfm_cam.size(); n_pj += x.pj_pose.size(); n_bt += x.bt_1.size(); n_pr += x.pr_var.size(); n_smc += x.sm_cam.size(); n_sm += x.sm_prm.size() / 8; }
-    sfm_cam.reserve(n_sfm); sfm_pt.reserve(n_sfm); sfm_nz.reserve(n_sfm); sfm_z.reserve(2 * n_sfm);
+    sfm_cam.alloc(n_sfm); sfm_pt.alloc(n_sfm); sfm_nz.alloc(n_sfm); sfm_z.alloc(2 * n_sfm);
     pj_pose.reserve(n_pj); pj_pt.reserve(n_pj); pj_nz.reserve(n_pj); pj_cal.reserve(n_pj); pj_sen.reserve(n_pj); pj_z.reserve(2 * n_pj);
     bt_1.reserve(n_bt); bt_2.reserve(n_bt); bt_nz.reserve(n_bt); bt_z.reserve(12 * n_bt);
-    m.fac_map.reserve(nfac);
+    m.fac_map.clear(); m.fac_map.resize(nfac);
   }
   auto cat = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
-  for (const Extract& x : part) {
-    const int64_t o_sfm = (int64_t)sfm_cam.size(), o_pj = (int64_t)pj_pose.size(), o_bt = (int64_t)bt_1.size(), o_pr = (int64_t)pr_var.size(),
+  struct Place { int64_t o_sfm, o_pj, o_bt, o_pr, o_sm; std::vector<std::pair<int64_t, int32_t>> sfm_rows; };   // per chunk: offsets of its tables, (count, noise row) of its GeneralSFM runs
+  std::vector<Place> place(part.size());
+  int64_t o_sfm_next = 0;
+  for (size_t pi = 0; pi < part.size(); pi++) {
+    const Extract& x = part[pi];
+    const int64_t o_sfm = o_sfm_next, o_pj = (int64_t)pj_pose.size(), o_bt = (int64_t)bt_1.size(), o_pr = (int64_t)pr_var.size(),
                   o_sm = (int64_t)sm_nz.size(), o_sen = (int64_t)(sensor.size() / 12), o_prd = (int64_t)pr_data.size(), o_smc = (int64_t)sm_cam.size();
-    for (const auto& fm : x.fac_map)
-      m.fac_map.emplace_back(fm.first, fm.second + (fm.first == GTG_FAC_GENERAL_SFM ? o_sfm : fm.first == GTG_FAC_PROJECTION ? o_pj :
-                                                      fm.first == GTG_FAC_BETWEEN_POSE3 ? o_bt : fm.first == GTG_FAC_PRIOR ? o_pr : fm.first == -2 ? o_sm : 0));
-    cat(sfm_cam, x.sfm_cam); cat(sfm_pt, x.sfm_pt); cat(sfm_z, x.sfm_z);
-    for (const auto& r : x.sfm_nz) sfm_nz.insert(sfm_nz.end(), (size_t)r.first, nt.add(r.second, 2));
+    place[pi].o_sfm = o_sfm; place[pi].o_pj = o_pj; place[pi].o_bt = o_bt; place[pi].o_pr = o_pr; place[pi].o_sm = o_sm;
+    o_sfm_next += (int64_t)x.sfm_cam.size();
+    for (const auto& r : x.sfm_nz) place[pi].sfm_rows.emplace_back(r.first, nt.add(r.second, 2));
     cat(pj_pose, x.pj_pose); cat(pj_pt, x.pj_pt); cat(pj_z, x.pj_z);
     for (const auto& r : x.pj_nz) pj_nz.insert(pj_nz.end(), (size_t)r.first, nt.add(r.second, 2));
     for (int32_t sidx : x.pj_sen) pj_sen.push_back(sidx < 0 ? -1 : (int32_t)(sidx + o_sen));
@@ -556,6 +566,27 @@ void GpuLevenbergMarquardtOptimizer::init(const NonlinearFactorGraph& graph, con
     cat(sm_cam, x.sm_cam); cat(sm_z, x.sm_z); cat(sm_prm, x.sm_prm);
     for (size_t k = 1; k < x.sm_ptr.size(); k++) sm_ptr.push_back(x.sm_ptr[k] + o_smc);
     for (const auto& r : x.sm_nz) sm_nz.insert(sm_nz.end(), (size_t)r.first, nt.add(r.second, 2));
+  }
+  {
+    auto fill = [&](size_t pi) {
+      const Extract& x = part[pi];
+      const Place& pl = place[pi];
+      const size_t k = x.sfm_cam.size();
+      if (k) {
+        std::memcpy(sfm_cam.data() + pl.o_sfm, x.sfm_cam.data(), 4 * k); std::memcpy(sfm_pt.data() + pl.o_sfm, x.sfm_pt.data(), 4 * k);
+        std::memcpy(sfm_z.data() + 2 * pl.o_sfm, x.sfm_z.data(), 16 * k);
+        int32_t* nz = sfm_nz.data() + pl.o_sfm;
+        for (const auto& r : pl.sfm_rows) { std::fill(nz, nz + r.first, r.second); nz += r.first; }
+      }
+      auto* fm_out = m.fac_map.data() + nfac * pi / nthreads;     // (the chunk's factors: graph indices [nfac pi / nthreads, nfac (pi + 1) / nthreads))
+      for (const auto& fm : x.fac_map)
+        *fm_out++ = {fm.first, fm.second + (fm.first == GTG_FAC_GENERAL_SFM ? pl.o_sfm : fm.first == GTG_FAC_PROJECTION ? pl.o_pj :
+                                             fm.first == GTG_FAC_BETWEEN_POSE3 ? pl.o_bt : fm.first == GTG_FAC_PRIOR ? pl.o_pr : fm.first == -2 ? pl.o_sm : 0)};
+    };
+    std::vector<std::thread> fillers;
+    for (size_t pi = 1; pi < part.size(); pi++) fillers.emplace_back(fill, pi);
+    fill(0);
+    for (auto& t : fillers) t.join();
   }
   lap("factors: merge, noise / calibration tables");
   gtg_problem pb{};

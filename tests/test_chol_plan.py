@@ -336,3 +336,57 @@ def test_dataflow_schedule_cannot_deadlock(stub, workload, nd):
     pl = _plan(workload, nd)
     for n_bulk in (1, 3, 248):
         _simulate_df(pl, pl["df"], n_bulk)
+
+
+_TABLES_CHILD = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from tools import host_profile as HP
+from gtsam_amd import lib as L
+problem, _ = HP.problem_for(%(workload)r)
+g = L.DeviceGraph(problem)
+pl = g.df_plan()
+t12, s6, chain = g.df_device_tables()
+sizes = np.zeros(8, np.int64)
+L._check(g.lib.gtg_debug_plan_sizes(g.h, sizes.ctypes.data), "sizes")
+out = dict(nt=pl["nt"], n_stored=int(sizes[4]), tasks=pl["tasks"].tolist(), klist=pl["klist"].tolist(), t12=t12.tolist(), s6=s6.tolist(), chain=chain.tolist(),
+           flops=g.cholesky_flops(), executed=g.cholesky_flops_executed())
+g.close()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("workload", ["bal:60:6000:7", "sphere2500"])
+def test_dataflow_device_tables_resolve_the_plan(workload):
+    """The dataflow plan as the kernels read it (gtg_debug_df_device_tables; built by the host loop here -- the dry-run runtime runs no
+    kernel --, by k_df_resolve on a GPU, where tests/test_gpu_device_analysis.py compares the two word for word): every task carries its six
+    plan words, the slots of its tile and of its diagonal tile and the tile's own sub-tile mask; every contraction step the slots of its two
+    operand tiles, distinct stored tiles, and their masks; a step's operand masks are never empty (an empty operand tile would not be in
+    the list), and the executed flop count is the stored-tile count minus what the masks skip."""
+    d = HP.run_snippet(_TABLES_CHILD % {"root": ROOT, "workload": workload})
+    nt, n_stored = d["nt"], d["n_stored"]
+    tasks, t12, s6 = np.array(d["tasks"]), np.array(d["t12"]), np.array(d["s6"])
+    assert t12.shape == (len(tasks), 12) and np.array_equal(t12[:, :6], tasks)
+    assert s6.shape == (len(d["klist"]), 6)
+    slot_of = {}
+    for row in t12:
+        I, J, q, qd = int(row[0]), int(row[1]), int(row[6]), int(row[7])
+        assert 0 <= q < n_stored and 0 <= qd < n_stored
+        assert slot_of.setdefault((I, J), q) == q and slot_of.setdefault((J, J), qd) == qd
+        mask = (int(row[10]) & 0xFFFFFFFF) | ((int(row[11]) & 0xFFFFFFFF) << 32)
+        assert mask != 0
+        if I == J: assert mask == 2 ** 64 - 1
+        if I == nt: assert mask == 0xFF
+        G, first = int(row[8]), int(row[9])
+        assert (G == 1 and first == -1) or (2 <= G <= 8 and first >= n_stored)
+        for e in range(int(row[2]), int(row[2]) + int(row[3])):
+            k = d["klist"][e]
+            a, b = int(s6[e][0]), int(s6[e][1])
+            assert 0 <= a < n_stored and 0 <= b < n_stored
+            assert slot_of.setdefault((I, k), a) == a and slot_of.setdefault((J, k), b) == b
+            ma = (int(s6[e][2]) & 0xFFFFFFFF) | ((int(s6[e][3]) & 0xFFFFFFFF) << 32)
+            mb = (int(s6[e][4]) & 0xFFFFFFFF) | ((int(s6[e][5]) & 0xFFFFFFFF) << 32)
+            assert ma != 0 and mb != 0
+    assert len(set(slot_of.values())) == len(slot_of)                 # one slot per tile
+    assert 0 < d["executed"] <= d["flops"]

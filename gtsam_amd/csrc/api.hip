@@ -340,6 +340,12 @@ int gtg_destroy(gtg_handle c) {
   try { df_join_prepared(); } catch (...) {}
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  // The releases below run while no dataflow factorisation of ANOTHER handle is in flight on this device: a handle that was destroyed
+  // beside a running factorisation stalled its persistent kernels past the 20 ms bound of their dependency waits (three of three time-outs of
+  // the round's last multi-handle stress runs sat in the second-to-last factorisation of a handle whose neighbour had just finished:
+  // profiles/r06_stress_240s.txt).  GTG_DESTROY_UNLOCKED=1: the A/B.
+  std::unique_lock<std::mutex> no_factorisation_in_flight;
+  if (!std::getenv("GTG_DESTROY_UNLOCKED")) no_factorisation_in_flight = std::unique_lock<std::mutex>(df_device_lock(c->device));
   auto& f = c->f;
   DevBuf<double>* dbl[] = {&c->values, &c->trial, &c->delta, &c->noise_data, &f.sfm_z, &f.sfm_J, &f.proj_z, &f.proj_J,
                            &f.calib, &f.sensor, &f.between_z, &f.between_J, &f.prior_data, &f.prior_J, &c->Hd, &c->gred0,

@@ -170,8 +170,9 @@ void analyze(gtg_context& c) {
   std::vector<int64_t> lm_obs_ptr, inc_ptr;
   DevBuf<int32_t> d_obs_pos;                    // (device pass: observation -> position of its camera, consumed by device_schur_terms)
   if (device_terms) {
+    clk.lap("variable roles, layout of the reduced variables (host)");
     device_incidence_lists(c, c.h_red_pos, d_obs_pos);
-    clk.lap("variable roles (host); incidence lists (device)");
+    clk.lap("incidence lists (device)");
   } else {
   obs_red.resize(c.n_obs); obs_lm.resize(c.n_obs);
   for (int64_t i = 0; i < n_sfm; i++) { obs_red[i] = c.h_red_index[hi.sfm_cam[i]]; obs_lm[i] = c.h_lm_index[hi.sfm_point[i]]; }
@@ -203,13 +204,15 @@ void analyze(gtg_context& c) {
   }
   // landmark -> priors (CSR, factor order; a handful)
   std::vector<int64_t> lm_pri_ptr(c.n_lm + 1, 0);
-  for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri_ptr[l + 1]++; }
-  for (int l = 0; l < c.n_lm; l++) lm_pri_ptr[l + 1] += lm_pri_ptr[l];
+  int64_t n_lm_pri = 0;
+  for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) { lm_pri_ptr[l + 1]++; n_lm_pri++; } }
+  if (n_lm_pri) for (int l = 0; l < c.n_lm; l++) lm_pri_ptr[l + 1] += lm_pri_ptr[l];     // (no prior on a landmark: the offsets are all zero already)
   std::vector<int32_t> lm_pri(lm_pri_ptr[c.n_lm]);
-  { std::vector<int64_t> w(lm_pri_ptr.begin(), lm_pri_ptr.end() - 1);
+  if (n_lm_pri) { std::vector<int64_t> w(lm_pri_ptr.begin(), lm_pri_ptr.end() - 1);
     for (int64_t i = 0; i < n_pri; i++) { const int l = c.h_lm_index[hi.prior_var[i]]; if (l >= 0) lm_pri[w[l]++] = (int32_t)i; } }
-  std::vector<int32_t> lm_owned(std::max(c.n_lm, 1), 0);
-  for (int l = 0; l < c.n_lm; l++) lm_owned[l] = (l % c.n_shards) == c.shard;
+  std::vector<int32_t> lm_owned(std::max(c.n_lm, 1), c.n_shards == 1 ? 1 : 0);
+  if (c.n_lm == 0) lm_owned[0] = 0;
+  if (c.n_shards > 1) for (int l = 0; l < c.n_lm; l++) lm_owned[l] = (l % c.n_shards) == c.shard;
 
   // off-diagonal pose-pose blocks from BetweenFactors
   struct HB { int64_t key; int32_t code; };
@@ -821,13 +824,18 @@ void analyze(gtg_context& c) {
       // and uploaded when both are done.
       {
         std::thread dfh; std::exception_ptr dferr;
-        double df_ms = 0.0;
-        if (c.use_df) dfh = std::thread([&] { try { StageClock k; build_df_plan_host(c.df, nt, dense ? nullptr : &T1, &tile_part, &part_parent); df_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - k.t).count(); } catch (...) { dferr = std::current_exception(); } });
-        try { StageClock k; build_chol_plan(c.plan, nt, dense ? nullptr : &B2, s, &pair_part, &part_parent); k.lap("  (stream schedule + slots, this thread)"); }
+        // (the dataflow lists -- the longer of the two, thousands of small allocations -- on THIS thread, whose allocator arena is warm: on a
+        // fresh thread the same code took 0.35 ms longer for its page faults; the stream schedule's slots and backward lists, 0.1 ms since
+        // its pair lists are built on demand, and their uploads on the second one)
+        double sp_ms = 0.0;
+        const int dev = c.device;
+        dfh = std::thread([&] { try { StageClock k; check_hip(hipSetDevice(dev), "hipSetDevice"); build_chol_plan(c.plan, nt, dense ? nullptr : &B2, s, &pair_part, &part_parent);
+                                      sp_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - k.t).count(); } catch (...) { dferr = std::current_exception(); } });
+        try { StageClock k; if (c.use_df) build_df_plan_host(c.df, nt, dense ? nullptr : &T1, &tile_part, &part_parent); k.lap("  (dataflow task lists, this thread)"); }
         catch (...) { if (dfh.joinable()) dfh.join(); throw; }
         if (dfh.joinable()) dfh.join();
         if (dferr) std::rethrow_exception(dferr);
-        if (clk.on) std::fprintf(stderr, "[gtsam_amd setup]   (dataflow task lists, second thread) %8.2f ms\n", df_ms);
+        if (clk.on) std::fprintf(stderr, "[gtsam_amd setup]   (stream schedule's slots + backward lists, second thread) %8.2f ms\n", sp_ms);
         clk.lap("tile schedules (task lists of both passes, two threads)");
         if (c.use_df) upload_df_plan(c.df, s, c.plan.h_slot, c.plan.n_stored, dense ? nullptr : &sub16, kernels_can_run ? c.plan.slot.p : nullptr);
         clk.lap("dataflow plan resolved to slots + uploaded");

@@ -1075,6 +1075,8 @@ int gtg_debug_potrf_stamps(gtg_handle c, double* A128, long long* out15) {
 int gtg_debug_plan_sizes(gtg_handle c, int64_t sizes[8]) {
   GTG_TRY
   if (!c || !c->uploaded || !sizes) throw std::invalid_argument("gtg_debug_plan_sizes: no problem uploaded");
+  (void)hipSetDevice(c->device);
+  ensure_stream_lists(c->plan, c->stream);
   const CholPlan& pl = c->plan;
   sizes[0] = pl.nt; sizes[1] = (int64_t)pl.rows.n; sizes[2] = (int64_t)pl.pairs.n; sizes[3] = (int64_t)pl.bcols.n;
   sizes[4] = pl.n_stored; sizes[5] = pl.n_exch; sizes[6] = (int64_t)pl.s1_off.size(); sizes[7] = (int64_t)pl.part_parent.size();
@@ -1086,6 +1088,8 @@ int gtg_debug_plan_lists(gtg_handle c, int32_t* rows, int32_t* pairs, int32_t* b
   GTG_TRY
   if (!c || !c->uploaded) throw std::invalid_argument("gtg_debug_plan_lists: no problem uploaded");
   DeviceGuard on_device(c->device);
+  (void)hipSetDevice(c->device);
+  ensure_stream_lists(c->plan, c->stream);
   const CholPlan& pl = c->plan;
   auto down = [&](int32_t* dst, const DevBuf<int32_t>& b, size_t n) { if (dst && n) check_hip(hipMemcpy(dst, b.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost), "D2H"); };
   down(rows, pl.rows, pl.rows.n); down(pairs, pl.pairs, pl.pairs.n); down(bcols, pl.bcols, pl.bcols.n);

@@ -770,6 +770,9 @@ void build_df_plan(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct, 
 
 void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_struct,
                         const std::vector<int32_t>* tile_part, const std::vector<int32_t>* part_parent) {
+  const bool sect_on = std::getenv("GTG_DF_PLAN_TIMING") != nullptr;
+  auto sect_t = std::chrono::high_resolution_clock::now();
+  auto sect = [&](const char* what) { if (!sect_on) return; const auto n = std::chrono::high_resolution_clock::now(); std::fprintf(stderr, "[df plan] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(n - sect_t).count()); sect_t = n; };
   std::vector<uint8_t> B((size_t)nt * nt, 0);
   for (int i = 0; i < nt; i++)
     for (int j = 0; j <= i; j++) B[(size_t)i * nt + j] = tile_struct ? (*tile_struct)[(size_t)i * nt + j] : 1;
@@ -781,9 +784,12 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
       for (size_t b = 0; b <= a; b++) B[(size_t)r[a] * nt + r[b]] = 1;
   }
   std::vector<std::vector<int32_t>> rowcols(nt);
+  const int bw = (nt + 63) / 64;
+  std::vector<uint64_t> rowbits((size_t)nt * bw, 0);     // the same rows as bit sets: a tile's contraction list is the AND of two of them
   for (int i = 0; i < nt; i++)
-    for (int k = 0; k < i; k++) if (B[(size_t)i * nt + k]) rowcols[i].push_back(k);
+    for (int k = 0; k < i; k++) if (B[(size_t)i * nt + k]) { rowcols[i].push_back(k); rowbits[(size_t)i * bw + (k >> 6)] |= 1ull << (k & 63); }
 
+  sect("symbolic fill + row lists");
   // ---- elimination-tree parallelism: several diagonal chains --------------------------------------------------------
   // With a nested-dissection ordering (analysis.hip) the block columns fall into PARTS: leaves that do not touch each other and the
   // separators above them (part_parent; children are numbered before their parent, a part is a contiguous range of tiles).  The
@@ -885,6 +891,10 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   struct Rec { int32_t I, J, koff, kcnt, r, R; };
   std::vector<std::vector<Rec>> finals(nt), early(nt);      // by place in `seq`
   std::vector<int> diag_last_g(nt + 1, -1);                  // group of the last early piece of PD(J) (-1: none)
+  std::vector<int> cut;
+  { size_t tiles = 0; for (int i = 0; i < nt; i++) tiles += rowcols[i].size();       // (room up front: a tile has a last piece and ~ a piece per 4 steps)
+    for (int g = 0; g < nt; g++) { finals[g].reserve(rowcols[g].size() + nt / 2 + 4); early[g].reserve(2 * (tiles / nt + 1) + 16); }
+    df.h_klist.reserve(16 * tiles); }
   auto emit = [&](int I, int J, std::vector<int32_t>& ks) {
     by_pos(ks);                                        // the steps in the order in which their operands come into being
     const int n = (int)ks.size(), G = pos[J];
@@ -894,7 +904,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     const int f = n - m;
     // the early steps cut into pieces of kPiece from the old end; a DIAGONAL tile's last early piece is short as well (kFinalDiag steps):
     // the last piece cannot start before it is done, and 4 steps are 73 us (round 5 trace: PD(J) late whenever that piece had 4)
-    std::vector<int> cut;   // piece r = steps [cut[r], cut[r + 1])
+    cut.clear();             // piece r = steps [cut[r], cut[r + 1])
     {
       const int tail = (near && m > kFinalDiag) ? kFinalDiag : 0;
       for (int b = 0; b < m - tail; b += kPiece) cut.push_back(b);
@@ -915,6 +925,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     }
     finals[G].push_back(Rec{I, J, off + m, f, R - 1, R});
   };
+  sect("parts, chains");
   std::vector<int32_t> ks;
   std::vector<int32_t> has_sub(nt, 0);
   for (int J = 0; J < nt; J++) {
@@ -929,7 +940,10 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
     for (int I = J + 1; I < nt; I++) {
       if (!B[(size_t)I * nt + J]) continue;
       ks.clear();
-      std::set_intersection(rowcols[I].begin(), rowcols[I].end(), rowcols[J].begin(), rowcols[J].end(), std::back_inserter(ks));
+      for (int w = 0; w < bw; w++) {
+        uint64_t both = rowbits[(size_t)I * bw + w] & rowbits[(size_t)J * bw + w];
+        while (both) { ks.push_back(64 * w + __builtin_ctzll(both)); both &= both - 1; }
+      }
       emit(I, J, ks);
       flops += t3 + (double)ks.size() * 2.0 * t3; stored++;
     }
@@ -946,7 +960,9 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   // youngest operand is in place q - 2: the latency-critical tasks of a column are taken a whole group of background work ahead of the
   // pieces that merely have to be done some columns later (with the early pieces of group q - 1 in front of them, the diagonal
   // accumulation was taken 30 us before it was needed and the chain waited 20 us for it every few columns)
-  auto put1 = [&](const Rec& t) { for (int32_t f : {t.I, t.J, t.koff, t.kcnt, t.r, t.R}) df.h_tasks.push_back(f); };
+  sect("contraction lists, pieces");
+  { size_t recs = 0; for (int g = 0; g < nt; g++) recs += finals[g].size() + early[g].size(); df.h_tasks.reserve(6 * recs); }
+  auto put1 = [&](const Rec& t) { const int32_t f[6] = {t.I, t.J, t.koff, t.kcnt, t.r, t.R}; df.h_tasks.insert(df.h_tasks.end(), f, f + 6); };
   auto put = [&](const std::vector<Rec>& v) { for (const Rec& t : v) put1(t); };
   // One chain: the two tasks of a column that the serial chain waits for -- PD(J) and the tile right below the diagonal tile -- are
   // queued one group EARLIER than the rest of their column, in front of the previous group's burst of early pieces (and behind their
@@ -985,6 +1001,7 @@ void build_df_plan_host(DfPlan& df, int nt, const std::vector<uint8_t>* tile_str
   df.flops = flops; df.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (df.h_klist.empty()) df.h_klist.push_back(0);
   df.h_has_sub = has_sub;
+  sect("ticket order");
 }
 
 void upload_df_plan(DfPlan& df, hipStream_t stream, const std::vector<int32_t>& slot, int64_t n_slots, const std::vector<uint64_t>* sub16, const int32_t* d_slot) {

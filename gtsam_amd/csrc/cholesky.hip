@@ -307,15 +307,9 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
   plan.bwd_off.assign(nt, 0); plan.bwd_cnt.assign(nt, 0);
   const double t3 = (double)T * T * T;
   double flops = 0.0; int64_t stored = 0;
-  auto emit_pairs = [&](std::vector<std::pair<int32_t, int32_t>>& v, int64_t& off, int64_t& cnt) {
-    // supertile order: (J / STJ, I / STI, J % STJ, I % STI)
-    std::sort(v.begin(), v.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
-      const int64_t ka = (((int64_t)(a.second / STJ) * 65536 + a.first / STI) * STJ + a.second % STJ) * STI + a.first % STI;
-      const int64_t kb = (((int64_t)(b.second / STJ) * 65536 + b.first / STI) * STJ + b.second % STJ) * STI + b.first % STI;
-      return ka < kb; });
-    off = (int64_t)pairs.size() / 2; cnt = (int64_t)v.size();
-    for (auto& ij : v) { pairs.push_back(ij.first); pairs.push_back(ij.second); }
-  };
+  // (the SYRK pair lists of the stream schedule -- a sorted list of (I, J) per column pair, 0.4 M entries on the L1723 shape -- are built
+  // by ensure_stream_lists when that schedule, the fall-back and A/B of the dataflow pass, is first used: 0.5 of this function's 0.7 ms)
+  plan.h_fill = B; plan.stream_lists = false;
   for (int p = 0; p < np; p++) {
     const int k = 2 * p; const bool two = k + 1 < nt;
     std::vector<int32_t> R;
@@ -333,28 +327,12 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
     plan.trsm_cnt[k] = (int64_t)rows.size() - plan.trsm_off[k];
     flops += t3 / 3.0 + (double)(plan.trsm_cnt[k] - 1) * t3;
     if (two) {
-      std::vector<std::pair<int32_t, int32_t>> s1;
-      s1.emplace_back(k + 1, k + 1);
-      for (int32_t I : R) s1.emplace_back(I, k + 1);
-      s1.emplace_back(nt, k + 1);
-      emit_pairs(s1, plan.s1_off[p], plan.s1_cnt[p]);
-      flops += (double)(plan.s1_cnt[p] - 1) * 2.0 * t3;
+      flops += (double)((int64_t)R.size() + 1) * 2.0 * t3;     // (the thin update's pairs: (k + 1, k + 1), (I, k + 1) for I in R; the rhs row's excluded)
       plan.trsm_off[k + 1] = (int64_t)rows.size();
       rows.insert(rows.end(), R.begin(), R.end()); rows.push_back(nt);
       plan.trsm_cnt[k + 1] = (int64_t)rows.size() - plan.trsm_off[k + 1];
       flops += t3 / 3.0 + (double)(plan.trsm_cnt[k + 1] - 1) * t3;
     }
-    std::vector<std::pair<int32_t, int32_t>> nar, rest, anc;
-    for (size_t b = 0; b < R.size(); b++) {
-      const int32_t J = R[b];
-      // with parts: targets in another part can only be in an ancestor (no tiles between independent subtrees)
-      auto& dst = (tree && plan.pair_part[J / 2] != plan.pair_part[p]) ? anc : (J / 2 == p + 1) ? nar : rest;
-      for (size_t a = b; a < R.size(); a++) dst.emplace_back(R[a], J);
-      dst.emplace_back(nt, J);
-    }
-    emit_pairs(nar, plan.nar_off[p], plan.nar_cnt[p]);
-    emit_pairs(rest, plan.rest_off[p], plan.rest_cnt[p]);
-    emit_pairs(anc, plan.anc_off[p], plan.anc_cnt[p]);
     const double kk = two ? 2.0 : 1.0;
     flops += (double)((int64_t)R.size() * ((int64_t)R.size() + 1) / 2) * 2.0 * t3 * kk;   // rhs row excluded
   }
@@ -391,10 +369,9 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
   plan.flops = flops;
   plan.dense_fraction = (double)stored / ((double)nt * (nt + 1) / 2.0);
   if (rows.empty()) rows.push_back(0);
-  if (pairs.empty()) { pairs.push_back(0); pairs.push_back(0); }
   if (bcols.empty()) bcols.push_back(0);
   plan.rows.upload(rows.data(), rows.size(), stream);
-  plan.pairs.upload(pairs.data(), pairs.size(), stream);
+  plan.pairs.free();
   plan.bcols.upload(bcols.data(), bcols.size(), stream);
   plan.n_stored = (int64_t)stored_list.size() / 2;
   plan.stored.upload(stored_list.data(), stored_list.size(), stream);
@@ -407,6 +384,54 @@ void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_st
   }
   plan.slot.upload(plan.h_slot.data(), plan.h_slot.size(), stream);
   check_hip(hipStreamSynchronize(stream), "plan upload");
+}
+
+// The stream schedule's SYRK pair lists (see build_chol_plan), from the fill structure the plan keeps: per column pair p the thin update
+// of its second column (s1), the look-ahead part of the trailing update (targets in pair p + 1: nar), the rest, and -- with parts -- the
+// targets in ancestor parts (anc); every list in supertile order.
+void ensure_stream_lists(CholPlan& plan, hipStream_t stream) {
+  if (plan.stream_lists) return;
+  const int nt = plan.nt, np = (nt + 1) / 2;
+  const bool tree = !plan.pair_part.empty();
+  const std::vector<uint8_t>& B = plan.h_fill;
+  std::vector<int32_t> pairs;
+  auto tiles_of = [&](int q, std::vector<int32_t>& out) { out.push_back(2 * q); if (2 * q + 1 < nt) out.push_back(2 * q + 1); };
+  auto emit_pairs = [&](std::vector<std::pair<int32_t, int32_t>>& v, int64_t& off, int64_t& cnt) {
+    // supertile order: (J / STJ, I / STI, J % STJ, I % STI)
+    std::sort(v.begin(), v.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+      const int64_t ka = (((int64_t)(a.second / STJ) * 65536 + a.first / STI) * STJ + a.second % STJ) * STI + a.first % STI;
+      const int64_t kb = (((int64_t)(b.second / STJ) * 65536 + b.first / STI) * STJ + b.second % STJ) * STI + b.first % STI;
+      return ka < kb; });
+    off = (int64_t)pairs.size() / 2; cnt = (int64_t)v.size();
+    for (auto& ij : v) { pairs.push_back(ij.first); pairs.push_back(ij.second); }
+  };
+  for (int p = 0; p < np; p++) {
+    const int k = 2 * p; const bool two = k + 1 < nt;
+    std::vector<int32_t> R;
+    for (int q = p + 1; q < np; q++) if (B[(size_t)q * np + p]) tiles_of(q, R);
+    if (two) {
+      std::vector<std::pair<int32_t, int32_t>> s1;
+      s1.emplace_back(k + 1, k + 1);
+      for (int32_t I : R) s1.emplace_back(I, k + 1);
+      s1.emplace_back(nt, k + 1);
+      emit_pairs(s1, plan.s1_off[p], plan.s1_cnt[p]);
+    }
+    std::vector<std::pair<int32_t, int32_t>> nar, rest, anc;
+    for (size_t b = 0; b < R.size(); b++) {
+      const int32_t J = R[b];
+      // with parts: targets in another part can only be in an ancestor (no tiles between independent subtrees)
+      auto& dst = (tree && plan.pair_part[J / 2] != plan.pair_part[p]) ? anc : (J / 2 == p + 1) ? nar : rest;
+      for (size_t a = b; a < R.size(); a++) dst.emplace_back(R[a], J);
+      dst.emplace_back(nt, J);
+    }
+    emit_pairs(nar, plan.nar_off[p], plan.nar_cnt[p]);
+    emit_pairs(rest, plan.rest_off[p], plan.rest_cnt[p]);
+    emit_pairs(anc, plan.anc_off[p], plan.anc_cnt[p]);
+  }
+  if (pairs.empty()) { pairs.push_back(0); pairs.push_back(0); }
+  plan.pairs.upload(pairs.data(), pairs.size(), stream);
+  check_hip(hipStreamSynchronize(stream), "plan upload");
+  plan.stream_lists = true;
 }
 
 // Multi-GPU exchange helper: copy the stored tiles of S into / out of a contiguous buffer, so that the all-reduce of
@@ -479,6 +504,7 @@ void launch_cholesky(gtg_context& c, SMat S, int NP, const CholPlan& plan, doubl
   CholStreams& g_cs = c.cs;
   const int nt = NP / T;
   if (plan.nt != nt) throw std::runtime_error("cholesky plan does not match the matrix");
+  ensure_stream_lists(const_cast<CholPlan&>(plan), c.stream);   // (the pair lists are this schedule's alone: built on its first use)
   const size_t smem_potrf = sizeof(double) * kPotrfSmemDoubles;
   const size_t smem_trsm = sizeof(double) * (TR * P);
   const size_t smem_syrk = 4 * (size_t)CHB;

@@ -87,6 +87,8 @@ struct CholPlan {
   // parent part (-1: root); updates of a pair whose target columns lie in an ancestor part
   std::vector<int32_t> pair_part, part_parent;
   std::vector<int64_t> anc_off, anc_cnt;
+  std::vector<uint8_t> h_fill;                 // the fill structure over column pairs ((np x np) bytes): what ensure_stream_lists builds the SYRK pair lists from
+  bool stream_lists = false;                    // `pairs` and the per-pair offsets are built (on first use of the stream schedule: cholesky.hip::ensure_stream_lists)
   int critical_pairs = 0;                       // pairs on the longest leaf-to-root path (= all pairs without parts)
   double flops = 0.0;                           // algorithmic flops of one factorisation over the stored tiles
   double dense_fraction = 1.0;                  // stored lower tiles / all lower tiles

@@ -28,6 +28,7 @@ void launch_scatter_delta(gtg_context& c);       // delta (variable id order) fr
 // ((np x np) row-major bytes, np = ceil(nt/2); nullptr = dense); symbolic fill-in is computed here.
 void build_chol_plan(CholPlan& plan, int nt, const std::vector<uint8_t>* pair_struct, hipStream_t s,
                      const std::vector<int32_t>* pair_part = nullptr, const std::vector<int32_t>* part_parent = nullptr);
+void ensure_stream_lists(CholPlan& plan, hipStream_t s);   // the stream schedule's SYRK pair lists, built on its first use
 // In-place tile-sparse blocked Cholesky of the NP x NP lower triangle of S (ld = NP) carrying one extra 128-row
 // tile (the rhs: forward solve for free).  Non-positive pivots set *fail_flag (device double) to nonzero.
 void launch_zero_tiles(gtg_context& c, SMat S, const CholPlan& plan);

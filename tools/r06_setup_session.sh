@@ -12,7 +12,7 @@ bench.write_workload_file("ladybug1723", "/tmp/l1723.txt")
 PY
 GTG_DEBUG_TIMING=1 tests/_build/bench_lm_gtsam /tmp/l1723.txt --steps 20 --warmup 5 > $out/cpp_bench.json 2> $out/cpp_host_setup_breakdown.txt
 GTG_HOST_SYMBOLIC=1 GTG_DEBUG_TIMING=1 tests/_build/bench_lm_gtsam /tmp/l1723.txt --steps 20 --warmup 5 > $out/cpp_bench_hostsym.json 2> $out/cpp_host_setup_breakdown_hostsym.txt
-awk '/threads started/{n++} n==2' $out/cpp_host_setup_breakdown.txt | cut -c1-120
+awk "/threads started/{n++} n==2" $out/cpp_host_setup_breakdown.txt | cut -c1-120
 echo ---- host symbolic
 grep -E "tile structure|resolved|library:" $out/cpp_host_setup_breakdown_hostsym.txt | tail -4
 python - <<PY

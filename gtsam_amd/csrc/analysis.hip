@@ -521,8 +521,7 @@ void analyze(gtg_context& c) {
         StageClock sub;
         std::vector<int32_t> ea, eb;
         const bool edges_on_device = device_terms && hoff_row.empty();    // the device's own block list is the edge list
-        if (!edges_on_device) for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } });
-        sub.lap("  (ordering: edge list)");
+        if (!edges_on_device) { for_each_block([&](int a, int b) { if (a != b) { ea.push_back(a); eb.push_back(b); } }); sub.lap("  (ordering: edge list, host)"); }
         PartRec leaf; leaf.parent = -1;
         if (device_rcm(c, nrv2, ea, eb, leaf.nodes, edges_on_device ? c.pair_row.p : nullptr, edges_on_device ? c.pair_col.p : nullptr, (int64_t)pair_row.size())) {
           parts.push_back(std::move(leaf)); ordered_on_device = true;
